@@ -1,0 +1,950 @@
+// TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference hot path (see
+// gz_oracle.h for the rules and for how its parity is pinned).
+//
+// Written flat, one function per stage, in the shape the HIP kernels use (pixel- and
+// block-parallel loops, separable blur as an x pass then a y pass, Malta taps from a
+// table), while keeping every float/double promotion and every accumulation order of
+// the reference.  Must be compiled with -ffp-contract=off and without
+// fast-math (oracle/Makefile does).  "ref:" comments cite /root/reference paths.
+
+#include "gz_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "malta_offsets.inc"
+
+namespace {
+
+typedef std::vector<float> Plane;
+
+// ===================================================================== block path ==
+
+// ref: guetzli/idct.cc:29-38.  Only rows 0..3 are used (as in Compute1dIDCT); rows
+// 4..7 follow from the even/odd symmetry out[7-x] = sum_u (-1)^u M[x][u] in[u].
+const int kIdctRows[4][8] = {
+  {8192, 11363, 10703,   9633,  8192,   6437,   4433,  2260},
+  {8192,  9633,  4433,  -2259, -8192, -11362, -10704, -6436},
+  {8192,  6437, -4433, -11362, -8192,   2261,  10704,  9633},
+  {8192,  2260, -10703, -6436,  8192,   9633,  -4433, -11363},
+};
+
+// ref: idct.cc:41-137 (Compute1dIDCT) -- exact int32 sums, order irrelevant.
+inline void idct_1d(const int16_t* in, int stride, int out[8]) {
+  for (int x = 0; x < 4; ++x) {
+    int even = 0, odd = 0;
+    for (int u = 0; u < 8; u += 2) even += kIdctRows[x][u] * in[u * stride];
+    for (int u = 1; u < 8; u += 2) odd += kIdctRows[x][u] * in[u * stride];
+    out[x] = even + odd;
+    out[7 - x] = even - odd;
+  }
+}
+
+// ref: fdct.cc:29-36
+const int16_t kFdctRowTab[4][7] = {
+  {22725, 21407, 19266, 16384, 12873,  8867, 4520},   // rows 0,4
+  {31521, 29692, 26722, 22725, 17855, 12299, 6270},   // rows 1,7
+  {29692, 27969, 25172, 21407, 16819, 11585, 5906},   // rows 2,6
+  {26722, 25172, 22654, 19266, 15137, 10426, 5315},   // rows 3,5
+};
+const int kFdctRowSel[8] = {0, 1, 2, 3, 0, 3, 2, 1};  // fdct.cc:230-240
+
+inline int mulhi16(int a, int b) { return (a * b) >> 16; }  // MULT, fdct.cc:150
+
+// ref: fdct.cc:68-145 (COLUMN_DCT8) as straight-line code on one column.
+inline void fdct_column(int16_t* col /*stride 8*/) {
+  const int i0 = col[0], i1 = col[8], i2 = col[16], i3 = col[24];
+  const int i4 = col[32], i5 = col[40], i6 = col[48], i7 = col[56];
+  int d07 = i0 - i7, s07 = i0 + i7;
+  int d25 = i2 - i5, s25 = i2 + i5;
+  int d34 = i3 - i4, s34 = i3 + i4;
+  int d16 = i1 - i6, s16 = i1 + i6;
+  int e0 = s07 - s34, e1 = s07 + s34;   // BUTTERFLY(m7, m4)
+  int e2 = s16 - s25, e3 = s16 + s25;   // BUTTERFLY(m6, m5)
+  e1 *= 8;
+  e3 *= 8;
+  col[0] = (int16_t)(e1 + e3);
+  col[32] = (int16_t)(e1 - e3);
+  e0 *= 8;
+  e2 *= 8;
+  d34 *= 8;
+  d07 *= 8;
+  const int kTan1 = 13036, kTan2 = 27146, kTan3m1 = -21746, k2Sqrt2 = 23170;
+  col[16] = (int16_t)(mulhi16(kTan2, e2) + e0);
+  col[48] = (int16_t)(mulhi16(kTan2, e0) - e2);
+  d25 *= 16;
+  d16 *= 16;
+  int p = mulhi16(d16 + d25, k2Sqrt2);   // m2 after BUTTERFLY(m1,m2); MULT
+  int q = mulhi16(d16 - d25, k2Sqrt2);   // m1
+  int m3 = d34 - q, m1 = d34 + q;        // BUTTERFLY(m3, m1)
+  int m0 = d07 - p, m2 = d07 + p;        // BUTTERFLY(m0, m2)
+  int m7 = m3, m6 = m1;
+  m3 = mulhi16(m3, kTan3m1) + m7 + 1;
+  m1 = mulhi16(m1, kTan1) + m2 + 1;
+  int m4 = mulhi16(kTan3m1, m0) + m0;
+  int m5 = mulhi16(kTan1, m2);
+  col[8] = (int16_t)m1;
+  col[24] = (int16_t)(m0 - m3);
+  col[40] = (int16_t)(m7 + m4);
+  col[56] = (int16_t)(m5 - m6);
+}
+
+// ref: fdct.cc:173-208 (RowDct)
+inline void fdct_row(int16_t* in, const int16_t* t) {
+  int a[4], b[4];
+  for (int k = 0; k < 4; ++k) {
+    a[k] = in[k] + in[7 - k];
+    b[k] = in[k] - in[7 - k];
+  }
+  const int C1 = t[0], C2 = t[1], C3 = t[2], C4 = t[3], C5 = t[4], C6 = t[5], C7 = t[6];
+  const int c0 = a[0] + a[3], c1 = a[0] - a[3], c2 = a[1] + a[2], c3 = a[1] - a[2];
+  in[0] = (int16_t)((C4 * (c0 + c2)) >> 16);
+  in[4] = (int16_t)((C4 * (c0 - c2)) >> 16);
+  in[2] = (int16_t)((C2 * c1 + C6 * c3) >> 16);
+  in[6] = (int16_t)((C6 * c1 - C2 * c3) >> 16);
+  in[1] = (int16_t)((C1 * b[0] + C3 * b[1] + C5 * b[2] + C7 * b[3]) >> 16);
+  in[3] = (int16_t)((C3 * b[0] - C7 * b[1] - C1 * b[2] - C5 * b[3]) >> 16);
+  in[5] = (int16_t)((C5 * b[0] - C1 * b[1] + C7 * b[2] + C3 * b[3]) >> 16);
+  in[7] = (int16_t)((C7 * b[0] - C5 * b[1] + C3 * b[2] - C1 * b[3]) >> 16);
+}
+
+// ref: color_transform.h:211-219; tables regenerated from the libjpeg formulas
+// (tools/gen_tables.py checks them against the reference's literal tables).
+inline uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+inline void ycc_to_rgb(int y, int cb, int cr, uint8_t* rgb) {
+  const int half = 1 << 15;
+  rgb[0] = clamp255(y + ((91881 * (cr - 128) + half) >> 16));
+  rgb[1] = clamp255(y + ((-46802 * (cr - 128) + (-22554 * (cb - 128) + half)) >> 16));
+  rgb[2] = clamp255(y + ((116130 * (cb - 128) + half) >> 16));
+}
+
+// ref: gamma_correct.cc:23-38
+const double* srgb_table() {
+  static double table[256];
+  static bool init = false;
+  if (!init) {
+    int i = 0;
+    for (; i < 11; ++i) table[i] = i / 12.92;
+    for (; i < 256; ++i) table[i] = 255.0 * std::pow(((i / 255.0) + 0.055) / 1.055, 2.4);
+    init = true;
+  }
+  return table;
+}
+
+// ref: quantize.h:24-29
+inline int16_t quantize_coeff(int16_t raw, int quant) {
+  const int r = raw % quant;
+  const int16_t delta =
+      (int16_t)(2 * r > quant ? quant - r : (-2) * r > quant ? -quant - r : -r);
+  return (int16_t)(raw + delta);
+}
+
+// ============================================================== butteraugli: blur ==
+
+struct BlurPlan {
+  int r;
+  std::vector<float> k;    // unnormalised taps   (ComputeKernel)
+  std::vector<float> ks;   // taps * (1/sum)      (Convolution interior)
+  float wsum;
+};
+
+// ref: butteraugli.cc:145-154.  <math.h> is included there, so fabs/exp resolve to the
+// float overloads.
+BlurPlan make_plan(float sigma) {
+  BlurPlan p;
+  const float m = 2.25;
+  const float scaler = -1.0 / (2 * sigma * sigma);
+  const int diff = std::max<int>(1, m * std::fabs(sigma));
+  p.r = diff;
+  p.k.resize(2 * diff + 1);
+  for (int i = -diff; i <= diff; ++i) p.k[i + diff] = std::exp(scaler * i * i);
+  float w = 0.0f;
+  for (size_t j = 0; j < p.k.size(); ++j) w += p.k[j];
+  p.wsum = w;
+  const float s = 1.0f / w;
+  p.ks = p.k;
+  for (size_t j = 0; j < p.ks.size(); ++j) p.ks[j] *= s;
+  return p;
+}
+
+// One output sample of Convolution (interior, :207-218) / ConvolveBorderColumn
+// (:156-181) along a line of `n` samples with stride `st`, at position x.
+inline float conv_at(const float* line, int st, int n, int x, const BlurPlan& p,
+                     float border_ratio) {
+  const int r = p.r;
+  if (x >= r && x < n - r) {
+    float sum = 0.0f;
+    const float* s = line + (x - r) * st;
+    for (int j = 0; j <= 2 * r; ++j) sum += s[j * st] * p.ks[j];
+    return sum;
+  }
+  const int lo = x < r ? 0 : x - r;
+  const int hi = std::min(n - 1, x + r);
+  float weight = 0.0f;
+  for (int j = lo; j <= hi; ++j) weight += p.k[j - x + r];
+  weight = (1.0f - border_ratio) * weight + border_ratio * p.wsum;
+  const float scale = 1.0f / weight;
+  float sum = 0.0f;
+  for (int j = lo; j <= hi; ++j) sum += line[j * st] * p.k[j - x + r];
+  return sum * scale;
+}
+
+// ref: butteraugli.cc:229-233 (Blur = Convolution along x, then along y).
+void blur(const float* in, int w, int h, float sigma, float border_ratio, float* out) {
+  const BlurPlan p = make_plan(sigma);
+  Plane tmp((size_t)w * h);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x)
+      tmp[(size_t)y * w + x] = conv_at(in + (size_t)y * w, 1, w, x, p, border_ratio);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x)
+      out[(size_t)y * w + x] = conv_at(tmp.data() + x, w, h, y, p, border_ratio);
+}
+
+// ============================================================= butteraugli: opsin ==
+
+// ref: butteraugli.h:498-534 (V = float: constants rounded to float first)
+inline void opsin_absorbance(float r, float g, float b, float out[3]) {
+  const float m0 = 0.254462330846, m1 = 0.488238255095, m2 = 0.0635278003854,
+              m3 = 1.01681026909;
+  const float m4 = 0.195214015766, m5 = 0.568019861857, m6 = 0.0860755536007,
+              m7 = 1.1510118369;
+  const float m8 = 0.07374607900105684, m9 = 0.06142425304154509,
+              m10 = 0.24416850520714256, m11 = 1.20481945273;
+  out[0] = m0 * r + m1 * g + m2 * b + m3;
+  out[1] = m4 * r + m5 * g + m6 * b + m7;
+  out[2] = m8 * r + m9 * g + m10 * b + m11;
+}
+
+// ref: butteraugli.h:548-591 (ClenshawRecursion, RationalPolynomial::operator())
+inline double clenshaw6(double x, const double* c) {
+  double b1 = 0.0, b2 = 0.0;
+  for (int i = 5; i >= 1; --i) {
+    const double x_b1 = x * b1;
+    const double t = (x_b1 + x_b1) - b2 + c[i];
+    b2 = b1;
+    b1 = t;
+  }
+  const double x_b1 = x * b1;
+  return x_b1 - b2 + c[0];
+}
+
+// ref: butteraugli.h:601-615 (GammaPolynomial)
+inline double gamma_poly(double v) {
+  static const double kMin = 0.971783, kMax = 590.188894;
+  static const double p[6] = {98.7821300963361, 164.273222212631, 92.948112871376,
+                              33.8165311212688, 6.91626704983562, 0.556380877028234};
+  static const double q[6] = {1, 1.64339473427892, 0.89392405219969,
+                              0.298947051776379, 0.0507146002577288,
+                              0.00226495093949756};
+  const double x01 = (v - kMin) / (kMax - kMin);
+  const double xc = 2.0 * x01 - 1.0;
+  const double yp = clenshaw6(xc, p);
+  const double yq = clenshaw6(xc, q);
+  if (yq == 0.0) return 0.0;
+  return static_cast<float>(yp / yq);
+}
+
+// ref: butteraugli.cc:324-366 (OpsinDynamicsImage)
+void opsin(const float* rgb, int w, int h, float* xyb) {
+  const size_t n = (size_t)w * h;
+  std::vector<Plane> bl(3, Plane(n));
+  const double kSigma = 1.2;
+  for (int c = 0; c < 3; ++c) blur(rgb + c * n, w, h, kSigma, 0.0f, bl[c].data());
+  for (size_t i = 0; i < n; ++i) {
+    float pre[3], cur[3], sens[3];
+    opsin_absorbance(bl[0][i], bl[1][i], bl[2][i], pre);
+    for (int c = 0; c < 3; ++c) sens[c] = gamma_poly(pre[c]) / pre[c];
+    opsin_absorbance(rgb[i], rgb[n + i], rgb[2 * n + i], cur);
+    for (int c = 0; c < 3; ++c) cur[c] *= sens[c];
+    xyb[i] = cur[0] - cur[1];
+    xyb[n + i] = cur[0] + cur[1];
+    xyb[2 * n + i] = cur[2];
+  }
+}
+
+// =================================================== butteraugli: frequency bands ==
+
+inline float remove_range(float w, float x) {   // butteraugli.cc:369
+  return x > w ? x - w : x < -w ? x + w : 0.0f;
+}
+inline float amplify_range(float w, float x) {  // :374
+  return x > w ? x + w : x < -w ? x - w : 2.0f * x;
+}
+inline float maximum_clamp(float v, float maxval) {  // :432-444
+  static const double kMul = 0.688059627878;
+  if (v >= maxval) {
+    v -= maxval;
+    v *= kMul;
+    v += maxval;
+  } else if (v < -maxval) {
+    v += maxval;
+    v *= kMul;
+    v -= maxval;
+  }
+  return v;
+}
+inline float suppress_bright(float hf, float brightness, float mul, float reg) {  // :420-430
+  float scaler = mul * reg / (reg + brightness);
+  return scaler * hf;
+}
+
+struct Psycho {
+  Plane lf[3], mf[3], hf[2], uhf[2];
+};
+
+// ref: butteraugli.cc:489-622 (SeparateFrequencies)
+void separate_frequencies(const float* xyb, int w, int h, Psycho* ps) {
+  const size_t n = (size_t)w * h;
+  static const double kSigmaLf = 7.46953768697, kSigmaHf = 3.734768843485,
+                      kSigmaUhf = 1.8673844217425;
+  static const double border_lf = -0.00457628248637, border_mf = -0.271277366628,
+                      border_hf = 0.147068973249;
+  for (int i = 0; i < 3; ++i) {
+    const float* src = xyb + i * n;
+    ps->lf[i].resize(n);
+    blur(src, w, h, kSigmaLf, border_lf, ps->lf[i].data());
+    Plane band(n);
+    for (size_t p = 0; p < n; ++p) band[p] = src[p] - ps->lf[i][p];
+    ps->mf[i].resize(n);
+    blur(band.data(), w, h, kSigmaHf, border_mf, ps->mf[i].data());
+    if (i == 2) break;
+    ps->hf[i] = band;
+    static const double w0 = 0.120079806822, w1 = 0.03430529365;
+    for (size_t p = 0; p < n; ++p) {
+      ps->hf[i][p] -= ps->mf[i][p];
+      ps->mf[i][p] = i == 0 ? remove_range(w0, ps->mf[i][p])
+                            : amplify_range(w1, ps->mf[i][p]);
+    }
+  }
+  // SuppressXByY (:470-487), all double per pixel.
+  {
+    static const double suppress = 2.96534974403, s = 0.745954517135;
+    for (size_t p = 0; p < n; ++p) {
+      const double xval = ps->hf[0][p];
+      const double yval = ps->hf[1][p];
+      const double scaler = s + (suppress * (1.0 - s)) / (suppress + yval * yval);
+      ps->hf[0][p] = scaler * xval;
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    ps->uhf[i] = ps->hf[i];
+    Plane blurred(n);
+    blur(ps->hf[i].data(), w, h, kSigmaUhf, border_hf, blurred.data());
+    ps->hf[i] = blurred;
+    static const double kRemoveHfRange = 0.0287615200377;
+    static const double kMaxclampHf = 78.8223237675;
+    static const double kMaxclampUhf = 5.8907152736;
+    static const float kMulSuppressHf = 1.10684769012;
+    static const float kMulRegHf = 0.478741530298;
+    static const float kRegHf = 2000 * kMulRegHf;
+    static const float kMulSuppressUhf = 1.76905001176;
+    static const float kMulRegUhf = 0.310148420674;
+    static const float kRegUhf = 2000 * kMulRegUhf;
+    for (size_t p = 0; p < n; ++p) {
+      float& uhf = ps->uhf[i][p];
+      float& hf = ps->hf[i][p];
+      uhf -= hf;
+      if (i == 0) {
+        hf = remove_range(kRemoveHfRange, hf);
+      } else {
+        const float br = ps->lf[1][p];   // raw LF-Y, before the vals conversion
+        hf = maximum_clamp(hf, kMaxclampHf);
+        uhf = maximum_clamp(uhf, kMaxclampUhf);
+        uhf = suppress_bright(uhf, br, kMulSuppressUhf, kRegUhf);
+        hf = suppress_bright(hf, br, kMulSuppressHf, kRegHf);
+      }
+    }
+  }
+  // XybLowFreqToVals (:382-399), V = float.
+  {
+    const float xmul = 5.57547552483, ymul = 1.20828034498, bmul = 6.08319517575;
+    const float y_to_b_mul = -0.628811683685;
+    for (size_t p = 0; p < n; ++p) {
+      const float x = ps->lf[0][p], y = ps->lf[1][p], b_arg = ps->lf[2][p];
+      const float b = b_arg + y_to_b_mul * y;
+      ps->lf[2][p] = b * bmul;
+      ps->lf[0][p] = x * xmul;
+      ps->lf[1][p] = y * ymul;
+    }
+  }
+}
+
+// ============================================================= butteraugli: Malta ==
+
+// ref: butteraugli.cc:1460-1568 (MaltaDiffMapImpl) + :914-1458 (MaltaUnit,
+// PaddedMaltaUnit: taps outside the image read 0).
+void malta(const float* lum0, const float* lum1, int w, int h, bool lf, double w_0gt1,
+           double w_0lt1, double norm1, float* acc) {
+  const double len = 3.75;
+  const double mulli = lf ? 0.405371989604 : 0.354191303559;  // :1570-1595
+  const float kWeight0 = 0.5;
+  const float kWeight1 = 0.33;
+  const double w_pre0gt1 = mulli * sqrt(kWeight0 * w_0gt1) / (len * 2 + 1);
+  const double w_pre0lt1 = mulli * sqrt(kWeight1 * w_0lt1) / (len * 2 + 1);
+  const float norm2_0gt1 = w_pre0gt1 * norm1;
+  const float norm2_0lt1 = w_pre0lt1 * norm1;
+  const size_t n = (size_t)w * h;
+  Plane diffs(n);
+  for (size_t i = 0; i < n; ++i) {
+    const float a = lum0[i], b = lum1[i];
+    const float absval = 0.5 * std::abs(a) + 0.5 * std::abs(b);
+    const float diff = a - b;
+    const float scaler = norm2_0gt1 / (static_cast<float>(norm1) + absval);
+    float d = scaler * diff;
+    const float scaler2 = norm2_0lt1 / (static_cast<float>(norm1) + absval);
+    const double fabs0 = std::fabs(a);
+    const double too_small = 0.55 * fabs0;
+    const double too_big = 1.05 * fabs0;
+    double impact = 0.0;
+    bool hit = true;
+    if (a < 0) {
+      if (b > -too_small) impact = scaler2 * (b + too_small);
+      else if (b < -too_big) impact = scaler2 * (-b - too_big);
+      else hit = false;
+    } else {
+      if (b < too_small) impact = scaler2 * (too_small - b);
+      else if (b > too_big) impact = scaler2 * (b - too_big);
+      else hit = false;
+    }
+    if (hit) {
+      if (diff < 0) d -= impact; else d += impact;
+    }
+    diffs[i] = d;
+  }
+  const int ntap = lf ? 5 : 9;
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      float ret = 0;
+      for (int o = 0; o < 16; ++o) {
+        const int cnt = lf ? kMaltaLFCount[o] : kMaltaHFCount[o];
+        float sum = 0;
+        bool first = true;
+        for (int t = 0; t < cnt && t < ntap; ++t) {
+          const int dy = lf ? kMaltaLF[o][t][0] : kMaltaHF[o][t][0];
+          const int dx = lf ? kMaltaLF[o][t][1] : kMaltaHF[o][t][1];
+          const int yy = y + dy, xx = x + dx;
+          const float v = (yy < 0 || yy >= h || xx < 0 || xx >= w)
+                              ? 0.0f : diffs[(size_t)yy * w + xx];
+          if (first) { sum = v; first = false; } else { sum += v; }
+        }
+        ret += sum * sum;
+      }
+      acc[(size_t)y * w + x] += ret;
+    }
+  }
+}
+
+// ============================================================== butteraugli: mask ==
+
+const double kGlobalScale = 1.0 / 20.35;  // butteraugli.cc:138-139
+
+struct MaskLuts { double x[512], y[512], dcx[512], dcy[512]; };
+
+// ref: butteraugli.cc:1638-1697 (MakeMask + MaskX/MaskY/MaskDcX/MaskDcY)
+void make_mask_lut(double extmul, double extoff, double mul, double offset,
+                   double scaler, double* lut) {
+  for (int i = 0; i < 512; ++i) {
+    const double c = mul / ((0.01 * scaler * i) + offset);
+    lut[i] = kGlobalScale * (1.0 + extmul * (c + extoff));
+    if (lut[i] < 1e-5) lut[i] = 1e-5;
+    lut[i] *= lut[i];
+  }
+}
+const MaskLuts& mask_luts() {
+  static MaskLuts l;
+  static bool init = false;
+  if (!init) {
+    make_mask_lut(2.59885507073, 3.08805636789, 5.62939030582, 0.315424196682,
+                  16.2770141832, l.x);
+    make_mask_lut(0.9613705131, -0.581933100068, 6.64307621174, 1.00846207765,
+                  2.2342321176, l.y);
+    make_mask_lut(10.0470705878, 3.18472654033, 0.373092999662, 0.0551512255218, 70.0,
+                  l.dcx);
+    make_mask_lut(0.0115640939227, 45.9483175519, 2.52611324247, 0.0142290066313, 5.0,
+                  l.dcy);
+    init = true;
+  }
+  return l;
+}
+// ref: butteraugli.cc:236-251
+inline double interp_clamp_neg(const double* a, int size, double ix) {
+  if (ix < 0) ix = 0;
+  const int base = static_cast<int>(ix);
+  if (base >= size - 1) return a[size - 1];
+  const double mix = ix - base;
+  return a[base] + mix * (a[base + 1] - a[base]);
+}
+
+// ref: butteraugli.cc:1699-1739 (DiffPrecompute)
+void diff_precompute(const float* p0, const float* p1, int w, int h, float* out) {
+  for (int y = 0; y < h; ++y) {
+    const int y2 = y + 1 < h ? y + 1 : y > 0 ? y - 1 : y;
+    for (int x = 0; x < w; ++x) {
+      const int x2 = x + 1 < w ? x + 1 : x > 0 ? x - 1 : x;
+      const size_t i = (size_t)y * w + x, ir = (size_t)y * w + x2, id = (size_t)y2 * w + x;
+      double sup0 = (std::fabs(p0[i] - p0[ir]) + std::fabs(p0[i] - p0[id]));
+      double sup1 = (std::fabs(p1[i] - p1[ir]) + std::fabs(p1[i] - p1[id]));
+      static const double mul0 = 0.918416534734;
+      float v = mul0 * std::min(sup0, sup1);
+      static const double cutoff = 55.0184555849;
+      if (v >= cutoff) v = cutoff;
+      out[i] = v;
+    }
+  }
+}
+
+// ref: butteraugli.cc:1741-1817 (Mask); xyb0/xyb1 need only planes 0 and 1.
+void mask(const float* x0, const float* y0, const float* x1, const float* y1, int w,
+          int h, float* mask3, float* mask_dc3) {
+  const size_t n = (size_t)w * h;
+  const double muls[2] = {0.207017089891, 0.267138152891};
+  const double normalizer = 1.0 / (muls[0] + muls[1]);
+  static const double r0 = 2.3770330432, r1 = 9.04353323561, r2 = 9.24456601467;
+  static const double border_ratio = -0.0724948220913;
+  Plane diff(n), mx(n), b1(n), b2(n), my(n);
+  diff_precompute(x0, x1, w, h, diff.data());
+  blur(diff.data(), w, h, r2, border_ratio, mx.data());
+  diff_precompute(y0, y1, w, h, diff.data());
+  blur(diff.data(), w, h, r0, border_ratio, b1.data());
+  blur(diff.data(), w, h, r1, border_ratio, b2.data());
+  for (size_t i = 0; i < n; ++i) {
+    const double val = normalizer * (muls[0] * b1[i] + muls[1] * b2[i]);
+    my[i] = val;
+  }
+  static const double mul[2] = {16.6963293877, 2.1364621982};
+  static const double w00 = 36.4671237619, w11 = 2.1887170895;
+  static const double w_ytob_hf = std::max<double>(0.086624184478, 0.0);
+  static const double w_ytob_lf = 21.6804277046;
+  static const double p1_to_p0 = 0.0513061271723;
+  const MaskLuts& l = mask_luts();
+  for (size_t i = 0; i < n; ++i) {
+    const double s0 = mx[i];
+    const double s1 = my[i];
+    const double p1 = mul[1] * w11 * s1;
+    const double p0 = mul[0] * w00 * s0 + p1_to_p0 * p1;
+    mask3[i] = interp_clamp_neg(l.x, 512, p0);
+    mask3[n + i] = interp_clamp_neg(l.y, 512, p1);
+    mask3[2 * n + i] = w_ytob_hf * interp_clamp_neg(l.y, 512, p1);
+    if (mask_dc3) {
+      mask_dc3[i] = interp_clamp_neg(l.dcx, 512, p0);
+      mask_dc3[n + i] = interp_clamp_neg(l.dcy, 512, p1);
+      mask_dc3[2 * n + i] = w_ytob_lf * interp_clamp_neg(l.dcy, 512, p1);
+    }
+  }
+}
+
+// ref: butteraugli.cc:753-782 (MaskPsychoImage)
+void mask_psycho(const Psycho& pi0, const Psycho& pi1, int w, int h, float* mask3,
+                 float* mask_dc3) {
+  const size_t n = (size_t)w * h;
+  static const double muls[4] = {0, 1.64178305129, 0.831081703362, 3.23680933546};
+  Plane m0[2], m1[2];
+  for (int i = 0; i < 2; ++i) {
+    const double a = muls[2 * i], b = muls[2 * i + 1];
+    m0[i].resize(n);
+    m1[i].resize(n);
+    for (size_t p = 0; p < n; ++p) {
+      m0[i][p] = a * pi0.uhf[i][p] + b * pi0.hf[i][p];
+      m1[i][p] = a * pi1.uhf[i][p] + b * pi1.hf[i][p];
+    }
+  }
+  mask(m0[0].data(), m0[1].data(), m1[0].data(), m1[1].data(), w, h, mask3, mask_dc3);
+}
+
+// ======================================================== butteraugli: the diffmap ==
+
+// ref: butteraugli.cc:654-668
+void l2diff(const Plane& i0, const Plane& i1, double w, Plane* acc) {
+  if (w == 0) return;
+  for (size_t p = 0; p < i0.size(); ++p) {
+    double diff = i0[p] - i1[p];
+    (*acc)[p] += w * diff * diff;
+  }
+}
+// ref: butteraugli.cc:672-714
+void l2diff_asym(const Plane& i0, const Plane& i1, double w_0gt1, double w_0lt1,
+                 Plane* acc) {
+  if (w_0gt1 == 0 && w_0lt1 == 0) return;
+  w_0gt1 *= 0.8;
+  w_0lt1 *= 0.8;
+  for (size_t p = 0; p < i0.size(); ++p) {
+    const float a = i0[p], b = i1[p];
+    float& out = (*acc)[p];
+    double diff = a - b;
+    out += w_0gt1 * diff * diff;
+    const double fabs0 = std::fabs(a);
+    const double too_small = 0.4 * fabs0;
+    const double too_big = 1.0 * fabs0;
+    if (a < 0) {
+      if (b > -too_small) {
+        double v = b + too_small;
+        out += w_0lt1 * v * v;
+      } else if (b < -too_big) {
+        double v = -b - too_big;
+        out += w_0lt1 * v * v;
+      }
+    } else {
+      if (b < too_small) {
+        double v = too_small - b;
+        out += w_0lt1 * v * v;
+      } else if (b > too_big) {
+        double v = b - too_big;
+        out += w_0lt1 * v * v;
+      }
+    }
+  }
+}
+// ref: butteraugli.cc:624-652
+void same_noise_levels(const Plane& i0, const Plane& i1, int w, int h, double kSigma,
+                       double wgt, double maxclamp, Plane* acc) {
+  const size_t n = i0.size();
+  Plane t(n), blurred(n);
+  for (size_t p = 0; p < n; ++p) {
+    double v0 = std::fabs(i0[p]);
+    double v1 = std::fabs(i1[p]);
+    if (v0 > maxclamp) v0 = maxclamp;
+    if (v1 > maxclamp) v1 = maxclamp;
+    t[p] = v0 - v1;
+  }
+  blur(t.data(), w, h, kSigma, 0.0, blurred.data());
+  for (size_t p = 0; p < n; ++p) {
+    double diff = blurred[p];
+    (*acc)[p] += wgt * diff * diff;
+  }
+}
+
+// ref: butteraugli.cc:817-908 (DiffmapPsychoImage) + :1597-1621 + :718-751
+void diffmap_psycho(const Psycho& pi0, const Psycho& pi1, int w, int h, float* result) {
+  const size_t n = (size_t)w * h;
+  const float hf_asymmetry_ = 0.8f;  // NB: sqrt(hf_asymmetry_) below is the FLOAT sqrt (math.h overload)
+  Plane dc[3], ac[3];
+  for (int c = 0; c < 3; ++c) {
+    dc[c].assign(n, 0.0f);
+    ac[c].assign(n, 0.0f);
+  }
+  static const double wUhfMalta = 5.1409625726, norm1Uhf = 58.5001247061;
+  malta(pi0.uhf[1].data(), pi1.uhf[1].data(), w, h, false, wUhfMalta * hf_asymmetry_,
+        wUhfMalta / hf_asymmetry_, norm1Uhf, ac[1].data());
+  static const double wUhfMaltaX = 4.91743441556, norm1UhfX = 687196.39002;
+  malta(pi0.uhf[0].data(), pi1.uhf[0].data(), w, h, false, wUhfMaltaX * hf_asymmetry_,
+        wUhfMaltaX / hf_asymmetry_, norm1UhfX, ac[0].data());
+  static const double wHfMalta = 153.671655716, norm1Hf = 83150785.9592;
+  malta(pi0.hf[1].data(), pi1.hf[1].data(), w, h, true, wHfMalta * std::sqrt(hf_asymmetry_),
+        wHfMalta / std::sqrt(hf_asymmetry_), norm1Hf, ac[1].data());
+  static const double wHfMaltaX = 668.358918152, norm1HfX = 0.882954368025;
+  malta(pi0.hf[0].data(), pi1.hf[0].data(), w, h, true, wHfMaltaX * std::sqrt(hf_asymmetry_),
+        wHfMaltaX / std::sqrt(hf_asymmetry_), norm1HfX, ac[0].data());
+  static const double wMfMalta = 6841.81248144, norm1Mf = 0.0135134962487;
+  malta(pi0.mf[1].data(), pi1.mf[1].data(), w, h, true, wMfMalta, wMfMalta, norm1Mf,
+        ac[1].data());
+  static const double wMfMaltaX = 813.901703816, norm1MfX = 16792.9322251;
+  malta(pi0.mf[0].data(), pi1.mf[0].data(), w, h, true, wMfMaltaX, wMfMaltaX, norm1MfX,
+        ac[0].data());
+  static const double wmul[9] = {0, 32.4449876135, 0, 0, 0, 0, 1.01370836411, 0,
+                                 1.74566011615};
+  static const double maxclamp = 85.7047444518, kSigmaHfX = 10.6666499623,
+                      wsn = 884.809801415;
+  same_noise_levels(pi0.hf[1], pi1.hf[1], w, h, kSigmaHfX, wsn, maxclamp, &ac[1]);
+  for (int c = 0; c < 3; ++c) {
+    if (c < 2)
+      l2diff_asym(pi0.hf[c], pi1.hf[c], wmul[c] * hf_asymmetry_, wmul[c] / hf_asymmetry_,
+                  &ac[c]);
+    l2diff(pi0.mf[c], pi1.mf[c], wmul[3 + c], &ac[c]);
+    l2diff(pi0.lf[c], pi1.lf[c], wmul[6 + c], &dc[c]);
+  }
+  Plane m(3 * n), mdc(3 * n);
+  mask_psycho(pi0, pi1, w, h, m.data(), mdc.data());
+  // CombineChannels + the first half of CalculateDiffmap
+  Plane d(n), blurred(n);
+  static const float kInitialSlope = 100.0f;
+  for (size_t p = 0; p < n; ++p) {
+    const float a = dc[0][p] * mdc[p] + dc[1][p] * mdc[n + p] + dc[2][p] * mdc[2 * n + p];
+    const float b = ac[0][p] * m[p] + ac[1][p] * m[n + p] + ac[2][p] * m[2 * n + p];
+    const float v = a + b;
+    d[p] = v < (1.0f / (kInitialSlope * kInitialSlope)) ? kInitialSlope * v : std::sqrt(v);
+  }
+  static const double kSigma = 1.72547472444, mul1 = 0.458794906198;
+  static const float scale = 1.0f / (1.0f + mul1);
+  static const double border_ratio = 1.0;
+  blur(d.data(), w, h, kSigma, border_ratio, blurred.data());
+  for (size_t p = 0; p < n; ++p) {
+    float v = d[p];
+    v += mul1 * blurred[p];
+    v *= scale;
+    result[p] = v;
+  }
+}
+
+// ======================================================== guetzli-side comparator ==
+
+struct Comparator {
+  int w, h;
+  float target;
+  std::vector<uint8_t> rgb;
+  Psycho pi0;            // butteraugli::ButteraugliComparator::pi0_
+};
+
+void linear_from_rgb8(const uint8_t* rgb, int w, int h, float* planes) {
+  const double* lut = srgb_table();
+  const size_t n = (size_t)w * h;
+  for (int c = 0; c < 3; ++c)
+    for (size_t p = 0; p < n; ++p) planes[c * n + p] = lut[rgb[3 * p + c]];
+}
+
+void reconstruct(const int16_t* coeffs, int w, int h, const int* q, int16_t* coeffs_out,
+                 uint8_t* srgb, float* linear) {
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8, nb = bw * bh;
+  const size_t n = (size_t)w * h;
+  const double* lut = srgb_table();
+  std::vector<uint8_t> ycc(3 * n);
+  for (int c = 0; c < 3; ++c) {
+    for (int by = 0; by < bh; ++by) {
+      for (int bx = 0; bx < bw; ++bx) {
+        int16_t blk[64];
+        const size_t off = ((size_t)c * nb + (size_t)by * bw + bx) * 64;
+        memcpy(blk, coeffs + off, sizeof(blk));
+        if (q) orc_quantize_block(blk, q + 64 * c);
+        if (coeffs_out) memcpy(coeffs_out + off, blk, sizeof(blk));
+        uint8_t px[64];
+        orc_idct_block(blk, px);
+        for (int iy = 0; iy < 8; ++iy)
+          for (int ix = 0; ix < 8; ++ix) {
+            const int x = 8 * bx + ix, y = 8 * by + iy;
+            if (x < w && y < h) ycc[((size_t)y * w + x) * 3 + c] = px[8 * iy + ix];
+          }
+      }
+    }
+  }
+  orc_ycbcr_to_rgb(ycc.data(), (int)n);
+  if (srgb) memcpy(srgb, ycc.data(), 3 * n);
+  if (linear)
+    for (int c = 0; c < 3; ++c)
+      for (size_t p = 0; p < n; ++p)
+        linear[c * n + p] = static_cast<float>(lut[ycc[3 * p + c]]);
+}
+
+}  // namespace
+
+// ==================================================================== C surface ==
+extern "C" {
+
+void orc_fdct_block(int16_t* block) {
+  for (int i = 0; i < 8; ++i) fdct_column(block + i);
+  for (int r = 0; r < 8; ++r) fdct_row(block + 8 * r, kFdctRowTab[kFdctRowSel[r]]);
+}
+
+// ref: idct.cc:139-161
+void orc_idct_block(const int16_t* block, uint8_t* out) {
+  int16_t cols[64];
+  for (int x = 0; x < 8; ++x) {
+    int t[8];
+    idct_1d(block + x, 8, t);
+    for (int y = 0; y < 8; ++y) cols[8 * y + x] = (int16_t)((t[y] + (1 << 10)) >> 11);
+  }
+  for (int y = 0; y < 8; ++y) {
+    int t[8];
+    idct_1d(cols + 8 * y, 1, t);
+    for (int x = 0; x < 8; ++x)
+      out[8 * y + x] = clamp255((t[x] + (257 << 17)) >> 18);
+  }
+}
+
+int orc_quantize_block(int16_t* block, const int* q) {
+  int changed = 0;
+  for (int k = 0; k < 64; ++k) {
+    const int16_t c = quantize_coeff(block[k], q[k]);
+    changed |= (c != block[k]);
+    block[k] = c;
+  }
+  return changed;
+}
+
+void orc_ycbcr_to_rgb(uint8_t* px, int npix) {
+  for (int i = 0; i < npix; ++i) {
+    uint8_t* p = px + 3 * i;
+    ycc_to_rgb(p[0], p[1], p[2], p);
+  }
+}
+
+void orc_srgb_to_linear_table(double* out256) {
+  memcpy(out256, srgb_table(), 256 * sizeof(double));
+}
+
+// ref: jpeg_data_encoder.cc:33-117
+int orc_encode_rgb(const uint8_t* rgb, int w, int h, int16_t* coeffs) {
+  if (w < 0 || w >= 1 << 16 || h < 0 || h >= 1 << 16) return -1;
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8, nb = bw * bh;
+  for (int by = 0; by < bh; ++by) {
+    for (int bx = 0; bx < bw; ++bx) {
+      int16_t blk[192];
+      for (int iy = 0; iy < 8; ++iy) {
+        for (int ix = 0; ix < 8; ++ix) {
+          const int y = std::min(h - 1, 8 * by + iy);
+          const int x = std::min(w - 1, 8 * bx + ix);
+          const uint8_t* p = rgb + 3 * ((size_t)y * w + x);
+          const int r = p[0], g = p[1], b = p[2];
+          const int HALF = 1 << 15;
+          int16_t* o = blk + 8 * iy + ix;
+          o[0] = (int16_t)((19595 * r + 38469 * g + 7471 * b - (128 << 16) + HALF) >> 16);
+          o[64] = (int16_t)((-11059 * r - 21709 * g + 32768 * b + HALF - 1) >> 16);
+          o[128] = (int16_t)((32768 * r - 27439 * g - 5329 * b + HALF - 1) >> 16);
+        }
+      }
+      for (int c = 0; c < 3; ++c) {
+        orc_fdct_block(blk + 64 * c);
+        int16_t* dst = coeffs + ((size_t)c * nb + (size_t)by * bw + bx) * 64;
+        // Quantize with q = 1: iquant = 65537, (v*iquant + 0x80000) >> 20
+        for (int k = 0; k < 64; ++k)
+          dst[k] = (int16_t)((blk[64 * c + k] * 65537 + 0x80000) >> 20);
+      }
+    }
+  }
+  return 0;
+}
+
+void orc_reconstruct(const int16_t* coeffs, int w, int h, const int* q,
+                     int16_t* coeffs_out, uint8_t* srgb, float* linear) {
+  reconstruct(coeffs, w, h, q, coeffs_out, srgb, linear);
+}
+
+int orc_compute_kernel(float sigma, float* taps, int cap) {
+  BlurPlan p = make_plan(sigma);
+  if ((int)p.k.size() > cap) return -(int)p.k.size();
+  memcpy(taps, p.k.data(), p.k.size() * sizeof(float));
+  return (int)p.k.size();
+}
+
+void orc_blur(const float* in, int w, int h, float sigma, float border_ratio,
+              float* out) {
+  blur(in, w, h, sigma, border_ratio, out);
+}
+
+void orc_opsin(const float* rgb, int w, int h, float* xyb) { opsin(rgb, w, h, xyb); }
+
+void orc_separate_frequencies(const float* xyb, int w, int h, float* out10) {
+  Psycho ps;
+  separate_frequencies(xyb, w, h, &ps);
+  const size_t n = (size_t)w * h;
+  for (int i = 0; i < 3; ++i) memcpy(out10 + i * n, ps.lf[i].data(), n * 4);
+  for (int i = 0; i < 3; ++i) memcpy(out10 + (3 + i) * n, ps.mf[i].data(), n * 4);
+  for (int i = 0; i < 2; ++i) memcpy(out10 + (6 + i) * n, ps.hf[i].data(), n * 4);
+  for (int i = 0; i < 2; ++i) memcpy(out10 + (8 + i) * n, ps.uhf[i].data(), n * 4);
+}
+
+void orc_mask(const float* xyb0, const float* xyb1, int w, int h, float* m,
+              float* mdc) {
+  const size_t n = (size_t)w * h;
+  mask(xyb0, xyb0 + n, xyb1, xyb1 + n, w, h, m, mdc);
+}
+
+void orc_malta(const float* lum0, const float* lum1, int w, int h, int lf,
+               double w_0gt1, double w_0lt1, double norm1, float* acc) {
+  malta(lum0, lum1, w, h, lf != 0, w_0gt1, w_0lt1, norm1, acc);
+}
+
+double orc_diffmap(const float* rgb0, const float* rgb1, int w, int h, float* diffmap) {
+  const size_t n = (size_t)w * h;
+  Plane xyb0(3 * n), xyb1(3 * n), d(n);
+  Psycho p0, p1;
+  opsin(rgb0, w, h, xyb0.data());
+  separate_frequencies(xyb0.data(), w, h, &p0);
+  opsin(rgb1, w, h, xyb1.data());
+  separate_frequencies(xyb1.data(), w, h, &p1);
+  diffmap_psycho(p0, p1, w, h, d.data());
+  float mx = 0.0f;
+  for (size_t p = 0; p < n; ++p) mx = std::max(mx, d[p]);
+  if (diffmap) memcpy(diffmap, d.data(), n * 4);
+  return mx;
+}
+
+// ref: butteraugli_comparator.cc:51-61
+void* orc_comparator_create(const uint8_t* rgb, int w, int h, float target) {
+  Comparator* c = new Comparator;
+  c->w = w;
+  c->h = h;
+  c->target = target;
+  c->rgb.assign(rgb, rgb + (size_t)3 * w * h);
+  const size_t n = (size_t)w * h;
+  Plane lin(3 * n), xyb(3 * n);
+  linear_from_rgb8(rgb, w, h, lin.data());
+  opsin(lin.data(), w, h, xyb.data());
+  separate_frequencies(xyb.data(), w, h, &c->pi0);
+  return c;
+}
+void orc_comparator_destroy(void* p) { delete (Comparator*)p; }
+
+// ref: butteraugli_comparator.cc:63-75 (the dead rgb0 opsin at :64-65 is skipped)
+float orc_comparator_compare(void* p, const int16_t* coeffs, float* distmap) {
+  Comparator* c = (Comparator*)p;
+  const size_t n = (size_t)c->w * c->h;
+  Plane lin(3 * n), xyb(3 * n), d(n);
+  reconstruct(coeffs, c->w, c->h, nullptr, nullptr, nullptr, lin.data());
+  opsin(lin.data(), c->w, c->h, xyb.data());
+  Psycho p1;
+  separate_frequencies(xyb.data(), c->w, c->h, &p1);
+  diffmap_psycho(c->pi0, p1, c->w, c->h, d.data());
+  float mx = 0.0f;
+  for (size_t i = 0; i < n; ++i) mx = std::max(mx, d[i]);
+  if (distmap) memcpy(distmap, d.data(), n * 4);
+  return mx;
+}
+
+// ref: butteraugli_comparator.cc:494-558
+void orc_comparator_block_weights(void* p, int direction, int max_block_dist,
+                                  double target_mul, const float* distmap,
+                                  float* block_weight) {
+  Comparator* c = (Comparator*)p;
+  const int w = c->w, h = c->h;
+  const double target_distance = c->target * target_mul;
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8;
+  std::vector<float> bmax((size_t)bw * bh);
+  for (int by = 0; by < bh; ++by)
+    for (int bx = 0; bx < bw; ++bx) {
+      float m = 0.0;
+      for (int y = 8 * by; y < std::min(h, 8 * by + 8); ++y)
+        for (int x = 8 * bx; x < std::min(w, 8 * bx + 8); ++x)
+          m = std::max(m, distmap[(size_t)y * w + x]);
+      bmax[(size_t)by * bw + bx] = m;
+    }
+  for (int by = 0; by < bh; ++by)
+    for (int bx = 0; bx < bw; ++bx) {
+      const int bix = by * bw + bx;
+      float local = static_cast<float>(target_distance);
+      const int x0 = std::max(0, bx - max_block_dist), y0 = std::max(0, by - max_block_dist);
+      const int x1 = std::min(bw, bx + 1 + max_block_dist);
+      const int y1 = std::min(bh, by + 1 + max_block_dist);
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) local = std::max(local, bmax[(size_t)y * bw + x]);
+      if (direction > 0) {
+        if (bmax[bix] <= target_distance && local <= 1.1 * target_distance)
+          block_weight[bix] = 1.0;
+      } else {
+        constexpr double kLocalMaxWeight = 0.5;
+        if (bmax[bix] <= (1 - kLocalMaxWeight) * target_distance + kLocalMaxWeight * local)
+          continue;
+        for (int y = y0; y < y1; ++y)
+          for (int x = x0; x < x1; ++x) {
+            const int d = std::max(std::abs(y - by), std::abs(x - bx));
+            const int ix = y * bw + x;
+            block_weight[ix] = std::max<float>(block_weight[ix], 1.0f / (d + 1.0f));
+          }
+      }
+    }
+}
+
+// ref: butteraugli_comparator.cc:415-421 (StartBlockComparisons -> mask_xyz_)
+void orc_comparator_block_mask(void* p, float* mask3) {
+  Comparator* c = (Comparator*)p;
+  const size_t n = (size_t)c->w * c->h;
+  Plane lin(3 * n), xyb(3 * n);
+  linear_from_rgb8(c->rgb.data(), c->w, c->h, lin.data());
+  opsin(lin.data(), c->w, c->h, xyb.data());
+  mask(xyb.data(), xyb.data() + n, xyb.data(), xyb.data() + n, c->w, c->h, mask3, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference hot path.
+ *
+ * Nothing under guetzli_amd/ may include, link, load or execute this.  Only tests/,
+ * __graft_entry__.smoke() and the cpu_baseline leg of bench.py use it, and only as
+ * the checker.  Parity of this restatement is PINNED: tests/test_oracle_vs_ref.py
+ * compares every function below bit-for-bit with the unmodified reference
+ * (oracle/_ref/libgz_ref.so, built from /root/reference by oracle/Makefile), and
+ * tests/golden/ holds reference-generated vectors for machines without _ref.
+ *
+ * Layouts (shared with include/guetzli_amd.h):
+ *   coeffs : int16, component-major, block-major: coeffs[(c*nb + by*bw + bx)*64 + k],
+ *            bw = ceil(w/8), bh = ceil(h/8), nb = bw*bh; values are DEQUANTISED.
+ *   planes : float, plane-major, row-major, stride == w (no padding): p[c*w*h + y*w + x]
+ *   rgb    : uint8 packed RGB, rgb[(y*w + x)*3 + c]
+ */
+#ifndef GZ_ORACLE_H_
+#define GZ_ORACLE_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- block path (a1-a7) ---- */
+void orc_fdct_block(int16_t* block);                       /* fdct.cc:230 */
+void orc_idct_block(const int16_t* block, uint8_t* out);   /* idct.cc:139 */
+int  orc_quantize_block(int16_t* block, const int* q);     /* quantize.cc:21 */
+void orc_ycbcr_to_rgb(uint8_t* pixels, int npix);          /* color_transform.h:211 */
+void orc_srgb_to_linear_table(double* out256);             /* gamma_correct.cc:23 */
+int  orc_encode_rgb(const uint8_t* rgb, int w, int h, int16_t* coeffs); /* jpeg_data_encoder.cc:66 */
+void orc_reconstruct(const int16_t* coeffs, int w, int h, const int* q /*3*64 or NULL*/,
+                     int16_t* coeffs_out, uint8_t* srgb, float* linear);
+
+/* ---- butteraugli stages (a9-a16) ---- */
+int  orc_compute_kernel(float sigma, float* taps, int cap);           /* butteraugli.cc:145 */
+void orc_blur(const float* in, int w, int h, float sigma, float border_ratio, float* out);
+void orc_opsin(const float* rgb, int w, int h, float* xyb);           /* butteraugli.cc:324 */
+void orc_separate_frequencies(const float* xyb, int w, int h, float* out10); /* :489 */
+void orc_mask(const float* xyb0, const float* xyb1, int w, int h, float* mask, float* mask_dc);
+void orc_malta(const float* lum0, const float* lum1, int w, int h, int lf,
+               double w_0gt1, double w_0lt1, double norm1, float* acc);
+double orc_diffmap(const float* rgb0, const float* rgb1, int w, int h, float* diffmap);
+
+/* ---- guetzli comparator (a17-a21) ---- */
+void* orc_comparator_create(const uint8_t* rgb, int w, int h, float target);
+void  orc_comparator_destroy(void* c);
+float orc_comparator_compare(void* c, const int16_t* coeffs, float* distmap);
+void  orc_comparator_block_weights(void* c, int direction, int max_block_dist,
+                                   double target_mul, const float* distmap,
+                                   float* block_weight);
+void  orc_comparator_block_mask(void* c, float* mask3);
+double orc_comparator_compare_block(void* c, const int16_t* coeffs, int bx, int by);
+int   orc_block_zeroing_orders(void* c, const int16_t* coeffs, const int16_t* orig,
+                               int lookahead, int new_model, int32_t* offsets,
+                               uint8_t* idx, float* err, int cap);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,6 @@
+"""guetzli_amd -- MI355X (gfx950) implementation of Guetzli's block-parallel hot path
+(block DCT / quantise / IDCT round trip + butteraugli distance map) behind the C ABI of
+include/guetzli_amd.h.  See DESIGN.md."""
+from .capi import Context, GuetzliAmdError, Library, load  # noqa: F401
+
+__all__ = ["Context", "GuetzliAmdError", "Library", "load"]

@@ -1,0 +1,59 @@
+"""Builds the product library guetzli_amd/libguetzli_amd.so for gfx950 with hipcc.
+
+In-tree, explicit hipcc (no JIT cache): the built .so travels to the GPU box with the
+repository snapshot.  Flags that matter for result parity (SURVEY.md §7 "hard parts"):
+  -ffp-contract=off                 no FMA contraction (the reference is SSE2, no FMA)
+  no -ffast-math, no -fgpu-flush-denormals-to-zero; correctly rounded f32 divide/sqrt is
+  the HIP default (-fhip-fp32-correctly-rounded-divide-sqrt).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libguetzli_amd.so")
+SOURCES = ["gz_api.hip"]
+HEADERS = ["gz_common.h", "gz_math.h", "gz_kernels_block.h", "gz_kernels_blur.h",
+           "gz_kernels_diff.h", "tables_generated.h"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _newer_than_lib():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps += [os.path.join(os.path.dirname(HERE), "include", "guetzli_amd.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension if sources are newer than the library."""
+    if not force and not _newer_than_lib():
+        return LIB
+    hipcc = hipcc_path()
+    if hipcc is None:
+        if os.path.exists(LIB):
+            return LIB     # prebuilt library shipped with the snapshot, no compiler here
+        raise RuntimeError("hipcc not found and no prebuilt libguetzli_amd.so")
+    cmd = [hipcc, f"--offload-arch={ARCH}"] + FLAGS + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

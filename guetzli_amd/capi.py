@@ -1,0 +1,270 @@
+"""ctypes binding of the C ABI in include/guetzli_amd.h.
+
+`load()` opens guetzli_amd/libguetzli_amd.so -- the hipcc-built gfx950 library -- and
+nothing else: there is no CPU implementation behind this module, and a missing library or
+a missing GPU is an error, not a fallback.  (The test-suite's CPU emulation build of the
+kernel sources is loaded by tests through `Library(path)` explicitly; the package never
+does that.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libguetzli_amd.so")
+
+GZ_OK = 0
+ERRORS = {-1: "GZ_E_ARG", -2: "GZ_E_NO_DEVICE", -3: "GZ_E_HIP", -4: "GZ_E_STATE",
+          -5: "GZ_E_NOMEM"}
+
+_P = C.c_void_p
+_I = C.c_int
+# name -> (restype, argtypes); mirrors include/guetzli_amd.h one to one
+SIGNATURES = {
+    "gz_abi_version": (_I, []),
+    "gz_device_count": (_I, []),
+    "gz_strerror": (C.c_char_p, [_I]),
+    "gz_last_error": (C.c_char_p, [_P]),
+    "gz_create": (_P, [_I, _I, _I, _P, C.c_float, C.POINTER(_I)]),
+    "gz_destroy": (None, [_P]),
+    "gz_synchronize": (_I, [_P]),
+    "gz_set_stream": (_I, [_P, _P]),
+    "gz_encode_rgb": (_I, [_P, _P]),
+    "gz_set_orig_coeffs": (_I, [_P, _P]),
+    "gz_quantize": (_I, [_P, _P, _P]),
+    "gz_set_coeffs": (_I, [_P, _P]),
+    "gz_set_coeff_blocks": (_I, [_P, _P, _I, _P]),
+    "gz_get_coeffs": (_I, [_P, _P]),
+    "gz_reconstruct": (_I, [_P, _P, _P]),
+    "gz_compare": (_I, [_P, _P, _P, _P]),
+    "gz_compare_enqueue": (_I, [_P, _I]),
+    "gz_last_distance": (_I, [_P, _P]),
+    "gz_time_compare": (_I, [_P, _I, _P]),
+    "gz_block_weights": (_I, [_P, _I, _I, C.c_double, _I, _P]),
+    "gz_probe_blur": (_I, [_P, _P, C.c_float, C.c_float, _P]),
+    "gz_probe_opsin": (_I, [_P, _P, _P]),
+    "gz_probe_separate_frequencies": (_I, [_P, _P, _P]),
+    "gz_probe_diffmap": (_I, [_P, _P, _P, _P, _P]),
+    "gz_probe_mask": (_I, [_P, _P, _P, _P, _P]),
+    "gz_probe_idct_blocks": (_I, [_I, _P, _I, _P]),
+    "gz_probe_fdct_blocks": (_I, [_I, _P, _I]),
+    "gz_probe_arith": (_I, [_I, _I, _P, _P, _P, _P, _I]),
+}
+
+
+class GuetzliAmdError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"], "need a C-contiguous array"
+    return a.ctypes.data
+
+
+class Library:
+    def __init__(self, path=DEFAULT_LIB):
+        if not os.path.exists(path):
+            raise GuetzliAmdError(
+                f"{path} not found: build it with `python -m guetzli_amd.build` (hipcc, "
+                "gfx950).  There is no CPU fallback.")
+        self.path = path
+        self.lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(self.lib, name)   # AttributeError if the ABI is incomplete
+            f.restype, f.argtypes = res, args
+
+    def check(self, rc, ctx=None):
+        if rc != GZ_OK:
+            msg = self.lib.gz_strerror(rc).decode()
+            if ctx:
+                msg += ": " + self.lib.gz_last_error(ctx).decode()
+            raise GuetzliAmdError(f"{ERRORS.get(rc, rc)} ({msg})")
+
+    def device_count(self):
+        return self.lib.gz_device_count()
+
+    # ---- context-free probes ----
+    def idct_blocks(self, blocks, device=0):
+        b = np.ascontiguousarray(blocks, np.int16).reshape(-1, 64)
+        out = np.zeros(b.shape, np.uint8)
+        self.check(self.lib.gz_probe_idct_blocks(device, _ptr(b), b.shape[0], _ptr(out)))
+        return out
+
+    def fdct_blocks(self, blocks, device=0):
+        b = np.ascontiguousarray(blocks, np.int16).reshape(-1, 64).copy()
+        self.check(self.lib.gz_probe_fdct_blocks(device, _ptr(b), b.shape[0]))
+        return b
+
+    def arith(self, op, a, b=None, c=None, device=0):
+        dt = np.float64 if op in (2, 3, 5, 6) else np.float32
+        odt = np.float64 if op in (2, 3, 5) else np.float32
+        a = np.ascontiguousarray(a, dt)
+        b = None if b is None else np.ascontiguousarray(b, dt)
+        c = None if c is None else np.ascontiguousarray(c, dt)
+        out = np.zeros(a.shape, odt)
+        self.check(self.lib.gz_probe_arith(device, op, _ptr(a), _ptr(b), _ptr(c), _ptr(out),
+                                           a.size))
+        return out
+
+    def context(self, rgb, target, device=0):
+        return Context(self, rgb, target, device)
+
+
+class Context:
+    """One (image, GPU) context == one guetzli::ButteraugliComparator + OutputImage."""
+
+    def __init__(self, library, rgb, target, device=0):
+        self.L = library
+        self.rgb = np.ascontiguousarray(rgb, np.uint8)
+        self.h, self.w, ch = self.rgb.shape
+        assert ch == 3
+        self.bw, self.bh = (self.w + 7) // 8, (self.h + 7) // 8
+        self.nb = self.bw * self.bh
+        err = C.c_int(0)
+        self.handle = library.lib.gz_create(device, self.w, self.h, _ptr(self.rgb),
+                                            float(target), C.byref(err))
+        if not self.handle:
+            library.check(err.value or -3)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.lib.gz_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        self.L.check(rc, self.handle)
+
+    def _coeff_buf(self):
+        return np.zeros((3, self.nb, 64), np.int16)
+
+    def synchronize(self):
+        self._chk(self.L.lib.gz_synchronize(self.handle))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.lib.gz_set_stream(self.handle, stream_ptr))
+
+    def encode_rgb(self, download=True):
+        out = self._coeff_buf() if download else None
+        self._chk(self.L.lib.gz_encode_rgb(self.handle, _ptr(out)))
+        return out
+
+    def set_orig_coeffs(self, coeffs):
+        co = np.ascontiguousarray(coeffs, np.int16)
+        assert co.size == 3 * self.nb * 64
+        self._chk(self.L.lib.gz_set_orig_coeffs(self.handle, _ptr(co)))
+
+    def quantize(self, q=None, download=True):
+        qq = None if q is None else np.ascontiguousarray(q, np.int32)
+        out = self._coeff_buf() if download else None
+        self._chk(self.L.lib.gz_quantize(self.handle, _ptr(qq), _ptr(out)))
+        return out
+
+    def set_coeffs(self, coeffs):
+        co = np.ascontiguousarray(coeffs, np.int16)
+        assert co.size == 3 * self.nb * 64
+        self._chk(self.L.lib.gz_set_coeffs(self.handle, _ptr(co)))
+
+    def set_coeff_blocks(self, block_index, blocks):
+        bi = np.ascontiguousarray(block_index, np.int32)
+        bl = np.ascontiguousarray(blocks, np.int16)
+        assert bl.size == bi.size * 192
+        self._chk(self.L.lib.gz_set_coeff_blocks(self.handle, _ptr(bi), bi.size, _ptr(bl)))
+
+    def get_coeffs(self):
+        out = self._coeff_buf()
+        self._chk(self.L.lib.gz_get_coeffs(self.handle, _ptr(out)))
+        return out
+
+    def reconstruct(self):
+        srgb = np.zeros((self.h, self.w, 3), np.uint8)
+        lin = np.zeros((3, self.h, self.w), np.float32)
+        self._chk(self.L.lib.gz_reconstruct(self.handle, _ptr(srgb), _ptr(lin)))
+        return srgb, lin
+
+    def compare(self, want_distmap=True, want_block_max=True):
+        dist = np.zeros(1, np.float32)
+        dm = np.zeros((self.h, self.w), np.float32) if want_distmap else None
+        bm = np.zeros(self.nb, np.float32) if want_block_max else None
+        self._chk(self.L.lib.gz_compare(self.handle, _ptr(dist), _ptr(dm), _ptr(bm)))
+        return float(dist[0]), dm, bm
+
+    def compare_enqueue(self, iters):
+        self._chk(self.L.lib.gz_compare_enqueue(self.handle, iters))
+
+    def last_distance(self):
+        d = np.zeros(1, np.float32)
+        self._chk(self.L.lib.gz_last_distance(self.handle, _ptr(d)))
+        return float(d[0])
+
+    def time_compare(self, iters):
+        ms = np.zeros(1, np.float32)
+        self._chk(self.L.lib.gz_time_compare(self.handle, iters, _ptr(ms)))
+        return float(ms[0])
+
+    def block_weights(self, direction, max_block_dist, target_mul, use_distmap=True,
+                      weights=None):
+        wgt = np.zeros(self.nb, np.float32) if weights is None else \
+            np.ascontiguousarray(weights, np.float32).copy()
+        self._chk(self.L.lib.gz_block_weights(self.handle, direction, max_block_dist,
+                                              target_mul, int(use_distmap), _ptr(wgt)))
+        return wgt
+
+    # ---- stage probes ----
+    def probe_blur(self, plane, sigma, border_ratio):
+        p = np.ascontiguousarray(plane, np.float32)
+        assert p.shape == (self.h, self.w)
+        out = np.zeros_like(p)
+        self._chk(self.L.lib.gz_probe_blur(self.handle, _ptr(p), sigma, border_ratio, _ptr(out)))
+        return out
+
+    def probe_opsin(self, rgb3):
+        p = np.ascontiguousarray(rgb3, np.float32)
+        assert p.shape == (3, self.h, self.w)
+        out = np.zeros_like(p)
+        self._chk(self.L.lib.gz_probe_opsin(self.handle, _ptr(p), _ptr(out)))
+        return out
+
+    def probe_separate_frequencies(self, xyb3):
+        p = np.ascontiguousarray(xyb3, np.float32)
+        out = np.zeros((10, self.h, self.w), np.float32)
+        self._chk(self.L.lib.gz_probe_separate_frequencies(self.handle, _ptr(p), _ptr(out)))
+        return out
+
+    def probe_diffmap(self, rgb0, rgb1):
+        a = np.ascontiguousarray(rgb0, np.float32)
+        b = np.ascontiguousarray(rgb1, np.float32)
+        d = np.zeros((self.h, self.w), np.float32)
+        s = np.zeros(1, np.float32)
+        self._chk(self.L.lib.gz_probe_diffmap(self.handle, _ptr(a), _ptr(b), _ptr(d), _ptr(s)))
+        return d, float(s[0])
+
+    def probe_mask(self, xyb0, xyb1):
+        a = np.ascontiguousarray(xyb0, np.float32)
+        b = np.ascontiguousarray(xyb1, np.float32)
+        m = np.zeros((3, self.h, self.w), np.float32)
+        mdc = np.zeros((3, self.h, self.w), np.float32)
+        self._chk(self.L.lib.gz_probe_mask(self.handle, _ptr(a), _ptr(b), _ptr(m), _ptr(mdc)))
+        return m, mdc
+
+
+_default = None
+
+
+def load():
+    """The product library (gfx950).  Raises if it is missing."""
+    global _default
+    if _default is None:
+        _default = Library(DEFAULT_LIB)
+    return _default

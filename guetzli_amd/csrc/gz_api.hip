@@ -1,0 +1,965 @@
+// C-ABI implementation (include/guetzli_amd.h): per-image context, device plane arena,
+// blur plans, and the kernel sequences for the block path and for
+// ButteraugliComparator::Compare.  Host code only orchestrates; every per-pixel /
+// per-block operation is in the gz_kernels_*.h kernels.
+//
+// Built by hipcc for gfx950 with -ffp-contract=off (guetzli_amd/build.py).  There is no
+// CPU path: without a usable HIP device gz_create fails with GZ_E_NO_DEVICE.
+
+#include "../../include/guetzli_amd.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "gz_common.h"
+#include "gz_kernels_block.h"
+#include "gz_kernels_blur.h"
+#include "gz_kernels_diff.h"
+
+using namespace gz;
+
+namespace {
+
+// ------------------------------------------------------------------ blur plans ------
+// Host-side restatement of ComputeKernel (butteraugli.cc:145-154) and of the border
+// normalisation of ConvolveBorderColumn (:156-181).  exp() is evaluated on the host with
+// the same libm float overload the reference uses; the device never recomputes taps.
+struct BlurCfg {
+  float sigma, border_ratio;
+  int r;
+  std::vector<float> k, ks;
+  float wsum;
+  // device border scales for the x axis (length w) and the y axis (length h)
+  float* d_scale = nullptr;   // 4*r floats: x.lo, x.hi, y.lo, y.hi
+  BorderScale bx, by;
+};
+
+void make_taps_host(float sigma, BlurCfg* c) {
+  const float m = 2.25;
+  const float scaler = -1.0 / (2 * sigma * sigma);
+  const int diff = std::max<int>(1, m * fabsf(sigma));
+  c->sigma = sigma;
+  c->r = diff;
+  c->k.resize(2 * diff + 1);
+  for (int i = -diff; i <= diff; ++i) c->k[i + diff] = expf(scaler * i * i);
+  float w = 0.0f;
+  for (size_t j = 0; j < c->k.size(); ++j) w += c->k[j];
+  c->wsum = w;
+  const float s = 1.0f / w;
+  c->ks = c->k;
+  for (size_t j = 0; j < c->ks.size(); ++j) c->ks[j] *= s;
+}
+
+// scale(x) for a border position x on an axis of length n.
+float border_scale(const BlurCfg& c, int n, int x) {
+  const int r = c.r;
+  const int lo = x < r ? 0 : x - r;
+  const int hi = std::min(n - 1, x + r);
+  float weight = 0.0f;
+  for (int j = lo; j <= hi; ++j) weight += c.k[j - x + r];
+  weight = (1.0f - c.border_ratio) * weight + c.border_ratio * c.wsum;
+  return 1.0f / weight;
+}
+
+void border_scales_host(const BlurCfg& c, int n, std::vector<float>* lo,
+                        std::vector<float>* hi) {
+  lo->assign(c.r, 1.0f);
+  hi->assign(c.r, 1.0f);
+  for (int i = 0; i < c.r; ++i) {
+    if (i < n) (*lo)[i] = border_scale(c, n, i);
+    if (n - 1 - i >= 0) (*hi)[i] = border_scale(c, n, n - 1 - i);
+  }
+}
+
+template <int R>
+Taps<R> taps_of(const BlurCfg& c) {
+  Taps<R> t;
+  for (int j = 0; j <= 2 * R; ++j) {
+    t.k[j] = c.k[j];
+    t.ks[j] = c.ks[j];
+  }
+  return t;
+}
+
+enum BlurId { B_OPSIN, B_LF, B_MF, B_HF, B_SN, B_MASKX, B_MASKY0, B_MASKY1, B_FINAL, B_COUNT };
+struct BlurSpec { double sigma, border; int r; };
+// sigmas / border ratios: butteraugli.cc:329, :497-508, :885, :1757-1760, :737-740
+const BlurSpec kBlurSpecs[B_COUNT] = {
+  {1.2, 0.0, 2},
+  {7.46953768697, -0.00457628248637, 16},
+  {3.734768843485, -0.271277366628, 8},
+  {1.8673844217425, 0.147068973249, 4},
+  {10.6666499623, 0.0, 23},
+  {9.24456601467, -0.0724948220913, 20},
+  {2.3770330432, -0.0724948220913, 5},
+  {9.04353323561, -0.0724948220913, 20},
+  {1.72547472444, 1.0, 3},
+};
+
+// MakeMask (butteraugli.cc:1638-1653) for MaskX / MaskY / MaskDcX / MaskDcY (:1655-1697)
+void make_mask_lut(double extmul, double extoff, double mul, double offset, double scaler,
+                   double* lut) {
+  const double kGlobalScale = 1.0 / 20.35;
+  for (int i = 0; i < 512; ++i) {
+    const double c = mul / ((0.01 * scaler * i) + offset);
+    lut[i] = kGlobalScale * (1.0 + extmul * (c + extoff));
+    if (lut[i] < 1e-5) lut[i] = 1e-5;
+    lut[i] *= lut[i];
+  }
+}
+
+// Malta normalisation constants (MaltaDiffMapImpl, butteraugli.cc:1468-1476)
+MaltaNorm malta_norm(bool lf, double w_0gt1, double w_0lt1, double norm1) {
+  const double len = 3.75;
+  const double mulli = lf ? 0.405371989604 : 0.354191303559;
+  const float kWeight0 = 0.5;
+  const float kWeight1 = 0.33;
+  const double w_pre0gt1 = mulli * sqrt(kWeight0 * w_0gt1) / (len * 2 + 1);
+  const double w_pre0lt1 = mulli * sqrt(kWeight1 * w_0lt1) / (len * 2 + 1);
+  MaltaNorm n;
+  n.norm2_0gt1 = w_pre0gt1 * norm1;
+  n.norm2_0lt1 = w_pre0lt1 * norm1;
+  n.norm1f = static_cast<float>(norm1);
+  return n;
+}
+
+struct Psycho {   // device planes of one image's PsychoImage (butteraugli.h:418-423)
+  float* lfv[3];  // lf in "vals" space
+  float* mf[2];   // X, Y  (mf[2] of the reference is dead: wmul[5] == 0)
+  float* hf[2];
+  float* uhf[2];
+};
+
+}  // namespace
+
+struct gz_ctx {
+  int device = 0;
+  int w = 0, h = 0, bw = 0, bh = 0, nb = 0, pitch = 0;
+  size_t plane = 0;   // floats per plane
+  float target = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  uint8_t* d_rgb = nullptr;
+  int16_t* d_orig = nullptr;   // [3][nb][64] original coefficients
+  int16_t* d_cand = nullptr;   // candidate coefficients
+  int* d_q = nullptr;          // [3][64]
+  float* d_srgb_lut = nullptr; // float(Srgb8ToLinearTable[i])
+  double* d_mask_luts = nullptr;
+  float* d_block_max = nullptr;
+  unsigned* d_max_bits = nullptr;
+  uint8_t* d_srgb_out = nullptr;
+  int32_t* d_blkidx = nullptr; size_t blkidx_cap = 0;
+  int16_t* d_blkdata = nullptr;
+
+  float* arena = nullptr;
+  float* extra_arena = nullptr;   // probe-only planes (ensure_pip)
+  std::vector<float*> free_planes;
+  BlurCfg blur[B_COUNT];
+
+  Psycho pi0;   // original
+  Psycho pi1;   // candidate
+  Psycho pip;   // probe "image 0" (allocated lazily)
+  bool have_pip = false;
+  // scratch
+  float *lin[3], *tmp[3], *xyb[3], *lf_raw[2], *hfp[2];
+  float *snb, *diffx, *diffy, *mxb, *myb1, *myb2, *ac[2], *dsq, *distmap;
+  float *mask_out[3], *mask_dc_out[3];
+  bool have_mask_out = false;
+
+  bool have_orig = false, have_cand = false, have_distmap = false;
+  std::vector<float> h_block_max;
+  float last_distance = 0.0f;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                            \
+  do {                                                                               \
+    hipError_t e_ = (call);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+      return GZ_E_HIP;                                                               \
+    }                                                                                \
+  } while (0)
+
+#define KCHK(ctx)                                                                    \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) {                                                          \
+      (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(e_);           \
+      return GZ_E_HIP;                                                               \
+    }                                                                                \
+  } while (0)
+
+const int kNumPlanes = 9 + 9 + 3 + 3 + 3 + 2 + 2 + 10;   // pi0, pi1, lin, tmp, xyb, lf_raw, hfp, 10 singles
+
+float* take_plane(gz_ctx* c) {
+  float* p = c->free_planes.back();
+  c->free_planes.pop_back();
+  return p;
+}
+void alloc_psycho(gz_ctx* c, Psycho* p) {
+  for (int i = 0; i < 3; ++i) p->lfv[i] = take_plane(c);
+  for (int i = 0; i < 2; ++i) p->mf[i] = take_plane(c);
+  for (int i = 0; i < 2; ++i) p->hf[i] = take_plane(c);
+  for (int i = 0; i < 2; ++i) p->uhf[i] = take_plane(c);
+}
+
+// ------------------------------------------------------------- blur dispatch helpers --
+template <int R, class Src, int NC>
+int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
+           const BlurCfg& cfg) {
+  if (cfg.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
+  dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), NC);
+  const Taps<R> tp = taps_of<R>(cfg);
+  const BorderScale bs = cfg.bx;
+  const int w = c->w, h = c->h, pitch = c->pitch;
+  GZ_LAUNCH((k_blur_h<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs);
+  KCHK(c);
+  return GZ_OK;
+}
+template <int R, int NC, class Post>
+int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg& cfg) {
+  if (cfg.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
+  dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, VH));
+  const Taps<R> tp = taps_of<R>(cfg);
+  const BorderScale bs = cfg.by;
+  const int w = c->w, h = c->h, pitch = c->pitch;
+  GZ_LAUNCH((k_blur_v<R, NC, Post>), grid, dim3(256), c->stream, src, post, w, h, pitch, tp, bs);
+  KCHK(c);
+  return GZ_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != GZ_OK) return rc_; } while (0)
+
+int setup_blur_cfg(gz_ctx* c, BlurCfg* cfg, float sigma, float border_ratio) {
+  make_taps_host(sigma, cfg);
+  cfg->border_ratio = border_ratio;
+  std::vector<float> xl, xh, yl, yh;
+  border_scales_host(*cfg, c->w, &xl, &xh);
+  border_scales_host(*cfg, c->h, &yl, &yh);
+  const int r = cfg->r;
+  if (cfg->d_scale == nullptr) HIPCHK(c, hipMalloc((void**)&cfg->d_scale, sizeof(float) * 4 * r));
+  std::vector<float> all;
+  all.insert(all.end(), xl.begin(), xl.end());
+  all.insert(all.end(), xh.begin(), xh.end());
+  all.insert(all.end(), yl.begin(), yl.end());
+  all.insert(all.end(), yh.begin(), yh.end());
+  HIPCHK(c, hipMemcpy(cfg->d_scale, all.data(), sizeof(float) * 4 * r, hipMemcpyHostToDevice));
+  cfg->bx.lo = cfg->d_scale;
+  cfg->bx.hi = cfg->d_scale + r;
+  cfg->by.lo = cfg->d_scale + 2 * r;
+  cfg->by.hi = cfg->d_scale + 3 * r;
+  return GZ_OK;
+}
+
+// --------------------------------------------------------------- pipeline stages ------
+// OpsinDynamicsImage: lin[3] -> xyb[3]
+int stage_opsin(gz_ctx* c) {
+  SrcPack<SrcPlain, 3> s;
+  PlanePack<3> t;
+  CPlanePack<3> ct;
+  for (int i = 0; i < 3; ++i) { s.s[i].p = c->lin[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
+  TRY((blur_h<2, SrcPlain, 3>(c, s, t, c->blur[B_OPSIN])));
+  PostOpsin post;
+  for (int i = 0; i < 3; ++i) { post.lin[i] = c->lin[i]; post.xyb[i] = c->xyb[i]; }
+  TRY((blur_v<2, 3, PostOpsin>(c, ct, post, c->blur[B_OPSIN])));
+  return GZ_OK;
+}
+
+// SeparateFrequencies: xyb[3] -> Psycho planes
+int stage_separate(gz_ctx* c, Psycho* ps) {
+  {  // LF
+    SrcPack<SrcPlain, 3> s;
+    PlanePack<3> t;
+    CPlanePack<3> ct;
+    for (int i = 0; i < 3; ++i) { s.s[i].p = c->xyb[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
+    TRY((blur_h<16, SrcPlain, 3>(c, s, t, c->blur[B_LF])));
+    PostLF post;
+    post.lf_raw[0] = c->lf_raw[0];
+    post.lf_raw[1] = c->lf_raw[1];
+    for (int i = 0; i < 3; ++i) post.lf_vals[i] = ps->lfv[i];
+    TRY((blur_v<16, 3, PostLF>(c, ct, post, c->blur[B_LF])));
+  }
+  {  // MF (X, Y)
+    SrcPack<SrcDiff, 2> s;
+    PlanePack<2> t;
+    CPlanePack<2> ct;
+    for (int i = 0; i < 2; ++i) {
+      s.s[i].a = c->xyb[i];
+      s.s[i].b = c->lf_raw[i];
+      t.p[i] = c->tmp[i];
+      ct.p[i] = c->tmp[i];
+    }
+    TRY((blur_h<8, SrcDiff, 2>(c, s, t, c->blur[B_MF])));
+    PostMF post;
+    for (int i = 0; i < 2; ++i) {
+      post.xyb[i] = c->xyb[i];
+      post.lf_raw[i] = c->lf_raw[i];
+      post.mf[i] = ps->mf[i];
+      post.hf_pre[i] = c->hfp[i];
+    }
+    TRY((blur_v<8, 2, PostMF>(c, ct, post, c->blur[B_MF])));
+  }
+  {  // HF / UHF
+    SrcPack<SrcPlain, 2> s;
+    PlanePack<2> t;
+    CPlanePack<2> ct;
+    for (int i = 0; i < 2; ++i) { s.s[i].p = c->hfp[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
+    TRY((blur_h<4, SrcPlain, 2>(c, s, t, c->blur[B_HF])));
+    PostHF post;
+    for (int i = 0; i < 2; ++i) {
+      post.hf_pre[i] = c->hfp[i];
+      post.hf[i] = ps->hf[i];
+      post.uhf[i] = ps->uhf[i];
+    }
+    post.lf_raw_y = c->lf_raw[1];
+    TRY((blur_v<4, 2, PostHF>(c, ct, post, c->blur[B_HF])));
+  }
+  return GZ_OK;
+}
+
+// Mask first half: DiffPrecompute + three blurs -> mxb, myb1, myb2
+int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk) {
+  dim3 grid(gz_div_up(c->w, 256), c->h, 2);
+  GZ_LAUNCH(k_mask_pre, grid, dim3(256), c->stream, pk, c->w, c->h, c->pitch);
+  KCHK(c);
+  {  // X: sigma r2 = 9.24 ; Y second: sigma r1 = 9.04 -- both radius 20, separate taps
+    SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
+    s.s[0].p = c->diffx; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKX])));
+    PostStore<1> post; post.out[0] = c->mxb;
+    TRY((blur_v<20, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKX])));
+  }
+  {
+    SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
+    s.s[0].p = c->diffy; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    TRY((blur_h<5, SrcPlain, 1>(c, s, t, c->blur[B_MASKY0])));
+    PostStore<1> post; post.out[0] = c->myb1;
+    TRY((blur_v<5, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKY0])));
+  }
+  {
+    SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
+    s.s[0].p = c->diffy; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKY1])));
+    PostStore<1> post; post.out[0] = c->myb2;
+    TRY((blur_v<20, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKY1])));
+  }
+  return GZ_OK;
+}
+
+MaskPrePack mask_pack_psycho(gz_ctx* c, const Psycho& a, const Psycho& b) {
+  // MaskPsychoImage muls (butteraugli.cc:759-764)
+  const double muls[4] = {0, 1.64178305129, 0.831081703362, 3.23680933546};
+  MaskPrePack pk;
+  for (int i = 0; i < 2; ++i) {
+    pk.in0[i].a = pk.in1[i].a = muls[2 * i];
+    pk.in0[i].b = pk.in1[i].b = muls[2 * i + 1];
+    pk.in0[i].plain = pk.in1[i].plain = 0;
+    pk.in0[i].hf = a.hf[i];
+    pk.in1[i].hf = b.hf[i];
+    pk.in0[i].uhf = muls[2 * i] == 0 ? nullptr : a.uhf[i];
+    pk.in1[i].uhf = muls[2 * i] == 0 ? nullptr : b.uhf[i];
+  }
+  pk.out[0] = c->diffx;
+  pk.out[1] = c->diffy;
+  return pk;
+}
+
+// DiffmapPsychoImage (butteraugli.cc:817-908) + score: p0 = original, p1 = candidate.
+int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block_max) {
+  const float hf_asymmetry_ = 0.8f;
+  {  // SameNoiseLevels blur input + blur (sigma 10.67)
+    SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
+    s.s[0].a = p0.hf[1]; s.s[0].b = p1.hf[1];
+    t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    TRY((blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN])));
+    PostStore<1> post; post.out[0] = c->snb;
+    TRY((blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN])));
+  }
+  const double wUhfMalta = 5.1409625726, norm1Uhf = 58.5001247061;
+  const double wUhfMaltaX = 4.91743441556, norm1UhfX = 687196.39002;
+  const double wHfMalta = 153.671655716, norm1Hf = 83150785.9592;
+  const double wHfMaltaX = 668.358918152, norm1HfX = 0.882954368025;
+  const double wMfMalta = 6841.81248144, norm1Mf = 0.0135134962487;
+  const double wMfMaltaX = 813.901703816, norm1MfX = 16792.9322251;
+  const float sqrt_asym = sqrtf(hf_asymmetry_);   // float sqrt overload in the reference
+  dim3 mgrid(gz_div_up(c->w, MW), gz_div_up(c->h, MH));
+  {  // Y channel
+    MaltaArgs<3> a;
+    a.pass[0] = {p0.uhf[1], p1.uhf[1],
+                 malta_norm(false, wUhfMalta * hf_asymmetry_, wUhfMalta / hf_asymmetry_, norm1Uhf), 0};
+    a.pass[1] = {p0.hf[1], p1.hf[1],
+                 malta_norm(true, wHfMalta * sqrt_asym, wHfMalta / sqrt_asym, norm1Hf), 1};
+    a.pass[2] = {p0.mf[1], p1.mf[1], malta_norm(true, wMfMalta, wMfMalta, norm1Mf), 1};
+    const double wmul1 = 32.4449876135;
+    a.tail.sn_blur = c->snb;
+    a.tail.hf0 = p0.hf[1];
+    a.tail.hf1 = p1.hf[1];
+    a.tail.w_sn = 884.809801415;
+    a.tail.w_0gt1 = (wmul1 * hf_asymmetry_) * 0.8;   // L2DiffAsymmetric: w *= 0.8 (:678-679)
+    a.tail.w_0lt1 = (wmul1 / hf_asymmetry_) * 0.8;
+    a.out = c->ac[1];
+    GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, a, c->w, c->h, c->pitch);
+    KCHK(c);
+  }
+  {  // X channel
+    MaltaArgs<3> a;
+    a.pass[0] = {p0.uhf[0], p1.uhf[0],
+                 malta_norm(false, wUhfMaltaX * hf_asymmetry_, wUhfMaltaX / hf_asymmetry_, norm1UhfX), 0};
+    a.pass[1] = {p0.hf[0], p1.hf[0],
+                 malta_norm(true, wHfMaltaX * sqrt_asym, wHfMaltaX / sqrt_asym, norm1HfX), 1};
+    a.pass[2] = {p0.mf[0], p1.mf[0], malta_norm(true, wMfMaltaX, wMfMaltaX, norm1MfX), 1};
+    a.tail.sn_blur = nullptr;
+    a.tail.hf0 = a.tail.hf1 = nullptr;
+    a.tail.w_sn = a.tail.w_0gt1 = a.tail.w_0lt1 = 0;
+    a.out = c->ac[0];
+    GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, a, c->w, c->h, c->pitch);
+    KCHK(c);
+  }
+  TRY(stage_mask_blurs(c, mask_pack_psycho(c, p0, p1)));
+  {
+    CombineArgs a;
+    a.mask_x_blur = c->mxb; a.mask_y_blur1 = c->myb1; a.mask_y_blur2 = c->myb2;
+    a.ac0 = c->ac[0]; a.ac1 = c->ac[1];
+    a.lf0_x = p0.lfv[0]; a.lf1_x = p1.lfv[0];
+    a.lf0_b = p0.lfv[2]; a.lf1_b = p1.lfv[2];
+    a.luts = c->d_mask_luts;
+    a.out = c->dsq;
+    for (int i = 0; i < 3; ++i) a.mask_out[i] = a.mask_dc_out[i] = nullptr;
+    dim3 grid(gz_div_up(c->w, 256), c->h);
+    GZ_LAUNCH(k_combine, grid, dim3(256), c->stream, a, c->w, c->h, c->pitch);
+    KCHK(c);
+  }
+  {  // CalculateDiffmap second half: blur(sigma 1.725, border_ratio 1.0) + mix
+    SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
+    s.s[0].p = c->dsq; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    TRY((blur_h<3, SrcPlain, 1>(c, s, t, c->blur[B_FINAL])));
+    PostDiffmapMix post; post.d = c->dsq; post.out = c->distmap;
+    TRY((blur_v<3, 1, PostDiffmapMix>(c, ct, post, c->blur[B_FINAL])));
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
+  GZ_LAUNCH(k_block_max, dim3(gz_div_up(c->nb, 4)), dim3(256), c->stream, c->distmap, c->w,
+            c->h, c->pitch, c->bw, c->nb, want_block_max ? c->d_block_max : nullptr,
+            c->d_max_bits);
+  KCHK(c);
+  return GZ_OK;
+}
+
+int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* srgb) {
+  GZ_LAUNCH(k_reconstruct, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream,
+            d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
+            srgb);
+  KCHK(c);
+  return GZ_OK;
+}
+
+// One full Compare of the current candidate, everything on the stream.
+int enqueue_compare(gz_ctx* c, bool want_block_max) {
+  TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr));
+  TRY(stage_opsin(c));
+  TRY(stage_separate(c, &c->pi1));
+  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max));
+  return GZ_OK;
+}
+
+int upload_planes(gz_ctx* c, const float* host, float* const* dev, int n) {
+  for (int i = 0; i < n; ++i)
+    HIPCHK(c, hipMemcpyAsync(dev[i], host + (size_t)i * c->w * c->h,
+                             sizeof(float) * c->w * c->h, hipMemcpyHostToDevice, c->stream));
+  return GZ_OK;
+}
+int download_plane(gz_ctx* c, const float* dev, float* host) {
+  HIPCHK(c, hipMemcpyAsync(host, dev, sizeof(float) * c->w * c->h, hipMemcpyDeviceToHost,
+                           c->stream));
+  return GZ_OK;
+}
+
+int ensure_pip(gz_ctx* c) {
+  if (c->have_pip) return GZ_OK;
+  HIPCHK(c, hipMalloc((void**)&c->extra_arena, sizeof(float) * c->plane * 15));
+  for (int i = 0; i < 15; ++i) c->free_planes.push_back(c->extra_arena + (size_t)i * c->plane);
+  alloc_psycho(c, &c->pip);
+  for (int i = 0; i < 3; ++i) { c->mask_out[i] = take_plane(c); c->mask_dc_out[i] = take_plane(c); }
+  c->have_pip = true;
+  return GZ_OK;
+}
+
+}  // namespace
+
+// ===================================================================== C surface ======
+extern "C" {
+
+int gz_abi_version(void) { return 1; }
+
+int gz_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return GZ_E_NO_DEVICE;
+  return n;
+}
+
+const char* gz_strerror(int code) {
+  switch (code) {
+    case GZ_OK: return "ok";
+    case GZ_E_ARG: return "invalid argument";
+    case GZ_E_NO_DEVICE: return "no usable HIP device";
+    case GZ_E_HIP: return "HIP runtime error";
+    case GZ_E_STATE: return "invalid call sequence";
+    case GZ_E_NOMEM: return "out of memory";
+    default: return "unknown error";
+  }
+}
+
+const char* gz_last_error(const gz_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, int* err) {
+  int dummy;
+  if (!err) err = &dummy;
+  *err = GZ_OK;
+  if (!rgb || w < 8 || h < 8 || w >= (1 << 16) || h >= (1 << 16)) { *err = GZ_E_ARG; return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev ||
+      hipSetDevice(device) != hipSuccess) {
+    *err = GZ_E_NO_DEVICE;
+    return nullptr;
+  }
+  gz_ctx* c = new gz_ctx;
+  c->device = device;
+  c->w = w; c->h = h;
+  c->bw = (w + 7) / 8; c->bh = (h + 7) / 8; c->nb = c->bw * c->bh;
+  c->pitch = w;
+  c->plane = (size_t)c->pitch * h;
+  c->target = target;
+  auto fail = [&](int code) { *err = code; gz_destroy(c); return (gz_ctx*)nullptr; };
+#define CHK0(call) do { if ((call) != hipSuccess) { return fail(GZ_E_HIP); } } while (0)
+  CHK0(hipStreamCreate(&c->own_stream));
+  c->stream = c->own_stream;
+  const size_t ncoef = (size_t)3 * c->nb * 64;
+  CHK0(hipMalloc((void**)&c->d_rgb, (size_t)3 * w * h));
+  CHK0(hipMalloc((void**)&c->d_orig, ncoef * 2));
+  CHK0(hipMalloc((void**)&c->d_cand, ncoef * 2));
+  CHK0(hipMalloc((void**)&c->d_q, sizeof(int) * 192));
+  CHK0(hipMalloc((void**)&c->d_srgb_lut, sizeof(float) * 256));
+  CHK0(hipMalloc((void**)&c->d_mask_luts, sizeof(double) * 2048));
+  CHK0(hipMalloc((void**)&c->d_block_max, sizeof(float) * c->nb));
+  CHK0(hipMalloc((void**)&c->d_max_bits, sizeof(unsigned)));
+  CHK0(hipMalloc((void**)&c->d_srgb_out, (size_t)3 * w * h));
+  CHK0(hipMalloc((void**)&c->arena, sizeof(float) * c->plane * kNumPlanes));
+  for (int i = kNumPlanes - 1; i >= 0; --i) c->free_planes.push_back(c->arena + (size_t)i * c->plane);
+  alloc_psycho(c, &c->pi0);
+  alloc_psycho(c, &c->pi1);
+  for (int i = 0; i < 3; ++i) { c->lin[i] = take_plane(c); }
+  for (int i = 0; i < 3; ++i) { c->tmp[i] = take_plane(c); }
+  for (int i = 0; i < 3; ++i) { c->xyb[i] = take_plane(c); }
+  for (int i = 0; i < 2; ++i) { c->lf_raw[i] = take_plane(c); c->hfp[i] = take_plane(c); }
+  c->snb = take_plane(c); c->diffx = take_plane(c); c->diffy = take_plane(c);
+  c->mxb = take_plane(c); c->myb1 = take_plane(c); c->myb2 = take_plane(c);
+  c->ac[0] = take_plane(c); c->ac[1] = take_plane(c);
+  c->dsq = take_plane(c); c->distmap = take_plane(c);
+  // lin planes must be contiguous for k_reconstruct / k_linear_from_rgb8 (plane stride)
+  if (c->lin[1] != c->lin[0] + c->plane || c->lin[2] != c->lin[0] + 2 * c->plane) return fail(GZ_E_STATE);
+
+  // tables
+  {
+    // Srgb8ToLinearTable (gamma_correct.cc:23-38), then float() as LinearRgb /
+    // ToLinearRGB store it (butteraugli_comparator.cc:42, output_image.cc:434).
+    float lut[256];
+    int i = 0;
+    for (; i < 11; ++i) lut[i] = (float)(i / 12.92);
+    for (; i < 256; ++i) lut[i] = (float)(255.0 * pow(((i / 255.0) + 0.055) / 1.055, 2.4));
+    CHK0(hipMemcpy(c->d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    std::vector<double> ml(2048);
+    make_mask_lut(2.59885507073, 3.08805636789, 5.62939030582, 0.315424196682, 16.2770141832, &ml[0]);
+    make_mask_lut(0.9613705131, -0.581933100068, 6.64307621174, 1.00846207765, 2.2342321176, &ml[512]);
+    make_mask_lut(10.0470705878, 3.18472654033, 0.373092999662, 0.0551512255218, 70.0, &ml[1024]);
+    make_mask_lut(0.0115640939227, 45.9483175519, 2.52611324247, 0.0142290066313, 5.0, &ml[1536]);
+    CHK0(hipMemcpy(c->d_mask_luts, ml.data(), sizeof(double) * 2048, hipMemcpyHostToDevice));
+  }
+  for (int b = 0; b < B_COUNT; ++b) {
+    // Blur(in, float sigma, float border_ratio): both narrowed to float at the call.
+    int rc = setup_blur_cfg(c, &c->blur[b], (float)kBlurSpecs[b].sigma, (float)kBlurSpecs[b].border);
+    if (rc != GZ_OK) return fail(rc);
+    if (c->blur[b].r != kBlurSpecs[b].r) return fail(GZ_E_STATE);
+  }
+  CHK0(hipMemcpy(c->d_rgb, rgb, (size_t)3 * w * h, hipMemcpyHostToDevice));
+  // pi0_ = SeparateFrequencies(OpsinDynamicsImage(LinearRgb(rgb)))
+  {
+    dim3 grid(gz_div_up(w, 256), h);
+    GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, w, h, c->pitch,
+              c->plane, c->d_srgb_lut, c->lin[0]);
+    if (hipGetLastError() != hipSuccess) return fail(GZ_E_HIP);
+    int rc = stage_opsin(c);
+    if (rc == GZ_OK) rc = stage_separate(c, &c->pi0);
+    if (rc != GZ_OK) return fail(rc);
+    CHK0(hipStreamSynchronize(c->stream));
+  }
+#undef CHK0
+  return c;
+}
+
+void gz_destroy(gz_ctx* c) {
+  if (!c) return;
+  if (c->own_stream) hipStreamSynchronize(c->own_stream);
+  hipFree(c->d_rgb); hipFree(c->d_orig); hipFree(c->d_cand); hipFree(c->d_q);
+  hipFree(c->d_srgb_lut); hipFree(c->d_mask_luts); hipFree(c->d_block_max);
+  hipFree(c->d_max_bits); hipFree(c->d_srgb_out); hipFree(c->arena);
+  hipFree(c->d_blkidx); hipFree(c->d_blkdata);
+  hipFree(c->extra_arena);
+  for (int b = 0; b < B_COUNT; ++b) hipFree(c->blur[b].d_scale);
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int gz_synchronize(gz_ctx* c) {
+  if (!c) return GZ_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_set_stream(gz_ctx* c, void* s) {
+  if (!c) return GZ_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return GZ_OK;
+}
+
+int gz_encode_rgb(gz_ctx* c, int16_t* coeffs_out) {
+  if (!c) return GZ_E_ARG;
+  GZ_LAUNCH(k_encode_rgb, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream, c->d_rgb,
+            c->w, c->h, c->bw, c->nb, c->d_orig);
+  KCHK(c);
+  c->have_orig = true;
+  if (coeffs_out) {
+    HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_orig, (size_t)3 * c->nb * 128,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return GZ_OK;
+}
+
+int gz_set_orig_coeffs(gz_ctx* c, const int16_t* coeffs) {
+  if (!c || !coeffs) return GZ_E_ARG;
+  HIPCHK(c, hipMemcpyAsync(c->d_orig, coeffs, (size_t)3 * c->nb * 128, hipMemcpyHostToDevice,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_orig = true;
+  return GZ_OK;
+}
+
+int gz_quantize(gz_ctx* c, const int* q, int16_t* coeffs_out) {
+  if (!c) return GZ_E_ARG;
+  if (!c->have_orig) { c->err = "no original coefficients"; return GZ_E_STATE; }
+  int ones[192];
+  if (!q) { for (int i = 0; i < 192; ++i) ones[i] = 1; q = ones; }
+  for (int i = 0; i < 192; ++i) if (q[i] <= 0) return GZ_E_ARG;
+  HIPCHK(c, hipMemcpyAsync(c->d_q, q, sizeof(int) * 192, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // q may live on the caller's stack
+  const size_t total = (size_t)3 * c->nb * 64;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  GZ_LAUNCH(k_quantize, dim3(blocks), dim3(256), c->stream, c->d_orig, c->d_cand, c->nb, c->d_q);
+  KCHK(c);
+  c->have_cand = true;
+  if (coeffs_out) {
+    HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_cand, total * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return GZ_OK;
+}
+
+int gz_set_coeffs(gz_ctx* c, const int16_t* coeffs) {
+  if (!c || !coeffs) return GZ_E_ARG;
+  HIPCHK(c, hipMemcpyAsync(c->d_cand, coeffs, (size_t)3 * c->nb * 128, hipMemcpyHostToDevice,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_cand = true;
+  return GZ_OK;
+}
+
+int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int16_t* blocks) {
+  if (!c || n < 0 || (n > 0 && (!block_index || !blocks))) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  for (int i = 0; i < n; ++i) {
+    if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;
+    for (int comp = 0; comp < 3; ++comp)
+      HIPCHK(c, hipMemcpyAsync(c->d_cand + ((size_t)comp * c->nb + block_index[i]) * 64,
+                               blocks + ((size_t)i * 3 + comp) * 64, 128,
+                               hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_get_coeffs(gz_ctx* c, int16_t* out) {
+  if (!c || !out) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  HIPCHK(c, hipMemcpyAsync(out, c->d_cand, (size_t)3 * c->nb * 128, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_reconstruct(gz_ctx* c, uint8_t* srgb, float* linear) {
+  if (!c) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  TRY(stage_reconstruct(c, c->d_cand, linear ? c->lin[0] : nullptr, srgb ? c->d_srgb_out : nullptr));
+  if (srgb) HIPCHK(c, hipMemcpyAsync(srgb, c->d_srgb_out, (size_t)3 * c->w * c->h, hipMemcpyDeviceToHost, c->stream));
+  if (linear) for (int i = 0; i < 3; ++i) TRY(download_plane(c, c->lin[i], linear + (size_t)i * c->w * c->h));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
+  if (!c || !distance) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  TRY(enqueue_compare(c, true));
+  unsigned bits = 0;
+  HIPCHK(c, hipMemcpyAsync(&bits, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
+  if (distmap) TRY(download_plane(c, c->distmap, distmap));
+  c->h_block_max.resize(c->nb);
+  HIPCHK(c, hipMemcpyAsync(c->h_block_max.data(), c->d_block_max, sizeof(float) * c->nb,
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(&c->last_distance, &bits, 4);
+  *distance = c->last_distance;
+  if (block_max) memcpy(block_max, c->h_block_max.data(), sizeof(float) * c->nb);
+  c->have_distmap = true;
+  return GZ_OK;
+}
+
+int gz_compare_enqueue(gz_ctx* c, int iters) {
+  if (!c || iters < 0) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  for (int i = 0; i < iters; ++i) TRY(enqueue_compare(c, true));
+  return GZ_OK;
+}
+
+int gz_last_distance(gz_ctx* c, float* distance) {
+  if (!c || !distance) return GZ_E_ARG;
+  unsigned bits = 0;
+  HIPCHK(c, hipMemcpyAsync(&bits, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(distance, &bits, 4);
+  return GZ_OK;
+}
+
+int gz_time_compare(gz_ctx* c, int iters, float* total_ms) {
+  if (!c || iters <= 0 || !total_ms) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < iters; ++i) TRY(enqueue_compare(c, true));
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  HIPCHK(c, hipEventElapsedTime(total_ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return GZ_OK;
+}
+
+// ComputeBlockErrorAdjustmentWeights, butteraugli_comparator.cc:521-557 (the per-block
+// maxima of :505-520 come from k_block_max).  O(nb) host work on nb floats.
+int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target_mul,
+                     int use_distmap, float* block_weight) {
+  if (!c || !block_weight || max_block_dist < 0) return GZ_E_ARG;
+  if (use_distmap && !c->have_distmap) { c->err = "no distance map yet"; return GZ_E_STATE; }
+  const int bw = c->bw, bh = c->bh;
+  std::vector<float> zero;
+  const float* bmax = c->h_block_max.data();
+  if (!use_distmap) { zero.assign(c->nb, 0.0f); bmax = zero.data(); }
+  const double target_distance = c->target * target_mul;
+  for (int by = 0; by < bh; ++by) {
+    for (int bx = 0; bx < bw; ++bx) {
+      const int bix = by * bw + bx;
+      float local = static_cast<float>(target_distance);
+      const int x0 = std::max(0, bx - max_block_dist), y0 = std::max(0, by - max_block_dist);
+      const int x1 = std::min(bw, bx + 1 + max_block_dist);
+      const int y1 = std::min(bh, by + 1 + max_block_dist);
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) local = std::max(local, bmax[y * bw + x]);
+      if (direction > 0) {
+        if (bmax[bix] <= target_distance && local <= 1.1 * target_distance) block_weight[bix] = 1.0;
+      } else {
+        const double kLocalMaxWeight = 0.5;
+        if (bmax[bix] <= (1 - kLocalMaxWeight) * target_distance + kLocalMaxWeight * local) continue;
+        for (int y = y0; y < y1; ++y)
+          for (int x = x0; x < x1; ++x) {
+            const int d = std::max(abs(y - by), abs(x - bx));
+            const int ix = y * bw + x;
+            block_weight[ix] = std::max<float>(block_weight[ix], 1.0f / (d + 1.0f));
+          }
+      }
+    }
+  }
+  return GZ_OK;
+}
+
+// ------------------------------------------------------------------- stage probes -----
+int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, float* out) {
+  if (!c || !in || !out) return GZ_E_ARG;
+  BlurCfg cfg;
+  TRY(setup_blur_cfg(c, &cfg, sigma, border_ratio));
+  float* src = c->xyb[0];
+  TRY(upload_planes(c, in, &src, 1));
+  SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
+  s.s[0].p = src; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+  PostStore<1> post; post.out[0] = c->xyb[1];
+  int rc = GZ_OK;
+#define GZ_BLUR_CASE(R)                                                     \
+  case R:                                                                   \
+    rc = blur_h<R, SrcPlain, 1>(c, s, t, cfg);                              \
+    if (rc == GZ_OK) rc = blur_v<R, 1, PostStore<1>>(c, ct, post, cfg);     \
+    break;
+  switch (cfg.r) {
+    GZ_BLUR_CASE(2) GZ_BLUR_CASE(3) GZ_BLUR_CASE(4) GZ_BLUR_CASE(5) GZ_BLUR_CASE(8)
+    GZ_BLUR_CASE(16) GZ_BLUR_CASE(20) GZ_BLUR_CASE(23)
+    default: c->err = "unsupported blur radius"; rc = GZ_E_ARG;
+  }
+#undef GZ_BLUR_CASE
+  if (rc == GZ_OK) rc = download_plane(c, c->xyb[1], out);
+  hipStreamSynchronize(c->stream);
+  hipFree(cfg.d_scale);
+  return rc;
+}
+
+int gz_probe_opsin(gz_ctx* c, const float* rgb3, float* xyb3) {
+  if (!c || !rgb3 || !xyb3) return GZ_E_ARG;
+  TRY(upload_planes(c, rgb3, c->lin, 3));
+  TRY(stage_opsin(c));
+  for (int i = 0; i < 3; ++i) TRY(download_plane(c, c->xyb[i], xyb3 + (size_t)i * c->w * c->h));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_probe_separate_frequencies(gz_ctx* c, const float* xyb3, float* out10) {
+  if (!c || !xyb3 || !out10) return GZ_E_ARG;
+  TRY(ensure_pip(c));
+  TRY(upload_planes(c, xyb3, c->xyb, 3));
+  TRY(stage_separate(c, &c->pip));
+  const size_t n = (size_t)c->w * c->h;
+  for (int i = 0; i < 3; ++i) TRY(download_plane(c, c->pip.lfv[i], out10 + i * n));
+  for (int i = 0; i < 2; ++i) TRY(download_plane(c, c->pip.mf[i], out10 + (3 + i) * n));
+  memset(out10 + 5 * n, 0, sizeof(float) * n);   // mf[2]: dead in the reference, not computed
+  for (int i = 0; i < 2; ++i) TRY(download_plane(c, c->pip.hf[i], out10 + (6 + i) * n));
+  for (int i = 0; i < 2; ++i) TRY(download_plane(c, c->pip.uhf[i], out10 + (8 + i) * n));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_probe_diffmap(gz_ctx* c, const float* rgb0, const float* rgb1, float* diffmap,
+                     float* score) {
+  if (!c || !rgb0 || !rgb1) return GZ_E_ARG;
+  TRY(ensure_pip(c));
+  TRY(upload_planes(c, rgb0, c->lin, 3));
+  TRY(stage_opsin(c));
+  TRY(stage_separate(c, &c->pip));
+  TRY(upload_planes(c, rgb1, c->lin, 3));
+  TRY(stage_opsin(c));
+  TRY(stage_separate(c, &c->pi1));
+  TRY(stage_diffmap(c, c->pip, c->pi1, false));
+  if (diffmap) TRY(download_plane(c, c->distmap, diffmap));
+  unsigned bits = 0;
+  HIPCHK(c, hipMemcpyAsync(&bits, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (score) memcpy(score, &bits, 4);
+  return GZ_OK;
+}
+
+int gz_probe_mask(gz_ctx* c, const float* xyb0, const float* xyb1, float* mask3,
+                  float* mask_dc3) {
+  if (!c || !xyb0 || !xyb1 || !mask3) return GZ_E_ARG;
+  TRY(ensure_pip(c));
+  // Mask(xyb0, xyb1) reads planes 0 and 1 of each image unchanged (butteraugli.cc:1765,1777)
+  float* a[2] = {c->pip.hf[0], c->pip.hf[1]};
+  float* b[2] = {c->pi1.hf[0], c->pi1.hf[1]};
+  TRY(upload_planes(c, xyb0, a, 2));
+  TRY(upload_planes(c, xyb1, b, 2));
+  MaskPrePack pk;
+  for (int i = 0; i < 2; ++i) {
+    pk.in0[i] = {nullptr, a[i], 0.0, 1.0, 1};
+    pk.in1[i] = {nullptr, b[i], 0.0, 1.0, 1};
+  }
+  pk.out[0] = c->diffx;
+  pk.out[1] = c->diffy;
+  TRY(stage_mask_blurs(c, pk));
+  CombineArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.mask_x_blur = c->mxb; ca.mask_y_blur1 = c->myb1; ca.mask_y_blur2 = c->myb2;
+  ca.luts = c->d_mask_luts;
+  ca.out = nullptr;
+  for (int i = 0; i < 3; ++i) { ca.mask_out[i] = c->mask_out[i]; ca.mask_dc_out[i] = c->mask_dc_out[i]; }
+  dim3 grid(gz_div_up(c->w, 256), c->h);
+  GZ_LAUNCH(k_combine, grid, dim3(256), c->stream, ca, c->w, c->h, c->pitch);
+  KCHK(c);
+  const size_t n = (size_t)c->w * c->h;
+  for (int i = 0; i < 3; ++i) {
+    TRY(download_plane(c, c->mask_out[i], mask3 + i * n));
+    if (mask_dc3) TRY(download_plane(c, c->mask_dc_out[i], mask_dc3 + i * n));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+static int probe_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev ||
+      hipSetDevice(device) != hipSuccess)
+    return GZ_E_NO_DEVICE;
+  return GZ_OK;
+}
+
+int gz_probe_idct_blocks(int device, const int16_t* blocks, int n, uint8_t* out) {
+  if (!blocks || !out || n <= 0) return GZ_E_ARG;
+  if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
+  int16_t* d_in = nullptr; uint8_t* d_out = nullptr;
+  if (hipMalloc((void**)&d_in, (size_t)n * 128) != hipSuccess) return GZ_E_HIP;
+  if (hipMalloc((void**)&d_out, (size_t)n * 64) != hipSuccess) { hipFree(d_in); return GZ_E_HIP; }
+  hipMemcpy(d_in, blocks, (size_t)n * 128, hipMemcpyHostToDevice);
+  GZ_LAUNCH(k_idct_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0, d_in, n, d_out);
+  int rc = hipGetLastError() == hipSuccess ? GZ_OK : GZ_E_HIP;
+  if (hipMemcpy(out, d_out, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
+  hipFree(d_in); hipFree(d_out);
+  return rc;
+}
+
+int gz_probe_fdct_blocks(int device, int16_t* blocks, int n) {
+  if (!blocks || n <= 0) return GZ_E_ARG;
+  if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
+  int16_t* d = nullptr;
+  if (hipMalloc((void**)&d, (size_t)n * 128) != hipSuccess) return GZ_E_HIP;
+  hipMemcpy(d, blocks, (size_t)n * 128, hipMemcpyHostToDevice);
+  GZ_LAUNCH(k_fdct_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0, d, n);
+  int rc = hipGetLastError() == hipSuccess ? GZ_OK : GZ_E_HIP;
+  if (hipMemcpy(blocks, d, (size_t)n * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
+  hipFree(d);
+  return rc;
+}
+
+int gz_probe_arith(int device, int op, const void* a, const void* b, const void* c,
+                   void* out, int n) {
+  if (!a || !out || n <= 0 || op < 0 || op > 6) return GZ_E_ARG;
+  if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
+  const size_t es = (op == 2 || op == 3 || op == 5 || op == 6) ? 8 : 4;
+  const size_t os = (op == 2 || op == 3 || op == 5) ? 8 : 4;
+  void *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+  hipMalloc(&da, es * n); hipMalloc(&db, es * n); hipMalloc(&dc, es * n); hipMalloc(&dout, os * n);
+  hipMemcpy(da, a, es * n, hipMemcpyHostToDevice);
+  if (b) hipMemcpy(db, b, es * n, hipMemcpyHostToDevice);
+  if (c) hipMemcpy(dc, c, es * n, hipMemcpyHostToDevice);
+  GZ_LAUNCH(k_probe_arith, dim3(gz_div_up(n, 256)), dim3(256), (hipStream_t)0, op,
+            (const void*)da, (const void*)db, (const void*)dc, dout, n);
+  int rc = hipGetLastError() == hipSuccess ? GZ_OK : GZ_E_HIP;
+  if (hipMemcpy(out, dout, os * n, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
+  hipFree(da); hipFree(db); hipFree(dc); hipFree(dout);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+// Block kernels: one 64-lane wavefront per 8x8 block, lane = pixel / coefficient index,
+// coefficients staged in LDS between the column and the row pass.
+//
+//   k_encode_rgb   RGB -> YCbCr -> integer FDCT -> /16        (jpeg_data_encoder.cc:40-117,
+//                                                              fdct.cc:29-240)
+//   k_quantize     Quantize() over all coefficients           (quantize.h:24-29)
+//   k_reconstruct  integer IDCT -> YCbCr->RGB -> sRGB LUT     (idct.cc:29-161,
+//                                                              color_transform.h:211-219,
+//                                                              output_image.cc:411-440)
+// All integer: results must be bit-identical to the reference.
+#pragma once
+#include "gz_common.h"
+
+namespace gz {
+
+#ifdef GZ_EMU
+#define GZ_CONST static const
+#else
+#define GZ_CONST __constant__ const
+#endif
+
+// idct.cc:29-38: kIDCTMatrix[8*x+u]; rows 4..7 are the (-1)^u mirror of rows 3..0, which
+// is what Compute1dIDCT's butterflies (:41-137) evaluate.
+GZ_CONST int kIdctM[64] = {
+  8192,  11363,  10703,   9633,   8192,   6437,   4433,   2260,
+  8192,   9633,   4433,  -2259,  -8192, -11362, -10704,  -6436,
+  8192,   6437,  -4433, -11362,  -8192,   2261,  10704,   9633,
+  8192,   2260, -10703,  -6436,   8192,   9633,  -4433, -11363,
+  8192,  -2260, -10703,   6436,   8192,  -9633,  -4433,  11363,
+  8192,  -6437,  -4433,  11362,  -8192,  -2261,  10704,  -9633,
+  8192,  -9633,   4433,   2259,  -8192,  11362, -10704,   6436,
+  8192, -11363,  10703,  -9633,   8192,  -6437,   4433,  -2260,
+};
+
+// fdct.cc:29-36, indexed by row class {0/4, 1/7, 2/6, 3/5}.
+GZ_CONST short kFdctRowTab[4][8] = {
+  {22725, 21407, 19266, 16384, 12873,  8867, 4520, 0},
+  {31521, 29692, 26722, 22725, 17855, 12299, 6270, 0},
+  {29692, 27969, 25172, 21407, 16819, 11585, 5906, 0},
+  {26722, 25172, 22654, 19266, 15137, 10426, 5315, 0},
+};
+
+constexpr int kBlocksPerWG = 4;   // 4 waves = 256 threads per workgroup
+
+GZ_DEVFN int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// --------------------------------------------------------------------- reconstruct --
+// coeffs: [3][nb][64] int16.  Outputs (either may be null): lin = 3 float planes with
+// row pitch `pitch`, plane stride `pstride`; srgb = packed u8.
+__global__ __launch_bounds__(256) void k_reconstruct(
+    const int16_t* __restrict__ coeffs, int w, int h, int bw, int nb, int pitch,
+    size_t pstride, const float* __restrict__ srgb_lut, float* __restrict__ lin,
+    uint8_t* __restrict__ srgb) {
+  __shared__ int s_in[kBlocksPerWG][64];
+  __shared__ int s_col[kBlocksPerWG][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * kBlocksPerWG + wave;
+  const bool live = blk < nb;
+  const int iy = lane >> 3, ix = lane & 7;
+  int px[3];
+  for (int c = 0; c < 3; ++c) {
+    s_in[wave][lane] = live ? (int)coeffs[((size_t)c * nb + blk) * 64 + lane] : 0;
+    __syncthreads();
+    // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
+    int acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[wave][8 * u + ix];
+    s_col[wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+    __syncthreads();
+    // row pass (:150-160): out = clamp((sum + (257 << 17)) >> 18)
+    acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[wave][8 * iy + u];
+    px[c] = clamp255((acc + (257 << 17)) >> 18);
+  }
+  if (!live) return;
+  const int x = 8 * (blk % bw) + ix, y = 8 * (blk / bw) + iy;
+  if (x >= w || y >= h) return;
+  // libjpeg YCbCr->RGB (color_transform.h; tables == these formulas, tools/gen_tables.py)
+  const int yy = px[0], cb = px[1] - 128, cr = px[2] - 128, half = 1 << 15;
+  const int r = clamp255(yy + ((91881 * cr + half) >> 16));
+  const int g = clamp255(yy + ((-46802 * cr + (-22554 * cb + half)) >> 16));
+  const int b = clamp255(yy + ((116130 * cb + half) >> 16));
+  if (lin) {
+    const size_t o = (size_t)y * pitch + x;
+    lin[o] = srgb_lut[r];
+    lin[pstride + o] = srgb_lut[g];
+    lin[2 * pstride + o] = srgb_lut[b];
+  }
+  if (srgb) {
+    uint8_t* p = srgb + ((size_t)y * w + x) * 3;
+    p[0] = (uint8_t)r;
+    p[1] = (uint8_t)g;
+    p[2] = (uint8_t)b;
+  }
+}
+
+// Bare-block IDCT probe (gz_probe_idct_blocks).
+__global__ __launch_bounds__(256) void k_idct_blocks(const int16_t* __restrict__ blocks,
+                                                     int n, uint8_t* __restrict__ out) {
+  __shared__ int s_in[kBlocksPerWG][64];
+  __shared__ int s_col[kBlocksPerWG][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * kBlocksPerWG + wave;
+  const bool live = blk < n;
+  const int iy = lane >> 3, ix = lane & 7;
+  s_in[wave][lane] = live ? (int)blocks[(size_t)blk * 64 + lane] : 0;
+  __syncthreads();
+  int acc = 0;
+  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[wave][8 * u + ix];
+  s_col[wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  __syncthreads();
+  acc = 0;
+  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[wave][8 * iy + u];
+  if (live) out[(size_t)blk * 64 + lane] = (uint8_t)clamp255((acc + (257 << 17)) >> 18);
+}
+
+// ------------------------------------------------------------------------ quantize --
+// quantize.h:24-29 applied to every coefficient of the original; q = int[3][64].
+__global__ __launch_bounds__(256) void k_quantize(const int16_t* __restrict__ orig,
+                                                  int16_t* __restrict__ cand, int nb,
+                                                  const int* __restrict__ q) {
+  const size_t total = (size_t)3 * nb * 64;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / ((size_t)nb * 64));
+    const int quant = q[c * 64 + (int)(i & 63)];
+    const int raw = orig[i];
+    const int r = raw % quant;
+    const int delta = 2 * r > quant ? quant - r : ((-2) * r > quant ? -quant - r : -r);
+    cand[i] = (int16_t)(raw + (int)(short)delta);
+  }
+}
+
+// -------------------------------------------------------------------------- encode --
+GZ_DEVFN int mulhi16(int a, int b) { return (a * b) >> 16; }   // MULT, fdct.cc:150
+
+// COLUMN_DCT8 (fdct.cc:68-145) on one column of an LDS-resident block (stride 8).
+GZ_DEVFN void fdct_column(short* col) {
+  const int i0 = col[0], i1 = col[8], i2 = col[16], i3 = col[24];
+  const int i4 = col[32], i5 = col[40], i6 = col[48], i7 = col[56];
+  int d07 = i0 - i7, s07 = i0 + i7;
+  int d25 = i2 - i5, s25 = i2 + i5;
+  int d34 = i3 - i4, s34 = i3 + i4;
+  int d16 = i1 - i6, s16 = i1 + i6;
+  int e0 = s07 - s34, e1 = s07 + s34;
+  int e2 = s16 - s25, e3 = s16 + s25;
+  e1 *= 8;
+  e3 *= 8;
+  col[0] = (short)(e1 + e3);
+  col[32] = (short)(e1 - e3);
+  e0 *= 8;
+  e2 *= 8;
+  d34 *= 8;
+  d07 *= 8;
+  const int kTan1 = 13036, kTan2 = 27146, kTan3m1 = -21746, k2Sqrt2 = 23170;
+  col[16] = (short)(mulhi16(kTan2, e2) + e0);
+  col[48] = (short)(mulhi16(kTan2, e0) - e2);
+  d25 *= 16;
+  d16 *= 16;
+  const int p = mulhi16(d16 + d25, k2Sqrt2);
+  const int q = mulhi16(d16 - d25, k2Sqrt2);
+  int m3 = d34 - q, m1 = d34 + q;
+  const int m0 = d07 - p, m2 = d07 + p;
+  const int m7 = m3, m6 = m1;
+  m3 = mulhi16(m3, kTan3m1) + m7 + 1;
+  m1 = mulhi16(m1, kTan1) + m2 + 1;
+  const int m4 = mulhi16(kTan3m1, m0) + m0;
+  const int m5 = mulhi16(kTan1, m2);
+  col[8] = (short)m1;
+  col[24] = (short)(m0 - m3);
+  col[40] = (short)(m7 + m4);
+  col[56] = (short)(m5 - m6);
+}
+
+// RowDct (fdct.cc:173-208) on one row.
+GZ_DEVFN void fdct_row(short* in, const short* t) {
+  const int a0 = in[0] + in[7], b0 = in[0] - in[7];
+  const int a1 = in[1] + in[6], b1 = in[1] - in[6];
+  const int a2 = in[2] + in[5], b2 = in[2] - in[5];
+  const int a3 = in[3] + in[4], b3 = in[3] - in[4];
+  const int C1 = t[0], C2 = t[1], C3 = t[2], C4 = t[3], C5 = t[4], C6 = t[5], C7 = t[6];
+  const int c0 = a0 + a3, c1 = a0 - a3, c2 = a1 + a2, c3 = a1 - a2;
+  in[0] = (short)((C4 * (c0 + c2)) >> 16);
+  in[4] = (short)((C4 * (c0 - c2)) >> 16);
+  in[2] = (short)((C2 * c1 + C6 * c3) >> 16);
+  in[6] = (short)((C6 * c1 - C2 * c3) >> 16);
+  in[1] = (short)((C1 * b0 + C3 * b1 + C5 * b2 + C7 * b3) >> 16);
+  in[3] = (short)((C3 * b0 - C7 * b1 - C1 * b2 - C5 * b3) >> 16);
+  in[5] = (short)((C5 * b0 - C1 * b1 + C7 * b2 + C3 * b3) >> 16);
+  in[7] = (short)((C7 * b0 - C5 * b1 + C3 * b2 - C1 * b3) >> 16);
+}
+
+GZ_DEVFN int fdct_row_class(int r) { return r == 0 || r == 4 ? 0 : (r == 1 || r == 7 ? 1 : (r == 2 || r == 6 ? 2 : 3)); }
+
+// EncodeRGBToJpeg with all-ones quant (jpeg_data_encoder.cc:66-117).
+__global__ __launch_bounds__(256) void k_encode_rgb(const uint8_t* __restrict__ rgb, int w,
+                                                    int h, int bw, int nb,
+                                                    int16_t* __restrict__ coeffs) {
+  __shared__ short s_blk[kBlocksPerWG][3][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * kBlocksPerWG + wave;
+  const bool live = blk < nb;
+  if (live) {
+    const int iy = lane >> 3, ix = lane & 7;
+    int y = 8 * (blk / bw) + iy, x = 8 * (blk % bw) + ix;
+    y = y < h - 1 ? y : h - 1;
+    x = x < w - 1 ? x : w - 1;
+    const uint8_t* p = rgb + ((size_t)y * w + x) * 3;
+    const int r = p[0], g = p[1], b = p[2], HALF = 1 << 15;
+    s_blk[wave][0][lane] = (short)((19595 * r + 38469 * g + 7471 * b - (128 << 16) + HALF) >> 16);
+    s_blk[wave][1][lane] = (short)((-11059 * r - 21709 * g + 32768 * b + HALF - 1) >> 16);
+    s_blk[wave][2][lane] = (short)((32768 * r - 27439 * g - 5329 * b + HALF - 1) >> 16);
+  }
+  __syncthreads();
+  if (live && lane < 24) fdct_column(&s_blk[wave][lane >> 3][lane & 7]);
+  __syncthreads();
+  if (live && lane < 24)
+    fdct_row(&s_blk[wave][lane >> 3][8 * (lane & 7)], kFdctRowTab[fdct_row_class(lane & 7)]);
+  __syncthreads();
+  if (live) {
+    for (int c = 0; c < 3; ++c) {
+      const int v = s_blk[wave][c][lane];
+      coeffs[((size_t)c * nb + blk) * 64 + lane] = (int16_t)((v * 65537 + 0x80000) >> 20);
+    }
+  }
+}
+
+// Bare-block FDCT probe.
+__global__ __launch_bounds__(256) void k_fdct_blocks(int16_t* __restrict__ blocks, int n) {
+  __shared__ short s_blk[kBlocksPerWG][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * kBlocksPerWG + wave;
+  const bool live = blk < n;
+  if (live) s_blk[wave][lane] = blocks[(size_t)blk * 64 + lane];
+  __syncthreads();
+  if (live && lane < 8) fdct_column(&s_blk[wave][lane]);
+  __syncthreads();
+  if (live && lane < 8) fdct_row(&s_blk[wave][8 * lane], kFdctRowTab[fdct_row_class(lane)]);
+  __syncthreads();
+  if (live) blocks[(size_t)blk * 64 + lane] = s_blk[wave][lane];
+}
+
+// sRGB u8 packed -> 3 linear float planes (LinearRgb, butteraugli_comparator.cc:33-47).
+__global__ __launch_bounds__(256) void k_linear_from_rgb8(const uint8_t* __restrict__ rgb,
+                                                          int w, int h, int pitch,
+                                                          size_t pstride,
+                                                          const float* __restrict__ lut,
+                                                          float* __restrict__ lin) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const uint8_t* p = rgb + ((size_t)y * w + x) * 3;
+  const size_t o = (size_t)y * pitch + x;
+  lin[o] = lut[p[0]];
+  lin[pstride + o] = lut[p[1]];
+  lin[2 * pstride + o] = lut[p[2]];
+}
+
+}  // namespace gz

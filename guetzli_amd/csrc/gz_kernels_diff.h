@@ -1,0 +1,285 @@
+// Difference-side kernels of ButteraugliComparator::DiffmapPsychoImage
+// (butteraugli.cc:817-908): Malta line filters, the L2 / noise terms, the visual mask and
+// the channel combination.
+#pragma once
+#include "gz_common.h"
+#include "gz_kernels_block.h"   // GZ_CONST
+#include "gz_math.h"
+#define GZ_TABLE GZ_CONST
+#include "tables_generated.h"
+
+namespace gz {
+
+// ------------------------------------------------------------------ DiffPrecompute --
+// Input of the mask blurs.  MaskPsychoImage (butteraugli.cc:753-782) feeds
+// a*uhf + b*hf (X: a = 0) of both images; StartBlockComparisons
+// (butteraugli_comparator.cc:415-421) feeds the raw XYB planes of the original twice.
+struct MaskIn {
+  const float* uhf;   // may be null when a == 0 (0*uhf + b*hf == b*hf up to the sign of 0,
+                      // which the fabs() differences below cannot see)
+  const float* hf;
+  double a, b;
+  int plain;          // 1: value = hf[idx] unchanged
+  GZ_DEVFN float operator()(size_t idx) const {
+    if (plain) return hf[idx];
+    if (uhf == nullptr) return (float)(b * (double)hf[idx]);
+    return (float)(a * (double)uhf[idx] + b * (double)hf[idx]);
+  }
+};
+struct MaskPrePack {
+  MaskIn in0[2];   // [X, Y] of image 0
+  MaskIn in1[2];   // [X, Y] of image 1
+  float* out[2];
+};
+
+// grid = (ceil(w/256), h, 2)
+__global__ __launch_bounds__(256) void k_mask_pre(MaskPrePack pk, int w, int h, int pitch) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
+  if (x >= w || y >= h) return;
+  // mirrored neighbour at the last column / row (butteraugli.cc:1706-1725)
+  const int x2 = x + 1 < w ? x + 1 : (x > 0 ? x - 1 : x);
+  const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
+  const size_t i = (size_t)y * pitch + x, ir = (size_t)y * pitch + x2,
+               id = (size_t)y2 * pitch + x;
+  const MaskIn a = pk.in0[c], b = pk.in1[c];
+  pk.out[c][i] = diff_precompute_px(a(i), a(ir), a(id), b(i), b(ir), b(id));
+}
+
+// ---------------------------------------------------------------------------- Malta --
+// One workgroup = 64x32 output pixels.  Per pass the per-pixel "diffs" value
+// (MaltaDiffMapImpl, butteraugli.cc:1468-1529) is computed for the tile plus a 4-pixel
+// halo straight into LDS (0 outside the image, PaddedMaltaUnit :1439-1457), then every
+// thread sums the 16 oriented line filters (MaltaUnit :914-1424, taps and order from
+// tables_generated.h) for its 8 pixels.  A channel's passes accumulate in registers in the
+// reference's order, followed by that channel's pointwise terms.
+constexpr int MW = 64;
+constexpr int MH = 32;
+constexpr int MPT = MH / 4;
+
+struct MaltaPass {
+  const float* p0;
+  const float* p1;
+  MaltaNorm nm;
+  int lf;   // 1: MaltaTagLF (5-tap), 0: MaltaTag (up to 9-tap)
+};
+
+template <bool LF>
+GZ_DEVFN float malta_unit(const float (*t)[MW + 8], int ly, int lx) {
+  // (ly, lx) are tile coordinates of the centre inside the haloed tile.
+  float ret = 0.0f;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float sum = 0.0f;
+    if (LF) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const float v = t[ly + kMaltaLF[o][k][0]][lx + kMaltaLF[o][k][1]];
+        sum = k == 0 ? v : sum + v;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        if (k < kMaltaHFCount[o]) {
+          const float v = t[ly + kMaltaHF[o][k][0]][lx + kMaltaHF[o][k][1]];
+          sum = k == 0 ? v : sum + v;
+        }
+      }
+    }
+    ret += sum * sum;
+  }
+  return ret;
+}
+
+struct MaltaTail {
+  // Y channel only (null for X): SameNoiseLevels second half (butteraugli.cc:644-651) and
+  // L2DiffAsymmetric on HF-Y (:672-714).
+  const float* sn_blur;
+  const float* hf0;
+  const float* hf1;
+  double w_sn, w_0gt1, w_0lt1;
+};
+
+template <int NPASS>
+struct MaltaArgs {
+  MaltaPass pass[NPASS];
+  MaltaTail tail;
+  float* out;
+};
+
+// grid = (ceil(w/MW), ceil(h/MH))
+template <int NPASS>
+__global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a, int w, int h, int pitch) {
+  __shared__ float tile[MH + 8][MW + 8];
+  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
+  float acc[MPT];
+#pragma unroll
+  for (int i = 0; i < MPT; ++i) acc[i] = 0.0f;
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const MaltaPass P = a.pass[ps];
+    if (ps > 0) __syncthreads();
+    for (int i = threadIdx.x; i < (MH + 8) * (MW + 8); i += 256) {
+      const int ry = i / (MW + 8), rx = i - ry * (MW + 8);
+      const int x = x0 - 4 + rx, y = y0 - 4 + ry;
+      float v = 0.0f;
+      if (x >= 0 && x < w && y >= 0 && y < h) {
+        const size_t idx = (size_t)y * pitch + x;
+        v = malta_diff(P.p0[idx], P.p1[idx], P.nm);
+      }
+      tile[ry][rx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MPT; ++i) {
+      const int ly = tg * MPT + i;
+      const float r = P.lf ? malta_unit<true>(tile, ly + 4, tx + 4)
+                           : malta_unit<false>(tile, ly + 4, tx + 4);
+      acc[i] += r;
+    }
+  }
+  const int x = x0 + tx;
+  if (x >= w) return;
+#pragma unroll
+  for (int i = 0; i < MPT; ++i) {
+    const int y = y0 + tg * MPT + i;
+    if (y >= h) break;
+    const size_t idx = (size_t)y * pitch + x;
+    float v = acc[i];
+    if (a.tail.sn_blur) {
+      const double d = (double)a.tail.sn_blur[idx];
+      v = (float)((double)v + (a.tail.w_sn * d) * d);
+      v = l2diff_asym_acc(v, a.tail.hf0[idx], a.tail.hf1[idx], a.tail.w_0gt1,
+                          a.tail.w_0lt1);
+    }
+    a.out[idx] = v;
+  }
+}
+
+// -------------------------------------------------- mask LUTs + combine + sqrt stage --
+// Mask second half (butteraugli.cc:1780-1816), L2Diff on the LF planes (:899),
+// CombineChannels (:1597-1621) and the first half of CalculateDiffmap (:718-735).
+struct CombineArgs {
+  const float* mask_x_blur;   // blur(diffX, 9.24)
+  const float* mask_y_blur1;  // blur(diffY, 2.377)
+  const float* mask_y_blur2;  // blur(diffY, 9.04)
+  const float* ac0;           // block_diff_ac[0]
+  const float* ac1;           // block_diff_ac[1]
+  const float* lf0_x;         // pi0.lf[0] / pi1.lf[0] (vals space)
+  const float* lf1_x;
+  const float* lf0_b;         // pi0.lf[2] / pi1.lf[2]
+  const float* lf1_b;
+  const double* luts;         // [4][512]: MaskX, MaskY, MaskDcX, MaskDcY
+  float* out;                 // sqrt-stage diffmap (input of the final blur)
+  float* mask_out[3];         // optional: mask planes (block search / probes), may be null
+  float* mask_dc_out[3];      // optional
+};
+
+GZ_DEVFN void mask_p0p1(float bx, float by1, float by2, double* p0, double* p1) {
+  const double muls0 = 0.207017089891, muls1 = 0.267138152891;
+  const double normalizer = 1.0 / (muls0 + muls1);
+  const float my = (float)(normalizer * (muls0 * (double)by1 + muls1 * (double)by2));
+  const double s0 = (double)bx, s1 = (double)my;
+  const double mul0 = 16.6963293877, mul1 = 2.1364621982;
+  const double w00 = 36.4671237619, w11 = 2.1887170895, p1_to_p0 = 0.0513061271723;
+  *p1 = (mul1 * w11) * s1;
+  *p0 = (mul0 * w00) * s0 + p1_to_p0 * (*p1);
+}
+
+__global__ __launch_bounds__(256) void k_combine(CombineArgs a, int w, int h, int pitch) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const size_t i = (size_t)y * pitch + x;
+  double p0, p1;
+  mask_p0p1(a.mask_x_blur[i], a.mask_y_blur1[i], a.mask_y_blur2[i], &p0, &p1);
+  const double w_ytob_hf = 0.086624184478, w_ytob_lf = 21.6804277046;
+  const float m0 = (float)interp_lut512(a.luts, p0);
+  const double my = interp_lut512(a.luts + 512, p1);
+  const float m1 = (float)my;
+  const float mdc0 = (float)interp_lut512(a.luts + 1024, p0);
+  const double mdcy = interp_lut512(a.luts + 1536, p1);
+  const float mdc1 = (float)mdcy;
+  const float mdc2 = (float)(w_ytob_lf * mdcy);
+  if (a.mask_out[0]) {
+    a.mask_out[0][i] = m0;
+    a.mask_out[1][i] = m1;
+    a.mask_out[2][i] = (float)(w_ytob_hf * my);
+  }
+  if (a.mask_dc_out[0]) {
+    a.mask_dc_out[0][i] = mdc0;
+    a.mask_dc_out[1][i] = mdc1;
+    a.mask_dc_out[2][i] = mdc2;
+  }
+  if (a.out == nullptr) return;
+  // block_diff_dc: only X (wmul[6]) and B (wmul[8]) are non-zero (butteraugli.cc:873-883)
+  const float dc0 = l2diff_acc(0.0f, a.lf0_x[i], a.lf1_x[i], 1.01370836411);
+  const float dc1 = 0.0f;
+  const float dc2 = l2diff_acc(0.0f, a.lf0_b[i], a.lf1_b[i], 1.74566011615);
+  const float ac0 = a.ac0[i], ac1 = a.ac1[i], ac2 = 0.0f;
+  const float m2 = (float)(w_ytob_hf * my);
+  // CombineChannels: DotProduct(diff_dc, dc_mask) + DotProduct(diff_ac, mask)
+  const float sdc = (dc0 * mdc0 + dc1 * mdc1) + dc2 * mdc2;
+  const float sac = (ac0 * m0 + ac1 * m1) + ac2 * m2;
+  const float v = sdc + sac;
+  const float kInitialSlope = 100.0f;
+  a.out[i] = v < (1.0f / (kInitialSlope * kInitialSlope)) ? kInitialSlope * v : sqrtf(v);
+}
+
+// ------------------------------------------------------------- block max + image max --
+// One wave per 8x8 block (lane = pixel): per-block maximum of the distance map (first loop
+// of ComputeBlockErrorAdjustmentWeights, butteraugli_comparator.cc:505-520) and the
+// global maximum (ButteraugliScoreFromDiffmap, butteraugli.cc:1623-1633).  max is exact
+// and order-free; values are >= 0 so the float order equals the order of their bits.
+__global__ __launch_bounds__(256) void k_block_max(const float* __restrict__ dm, int w,
+                                                   int h, int pitch, int bw, int nb,
+                                                   float* __restrict__ block_max,
+                                                   unsigned* __restrict__ global_max_bits) {
+  __shared__ float s[256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * 4 + wave;
+  float v = 0.0f;
+  if (blk < nb) {
+    const int x = 8 * (blk % bw) + (lane & 7), y = 8 * (blk / bw) + (lane >> 3);
+    if (x < w && y < h) v = dm[(size_t)y * pitch + x];
+  }
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) {
+    if (lane < off) {
+      const float o = s[threadIdx.x + off];
+      if (o > s[threadIdx.x]) s[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (lane == 0 && blk < nb) {
+    const float m = s[threadIdx.x];
+    if (block_max) block_max[blk] = m;
+    atomicMax(global_max_bits, __float_as_uint(m));
+  }
+}
+
+// Pitched device plane -> packed (w-stride) plane, for host download; and back.
+__global__ __launch_bounds__(256) void k_copy_plane(const float* __restrict__ src,
+                                                    int src_pitch, float* __restrict__ dst,
+                                                    int dst_pitch, int w, int h) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < w && y < h) dst[(size_t)y * dst_pitch + x] = src[(size_t)y * src_pitch + x];
+}
+
+// Arithmetic self-check (gz_probe_arith).
+__global__ void k_probe_arith(int op, const void* a, const void* b, const void* c, void* out,
+                              int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (op) {
+    case 0: ((float*)out)[i] = ((const float*)a)[i] / ((const float*)b)[i]; break;
+    case 1: ((float*)out)[i] = sqrtf(((const float*)a)[i]); break;
+    case 2: ((double*)out)[i] = ((const double*)a)[i] / ((const double*)b)[i]; break;
+    case 3: ((double*)out)[i] = sqrt(((const double*)a)[i]); break;
+    case 4: ((float*)out)[i] = ((const float*)a)[i] * ((const float*)b)[i] + ((const float*)c)[i]; break;
+    case 5: ((double*)out)[i] = ((const double*)a)[i] * ((const double*)b)[i] + ((const double*)c)[i]; break;
+    case 6: ((float*)out)[i] = (float)((const double*)a)[i]; break;
+    default: break;
+  }
+}
+
+}  // namespace gz

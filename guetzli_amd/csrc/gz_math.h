@@ -1,0 +1,205 @@
+// Per-pixel arithmetic of the butteraugli chain, as device functions.
+//
+// Bit-exactness contract: the reference is x86-64 SSE2 code without FMA
+// and without fast-math, so every operation rounds once to its static C++ type.  This
+// file is compiled with -ffp-contract=off; every expression below keeps the reference's
+// operand types, promotions and association.  gfx950 provides correctly rounded
+// f32/f64 + - * / sqrt and conversions, and denormals are preserved (HIP default).
+// All transcendental work (exp for blur taps, pow for the sRGB LUT, the mask LUTs) is
+// done on the host and uploaded.
+#pragma once
+#include "gz_common.h"
+
+namespace gz {
+
+// ---- OpsinAbsorbance<float>, butteraugli.h:498-534 -------------------------------
+GZ_DEVFN void opsin_absorbance(float r, float g, float b, float* o0, float* o1,
+                               float* o2) {
+  const float m0 = (float)0.254462330846, m1 = (float)0.488238255095,
+              m2 = (float)0.0635278003854, m3 = (float)1.01681026909;
+  const float m4 = (float)0.195214015766, m5 = (float)0.568019861857,
+              m6 = (float)0.0860755536007, m7 = (float)1.1510118369;
+  const float m8 = (float)0.07374607900105684, m9 = (float)0.06142425304154509,
+              m10 = (float)0.24416850520714256, m11 = (float)1.20481945273;
+  *o0 = ((m0 * r + m1 * g) + m2 * b) + m3;
+  *o1 = ((m4 * r + m5 * g) + m6 * b) + m7;
+  *o2 = ((m8 * r + m9 * g) + m10 * b) + m11;
+}
+
+// ---- GammaPolynomial, butteraugli.h:548-615 (Clenshaw, degree 5/5, all double) ----
+GZ_DEVFN double clenshaw6(double x, double c0, double c1, double c2, double c3, double c4,
+                          double c5) {
+  double b1 = 0.0, b2 = 0.0, xb, t;
+  xb = x * b1; t = ((xb + xb) - b2) + c5; b2 = b1; b1 = t;
+  xb = x * b1; t = ((xb + xb) - b2) + c4; b2 = b1; b1 = t;
+  xb = x * b1; t = ((xb + xb) - b2) + c3; b2 = b1; b1 = t;
+  xb = x * b1; t = ((xb + xb) - b2) + c2; b2 = b1; b1 = t;
+  xb = x * b1; t = ((xb + xb) - b2) + c1; b2 = b1; b1 = t;
+  xb = x * b1;
+  return (xb - b2) + c0;
+}
+
+// Returns (double)(float)(yp/yq) exactly like RationalPolynomial::operator().
+GZ_DEVFN double gamma_poly(double v) {
+  const double kMin = 0.971783, kMax = 590.188894;
+  const double x01 = (v - kMin) / (kMax - kMin);
+  const double xc = 2.0 * x01 - 1.0;
+  const double yp = clenshaw6(xc, 98.7821300963361, 164.273222212631, 92.948112871376,
+                              33.8165311212688, 6.91626704983562, 0.556380877028234);
+  const double yq = clenshaw6(xc, 1, 1.64339473427892, 0.89392405219969,
+                              0.298947051776379, 0.0507146002577288,
+                              0.00226495093949756);
+  if (yq == 0.0) return 0.0;
+  return (double)(float)(yp / yq);
+}
+
+// One pixel of OpsinDynamicsImage (butteraugli.cc:337-363): blurred rgb -> sensitivity,
+// sharp rgb -> mixed * sensitivity -> XYB.
+GZ_DEVFN void opsin_pixel(float br, float bg, float bb, float r, float g, float b,
+                          float* x, float* y, float* z) {
+  float p0, p1, p2, c0, c1, c2;
+  opsin_absorbance(br, bg, bb, &p0, &p1, &p2);
+  const float s0 = (float)(gamma_poly((double)p0) / (double)p0);
+  const float s1 = (float)(gamma_poly((double)p1) / (double)p1);
+  const float s2 = (float)(gamma_poly((double)p2) / (double)p2);
+  opsin_absorbance(r, g, b, &c0, &c1, &c2);
+  c0 *= s0;
+  c1 *= s1;
+  c2 *= s2;
+  *x = c0 - c1;
+  *y = c0 + c1;
+  *z = c2;
+}
+
+// ---- SeparateFrequencies helpers, butteraugli.cc:369-487 -------------------------
+GZ_DEVFN float remove_range(float w, float x) {
+  return x > w ? x - w : x < -w ? x + w : 0.0f;
+}
+GZ_DEVFN float amplify_range(float w, float x) {
+  return x > w ? x + w : x < -w ? x - w : 2.0f * x;
+}
+GZ_DEVFN float maximum_clamp(float v, float maxval) {
+  const double kMul = 0.688059627878;
+  if (v >= maxval) {
+    v -= maxval;
+    v = (float)((double)v * kMul);
+    v += maxval;
+  } else if (v < -maxval) {
+    v += maxval;
+    v = (float)((double)v * kMul);
+    v -= maxval;
+  }
+  return v;
+}
+GZ_DEVFN float suppress_bright(float hf, float brightness, float mul, float reg) {
+  const float scaler = (mul * reg) / (reg + brightness);
+  return scaler * hf;
+}
+GZ_DEVFN float suppress_x_by_y(float xv, float yv) {
+  const double suppress = 2.96534974403, s = 0.745954517135;
+  const double xval = xv, yval = yv;
+  const double scaler = s + (suppress * (1.0 - s)) / (suppress + yval * yval);
+  return (float)(scaler * xval);
+}
+// XybLowFreqToVals<float>, butteraugli.cc:382-399
+GZ_DEVFN void lf_to_vals(float x, float y, float b_arg, float* vx, float* vy, float* vb) {
+  const float xmul = (float)5.57547552483, ymul = (float)1.20828034498,
+              bmul = (float)6.08319517575, y_to_b_mul = (float)-0.628811683685;
+  const float b = b_arg + y_to_b_mul * y;
+  *vb = b * bmul;
+  *vx = x * xmul;
+  *vy = y * ymul;
+}
+
+// ---- Malta per-pixel "diffs" value, butteraugli.cc:1473-1529 ---------------------
+struct MaltaNorm {
+  float norm2_0gt1, norm2_0lt1, norm1f;
+};
+GZ_DEVFN float malta_diff(float a, float b, const MaltaNorm nm) {
+  const float absval = (float)(0.5 * (double)fabsf(a) + 0.5 * (double)fabsf(b));
+  const float diff = a - b;
+  const float scaler = nm.norm2_0gt1 / (nm.norm1f + absval);
+  float d = scaler * diff;
+  const float scaler2 = nm.norm2_0lt1 / (nm.norm1f + absval);
+  const double fabs0 = (double)fabsf(a);
+  const double too_small = 0.55 * fabs0;
+  const double too_big = 1.05 * fabs0;
+  const double bd = (double)b;
+  double impact;
+  bool hit = true;
+  if (a < 0) {
+    if (bd > -too_small) impact = (double)scaler2 * (bd + too_small);
+    else if (bd < -too_big) impact = (double)scaler2 * (-bd - too_big);
+    else { hit = false; impact = 0.0; }
+  } else {
+    if (bd < too_small) impact = (double)scaler2 * (too_small - bd);
+    else if (bd > too_big) impact = (double)scaler2 * (bd - too_big);
+    else { hit = false; impact = 0.0; }
+  }
+  if (hit) d = diff < 0 ? (float)((double)d - impact) : (float)((double)d + impact);
+  return d;
+}
+
+// ---- L2Diff / L2DiffAsymmetric / SameNoiseLevels accumulations -------------------
+// butteraugli.cc:654-668
+GZ_DEVFN float l2diff_acc(float acc, float a, float b, double w) {
+  const double diff = (double)(a - b);
+  return (float)((double)acc + (w * diff) * diff);
+}
+// butteraugli.cc:672-714; w_0gt1 / w_0lt1 are already multiplied by 0.8.
+GZ_DEVFN float l2diff_asym_acc(float acc, float a, float b, double w_0gt1, double w_0lt1) {
+  const double diff = (double)(a - b);
+  acc = (float)((double)acc + (w_0gt1 * diff) * diff);
+  const double fabs0 = (double)fabsf(a);
+  const double too_small = 0.4 * fabs0;
+  const double too_big = 1.0 * fabs0;
+  const double bd = (double)b;
+  if (a < 0) {
+    if (bd > -too_small) {
+      const double v = bd + too_small;
+      acc = (float)((double)acc + (w_0lt1 * v) * v);
+    } else if (bd < -too_big) {
+      const double v = -bd - too_big;
+      acc = (float)((double)acc + (w_0lt1 * v) * v);
+    }
+  } else {
+    if (bd < too_small) {
+      const double v = too_small - bd;
+      acc = (float)((double)acc + (w_0lt1 * v) * v);
+    } else if (bd > too_big) {
+      const double v = bd - too_big;
+      acc = (float)((double)acc + (w_0lt1 * v) * v);
+    }
+  }
+  return acc;
+}
+// butteraugli.cc:631-641 (input of the SameNoiseLevels blur)
+GZ_DEVFN float same_noise_pre(float a, float b) {
+  const double maxclamp = 85.7047444518;
+  double v0 = (double)fabsf(a);
+  double v1 = (double)fabsf(b);
+  if (v0 > maxclamp) v0 = maxclamp;
+  if (v1 > maxclamp) v1 = maxclamp;
+  return (float)(v0 - v1);
+}
+
+// ---- Mask: DiffPrecompute core (butteraugli.cc:1723-1733) and LUT interpolation ---
+GZ_DEVFN float diff_precompute_px(float c0, float r0, float d0, float c1, float r1,
+                                  float d1) {
+  const double sup0 = (double)(fabsf(c0 - r0) + fabsf(c0 - d0));
+  const double sup1 = (double)(fabsf(c1 - r1) + fabsf(c1 - d1));
+  const double mul0 = 0.918416534734, cutoff = 55.0184555849;
+  float v = (float)(mul0 * (sup0 < sup1 ? sup0 : sup1));   // std::min(sup0, sup1)
+  if ((double)v >= cutoff) v = (float)cutoff;
+  return v;
+}
+// InterpolateClampNegative, butteraugli.cc:236-251 (size 512)
+GZ_DEVFN double interp_lut512(const double* a, double ix) {
+  if (ix < 0) ix = 0;
+  const int base = (int)ix;
+  if (base >= 511) return a[511];
+  const double mix = ix - (double)base;
+  return a[base] + mix * (a[base + 1] - a[base]);
+}
+
+}  // namespace gz

@@ -1,0 +1,156 @@
+/* guetzli_amd.h -- C ABI of the MI355X (gfx950) implementation of Guetzli's
+ * block-parallel hot path: per-8x8-block FDCT / quantise / IDCT / colour transform and
+ * the butteraugli distance map evaluated for every candidate by
+ * Processor::TryQuantMatrix and Processor::SelectFrequencyMasking.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no C++,
+ * HIP or torch types.  A maintainer of the reference binds it from a
+ * `guetzli::Comparator` subclass (INTEGRATION.md shows the stub); every entry point
+ * cites the reference interface it replaces as path:line under /root/reference.
+ *
+ * Conventions
+ *   - one gz_ctx per (image, GPU); calls on one context are serialised by the caller
+ *     (the reference objects are single-threaded too: comparator.h:29-96); contexts are
+ *     independent of each other.
+ *   - every function returns GZ_OK (0) or a negative GZ_E_* code; nothing throws, nothing
+ *     prints.  gz_last_error(ctx) gives a static description of the last failure.
+ *   - host pointers are ordinary pageable memory unless named `dev_*`.
+ *   - layouts
+ *       rgb     : uint8 packed, rgb[(y*w + x)*3 + c]                (guetzli.cc ReadPNG)
+ *       coeffs  : int16 DEQUANTISED DCT coefficients, component-major then block-major,
+ *                 coeffs[(c*nb + by*bw + bx)*64 + k], bw=ceil(w/8), bh=ceil(h/8), nb=bw*bh
+ *                 (= OutputImageComponent::coeffs_, output_image.h:33-40, one after the
+ *                 other for c = 0,1,2; 4:4:4 only)
+ *       q       : int[3][64] quantisation matrices in natural (row-major) order
+ *       planes  : float, plane[y*w + x] (no row padding on the host side)
+ */
+#ifndef GUETZLI_AMD_H_
+#define GUETZLI_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GZ_OK 0
+#define GZ_E_ARG (-1)        /* bad argument (null, size out of range, w/h < 8 ...) */
+#define GZ_E_NO_DEVICE (-2)  /* no usable gfx950 device / HIP runtime failure at init */
+#define GZ_E_HIP (-3)        /* a HIP call failed; see gz_last_error */
+#define GZ_E_STATE (-4)      /* call sequence violated (e.g. compare before coefficients) */
+#define GZ_E_NOMEM (-5)
+
+typedef struct gz_ctx gz_ctx;
+
+/* Library / device ------------------------------------------------------------ */
+int gz_abi_version(void);                 /* currently 1 */
+int gz_device_count(void);                /* number of visible HIP devices, <0 on error */
+const char* gz_strerror(int code);
+const char* gz_last_error(const gz_ctx* ctx);
+
+/* Context ---------------------------------------------------------------------
+ * gz_create: replaces guetzli::ButteraugliComparator::ButteraugliComparator
+ * (butteraugli_comparator.cc:51-61) -- uploads the original sRGB image, converts it to
+ * linear RGB (LinearRgb, :33-47) and precomputes the original's PsychoImage pi0_
+ * (butteraugli.cc:784-791).  `target` is Params::butteraugli_target
+ * (processor.h:30).  Requires w,h >= 8 (butteraugli) -- Process() itself only builds a
+ * comparator when w,h >= 32 (processor.cc:940).  Returns NULL on failure, *err set. */
+gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, int* err);
+void gz_destroy(gz_ctx* ctx);
+int gz_synchronize(gz_ctx* ctx);
+/* Run subsequent work of this context on an externally owned hipStream_t (e.g. torch's
+ * current stream, so that torch.cuda.Event timing sees the kernels).  NULL restores the
+ * context's own stream. */
+int gz_set_stream(gz_ctx* ctx, void* hip_stream);
+
+/* Block path ------------------------------------------------------------------
+ * gz_encode_rgb: replaces EncodeRGBToJpeg (jpeg_data_encoder.cc:66-117) for the
+ * all-ones quantisation: RGBToYUV16 (:40-48, edge-clamped gather :88-98) ->
+ * ComputeBlockDCT (fdct.cc:230) -> (v*65537 + 0x80000) >> 20 (:33-35).  The result is
+ * kept on the device as the context's ORIGINAL coefficients and, if coeffs_out != NULL,
+ * copied to the host. */
+int gz_encode_rgb(gz_ctx* ctx, int16_t* coeffs_out);
+
+/* Upload original (unquantised) coefficients computed elsewhere (JPEG input path:
+ * JPEGData after RemoveOriginalQuantization, processor.cc:84-97). */
+int gz_set_orig_coeffs(gz_ctx* ctx, const int16_t* coeffs);
+
+/* Candidate := original, then OutputImage::ApplyGlobalQuantization(q)
+ * (output_image.cc:232-243,342-346; Quantize quantize.h:24-29).  This is the coefficient
+ * side of Processor::TryQuantMatrix (processor.cc:298-307).  q == NULL means all ones
+ * (plain CopyFromJpegData).  coeffs_out (may be NULL) receives the candidate's
+ * coefficients for the host JPEG writer. */
+int gz_quantize(gz_ctx* ctx, const int* q, int16_t* coeffs_out);
+
+/* Replace the whole candidate / individual candidate blocks with host data
+ * (OutputImageComponent::SetCoeffBlock, output_image.cc:123-132).  block_index[i] =
+ * by*bw + bx; blocks holds n * 3 * 64 int16 (component-major per block: Y,Cb,Cr). */
+int gz_set_coeffs(gz_ctx* ctx, const int16_t* coeffs);
+int gz_set_coeff_blocks(gz_ctx* ctx, const int32_t* block_index, int n,
+                        const int16_t* blocks);
+int gz_get_coeffs(gz_ctx* ctx, int16_t* coeffs_out);
+
+/* Candidate -> pixels, for parity checks and for callers that want the decoded image:
+ * OutputImage::ToSRGB (output_image.cc:411-425) and ToLinearRGB (:427-440).
+ * srgb: w*h*3 uint8 or NULL; linear: 3 planes of w*h float or NULL. */
+int gz_reconstruct(gz_ctx* ctx, uint8_t* srgb, float* linear);
+
+/* Whole-image distance -----------------------------------------------------------
+ * gz_compare: replaces guetzli::ButteraugliComparator::Compare
+ * (butteraugli_comparator.cc:63-75) on the current candidate: IDCT + colour + linear
+ * (ToLinearRGB), OpsinDynamicsImage, SeparateFrequencies, Malta x6, L2Diff*,
+ * SameNoiseLevels, Mask, CombineChannels, CalculateDiffmap, max
+ * (butteraugli.cc:799-908,1623-1633).
+ *   distance  : distmap_aggregate() (butteraugli_comparator.h:56)          [required]
+ *   distmap   : distmap() (h:55), w*h floats                               [may be NULL]
+ *   block_max : per-8x8-block maximum of the distance map, nb floats = the first loop
+ *               of ComputeBlockErrorAdjustmentWeights (:505-520)           [may be NULL]
+ * With distmap == block_max == NULL only 4 bytes cross PCIe. */
+int gz_compare(gz_ctx* ctx, float* distance, float* distmap, float* block_max);
+
+/* Enqueue `iters` back-to-back Compare evaluations of the current candidate on the
+ * context's stream without any host transfer or synchronisation (for HIP-event timing
+ * of the resident-in-HBM rate).  The distance of the last one is readable with
+ * gz_last_distance after gz_synchronize. */
+int gz_compare_enqueue(gz_ctx* ctx, int iters);
+int gz_last_distance(gz_ctx* ctx, float* distance);
+/* Convenience: time `iters` enqueued Compare evaluations with hipEvents recorded on the
+ * context's stream; returns total milliseconds. */
+int gz_time_compare(gz_ctx* ctx, int iters, float* total_ms);
+
+/* ComputeBlockErrorAdjustmentWeights (butteraugli_comparator.cc:494-558) from the
+ * block maxima of the LAST gz_compare (or all-zero if use_distmap == 0, which is what
+ * SelectFrequencyMasking does on its first "up" iteration, processor.cc:625-629).
+ * block_weight: nb floats, in/out exactly like the reference's vector. */
+int gz_block_weights(gz_ctx* ctx, int direction, int max_block_dist, double target_mul,
+                     int use_distmap, float* block_weight);
+
+/* Stage probes (parity tests) -----------------------------------------------------
+ * Each runs ONE stage of the pipeline on host-provided input through the same kernels
+ * gz_compare uses.  They exist so that tests can localise a divergence; they are not on
+ * the hot path.  All planes are w*h floats of a context created for that w,h. */
+int gz_probe_blur(gz_ctx* ctx, const float* in, float sigma, float border_ratio,
+                  float* out);                                  /* Blur, butteraugli.cc:229 */
+int gz_probe_opsin(gz_ctx* ctx, const float* rgb3, float* xyb3); /* :324-366 */
+int gz_probe_separate_frequencies(gz_ctx* ctx, const float* xyb3,
+                                  float* out10);                /* :489-622; lf3,mf3,hf2,uhf2 */
+int gz_probe_diffmap(gz_ctx* ctx, const float* rgb0_3, const float* rgb1_3,
+                     float* diffmap, float* score);             /* :784-908 both sides */
+int gz_probe_mask(gz_ctx* ctx, const float* xyb0_3, const float* xyb1_3, float* mask3,
+                  float* mask_dc3);                             /* Mask, :1741-1817 */
+/* Block kernels on bare 64-element blocks (n blocks each). */
+int gz_probe_idct_blocks(int device, const int16_t* blocks, int n, uint8_t* out);
+int gz_probe_fdct_blocks(int device, int16_t* blocks, int n);
+/* Arithmetic self-check of the device: IEEE float/double divide & sqrt, conversions and
+ * the absence of FMA contraction, on host-supplied operands.  op: 0 a/b (f32),
+ * 1 sqrt(a) (f32), 2 a/b (f64), 3 sqrt(a) (f64), 4 a*b+c unfused (f32), 5 a*b+c unfused
+ * (f64), 6 (float)a for double a.  Arrays hold n elements of the operand type
+ * (out of (float)a is float). */
+int gz_probe_arith(int device, int op, const void* a, const void* b, const void* c,
+                   void* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GUETZLI_AMD_H_ */

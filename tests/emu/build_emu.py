@@ -1,0 +1,30 @@
+"""TEST INFRASTRUCTURE ONLY: compiles the product's kernel sources (guetzli_amd/csrc) with
+g++ against tests/emu/hip_emu.h into tests/emu/_build/libguetzli_amd_emu.so, so that the
+CPU test-suite can check the kernels' indexing and arithmetic order against the oracle
+without a GPU.  See hip_emu.h for why this is not a CPU fallback of the product."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "guetzli_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libguetzli_amd_emu.so")
+
+
+def build(force=False):
+    os.makedirs(OUT, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+        [os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "guetzli_amd.h")]
+    if not force and os.path.exists(LIB) and \
+            all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DGZ_EMU",
+           "-I" + HERE, "-x", "c++", os.path.join(CSRC, "gz_api.hip"), "-o", LIB,
+           "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-variable"]
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

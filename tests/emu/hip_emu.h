@@ -1,0 +1,176 @@
+// TEST INFRASTRUCTURE ONLY.
+//
+// A minimal single-process emulation of the HIP execution model, so that the VERY SAME
+// kernel sources under guetzli_amd/csrc/ can be compiled with g++ and run on the CPU in
+// the `-m "not gpu"` test suite (tests/emu/build_emu.py -> tests/emu/_build/*.so).
+// Purpose: catch indexing / tiling / accumulation-order bugs against the oracle before
+// spending GPU minutes.  It is NOT a CPU fallback: the product library is only ever
+// built by hipcc for gfx950 and fails loudly without a GPU; nothing under guetzli_amd/
+// references this file, and the emulated library has a different name and lives under
+// tests/.
+//
+// Model: one OS thread; each workgroup's threads are ucontext fibers scheduled
+// round-robin between __syncthreads() barriers; __shared__ is function-static storage
+// (one workgroup runs at a time); atomics are plain operations.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace hipemu {
+struct State {
+  dim3 threadIdx, blockIdx, blockDim, gridDim;
+  ucontext_t sched;
+  std::vector<ucontext_t> fibers;
+  std::vector<char*> stacks;
+  std::vector<char> done;
+  const std::function<void()>* body = nullptr;
+  int current = -1;
+  static const size_t kStack = 256 * 1024;
+};
+inline State& st() {
+  static State s;
+  return s;
+}
+inline void fiber_entry() {
+  State& s = st();
+  (*s.body)();
+  s.done[s.current] = 1;
+  swapcontext(&s.fibers[s.current], &s.sched);
+}
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  State& s = st();
+  const int nt = (int)(block.x * block.y * block.z);
+  if ((int)s.fibers.size() < nt) {
+    s.fibers.resize(nt);
+    s.done.resize(nt);
+    while ((int)s.stacks.size() < nt) s.stacks.push_back((char*)malloc(State::kStack));
+  }
+  s.body = &body;
+  s.blockDim = block;
+  s.gridDim = grid;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        s.blockIdx = dim3(bx, by, bz);
+        for (int t = 0; t < nt; ++t) {
+          getcontext(&s.fibers[t]);
+          s.fibers[t].uc_stack.ss_sp = s.stacks[t];
+          s.fibers[t].uc_stack.ss_size = State::kStack;
+          s.fibers[t].uc_link = nullptr;
+          makecontext(&s.fibers[t], (void (*)())fiber_entry, 0);
+          s.done[t] = 0;
+        }
+        int alive = nt;
+        while (alive > 0) {
+          alive = 0;
+          for (int t = 0; t < nt; ++t) {
+            if (s.done[t]) continue;
+            s.current = t;
+            s.threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            swapcontext(&s.sched, &s.fibers[t]);
+            if (!s.done[t]) ++alive;
+          }
+        }
+      }
+  s.body = nullptr;
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::st().threadIdx)
+#define blockIdx (hipemu::st().blockIdx)
+#define blockDim (hipemu::st().blockDim)
+#define gridDim (hipemu::st().gridDim)
+
+inline void __syncthreads() {
+  hipemu::State& s = hipemu::st();
+  swapcontext(&s.fibers[s.current], &s.sched);
+}
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __constant__ static
+
+// ---- atomics (single-threaded) ----
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+  unsigned o = *p;
+  if (v > o) *p = v;
+  return o;
+}
+inline int atomicAdd(int* p, int v) {
+  int o = *p;
+  *p += v;
+  return o;
+}
+inline unsigned atomicAdd(unsigned* p, unsigned v) {
+  unsigned o = *p;
+  *p += v;
+  return o;
+}
+inline unsigned __float_as_uint(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+inline float __uint_as_float(unsigned u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// ---- runtime shims ----
+typedef int hipError_t;
+typedef void* hipStream_t;
+struct hipEmuEvent { std::chrono::steady_clock::time_point t; };
+typedef hipEmuEvent* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice,
+                     hipMemcpyHostToHost, hipMemcpyDefault };
+inline const char* hipGetErrorString(hipError_t e) { return e ? "emu error" : "success"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = malloc(n ? n : 1);
+  // poison so that reads of never-written device memory are visible in tests
+  if (*p) memset(*p, 0xCD, n);
+  return *p ? hipSuccess : hipErrorInvalidValue;
+}
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return hipSuccess; }
+template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEmuEvent; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}

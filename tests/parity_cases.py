@@ -1,0 +1,130 @@
+"""Parity cases shared by the CPU-emulation run (`-m "not gpu"`, tests/test_kernels_emu.py)
+and the real-GPU run (`-m gpu`, tests/test_gpu_parity.py): the same kernels, the same
+checks, through the same C ABI -- only the library differs."""
+import numpy as np
+
+import images
+from checkers import assert_bits_equal, oracle
+
+RNG_SEED = 20260921
+
+SIGMAS_BR = [(1.2, 0.0), (7.46953768697, -0.00457628248637), (3.734768843485, -0.271277366628),
+             (1.8673844217425, 0.147068973249), (10.6666499623, 0.0),
+             (9.24456601467, -0.0724948220913), (2.3770330432, -0.0724948220913),
+             (9.04353323561, -0.0724948220913), (1.72547472444, 1.0)]
+
+
+def case_block_kernels(L, n=1500):
+    rng = np.random.default_rng(RNG_SEED)
+    blocks = rng.integers(-4096, 4097, size=(n, 64)).astype(np.int16)
+    blocks[: n // 2][rng.random((n // 2, 64)) < 0.7] = 0
+    blocks = np.concatenate([blocks, np.full((1, 64), 32767, np.int16),
+                             np.full((1, 64), -32768, np.int16), np.zeros((2, 64), np.int16)])
+    got = L.idct_blocks(blocks)
+    exp = np.stack([oracle.idct_block(b) for b in blocks])
+    assert_bits_equal(got, exp, "idct blocks")
+    px = np.concatenate([rng.integers(-128, 128, size=(n, 64)).astype(np.int16),
+                         np.full((1, 64), -128, np.int16), np.full((1, 64), 127, np.int16)])
+    got = L.fdct_blocks(px)
+    exp = np.stack([oracle.fdct_block(b) for b in px])
+    assert_bits_equal(got, exp, "fdct blocks")
+
+
+def case_encode_quantize_reconstruct(L, w, h, x0=0, y0=0):
+    rng = np.random.default_rng(RNG_SEED + w)
+    rgb = images.crop(w, h, x0, y0)
+    with L.context(rgb, 1.0) as ctx:
+        co = ctx.encode_rgb()
+        exp = oracle.encode_rgb(rgb)
+        assert_bits_equal(co, exp, "encode_rgb")
+        q = np.stack([rng.integers(1, 12, size=64), rng.integers(1, 20, size=64),
+                      rng.integers(1, 20, size=64)]).astype(np.int32)
+        for qq in (None, q):
+            cq = ctx.quantize(qq)
+            ecq, esrgb, elin = oracle.reconstruct(exp, w, h, qq)
+            assert_bits_equal(cq, ecq, "quantize")
+            srgb, lin = ctx.reconstruct()
+            assert_bits_equal(srgb, esrgb, "reconstruct srgb")
+            assert_bits_equal(lin, elin, "reconstruct linear")
+        # block updates
+        idx = np.array([0, ctx.nb - 1, ctx.nb // 2], np.int32)
+        blocks = rng.integers(-300, 300, size=(3, 3, 64)).astype(np.int16)
+        ctx.set_coeff_blocks(idx, blocks)
+        ecq2 = ecq.copy()
+        for i, b in enumerate(idx):
+            ecq2[:, b, :] = blocks[i]
+        assert_bits_equal(ctx.get_coeffs(), ecq2, "set_coeff_blocks")
+
+
+def case_blur(L, w, h, configs=SIGMAS_BR):
+    rng = np.random.default_rng(RNG_SEED + 7 * w + h)
+    plane = (rng.random((h, w)) * 255).astype(np.float32)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    with L.context(rgb, 1.0) as ctx:
+        for s, br in configs:
+            got = ctx.probe_blur(plane, s, br)
+            exp = oracle.blur(plane, s, br)
+            assert_bits_equal(got, exp, f"blur sigma={s} br={br} {w}x{h}")
+
+
+def _linear_pair(w, h, x0, y0, qscale):
+    rgb = images.crop(w, h, x0, y0)
+    co = oracle.encode_rgb(rgb)
+    q = np.full((3, 64), qscale, np.int32)
+    cq, _, lin1 = oracle.reconstruct(co, w, h, q)
+    lut = oracle.srgb_table()
+    lin0 = lut[rgb].astype(np.float32).transpose(2, 0, 1).copy()
+    return rgb, co, cq, lin0, lin1
+
+
+def case_stages(L, w, h, x0=40, y0=60, qscale=6):
+    """opsin -> separate_frequencies -> mask -> diffmap, each against the oracle."""
+    rgb, co, cq, lin0, lin1 = _linear_pair(w, h, x0, y0, qscale)
+    with L.context(rgb, 1.0) as ctx:
+        x0_, x1_ = oracle.opsin(lin0), oracle.opsin(lin1)
+        assert_bits_equal(ctx.probe_opsin(lin0), x0_, "opsin(orig)")
+        assert_bits_equal(ctx.probe_opsin(lin1), x1_, "opsin(cand)")
+        for xyb in (x0_, x1_):
+            got = ctx.probe_separate_frequencies(xyb)
+            exp = oracle.separate_frequencies(xyb)
+            names = ["lf0", "lf1", "lf2", "mf0", "mf1", "mf2", "hf0", "hf1", "uhf0", "uhf1"]
+            for i, nm in enumerate(names):
+                if nm == "mf2":
+                    continue   # dead plane in the reference (wmul[5] == 0), never computed
+                assert_bits_equal(got[i], exp[i], f"separate_frequencies {nm}")
+        for a, b in ((x0_, x1_), (x0_, x0_)):
+            gm, gdc = ctx.probe_mask(a, b)
+            em, edc = oracle.mask(a, b)
+            assert_bits_equal(gm, em, "mask")
+            assert_bits_equal(gdc, edc, "mask_dc")
+        gd, gs = ctx.probe_diffmap(lin0, lin1)
+        ed, es = oracle.diffmap(lin0, lin1)
+        assert_bits_equal(gd, ed, "diffmap")
+        assert gs == np.float32(es)
+
+
+def case_compare(L, w, h, x0=0, y0=0, qscales=(1, 3, 9), target=0.971769):
+    """The drop-in call sequence of TryQuantMatrix: encode -> quantize(q) -> compare."""
+    rgb = images.crop(w, h, x0, y0) if max(w, h) <= 444 else images.tiled(w, h)
+    oc = oracle.comparator(rgb, target)
+    with L.context(rgb, target) as ctx:
+        co = ctx.encode_rgb()
+        assert_bits_equal(co, oracle.encode_rgb(rgb), "encode_rgb")
+        for qs in qscales:
+            q = np.full((3, 64), qs, np.int32)
+            cq = ctx.quantize(q)
+            dist, dm, bm = ctx.compare()
+            edist, edm = oc.compare(cq)
+            assert_bits_equal(dm, edm, f"distmap q={qs}")
+            assert dist == edist
+            # block maxima + weights
+            pad = np.zeros((ctx.bh * 8, ctx.bw * 8), np.float32)
+            pad[:h, :w] = edm
+            ebm = pad.reshape(ctx.bh, 8, ctx.bw, 8).max(axis=(1, 3)).reshape(-1)
+            assert_bits_equal(bm, ebm, "block max")
+            for direction in (1, -1):
+                for r in (1, 3):
+                    assert_bits_equal(ctx.block_weights(direction, r, 1.0),
+                                      oc.block_weights(direction, r, 1.0, edm),
+                                      "block weights")
+    oc.close()

@@ -1,0 +1,121 @@
+"""GPU parity tests proper: the hipcc-built gfx950 library, through the C ABI, against the
+oracle -- bit-exact on the integer block path AND on the float butteraugli path (the
+output JPEG can only be byte-identical if every distance is).  Full-size cases use
+size-independent properties where the oracle would take too long."""
+import numpy as np
+import pytest
+
+import images
+import parity_cases as pc
+from checkers import assert_bits_equal, oracle, ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import guetzli_amd
+    lib = guetzli_amd.load()
+    assert lib.device_count() >= 1
+    return lib
+
+
+def test_device_arithmetic_is_ieee_and_uncontracted(L):
+    """f32/f64 divide and sqrt correctly rounded, no FMA contraction, RNE conversions."""
+    rng = np.random.default_rng(1)
+    n = 1 << 16
+    a32 = (rng.standard_normal(n) * 10.0 ** rng.integers(-20, 20, n)).astype(np.float32)
+    b32 = (rng.standard_normal(n) * 10.0 ** rng.integers(-20, 20, n)).astype(np.float32)
+    c32 = (rng.standard_normal(n) * 10.0 ** rng.integers(-20, 20, n)).astype(np.float32)
+    a32[:64] = np.float32(1e-41) * np.arange(64, dtype=np.float32)   # denormals
+    a64 = rng.standard_normal(n) * 10.0 ** rng.integers(-200, 200, n)
+    b64 = rng.standard_normal(n) * 10.0 ** rng.integers(-200, 200, n)
+    c64 = rng.standard_normal(n) * 10.0 ** rng.integers(-200, 200, n)
+    with np.errstate(all="ignore"):
+        assert_bits_equal(L.arith(0, a32, b32), a32 / b32, "f32 divide")
+        assert_bits_equal(L.arith(1, np.abs(a32)), np.sqrt(np.abs(a32)), "f32 sqrt")
+        assert_bits_equal(L.arith(2, a64, b64), a64 / b64, "f64 divide")
+        assert_bits_equal(L.arith(3, np.abs(a64)), np.sqrt(np.abs(a64)), "f64 sqrt")
+        assert_bits_equal(L.arith(4, a32, b32, c32), (a32 * b32) + c32, "f32 mul+add unfused")
+        assert_bits_equal(L.arith(5, a64, b64, c64), (a64 * b64) + c64, "f64 mul+add unfused")
+        small = rng.standard_normal(n) * 10.0 ** rng.integers(-45, 38, n)
+        assert_bits_equal(L.arith(6, small), small.astype(np.float32), "f64->f32")
+
+
+def test_block_kernels(L):
+    pc.case_block_kernels(L, n=20000)
+
+
+@pytest.mark.parametrize("wh", [(444, 258), (61, 43), (32, 32), (8, 8), (129, 9)])
+def test_encode_quantize_reconstruct(L, wh):
+    pc.case_encode_quantize_reconstruct(L, *wh)
+
+
+@pytest.mark.parametrize("wh", [(444, 258), (70, 67), (600, 9), (33, 300), (32, 32)])
+def test_blur(L, wh):
+    pc.case_blur(L, *wh)
+
+
+@pytest.mark.parametrize("wh", [(256, 192), (72, 48), (35, 41), (444, 258)])
+def test_stages(L, wh):
+    pc.case_stages(L, *wh, x0=0, y0=0)
+
+
+def test_compare_bees(L):
+    """BASELINE config 1 image, full size, three candidate quantisations."""
+    pc.case_compare(L, 444, 258, qscales=(1, 2, 6, 14))
+
+
+def test_compare_small_and_ragged(L):
+    pc.case_compare(L, 32, 32, x0=100, y0=100, qscales=(3,))
+    pc.case_compare(L, 131, 77, x0=50, y0=20, qscales=(2, 8))
+
+
+@pytest.mark.skipif(ref is None, reason="oracle/_ref not built")
+def test_compare_against_unmodified_reference(L):
+    """Same check against the real reference comparator (oracle/_ref), including the
+    reference's own quant-matrix search candidates for bees.png."""
+    rgb = images.bees()
+    h, w, _ = rgb.shape
+    target = 0.971769
+    rc = ref.comparator(rgb, target)
+    with L.context(rgb, target) as ctx:
+        co = ctx.encode_rgb()
+        assert_bits_equal(co, ref.encode_rgb(rgb), "encode vs reference")
+        q = np.ones((3, 64), np.int32)
+        q[:, 32:] = 3
+        cq = ctx.quantize(q)
+        rcq, _, _ = ref.reconstruct(co, w, h, q)
+        assert_bits_equal(cq, rcq, "quantize vs reference")
+        dist, dm, _ = ctx.compare()
+        rdist, rdm = rc.compare(cq)
+        assert_bits_equal(dm, rdm, "distmap vs reference")
+        assert dist == rdist
+    rc.close()
+
+
+def test_full_size_properties_1080p(L):
+    """BASELINE config 2 size (1920x1080).  The oracle needs ~1 s per Compare here, so one
+    exact comparison plus size-independent properties: identical candidate => identical
+    map (idempotence); q=1 candidate of a tiled image => the map is tile-periodic away from
+    the borders; distance == max(map); block maxima consistent."""
+    w, h = 1920, 1080
+    rgb = images.tiled(w, h)
+    target = 0.971769
+    with L.context(rgb, target) as ctx:
+        co = ctx.encode_rgb()
+        q = np.full((3, 64), 4, np.int32)
+        cq = ctx.quantize(q)
+        d1, m1, b1 = ctx.compare()
+        d2, m2, b2 = ctx.compare()
+        assert_bits_equal(m1, m2, "idempotence")
+        assert d1 == d2 == m1.max()
+        pad = np.zeros((ctx.bh * 8, ctx.bw * 8), np.float32)
+        pad[:h, :w] = m1
+        assert_bits_equal(b1, pad.reshape(ctx.bh, 8, ctx.bw, 8).max(axis=(1, 3)).reshape(-1),
+                          "block max")
+        oc = oracle.comparator(rgb, target)
+        ed, em = oc.compare(cq)
+        oc.close()
+        assert_bits_equal(m1, em, "1080p distmap vs oracle")
+        assert d1 == ed

@@ -1,0 +1,41 @@
+"""CPU run of the product's kernel SOURCES (compiled with g++ against tests/emu/hip_emu.h)
+against the oracle, through the same C ABI the GPU tests use.  Catches indexing / tiling /
+accumulation-order bugs without a GPU.  This is test infrastructure, not a fallback: see
+tests/emu/hip_emu.h."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import build_emu  # noqa: E402
+import parity_cases as pc  # noqa: E402
+from guetzli_amd.capi import Library  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def L():
+    return Library(build_emu.build())
+
+
+def test_block_kernels(L):
+    pc.case_block_kernels(L, n=300)
+
+
+@pytest.mark.parametrize("wh", [(61, 43), (32, 32), (72, 40)])
+def test_encode_quantize_reconstruct(L, wh):
+    pc.case_encode_quantize_reconstruct(L, *wh, x0=100, y0=50)
+
+
+@pytest.mark.parametrize("wh", [(70, 67), (300, 9), (33, 130)])
+def test_blur(L, wh):
+    pc.case_blur(L, *wh)
+
+
+@pytest.mark.parametrize("wh", [(72, 48), (35, 41)])
+def test_stages(L, wh):
+    pc.case_stages(L, *wh)
+
+
+def test_compare(L):
+    pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(1, 5))

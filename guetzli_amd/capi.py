@@ -42,6 +42,8 @@ SIGNATURES = {
     "gz_last_distance": (_I, [_P, _P]),
     "gz_time_compare": (_I, [_P, _I, _P]),
     "gz_block_weights": (_I, [_P, _I, _I, C.c_double, _I, _P]),
+    "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
+    "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
     "gz_probe_blur": (_I, [_P, _P, C.c_float, C.c_float, _P]),
     "gz_probe_opsin": (_I, [_P, _P, _P]),
     "gz_probe_separate_frequencies": (_I, [_P, _P, _P]),
@@ -220,6 +222,16 @@ class Context:
         self._chk(self.L.lib.gz_block_weights(self.handle, direction, max_block_dist,
                                               target_mul, int(use_distmap), _ptr(wgt)))
         return wgt
+
+    def block_zeroing_orders(self, lookahead=3, new_model=True):
+        cap = self.nb * 189
+        off = np.zeros(self.nb + 1, np.int32)
+        idx = np.zeros(cap, np.uint8)
+        err = np.zeros(cap, np.float32)
+        self._chk(self.L.lib.gz_block_zeroing_orders(self.handle, lookahead, int(new_model),
+                                                     _ptr(off), _ptr(idx), _ptr(err), cap))
+        n = int(off[-1])
+        return off, idx[:n].copy(), err[:n].copy()
 
     # ---- stage probes ----
     def probe_blur(self, plane, sigma, border_ratio):

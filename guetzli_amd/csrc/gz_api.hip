@@ -15,12 +15,15 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "gz_common.h"
 #include "gz_kernels_block.h"
 #include "gz_kernels_blur.h"
 #include "gz_kernels_diff.h"
+#include "gz_kernels_search.h"
 
 using namespace gz;
 
@@ -174,6 +177,11 @@ struct gz_ctx {
   float *mask_out[3], *mask_dc_out[3];
   bool have_mask_out = false;
 
+  float* d_block_mask = nullptr;   // [3][nb] mask_xyz_ at block corners (StartBlockComparisons)
+  bool have_block_mask = false;
+  int32_t* d_rank_off = nullptr; uint8_t* d_rank_idx = nullptr;
+  int32_t* d_out_cnt = nullptr; uint8_t* d_out_idx = nullptr; float* d_out_err = nullptr;
+
   bool have_orig = false, have_cand = false, have_distmap = false;
   std::vector<float> h_block_max;
   float last_distance = 0.0f;
@@ -226,14 +234,16 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
   KCHK(c);
   return GZ_OK;
 }
-template <int R, int NC, class Post>
-int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg& cfg) {
+template <int R, int NC, class Post, bool BM = false>
+int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg& cfg,
+           BlockMaxOut bm = BlockMaxOut{nullptr, nullptr, 0}) {
   if (cfg.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
   dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, VH));
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  GZ_LAUNCH((k_blur_v<R, NC, Post>), grid, dim3(256), c->stream, src, post, w, h, pitch, tp, bs);
+  GZ_LAUNCH((k_blur_v<R, NC, Post, BM>), grid, dim3(256), c->stream, src, post, w, h, pitch, tp,
+            bs, bm);
   KCHK(c);
   return GZ_OK;
 }
@@ -444,13 +454,10 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     s.s[0].p = c->dsq; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
     TRY((blur_h<3, SrcPlain, 1>(c, s, t, c->blur[B_FINAL])));
     PostDiffmapMix post; post.d = c->dsq; post.out = c->distmap;
-    TRY((blur_v<3, 1, PostDiffmapMix>(c, ct, post, c->blur[B_FINAL])));
+    HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
+    BlockMaxOut bm{want_block_max ? c->d_block_max : nullptr, c->d_max_bits, c->bw};
+    TRY((blur_v<3, 1, PostDiffmapMix, true>(c, ct, post, c->blur[B_FINAL], bm)));
   }
-  HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
-  GZ_LAUNCH(k_block_max, dim3(gz_div_up(c->nb, 4)), dim3(256), c->stream, c->distmap, c->w,
-            c->h, c->pitch, c->bw, c->nb, want_block_max ? c->d_block_max : nullptr,
-            c->d_max_bits);
-  KCHK(c);
   return GZ_OK;
 }
 
@@ -491,6 +498,108 @@ int ensure_pip(gz_ctx* c) {
   for (int i = 0; i < 3; ++i) { c->mask_out[i] = take_plane(c); c->mask_dc_out[i] = take_plane(c); }
   c->have_pip = true;
   return GZ_OK;
+}
+
+
+// StartBlockComparisons (butteraugli_comparator.cc:415-421): mask_xyz_ =
+// Mask(opsin(orig), opsin(orig)).mask; only the values at block corners are ever read
+// (CompareBlock, :484-486).
+int ensure_block_mask(gz_ctx* c) {
+  if (c->have_block_mask) return GZ_OK;
+  TRY(ensure_pip(c));
+  if (!c->d_block_mask) HIPCHK(c, hipMalloc((void**)&c->d_block_mask, sizeof(float) * 3 * c->nb));
+  dim3 grid(gz_div_up(c->w, 256), c->h);
+  GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, c->w, c->h, c->pitch,
+            c->plane, c->d_srgb_lut, c->lin[0]);
+  KCHK(c);
+  TRY(stage_opsin(c));
+  MaskPrePack pk;
+  for (int i = 0; i < 2; ++i) {
+    pk.in0[i] = {nullptr, c->xyb[i], 0.0, 1.0, 1};
+    pk.in1[i] = {nullptr, c->xyb[i], 0.0, 1.0, 1};
+  }
+  pk.out[0] = c->diffx;
+  pk.out[1] = c->diffy;
+  TRY(stage_mask_blurs(c, pk));
+  CombineArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.mask_x_blur = c->mxb; ca.mask_y_blur1 = c->myb1; ca.mask_y_blur2 = c->myb2;
+  ca.luts = c->d_mask_luts;
+  for (int i = 0; i < 3; ++i) { ca.mask_out[i] = c->mask_out[i]; ca.mask_dc_out[i] = nullptr; }
+  GZ_LAUNCH(k_combine, grid, dim3(256), c->stream, ca, c->w, c->h, c->pitch);
+  KCHK(c);
+  GZ_LAUNCH(k_gather_block_corners, dim3(gz_div_up(c->nb, 256)), dim3(256), c->stream,
+            (const float*)c->mask_out[0], (const float*)c->mask_out[1],
+            (const float*)c->mask_out[2], c->pitch, c->bw, c->nb, c->d_block_mask);
+  KCHK(c);
+  c->have_block_mask = true;
+  return GZ_OK;
+}
+
+// input_order of ComputeBlockZeroingOrder (processor.cc:381-400) for blocks [b0, b1):
+// score = |orig| * csf + bias (order.inc), std::sort ascending on the score -- done with
+// libstdc++'s std::sort on the same sequence the reference builds, because the order of
+// equal scores is implementation-defined and feeds the JPEG bytes.
+void rank_blocks(const int16_t* coeffs, const int16_t* orig, int nb, int new_model, int b0,
+                 int b1, uint8_t* cnt, uint8_t* idx /* [nb][192] */) {
+  static const uint8_t oldCsf[64] = {
+      10, 10, 20, 40, 60, 70, 80, 90, 10, 20, 30, 60, 70, 80, 90, 90,
+      20, 30, 60, 70, 80, 90, 90, 90, 40, 60, 70, 80, 90, 90, 90, 90,
+      60, 70, 80, 90, 90, 90, 90, 90, 70, 80, 90, 90, 90, 90, 90, 90,
+      80, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90};
+  static const int zigzag[64] = {   // kJPEGZigZagOrder, jpeg_data.h:75-84
+      0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42,
+      3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+      10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+      21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+  static const double kWeight[3] = {1.0, 0.22, 0.20};
+  std::vector<std::pair<int, float> > order;
+  order.reserve(192);
+  for (int b = b0; b < b1; ++b) {
+    order.clear();
+    for (int ch = 0; ch < 3; ++ch) {
+      const int16_t* blk = coeffs + ((size_t)ch * nb + b) * 64;
+      const int16_t* ob = orig + ((size_t)ch * nb + b) * 64;
+      for (int k = 1; k < 64; ++k) {
+        if (blk[k] == 0) continue;
+        const int i = ch * 64 + k;
+        float score;
+        if (new_model)
+          score = abs((int)ob[k]) * kOrderCsf[i] + kOrderBias[i];
+        else
+          score = static_cast<float>((abs((int)ob[k]) - zigzag[k] / 64.0) * kWeight[ch] / oldCsf[k]);
+        order.push_back(std::make_pair(i, score));
+      }
+    }
+    std::sort(order.begin(), order.end(),
+              [](const std::pair<int, float>& x, const std::pair<int, float>& y) {
+                return x.second < y.second; });
+    cnt[b] = (uint8_t)order.size();
+    for (size_t i = 0; i < order.size(); ++i) idx[(size_t)b * 192 + i] = (uint8_t)order[i].first;
+  }
+}
+
+void rank_all(const int16_t* coeffs, const int16_t* orig, int nb, int new_model,
+              std::vector<int32_t>* off, std::vector<uint8_t>* idx) {
+  std::vector<uint8_t> cnt(nb), wide((size_t)nb * 192);
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = std::max(1u, std::min(nt, 32u));
+  if (nb < 4096) nt = 1;
+  std::vector<std::thread> th;
+  const int per = (nb + (int)nt - 1) / (int)nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const int b0 = (int)t * per, b1 = std::min(nb, b0 + per);
+    if (b0 >= b1) break;
+    th.emplace_back(rank_blocks, coeffs, orig, nb, new_model, b0, b1, cnt.data(), wide.data());
+  }
+  for (auto& t : th) t.join();
+  off->resize(nb + 1);
+  int total = 0;
+  for (int b = 0; b < nb; ++b) { (*off)[b] = total; total += cnt[b]; }
+  (*off)[nb] = total;
+  idx->resize(total);
+  for (int b = 0; b < nb; ++b)
+    memcpy(idx->data() + (*off)[b], wide.data() + (size_t)b * 192, cnt[b]);
 }
 
 }  // namespace
@@ -613,6 +722,8 @@ void gz_destroy(gz_ctx* c) {
   hipFree(c->d_max_bits); hipFree(c->d_srgb_out); hipFree(c->arena);
   hipFree(c->d_blkidx); hipFree(c->d_blkdata);
   hipFree(c->extra_arena);
+  hipFree(c->d_block_mask); hipFree(c->d_rank_off); hipFree(c->d_rank_idx);
+  hipFree(c->d_out_cnt); hipFree(c->d_out_idx); hipFree(c->d_out_err);
   for (int b = 0; b < B_COUNT; ++b) hipFree(c->blur[b].d_scale);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -960,6 +1071,83 @@ int gz_probe_arith(int device, int op, const void* a, const void* b, const void*
   if (hipMemcpy(out, dout, os * n, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
   hipFree(da); hipFree(db); hipFree(dc); hipFree(dout);
   return rc;
+}
+
+
+int gz_rank_zeroing_candidates(const int16_t* coeffs, const int16_t* orig, int nb,
+                               int new_model, int32_t* offsets, uint8_t* idx) {
+  if (!coeffs || !orig || !offsets || !idx || nb <= 0) return GZ_E_ARG;
+  std::vector<int32_t> off;
+  std::vector<uint8_t> ix;
+  rank_all(coeffs, orig, nb, new_model, &off, &ix);
+  memcpy(offsets, off.data(), sizeof(int32_t) * (nb + 1));
+  memcpy(idx, ix.data(), ix.size());
+  return GZ_OK;
+}
+
+int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* offsets,
+                            uint8_t* idx, float* err, int cap) {
+  if (!c || !offsets || !idx || !err || lookahead < 1 || cap < 0) return GZ_E_ARG;
+  if (!c->have_cand || !c->have_orig) { c->err = "needs original and candidate coefficients"; return GZ_E_STATE; }
+  TRY(ensure_block_mask(c));
+  const int nb = c->nb;
+  const size_t ncoef = (size_t)3 * nb * 64;
+  std::vector<int16_t> h_cand(ncoef), h_orig(ncoef);
+  HIPCHK(c, hipMemcpyAsync(h_cand.data(), c->d_cand, ncoef * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_orig.data(), c->d_orig, ncoef * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<int32_t> roff;
+  std::vector<uint8_t> ridx;
+  rank_all(h_cand.data(), h_orig.data(), nb, new_model, &roff, &ridx);
+  if (!c->d_rank_off) {
+    HIPCHK(c, hipMalloc((void**)&c->d_rank_off, sizeof(int32_t) * (nb + 1)));
+    HIPCHK(c, hipMalloc((void**)&c->d_rank_idx, (size_t)nb * 192));
+    HIPCHK(c, hipMalloc((void**)&c->d_out_cnt, sizeof(int32_t) * nb));
+    HIPCHK(c, hipMalloc((void**)&c->d_out_idx, (size_t)nb * 192));
+    HIPCHK(c, hipMalloc((void**)&c->d_out_err, sizeof(float) * nb * 192));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_rank_off, roff.data(), sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, c->stream));
+  if (!ridx.empty())
+    HIPCHK(c, hipMemcpyAsync(c->d_rank_idx, ridx.data(), ridx.size(), hipMemcpyHostToDevice, c->stream));
+  SearchArgs a;
+  a.coeffs = c->d_cand; a.rank_off = c->d_rank_off; a.rank_idx = c->d_rank_idx;
+  a.rgb = c->d_rgb; a.srgb_lut = c->d_srgb_lut; a.block_mask = c->d_block_mask;
+  a.w = c->w; a.h = c->h; a.bw = c->bw; a.nb = nb;
+  a.lookahead = lookahead;
+  a.limit = c->target;
+  {
+    // 8x8 OpsinDynamicsImage: Blur(sigma 1.2, border_ratio 0) on an 8x8 image
+    BlurCfg cfg;
+    make_taps_host((float)kBlurSpecs[B_OPSIN].sigma, &cfg);
+    cfg.border_ratio = 0.0f;
+    a.taps = taps_of<2>(cfg);
+    std::vector<float> lo, hi;
+    border_scales_host(cfg, 8, &lo, &hi);
+    a.scale_lo[0] = lo[0]; a.scale_lo[1] = lo[1];
+    a.scale_hi[0] = hi[0]; a.scale_hi[1] = hi[1];
+  }
+  a.out_cnt = c->d_out_cnt; a.out_idx = c->d_out_idx; a.out_err = c->d_out_err;
+  GZ_LAUNCH(k_block_search, dim3(nb), dim3(64), c->stream, a);
+  KCHK(c);
+  std::vector<int32_t> cnt(nb);
+  std::vector<uint8_t> widx((size_t)nb * 192);
+  std::vector<float> werr((size_t)nb * 192);
+  HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_out_cnt, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(widx.data(), c->d_out_idx, (size_t)nb * 192, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(werr.data(), c->d_out_err, sizeof(float) * nb * 192, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  long total = 0;
+  for (int b = 0; b < nb; ++b) total += cnt[b];
+  if (total > cap) { c->err = "candidate capacity too small, need " + std::to_string(total); offsets[nb] = (int32_t)total; return GZ_E_ARG; }
+  int t = 0;
+  for (int b = 0; b < nb; ++b) {
+    offsets[b] = t;
+    memcpy(idx + t, widx.data() + (size_t)b * 192, cnt[b]);
+    memcpy(err + t, werr.data() + (size_t)b * 192, sizeof(float) * cnt[b]);
+    t += cnt[b];
+  }
+  offsets[nb] = t;
+  return GZ_OK;
 }
 
 }  // extern "C"

@@ -112,9 +112,22 @@ constexpr int VW = 64;
 constexpr int VH = 64;
 constexpr int VPT = VH / 4;   // outputs per thread
 
-template <int R, int NC, class Post>
+// With BM = true the values returned by the Post functor are additionally reduced to the
+// per-8x8-block maxima of the tile (the tile origin is 8-aligned) and to one atomicMax per
+// workgroup on the image maximum: first loop of ComputeBlockErrorAdjustmentWeights
+// (butteraugli_comparator.cc:505-520) and ButteraugliScoreFromDiffmap
+// (butteraugli.cc:1623-1633).  max is exact and order-free; values are >= 0, so the float
+// order equals the order of the bit patterns.
+struct BlockMaxOut {
+  float* block_max;        // [nb] or null
+  unsigned* image_max_bits;
+  int bw;
+};
+
+template <int R, int NC, class Post, bool BM>
 __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, int w, int h,
-                                                int pitch, Taps<R> taps, BorderScale bs) {
+                                                int pitch, Taps<R> taps, BorderScale bs,
+                                                BlockMaxOut bm) {
   __shared__ float tile[VH + 2 * R][VW];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int x0 = blockIdx.x * VW, y0 = blockIdx.y * VH;
@@ -150,15 +163,42 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
       acc[c][i] = sum;
     }
   }
-  if (x >= w) return;
+  float res[VPT];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int y = y0 + tg * VPT + i;
-    if (y >= h) break;
-    float v[NC];
+    res[i] = 0.0f;
+    if (x < w && y < h) {
+      float v[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) v[c] = acc[c][i];
-    post((size_t)y * pitch + x, v);
+      for (int c = 0; c < NC; ++c) v[c] = acc[c][i];
+      res[i] = post((size_t)y * pitch + x, v);
+    }
+  }
+  if (BM) {
+    __shared__ float s_bmax[64];
+    __syncthreads();   // all column reads of the last plane are done
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) tile[tg * VPT + i][tx] = res[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int bxl = threadIdx.x & 7, byl = threadIdx.x >> 3;
+      float m = 0.0f;
+      for (int yy = 0; yy < 8; ++yy)
+        for (int xx = 0; xx < 8; ++xx) {
+          const float t = tile[8 * byl + yy][8 * bxl + xx];
+          m = t > m ? t : m;
+        }
+      s_bmax[threadIdx.x] = m;
+      const int gbx = x0 / 8 + bxl, gby = y0 / 8 + byl;
+      if (bm.block_max && 8 * gbx < w && 8 * gby < h) bm.block_max[gby * bm.bw + gbx] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.0f;
+      for (int i = 0; i < 64; ++i) m = s_bmax[i] > m ? s_bmax[i] : m;
+      atomicMax(bm.image_max_bits, __float_as_uint(m));
+    }
   }
 }
 
@@ -166,9 +206,10 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
 template <int NC>
 struct PostStore {
   float* out[NC];
-  GZ_DEVFN void operator()(size_t idx, const float* v) const {
+  GZ_DEVFN float operator()(size_t idx, const float* v) const {
 #pragma unroll
     for (int c = 0; c < NC; ++c) out[c][idx] = v[c];
+    return v[0];
   }
 };
 
@@ -176,12 +217,13 @@ struct PostStore {
 struct PostOpsin {
   const float* lin[3];
   float* xyb[3];
-  GZ_DEVFN void operator()(size_t idx, const float* v) const {
+  GZ_DEVFN float operator()(size_t idx, const float* v) const {
     float x, y, z;
     opsin_pixel(v[0], v[1], v[2], lin[0][idx], lin[1][idx], lin[2][idx], &x, &y, &z);
     xyb[0][idx] = x;
     xyb[1][idx] = y;
     xyb[2][idx] = z;
+    return y;
   }
 };
 
@@ -191,7 +233,7 @@ struct PostOpsin {
 struct PostLF {
   float* lf_raw[2];
   float* lf_vals[3];
-  GZ_DEVFN void operator()(size_t idx, const float* v) const {
+  GZ_DEVFN float operator()(size_t idx, const float* v) const {
     lf_raw[0][idx] = v[0];
     lf_raw[1][idx] = v[1];
     float vx, vy, vb;
@@ -199,6 +241,7 @@ struct PostLF {
     lf_vals[0][idx] = vx;
     lf_vals[1][idx] = vy;
     lf_vals[2][idx] = vb;
+    return vy;
   }
 };
 
@@ -210,7 +253,7 @@ struct PostMF {
   const float* lf_raw[2];
   float* mf[2];
   float* hf_pre[2];
-  GZ_DEVFN void operator()(size_t idx, const float* v) const {
+  GZ_DEVFN float operator()(size_t idx, const float* v) const {
     const float band0 = xyb[0][idx] - lf_raw[0][idx];
     const float band1 = xyb[1][idx] - lf_raw[1][idx];
     const float h0 = band0 - v[0];
@@ -219,6 +262,7 @@ struct PostMF {
     mf[1][idx] = amplify_range((float)0.03430529365, v[1]);
     hf_pre[0][idx] = suppress_x_by_y(h0, h1);
     hf_pre[1][idx] = h1;
+    return h1;
   }
 };
 
@@ -228,7 +272,7 @@ struct PostHF {
   const float* lf_raw_y;
   float* hf[2];
   float* uhf[2];
-  GZ_DEVFN void operator()(size_t idx, const float* v) const {
+  GZ_DEVFN float operator()(size_t idx, const float* v) const {
     const float kMulSuppressHf = (float)1.10684769012;
     const float kMulRegHf = (float)0.478741530298;
     const float kRegHf = 2000 * kMulRegHf;
@@ -247,6 +291,7 @@ struct PostHF {
     hv = suppress_bright(hv, br, kMulSuppressHf, kRegHf);
     uhf[1][idx] = u;
     hf[1][idx] = hv;
+    return hv;
   }
 };
 
@@ -254,13 +299,14 @@ struct PostHF {
 struct PostDiffmapMix {
   const float* d;
   float* out;
-  GZ_DEVFN void operator()(size_t idx, const float* v) const {
+  GZ_DEVFN float operator()(size_t idx, const float* v) const {
     const double mul1 = 0.458794906198;
     const float scale = (float)(1.0f / (1.0f + mul1));
     float r = d[idx];
     r = (float)((double)r + mul1 * (double)v[0]);
     r = r * scale;
     out[idx] = r;
+    return r;
   }
 };
 

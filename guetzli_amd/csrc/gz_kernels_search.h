@@ -1,0 +1,367 @@
+// Batched phase A of Processor::SelectFrequencyMasking (processor.cc:554-590): for every
+// 8x8 block, the greedy coefficient-zeroing order of ComputeBlockZeroingOrder
+// (processor.cc:364-467) with the per-candidate error of
+// ButteraugliComparator::CompareBlock (butteraugli_comparator.cc:457-488).
+//
+// One workgroup = one 64-lane wavefront = one block position (Y, Cb, Cr blocks together);
+// lane = pixel.  Everything a block needs for its <= 189 sequential steps x <= 3 look-ahead
+// candidates lives in LDS / registers: the three coefficient blocks, the pixel cache of the
+// current state, the original block's 8x8 opsin image, the ranked candidate list.  HBM
+// traffic is the compulsory ~1.5 KB per block; the kernel is bound by the dependent
+// FP64 chains (8x8 opsin polynomial, DJB FFT butterflies, the two in-order sums), not by
+// bandwidth.
+//
+// Per candidate (CompareBlock): integer IDCT of the changed component -> edge replicate
+// (ToPixels, output_image.cc:85-96) -> YCbCr->RGB -> sRGB LUT -> 8x8 OpsinDynamicsImage
+// (r=2 blur with border renormalisation on columns/rows 0,1,6,7) -> per-channel
+// difference in double -> ButteraugliBlockDiff (:382-411): 4*mean^2 with the mean summed
+// in index order, 2-D real FFT (RealFFT8 rows, FFT8 / RealFFT8 columns, :154-380) and the
+// CSF-weighted power sum in index order -> sqrt(sum_c diff_c * mask_c(corner)).
+#pragma once
+#include "gz_common.h"
+#include "gz_kernels_block.h"
+#include "gz_kernels_blur.h"
+#include "gz_math.h"
+
+namespace gz {
+
+// GetContrastSensitivityMatrix, butteraugli_comparator.cc:93-134 (entries 4..36 are read).
+GZ_CONST double kCsf8x8[37] = {
+  0.0, 0.0, 0.0, 0.0,
+  0.3831134973, 0.676303603859, 1.1550451483, 8,
+  8, 0.692062533689, 0.847511538605, 0.498250875965, 0.36198671102, 0.308982169883,
+  0.1312701920435, 4.71274312228,
+  1.1550451483, 0.847511538605, 4.71274312228, 0.991205724152, 1.30229591239,
+  0.627264168628, 0.4, 0.1312701920435,
+  0.676303603859, 0.498250875965, 0.991205724152, 0.5, 0.3831134973, 0.349686450518,
+  0.627264168628, 0.308982169883,
+  0.3831134973, 0.36198671102, 1.30229591239, 0.3831134973, 0.323078800177,
+};
+
+struct Cpx {
+  double re, im;
+};
+
+#define GZ_SQRT_HALF 0.70710678118654752440084436210484903
+
+// RealFFT8 (butteraugli_comparator.cc:282-353) in single-assignment form with the final
+// output order; one rounding per written operation, same association as the reference.
+GZ_DEVFN void real_fft8(const double a0, const double a1, const double a2, const double a3,
+                        const double a4, const double a5, const double a6, const double a7,
+                        Cpx* F) {
+  const double d26 = a2 - a6, s26 = a6 + a2;
+  const double d04 = a0 - a4, s04 = a4 + a0;
+  const double d15 = a1 - a5, s15 = a5 + a1;
+  const double d37 = a3 - a7, s37 = a7 + a3;
+  const double nd37 = -d37, nd26 = -d26;
+  const double m6 = (d15 - d37) * GZ_SQRT_HALF;
+  const double m1 = (d15 + d37) * GZ_SQRT_HALF;
+  const double m5 = (nd37 - d15) * GZ_SQRT_HALF;
+  const double m2 = (nd37 + d15) * GZ_SQRT_HALF;
+  const double e = s26 + s04, o = s37 + s15;
+  const double t3 = s15 - s37, t1 = s04 - s26;
+  F[0].re = e + o;      F[0].im = 0.0;
+  F[1].re = m2 + d04;   F[1].im = m5 + nd26;
+  F[2].re = t1;         F[2].im = -t3;
+  F[3].re = d04 - m6;   F[3].im = d26 - m1;
+  F[4].re = e - o;      F[4].im = 0.0;
+  F[5].re = d04 - m2;   F[5].im = nd26 - m5;
+  F[6].re = t1;         F[6].im = t3;
+  F[7].re = m6 + d04;   F[7].im = m1 + d26;
+}
+
+// FFT8 + FFT4 (butteraugli_comparator.cc:154-277), complex input, final output order.
+GZ_DEVFN void fft8(const Cpx* a, Cpx* F) {
+  const double I0 = a[4].im + a[0].im, dI04 = a[0].im - a[4].im;
+  const double R2 = a[6].re + a[2].re, dR26 = a[2].re - a[6].re;
+  const double a6im = dI04 - dR26, a4im = dI04 + dR26;
+  const double dI26 = a[2].im - a[6].im, I2 = a[6].im + a[2].im;
+  const double dR04 = a[0].re - a[4].re, R0 = a[4].re + a[0].re;
+  const double a4re = dR04 - dI26, a6re = dR04 + dI26;
+  const double dR15 = a[1].re - a[5].re, R1 = a[5].re + a[1].re;
+  const double dI37 = a[3].im - a[7].im, I3 = a[7].im + a[3].im;
+  const double u1 = dR15 - dI37, u3 = dR15 + dI37;
+  const double dI15 = a[1].im - a[5].im, I1 = a[5].im + a[1].im;
+  const double dR37 = a[3].re - a[7].re, R3 = a[7].re + a[3].re;
+  const double u2 = dI15 - dR37, u4 = dI15 + dR37;
+  const double m6 = (u1 - u4) * GZ_SQRT_HALF;
+  const double m1 = (u1 + u4) * GZ_SQRT_HALF;
+  const double m5 = (u2 - u3) * GZ_SQRT_HALF;
+  const double m2 = (u2 + u3) * GZ_SQRT_HALF;
+  const double e = R2 + R0, o = R3 + R1, t1 = R0 - R2, t3 = R1 - R3;
+  const double f = I2 + I0, g = I3 + I1, t2 = I0 - I2, t4 = I1 - I3;
+  F[0].re = e + o;       F[0].im = f + g;
+  F[1].re = m2 + a6re;   F[1].im = m5 + a6im;
+  F[2].re = t1 + t4;     F[2].im = t2 - t3;
+  F[3].re = a4re - m6;   F[3].im = a4im - m1;
+  F[4].re = e - o;       F[4].im = f - g;
+  F[5].re = a6re - m2;   F[5].im = a6im - m5;
+  F[6].re = t1 - t4;     F[6].im = t2 + t3;
+  F[7].re = m6 + a4re;   F[7].im = m1 + a4im;
+}
+
+struct SearchArgs {
+  const int16_t* coeffs;        // candidate image coefficients [3][nb][64]
+  const int32_t* rank_off;      // [nb+1]
+  const uint8_t* rank_idx;      // host-ranked input_order (processor.cc:381-400)
+  const uint8_t* rgb;           // original sRGB image
+  const float* srgb_lut;        // 256 floats
+  const float* block_mask;      // [3][nb]: mask_xyz_[c](8*by, 8*bx)
+  int w, h, bw, nb;
+  int lookahead;                // Params::zeroing_greedy_lookahead
+  float limit;                  // Comparator::BlockErrorLimit()
+  Taps<2> taps;                 // sigma 1.2
+  float scale_lo[2], scale_hi[2];   // border scales for an axis of length 8, border_ratio 0
+  int32_t* out_cnt;             // [nb]
+  uint8_t* out_idx;             // [nb][192]
+  float* out_err;               // [nb][192]
+};
+
+struct SearchLds {
+  short coef[192];
+  int in[64], col[64];
+  int ycc[3][64];       // pixel cache of the current (processed) block
+  int cpx[64];          // changed component of the candidate
+  float lin[3][64];
+  float tmp[3][64];
+  float x0[3][64];      // original block's opsin image (per_block_pregamma_)
+  double d[3][64];
+  Cpx rowf[3][8][5];    // row FFT outputs F0..F4
+  double pw[3][40];     // |.|^2 * 0.000064 for flat indices 4..36
+  double red[4];
+  float lut[256];
+  unsigned char list[192];
+  unsigned char oidx[192];
+  float oerr[192];
+};
+
+// Integer IDCT of s.coef[c] with coefficient `zero_k` forced to 0 (or -1: none); result of
+// this lane's pixel returned, and left in `dst[lane]` after the trailing barrier.
+GZ_DEVFN void idct_component(SearchLds& s, int c, int zero_k, int lane, int* dst) {
+  const int iy = lane >> 3, ix = lane & 7;
+  s.in[lane] = lane == zero_k ? 0 : (int)s.coef[64 * c + lane];
+  __syncthreads();
+  int acc = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s.in[8 * u + ix];
+  s.col[lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  __syncthreads();
+  acc = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s.col[8 * iy + u];
+  dst[lane] = clamp255((acc + (257 << 17)) >> 18);
+  __syncthreads();
+}
+
+// 5-tap blur along one axis of the 8x8 tile held in `src` (Convolution on an 8-wide image:
+// positions 2..5 interior, 0,1,6,7 border).
+GZ_DEVFN float blur8(const float* src, int pos, int base, int stride, const SearchArgs& a) {
+  float sum = 0.0f;
+  if (pos >= 2 && pos < 6) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sum += src[base + (pos - 2 + j) * stride] * a.taps.ks[j];
+    return sum;
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int p = pos - 2 + j;
+    if (p >= 0 && p < 8) sum += src[base + p * stride] * a.taps.k[j];
+  }
+  return sum * (pos < 2 ? a.scale_lo[pos] : a.scale_hi[7 - pos]);
+}
+
+// 8x8 OpsinDynamicsImage of s.lin -> this lane's (x, y, b).
+GZ_DEVFN void opsin8x8(SearchLds& s, int lane, const SearchArgs& a, float* ox, float* oy,
+                       float* ob) {
+  const int iy = lane >> 3, ix = lane & 7;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s.tmp[c][lane] = blur8(s.lin[c], ix, 8 * iy, 1, a);
+  __syncthreads();
+  float b[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) b[c] = blur8(s.tmp[c], iy, ix, 8, a);
+  opsin_pixel(b[0], b[1], b[2], s.lin[0][lane], s.lin[1][lane], s.lin[2][lane], ox, oy, ob);
+  __syncthreads();
+}
+
+// CompareBlock for the current block with coefficient `ci` (= c*64+k) zeroed.
+// Uniform result (every lane returns the same value).
+GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, int vw, int vh, float m0,
+                              float m1, float m2, const SearchArgs& a) {
+  const int cc = ci >> 6, kk = ci & 63;
+  idct_component(s, cc, kk, lane, s.cpx);
+  // edge replication + colour + LUT
+  const int iy = lane >> 3, ix = lane & 7;
+  const int sx = ix < vw ? ix : vw - 1, sy = iy < vh ? iy : vh - 1;
+  const int sp = 8 * sy + sx;
+  const int py = cc == 0 ? s.cpx[sp] : s.ycc[0][sp];
+  const int pcb = (cc == 1 ? s.cpx[sp] : s.ycc[1][sp]) - 128;
+  const int pcr = (cc == 2 ? s.cpx[sp] : s.ycc[2][sp]) - 128;
+  const int half = 1 << 15;
+  const int r = clamp255(py + ((91881 * pcr + half) >> 16));
+  const int g = clamp255(py + ((-46802 * pcr + (-22554 * pcb + half)) >> 16));
+  const int b = clamp255(py + ((116130 * pcb + half) >> 16));
+  s.lin[0][lane] = s.lut[r];
+  s.lin[1][lane] = s.lut[g];
+  s.lin[2][lane] = s.lut[b];
+  __syncthreads();
+  float x, y, z;
+  opsin8x8(s, lane, a, &x, &y, &z);
+  s.d[0][lane] = (double)s.x0[0][lane] - (double)x;
+  s.d[1][lane] = (double)s.x0[1][lane] - (double)y;
+  s.d[2][lane] = (double)s.x0[2][lane] - (double)z;
+  __syncthreads();
+  // mean term (lanes 0..2, in index order) and row FFTs (lanes 8..31)
+  double dc_term = 0.0;
+  if (lane < 3) {
+    double sum = 0.0;
+    for (int i = 0; i < 64; ++i) sum += s.d[lane][i];
+    const double avg = sum / 64;
+    dc_term = (4.0 * avg) * avg;
+  } else if (lane >= 8 && lane < 32) {
+    const int ch = (lane - 8) >> 3, row = (lane - 8) & 7;
+    const double* p = &s.d[ch][8 * row];
+    Cpx F[8];
+    real_fft8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], F);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s.rowf[ch][row][k] = F[k];
+  }
+  __syncthreads();
+  // column stage: 15 lanes; lane -> (channel, transposed row k)
+  if (lane < 15) {
+    const int ch = lane / 5, k = lane - 5 * ch;
+    Cpx F[8];
+    if (k == 0 || k == 4) {
+      real_fft8(s.rowf[ch][0][k].re, s.rowf[ch][1][k].re, s.rowf[ch][2][k].re,
+                s.rowf[ch][3][k].re, s.rowf[ch][4][k].re, s.rowf[ch][5][k].re,
+                s.rowf[ch][6][k].re, s.rowf[ch][7][k].re, F);
+    } else {
+      Cpx in[8];
+#pragma unroll
+      for (int x2 = 0; x2 < 8; ++x2) in[x2] = s.rowf[ch][x2][k];
+      fft8(in, F);
+    }
+#pragma unroll
+    for (int x2 = 0; x2 < 8; ++x2) {
+      double v = F[x2].re * F[x2].re + F[x2].im * F[x2].im;
+      v = v * 0.000064;
+      s.pw[ch][8 * k + x2] = v;
+    }
+  }
+  __syncthreads();
+  if (lane < 3) {
+    double acc = dc_term;   // diff_xyb[c] starts at 0.0: 0.0 + 4*avg*avg
+    for (int i = 4; i < 37; ++i) acc += kCsf8x8[i] * s.pw[lane][i];
+    s.red[lane] = acc;
+  }
+  __syncthreads();
+  double diff = 0.0;
+  diff += s.red[0] * (double)m0;
+  diff += s.red[1] * (double)m1;
+  diff += s.red[2] * (double)m2;
+  const float err = (float)sqrt(diff);
+  __syncthreads();
+  return err;
+}
+
+// grid = nb workgroups of 64 threads.
+__global__ __launch_bounds__(64) void k_block_search(SearchArgs a) {
+  __shared__ SearchLds s;
+  const int blk = blockIdx.x, lane = threadIdx.x;
+  const int bx = blk % a.bw, by = blk / a.bw;
+  const int xmin = 8 * bx, ymin = 8 * by;
+  const int vw = a.w - xmin < 8 ? a.w - xmin : 8;   // in-image width / height of the block
+  const int vh = a.h - ymin < 8 ? a.h - ymin : 8;
+  const int iy = lane >> 3, ix = lane & 7;
+  for (int i = lane; i < 256; i += 64) s.lut[i] = a.srgb_lut[i];
+  for (int c = 0; c < 3; ++c) s.coef[64 * c + lane] = a.coeffs[((size_t)c * a.nb + blk) * 64 + lane];
+  const int r0 = a.rank_off[blk];
+  int n = a.rank_off[blk + 1] - r0;
+  for (int i = lane; i < n; i += 64) s.list[i] = a.rank_idx[r0 + i];
+  __syncthreads();
+  // SwitchBlock (butteraugli_comparator.cc:427-455): original block, clamped gather
+  {
+    const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
+    const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
+    const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
+    s.lin[0][lane] = s.lut[p[0]];
+    s.lin[1][lane] = s.lut[p[1]];
+    s.lin[2][lane] = s.lut[p[2]];
+    __syncthreads();
+    float x0, y0, z0;
+    opsin8x8(s, lane, a, &x0, &y0, &z0);
+    s.x0[0][lane] = x0;
+    s.x0[1][lane] = y0;
+    s.x0[2][lane] = z0;
+  }
+  for (int c = 0; c < 3; ++c) idct_component(s, c, -1, lane, s.ycc[c]);
+  const float m0 = a.block_mask[blk], m1 = a.block_mask[a.nb + blk],
+              m2 = a.block_mask[2 * a.nb + blk];
+  int m = 0;
+  while (n > 0) {
+    float best_err = 1e17f;
+    int best_i = 0;
+    const int tries = n < a.lookahead ? n : a.lookahead;
+    for (int i = 0; i < tries; ++i) {
+      const float e = eval_candidate(s, (int)s.list[i], lane, vw, vh, m0, m1, m2, a);
+      const float max_err = e > 0.0f ? e : 0.0f;   // std::max(0, err)
+      if (max_err < best_err) {
+        best_err = max_err;
+        best_i = i;
+      }
+    }
+    const int ci = (int)s.list[best_i];
+    __syncthreads();
+    if (lane == 0) {
+      s.coef[ci] = 0;
+      s.oidx[m] = (unsigned char)ci;
+      s.oerr[m] = best_err;
+    }
+    // erase list[best_i]
+    for (int base = 0; base < n; base += 64) {
+      const int j = base + lane;
+      unsigned char v = 0;
+      const bool mv = j >= best_i && j < n - 1;
+      if (mv) v = s.list[j + 1];
+      __syncthreads();
+      if (mv) s.list[j] = v;
+      __syncthreads();
+    }
+    ++m;
+    --n;
+    idct_component(s, ci >> 6, -1, lane, s.ycc[ci >> 6]);
+  }
+  __syncthreads();
+  // monotone minimum from the end + cut at the block error limit (processor.cc:447-459)
+  if (lane == 0) {
+    float min_err = 1e10f;
+    for (int i = m - 1; i >= 0; --i) {
+      min_err = s.oerr[i] < min_err ? s.oerr[i] : min_err;
+      s.oerr[i] = min_err;
+    }
+    int num = 0;
+    while (num < m && s.oerr[num] <= a.limit) ++num;
+    s.red[3] = (double)num;
+    a.out_cnt[blk] = num;
+  }
+  __syncthreads();
+  const int num = (int)s.red[3];
+  for (int i = lane; i < num; i += 64) {
+    a.out_idx[(size_t)blk * 192 + i] = s.oidx[i];
+    a.out_err[(size_t)blk * 192 + i] = s.oerr[i];
+  }
+}
+
+// Picks mask planes at block corners: out[c][blk] = mask[c](8*by, 8*bx).
+__global__ __launch_bounds__(256) void k_gather_block_corners(const float* m0, const float* m1,
+                                                              const float* m2, int pitch, int bw,
+                                                              int nb, float* out) {
+  const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk >= nb) return;
+  const size_t idx = (size_t)(8 * (blk / bw)) * pitch + 8 * (blk % bw);
+  out[blk] = m0[idx];
+  out[nb + blk] = m1[idx];
+  out[2 * nb + blk] = m2[idx];
+}
+
+}  // namespace gz

@@ -126,6 +126,26 @@ int gz_time_compare(gz_ctx* ctx, int iters, float* total_ms);
 int gz_block_weights(gz_ctx* ctx, int direction, int max_block_dist, double target_mul,
                      int use_distmap, float* block_weight);
 
+/* Per-block zeroing search ---------------------------------------------------------
+ * gz_block_zeroing_orders: phase A of Processor::SelectFrequencyMasking
+ * (processor.cc:554-590) for comp_mask 7 on a 4:4:4 image: for every block,
+ * ComputeBlockZeroingOrder (processor.cc:364-467) with CompareBlock
+ * (butteraugli_comparator.cc:457-488) evaluated on the device, between the reference's
+ * StartBlockComparisons / FinishBlockComparisons (:415-425).  Operates on the current
+ * candidate (e.g. after gz_quantize(best_q)) and the original coefficients.
+ *   lookahead = Params::zeroing_greedy_lookahead (3), new_model =
+ *   Params::new_zeroing_model (processor.h:35-36).
+ * Outputs are the reference's CSR arrays: candidate_coeff_offsets[nb+1],
+ * candidate_coeffs[], candidate_coeff_errors[] (processor.cc:554-558).  cap = capacity of
+ * idx/err in elements (nb*189 always suffices); if too small, GZ_E_ARG is returned and
+ * offsets[nb] holds the required size. */
+int gz_block_zeroing_orders(gz_ctx* ctx, int lookahead, int new_model, int32_t* offsets,
+                            uint8_t* idx, float* err, int cap);
+/* Host-only helper, exported for tests: the ranked input_order of
+ * ComputeBlockZeroingOrder (processor.cc:381-400) for every block, as CSR. */
+int gz_rank_zeroing_candidates(const int16_t* coeffs, const int16_t* orig, int nb,
+                               int new_model, int32_t* offsets, uint8_t* idx);
+
 /* Stage probes (parity tests) -----------------------------------------------------
  * Each runs ONE stage of the pipeline on host-provided input through the same kernels
  * gz_compare uses.  They exist so that tests can localise a divergence; they are not on

@@ -18,6 +18,8 @@
 
 #include "malta_offsets.inc"
 
+extern "C" void orc_comparator_block_mask(void* p, float* mask3);
+
 namespace {
 
 typedef std::vector<float> Plane;
@@ -728,6 +730,197 @@ void reconstruct(const int16_t* coeffs, int w, int h, const int* q, int16_t* coe
         linear[c * n + p] = static_cast<float>(lut[ycc[3 * p + c]]);
 }
 
+
+// ============================================================ block search (a18, a21) ==
+
+// ref: butteraugli_comparator.cc:93-134 (GetContrastSensitivityMatrix); entries 4..36 are
+// the ones ButteraugliBlockDiff reads.
+const double kCsf8x8[37] = {
+  0.0, 0.0, 0.0, 0.0,
+  0.3831134973, 0.676303603859, 1.1550451483, 8,
+  8, 0.692062533689, 0.847511538605, 0.498250875965, 0.36198671102, 0.308982169883,
+  0.1312701920435, 4.71274312228,
+  1.1550451483, 0.847511538605, 4.71274312228, 0.991205724152, 1.30229591239,
+  0.627264168628, 0.4, 0.1312701920435,
+  0.676303603859, 0.498250875965, 0.991205724152, 0.5, 0.3831134973, 0.349686450518,
+  0.627264168628, 0.308982169883,
+  0.3831134973, 0.36198671102, 1.30229591239, 0.3831134973, 0.323078800177,
+};
+
+struct Cpx { double re, im; };
+const double kSqrtHalf = 0.70710678118654752440084436210484903;
+
+// ref: butteraugli_comparator.cc:282-353 (RealFFT8) in single-assignment form, outputs
+// already in the final (reordered) positions F[0..7].  Every + - * is one rounding, in
+// the reference's association.
+inline void real_fft8(const double* a, Cpx* F) {
+  const double d26 = a[2] - a[6], s26 = a[6] + a[2];
+  const double d04 = a[0] - a[4], s04 = a[4] + a[0];
+  const double d15 = a[1] - a[5], s15 = a[5] + a[1];
+  const double d37 = a[3] - a[7], s37 = a[7] + a[3];
+  const double nd37 = -d37, nd26 = -d26;
+  const double m6 = (d15 - d37) * kSqrtHalf;
+  const double m1 = (d15 + d37) * kSqrtHalf;
+  const double m5 = (nd37 - d15) * kSqrtHalf;
+  const double m2 = (nd37 + d15) * kSqrtHalf;
+  const double e = s26 + s04, o = s37 + s15;
+  const double t3 = s15 - s37, t1 = s04 - s26;
+  F[0] = {e + o, 0.0};
+  F[1] = {m2 + d04, m5 + nd26};   // pre-reorder out[6]
+  F[2] = {t1, -t3};               // out[3]
+  F[3] = {d04 - m6, d26 - m1};    // out[5]
+  F[4] = {e - o, 0.0};            // out[1]
+  F[5] = {d04 - m2, nd26 - m5};   // out[7]
+  F[6] = {t1, t3};                // out[2]
+  F[7] = {m6 + d04, m1 + d26};    // out[4]
+}
+
+// ref: butteraugli_comparator.cc:154-277 (FFT4 + FFT8), complex in, final order out.
+inline void fft8(const Cpx* a, Cpx* F) {
+  const double I0 = a[4].im + a[0].im, dI04 = a[0].im - a[4].im;
+  const double R2 = a[6].re + a[2].re, dR26 = a[2].re - a[6].re;
+  const double a6im = dI04 - dR26, a4im = dI04 + dR26;
+  const double dI26 = a[2].im - a[6].im, I2 = a[6].im + a[2].im;
+  const double dR04 = a[0].re - a[4].re, R0 = a[4].re + a[0].re;
+  const double a4re = dR04 - dI26, a6re = dR04 + dI26;
+  const double dR15 = a[1].re - a[5].re, R1 = a[5].re + a[1].re;
+  const double dI37 = a[3].im - a[7].im, I3 = a[7].im + a[3].im;
+  const double u1 = dR15 - dI37, u3 = dR15 + dI37;
+  const double dI15 = a[1].im - a[5].im, I1 = a[5].im + a[1].im;
+  const double dR37 = a[3].re - a[7].re, R3 = a[7].re + a[3].re;
+  const double u2 = dI15 - dR37, u4 = dI15 + dR37;
+  const double m6 = (u1 - u4) * kSqrtHalf;
+  const double m1 = (u1 + u4) * kSqrtHalf;
+  const double m5 = (u2 - u3) * kSqrtHalf;
+  const double m2 = (u2 + u3) * kSqrtHalf;
+  const Cpx o5 = {a4re - m6, a4im - m1};
+  const Cpx o4 = {m6 + a4re, m1 + a4im};
+  const Cpx o7 = {a6re - m2, a6im - m5};
+  const Cpx o6 = {m2 + a6re, m5 + a6im};
+  // FFT4 on (R0,I0) (R1,I1) (R2,I2) (R3,I3)
+  const double e = R2 + R0, o = R3 + R1, t1 = R0 - R2, t3 = R1 - R3;
+  const double f = I2 + I0, g = I3 + I1, t2 = I0 - I2, t4 = I1 - I3;
+  const Cpx o0 = {e + o, f + g};
+  const Cpx o1 = {e - o, f - g};
+  const Cpx o2 = {t1 - t4, t2 + t3};
+  const Cpx o3 = {t1 + t4, t2 - t3};
+  F[0] = o0; F[1] = o6; F[2] = o3; F[3] = o5; F[4] = o1; F[5] = o7; F[6] = o2; F[7] = o4;
+}
+
+// ref: butteraugli_comparator.cc:357-380 (ButteraugliFFTSquared): fills p[4..36].
+void fft_squared(const double* block, double* p) {
+  Cpx C[64], T[64];
+  for (int y = 0; y < 8; ++y) real_fft8(block + 8 * y, C + 8 * y);
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j) T[8 * i + j] = C[8 * j + i];
+  double r0[8], r1[8];
+  for (int x = 0; x < 8; ++x) {
+    r0[x] = T[x].re;
+    r1[x] = T[32 + x].re;
+  }
+  real_fft8(r0, T);
+  real_fft8(r1, T + 32);
+  for (int y = 1; y < 4; ++y) {
+    Cpx in[8];
+    memcpy(in, T + 8 * y, sizeof(in));
+    fft8(in, T + 8 * y);
+  }
+  for (int i = 4; i < 37; ++i) {
+    double v = T[i].re * T[i].re + T[i].im * T[i].im;
+    v *= 0.000064;
+    p[i] = v;
+  }
+}
+
+// ref: butteraugli_comparator.cc:382-411 (ButteraugliBlockDiff)
+void block_diff(const double* xyb0, const double* xyb1, double* diff_xyb) {
+  double avg[3] = {0.0, 0.0, 0.0};
+  for (int i = 0; i < 192; ++i) avg[i / 64] += xyb0[i] - xyb1[i];
+  for (int c = 0; c < 3; ++c) {
+    const double a = avg[c] / 64;
+    diff_xyb[c] += 4.0 * a * a;
+  }
+  double d[3][64], p[3][64];
+  for (int c = 0; c < 3; ++c) {
+    for (int i = 0; i < 64; ++i) d[c][i] = xyb0[64 * c + i] - xyb1[64 * c + i];
+    fft_squared(d[c], p[c]);
+  }
+  for (int i = 4; i < 37; ++i) {
+    const double w = kCsf8x8[i];
+    diff_xyb[0] += w * p[0][i];
+    diff_xyb[1] += w * p[1][i];
+    diff_xyb[2] += w * p[2][i];
+  }
+}
+
+// 8x8 OpsinDynamicsImage of a packed 3x64 linear-RGB block (SwitchBlock :427-455 and
+// CompareBlock :466-470 both go through the general image code).
+void opsin8x8(const float* lin3x64, float* xyb3x64) { opsin(lin3x64, 8, 8, xyb3x64); }
+
+struct BlockSearch {
+  const Comparator* cmp;
+  Plane mask;            // mask_xyz_ (3 planes)
+  float orig_xyb[192];   // per_block_pregamma_ of the current block
+  int bx, by;
+};
+
+// ref: butteraugli_comparator.cc:427-455
+void switch_block(BlockSearch* bs, int bx, int by) {
+  const Comparator* c = bs->cmp;
+  bs->bx = bx;
+  bs->by = by;
+  const double* lut = srgb_table();
+  float lin[192];
+  for (int iy = 0, i = 0; iy < 8; ++iy)
+    for (int ix = 0; ix < 8; ++ix, ++i) {
+      const int x = std::min(8 * bx + ix, c->w - 1);
+      const int y = std::min(8 * by + iy, c->h - 1);
+      const size_t px = (size_t)y * c->w + x;
+      for (int ch = 0; ch < 3; ++ch) lin[64 * ch + i] = lut[c->rgb[3 * px + ch]];
+    }
+  opsin8x8(lin, bs->orig_xyb);
+}
+
+// ref: butteraugli_comparator.cc:457-488 (CompareBlock) for a candidate 3x64 coefficient
+// block; pixels past the image edge replicate the last in-image column / row
+// (OutputImageComponent::ToPixels, output_image.cc:85-96).
+double compare_block(const BlockSearch* bs, const int16_t* block192) {
+  const Comparator* c = bs->cmp;
+  const double* lut = srgb_table();
+  uint8_t ycc[192];
+  for (int ch = 0; ch < 3; ++ch) orc_idct_block(block192 + 64 * ch, ycc + 64 * ch);
+  const int xmin = 8 * bs->bx, ymin = 8 * bs->by;
+  float lin[192];
+  for (int iy = 0, i = 0; iy < 8; ++iy)
+    for (int ix = 0; ix < 8; ++ix, ++i) {
+      const int sx = std::min(xmin + ix, c->w - 1) - xmin;
+      const int sy = std::min(ymin + iy, c->h - 1) - ymin;
+      uint8_t px[3] = {ycc[8 * sy + sx], ycc[64 + 8 * sy + sx], ycc[128 + 8 * sy + sx]};
+      ycc_to_rgb(px[0], px[1], px[2], px);
+      for (int ch = 0; ch < 3; ++ch) lin[64 * ch + i] = static_cast<float>(lut[px[ch]]);
+    }
+  float xyb1[192];
+  opsin8x8(lin, xyb1);
+  double b0[192], b1[192];
+  for (int i = 0; i < 192; ++i) {
+    b0[i] = bs->orig_xyb[i];
+    b1[i] = xyb1[i];
+  }
+  double diff_xyz[3] = {0.0, 0.0, 0.0};
+  block_diff(b0, b1, diff_xyz);
+  const size_t n = (size_t)c->w * c->h;
+  double diff = 0.0;
+  for (int ch = 0; ch < 3; ++ch)
+    diff += diff_xyz[ch] * bs->mask[ch * n + (size_t)ymin * c->w + xmin];
+  return sqrt(diff);
+}
+
+void init_block_search(BlockSearch* bs, const Comparator* c) {
+  bs->cmp = c;
+  bs->mask.resize((size_t)3 * c->w * c->h);
+  orc_comparator_block_mask((void*)c, bs->mask.data());
+}
+
 }  // namespace
 
 // ==================================================================== C surface ==
@@ -945,6 +1138,111 @@ void orc_comparator_block_mask(void* p, float* mask3) {
   linear_from_rgb8(c->rgb.data(), c->w, c->h, lin.data());
   opsin(lin.data(), c->w, c->h, xyb.data());
   mask(xyb.data(), xyb.data() + n, xyb.data(), xyb.data() + n, c->w, c->h, mask3, nullptr);
+}
+
+
+double orc_comparator_compare_block(void* p, const int16_t* coeffs, int bx, int by) {
+  Comparator* c = (Comparator*)p;
+  BlockSearch bs;
+  init_block_search(&bs, c);
+  switch_block(&bs, bx, by);
+  const int bw = (c->w + 7) / 8, nb = bw * ((c->h + 7) / 8);
+  int16_t blk[192];
+  for (int ch = 0; ch < 3; ++ch)
+    memcpy(blk + 64 * ch, coeffs + ((size_t)ch * nb + (size_t)by * bw + bx) * 64, 128);
+  return compare_block(&bs, blk);
+}
+
+// ref: processor.cc:364-467 (ComputeBlockZeroingOrder) over all blocks as in
+// SelectFrequencyMasking phase A (:554-590), comp_mask 7, 4:4:4.
+int orc_block_zeroing_orders(void* p, const int16_t* coeffs, const int16_t* orig,
+                             int lookahead, int new_model, int32_t* offsets, uint8_t* idx,
+                             float* err, int cap) {
+  Comparator* c = (Comparator*)p;
+  const int bw = (c->w + 7) / 8, bh = (c->h + 7) / 8, nb = bw * bh;
+  BlockSearch bs;
+  init_block_search(&bs, c);
+  static const uint8_t oldCsf[64] = {
+      10, 10, 20, 40, 60, 70, 80, 90, 10, 20, 30, 60, 70, 80, 90, 90,
+      20, 30, 60, 70, 80, 90, 90, 90, 40, 60, 70, 80, 90, 90, 90, 90,
+      60, 70, 80, 90, 90, 90, 90, 90, 70, 80, 90, 90, 90, 90, 90, 90,
+      80, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90};
+  static const int zigzag[64] = {
+      0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42,
+      3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+      10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+      21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+  static const double kWeight[3] = {1.0, 0.22, 0.20};
+  int total = 0;
+  for (int by = 0, bix = 0; by < bh; ++by) {
+    for (int bx = 0; bx < bw; ++bx, ++bix) {
+      int16_t block[192], oblock[192];
+      for (int ch = 0; ch < 3; ++ch) {
+        memcpy(block + 64 * ch, coeffs + ((size_t)ch * nb + bix) * 64, 128);
+        memcpy(oblock + 64 * ch, orig + ((size_t)ch * nb + bix) * 64, 128);
+      }
+      std::vector<std::pair<int, float> > input_order;
+      for (int ch = 0; ch < 3; ++ch)
+        for (int k = 1; k < 64; ++k) {
+          const int i = ch * 64 + k;
+          if (block[i] != 0) {
+            float score;
+            if (new_model)
+              score = std::abs(oblock[i]) * kOrderCsf[i] + kOrderBias[i];
+            else
+              score = static_cast<float>((std::abs(oblock[i]) - zigzag[k] / 64.0) *
+                                         kWeight[ch] / oldCsf[k]);
+            input_order.push_back(std::make_pair(i, score));
+          }
+        }
+      std::sort(input_order.begin(), input_order.end(),
+                [](const std::pair<int, float>& a, const std::pair<int, float>& b) {
+                  return a.second < b.second; });
+      int16_t processed[192];
+      memcpy(processed, block, sizeof(processed));
+      switch_block(&bs, bx, by);
+      std::vector<std::pair<int, float> > out;
+      while (!input_order.empty()) {
+        float best_err = 1e17f;
+        int best_i = 0;
+        for (size_t i = 0; i < std::min<size_t>(lookahead, input_order.size()); ++i) {
+          int16_t cand[192];
+          memcpy(cand, processed, sizeof(cand));
+          cand[input_order[i].first] = 0;
+          float max_err = 0;
+          if (8 * bx < c->w && 8 * by < c->h) {
+            const float e = static_cast<float>(compare_block(&bs, cand));
+            max_err = std::max(max_err, e);
+          }
+          if (max_err < best_err) {
+            best_err = max_err;
+            best_i = (int)i;
+          }
+        }
+        const int ci = input_order[best_i].first;
+        processed[ci] = 0;
+        input_order.erase(input_order.begin() + best_i);
+        out.push_back(std::make_pair(ci, best_err));
+      }
+      float min_err = 1e10;
+      for (int i = (int)out.size() - 1; i >= 0; --i) {
+        min_err = std::min(min_err, out[i].second);
+        out[i].second = min_err;
+      }
+      size_t num = 0;
+      while (num < out.size() && out[num].second <= c->target) ++num;
+      offsets[bix] = total;
+      for (size_t i = 0; i < num; ++i) {
+        if (total < cap) {
+          idx[total] = (uint8_t)out[i].first;
+          err[total] = out[i].second;
+        }
+        ++total;
+      }
+    }
+  }
+  offsets[nb] = total;
+  return total <= cap ? total : -total;
 }
 
 }  // extern "C"

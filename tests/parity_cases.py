@@ -128,3 +128,19 @@ def case_compare(L, w, h, x0=0, y0=0, qscales=(1, 3, 9), target=0.971769):
                                       oc.block_weights(direction, r, 1.0, edm),
                                       "block weights")
     oc.close()
+
+
+def case_block_search(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
+    """Phase A of SelectFrequencyMasking through gz_block_zeroing_orders."""
+    rgb = images.crop(w, h, x0, y0) if max(w, h) <= 444 else images.tiled(w, h)
+    oc = oracle.comparator(rgb, target)
+    with L.context(rgb, target) as ctx:
+        co = ctx.encode_rgb()
+        cq = ctx.quantize(np.full((3, 64), qs, np.int32))
+        off, idx, err = ctx.block_zeroing_orders()
+        eoff, eidx, eerr = oc.block_zeroing_orders(cq, co)
+        assert_bits_equal(off, eoff, "candidate offsets")
+        assert_bits_equal(idx, eidx, "candidate coefficient indices")
+        assert_bits_equal(err, eerr, "candidate errors")
+        assert off[-1] > 0
+    oc.close()

@@ -119,3 +119,14 @@ def test_full_size_properties_1080p(L):
         oc.close()
         assert_bits_equal(m1, em, "1080p distmap vs oracle")
         assert d1 == ed
+
+
+def test_block_search_small_ragged(L):
+    pc.case_block_search(L, 45, 27)
+    pc.case_block_search(L, 64, 40, x0=10, y0=10, qs=2)
+
+
+def test_block_search_bees(L):
+    """Phase A on the whole BASELINE config-1 image (1848 blocks, ~300k CompareBlock
+    evaluations) against the oracle, bit for bit."""
+    pc.case_block_search(L, 444, 258, x0=0, y0=0, qs=2)

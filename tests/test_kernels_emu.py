@@ -39,3 +39,7 @@ def test_stages(L, wh):
 
 def test_compare(L):
     pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(1, 5))
+
+
+def test_block_search(L):
+    pc.case_block_search(L, 45, 27)

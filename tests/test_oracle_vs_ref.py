@@ -191,3 +191,23 @@ def test_comparator_compare_and_weights():
                     oc.block_weights(direction, r, 1.0, rmap, w0),
                     rc.block_weights(direction, r, 1.0, rmap, w0), "block weights")
     assert_bits_equal(oc.block_mask(), rc.block_mask(), "block mask")
+
+
+def test_compare_block_and_zeroing_orders():
+    """Phase A of SelectFrequencyMasking: CompareBlock values and the per-block candidate
+    lists (processor.cc:364-467,554-590), including ragged right/bottom edge blocks."""
+    w, h = 61, 43
+    rgb = images.crop(w, h, 300, 150)
+    target = 0.971769
+    co = ref.encode_rgb(rgb)
+    q = np.full((3, 64), 3, np.int32)
+    cq, _, _ = ref.reconstruct(co, w, h, q)
+    oc, rc = oracle.comparator(rgb, target), ref.comparator(rgb, target)
+    for bx, by in [(0, 0), (3, 2), (7, 5), (7, 0), (0, 5)]:
+        assert oc.compare_block(cq, bx, by) == rc.compare_block(cq, bx, by), (bx, by)
+    oo, oi, oe = oc.block_zeroing_orders(cq, co)
+    ro, ri, re_ = rc.block_zeroing_orders(cq, co)
+    assert_bits_equal(oo, ro, "candidate offsets")
+    assert_bits_equal(oi, ri, "candidate coefficient indices")
+    assert_bits_equal(oe, re_, "candidate errors")
+    assert ro[-1] > 100

@@ -24,6 +24,7 @@
 #include "gz_kernels_blur.h"
 #include "gz_kernels_diff.h"
 #include "gz_kernels_search.h"
+#include "order_tables_generated.h"   // host-side csf/bias of order.inc
 
 using namespace gz;
 

@@ -59,3 +59,38 @@ def test_argument_errors_and_no_silent_fallback(lib_path):
 def test_missing_library_is_an_error(tmp_path):
     with pytest.raises(capi.GuetzliAmdError):
         capi.Library(str(tmp_path / "nope.so"))
+
+
+def test_host_side_candidate_ranking(lib_path):
+    """gz_rank_zeroing_candidates is pure host code of the PRODUCT library (hipcc-built):
+    input_order of ComputeBlockZeroingOrder (processor.cc:381-400).  Checked against a
+    numpy restatement using the order.inc tables (host tables must not live in device
+    constant memory)."""
+    import re
+    import images
+    from checkers import oracle
+    src = open(os.path.join(ROOT, "oracle", "malta_offsets.inc")).read()
+
+    def tab(name):
+        m = re.search(r"%s\[192\] = \{(.*?)\};" % name, src, re.S)
+        return np.array([float(v.strip().rstrip("f")) for v in m.group(1).split(",") if v.strip()],
+                        np.float32)
+    csf, bias = tab("kOrderCsf"), tab("kOrderBias")
+    rgb = images.crop(64, 48, 100, 100)
+    co = oracle.encode_rgb(rgb)
+    cq, _, _ = oracle.reconstruct(co, 64, 48, np.full((3, 64), 3, np.int32))
+    nb = co.shape[1]
+    L = capi.Library(lib_path)
+    off = np.zeros(nb + 1, np.int32)
+    idx = np.zeros(nb * 192, np.uint8)
+    assert L.lib.gz_rank_zeroing_candidates(cq.ctypes.data, co.ctypes.data, nb, 1,
+                                            off.ctypes.data, idx.ctypes.data) == 0
+    for b in range(nb):
+        cand = [(c * 64 + k) for c in range(3) for k in range(1, 64) if cq[c, b, k] != 0]
+        score = np.array([np.float32(np.float32(abs(int(co[i // 64, b, i % 64]))) * csf[i]) + bias[i]
+                          for i in cand], np.float32)
+        if len(set(score.tolist())) != len(score):
+            continue   # ties: order is libstdc++-specific, covered by the GPU parity tests
+        exp = [cand[j] for j in np.argsort(score, kind="stable")]
+        assert idx[off[b]:off[b + 1]].tolist() == exp, b
+    assert off[-1] > 500

@@ -55,5 +55,37 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "libguetzli_amd_host.so")
+HOST_SOURCES = ["jpeg_writer.cc", "processor.cc"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+              "-Wno-unused-parameter"]
+
+
+def build_host(force=False, verbose=False, device_lib=None, out=None):
+    """The host search driver (C++, g++) linked against the C-ABI library."""
+    device_lib = device_lib or LIB
+    out = out or HOST_LIB
+    srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, h) for h in ("jpeg_writer.h", "processor.h")] + \
+        [os.path.join(os.path.dirname(HERE), "include", "guetzli_amd.h"), device_lib]
+    if not force and os.path.exists(out) and \
+            all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps if os.path.exists(d)):
+        return out
+    if shutil.which("g++") is None:
+        if os.path.exists(out):
+            return out
+        raise RuntimeError("g++ not found and no prebuilt host library")
+    libdir, libname = os.path.split(device_lib)
+    cmd = ["g++"] + HOST_FLAGS + srcs + ["-o", out, "-L" + libdir,
+                                         "-l:" + libname, "-Wl,-rpath," + libdir,
+                                         "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

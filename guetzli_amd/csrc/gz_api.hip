@@ -798,14 +798,22 @@ int gz_set_coeffs(gz_ctx* c, const int16_t* coeffs) {
 int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int16_t* blocks) {
   if (!c || n < 0 || (n > 0 && (!block_index || !blocks))) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
-  for (int i = 0; i < n; ++i) {
+  if (n == 0) return GZ_OK;
+  for (int i = 0; i < n; ++i)
     if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;
-    for (int comp = 0; comp < 3; ++comp)
-      HIPCHK(c, hipMemcpyAsync(c->d_cand + ((size_t)comp * c->nb + block_index[i]) * 64,
-                               blocks + ((size_t)i * 3 + comp) * 64, 128,
-                               hipMemcpyHostToDevice, c->stream));
+  if ((size_t)n > c->blkidx_cap) {
+    hipFree(c->d_blkidx); hipFree(c->d_blkdata);
+    c->d_blkidx = nullptr; c->d_blkdata = nullptr;
+    c->blkidx_cap = std::max<size_t>((size_t)n, std::min<size_t>((size_t)c->nb, 2 * c->blkidx_cap + 1024));
+    HIPCHK(c, hipMalloc((void**)&c->d_blkidx, sizeof(int32_t) * c->blkidx_cap));
+    HIPCHK(c, hipMalloc((void**)&c->d_blkdata, c->blkidx_cap * 384));
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_blkidx, block_index, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_blkdata, blocks, (size_t)n * 384, hipMemcpyHostToDevice, c->stream));
+  GZ_LAUNCH(k_scatter_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), c->stream,
+            (const int32_t*)c->d_blkidx, (const int16_t*)c->d_blkdata, n, c->nb, c->d_cand);
+  KCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
   return GZ_OK;
 }
 

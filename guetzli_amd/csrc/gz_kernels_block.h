@@ -241,6 +241,21 @@ __global__ __launch_bounds__(256) void k_fdct_blocks(int16_t* __restrict__ block
   if (live) blocks[(size_t)blk * 64 + lane] = s_blk[wave][lane];
 }
 
+// OutputImageComponent::SetCoeffBlock for a batch of blocks (output_image.cc:123-132):
+// blocks[i] = 3 x 64 coefficients (Y, Cb, Cr) of block index[i].  One wave per block.
+__global__ __launch_bounds__(256) void k_scatter_blocks(const int32_t* __restrict__ index,
+                                                        const int16_t* __restrict__ blocks,
+                                                        int n, int nb,
+                                                        int16_t* __restrict__ coeffs) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * kBlocksPerWG + wave;
+  if (i >= n) return;
+  const int b = index[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    coeffs[((size_t)c * nb + b) * 64 + lane] = blocks[((size_t)i * 3 + c) * 64 + lane];
+}
+
 // sRGB u8 packed -> 3 linear float planes (LinearRgb, butteraugli_comparator.cc:33-47).
 __global__ __launch_bounds__(256) void k_linear_from_rgb8(const uint8_t* __restrict__ rgb,
                                                           int w, int h, int pitch,

@@ -1,0 +1,85 @@
+"""Python binding of the host search driver (guetzli_amd/host, libguetzli_amd_host.so):
+guetzli_amd.process(rgb, quality=95) == guetzli::Process(params, stats, rgb, w, h, &out)
+with the numeric hot path on the MI355X.  No CPU fallback: the host library links the
+gfx950 C-ABI library and fails if no GPU is usable."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_HOST_LIB = os.path.join(HERE, "libguetzli_amd_host.so")
+
+
+class HostLibrary:
+    def __init__(self, path=DEFAULT_HOST_LIB):
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: run `python -m guetzli_amd.build`")
+        self.lib = C.CDLL(path)
+        self.lib.gzh_process.restype = C.c_long
+        self.lib.gzh_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_float,
+                                         C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                         C.c_void_p, C.c_long]
+        self.lib.gzh_write_jpeg.restype = C.c_long
+        self.lib.gzh_write_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_long]
+        self.lib.gzh_butteraugli_score_for_quality.restype = C.c_double
+        self.lib.gzh_butteraugli_score_for_quality.argtypes = [C.c_double]
+
+    def process(self, rgb, quality=95.0, target=None, device=0, want_trace=False):
+        """Returns (jpeg_bytes, info) where info has 'trace' (the --verbose text, if
+        requested), 'timers' (seconds per phase) and 'counters'."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        h, w, ch = rgb.shape
+        assert ch == 3
+        cap = 3 * w * h + (1 << 16)
+        out = np.zeros(cap, np.uint8)
+        tr = C.create_string_buffer(1 << 24) if want_trace else None
+        tm = C.create_string_buffer(1 << 12)
+        n = self.lib.gzh_process(rgb.ctypes.data, w, h,
+                                 -1.0 if target is not None else float(quality),
+                                 float(target or 0.0), device, out.ctypes.data, cap,
+                                 tr, len(tr) if tr else 0, tm, len(tm))
+        if n < 0:
+            raise RuntimeError("guetzli_amd.Process failed (see stderr)")
+        assert n <= cap
+        timers, counters = {}, {}
+        for item in tm.value.decode().split(";"):
+            if "=" in item:
+                k, v = item.split("=")
+                if k.startswith("#"):
+                    counters[k[1:]] = int(v)
+                else:
+                    timers[k] = float(v)
+        return out[:n].tobytes(), {"trace": tr.value.decode() if tr else None,
+                                   "timers": timers, "counters": counters}
+
+    def write_jpeg(self, coeffs, w, h, q=None):
+        """WriteJpeg of dequantised coefficients [3][nb][64] with quant matrices q[3][64];
+        q=None writes the q=1 'original' frame of EncodeRGBToJpeg."""
+        co = np.ascontiguousarray(coeffs, np.int16)
+        qq = None if q is None else np.ascontiguousarray(q, np.int32)
+        cap = 6 * w * h + (1 << 16)
+        out = np.zeros(cap, np.uint8)
+        n = self.lib.gzh_write_jpeg(co.ctypes.data, w, h,
+                                    qq.ctypes.data if qq is not None else None,
+                                    int(q is None), out.ctypes.data, cap)
+        assert 0 <= n <= cap, n
+        return out[:n].tobytes()
+
+    def butteraugli_score_for_quality(self, q):
+        return self.lib.gzh_butteraugli_score_for_quality(q)
+
+
+_default = None
+
+
+def load_host():
+    global _default
+    if _default is None:
+        _default = HostLibrary()
+    return _default
+
+
+def process(rgb, quality=95.0, **kw):
+    return load_host().process(rgb, quality=quality, **kw)

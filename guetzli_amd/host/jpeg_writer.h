@@ -1,0 +1,82 @@
+// Baseline-sequential JPEG serialisation used by the host search driver: what
+// OutputImage::SaveToJpegData + WriteJpeg produce in the reference
+// (output_image.cc:348-409, jpeg_data_writer.cc:33-553, entropy_encode.cc:25-145,
+// jpeg_bit_writer.h:31-108, jpeg_data.cc:71-102).  Byte-exact by contract: the size of
+// every candidate feeds ScoreJPEG and the bytes of the winner are the product's output.
+//
+// Host-side C++ (serial entropy coding); written from scratch around a
+// flat coefficient layout (the device layout of include/guetzli_amd.h), not around the
+// reference's JPEGData object model.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace guetzli_amd {
+
+constexpr int kBlock = 64;
+constexpr int kHistoSize = 257;   // 256 symbols + the reserved all-ones code
+
+extern const int kNaturalOrder[64];   // zig-zag position -> natural index
+extern const int kZigZagOrder[64];    // natural index -> zig-zag position
+
+// Symbol statistics with every real symbol counted twice and one reserved symbol counted
+// once, so that the reserved symbol always ends up with the longest (all-ones) code
+// (JpegHistogram, jpeg_data_writer.h:53-85).
+struct SymbolHistogram {
+  uint32_t counts[kHistoSize];
+  SymbolHistogram() { Clear(); }
+  void Clear();
+  void Add(int symbol, int weight = 1) { counts[symbol] += 2 * weight; }
+  void Merge(const SymbolHistogram& other);
+  int NumSymbols() const;
+};
+
+// Length-limited Huffman depths (CreateHuffmanTree, entropy_encode.cc:73-145).
+void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth);
+
+size_t HistogramHeaderBits(const SymbolHistogram& h);                       // :218-226
+size_t HistogramEntropyBits(const SymbolHistogram& h, const uint8_t* depth);  // :228-239
+// Greedy pairwise clustering from the back (ClusterHistograms, :295-342).  Returns the
+// estimated size in bytes.
+size_t ClusterHistograms(SymbolHistogram* histo, size_t* num, int* histo_indexes,
+                         uint8_t* depth);
+
+// One AC block's symbols (UpdateACHistogramForDCTBlock :197-216 / processor.cc:471-495):
+// coefficients are DEQUANTISED values, q the component's quant matrix (null = already
+// quantised).
+void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHistogram* h);
+
+// A frame ready to be written: quantised coefficient planes + tables.
+struct QuantTable {
+  int values[64];
+  int precision;   // 0: 8 bit, 1: 16 bit
+  int index;
+};
+struct Frame {
+  int width = 0, height = 0, bw = 0, bh = 0;
+  int ncomp = 3;
+  std::vector<int16_t> coeffs[3];    // [nb][64], quantised values (coeff / quant)
+  std::vector<QuantTable> quant;
+  int quant_idx[3] = {0, 0, 0};
+};
+
+// OutputImage::SaveToJpegData + SaveQuantTables for a 4:4:4 image given by dequantised
+// coefficients (device layout, [3][nb][64]) and its quant matrices.
+void FrameFromImage(const int16_t* coeffs, const int q[3][64], int w, int h, Frame* f);
+// The q=1 "original" JPEGData of EncodeRGBToJpeg (jpeg_data_encoder.cc:66-117): three
+// separate all-ones tables that all carry table index 0.
+void FrameFromOriginal(const int16_t* coeffs, int w, int h, Frame* f);
+
+void BuildDCHistograms(const Frame& f, SymbolHistogram* histo);   // :241-265
+void BuildACHistograms(const Frame& f, SymbolHistogram* histo);   // :267-275
+size_t HeaderSize(const Frame& f);                                // JpegHeaderSize :278-303
+size_t EstimateDCSize(const Frame& f);                            // processor.cc:527-535
+
+// WriteJpeg (jpeg_data_writer.cc:540-553) with strip_metadata semantics (a fixed JFIF
+// APP0).  Returns false on an internal inconsistency.
+bool WriteJpeg(const Frame& f, std::string* out);
+
+}  // namespace guetzli_amd

@@ -1,0 +1,615 @@
+#include "processor.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <utility>
+
+#include "../../include/guetzli_amd.h"
+#include "jpeg_writer.h"
+
+namespace guetzli_amd {
+
+// ------------------------------------------------------------- quality / score tables --
+namespace {
+const int kLowestQuality = 70;
+const int kHighestQuality = 110;
+// Median butteraugli scores of libjpeg-turbo output per quality level 70..111
+// (kScoreForQuality, quality.cc:31-74) -- data.
+const double kQualityScore[] = {
+  2.810761, 2.729300, 2.689687, 2.636811, 2.547863, 2.525400, 2.473416, 2.366133, 2.338078,
+  2.318654, 2.201674, 2.145517, 2.087322, 2.009328, 1.945456, 1.900112, 1.805701, 1.750194,
+  1.644175, 1.562165, 1.473608, 1.382021, 1.294298, 1.185402, 1.066781, 0.971769, 0.852901,
+  0.724544, 0.611302, 0.443185, 0.211578, 0.209462, 0.207346, 0.205230, 0.203114, 0.200999,
+  0.198883, 0.196767, 0.194651, 0.192535, 0.190420, 0.190420,
+};
+}  // namespace
+
+double ButteraugliScoreForQuality(double quality) {
+  if (quality < kLowestQuality) quality = kLowestQuality;
+  if (quality > kHighestQuality) quality = kHighestQuality;
+  const int index = static_cast<int>(quality);
+  const double mix = quality - index;
+  return kQualityScore[index - kLowestQuality] * (1 - mix) +
+         kQualityScore[index - kLowestQuality + 1] * mix;
+}
+
+double ScoreJPEG(double butteraugli_distance, int size, double butteraugli_target) {
+  const double kScale = 50, kMaxExponent = 10, kLargeSize = 1e30;
+  const double diff = butteraugli_distance - butteraugli_target;
+  if (diff <= 0.0) return size;
+  const double exponent = kScale * diff;
+  if (exponent > kMaxExponent) return kLargeSize * std::exp(kMaxExponent) * diff + size;
+  return std::exp(exponent) * size;
+}
+
+namespace {
+
+typedef int QuantMatrix[3][64];
+
+struct Stopwatch {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double lap() {
+    const auto t1 = std::chrono::steady_clock::now();
+    const double s = std::chrono::duration<double>(t1 - t0).count();
+    t0 = t1;
+    return s;
+  }
+};
+
+// ------------------------------------------------------------ quant matrix bisection --
+// QuantMatrixGenerator (processor.cc:194-296): a 1-D family of matrices indexed by a
+// "heuristic score"; bracket a passing (a) and a failing (b) score, then bisect.
+double Csf(int k) { return 1.0 / (1.0 + kZigZagOrder[k] / 2.0); }
+
+double HeuristicScore(const QuantMatrix q) {   // QuantMatrixHeuristicScore, :182-190
+  double score = 0.0;
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 64; ++k) score += 0.5 * (q[c][k] - 1.0) * Csf(k);
+  return score;
+}
+
+bool SameMatrix(const QuantMatrix a, const QuantMatrix b) {
+  return memcmp(a, b, sizeof(QuantMatrix)) == 0;
+}
+
+struct Trial {
+  QuantMatrix q;
+  size_t jpg_size;
+  bool dist_ok;
+};
+
+class MatrixSearch {
+ public:
+  MatrixSearch() : lo_(-1.0), hi_(-1.0), total_(0.0) {
+    for (int k = 0; k < 64; ++k) total_ += 3.0 * Csf(k);
+  }
+  bool Next(QuantMatrix q) {
+    for (int guard = 0; guard < 1000; ++guard) {
+      double h;
+      if (hi_ == -1.0) {
+        if (lo_ == -1.0) {
+          h = total_;
+        } else {
+          h = lo_ < 5.0 * total_ ? lo_ + total_ : 2 * (lo_ + total_);
+        }
+        if (h > 100 * total_) return false;   // nothing creates enough error
+      } else if (hi_ == 0.0) {
+        return false;
+      } else if (lo_ == -1.0) {
+        h = 0.0;
+      } else {
+        QuantMatrix lower, upper;
+        const double eps = 0.05;
+        FromScore((1 - eps) * lo_ + eps * 0.5 * (lo_ + hi_), lower);
+        FromScore((1 - eps) * hi_ + eps * 0.5 * (lo_ + hi_), upper);
+        if (SameMatrix(lower, upper)) return false;
+        h = (lo_ + hi_) * 0.5;
+      }
+      FromScore(h, q);
+      bool seen = false;
+      for (size_t i = 0; i < tried_.size(); ++i) {
+        if (SameMatrix(q, tried_[i].q)) {
+          if (tried_[i].dist_ok) lo_ = h; else hi_ = h;
+          seen = true;
+          break;
+        }
+      }
+      if (!seen) return true;
+    }
+    return false;
+  }
+  void Add(const Trial& t) {
+    tried_.push_back(t);
+    const double h = HeuristicScore(t.q);
+    if (t.dist_ok) lo_ = std::max(lo_, h);
+    else hi_ = hi_ == -1.0 ? h : std::min(hi_, h);
+  }
+
+ private:
+  void FromScore(double score, QuantMatrix q) const {   // :269-279
+    const int level = static_cast<int>(score / total_);
+    score -= level * total_;
+    for (int k = 63; k >= 0; --k) {
+      const int nat = kNaturalOrder[k];
+      for (int c = 0; c < 3; ++c) q[c][nat] = 2 * level + (score > 0.0 ? 3 : 1);
+      score -= 3.0 * Csf(nat);
+    }
+  }
+  double lo_, hi_, total_;
+  std::vector<Trial> tried_;
+};
+
+inline int16_t QuantizeCoeff(int16_t raw, int quant) {   // quantize.h:24-29
+  const int r = raw % quant;
+  const int16_t delta = (int16_t)(2 * r > quant ? quant - r : (-2) * r > quant ? -quant - r : -r);
+  return (int16_t)(raw + delta);
+}
+
+// ------------------------------------------------------------------- the encoder ------
+class Encoder {
+ public:
+  Encoder(const Params& p, ProcessStats* s) : params_(p), stats_(s) {}
+  ~Encoder() { if (ctx_) gz_destroy(ctx_); }
+  bool Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* out);
+
+ private:
+  void Log(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+  void LogMatrix(const QuantMatrix q);
+  bool Fail(const char* what, int rc);
+  void Serialize(std::string* jpg);   // SaveToJpegData + WriteJpeg of the current image
+  bool CompareCurrent();
+  void MaybeOutput(const std::string& jpg);
+  bool DistanceOK(double target_mul) const { return distance_ <= target_mul * params_.butteraugli_target; }
+  bool TryMatrix(float target_mul, const QuantMatrix q, Trial* t);
+  bool SelectMatrix(QuantMatrix best);
+  bool SelectFrequencyMasking(double target_mul);
+  bool SetImageFromQuantization(const QuantMatrix q);
+
+  Params params_;
+  ProcessStats* stats_;
+  gz_ctx* ctx_ = nullptr;
+  int w_ = 0, h_ = 0, bw_ = 0, bh_ = 0, nb_ = 0;
+  std::vector<int16_t> orig_;    // unquantised coefficients (JPEGData of EncodeRGBToJpeg)
+  std::vector<int16_t> img_;     // coefficients of the working image (OutputImage::coeffs_)
+  QuantMatrix quant_;            // its quant matrices
+  float distance_ = 0.0f;        // ButteraugliComparator::distance_
+  std::string best_jpg_;         // GuetzliOutput
+  double best_score_ = -1;
+  double t_write_ = 0, t_compare_ = 0, t_quant_ = 0, t_blocksearch_ = 0, t_phaseb_ = 0,
+         t_upload_ = 0;
+};
+
+void Encoder::Log(const char* fmt, ...) {   // GUETZLI_LOG / PrintDebug, debug_print.h
+  if (!stats_->debug_output && !stats_->debug_output_file) return;
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (stats_->debug_output) stats_->debug_output->append(buf);
+  if (stats_->debug_output_file) fputs(buf, stats_->debug_output_file);
+}
+
+void Encoder::LogMatrix(const QuantMatrix q) {   // GUETZLI_LOG_QUANT
+  for (int y = 0; y < 8; ++y) {
+    for (int c = 0; c < 3; ++c) {
+      for (int x = 0; x < 8; ++x) Log(" %2d", q[c][8 * y + x]);
+      Log("   ");
+    }
+    Log("\n");
+  }
+}
+
+bool Encoder::Fail(const char* what, int rc) {
+  fprintf(stderr, "guetzli_amd: %s failed: %s (%s)\n", what, gz_strerror(rc),
+          ctx_ ? gz_last_error(ctx_) : "");
+  return false;
+}
+
+void Encoder::Serialize(std::string* jpg) {
+  Stopwatch sw;
+  Frame f;
+  FrameFromImage(img_.data(), quant_, w_, h_, &f);
+  WriteJpeg(f, jpg);
+  t_write_ += sw.lap();
+}
+
+bool Encoder::CompareCurrent() {   // comparator_->Compare(*img)
+  Stopwatch sw;
+  const int rc = gz_compare(ctx_, &distance_, nullptr, nullptr);
+  t_compare_ += sw.lap();
+  if (rc != GZ_OK) return Fail("gz_compare", rc);
+  Log(" BA[100.00%%] D[%6.4f]", distance_);
+  return true;
+}
+
+void Encoder::MaybeOutput(const std::string& jpg) {   // processor.cc:139-148
+  const double score = ScoreJPEG(distance_, (int)jpg.size(), params_.butteraugli_target);
+  Log(" Score[%.4f]", score);
+  if (score < best_score_ || best_score_ < 0) {
+    best_jpg_ = jpg;
+    best_score_ = score;
+    Log(" (*)");
+  }
+  Log("\n");
+}
+
+// img := orig, then ApplyGlobalQuantization(q); device and host copies.
+bool Encoder::SetImageFromQuantization(const QuantMatrix q) {
+  Stopwatch sw;
+  const int rc = gz_quantize(ctx_, &q[0][0], img_.data());
+  t_quant_ += sw.lap();
+  if (rc != GZ_OK) return Fail("gz_quantize", rc);
+  memcpy(quant_, q, sizeof(QuantMatrix));
+  return true;
+}
+
+bool Encoder::TryMatrix(float target_mul, const QuantMatrix q, Trial* t) {   // :298-326
+  memcpy(t->q, q, sizeof(QuantMatrix));
+  if (!SetImageFromQuantization(q)) return false;
+  std::string jpg;
+  Serialize(&jpg);
+  Log("Iter %2d: %s quantization matrix:\n", stats_->counters[kNumItersCnt] + 1, "f111111");
+  LogMatrix(q);
+  Log("Iter %2d: %s GQ[%5.2f] Out[%7zd]", stats_->counters[kNumItersCnt] + 1, "f111111",
+      HeuristicScore(q), jpg.size());
+  ++stats_->counters[kNumItersCnt];
+  if (!CompareCurrent()) return false;
+  t->dist_ok = DistanceOK(target_mul);
+  t->jpg_size = jpg.size();
+  MaybeOutput(jpg);
+  return true;
+}
+
+bool Encoder::SelectMatrix(QuantMatrix best_q) {   // SelectQuantMatrix, :328-360
+  MatrixSearch search;
+  const float target_mul_high = 0.97f, target_mul_low = 0.95f;
+  Trial best;
+  if (!TryMatrix(target_mul_high, best_q, &best)) return false;
+  for (;;) {
+    QuantMatrix next;
+    if (!search.Next(next)) break;
+    Trial t;
+    if (!TryMatrix(target_mul_high, next, &t)) return false;
+    search.Add(t);
+    const bool better = t.dist_ok != best.dist_ok ? t.dist_ok : t.jpg_size < best.jpg_size;
+    if (better) {
+      best = t;
+      if (t.dist_ok && !DistanceOK(target_mul_low)) break;
+    }
+  }
+  memcpy(best_q, best.q, sizeof(QuantMatrix));
+  Log("\n%s selected quantization matrix:\n", "YUV444");
+  LogMatrix(best_q);
+  if (!best.dist_ok)
+    for (int c = 0; c < 3; ++c)
+      for (int k = 0; k < 64; ++k) best_q[c][k] = 1;
+  return true;
+}
+
+// Entropy-size model of the AC coefficients (processor.cc:497-525).
+size_t EntropyCodes(const SymbolHistogram* histo, uint8_t* depths /*3*257*/) {
+  SymbolHistogram clustered[3] = {histo[0], histo[1], histo[2]};
+  size_t num = 3;
+  int indexes[3];
+  uint8_t cdepths[3 * kHistoSize];
+  ClusterHistograms(clustered, &num, indexes, cdepths);
+  for (int i = 0; i < 3; ++i)
+    memcpy(&depths[i * kHistoSize], &cdepths[indexes[i] * kHistoSize], kHistoSize);
+  size_t header = 0;
+  for (size_t i = 0; i < num; ++i) header += HistogramHeaderBits(clustered[i]) / 8;
+  return header;
+}
+size_t EntropyDataSize(const SymbolHistogram* histo, const uint8_t* depths) {
+  size_t bits = 0;
+  for (int i = 0; i < 3; ++i) bits += HistogramEntropyBits(histo[i], &depths[i * kHistoSize]);
+  return (bits + 7) / 8;
+}
+
+bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-780, mask 7
+  Stopwatch sw;
+  const int nb = nb_;
+  // ---- phase A on the device ----
+  std::vector<int32_t> cand_off(nb + 1);
+  std::vector<uint8_t> cand_idx((size_t)nb * 189);
+  std::vector<float> cand_err((size_t)nb * 189);
+  int rc = gz_block_zeroing_orders(ctx_, params_.zeroing_greedy_lookahead,
+                                   params_.new_zeroing_model ? 1 : 0, cand_off.data(),
+                                   cand_idx.data(), cand_err.data(), nb * 189);
+  t_blocksearch_ += sw.lap();
+  if (rc != GZ_OK) return Fail("gz_block_zeroing_orders", rc);
+
+  // ---- size model of the starting point ----
+  SymbolHistogram ac_histo[3];
+  int header_size, dc_size;
+  {
+    Frame f;
+    FrameFromImage(img_.data(), quant_, w_, h_, &f);
+    header_size = (int)HeaderSize(f);
+    dc_size = (int)EstimateDCSize(f);
+    BuildACHistograms(f, ac_histo);
+  }
+  std::vector<uint8_t> ac_depths(3 * kHistoSize);
+  int ac_header = (int)EntropyCodes(ac_histo, ac_depths.data());
+  const int base_size = header_size + dc_size + ac_header +
+                        (int)EntropyDataSize(ac_histo, ac_depths.data());
+  int prev_size = base_size;
+
+  std::vector<float> max_block_error(nb, 0.0f);
+  std::vector<int> next_cand(nb, 0);   // last_indexes
+  std::vector<float> weight(nb);
+  std::vector<std::pair<int, float> > order;
+  std::vector<char> touched(nb);
+  std::vector<int32_t> dirty;
+  std::vector<int16_t> dirty_blocks;
+  bool first_up = true;
+  const size_t comp_stride = (size_t)nb * 64;
+
+  for (int direction = 1; direction >= -1; direction -= 2) {
+    for (;;) {
+      int blocks_to_change = 0;
+      for (int radius = 1; radius <= 4; ++radius) {
+        std::fill(weight.begin(), weight.end(), 0.0f);
+        rc = gz_block_weights(ctx_, direction, radius, target_mul, first_up ? 0 : 1, weight.data());
+        if (rc != GZ_OK) return Fail("gz_block_weights", rc);
+        order.clear();
+        blocks_to_change = 0;
+        for (int b = 0; b < nb; ++b) {
+          if (weight[b] == 0) continue;
+          const int at = next_cand[b], off = cand_off[b], count = cand_off[b + 1] - off;
+          const float* errs = &cand_err[off];
+          const float base = max_block_error[b];
+          if (direction > 0) {
+            for (int i = at; i < count; ++i)
+              order.push_back(std::make_pair(b, (errs[i] - base) / weight[b]));
+            blocks_to_change += at < count ? 1 : 0;
+          } else {
+            for (int i = at - 1; i >= 0; --i)
+              order.push_back(std::make_pair(b, (base - errs[i]) / weight[b]));
+            blocks_to_change += at > 0 ? 1 : 0;
+          }
+        }
+        if (!order.empty()) break;
+      }
+      if (order.empty()) break;
+
+      // std::sort on the reference's own element type and predicate: the order of equal
+      // keys is libstdc++-defined and decides which coefficients change.
+      std::sort(order.begin(), order.end(),
+                [](const std::pair<int, float>& a, const std::pair<int, float>& b) {
+                  return a.second < b.second; });
+
+      double rel_size_delta = direction > 0 ? 0.01 : 0.0005;
+      if (direction > 0 && DistanceOK(1.0)) rel_size_delta = 0.05;
+      const double min_size_delta = base_size * rel_size_delta;
+      const float per_block = direction > 0 ? 2.0f : 1 * 1 * 0.2f;
+      int min_coeffs_to_change = per_block * blocks_to_change;
+      if (first_up) {
+        const float limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
+        const auto it = std::partition_point(order.begin(), order.end(),
+                                             [=](const std::pair<int, float>& a) { return a.second < limit; });
+        min_coeffs_to_change = std::max<int>(min_coeffs_to_change, it - order.begin());
+        first_up = false;
+      }
+
+      std::fill(touched.begin(), touched.end(), 0);
+      dirty.clear();
+      float val_threshold = 0.0;
+      int changed_coeffs = 0;
+      int est_size = prev_size;
+      for (size_t i = 0; i < order.size(); ++i) {
+        const int b = order[i].first;
+        const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
+        const int c = idx / 64, k = idx % 64;
+        const int* q = quant_[c];
+        const int16_t* orig_blk = &orig_[c * comp_stride + (size_t)b * 64];
+        int16_t* blk = &img_[c * comp_stride + (size_t)b * 64];
+        const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
+        AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
+        double sum_of_hf = 0;
+        for (int ii = 3; ii < 64; ++ii) {
+          if ((ii & 7) < 3 && ii < 3 * 8) continue;
+          sum_of_hf += std::abs(orig_blk[ii]);
+        }
+        const int limit = sum_of_hf < 60 ? 4 : 8;
+        const bool precious = (k == 1 || k == 8) && std::abs(orig_blk[k]) >= limit;
+        if (!precious || newval != 0) blk[k] = (int16_t)newval;
+        AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
+        next_cand[b] += direction;
+        if (!touched[b]) {
+          touched[b] = 1;
+          dirty.push_back(b);
+        }
+        val_threshold = order[i].second;
+        ++changed_coeffs;
+        if (i % 10 == 0) ac_header = (int)EntropyCodes(ac_histo, ac_depths.data());
+        est_size = header_size + dc_size + ac_header +
+                   (int)EntropyDataSize(ac_histo, ac_depths.data());
+        if (changed_coeffs > min_coeffs_to_change &&
+            std::abs(est_size - prev_size) > min_size_delta)
+          break;
+      }
+      const size_t order_size = order.size();
+      for (int b = 0; b < nb; ++b) max_block_error[b] += weight[b] * val_threshold * direction;
+
+      ++stats_->counters[kNumItersCnt];
+      ++stats_->counters[direction > 0 ? kNumItersUpCnt : kNumItersDownCnt];
+      t_phaseb_ += sw.lap();
+
+      // push the edited blocks to the device image
+      dirty_blocks.resize(dirty.size() * 192);
+      for (size_t i = 0; i < dirty.size(); ++i)
+        for (int c = 0; c < 3; ++c)
+          memcpy(&dirty_blocks[(i * 3 + c) * 64], &img_[c * comp_stride + (size_t)dirty[i] * 64], 128);
+      rc = gz_set_coeff_blocks(ctx_, dirty.data(), (int)dirty.size(), dirty_blocks.data());
+      t_upload_ += sw.lap();
+      if (rc != GZ_OK) return Fail("gz_set_coeff_blocks", rc);
+
+      std::string jpg;
+      Serialize(&jpg);
+      Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
+          "EstErr[%.2f%%]",
+          stats_->counters[kNumItersCnt], "f111111", 7, direction > 0 ? "up" : "down",
+          changed_coeffs, order_size, dirty.size(), blocks_to_change, nb, val_threshold,
+          jpg.size(), 100.0 - (100.0 * est_size) / jpg.size());
+      if (!CompareCurrent()) return false;
+      MaybeOutput(jpg);
+      prev_size = est_size;
+      sw.lap();
+    }
+  }
+  return true;
+}
+
+bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* out) {
+  Stopwatch total, sw;
+  if (params_.butteraugli_target > 2.0f) {   // processor.cc:800-806
+    fprintf(stderr,
+            "Guetzli should be called with quality >= 84, otherwise the\n"
+            "output will have noticeable artifacts. If you want to\n"
+            "proceed anyway, please edit the source code.\n");
+    return false;
+  }
+  if (params_.try_420 || params_.force_420) {
+    fprintf(stderr, "guetzli_amd: the YUV420 modes are not implemented on the device path\n");
+    return false;
+  }
+  if (w < 0 || w >= 1 << 16 || h < 0 || h >= 1 << 16 || rgb.size() != (size_t)3 * w * h) {
+    fprintf(stderr, "Could not create jpg data from rgb pixels\n");   // EncodeRGBToJpeg failed
+    return false;
+  }
+  w_ = w; h_ = h;
+  bw_ = (w + 7) / 8; bh_ = (h + 7) / 8; nb_ = bw_ * bh_;
+  if (w < 32 || h < 32) {
+    // "image too small for Butteraugli" (processor.cc:832-838, :940): the reference emits
+    // the unquantised JPEG; that needs the forward DCT only.  Images this small are not a
+    // GPU workload; refuse rather than add a CPU path.
+    fprintf(stderr, "guetzli_amd: images smaller than 32x32 are not supported\n");
+    return false;
+  }
+  int err = 0;
+  ctx_ = gz_create(params_.device, w, h, rgb.data(), params_.butteraugli_target, &err);
+  if (!ctx_) return Fail("gz_create", err);
+  orig_.resize((size_t)3 * nb_ * 64);
+  img_.resize(orig_.size());
+  int rc = gz_encode_rgb(ctx_, orig_.data());
+  if (rc != GZ_OK) return Fail("gz_encode_rgb", rc);
+  stats_->timers["create+encode"] = sw.lap();
+
+  // the unquantised original as the fallback output (processor.cc:826-846)
+  std::string jpg;
+  {
+    Frame f;
+    FrameFromOriginal(orig_.data(), w, h, &f);
+    Stopwatch ws;
+    WriteJpeg(f, &jpg);
+    t_write_ += ws.lap();
+  }
+  best_score_ = -1;
+  Log("Original Out[%7zd]", jpg.size());
+  QuantMatrix ones;
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 64; ++k) ones[c][k] = 1;
+  if (!SetImageFromQuantization(ones)) return false;
+  if (!CompareCurrent()) return false;
+  MaybeOutput(jpg);
+
+  QuantMatrix best_q;
+  memcpy(best_q, ones, sizeof(best_q));
+  if (!SelectMatrix(best_q)) return false;
+  stats_->timers["select_quant_matrix"] = sw.lap();
+  if (!SetImageFromQuantization(best_q)) return false;
+  if (!SelectFrequencyMasking(1.0)) return false;
+  stats_->timers["select_frequency_masking"] = sw.lap();
+  stats_->timers["jpeg_write"] = t_write_;
+  stats_->timers["compare"] = t_compare_;
+  stats_->timers["quantize"] = t_quant_;
+  stats_->timers["block_search"] = t_blocksearch_;
+  stats_->timers["phase_b_host"] = t_phaseb_;
+  stats_->timers["block_upload"] = t_upload_;
+  stats_->timers["total"] = total.lap();
+  *out = best_jpg_;
+  return true;
+}
+
+}  // namespace
+
+bool Process(const Params& params, ProcessStats* stats, const std::vector<uint8_t>& rgb, int w,
+             int h, std::string* out) {
+  ProcessStats dummy;
+  if (stats == nullptr) stats = &dummy;
+  Encoder enc(params, stats);
+  return enc.Run(rgb, w, h, out);
+}
+
+}  // namespace guetzli_amd
+
+// ---------------------------------------------------------------- C wrapper (ctypes) ---
+extern "C" {
+
+// quality < 0: `target` is used as the butteraugli target directly.
+long gzh_process(const uint8_t* rgb, int w, int h, double quality, float target, int device,
+                 uint8_t* out, long cap, char* trace, long trace_cap, char* timers,
+                 long timers_cap) {
+  guetzli_amd::Params params;
+  params.butteraugli_target =
+      quality >= 0 ? (float)guetzli_amd::ButteraugliScoreForQuality(quality) : target;
+  params.device = device;
+  guetzli_amd::ProcessStats stats;
+  std::string dbg;
+  if (trace) stats.debug_output = &dbg;
+  std::vector<uint8_t> v(rgb, rgb + (size_t)3 * w * h);
+  std::string jpg;
+  if (!guetzli_amd::Process(params, &stats, v, w, h, &jpg)) return -1;
+  if ((long)jpg.size() <= cap) memcpy(out, jpg.data(), jpg.size());
+  if (trace && trace_cap > 0) {
+    const size_t n = std::min<size_t>(dbg.size(), (size_t)trace_cap - 1);
+    memcpy(trace, dbg.data(), n);
+    trace[n] = 0;
+  }
+  if (timers && timers_cap > 0) {
+    std::string s;
+    for (const auto& kv : stats.timers) {
+      char buf[128];
+      snprintf(buf, sizeof(buf), "%s=%.6f;", kv.first.c_str(), kv.second);
+      s += buf;
+    }
+    for (const auto& kv : stats.counters) {
+      char buf[128];
+      snprintf(buf, sizeof(buf), "#%s=%d;", kv.first.c_str(), kv.second);
+      s += buf;
+    }
+    const size_t n = std::min<size_t>(s.size(), (size_t)timers_cap - 1);
+    memcpy(timers, s.data(), n);
+    timers[n] = 0;
+  }
+  return (long)jpg.size();
+}
+
+double gzh_butteraugli_score_for_quality(double q) {
+  return guetzli_amd::ButteraugliScoreForQuality(q);
+}
+
+// WriteJpeg of an image given by dequantised coefficients + quant matrices (test hook).
+long gzh_write_jpeg(const int16_t* coeffs, int w, int h, const int* q, int original,
+                    uint8_t* out, long cap) {
+  guetzli_amd::Frame f;
+  if (original) {
+    guetzli_amd::FrameFromOriginal(coeffs, w, h, &f);
+  } else {
+    int qq[3][64];
+    memcpy(qq, q, sizeof(qq));
+    guetzli_amd::FrameFromImage(coeffs, qq, w, h, &f);
+  }
+  std::string s;
+  if (!guetzli_amd::WriteJpeg(f, &s)) return -1;
+  if ((long)s.size() <= cap) memcpy(out, s.data(), s.size());
+  return (long)s.size();
+}
+
+}  // extern "C"

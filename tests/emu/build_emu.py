@@ -26,5 +26,17 @@ def build(force=False):
     return LIB
 
 
+HOST_LIB = os.path.join(OUT, "libguetzli_amd_host_emu.so")
+
+
+def build_host(force=False):
+    """The product's host driver sources linked against the EMULATED device library, so
+    that a whole encode can be checked on the CPU against the reference."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from guetzli_amd import build as gzbuild
+    return gzbuild.build_host(force=force, device_lib=build(), out=HOST_LIB)
+
+
 if __name__ == "__main__":
     print(build(force=True))

@@ -130,3 +130,38 @@ def test_block_search_bees(L):
     """Phase A on the whole BASELINE config-1 image (1848 blocks, ~300k CompareBlock
     evaluations) against the oracle, bit for bit."""
     pc.case_block_search(L, 444, 258, x0=0, y0=0, qs=2)
+
+
+# SHA-256 of the reference's output JPEGs (unmodified guetzli, default flags = quality 95),
+# BASELINE.md section 2; the bees hash is re-derived from oracle/_ref in the CPU suite.
+GOLDEN_JPEG_SHA = {
+    (444, 258, 95): "f2673f12a4856e020627fa151493a80b1cb2ee4dc81e28afc62dc089baf50242",
+    (444, 258, 84): "95f509f457ce8ddd85087c804664539e0ef7b1f3a6c6ca1cbedcd9ba29a89379",
+    (1920, 1080, 95): "9c0eb414b8e73f4372c0b089eafe2350e6ff2ae83926d1c0c5f35cb5f7919729",
+}
+GOLDEN_TRACE_SHA = {
+    (444, 258, 95): "954ec7623366bc3c345fc5b0748017f9a5e0128aba0917a249cca390a615f787",
+}
+
+
+@pytest.mark.parametrize("q", [95, 84])
+def test_whole_encode_bees_bit_identical_jpeg(q):
+    """BASELINE config 1: guetzli tests/bees.png --quality 95 (and 84): the output JPEG is
+    byte-identical to the reference's, and so is the --verbose trace."""
+    import hashlib
+    import guetzli_amd
+    rgb = images.bees()
+    jpg, info = guetzli_amd.process(rgb, quality=q, want_trace=True)
+    assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(444, 258, q)]
+    if (444, 258, q) in GOLDEN_TRACE_SHA:
+        assert hashlib.sha256(info["trace"].encode()).hexdigest() == GOLDEN_TRACE_SHA[(444, 258, q)]
+
+
+def test_whole_encode_1080p_bit_identical_jpeg():
+    """BASELINE config 2 (1920x1080, quality 95): byte-identical to the reference output."""
+    import hashlib
+    import guetzli_amd
+    rgb = images.tiled(1920, 1080)
+    jpg, info = guetzli_amd.process(rgb, quality=95)
+    assert len(jpg) == 721187
+    assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(1920, 1080, 95)]

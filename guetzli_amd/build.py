@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libguetzli_amd.so")
 SOURCES = ["gz_api.hip"]
 HEADERS = ["gz_common.h", "gz_math.h", "gz_kernels_block.h", "gz_kernels_blur.h",
-           "gz_kernels_diff.h", "gz_kernels_search.h", "tables_generated.h", "order_tables_generated.h"]
+           "gz_kernels_diff.h", "gz_kernels_search.h", "gz_host_weights.h", "tables_generated.h", "order_tables_generated.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -67,7 +67,7 @@ def build_host(force=False, verbose=False, device_lib=None, out=None):
     device_lib = device_lib or LIB
     out = out or HOST_LIB
     srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
-    deps = srcs + [os.path.join(HOST_DIR, h) for h in ("jpeg_writer.h", "processor.h")] + \
+    deps = srcs + [os.path.join(HOST_DIR, h) for h in ("jpeg_writer.h", "processor.h", "lazy_sort.h")] + \
         [os.path.join(os.path.dirname(HERE), "include", "guetzli_amd.h"), device_lib]
     if not force and os.path.exists(out) and \
             all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps if os.path.exists(d)):

@@ -24,6 +24,7 @@
 #include "gz_kernels_blur.h"
 #include "gz_kernels_diff.h"
 #include "gz_kernels_search.h"
+#include "gz_host_weights.h"
 #include "order_tables_generated.h"   // host-side csf/bias of order.inc
 
 using namespace gz;
@@ -891,34 +892,11 @@ int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target
                      int use_distmap, float* block_weight) {
   if (!c || !block_weight || max_block_dist < 0) return GZ_E_ARG;
   if (use_distmap && !c->have_distmap) { c->err = "no distance map yet"; return GZ_E_STATE; }
-  const int bw = c->bw, bh = c->bh;
   std::vector<float> zero;
   const float* bmax = c->h_block_max.data();
   if (!use_distmap) { zero.assign(c->nb, 0.0f); bmax = zero.data(); }
-  const double target_distance = c->target * target_mul;
-  for (int by = 0; by < bh; ++by) {
-    for (int bx = 0; bx < bw; ++bx) {
-      const int bix = by * bw + bx;
-      float local = static_cast<float>(target_distance);
-      const int x0 = std::max(0, bx - max_block_dist), y0 = std::max(0, by - max_block_dist);
-      const int x1 = std::min(bw, bx + 1 + max_block_dist);
-      const int y1 = std::min(bh, by + 1 + max_block_dist);
-      for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) local = std::max(local, bmax[y * bw + x]);
-      if (direction > 0) {
-        if (bmax[bix] <= target_distance && local <= 1.1 * target_distance) block_weight[bix] = 1.0;
-      } else {
-        const double kLocalMaxWeight = 0.5;
-        if (bmax[bix] <= (1 - kLocalMaxWeight) * target_distance + kLocalMaxWeight * local) continue;
-        for (int y = y0; y < y1; ++y)
-          for (int x = x0; x < x1; ++x) {
-            const int d = std::max(abs(y - by), abs(x - bx));
-            const int ix = y * bw + x;
-            block_weight[ix] = std::max<float>(block_weight[ix], 1.0f / (d + 1.0f));
-          }
-      }
-    }
-  }
+  block_weights_host(bmax, c->bw, c->bh, c->target, direction, max_block_dist, target_mul,
+                     block_weight);
   return GZ_OK;
 }
 

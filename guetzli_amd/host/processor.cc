@@ -11,6 +11,7 @@
 
 #include "../../include/guetzli_amd.h"
 #include "jpeg_writer.h"
+#include "lazy_sort.h"
 
 namespace guetzli_amd {
 
@@ -182,6 +183,8 @@ class Encoder {
   double best_score_ = -1;
   double t_write_ = 0, t_compare_ = 0, t_quant_ = 0, t_blocksearch_ = 0, t_phaseb_ = 0,
          t_upload_ = 0;
+  double t_pb_weights_ = 0, t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
+  long n_steps_ = 0, n_order_ = 0;
 };
 
 void Encoder::Log(const char* fmt, ...) {   // GUETZLI_LOG / PrintDebug, debug_print.h
@@ -347,15 +350,20 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   std::vector<char> touched(nb);
   std::vector<int32_t> dirty;
   std::vector<int16_t> dirty_blocks;
+  std::vector<char> pending_flag((size_t)3 * nb, 0);
+  std::vector<int> pending;
   bool first_up = true;
   const size_t comp_stride = (size_t)nb * 64;
 
   for (int direction = 1; direction >= -1; direction -= 2) {
     for (;;) {
       int blocks_to_change = 0;
+      Stopwatch pw;
       for (int radius = 1; radius <= 4; ++radius) {
         std::fill(weight.begin(), weight.end(), 0.0f);
+        pw.lap();
         rc = gz_block_weights(ctx_, direction, radius, target_mul, first_up ? 0 : 1, weight.data());
+        t_pb_weights_ += pw.lap();
         if (rc != GZ_OK) return Fail("gz_block_weights", rc);
         order.clear();
         blocks_to_change = 0;
@@ -376,13 +384,21 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         }
         if (!order.empty()) break;
       }
+      t_pb_order_ += pw.lap();
       if (order.empty()) break;
+      n_order_ += (long)order.size();
 
-      // std::sort on the reference's own element type and predicate: the order of equal
-      // keys is libstdc++-defined and decides which coefficients change.
-      std::sort(order.begin(), order.end(),
-                [](const std::pair<int, float>& a, const std::pair<int, float>& b) {
-                  return a.second < b.second; });
+      // The reference std::sort-s `order` here (processor.cc:675-678) and then consumes a
+      // prefix.  Equal keys occur across different blocks and std::sort is not stable, so
+      // the permutation must be libstdc++'s; LazySorted yields exactly that permutation,
+      // front first, without sorting the part the scan never reaches.
+      struct KeyLess {
+        bool operator()(const std::pair<int, float>& a, const std::pair<int, float>& b) const {
+          return a.second < b.second;
+        }
+      };
+      LazySorted<std::pair<int, float>, KeyLess> sorted(order.data(), order.size(), KeyLess());
+      t_pb_sort_ += pw.lap();
 
       double rel_size_delta = direction > 0 ? 0.01 : 0.0005;
       if (direction > 0 && DistanceOK(1.0)) rel_size_delta = 0.05;
@@ -390,10 +406,11 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       const float per_block = direction > 0 ? 2.0f : 1 * 1 * 0.2f;
       int min_coeffs_to_change = per_block * blocks_to_change;
       if (first_up) {
+        // partition_point over the sorted sequence == number of keys below the limit
         const float limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
-        const auto it = std::partition_point(order.begin(), order.end(),
-                                             [=](const std::pair<int, float>& a) { return a.second < limit; });
-        min_coeffs_to_change = std::max<int>(min_coeffs_to_change, it - order.begin());
+        int below = 0;
+        for (size_t i = 0; i < order.size(); ++i) below += order[i].second < limit ? 1 : 0;
+        min_coeffs_to_change = std::max<int>(min_coeffs_to_change, below);
         first_up = false;
       }
 
@@ -402,37 +419,75 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       float val_threshold = 0.0;
       int changed_coeffs = 0;
       int est_size = prev_size;
-      for (size_t i = 0; i < order.size(); ++i) {
-        const int b = order[i].first;
+      // One step of the reference loop (processor.cc:704-750) without its size estimate:
+      // change one coefficient of block b.  `histo_now`: keep ac_histo current after every
+      // step (the reference does); otherwise the block's symbols are taken out at its first
+      // change and put back by FlushPendingBlocks.
+      const size_t n_order = order.size();
+      auto apply_step = [&](size_t i, bool histo_now) {
+        const int b = sorted[i].first;
         const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
         const int c = idx / 64, k = idx % 64;
         const int* q = quant_[c];
         const int16_t* orig_blk = &orig_[c * comp_stride + (size_t)b * 64];
         int16_t* blk = &img_[c * comp_stride + (size_t)b * 64];
         const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
-        AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
-        double sum_of_hf = 0;
-        for (int ii = 3; ii < 64; ++ii) {
-          if ((ii & 7) < 3 && ii < 3 * 8) continue;
-          sum_of_hf += std::abs(orig_blk[ii]);
+        if (histo_now) {
+          AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
+        } else if (!pending_flag[(size_t)c * nb + b]) {
+          AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
+          pending_flag[(size_t)c * nb + b] = 1;
+          pending.push_back(c * nb + b);
         }
-        const int limit = sum_of_hf < 60 ? 4 : 8;
-        const bool precious = (k == 1 || k == 8) && std::abs(orig_blk[k]) >= limit;
+        bool precious = false;
+        if ((k == 1 || k == 8) && newval == 0) {   // the test only matters for these two
+          double sum_of_hf = 0;
+          for (int ii = 3; ii < 64; ++ii) {
+            if ((ii & 7) < 3 && ii < 3 * 8) continue;
+            sum_of_hf += std::abs(orig_blk[ii]);
+          }
+          const int limit = sum_of_hf < 60 ? 4 : 8;
+          precious = std::abs(orig_blk[k]) >= limit;
+        }
         if (!precious || newval != 0) blk[k] = (int16_t)newval;
-        AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
+        if (histo_now) AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
         next_cand[b] += direction;
         if (!touched[b]) {
           touched[b] = 1;
           dirty.push_back(b);
         }
-        val_threshold = order[i].second;
+        val_threshold = sorted[i].second;
         ++changed_coeffs;
-        if (i % 10 == 0) ac_header = (int)EntropyCodes(ac_histo, ac_depths.data());
-        est_size = header_size + dc_size + ac_header +
-                   (int)EntropyDataSize(ac_histo, ac_depths.data());
-        if (changed_coeffs > min_coeffs_to_change &&
-            std::abs(est_size - prev_size) > min_size_delta)
-          break;
+      };
+      // The stopping rule can only fire once changed_coeffs > min_coeffs_to_change, and the
+      // size estimate of step i uses the Huffman depths refreshed at the last multiple of 10
+      // not above i.  Up to that refresh point nothing the estimate produces is observable,
+      // so those steps only edit coefficients; their histogram effect is applied per block.
+      {
+        const size_t last_needed = std::min<size_t>((size_t)std::max(min_coeffs_to_change, 0), n_order - 1);
+        const size_t fast_until = last_needed / 10 * 10;
+        for (size_t i = 0; i < fast_until; ++i) apply_step(i, false);
+        for (size_t j = 0; j < pending.size(); ++j) {
+          const int c = pending[j] / nb, b = pending[j] % nb;
+          AddBlockACSymbols(&img_[c * comp_stride + (size_t)b * 64], quant_[c], 1, &ac_histo[c]);
+          pending_flag[pending[j]] = 0;
+        }
+        pending.clear();
+        n_steps_ += (long)fast_until;
+        for (size_t i = fast_until; i < n_order; ++i) {
+          apply_step(i, true);
+          if (i % 10 == 0) {
+            Stopwatch cw;
+            ac_header = (int)EntropyCodes(ac_histo, ac_depths.data());
+            t_pb_codes_ += cw.lap();
+          }
+          ++n_steps_;
+          est_size = header_size + dc_size + ac_header +
+                     (int)EntropyDataSize(ac_histo, ac_depths.data());
+          if (changed_coeffs > min_coeffs_to_change &&
+              std::abs(est_size - prev_size) > min_size_delta)
+            break;
+        }
       }
       const size_t order_size = order.size();
       for (int b = 0; b < nb; ++b) max_block_error[b] += weight[b] * val_threshold * direction;
@@ -532,6 +587,13 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   stats_->timers["block_search"] = t_blocksearch_;
   stats_->timers["phase_b_host"] = t_phaseb_;
   stats_->timers["block_upload"] = t_upload_;
+  stats_->timers["pb_weights"] = t_pb_weights_;
+  stats_->timers["pb_order"] = t_pb_order_;
+  stats_->timers["pb_sort"] = t_pb_sort_;
+  stats_->timers["pb_loop"] = t_pb_loop_;
+  stats_->timers["pb_loop_codes"] = t_pb_codes_;
+  stats_->counters["phase B coefficient steps"] = (int)n_steps_;
+  stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
   stats_->timers["total"] = total.lap();
   *out = best_jpg_;
   return true;

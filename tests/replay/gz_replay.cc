@@ -1,0 +1,240 @@
+// TEST INFRASTRUCTURE ONLY -- record / replay shim of the C ABI (include/guetzli_amd.h)
+// for the entry points the host search driver (guetzli_amd/host) calls.
+//
+// Purpose: the host driver's decisions (quant-matrix bisection, global coefficient order,
+// entropy-size model, JPEG bytes) can be exercised at REAL image sizes on a machine
+// without a GPU.  On the GPU box the shim runs in RECORD mode: every call is forwarded to
+// the real gfx950 library (dlopen) and its device-computed results are appended to a log.
+// In REPLAY mode the log stands in for the device: the host driver linked against this
+// shim must reproduce the reference's JPEG byte for byte from it.  Nothing under
+// guetzli_amd/ links or loads this file; it is never a fallback of the product.
+//
+//   GZ_REPLAY_MODE = record | replay
+//   GZ_REPLAY_FILE = log path
+//   GZ_REPLAY_REAL = path of the real libguetzli_amd.so (record mode)
+//
+// Replayed results: original coefficients (gz_encode_rgb), distance + per-block maxima of
+// every gz_compare, the CSR arrays of gz_block_zeroing_orders.  Integer work that is a
+// pure function of replayed data (gz_quantize) is recomputed with the reference formula
+// (quantize.h:24-29); gz_block_weights runs the product's own header.
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../guetzli_amd/csrc/gz_host_weights.h"
+#include "../../include/guetzli_amd.h"
+
+namespace {
+
+struct Real {
+  void* h = nullptr;
+  decltype(&gz_create) create;
+  decltype(&gz_destroy) destroy;
+  decltype(&gz_encode_rgb) encode_rgb;
+  decltype(&gz_quantize) quantize;
+  decltype(&gz_compare) compare;
+  decltype(&gz_block_weights) block_weights;
+  decltype(&gz_block_zeroing_orders) block_zeroing_orders;
+  decltype(&gz_set_coeff_blocks) set_coeff_blocks;
+  decltype(&gz_strerror) strerror_;
+  decltype(&gz_last_error) last_error;
+};
+
+bool recording() {
+  const char* m = getenv("GZ_REPLAY_MODE");
+  return m && strcmp(m, "record") == 0;
+}
+
+Real* real() {
+  static Real r;
+  if (r.h) return &r;
+  const char* p = getenv("GZ_REPLAY_REAL");
+  r.h = dlopen(p ? p : "libguetzli_amd.so", RTLD_NOW | RTLD_LOCAL);
+  if (!r.h) {
+    fprintf(stderr, "gz_replay: cannot open real library: %s\n", dlerror());
+    abort();
+  }
+#define SYM(field, name) r.field = (decltype(r.field))dlsym(r.h, name); if (!r.field) abort();
+  SYM(create, "gz_create") SYM(destroy, "gz_destroy") SYM(encode_rgb, "gz_encode_rgb")
+  SYM(quantize, "gz_quantize") SYM(compare, "gz_compare") SYM(block_weights, "gz_block_weights")
+  SYM(block_zeroing_orders, "gz_block_zeroing_orders")
+  SYM(set_coeff_blocks, "gz_set_coeff_blocks") SYM(strerror_, "gz_strerror")
+  SYM(last_error, "gz_last_error")
+#undef SYM
+  return &r;
+}
+
+enum Tag : int32_t { T_CREATE = 1, T_ORIG = 2, T_COMPARE = 3, T_ORDERS = 4 };
+
+}  // namespace
+
+struct gz_ctx {
+  gz_ctx* inner = nullptr;   // record mode: the real context
+  FILE* f = nullptr;
+  int w = 0, h = 0, bw = 0, bh = 0, nb = 0;
+  float target = 0;
+  std::vector<int16_t> orig;
+  std::vector<float> bmax;
+  bool have_bmax = false;
+  std::string err;
+};
+
+namespace {
+
+void put(gz_ctx* c, const void* p, size_t n) {
+  if (fwrite(p, 1, n, c->f) != n) { fprintf(stderr, "gz_replay: write failed\n"); abort(); }
+}
+void get(gz_ctx* c, void* p, size_t n) {
+  if (fread(p, 1, n, c->f) != n) { fprintf(stderr, "gz_replay: log exhausted\n"); abort(); }
+}
+void put_tag(gz_ctx* c, int32_t t) { put(c, &t, 4); }
+void expect_tag(gz_ctx* c, int32_t t) {
+  int32_t g = 0;
+  get(c, &g, 4);
+  if (g != t) { fprintf(stderr, "gz_replay: log out of sync (want %d got %d)\n", t, g); abort(); }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gz_abi_version(void) { return 1; }
+const char* gz_strerror(int code) { return recording() ? real()->strerror_(code) : "replay error"; }
+const char* gz_last_error(const gz_ctx* c) {
+  if (!c) return "";
+  return c->inner ? real()->last_error(c->inner) : c->err.c_str();
+}
+
+gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, int* err) {
+  const char* path = getenv("GZ_REPLAY_FILE");
+  if (!path) { fprintf(stderr, "gz_replay: GZ_REPLAY_FILE not set\n"); abort(); }
+  gz_ctx* c = new gz_ctx;
+  c->w = w; c->h = h; c->bw = (w + 7) / 8; c->bh = (h + 7) / 8; c->nb = c->bw * c->bh;
+  c->target = target;
+  if (err) *err = GZ_OK;
+  if (recording()) {
+    c->inner = real()->create(device, w, h, rgb, target, err);
+    if (!c->inner) { delete c; return nullptr; }
+    c->f = fopen(path, "wb");
+    if (!c->f) abort();
+    put_tag(c, T_CREATE);
+    const int32_t hdr[2] = {w, h};
+    put(c, hdr, 8);
+    put(c, &target, 4);
+  } else {
+    c->f = fopen(path, "rb");
+    if (!c->f) { fprintf(stderr, "gz_replay: cannot open %s\n", path); abort(); }
+    expect_tag(c, T_CREATE);
+    int32_t hdr[2];
+    float t;
+    get(c, hdr, 8);
+    get(c, &t, 4);
+    if (hdr[0] != w || hdr[1] != h || t != target) {
+      fprintf(stderr, "gz_replay: log is for %dx%d target %g\n", hdr[0], hdr[1], t);
+      abort();
+    }
+  }
+  return c;
+}
+
+void gz_destroy(gz_ctx* c) {
+  if (!c) return;
+  if (c->inner) real()->destroy(c->inner);
+  if (c->f) fclose(c->f);
+  delete c;
+}
+
+int gz_encode_rgb(gz_ctx* c, int16_t* coeffs_out) {
+  const size_t n = (size_t)3 * c->nb * 64;
+  c->orig.resize(n);
+  if (c->inner) {
+    const int rc = real()->encode_rgb(c->inner, c->orig.data());
+    if (rc != GZ_OK) return rc;
+    put_tag(c, T_ORIG);
+    put(c, c->orig.data(), n * 2);
+  } else {
+    expect_tag(c, T_ORIG);
+    get(c, c->orig.data(), n * 2);
+  }
+  if (coeffs_out) memcpy(coeffs_out, c->orig.data(), n * 2);
+  return GZ_OK;
+}
+
+int gz_quantize(gz_ctx* c, const int* q, int16_t* coeffs_out) {
+  if (c->inner) return real()->quantize(c->inner, q, coeffs_out);
+  if (!coeffs_out) return GZ_OK;
+  const size_t per = (size_t)c->nb * 64;
+  for (int ch = 0; ch < 3; ++ch)
+    for (size_t i = 0; i < per; ++i) {
+      const int quant = q ? q[ch * 64 + (int)(i & 63)] : 1;
+      const int raw = c->orig[ch * per + i];
+      const int r = raw % quant;
+      const int delta = 2 * r > quant ? quant - r : ((-2) * r > quant ? -quant - r : -r);
+      coeffs_out[ch * per + i] = (int16_t)(raw + delta);
+    }
+  return GZ_OK;
+}
+
+int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
+  if (distmap) { fprintf(stderr, "gz_replay: distmap download is not logged\n"); abort(); }
+  c->bmax.resize(c->nb);
+  if (c->inner) {
+    const int rc = real()->compare(c->inner, distance, nullptr, c->bmax.data());
+    if (rc != GZ_OK) return rc;
+    put_tag(c, T_COMPARE);
+    put(c, distance, 4);
+    put(c, c->bmax.data(), sizeof(float) * c->nb);
+  } else {
+    expect_tag(c, T_COMPARE);
+    get(c, distance, 4);
+    get(c, c->bmax.data(), sizeof(float) * c->nb);
+  }
+  c->have_bmax = true;
+  if (block_max) memcpy(block_max, c->bmax.data(), sizeof(float) * c->nb);
+  return GZ_OK;
+}
+
+int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target_mul,
+                     int use_distmap, float* block_weight) {
+  if (c->inner)
+    return real()->block_weights(c->inner, direction, max_block_dist, target_mul, use_distmap,
+                                 block_weight);
+  std::vector<float> zero;
+  const float* bmax = c->bmax.data();
+  if (!use_distmap) { zero.assign(c->nb, 0.0f); bmax = zero.data(); }
+  gz::block_weights_host(bmax, c->bw, c->bh, c->target, direction, max_block_dist, target_mul,
+                         block_weight);
+  return GZ_OK;
+}
+
+int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* offsets,
+                            uint8_t* idx, float* err, int cap) {
+  if (c->inner) {
+    const int rc = real()->block_zeroing_orders(c->inner, lookahead, new_model, offsets, idx, err, cap);
+    if (rc != GZ_OK) return rc;
+    put_tag(c, T_ORDERS);
+    put(c, offsets, sizeof(int32_t) * (c->nb + 1));
+    put(c, idx, offsets[c->nb]);
+    put(c, err, sizeof(float) * offsets[c->nb]);
+    return GZ_OK;
+  }
+  expect_tag(c, T_ORDERS);
+  get(c, offsets, sizeof(int32_t) * (c->nb + 1));
+  if (offsets[c->nb] > cap) return GZ_E_ARG;
+  get(c, idx, offsets[c->nb]);
+  get(c, err, sizeof(float) * offsets[c->nb]);
+  return GZ_OK;
+}
+
+int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int16_t* blocks) {
+  if (c->inner) return real()->set_coeff_blocks(c->inner, block_index, n, blocks);
+  for (int i = 0; i < n; ++i)
+    if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;
+  return GZ_OK;
+}
+
+}  // extern "C"

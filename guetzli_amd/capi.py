@@ -44,6 +44,10 @@ SIGNATURES = {
     "gz_block_weights": (_I, [_P, _I, _I, C.c_double, _I, _P]),
     "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
+    "gz_jpeg_histograms": (_I, [_P, _P, _P]),
+    "gz_jpeg_scan": (_I, [_P, _I, _P, _P, _P]),
+    "gz_jpeg_scan_keep": (_I, [_P]),
+    "gz_jpeg_scan_bytes": (_I, [_P, _I, _P, C.c_size_t, _P]),
     "gz_probe_blur": (_I, [_P, _P, C.c_float, C.c_float, _P]),
     "gz_probe_opsin": (_I, [_P, _P, _P]),
     "gz_probe_separate_frequencies": (_I, [_P, _P, _P]),
@@ -232,6 +236,35 @@ class Context:
                                                      _ptr(off), _ptr(idx), _ptr(err), cap))
         n = int(off[-1])
         return off, idx[:n].copy(), err[:n].copy()
+
+    # ---- entropy coding of the candidate ----
+    def jpeg_histograms(self, q):
+        """(DC, AC) x component x symbol occurrence counts, uint32 [2][3][256]."""
+        qq = np.ascontiguousarray(q, np.int32)
+        assert qq.shape == (3, 64)
+        counts = np.zeros((2, 3, 256), np.uint32)
+        self._chk(self.L.lib.gz_jpeg_histograms(self.handle, _ptr(qq), _ptr(counts)))
+        return counts
+
+    def jpeg_scan(self, ncomp, depth, code):
+        """Encodes the scan on the device; returns its exact (stuffed) size in bytes."""
+        d = np.ascontiguousarray(depth, np.uint8)
+        cd = np.ascontiguousarray(code, np.uint16)
+        assert d.shape == (2, 3, 256) and cd.shape == (2, 3, 256)
+        n = np.zeros(1, np.uint64)
+        self._chk(self.L.lib.gz_jpeg_scan(self.handle, ncomp, _ptr(d), _ptr(cd), _ptr(n)))
+        return int(n[0])
+
+    def jpeg_scan_keep(self):
+        self._chk(self.L.lib.gz_jpeg_scan_keep(self.handle))
+
+    def jpeg_scan_bytes(self, kept=False, cap=None):
+        cap = cap or (self.nb * 3 * 64 * 4 + 1024)
+        out = np.zeros(cap, np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self.L.lib.gz_jpeg_scan_bytes(self.handle, int(kept), _ptr(out), cap,
+                                                C.byref(n)))
+        return out[:n.value].tobytes()
 
     # ---- stage probes ----
     def probe_blur(self, plane, sigma, border_ratio):

@@ -24,6 +24,7 @@
 #include "gz_kernels_blur.h"
 #include "gz_kernels_diff.h"
 #include "gz_kernels_search.h"
+#include "gz_kernels_entropy.h"
 #include "gz_host_weights.h"
 #include "order_tables_generated.h"   // host-side csf/bias of order.inc
 
@@ -183,6 +184,19 @@ struct gz_ctx {
   bool have_block_mask = false;
   int32_t* d_rank_off = nullptr; uint8_t* d_rank_idx = nullptr;
   int32_t* d_out_cnt = nullptr; uint8_t* d_out_idx = nullptr; float* d_out_err = nullptr;
+
+  // device entropy coder (gz_kernels_entropy.h)
+  int* d_jq = nullptr;                    // [3][64] quant matrices of the frame being written
+  unsigned* d_hist = nullptr;             // [2][3][256]
+  unsigned char* d_code_depth = nullptr;  // [2][3][256]
+  unsigned short* d_code_bits = nullptr;  // [2][3][256]
+  unsigned* d_mcu_bits = nullptr;         // [nb]
+  unsigned long long* d_mcu_off = nullptr;   // [nb+1]
+  unsigned long long* d_ff_count = nullptr;
+  unsigned* d_words = nullptr; size_t words_cap = 0;        // scan bits of the last gz_jpeg_scan
+  unsigned* d_words_kept = nullptr; size_t words_kept_cap = 0;
+  unsigned long long scan_bits = 0, scan_ff = 0, kept_bits = 0, kept_ff = 0;
+  bool have_jq = false, have_scan = false, have_kept = false;
 
   bool have_orig = false, have_cand = false, have_distmap = false;
   std::vector<float> h_block_max;
@@ -726,6 +740,9 @@ void gz_destroy(gz_ctx* c) {
   hipFree(c->extra_arena);
   hipFree(c->d_block_mask); hipFree(c->d_rank_off); hipFree(c->d_rank_idx);
   hipFree(c->d_out_cnt); hipFree(c->d_out_idx); hipFree(c->d_out_err);
+  hipFree(c->d_jq); hipFree(c->d_hist); hipFree(c->d_code_depth); hipFree(c->d_code_bits);
+  hipFree(c->d_mcu_bits); hipFree(c->d_mcu_off); hipFree(c->d_ff_count);
+  hipFree(c->d_words); hipFree(c->d_words_kept);
   for (int b = 0; b < B_COUNT; ++b) hipFree(c->blur[b].d_scale);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -897,6 +914,122 @@ int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target
   if (!use_distmap) { zero.assign(c->nb, 0.0f); bmax = zero.data(); }
   block_weights_host(bmax, c->bw, c->bh, c->target, direction, max_block_dist, target_mul,
                      block_weight);
+  return GZ_OK;
+}
+
+
+// ------------------------------------------------------------- device entropy coder ----
+static int ensure_entropy_buffers(gz_ctx* c) {
+  if (c->d_jq) return GZ_OK;
+  HIPCHK(c, hipMalloc((void**)&c->d_jq, sizeof(int) * 192));
+  HIPCHK(c, hipMalloc((void**)&c->d_hist, sizeof(unsigned) * 1536));
+  HIPCHK(c, hipMalloc((void**)&c->d_code_depth, 1536));
+  HIPCHK(c, hipMalloc((void**)&c->d_code_bits, sizeof(unsigned short) * 1536));
+  HIPCHK(c, hipMalloc((void**)&c->d_mcu_bits, sizeof(unsigned) * c->nb));
+  HIPCHK(c, hipMalloc((void**)&c->d_mcu_off, sizeof(unsigned long long) * (c->nb + 1)));
+  HIPCHK(c, hipMalloc((void**)&c->d_ff_count, sizeof(unsigned long long)));
+  return GZ_OK;
+}
+
+int gz_jpeg_histograms(gz_ctx* c, const int* q, uint32_t* counts) {
+  if (!c || !q || !counts) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  for (int i = 0; i < 192; ++i) if (q[i] <= 0) return GZ_E_ARG;
+  TRY(ensure_entropy_buffers(c));
+  HIPCHK(c, hipMemcpyAsync(c->d_jq, q, sizeof(int) * 192, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_hist, 0, sizeof(unsigned) * 1536, c->stream));
+  const int grid = std::min(c->nb, 2048);
+  GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64), c->stream, (const int16_t*)c->d_cand,
+            (const int*)c->d_jq, c->nb, c->d_hist);
+  KCHK(c);
+  HIPCHK(c, hipMemcpyAsync(counts, c->d_hist, sizeof(unsigned) * 1536, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_jq = true;
+  return GZ_OK;
+}
+
+int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* code,
+                 uint64_t* scan_bytes) {
+  if (!c || !depth || !code || !scan_bytes || (ncomp != 1 && ncomp != 3)) return GZ_E_ARG;
+  if (!c->have_cand || !c->have_jq) { c->err = "gz_jpeg_histograms must precede gz_jpeg_scan"; return GZ_E_STATE; }
+  HIPCHK(c, hipMemcpyAsync(c->d_code_depth, depth, 1536, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_code_bits, code, sizeof(unsigned short) * 1536, hipMemcpyHostToDevice, c->stream));
+  JpegCodes codes{c->d_code_depth, c->d_code_bits};
+  GZ_LAUNCH(k_jpeg_block_bits, dim3(c->nb), dim3(64), c->stream, (const int16_t*)c->d_cand,
+            (const int*)c->d_jq, c->nb, ncomp, codes, c->d_mcu_bits);
+  KCHK(c);
+  GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), c->stream, (const unsigned*)c->d_mcu_bits,
+            c->nb, c->d_mcu_off);
+  KCHK(c);
+  unsigned long long total_bits = 0;
+  HIPCHK(c, hipMemcpyAsync(&total_bits, c->d_mcu_off + c->nb, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // also: depth/code may live on the caller's stack
+  const unsigned long long nbytes = (total_bits + 7) / 8;
+  const size_t need_words = (size_t)(nbytes / 4 + 4);
+  if (need_words > c->words_cap) {
+    hipFree(c->d_words);
+    c->d_words = nullptr;
+    c->words_cap = need_words + need_words / 4 + 1024;
+    HIPCHK(c, hipMalloc((void**)&c->d_words, sizeof(unsigned) * c->words_cap));
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_words, 0, sizeof(unsigned) * need_words, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_ff_count, 0, 8, c->stream));
+  GZ_LAUNCH(k_jpeg_emit, dim3(c->nb), dim3(64), c->stream, (const int16_t*)c->d_cand,
+            (const int*)c->d_jq, c->nb, ncomp, codes, (const unsigned long long*)c->d_mcu_off,
+            c->d_words);
+  KCHK(c);
+  const int cgrid = (int)std::min<size_t>(1024, (need_words + 255) / 256);
+  GZ_LAUNCH(k_jpeg_count_ff, dim3(cgrid), dim3(256), c->stream, (const unsigned*)c->d_words,
+            nbytes, c->d_ff_count);
+  KCHK(c);
+  unsigned long long ff = 0;
+  HIPCHK(c, hipMemcpyAsync(&ff, c->d_ff_count, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->scan_bits = total_bits;
+  c->scan_ff = ff;
+  c->have_scan = true;
+  *scan_bytes = nbytes + ff;
+  return GZ_OK;
+}
+
+int gz_jpeg_scan_keep(gz_ctx* c) {
+  if (!c) return GZ_E_ARG;
+  if (!c->have_scan) { c->err = "no scan to keep"; return GZ_E_STATE; }
+  const size_t need_words = (size_t)((c->scan_bits + 7) / 8 / 4 + 4);
+  if (need_words > c->words_kept_cap) {
+    hipFree(c->d_words_kept);
+    c->d_words_kept = nullptr;
+    c->words_kept_cap = need_words + need_words / 4 + 1024;
+    HIPCHK(c, hipMalloc((void**)&c->d_words_kept, sizeof(unsigned) * c->words_kept_cap));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_words_kept, c->d_words, sizeof(unsigned) * need_words,
+                           hipMemcpyDeviceToDevice, c->stream));
+  c->kept_bits = c->scan_bits;
+  c->kept_ff = c->scan_ff;
+  c->have_kept = true;
+  return GZ_OK;
+}
+
+int gz_jpeg_scan_bytes(gz_ctx* c, int kept, uint8_t* out, size_t cap, size_t* n) {
+  if (!c || !out || !n) return GZ_E_ARG;
+  if (kept ? !c->have_kept : !c->have_scan) { c->err = "no scan"; return GZ_E_STATE; }
+  const unsigned long long bits = kept ? c->kept_bits : c->scan_bits;
+  const unsigned long long ff = kept ? c->kept_ff : c->scan_ff;
+  const size_t nbytes = (size_t)((bits + 7) / 8);
+  *n = nbytes + (size_t)ff;
+  if (*n > cap) return GZ_E_ARG;
+  std::vector<unsigned> w(nbytes / 4 + 1);
+  HIPCHK(c, hipMemcpyAsync(w.data(), kept ? c->d_words_kept : c->d_words, sizeof(unsigned) * w.size(),
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // byte stuffing (BitWriter::EmitByte, jpeg_bit_writer.h:66-72): 0x00 after every 0xFF
+  size_t o = 0;
+  for (size_t j = 0; j < nbytes; ++j) {
+    const uint8_t b = (uint8_t)(w[j >> 2] >> (24 - 8 * (j & 3)));
+    out[o++] = b;
+    if (b == 0xff) out[o++] = 0;
+  }
+  if (o != *n) { c->err = "stuffed size mismatch"; return GZ_E_STATE; }
   return GZ_OK;
 }
 

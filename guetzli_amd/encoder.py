@@ -23,6 +23,9 @@ class HostLibrary:
         self.lib.gzh_write_jpeg.restype = C.c_long
         self.lib.gzh_write_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_long]
+        self.lib.gzh_jpeg_head.restype = C.c_long
+        self.lib.gzh_jpeg_head.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
         self.lib.gzh_butteraugli_score_for_quality.restype = C.c_double
         self.lib.gzh_butteraugli_score_for_quality.argtypes = [C.c_double]
 
@@ -66,6 +69,21 @@ class HostLibrary:
                                     int(q is None), out.ctypes.data, cap)
         assert 0 <= n <= cap, n
         return out[:n].tobytes()
+
+    def jpeg_head(self, counts, w, h, q=None, ncomp=3):
+        """SOI..SOS bytes + per-component Huffman codes (depth, code: [2][3][256]) from the
+        symbol counts of gz_jpeg_histograms; q=None is the q=1 'original' frame."""
+        cnt = np.ascontiguousarray(counts, np.uint32)
+        assert cnt.shape == (2, 3, 256)
+        qq = None if q is None else np.ascontiguousarray(q, np.int32)
+        head = np.zeros(1 << 16, np.uint8)
+        depth = np.zeros((2, 3, 256), np.uint8)
+        code = np.zeros((2, 3, 256), np.uint16)
+        n = self.lib.gzh_jpeg_head(cnt.ctypes.data, qq.ctypes.data if qq is not None else None,
+                                   w, h, ncomp, head.ctypes.data, head.size,
+                                   depth.ctypes.data, code.ctypes.data)
+        assert 0 <= n <= head.size, n
+        return head[:n].tobytes(), depth, code
 
     def butteraugli_score_for_quality(self, q):
         return self.lib.gzh_butteraugli_score_for_quality(q)

@@ -218,6 +218,28 @@ void FrameFromImage(const int16_t* coeffs, const int q[3][64], int w, int h, Fra
   AssignQuantTables(q, f);
 }
 
+void FrameTables(const int q[3][64], int w, int h, int ncomp, Frame* f) {
+  f->width = w;
+  f->height = h;
+  f->bw = (w + 7) / 8;
+  f->bh = (h + 7) / 8;
+  f->ncomp = ncomp;
+  for (int c = 0; c < 3; ++c) f->coeffs[c].clear();
+  if (q) {
+    AssignQuantTables(q, f);
+  } else {   // the q=1 frame of EncodeRGBToJpeg: three all-ones tables, all with index 0
+    f->quant.clear();
+    for (int c = 0; c < 3; ++c) {
+      QuantTable t;
+      for (int k = 0; k < 64; ++k) t.values[k] = 1;
+      t.precision = 0;
+      t.index = 0;
+      f->quant.push_back(t);
+      f->quant_idx[c] = c;
+    }
+  }
+}
+
 void FrameFromOriginal(const int16_t* coeffs, int w, int h, Frame* f) {
   f->width = w;
   f->height = h;
@@ -394,10 +416,14 @@ inline void Push16(std::string* s, size_t v) {
 
 }  // namespace
 
-bool WriteJpeg(const Frame& f, std::string* out) {
+bool BuildJpegHead(const Frame& f, const SymbolHistogram* dc_histo,
+                   const SymbolHistogram* ac_histo, JpegHead* head) {
+  std::string* out = &head->bytes;
   out->clear();
   const int nc = f.ncomp;
-  const size_t nb = (size_t)f.bw * f.bh;
+  head->ncomp = nc;
+  memset(head->depth, 0, sizeof(head->depth));
+  memset(head->code, 0, sizeof(head->code));
   out->push_back((char)0xff);
   out->push_back((char)0xd8);
   static const unsigned char kApp0[] = {0xff, 0xe0, 0x00, 0x10, 0x4a, 0x46, 0x49, 0x46, 0x00,
@@ -435,22 +461,20 @@ bool WriteJpeg(const Frame& f, std::string* out) {
     }
   }
   // Huffman codes (BuildAndEncodeHuffmanCodes :361-444)
-  std::vector<SymbolHistogram> histo(nc);
-  BuildDCHistograms(f, histo.data());
+  std::vector<SymbolHistogram> histo(dc_histo, dc_histo + nc);
   size_t num_dc = nc;
   int dc_index[4], ac_index[4];
   std::vector<uint8_t> depths((size_t)nc * kHistoSize);
   ClusterHistograms(histo.data(), &num_dc, dc_index, depths.data());
-  histo.resize(num_dc + nc);
+  histo.resize(num_dc);
+  histo.insert(histo.end(), ac_histo, ac_histo + nc);
   depths.resize((num_dc + nc) * kHistoSize);
-  BuildACHistograms(f, &histo[num_dc]);
   size_t num_ac = nc;
   ClusterHistograms(&histo[num_dc], &num_ac, ac_index, &depths[num_dc * kHistoSize]);
   const int num_histo = (int)(num_dc + num_ac);
   histo.resize(num_histo);
   int total_symbols = 0;
   for (int i = 0; i < num_histo; ++i) total_symbols += histo[i].NumSymbols();
-  CodeTable dc_table[3], ac_table[3];
   out->push_back((char)0xff);
   out->push_back((char)0xc4);
   Push16(out, 2 + (size_t)num_histo * 17 + total_symbols);
@@ -461,8 +485,12 @@ bool WriteJpeg(const Frame& f, std::string* out) {
     CodeTable table;
     CanonicalCode(&depths[(size_t)i * kHistoSize], counts, values, &table);
     for (int c = 0; c < nc; ++c) {
-      if (is_dc && dc_index[c] == idx) dc_table[c] = table;
-      if (!is_dc && ac_index[c] == idx) ac_table[c] = table;
+      if ((is_dc && dc_index[c] == idx) || (!is_dc && ac_index[c] == idx)) {
+        for (int j = 0; j < 256; ++j) {
+          head->depth[is_dc ? 0 : 1][c][j] = table.depth[j];
+          head->code[is_dc ? 0 : 1][c][j] = table.depth[j] == 255 ? 0 : (uint16_t)table.code[j];
+        }
+      }
     }
     int max_len = 16;
     while (max_len > 0 && counts[max_len] == 0) --max_len;
@@ -486,6 +514,26 @@ bool WriteJpeg(const Frame& f, std::string* out) {
     out->push_back((char)63);
     out->push_back((char)0);
   }
+  return true;
+}
+
+bool WriteJpeg(const Frame& f, std::string* out) {
+  const int nc = f.ncomp;
+  const size_t nb = (size_t)f.bw * f.bh;
+  SymbolHistogram dc_histo[3], ac_histo[3];
+  BuildDCHistograms(f, dc_histo);
+  BuildACHistograms(f, ac_histo);
+  JpegHead head;
+  if (!BuildJpegHead(f, dc_histo, ac_histo, &head)) return false;
+  *out = head.bytes;
+  CodeTable dc_table[3], ac_table[3];
+  for (int c = 0; c < nc; ++c)
+    for (int j = 0; j < 256; ++j) {
+      dc_table[c].depth[j] = head.depth[0][c][j];
+      dc_table[c].code[j] = head.code[0][c][j];
+      ac_table[c].depth[j] = head.depth[1][c][j];
+      ac_table[c].code[j] = head.code[1][c][j];
+    }
   // scan (EncodeScan :499-536), 4:4:4: one block per component per MCU
   {
     BitSink sink(out);

@@ -70,10 +70,28 @@ void FrameFromImage(const int16_t* coeffs, const int q[3][64], int w, int h, Fra
 // separate all-ones tables that all carry table index 0.
 void FrameFromOriginal(const int16_t* coeffs, int w, int h, Frame* f);
 
+// The tables of a frame without its coefficients (enough for HeaderSize / BuildJpegHead):
+// q = the image's quant matrices, or null for the q=1 "original" flavour.
+void FrameTables(const int q[3][64], int w, int h, int ncomp, Frame* f);
+
 void BuildDCHistograms(const Frame& f, SymbolHistogram* histo);   // :241-265
 void BuildACHistograms(const Frame& f, SymbolHistogram* histo);   // :267-275
 size_t HeaderSize(const Frame& f);                                // JpegHeaderSize :278-303
 size_t EstimateDCSize(const Frame& f);                            // processor.cc:527-535
+
+// Everything of the file in front of the entropy-coded scan -- SOI, APP0, DQT, SOF, DHT, SOS
+// (jpeg_data_writer.cc:33-127,361-444) -- built from the frame's tables (f.coeffs is not
+// read) and the symbol statistics, plus the per-component codes the scan is written with
+// (depth 255 = symbol has no code).  The scan itself comes from the device
+// (gz_jpeg_scan) or, in WriteJpeg, from the host bit writer.
+struct JpegHead {
+  int ncomp;
+  std::string bytes;
+  uint8_t depth[2][3][256];    // (DC, AC) x component x symbol
+  uint16_t code[2][3][256];
+};
+bool BuildJpegHead(const Frame& f, const SymbolHistogram* dc_histo,
+                   const SymbolHistogram* ac_histo, JpegHead* head);
 
 // WriteJpeg (jpeg_data_writer.cc:540-553) with strip_metadata semantics (a fixed JFIF
 // APP0).  Returns false on an internal inconsistency.

@@ -162,14 +162,19 @@ class Encoder {
   void Log(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
   void LogMatrix(const QuantMatrix q);
   bool Fail(const char* what, int rc);
-  void Serialize(std::string* jpg);   // SaveToJpegData + WriteJpeg of the current image
+  // SaveToJpegData + WriteJpeg of the current image: marker segments and Huffman codes
+  // on the host from the symbol statistics, the scan on the device.  *size = jpg.size().
+  bool DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolHistogram* ac);
+  bool Serialize(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac,
+                 size_t* size);
   bool CompareCurrent();
-  void MaybeOutput(const std::string& jpg);
+  bool MaybeOutput(size_t size);
+  bool VerifyAgainstHostWriter(const int (*q)[64], size_t size);
   bool DistanceOK(double target_mul) const { return distance_ <= target_mul * params_.butteraugli_target; }
   bool TryMatrix(float target_mul, const QuantMatrix q, Trial* t);
   bool SelectMatrix(QuantMatrix best);
   bool SelectFrequencyMasking(double target_mul);
-  bool SetImageFromQuantization(const QuantMatrix q);
+  bool SetImageFromQuantization(const QuantMatrix q, bool download);
 
   Params params_;
   ProcessStats* stats_;
@@ -179,7 +184,10 @@ class Encoder {
   std::vector<int16_t> img_;     // coefficients of the working image (OutputImage::coeffs_)
   QuantMatrix quant_;            // its quant matrices
   float distance_ = 0.0f;        // ButteraugliComparator::distance_
-  std::string best_jpg_;         // GuetzliOutput
+  JpegHead head_;                // marker segments + codes of the last Serialize
+  std::string best_head_;        // GuetzliOutput: head of the best candidate; its scan is
+                                 // kept on the device (gz_jpeg_scan_keep)
+  bool verify_ = false;          // GZ_VERIFY_ENTROPY=1: cross-check against the host writer
   double best_score_ = -1;
   double t_write_ = 0, t_compare_ = 0, t_quant_ = 0, t_blocksearch_ = 0, t_phaseb_ = 0,
          t_upload_ = 0;
@@ -214,12 +222,72 @@ bool Encoder::Fail(const char* what, int rc) {
   return false;
 }
 
-void Encoder::Serialize(std::string* jpg) {
+static bool ChromaAllZero(const SymbolHistogram* dc, const SymbolHistogram* ac) {
+  // all DC differences zero (so every DC is zero) and nothing but end-of-block in AC
+  for (int c = 1; c < 3; ++c)
+    for (int i = 1; i + 1 < kHistoSize; ++i)
+      if (dc[c].counts[i] || ac[c].counts[i]) return false;
+  return true;
+}
+
+bool Encoder::DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolHistogram* ac) {
+  std::vector<uint32_t> counts(2 * 3 * 256);
+  const int rc = gz_jpeg_histograms(ctx_, &q[0][0], counts.data());
+  if (rc != GZ_OK) return Fail("gz_jpeg_histograms", rc);
+  for (int c = 0; c < 3; ++c) {
+    dc[c].Clear();
+    ac[c].Clear();
+    for (int i = 0; i < 256; ++i) {
+      dc[c].Add(i, (int)counts[(0 * 3 + c) * 256 + i]);
+      ac[c].Add(i, (int)counts[(1 * 3 + c) * 256 + i]);
+    }
+  }
+  return true;
+}
+
+bool Encoder::Serialize(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac,
+                        size_t* size) {
   Stopwatch sw;
   Frame f;
-  FrameFromImage(img_.data(), quant_, w_, h_, &f);
-  WriteJpeg(f, jpg);
+  // a single component is written when both chroma planes are entirely zero
+  // (OutputImage::SaveToJpegData, output_image.cc:348-409); the q=1 original always has 3
+  FrameTables(q, w_, h_, q && ChromaAllZero(dc, ac) ? 1 : 3, &f);
+  if (!BuildJpegHead(f, dc, ac, &head_)) return Fail("BuildJpegHead", GZ_E_STATE);
+  uint64_t scan_bytes = 0;
+  const int rc = gz_jpeg_scan(ctx_, head_.ncomp, &head_.depth[0][0][0], &head_.code[0][0][0],
+                              &scan_bytes);
+  if (rc != GZ_OK) return Fail("gz_jpeg_scan", rc);
+  *size = head_.bytes.size() + (size_t)scan_bytes + 2;   // + EOI
   t_write_ += sw.lap();
+  if (verify_ && !VerifyAgainstHostWriter(q, *size)) return false;
+  return true;
+}
+
+// Test hook (GZ_VERIFY_ENTROPY=1): the device scan + host head must equal the serial host
+// writer on the same coefficients, byte for byte.
+bool Encoder::VerifyAgainstHostWriter(const int (*q)[64], size_t size) {
+  std::vector<int16_t> co(img_.size());
+  int rc = gz_get_coeffs(ctx_, co.data());
+  if (rc != GZ_OK) return Fail("gz_get_coeffs", rc);
+  Frame f;
+  if (q) FrameFromImage(co.data(), q, w_, h_, &f);
+  else FrameFromOriginal(co.data(), w_, h_, &f);
+  std::string ref;
+  WriteJpeg(f, &ref);
+  std::string got = head_.bytes;
+  std::vector<uint8_t> scan(3 * co.size() + 1024);
+  size_t n = 0;
+  rc = gz_jpeg_scan_bytes(ctx_, 0, scan.data(), scan.size(), &n);
+  if (rc != GZ_OK) return Fail("gz_jpeg_scan_bytes", rc);
+  got.append((const char*)scan.data(), n);
+  got.push_back((char)0xff);
+  got.push_back((char)0xd9);
+  if (got != ref || got.size() != size) {
+    fprintf(stderr, "guetzli_amd: device entropy coder mismatch (device %zu/%zu bytes, host %zu)\n",
+            got.size(), size, ref.size());
+    return false;
+  }
+  return true;
 }
 
 bool Encoder::CompareCurrent() {   // comparator_->Compare(*img)
@@ -231,21 +299,24 @@ bool Encoder::CompareCurrent() {   // comparator_->Compare(*img)
   return true;
 }
 
-void Encoder::MaybeOutput(const std::string& jpg) {   // processor.cc:139-148
-  const double score = ScoreJPEG(distance_, (int)jpg.size(), params_.butteraugli_target);
+bool Encoder::MaybeOutput(size_t size) {   // processor.cc:139-148
+  const double score = ScoreJPEG(distance_, (int)size, params_.butteraugli_target);
   Log(" Score[%.4f]", score);
   if (score < best_score_ || best_score_ < 0) {
-    best_jpg_ = jpg;
+    best_head_ = head_.bytes;
+    const int rc = gz_jpeg_scan_keep(ctx_);
+    if (rc != GZ_OK) return Fail("gz_jpeg_scan_keep", rc);
     best_score_ = score;
     Log(" (*)");
   }
   Log("\n");
+  return true;
 }
 
 // img := orig, then ApplyGlobalQuantization(q); device and host copies.
-bool Encoder::SetImageFromQuantization(const QuantMatrix q) {
+bool Encoder::SetImageFromQuantization(const QuantMatrix q, bool download) {
   Stopwatch sw;
-  const int rc = gz_quantize(ctx_, &q[0][0], img_.data());
+  const int rc = gz_quantize(ctx_, &q[0][0], download ? img_.data() : nullptr);
   t_quant_ += sw.lap();
   if (rc != GZ_OK) return Fail("gz_quantize", rc);
   memcpy(quant_, q, sizeof(QuantMatrix));
@@ -254,19 +325,19 @@ bool Encoder::SetImageFromQuantization(const QuantMatrix q) {
 
 bool Encoder::TryMatrix(float target_mul, const QuantMatrix q, Trial* t) {   // :298-326
   memcpy(t->q, q, sizeof(QuantMatrix));
-  if (!SetImageFromQuantization(q)) return false;
-  std::string jpg;
-  Serialize(&jpg);
+  if (!SetImageFromQuantization(q, false)) return false;
+  SymbolHistogram dc[3], ac[3];
+  size_t size = 0;
+  if (!DeviceHistograms(q, dc, ac) || !Serialize(q, dc, ac, &size)) return false;
   Log("Iter %2d: %s quantization matrix:\n", stats_->counters[kNumItersCnt] + 1, "f111111");
   LogMatrix(q);
   Log("Iter %2d: %s GQ[%5.2f] Out[%7zd]", stats_->counters[kNumItersCnt] + 1, "f111111",
-      HeuristicScore(q), jpg.size());
+      HeuristicScore(q), size);
   ++stats_->counters[kNumItersCnt];
   if (!CompareCurrent()) return false;
   t->dist_ok = DistanceOK(target_mul);
-  t->jpg_size = jpg.size();
-  MaybeOutput(jpg);
-  return true;
+  t->jpg_size = size;
+  return MaybeOutput(size);
 }
 
 bool Encoder::SelectMatrix(QuantMatrix best_q) {   // SelectQuantMatrix, :328-360
@@ -328,14 +399,18 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   if (rc != GZ_OK) return Fail("gz_block_zeroing_orders", rc);
 
   // ---- size model of the starting point ----
-  SymbolHistogram ac_histo[3];
+  SymbolHistogram dc_histo[3], ac_histo[3];
   int header_size, dc_size;
   {
+    if (!DeviceHistograms(quant_, dc_histo, ac_histo)) return false;
     Frame f;
-    FrameFromImage(img_.data(), quant_, w_, h_, &f);
+    FrameTables(quant_, w_, h_, ChromaAllZero(dc_histo, ac_histo) ? 1 : 3, &f);
     header_size = (int)HeaderSize(f);
-    dc_size = (int)EstimateDCSize(f);
-    BuildACHistograms(f, ac_histo);
+    SymbolHistogram dcs[3] = {dc_histo[0], dc_histo[1], dc_histo[2]};
+    size_t num = f.ncomp;
+    int indexes[3];
+    uint8_t depths[3 * kHistoSize];
+    dc_size = (int)ClusterHistograms(dcs, &num, indexes, depths);   // EstimateDCSize
   }
   std::vector<uint8_t> ac_depths(3 * kHistoSize);
   int ac_header = (int)EntropyCodes(ac_histo, ac_depths.data());
@@ -505,15 +580,15 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       t_upload_ += sw.lap();
       if (rc != GZ_OK) return Fail("gz_set_coeff_blocks", rc);
 
-      std::string jpg;
-      Serialize(&jpg);
+      size_t jpg_size = 0;
+      if (!Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;
       Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
           "EstErr[%.2f%%]",
           stats_->counters[kNumItersCnt], "f111111", 7, direction > 0 ? "up" : "down",
           changed_coeffs, order_size, dirty.size(), blocks_to_change, nb, val_threshold,
-          jpg.size(), 100.0 - (100.0 * est_size) / jpg.size());
+          jpg_size, 100.0 - (100.0 * est_size) / jpg_size);
       if (!CompareCurrent()) return false;
-      MaybeOutput(jpg);
+      if (!MaybeOutput(jpg_size)) return false;
       prev_size = est_size;
       sw.lap();
     }
@@ -557,28 +632,26 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   stats_->timers["create+encode"] = sw.lap();
 
   // the unquantised original as the fallback output (processor.cc:826-846)
-  std::string jpg;
-  {
-    Frame f;
-    FrameFromOriginal(orig_.data(), w, h, &f);
-    Stopwatch ws;
-    WriteJpeg(f, &jpg);
-    t_write_ += ws.lap();
-  }
+  verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
   best_score_ = -1;
-  Log("Original Out[%7zd]", jpg.size());
   QuantMatrix ones;
   for (int c = 0; c < 3; ++c)
     for (int k = 0; k < 64; ++k) ones[c][k] = 1;
-  if (!SetImageFromQuantization(ones)) return false;
-  if (!CompareCurrent()) return false;
-  MaybeOutput(jpg);
+  if (!SetImageFromQuantization(ones, false)) return false;
+  {
+    SymbolHistogram dc[3], ac[3];
+    size_t size = 0;
+    if (!DeviceHistograms(ones, dc, ac) || !Serialize(nullptr, dc, ac, &size)) return false;
+    Log("Original Out[%7zd]", size);
+    if (!CompareCurrent()) return false;
+    if (!MaybeOutput(size)) return false;
+  }
 
   QuantMatrix best_q;
   memcpy(best_q, ones, sizeof(best_q));
   if (!SelectMatrix(best_q)) return false;
   stats_->timers["select_quant_matrix"] = sw.lap();
-  if (!SetImageFromQuantization(best_q)) return false;
+  if (!SetImageFromQuantization(best_q, true)) return false;
   if (!SelectFrequencyMasking(1.0)) return false;
   stats_->timers["select_frequency_masking"] = sw.lap();
   stats_->timers["jpeg_write"] = t_write_;
@@ -594,8 +667,17 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   stats_->timers["pb_loop_codes"] = t_pb_codes_;
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
+  {  // the winner: its head from the host, its scan from the device
+    std::vector<uint8_t> scan((size_t)6 * w * h + 4096);
+    size_t n = 0;
+    rc = gz_jpeg_scan_bytes(ctx_, 1, scan.data(), scan.size(), &n);
+    if (rc != GZ_OK) return Fail("gz_jpeg_scan_bytes", rc);
+    *out = best_head_;
+    out->append((const char*)scan.data(), n);
+    out->push_back((char)0xff);
+    out->push_back((char)0xd9);
+  }
   stats_->timers["total"] = total.lap();
-  *out = best_jpg_;
   return true;
 }
 
@@ -672,6 +754,30 @@ long gzh_write_jpeg(const int16_t* coeffs, int w, int h, const int* q, int origi
   if (!guetzli_amd::WriteJpeg(f, &s)) return -1;
   if ((long)s.size() <= cap) memcpy(out, s.data(), s.size());
   return (long)s.size();
+}
+
+// Marker segments + Huffman codes from symbol counts (test hook of BuildJpegHead):
+// counts uint32 [2][3][256] as gz_jpeg_histograms returns them; q null = the q=1 original.
+// Returns the head length (bytes copied to head_out if they fit) or -1.
+long gzh_jpeg_head(const uint32_t* counts, const int* q, int w, int h, int ncomp,
+                   uint8_t* head_out, long cap, uint8_t* depth /*[2][3][256]*/,
+                   uint16_t* code /*[2][3][256]*/) {
+  guetzli_amd::SymbolHistogram dc[3], ac[3];
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 256; ++i) {
+      dc[c].Add(i, (int)counts[(0 * 3 + c) * 256 + i]);
+      ac[c].Add(i, (int)counts[(1 * 3 + c) * 256 + i]);
+    }
+  guetzli_amd::Frame f;
+  int qq[3][64];
+  if (q) memcpy(qq, q, sizeof(qq));
+  guetzli_amd::FrameTables(q ? qq : nullptr, w, h, ncomp, &f);
+  guetzli_amd::JpegHead head;
+  if (!guetzli_amd::BuildJpegHead(f, dc, ac, &head)) return -1;
+  if ((long)head.bytes.size() <= cap) memcpy(head_out, head.bytes.data(), head.bytes.size());
+  memcpy(depth, head.depth, sizeof(head.depth));
+  memcpy(code, head.code, sizeof(head.code));
+  return (long)head.bytes.size();
 }
 
 }  // extern "C"

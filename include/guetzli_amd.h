@@ -146,6 +146,32 @@ int gz_block_zeroing_orders(gz_ctx* ctx, int lookahead, int new_model, int32_t* 
 int gz_rank_zeroing_candidates(const int16_t* coeffs, const int16_t* orig, int nb,
                                int new_model, int32_t* offsets, uint8_t* idx);
 
+/* Entropy coding of the candidate -----------------------------------------------------
+ * The search needs the exact size of every candidate's JPEG (ScoreJPEG) and the bytes of the
+ * winner only.  The candidate's coefficients are resident, so the symbol statistics and the
+ * scan are produced on the device; Huffman code construction (ClusterHistograms,
+ * BuildHuffmanCode, jpeg_data_writer.cc:158-342) and the marker segments stay on the host.
+ *
+ * gz_jpeg_histograms: BuildDCHistograms + BuildACHistograms (jpeg_data_writer.cc:241-275)
+ * of the candidate quantised by q (int[3][64]; value = coeff / q as in
+ * OutputImage::SaveToJpegData, output_image.cc:348-409).  counts: uint32 [2][3][256] =
+ * (DC, AC) x component x symbol, raw occurrence counts.  Remembers q for gz_jpeg_scan.
+ *
+ * gz_jpeg_scan: EncodeScan (:499-536) of the same frame with ncomp (1 or 3) components
+ * under the codes depth / code ([2][3][256] each, per component, already resolved through
+ * the DC/AC table indexes).  The bit stream stays on the device; *scan_bytes receives its
+ * exact length in bytes including the 0x00 stuffed after every 0xFF and the final
+ * 1-padding (jpeg_bit_writer.h:31-108).
+ *
+ * gz_jpeg_scan_keep snapshots the last scan on the device (the caller's "best so far",
+ * processor.cc:139-148); gz_jpeg_scan_bytes downloads the last (kept = 0) or the kept
+ * (kept = 1) scan as stuffed bytes. */
+int gz_jpeg_histograms(gz_ctx* ctx, const int* q, uint32_t* counts);
+int gz_jpeg_scan(gz_ctx* ctx, int ncomp, const uint8_t* depth, const uint16_t* code,
+                 uint64_t* scan_bytes);
+int gz_jpeg_scan_keep(gz_ctx* ctx);
+int gz_jpeg_scan_bytes(gz_ctx* ctx, int kept, uint8_t* out, size_t cap, size_t* n);
+
 /* Stage probes (parity tests) -----------------------------------------------------
  * Each runs ONE stage of the pipeline on host-provided input through the same kernels
  * gz_compare uses.  They exist so that tests can localise a divergence; they are not on

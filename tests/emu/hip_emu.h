@@ -88,6 +88,14 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       }
   s.body = nullptr;
 }
+inline int linear_tid() {
+  State& s = st();
+  return (int)(s.threadIdx.x + s.blockDim.x * (s.threadIdx.y + s.blockDim.y * s.threadIdx.z));
+}
+inline int num_threads() {
+  State& s = st();
+  return (int)(s.blockDim.x * s.blockDim.y * s.blockDim.z);
+}
 }  // namespace hipemu
 
 #define threadIdx (hipemu::st().threadIdx)
@@ -134,6 +142,63 @@ inline float __uint_as_float(unsigned u) {
   memcpy(&f, &u, 4);
   return f;
 }
+
+inline unsigned atomicOr(unsigned* p, unsigned v) {
+  unsigned o = *p;
+  *p |= v;
+  return o;
+}
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+  unsigned long long o = *p;
+  *p += v;
+  return o;
+}
+
+// ---- wavefront operations (wave64) ----
+// Emulated with two scheduler round trips (every fiber publishes, every fiber reads), so
+// they behave like the hardware's convergent lane exchange PROVIDED all threads of the
+// workgroup execute them together -- which is how the product kernels use them.
+namespace hipemu {
+inline long long* wave_slots() {
+  static long long slots[1024];
+  return slots;
+}
+inline void yield() {
+  State& s = st();
+  swapcontext(&s.fibers[s.current], &s.sched);
+}
+}  // namespace hipemu
+inline unsigned long long __ballot(int pred) {
+  const int tid = hipemu::linear_tid();
+  hipemu::wave_slots()[tid] = pred ? 1 : 0;
+  hipemu::yield();
+  const int base = tid & ~63;
+  const int nt = hipemu::num_threads();
+  unsigned long long m = 0;
+  for (int i = 0; i < 64 && base + i < nt; ++i)
+    if (hipemu::wave_slots()[base + i]) m |= 1ull << i;
+  hipemu::yield();
+  return m;
+}
+inline int __shfl(int v, int src_lane) {
+  const int tid = hipemu::linear_tid();
+  hipemu::wave_slots()[tid] = v;
+  hipemu::yield();
+  const int r = (int)hipemu::wave_slots()[(tid & ~63) + (src_lane & 63)];
+  hipemu::yield();
+  return r;
+}
+inline int __shfl_up(int v, unsigned delta) {
+  const int tid = hipemu::linear_tid();
+  hipemu::wave_slots()[tid] = v;
+  hipemu::yield();
+  const int lane = tid & 63;
+  const int r = lane >= (int)delta ? (int)hipemu::wave_slots()[tid - (int)delta] : v;
+  hipemu::yield();
+  return r;
+}
+inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
+inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 
 // ---- runtime shims ----
 typedef int hipError_t;

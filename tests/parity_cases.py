@@ -144,3 +144,85 @@ def case_block_search(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
         assert_bits_equal(err, eerr, "candidate errors")
         assert off[-1] > 0
     oc.close()
+
+
+ZIGZAG_NATURAL = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
+                  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                  58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def expected_jpeg_histograms(cq, q):
+    """BuildDCHistograms / BuildACHistograms (jpeg_data_writer.cc:241-275) from their
+    definition, on quantised values cq / q (C truncation)."""
+    cq = cq.astype(np.int64)
+    qq = np.asarray(q, np.int64)[:, None, :]
+    qv = np.sign(cq) * (np.abs(cq) // qq)
+    counts = np.zeros((2, 3, 256), np.int64)
+    for c in range(3):
+        dc = qv[c, :, 0]
+        diff = np.abs(np.diff(np.concatenate([[0], dc])))
+        nbits = np.where(diff > 0, np.floor(np.log2(np.maximum(diff, 1))).astype(np.int64) + 1, 0)
+        np.add.at(counts[0, c], nbits, 1)
+        zz = qv[c][:, ZIGZAG_NATURAL]
+        for blk in zz:
+            run = 0
+            for k in range(1, 64):
+                v = int(blk[k])
+                if v == 0:
+                    run += 1
+                    continue
+                while run > 15:
+                    counts[1, c, 0xf0] += 1
+                    run -= 16
+                counts[1, c, (run << 4) + abs(v).bit_length()] += 1
+                run = 0
+            if run > 0:
+                counts[1, c, 0] += 1
+    return counts.astype(np.uint32)
+
+
+def case_jpeg_entropy(L, host, w, h, x0=0, y0=0, check_histograms=True):
+    """Device symbol statistics + device scan (gz_jpeg_histograms / gz_jpeg_scan) with the
+    host-built marker segments must reproduce the reference's WriteJpeg byte for byte."""
+    from checkers import ref
+    rng = np.random.default_rng(RNG_SEED + 31 * w + h)
+    rgb = images.crop(w, h, x0, y0) if max(w, h) <= 444 else images.tiled(w, h)
+    co = oracle.encode_rgb(rgb)
+    nb = co.shape[1]
+    qs = [None,
+          np.full((3, 64), 3, np.int32),
+          np.stack([rng.integers(1, 9, 64), rng.integers(1, 30, 64), rng.integers(1, 30, 64)]).astype(np.int32),
+          np.stack([rng.integers(200, 400, 64), rng.integers(1, 30, 64), rng.integers(1, 30, 64)]).astype(np.int32)]
+    cases = []
+    for q in qs:
+        cq, _, _ = oracle.reconstruct(co, w, h, q)
+        cases.append((cq, q, False))
+    # dense large-magnitude coefficients (long MCUs, long codes, ZRL runs), q = 1
+    wild = rng.integers(-2040, 2041, size=co.shape).astype(np.int16)
+    wild[:, :, 1:][rng.random((3, nb, 63)) < 0.35] = 0
+    wild[:, nb // 3:nb // 3 + 2, 1:40] = 0
+    cases.append((wild, np.ones((3, 64), np.int32), False))
+    # grey image: both chroma planes zero -> a single-component frame
+    grey = cases[1][0].copy()
+    grey[1:] = 0
+    cases.append((grey, qs[1], True))
+    with L.context(rgb, 1.0) as ctx:
+        for cq, q, is_grey in cases:
+            qq = np.ones((3, 64), np.int32) if q is None else q
+            ctx.set_coeffs(cq)
+            counts = ctx.jpeg_histograms(qq)
+            if check_histograms:
+                assert_bits_equal(counts, expected_jpeg_histograms(cq, qq), "jpeg histograms")
+            ncomp = 1 if is_grey else 3
+            head, depth, code = host.jpeg_head(counts, w, h, q, ncomp)
+            n = ctx.jpeg_scan(ncomp, depth, code)
+            scan = ctx.jpeg_scan_bytes()
+            assert len(scan) == n
+            got = head + scan + b"\xff\xd9"
+            exp = host.write_jpeg(cq, w, h, q)           # pinned to the reference in
+            assert got == exp, (len(got), len(exp))      # test_host_encoder.test_write_jpeg_bytes
+            if ref is not None and q is not None and not is_grey and cq is not wild:
+                assert got == ref.write_jpeg(co, w, h, q)
+            ctx.jpeg_scan_keep()
+            assert ctx.jpeg_scan_bytes(kept=True) == scan

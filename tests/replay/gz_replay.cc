@@ -40,6 +40,11 @@ struct Real {
   decltype(&gz_block_weights) block_weights;
   decltype(&gz_block_zeroing_orders) block_zeroing_orders;
   decltype(&gz_set_coeff_blocks) set_coeff_blocks;
+  decltype(&gz_get_coeffs) get_coeffs;
+  decltype(&gz_jpeg_histograms) jpeg_histograms;
+  decltype(&gz_jpeg_scan) jpeg_scan;
+  decltype(&gz_jpeg_scan_keep) jpeg_scan_keep;
+  decltype(&gz_jpeg_scan_bytes) jpeg_scan_bytes;
   decltype(&gz_strerror) strerror_;
   decltype(&gz_last_error) last_error;
 };
@@ -63,12 +68,15 @@ Real* real() {
   SYM(quantize, "gz_quantize") SYM(compare, "gz_compare") SYM(block_weights, "gz_block_weights")
   SYM(block_zeroing_orders, "gz_block_zeroing_orders")
   SYM(set_coeff_blocks, "gz_set_coeff_blocks") SYM(strerror_, "gz_strerror")
-  SYM(last_error, "gz_last_error")
+  SYM(last_error, "gz_last_error") SYM(get_coeffs, "gz_get_coeffs")
+  SYM(jpeg_histograms, "gz_jpeg_histograms") SYM(jpeg_scan, "gz_jpeg_scan")
+  SYM(jpeg_scan_keep, "gz_jpeg_scan_keep") SYM(jpeg_scan_bytes, "gz_jpeg_scan_bytes")
 #undef SYM
   return &r;
 }
 
-enum Tag : int32_t { T_CREATE = 1, T_ORIG = 2, T_COMPARE = 3, T_ORDERS = 4 };
+enum Tag : int32_t { T_CREATE = 1, T_ORIG = 2, T_COMPARE = 3, T_ORDERS = 4, T_HISTO = 5, T_SCAN = 6,
+                     T_BYTES = 7 };
 
 }  // namespace
 
@@ -234,6 +242,60 @@ int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int1
   if (c->inner) return real()->set_coeff_blocks(c->inner, block_index, n, blocks);
   for (int i = 0; i < n; ++i)
     if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;
+  return GZ_OK;
+}
+
+int gz_get_coeffs(gz_ctx* c, int16_t* out) {
+  if (c->inner) return real()->get_coeffs(c->inner, out);
+  fprintf(stderr, "gz_replay: gz_get_coeffs is not logged\n");
+  abort();
+}
+
+int gz_jpeg_histograms(gz_ctx* c, const int* q, uint32_t* counts) {
+  if (c->inner) {
+    const int rc = real()->jpeg_histograms(c->inner, q, counts);
+    if (rc != GZ_OK) return rc;
+    put_tag(c, T_HISTO);
+    put(c, counts, sizeof(uint32_t) * 1536);
+    return GZ_OK;
+  }
+  expect_tag(c, T_HISTO);
+  get(c, counts, sizeof(uint32_t) * 1536);
+  return GZ_OK;
+}
+
+int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* code,
+                 uint64_t* scan_bytes) {
+  if (c->inner) {
+    const int rc = real()->jpeg_scan(c->inner, ncomp, depth, code, scan_bytes);
+    if (rc != GZ_OK) return rc;
+    put_tag(c, T_SCAN);
+    put(c, scan_bytes, 8);
+    return GZ_OK;
+  }
+  expect_tag(c, T_SCAN);
+  get(c, scan_bytes, 8);
+  return GZ_OK;
+}
+
+int gz_jpeg_scan_keep(gz_ctx* c) { return c->inner ? real()->jpeg_scan_keep(c->inner) : GZ_OK; }
+
+int gz_jpeg_scan_bytes(gz_ctx* c, int kept, uint8_t* out, size_t cap, size_t* n) {
+  if (c->inner) {
+    const int rc = real()->jpeg_scan_bytes(c->inner, kept, out, cap, n);
+    if (rc != GZ_OK) return rc;
+    put_tag(c, T_BYTES);
+    const uint64_t n64 = *n;
+    put(c, &n64, 8);
+    put(c, out, *n);
+    return GZ_OK;
+  }
+  expect_tag(c, T_BYTES);
+  uint64_t n64 = 0;
+  get(c, &n64, 8);
+  *n = (size_t)n64;
+  if (*n > cap) return GZ_E_ARG;
+  get(c, out, *n);
   return GZ_OK;
 }
 

@@ -132,6 +132,21 @@ def test_block_search_bees(L):
     pc.case_block_search(L, 444, 258, x0=0, y0=0, qs=2)
 
 
+@pytest.mark.parametrize("wh", [(444, 258), (61, 43), (32, 32), (129, 9), (8, 8)])
+def test_jpeg_entropy(L, wh):
+    """Device symbol statistics + device scan vs the reference's WriteJpeg, byte for byte."""
+    import guetzli_amd
+    pc.case_jpeg_entropy(L, guetzli_amd.load_host(), *wh, check_histograms=wh[0] * wh[1] < 20000)
+
+
+def test_jpeg_entropy_1080p():
+    """Full-size scan (32 400 MCUs): byte-identical to the serial host writer, which the
+    CPU suite pins to the reference."""
+    import guetzli_amd
+    Lb = guetzli_amd.load()
+    pc.case_jpeg_entropy(Lb, guetzli_amd.load_host(), 1920, 1080, check_histograms=False)
+
+
 # SHA-256 of the reference's output JPEGs (unmodified guetzli, default flags = quality 95),
 # BASELINE.md section 2; the bees hash is re-derived from oracle/_ref in the CPU suite.
 GOLDEN_JPEG_SHA = {

@@ -43,3 +43,14 @@ def test_compare(L):
 
 def test_block_search(L):
     pc.case_block_search(L, 45, 27)
+
+
+@pytest.fixture(scope="module")
+def host_emu():
+    from guetzli_amd.encoder import HostLibrary
+    return HostLibrary(build_emu.build_host())
+
+
+@pytest.mark.parametrize("wh", [(61, 43), (32, 32), (129, 9), (8, 8)])
+def test_jpeg_entropy(L, host_emu, wh):
+    pc.case_jpeg_entropy(L, host_emu, *wh, x0=100, y0=50)

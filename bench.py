@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the Guetzli hot path on MI355X.
+"""bench.py -- MPix/s encoded at --quality 95 on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): one 1920x1080 sRGB image (tests/golden/bees.png
-tiled from the origin), --quality 95 (butteraugli target 0.971769), one
-image per GPU ("weak" scaling: rank r processes the image circularly shifted by
-(37r, 53r), as in config 5).
+Workload (BASELINE.json configs[1]): one 1920x1080 sRGB image (tests/golden/bees.png tiled
+from the origin), --quality 95 (butteraugli target 0.971769).  One image per
+GPU per step ("weak" scaling: rank r encodes the image circularly shifted by (37r, 53r)
+pixels, as in config 5); images are independent, so there is no data-path collective --
+only the barrier and the max-over-ranks of the elapsed time.
 
-A STEP is one pass of the hot path over that image: one candidate evaluation exactly as
-Processor::TryQuantMatrix performs it (processor.cc:298-326) -- ApplyGlobalQuantization
-(quantize.h) -> integer IDCT -> YCbCr->RGB -> linear -> full butteraugli distance map and
-its maximum -- with the image, its original coefficients and the original's PsychoImage
-already resident in HBM; only the 192-entry quant matrix goes in and the 4-byte distance
-comes out.  `value` = megapixels of candidate evaluated per second, whole job.
+A STEP is one whole encode: guetzli::Process(params, stats, rgb, w, h, &out) through the
+host search driver (guetzli_amd/host) with every per-pixel / per-block operation on the GPU
+behind the C ABI (RGB->YCbCr + FDCT, quantise, IDCT + colour + butteraugli Compare for
+every candidate, the per-block zeroing search, JPEG entropy coding of every candidate).
+`value` = megapixels encoded per second, whole job.  The step starts from packed 8-bit RGB
+in host memory and ends with the JPEG bytes in host memory, so the (small) PCIe traffic of
+the boundary is inside the number.  Rank 0's output is checked against the reference's
+JPEG (SHA-256 recorded from the unmodified reference) after the timed region.
 
-Also reported on the same JSON line:
-  roofline     -- HBM roofline of the Compare chain: SURVEY.md 8(d) algorithmic bytes
-                  (494 B/px per Compare) / average Compare duration measured with HIP
-                  events on the stream the kernels run on.
-  cpu_baseline -- the unmodified reference (oracle/_ref, 1 thread) doing the same step on
-                  this box's host CPU, rank 0, N=1 only, bounded sample.
+Also on the JSON line:
+  roofline     -- HBM roofline of the butteraugli evaluation (the second half of the
+                  metric): SURVEY.md 8(d) algorithmic bytes of one Compare (494 B/px) /
+                  average duration of one Compare chain measured with HIP events on the
+                  stream the kernels run on (gz_time_compare), same process, same image.
+  cpu_baseline -- the unmodified reference guetzli::Process (oracle/_ref, 1 thread) on this
+                  box's host CPU, rank 0, N=1 only, on a bounded sample: tests/golden/bees.png
+                  (444x258, config 0), --quality 95.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,51 +40,39 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_PX = 494.0          # 123.5 float-plane passes per Compare
-HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
+QUALITY = 95.0
 TARGET_Q95 = 0.971769              # ButteraugliScoreForQuality(95), quality.cc:31-85
 W, H = 1920, 1080
+GOLDEN_SHA_1080P_Q95 = "9c0eb414b8e73f4372c0b089eafe2350e6ff2ae83926d1c0c5f35cb5f7919729"
 
 
-def quant_matrix(step):
-    """A deterministic family of candidate matrices like QuantMatrixGenerator's
-    (processor.cc:269-279): values in {1, 3, 5} growing with frequency."""
-    import numpy as np
-    k = np.arange(64)
-    zz = (k // 8) + (k % 8)
-    lvl = 1 + 2 * ((zz + step) % 3 == 0) + 2 * (zz > 6 + step % 4)
-    return np.broadcast_to(lvl.astype(np.int32), (3, 64)).copy()
-
-
-def cpu_baseline(rgb, sample_steps):
-    """Reference ButteraugliComparator::Compare + ApplyGlobalQuantization on the host."""
-    import numpy as np
-    from checkers import ref, oracle
-    chk, kind = (ref, "reference") if ref is not None else (oracle, "port")
+def cpu_baseline():
+    """Reference guetzli::Process on the host CPU (bounded sample: bees.png)."""
+    import images
+    from checkers import ref
+    if ref is None:
+        return None
+    rgb = images.bees()
     h, w, _ = rgb.shape
-    co = chk.encode_rgb(rgb)
-    cmp_ = chk.comparator(rgb, TARGET_Q95)
     t0 = time.perf_counter()
-    for s in range(sample_steps):
-        cq, _, _ = chk.reconstruct(co, w, h, quant_matrix(s))
-        cmp_.compare(cq)
+    jpg, _ = ref.process(rgb, TARGET_Q95)
     dt = time.perf_counter() - t0
-    cmp_.close()
-    return {"value": round(sample_steps * w * h / 1e6 / dt, 5), "unit": "MPix/s", "cores": 1,
-            "kind": kind,
-            "sample": f"{sample_steps} candidate evaluations of the same {w}x{h} image, "
-                      f"{dt:.1f} s of CPU, single thread ({os.cpu_count()} host cores present)"}
+    return {"value": round(w * h / 1e6 / dt, 6), "unit": "MPix/s", "cores": 1,
+            "kind": "reference",
+            "sample": f"unmodified reference guetzli::Process on tests/golden/bees.png "
+                      f"({w}x{h}), --quality 95: {dt:.1f} s of CPU, single thread "
+                      f"({os.cpu_count()} host cores present); output {len(jpg)} bytes"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12)
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import guetzli_amd
     import images
@@ -96,14 +90,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    L = guetzli_amd.load()
+    host = guetzli_amd.load_host()        # links the gfx950 C-ABI library; no fallback
     rgb = images.shifted(images.tiled(W, H), rank)
-    ctx = L.context(rgb, TARGET_Q95, device=local_rank)
-    ctx.encode_rgb(download=False)
 
-    def step(i):
-        ctx.quantize(quant_matrix(i), download=False)
-        ctx.compare_enqueue(1)
+    def step():
+        return host.process(rgb, quality=QUALITY, device=local_rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -111,51 +102,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    for _ in range(args.warmup):
+        step()
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for _ in range(args.steps):
+        jpg, info = step()
     fence()
     dt = time.perf_counter() - t0
-    last = ctx.last_distance()
-    assert last > 0.0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline leg: HIP events on the context's own stream around Compare only
-    iters = max(10, args.steps)
-    ms = ctx.time_compare(iters) / iters
+    # roofline leg: HIP events on the context's stream around whole Compare chains
+    L = guetzli_amd.load()
+    with L.context(rgb, TARGET_Q95, device=local_rank) as ctx:
+        ctx.encode_rgb(download=False)
+        import numpy as np
+        ctx.quantize(np.full((3, 64), 3, np.int32), download=False)
+        ctx.time_compare(5)
+        iters = 50
+        ms = ctx.time_compare(iters) / iters
     achieved = ALGO_BYTES_PER_PX * W * H / (ms * 1e-3) / 1e9
 
     if rank == 0:
+        sha = hashlib.sha256(jpg).hexdigest()
+        assert sha == GOLDEN_SHA_1080P_Q95, f"output JPEG differs from the reference: {sha}"
         out = {
-            "metric": "MPix/s of candidate evaluation at --quality 95 "
-                      "(quantize + IDCT + butteraugli Compare; encode search driver not yet on device path)",
-            "value": round(world * args.steps * W * H / 1e6 / dt, 3),
+            "metric": "MPix/s encoded at --quality 95",
+            "value": round(world * args.steps * W * H / 1e6 / dt, 4),
             "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32+f64 (butteraugli), int32/int16 (DCT/quantize)",
+            "dtype": "f32+f64 (butteraugli), int32/int16 (DCT/quantize/entropy coding)",
             "data": "synthetic (tests/golden/bees.png tiled to 1920x1080, SURVEY 8d)",
-            "config": {"workload": "single 1920x1080 sRGB image, --quality 95, one candidate "
-                                   "evaluation per step, 1 image per GPU",
-                       "butteraugli_target": TARGET_Q95, "images_per_gpu": 1},
-            "roofline": {"bound": "hbm", "kernel": "Compare chain (all kernels of one gz_compare)",
+            "config": {"workload": "single 1920x1080 sRGB image, --quality 95, whole "
+                                   "guetzli::Process per step (host RGB in, JPEG bytes out), "
+                                   "1 image per GPU per step",
+                       "butteraugli_target": TARGET_Q95, "images_per_gpu": 1,
+                       "output_bytes": len(jpg), "output_sha256_matches_reference": True,
+                       "iterations": info["counters"].get("number of iterations")},
+            "roofline": {"bound": "hbm",
+                         "kernel": "butteraugli Compare chain (21 launches per Compare: "
+                                   "k_reconstruct, 9 k_blur_h, 9 k_blur_v, 2 k_malta, k_mask_pre, k_combine)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "ms_per_compare": round(ms, 4),
                          "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W * H},
-            "last_distance": last,
+            "host_timers_s": {k: round(v, 3) for k, v in info["timers"].items()
+                              if k in ("total", "phase_b_host", "compare", "block_search",
+                                       "jpeg_write", "create+encode", "select_quant_matrix")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rgb, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,39 @@
+"""Batch sharding of independent images over the GPUs of one node (BASELINE
+config 5): image k -> rank k mod world, one process per GPU, no data-path collective.  The
+process group (RCCL on GPUs, gloo in the CPU tests) is used only for the work split's
+bookkeeping: a barrier, the max-over-ranks of the elapsed time and an all-gather of one small
+result record per image -- what the reference's golden test does with `xargs -P`
+(tests/golden_test.sh:24-26)."""
+import hashlib
+import time
+
+
+def shard(n_images, rank, world):
+    """Indices of the images rank `rank` encodes."""
+    return list(range(rank, n_images, world))
+
+
+def max_over_ranks(seconds, dist=None, device=None):
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def encode_batch(get_image, n_images, process, rank=0, world=1, dist=None):
+    """Encodes this rank's shard with `process(rgb) -> (jpeg_bytes, info)` and returns the
+    records of ALL images (index, bytes, sha256, seconds, rank), ordered by index, on every
+    rank."""
+    mine = []
+    for k in shard(n_images, rank, world):
+        t0 = time.perf_counter()
+        jpg, _ = process(get_image(k))
+        mine.append({"index": k, "bytes": len(jpg), "sha256": hashlib.sha256(jpg).hexdigest(),
+                     "seconds": time.perf_counter() - t0, "rank": rank})
+    if dist is None or world == 1:
+        return mine
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    return sorted((r for part in gathered for r in part), key=lambda r: r["index"])

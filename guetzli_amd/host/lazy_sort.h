@@ -19,18 +19,28 @@
 // asks for them.  Element i of the result is identical to element i after std::sort on
 // the same input (tests/test_host_logic.py checks this against std::sort itself,
 // including tie-heavy and depth-limit inputs).
+//
+// Large ranges are partitioned in parallel with the same outcome: libstdc++'s unguarded
+// Hoare partition swaps the k-th element from the left that is not less than the pivot with
+// the k-th element from the right that is not greater, for as long as the former lies left
+// of the latter, so the final arrangement and the cut follow from the two ordered lists of
+// such positions (built by chunks), without replaying the scan.
 #pragma once
 #include <algorithm>
 #include <cstddef>
+#include <cstdint>
 #include <vector>
+
+#include "parallel.h"
 
 namespace guetzli_amd {
 
 template <class T, class Less>
 class LazySorted {
  public:
-  LazySorted(T* data, size_t n, Less less, int depth_override = -1)
-      : a_(data), n_(n), less_(less), done_(0) {
+  LazySorted(T* data, size_t n, Less less, int depth_override = -1,
+             size_t parallel_threshold = 1 << 17)
+      : a_(data), n_(n), less_(less), done_(0), par_threshold_(parallel_threshold) {
     if (n_ == 0) return;
     int lg = 0;
     for (size_t m = n_; m > 1; m >>= 1) ++lg;
@@ -44,6 +54,41 @@ class LazySorted {
   }
   void SortAll() {
     while (done_ < n_) Refine();
+  }
+  // Finalises positions [0, upto) using the worker pool: the pending ranges that reach into
+  // the prefix are split (in parallel) down to a grain, then finished independently -- the
+  // ranges are disjoint and refining one never touches another, so the result is the one
+  // the serial order of refinement gives.
+  void EnsureSorted(size_t upto) {
+    if (upto > n_) upto = n_;
+    WorkerPool& pool = WorkerPool::Get();
+    if (upto <= done_ || pool.size() == 1 || upto - done_ < (1u << 16)) {
+      while (done_ < upto) Refine();
+      return;
+    }
+    std::vector<Range> work;
+    while (!pending_.empty() && pending_.back().lo < upto) {
+      work.push_back(pending_.back());
+      pending_.pop_back();
+    }
+    const size_t grain = std::max<size_t>(8192, (upto - done_) / (8 * (size_t)pool.size()));
+    for (size_t i = 0; i < work.size();) {
+      const Range r = work[i];
+      if (r.hi - r.lo > grain && r.hi - r.lo > 16 && r.depth > 0) {
+        const size_t mid = r.lo + (r.hi - r.lo) / 2;
+        MoveMedianToFirst(r.lo, r.lo + 1, mid, r.hi - 1);
+        const size_t cut = Partition(r.lo + 1, r.hi, r.lo);
+        work[i] = Range{r.lo, cut, r.depth - 1};
+        work.push_back(Range{cut, r.hi, r.depth - 1});
+      } else {
+        ++i;
+      }
+    }
+    pool.Run((int)work.size(), [&](int w) {
+      std::vector<Range> stack(1, work[w]);
+      while (!stack.empty()) RefineOn(&stack, false);
+    });
+    for (const Range& r : work) done_ = std::max(done_, r.hi);
   }
 
  private:
@@ -66,7 +111,93 @@ class LazySorted {
     }
   }
 
+  // Same result as Partition() below, computed by chunks on the worker pool: one pass
+  // records, per chunk, the positions not less than the pivot ("left stoppers") and not
+  // greater than it ("right stoppers"); pair k = (k-th left stopper from the left, k-th
+  // right stopper from the right) is swapped while the former lies left of the latter.
+  size_t ParallelPartition(size_t first, size_t last, size_t pivot) {
+    WorkerPool& pool = WorkerPool::Get();
+    const T pv = a_[pivot];
+    const size_t n = last - first;
+    const int chunks = std::max(1, std::min<int>(4 * pool.size(), (int)(n / 8192)));
+    const size_t per = (n + chunks - 1) / chunks;
+    if (lbuf_.size() < n) {
+      lbuf_.resize(n);
+      rbuf_.resize(n);
+    }
+    std::vector<size_t> cnt_l(chunks + 1, 0), cnt_r(chunks + 1, 0);
+    pool.Run(chunks, [&](int c) {
+      const size_t lo = c * per, hi = std::min(n, lo + per);
+      uint32_t* lp = &lbuf_[lo];
+      uint32_t* rp = &rbuf_[lo];
+      size_t nl = 0, nr = 0;
+      for (size_t i = lo; i < hi; ++i) {
+        const T& e = a_[first + i];
+        lp[nl] = (uint32_t)i;
+        nl += !less_(e, pv);
+        rp[nr] = (uint32_t)i;
+        nr += !less_(pv, e);
+      }
+      cnt_l[c + 1] = nl;
+      cnt_r[c + 1] = nr;
+    });
+    for (int c = 0; c < chunks; ++c) {
+      cnt_l[c + 1] += cnt_l[c];
+      cnt_r[c + 1] += cnt_r[c];
+    }
+    const size_t nl = cnt_l[chunks], nr = cnt_r[chunks];
+    // k-th (0-based) left stopper in ascending order / right stopper in ascending order
+    auto left_at = [&](size_t k) {
+      const int c = (int)(std::upper_bound(cnt_l.begin(), cnt_l.end(), k) - cnt_l.begin()) - 1;
+      return (size_t)lbuf_[c * per + (k - cnt_l[c])];
+    };
+    auto right_at = [&](size_t k) {
+      const int c = (int)(std::upper_bound(cnt_r.begin(), cnt_r.end(), k) - cnt_r.begin()) - 1;
+      return (size_t)rbuf_[c * per + (k - cnt_r[c])];
+    };
+    // m = number of swapped pairs = max k with l_k < r_k (monotone in k)
+    size_t lo_k = 0, hi_k = std::min(nl, nr);
+    while (lo_k < hi_k) {
+      const size_t k = (lo_k + hi_k + 1) / 2;
+      if (left_at(k - 1) < right_at(nr - k)) lo_k = k; else hi_k = k - 1;
+    }
+    const size_t m = lo_k;
+    const int schunks = m ? std::max(1, std::min<int>(4 * pool.size(), (int)(m / 4096))) : 0;
+    const size_t sper = schunks ? (m + schunks - 1) / schunks : 0;
+    pool.Run(schunks, [&](int sc) {
+      const size_t k0 = sc * sper, k1 = std::min(m, k0 + sper);
+      if (k0 >= k1) return;
+      // cursors into the chunked lists: left ascending from k0, right descending from nr-1-k0
+      int cl = (int)(std::upper_bound(cnt_l.begin(), cnt_l.end(), k0) - cnt_l.begin()) - 1;
+      size_t il = k0 - cnt_l[cl];
+      size_t rk = nr - 1 - k0;
+      int cr = (int)(std::upper_bound(cnt_r.begin(), cnt_r.end(), rk) - cnt_r.begin()) - 1;
+      size_t ir = rk - cnt_r[cr];
+      for (size_t k = k0; k < k1; ++k) {
+        while (il >= cnt_l[cl + 1] - cnt_l[cl]) { ++cl; il = 0; }
+        std::swap(a_[first + lbuf_[cl * per + il]], a_[first + rbuf_[cr * per + ir]]);
+        ++il;
+        if (k + 1 < k1) {
+          while (ir == 0) { --cr; ir = cnt_r[cr + 1] - cnt_r[cr]; }
+          --ir;
+        }
+      }
+    });
+    // the scan stops at the next untouched left stopper or at the last swapped right one
+    size_t cut = last;
+    if (m < nl) cut = std::min(cut, first + left_at(m));
+    if (m >= 1) cut = std::min(cut, first + right_at(nr - m));
+    return cut;
+  }
+
   size_t Partition(size_t first, size_t last, size_t pivot) {
+    if (last - first >= par_threshold_ && last - first < (size_t)UINT32_MAX &&
+        (WorkerPool::Get().size() > 1 || par_threshold_ < 1024))
+      return ParallelPartition(first, last, pivot);
+    return SerialPartition(first, last, pivot);
+  }
+
+  size_t SerialPartition(size_t first, size_t last, size_t pivot) {
     for (;;) {
       while (less_(a_[first], a_[pivot])) ++first;
       --last;
@@ -91,29 +222,37 @@ class LazySorted {
 
   // Takes the leftmost pending range one step further.
   void Refine() {
-    Range r = pending_.back();
-    pending_.pop_back();
+    const size_t fin = RefineOn(&pending_, true);
+    if (fin) done_ = fin;
+  }
+  // One refinement step on the top of `stack`; returns the end of the range if it became
+  // final, else 0.
+  size_t RefineOn(std::vector<Range>* stack, bool may_use_pool) {
+    Range r = stack->back();
+    stack->pop_back();
     if (r.hi - r.lo <= 16) {
       InsertionSort(r.lo, r.hi);
-      done_ = r.hi;
-      return;
+      return r.hi;
     }
     if (r.depth == 0) {
       std::partial_sort(a_ + r.lo, a_ + r.hi, a_ + r.hi, less_);   // the heap-sort fallback
-      done_ = r.hi;
-      return;
+      return r.hi;
     }
     const size_t mid = r.lo + (r.hi - r.lo) / 2;
     MoveMedianToFirst(r.lo, r.lo + 1, mid, r.hi - 1);
-    const size_t cut = Partition(r.lo + 1, r.hi, r.lo);
-    pending_.push_back(Range{cut, r.hi, r.depth - 1});
-    pending_.push_back(Range{r.lo, cut, r.depth - 1});
+    const size_t cut = may_use_pool ? Partition(r.lo + 1, r.hi, r.lo)
+                                    : SerialPartition(r.lo + 1, r.hi, r.lo);
+    stack->push_back(Range{cut, r.hi, r.depth - 1});
+    stack->push_back(Range{r.lo, cut, r.depth - 1});
+    return 0;
   }
 
   T* a_;
   size_t n_;
   Less less_;
   size_t done_;
+  size_t par_threshold_;
+  std::vector<uint32_t> lbuf_, rbuf_;   // per-chunk stopper positions (ParallelPartition)
   std::vector<Range> pending_;   // back() is the leftmost unsorted range
 };
 

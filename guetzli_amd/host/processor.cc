@@ -12,6 +12,7 @@
 #include "../../include/guetzli_amd.h"
 #include "jpeg_writer.h"
 #include "lazy_sort.h"
+#include "parallel.h"
 
 namespace guetzli_amd {
 
@@ -422,6 +423,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   std::vector<int> next_cand(nb, 0);   // last_indexes
   std::vector<float> weight(nb);
   std::vector<std::pair<int, float> > order;
+  std::vector<size_t> order_off(nb + 1);
   std::vector<char> touched(nb);
   std::vector<int32_t> dirty;
   std::vector<int16_t> dirty_blocks;
@@ -440,22 +442,41 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         rc = gz_block_weights(ctx_, direction, radius, target_mul, first_up ? 0 : 1, weight.data());
         t_pb_weights_ += pw.lap();
         if (rc != GZ_OK) return Fail("gz_block_weights", rc);
-        order.clear();
+        // `order` in the reference's sequence (blocks ascending; within a block the
+        // remaining candidates ascending for "up", the applied ones descending for "down",
+        // processor.cc:640-673), filled by block ranges in parallel at precomputed offsets.
         blocks_to_change = 0;
+        size_t total = 0;
         for (int b = 0; b < nb; ++b) {
+          order_off[b] = total;
           if (weight[b] == 0) continue;
-          const int at = next_cand[b], off = cand_off[b], count = cand_off[b + 1] - off;
-          const float* errs = &cand_err[off];
-          const float base = max_block_error[b];
-          if (direction > 0) {
-            for (int i = at; i < count; ++i)
-              order.push_back(std::make_pair(b, (errs[i] - base) / weight[b]));
-            blocks_to_change += at < count ? 1 : 0;
-          } else {
-            for (int i = at - 1; i >= 0; --i)
-              order.push_back(std::make_pair(b, (base - errs[i]) / weight[b]));
-            blocks_to_change += at > 0 ? 1 : 0;
-          }
+          const int at = next_cand[b], count = cand_off[b + 1] - cand_off[b];
+          const int n_b = direction > 0 ? count - at : at;
+          blocks_to_change += n_b > 0 ? 1 : 0;
+          total += (size_t)n_b;
+        }
+        order_off[nb] = total;
+        order.resize(total);
+        {
+          WorkerPool& pool = WorkerPool::Get();
+          const int chunks = total < (1u << 16) ? 1 : 4 * pool.size();
+          const int per = (nb + chunks - 1) / chunks;
+          pool.Run(chunks, [&](int ch) {
+            const int b0 = ch * per, b1 = std::min(nb, b0 + per);
+            for (int b = b0; b < b1; ++b) {
+              if (order_off[b + 1] == order_off[b]) continue;
+              std::pair<int, float>* dst = &order[order_off[b]];
+              const int at = next_cand[b], off = cand_off[b], count = cand_off[b + 1] - off;
+              const float* errs = &cand_err[off];
+              const float base = max_block_error[b];
+              const float wb = weight[b];
+              if (direction > 0) {
+                for (int i = at; i < count; ++i) *dst++ = std::make_pair(b, (errs[i] - base) / wb);
+              } else {
+                for (int i = at - 1; i >= 0; --i) *dst++ = std::make_pair(b, (base - errs[i]) / wb);
+              }
+            }
+          });
         }
         if (!order.empty()) break;
       }
@@ -489,6 +510,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         first_up = false;
       }
 
+      t_pb_sort_ += pw.lap();
       std::fill(touched.begin(), touched.end(), 0);
       dirty.clear();
       float val_threshold = 0.0;
@@ -541,6 +563,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       {
         const size_t last_needed = std::min<size_t>((size_t)std::max(min_coeffs_to_change, 0), n_order - 1);
         const size_t fast_until = last_needed / 10 * 10;
+        sorted.EnsureSorted(fast_until);
         for (size_t i = 0; i < fast_until; ++i) apply_step(i, false);
         for (size_t j = 0; j < pending.size(); ++j) {
           const int c = pending[j] / nb, b = pending[j] % nb;
@@ -564,6 +587,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
             break;
         }
       }
+      t_pb_loop_ += pw.lap();
       const size_t order_size = order.size();
       for (int b = 0; b < nb; ++b) max_block_error[b] += weight[b] * val_threshold * direction;
 

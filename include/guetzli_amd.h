@@ -85,7 +85,8 @@ int gz_quantize(gz_ctx* ctx, const int* q, int16_t* coeffs_out);
 
 /* Replace the whole candidate / individual candidate blocks with host data
  * (OutputImageComponent::SetCoeffBlock, output_image.cc:123-132).  block_index[i] =
- * by*bw + bx; blocks holds n * 3 * 64 int16 (component-major per block: Y,Cb,Cr). */
+ * by*bw + bx, all distinct; blocks holds n * 3 * 64 int16 (component-major per block:
+ * Y,Cb,Cr). */
 int gz_set_coeffs(gz_ctx* ctx, const int16_t* coeffs);
 int gz_set_coeff_blocks(gz_ctx* ctx, const int32_t* block_index, int n,
                         const int16_t* blocks);

@@ -17,11 +17,15 @@ struct Less {
   bool operator()(const E& a, const E& b) const { return a.second < b.second; }
 };
 
+static size_t g_par_threshold = 1 << 17;
+static int g_ensure = 0;
+
 static int check(std::vector<E> v, const char* what, size_t prefix_only = 0) {
   std::vector<E> ref = v;
   std::sort(ref.begin(), ref.end(), Less());
-  guetzli_amd::LazySorted<E, Less> lazy(v.data(), v.size(), Less());
+  guetzli_amd::LazySorted<E, Less> lazy(v.data(), v.size(), Less(), -1, g_par_threshold);
   const size_t upto = prefix_only ? std::min(prefix_only, v.size()) : v.size();
+  if (g_ensure) lazy.EnsureSorted(g_ensure == 1 ? upto : upto / 2);
   for (size_t i = 0; i < upto; ++i) {
     const E& e = lazy[i];
     if (e.first != ref[i].first || e.second != ref[i].second) {
@@ -33,7 +37,21 @@ static int check(std::vector<E> v, const char* what, size_t prefix_only = 0) {
   return 0;
 }
 
+int run_all();
 int main() {
+  int fails = run_all();          // serial partitions below 128K elements, parallel above
+  g_par_threshold = 24;           // parallel partition for (almost) every range
+  fails += run_all();
+  g_par_threshold = 1 << 17;
+  g_ensure = 1;                   // pool-parallel EnsureSorted over the whole prefix
+  fails += run_all();
+  g_ensure = 2;                   // ... over half of it, the rest lazily
+  fails += run_all();
+  printf(fails ? "lazy_sort: %d FAILURES\n" : "lazy_sort: ok\n", fails);
+  return fails ? 1 : 0;
+}
+
+int run_all() {
   std::mt19937 rng(12345);
   int fails = 0;
   const size_t sizes[] = {0, 1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 100, 257, 1000, 4097, 65536, 300001, 2000003};
@@ -88,6 +106,5 @@ int main() {
       if (idsum != (long)v.size() * ((long)v.size() - 1) / 2) { printf("FAIL depth %d not a permutation\n", depth); ++fails; }
     }
   }
-  printf(fails ? "lazy_sort: %d FAILURES\n" : "lazy_sort: ok\n", fails);
-  return fails ? 1 : 0;
+  return fails;
 }

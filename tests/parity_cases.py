@@ -47,8 +47,8 @@ def case_encode_quantize_reconstruct(L, w, h, x0=0, y0=0):
             assert_bits_equal(srgb, esrgb, "reconstruct srgb")
             assert_bits_equal(lin, elin, "reconstruct linear")
         # block updates
-        idx = np.array([0, ctx.nb - 1, ctx.nb // 2], np.int32)
-        blocks = rng.integers(-300, 300, size=(3, 3, 64)).astype(np.int16)
+        idx = np.unique(np.array([0, ctx.nb - 1, ctx.nb // 2], np.int32))   # must be distinct
+        blocks = rng.integers(-300, 300, size=(len(idx), 3, 64)).astype(np.int16)
         ctx.set_coeff_blocks(idx, blocks)
         ecq2 = ecq.copy()
         for i, b in enumerate(idx):

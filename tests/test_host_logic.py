@@ -10,7 +10,7 @@ def test_lazy_sort_is_std_sort(tmp_path):
     """guetzli_amd/host/lazy_sort.h yields std::sort's permutation (ties included): the
     C++ check in tests/cpp/test_lazy_sort.cc compares against std::sort itself."""
     exe = str(tmp_path / "test_lazy_sort")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall",
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread",
                     os.path.join(ROOT, "tests", "cpp", "test_lazy_sort.cc"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr

@@ -56,6 +56,9 @@ SIGNATURES = {
     "gz_probe_idct_blocks": (_I, [_I, _P, _I, _P]),
     "gz_probe_fdct_blocks": (_I, [_I, _P, _I]),
     "gz_probe_arith": (_I, [_I, _I, _P, _P, _P, _P, _I]),
+    "gz_dct_double_blocks": (_I, [_I, _P, _I, _I]),
+    "gz_component_to_float_pixels": (_I, [_I, _P, _I, _I, _P]),
+    "gz_component_set_downsampled": (_I, [_I, _P, _I, _I, _I, _I, _P]),
 }
 
 
@@ -103,6 +106,31 @@ class Library:
         b = np.ascontiguousarray(blocks, np.int16).reshape(-1, 64).copy()
         self.check(self.lib.gz_probe_fdct_blocks(device, _ptr(b), b.shape[0]))
         return b
+
+    def dct_double_blocks(self, blocks, inverse=False, device=0):
+        """ComputeBlockDCTDouble / ComputeBlockIDCTDouble (dct_double.cc:76-85) per block."""
+        b = np.ascontiguousarray(blocks, np.float64).reshape(-1, 64).copy()
+        self.check(self.lib.gz_dct_double_blocks(device, _ptr(b), b.shape[0], int(inverse)))
+        return b
+
+    def component_to_float_pixels(self, coeffs, w, h, device=0):
+        """OutputImageComponent::ToFloatPixels (output_image.cc:99-121), stride 1."""
+        nb = ((w + 7) // 8) * ((h + 7) // 8)
+        co = np.ascontiguousarray(coeffs, np.int16)
+        assert co.size == nb * 64
+        out = np.zeros((h, w), np.float32)
+        self.check(self.lib.gz_component_to_float_pixels(device, _ptr(co), w, h, _ptr(out)))
+        return out
+
+    def component_set_downsampled(self, pixels, fx, fy, device=0):
+        """SetDownsampledCoefficients (output_image.cc:265-300) of an h x w float plane."""
+        px = np.ascontiguousarray(pixels, np.float32)
+        h, w = px.shape
+        nb = ((w + 8 * fx - 1) // (8 * fx)) * ((h + 8 * fy - 1) // (8 * fy))
+        out = np.zeros((nb, 64), np.int16)
+        self.check(self.lib.gz_component_set_downsampled(device, _ptr(px), w, h, fx, fy,
+                                                         _ptr(out)))
+        return out
 
     def arith(self, op, a, b=None, c=None, device=0):
         dt = np.float64 if op in (2, 3, 5, 6) else np.float32

@@ -25,6 +25,7 @@
 #include "gz_kernels_diff.h"
 #include "gz_kernels_search.h"
 #include "gz_kernels_entropy.h"
+#include "gz_kernels_dctd.h"
 #include "gz_host_weights.h"
 #include "order_tables_generated.h"   // host-side csf/bias of order.inc
 
@@ -1172,6 +1173,76 @@ int gz_probe_fdct_blocks(int device, int16_t* blocks, int n) {
   if (hipMemcpy(blocks, d, (size_t)n * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
   hipFree(d);
   return rc;
+}
+
+// ----------------------------------------------------------- double-precision DCT ----
+namespace {
+struct DevBuf {   // scoped device allocation for the context-free entry points
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
+};
+}  // namespace
+
+int gz_dct_double_blocks(int device, double* blocks, int n, int inverse) {
+  if (!blocks || n <= 0) return GZ_E_ARG;
+  if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
+  DevBuf d;
+  const size_t bytes = (size_t)n * 64 * sizeof(double);
+  if (!d.alloc(bytes)) return GZ_E_NOMEM;
+  if (hipMemcpy(d.p, blocks, bytes, hipMemcpyHostToDevice) != hipSuccess) return GZ_E_HIP;
+  double* dblk = (double*)d.p;
+  if (inverse) {
+    GZ_LAUNCH((k_dctd_blocks<true>), dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0,
+              dblk, n);
+  } else {
+    GZ_LAUNCH((k_dctd_blocks<false>), dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0,
+              dblk, n);
+  }
+  if (hipGetLastError() != hipSuccess) return GZ_E_HIP;
+  if (hipMemcpy(blocks, d.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return GZ_E_HIP;
+  return GZ_OK;
+}
+
+int gz_component_to_float_pixels(int device, const int16_t* coeffs, int w, int h, float* out) {
+  if (!coeffs || !out || w <= 0 || h <= 0 || w >= (1 << 16) || h >= (1 << 16)) return GZ_E_ARG;
+  if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8, nb = bw * bh;
+  DevBuf dc, dp;
+  if (!dc.alloc((size_t)nb * 128) || !dp.alloc((size_t)w * h * sizeof(float))) return GZ_E_NOMEM;
+  if (hipMemcpy(dc.p, coeffs, (size_t)nb * 128, hipMemcpyHostToDevice) != hipSuccess) return GZ_E_HIP;
+  const int16_t* dcoef = (const int16_t*)dc.p;
+  float* dpix = (float*)dp.p;
+  GZ_LAUNCH(k_to_float_pixels, dim3(gz_div_up(nb, kBlocksPerWG)), dim3(256), (hipStream_t)0,
+            dcoef, w, h, bw, nb, dpix);
+  if (hipGetLastError() != hipSuccess) return GZ_E_HIP;
+  if (hipMemcpy(out, dp.p, (size_t)w * h * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    return GZ_E_HIP;
+  return GZ_OK;
+}
+
+int gz_component_set_downsampled(int device, const float* pixels, int w, int h, int fx, int fy,
+                                 int16_t* coeffs_out) {
+  if (!pixels || !coeffs_out || w <= 0 || h <= 0 || w >= (1 << 16) || h >= (1 << 16) ||
+      fx < 1 || fy < 1 || fx > 4 || fy > 4)
+    return GZ_E_ARG;
+  if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
+  const int bw = (w + 8 * fx - 1) / (8 * fx), bh = (h + 8 * fy - 1) / (8 * fy), nb = bw * bh;
+  DevBuf dc, dp;
+  if (!dc.alloc((size_t)nb * 128) || !dp.alloc((size_t)w * h * sizeof(float))) return GZ_E_NOMEM;
+  if (hipMemcpy(dp.p, pixels, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    return GZ_E_HIP;
+  const float* dpix = (const float*)dp.p;
+  int16_t* dcoef = (int16_t*)dc.p;
+  GZ_LAUNCH(k_set_downsampled_coeffs, dim3(gz_div_up(nb, kBlocksPerWG)), dim3(256), (hipStream_t)0,
+            dpix, w, h, fx, fy, bw, nb, dcoef);
+  if (hipGetLastError() != hipSuccess) return GZ_E_HIP;
+  if (hipMemcpy(coeffs_out, dc.p, (size_t)nb * 128, hipMemcpyDeviceToHost) != hipSuccess)
+    return GZ_E_HIP;
+  return GZ_OK;
 }
 
 int gz_probe_arith(int device, int op, const void* a, const void* b, const void* c,

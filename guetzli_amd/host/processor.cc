@@ -192,6 +192,8 @@ class Encoder {
   double best_score_ = -1;
   double t_write_ = 0, t_compare_ = 0, t_quant_ = 0, t_blocksearch_ = 0, t_phaseb_ = 0,
          t_upload_ = 0;
+  double t_pb_ensure_ = 0, t_pb_fast_ = 0, t_pb_flush_ = 0;
+  long n_fast_ = 0;
   double t_pb_weights_ = 0, t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0;
 };
@@ -563,15 +565,20 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       {
         const size_t last_needed = std::min<size_t>((size_t)std::max(min_coeffs_to_change, 0), n_order - 1);
         const size_t fast_until = last_needed / 10 * 10;
+        Stopwatch fw;
         sorted.EnsureSorted(fast_until);
+        t_pb_ensure_ += fw.lap();
         for (size_t i = 0; i < fast_until; ++i) apply_step(i, false);
+        t_pb_fast_ += fw.lap();
         for (size_t j = 0; j < pending.size(); ++j) {
           const int c = pending[j] / nb, b = pending[j] % nb;
           AddBlockACSymbols(&img_[c * comp_stride + (size_t)b * 64], quant_[c], 1, &ac_histo[c]);
           pending_flag[pending[j]] = 0;
         }
         pending.clear();
+        t_pb_flush_ += fw.lap();
         n_steps_ += (long)fast_until;
+        n_fast_ += (long)fast_until;
         for (size_t i = fast_until; i < n_order; ++i) {
           apply_step(i, true);
           if (i % 10 == 0) {
@@ -689,6 +696,10 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   stats_->timers["pb_sort"] = t_pb_sort_;
   stats_->timers["pb_loop"] = t_pb_loop_;
   stats_->timers["pb_loop_codes"] = t_pb_codes_;
+  stats_->timers["pb_loop_ensure_sorted"] = t_pb_ensure_;
+  stats_->timers["pb_loop_fast_steps"] = t_pb_fast_;
+  stats_->timers["pb_loop_flush"] = t_pb_flush_;
+  stats_->counters["phase B fast steps"] = (int)n_fast_;
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
   {  // the winner: its head from the host, its scan from the device

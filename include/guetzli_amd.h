@@ -97,6 +97,25 @@ int gz_get_coeffs(gz_ctx* ctx, int16_t* coeffs_out);
  * srgb: w*h*3 uint8 or NULL; linear: 3 planes of w*h float or NULL. */
 int gz_reconstruct(gz_ctx* ctx, uint8_t* srgb, float* linear);
 
+/* Double-precision DCT -----------------------------------------
+ * gz_dct_double_blocks: ComputeBlockDCTDouble (inverse == 0) / ComputeBlockIDCTDouble
+ * (inverse != 0), dct_double.cc:76-85, on n bare blocks of 64 doubles, in place.
+ * gz_component_to_float_pixels: OutputImageComponent::ToFloatPixels with stride 1
+ * (output_image.cc:99-121): one 4:4:4 component's coefficients [ceil(w/8)*ceil(h/8)][64]
+ * -> out[y*w + x] = float(IDCTDouble + 128).
+ * gz_component_set_downsampled: SetDownsampledCoefficients (output_image.cc:265-300):
+ * pixels (w*h floats of the full-resolution component) averaged fx x fy, forward
+ * DCTDouble, DC - 1024, round() -> int16 coefficients of the subsampled component,
+ * ceil(w/(8 fx)) * ceil(h/(8 fy)) blocks (OutputImageComponent::Reset, :40-49).
+ * These are the two consumers of dct_double.cc on the reference's YUV420 path
+ * (OutputImage::Downsample, :304-340); all three are bit-exact (FP64, no contraction).
+ * Context-free: they take a device ordinal. */
+int gz_dct_double_blocks(int device, double* blocks, int n, int inverse);
+int gz_component_to_float_pixels(int device, const int16_t* coeffs, int w, int h,
+                                 float* out);
+int gz_component_set_downsampled(int device, const float* pixels, int w, int h, int fx,
+                                 int fy, int16_t* coeffs_out);
+
 /* Whole-image distance -----------------------------------------------------------
  * gz_compare: replaces guetzli::ButteraugliComparator::Compare
  * (butteraugli_comparator.cc:63-75) on the current candidate: IDCT + colour + linear

@@ -947,6 +947,81 @@ void orc_idct_block(const int16_t* block, uint8_t* out) {
   }
 }
 
+// ---- double-precision DCT (a8) ------------------------------------------------
+// ref: dct_double.cc:28-45 -- the 10-digit basis values are data of the reference.
+static const double kDctBasis[8][8] = {
+  { 0.3535533906,  0.3535533906,  0.3535533906,  0.3535533906,  0.3535533906,  0.3535533906,  0.3535533906,  0.3535533906},
+  { 0.4903926402,  0.4157348062,  0.2777851165,  0.0975451610, -0.0975451610, -0.2777851165, -0.4157348062, -0.4903926402},
+  { 0.4619397663,  0.1913417162, -0.1913417162, -0.4619397663, -0.4619397663, -0.1913417162,  0.1913417162,  0.4619397663},
+  { 0.4157348062, -0.0975451610, -0.4903926402, -0.2777851165,  0.2777851165,  0.4903926402,  0.0975451610, -0.4157348062},
+  { 0.3535533906, -0.3535533906, -0.3535533906,  0.3535533906,  0.3535533906, -0.3535533906, -0.3535533906,  0.3535533906},
+  { 0.2777851165, -0.4903926402,  0.0975451610,  0.4157348062, -0.4157348062, -0.0975451610,  0.4903926402, -0.2777851165},
+  { 0.1913417162, -0.4619397663,  0.4619397663, -0.1913417162, -0.1913417162,  0.4619397663, -0.4619397663,  0.1913417162},
+  { 0.0975451610, -0.2777851165,  0.4157348062, -0.4903926402,  0.4903926402, -0.4157348062,  0.2777851165, -0.0975451610},
+};
+
+// ref: dct_double.cc:47-85.  Both transforms are two sweeps of an 8-point matrix-vector
+// product, columns first, each output accumulated from 0.0 over u = 0..7 in order; the
+// forward transform uses basis[out][u], the inverse basis[u][out].
+void orc_dct_double(double* block, int inverse) {
+  double mid[64];
+  for (int x = 0; x < 8; ++x)          // column x
+    for (int v = 0; v < 8; ++v) {
+      double acc = 0.0;
+      for (int u = 0; u < 8; ++u)
+        acc += (inverse ? kDctBasis[u][v] : kDctBasis[v][u]) * block[8 * u + x];
+      mid[8 * v + x] = acc;
+    }
+  for (int y = 0; y < 8; ++y)          // row y
+    for (int v = 0; v < 8; ++v) {
+      double acc = 0.0;
+      for (int u = 0; u < 8; ++u)
+        acc += (inverse ? kDctBasis[u][v] : kDctBasis[v][u]) * mid[8 * y + u];
+      block[8 * y + v] = acc;
+    }
+}
+
+// ref: output_image.cc:99-121 (stride 1, factor 1x1 component)
+void orc_to_float_pixels(const int16_t* coeffs, int w, int h, float* out) {
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8;
+  for (int by = 0; by < bh; ++by)
+    for (int bx = 0; bx < bw; ++bx) {
+      double d[64];
+      for (int k = 0; k < 64; ++k) d[k] = coeffs[((size_t)by * bw + bx) * 64 + k];
+      orc_dct_double(d, 1);
+      for (int iy = 0; iy < 8 && 8 * by + iy < h; ++iy)
+        for (int ix = 0; ix < 8 && 8 * bx + ix < w; ++ix)
+          out[(size_t)(8 * by + iy) * w + 8 * bx + ix] = static_cast<float>(d[8 * iy + ix] + 128.0);
+    }
+}
+
+// ref: output_image.cc:265-300 (and Reset, :40-49, for the block grid of the subsampled
+// component).  Returns the number of blocks written.
+int orc_set_downsampled(const float* pixels, int w, int h, int fx, int fy, int16_t* out) {
+  const int bw = (w + 8 * fx - 1) / (8 * fx), bh = (h + 8 * fy - 1) / (8 * fy);
+  for (int by = 0; by < bh; ++by)
+    for (int bx = 0; bx < bw; ++bx) {
+      double d[64];
+      for (int iy = 0; iy < 8; ++iy)
+        for (int ix = 0; ix < 8; ++ix) {
+          float avg = 0.0;
+          for (int j = 0; j < fy; ++j)
+            for (int i = 0; i < fx; ++i) {
+              const int x = std::min(8 * bx * fx + ix * fx + i, w - 1);
+              const int y = std::min(8 * by * fy + iy * fy + j, h - 1);
+              avg += pixels[(size_t)y * w + x];
+            }
+          avg /= fx * fy;
+          d[8 * iy + ix] = avg;
+        }
+      orc_dct_double(d, 0);
+      d[0] -= 1024.0;
+      for (int k = 0; k < 64; ++k)
+        out[((size_t)by * bw + bx) * 64 + k] = static_cast<int16_t>(std::round(d[k]));
+    }
+  return bw * bh;
+}
+
 int orc_quantize_block(int16_t* block, const int* q) {
   int changed = 0;
   for (int k = 0; k < 64; ++k) {

@@ -30,6 +30,12 @@ int  orc_encode_rgb(const uint8_t* rgb, int w, int h, int16_t* coeffs); /* jpeg_
 void orc_reconstruct(const int16_t* coeffs, int w, int h, const int* q /*3*64 or NULL*/,
                      int16_t* coeffs_out, uint8_t* srgb, float* linear);
 
+/* ---- double-precision DCT (a8) and its two users on the 4:2:0 path ---- */
+void orc_dct_double(double* block, int inverse);           /* dct_double.cc:76-85 */
+void orc_to_float_pixels(const int16_t* coeffs, int w, int h, float* out); /* output_image.cc:99 */
+int  orc_set_downsampled(const float* pixels, int w, int h, int fx, int fy,
+                         int16_t* coeffs_out);             /* output_image.cc:265 */
+
 /* ---- butteraugli stages (a9-a16) ---- */
 int  orc_compute_kernel(float sigma, float* taps, int cap);           /* butteraugli.cc:145 */
 void orc_blur(const float* in, int w, int h, float sigma, float border_ratio, float* out);

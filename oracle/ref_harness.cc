@@ -101,6 +101,41 @@ int ref_quantize_block(int16_t* block, const int* q) {
 }
 void ref_dct_double(double* block) { guetzli::ComputeBlockDCTDouble(block); }
 void ref_idct_double(double* block) { guetzli::ComputeBlockIDCTDouble(block); }
+// OutputImageComponent::ToFloatPixels (output_image.cc:99-121), stride 1: one component's
+// coefficients [nb][64] -> w*h floats.
+void ref_to_float_pixels(const int16_t* coeffs, int w, int h, float* out) {
+  guetzli::OutputImageComponent comp(w, h);
+  const int bw = comp.width_in_blocks(), bh = comp.height_in_blocks();
+  for (int by = 0; by < bh; ++by)
+    for (int bx = 0; bx < bw; ++bx)
+      comp.SetCoeffBlock(bx, by, coeffs + ((size_t)by * bw + bx) * 64);
+  comp.ToFloatPixels(out, 1);
+}
+// OutputImage::Downsample (output_image.cc:304-340) with sharpening and blurring off, i.e.
+// ToFloatPixels + SetDownsampledCoefficients(:265-300) of the two chroma components by
+// (fx, fy).  coeffs = 3 components at 4:4:4; out_u / out_v receive
+// ceil(w/(8fx))*ceil(h/(8fy)) blocks each.  Returns the number of blocks per component.
+int ref_downsample_plain(const int16_t* coeffs, int w, int h, int fx, int fy,
+                         int16_t* out_u, int16_t* out_v) {
+  guetzli::OutputImage img(w, h);
+  FillOutputImage(&img, coeffs);
+  guetzli::OutputImage::DownsampleConfig cfg;
+  cfg.u_factor_x = cfg.v_factor_x = fx;
+  cfg.u_factor_y = cfg.v_factor_y = fy;
+  cfg.u_sharpen = cfg.u_blur = cfg.v_sharpen = cfg.v_blur = false;
+  cfg.use_silver_screen = false;
+  img.Downsample(cfg);
+  int nb = 0;
+  for (int c = 1; c < 3; ++c) {
+    const guetzli::OutputImageComponent& comp = img.component(c);
+    nb = comp.width_in_blocks() * comp.height_in_blocks();
+    int16_t* dst = c == 1 ? out_u : out_v;
+    for (int by = 0; by < comp.height_in_blocks(); ++by)
+      for (int bx = 0; bx < comp.width_in_blocks(); ++bx)
+        comp.GetCoeffBlock(bx, by, dst + ((size_t)by * comp.width_in_blocks() + bx) * 64);
+  }
+  return nb;
+}
 void ref_ycbcr_to_rgb(uint8_t* pixels, int npix) {
   for (int i = 0; i < npix; ++i) guetzli::ColorTransformYCbCrToRGB(pixels + 3 * i);
 }

@@ -40,6 +40,7 @@ _SIGS = {
     "comparator_compare_block": (C.c_double, [_P, _P, C.c_int, C.c_int]),
     "block_zeroing_orders": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P,
                                        C.c_int]),
+    "to_float_pixels": (None, [_P, C.c_int, C.c_int, _P]),
 }
 _REF_ONLY = {
     "process": (C.c_long, [_P, C.c_int, C.c_int, C.c_float, _P, C.c_long, _P, C.c_long]),
@@ -48,6 +49,11 @@ _REF_ONLY = {
     "score_jpeg": (C.c_double, [C.c_double, C.c_int, C.c_double]),
     "dct_double": (None, [_P]),
     "idct_double": (None, [_P]),
+    "downsample_plain": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+}
+_ORC_ONLY = {
+    "dct_double": (None, [_P, C.c_int]),
+    "set_downsampled": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 }
 
 
@@ -123,6 +129,36 @@ class Checker:
         lin = np.zeros((3, h, w), np.float32)
         self._reconstruct(_ptr(co), w, h, _ptr(qq), _ptr(cout), _ptr(srgb), _ptr(lin))
         return cout, srgb, lin
+
+    # ---- double-precision DCT (a8) and its users -------------------------------
+    def dct_double(self, block, inverse=False):
+        b = np.ascontiguousarray(block, np.float64).reshape(64).copy()
+        if self.prefix == "orc_":
+            self._dct_double(_ptr(b), int(inverse))
+        else:
+            (self._idct_double if inverse else self._dct_double)(_ptr(b))
+        return b
+
+    def to_float_pixels(self, coeffs, w, h):
+        co = np.ascontiguousarray(coeffs, np.int16)
+        out = np.zeros((h, w), np.float32)
+        self._to_float_pixels(_ptr(co), w, h, _ptr(out))
+        return out
+
+    def downsample_chroma(self, coeffs, w, h, fx, fy):
+        """Chroma coefficients after OutputImage::Downsample with sharpen/blur off:
+        ToFloatPixels + SetDownsampledCoefficients of components 1 and 2."""
+        co = np.ascontiguousarray(coeffs, np.int16).reshape(3, -1, 64)
+        nb = ((w + 8 * fx - 1) // (8 * fx)) * ((h + 8 * fy - 1) // (8 * fy))
+        u = np.zeros((nb, 64), np.int16)
+        v = np.zeros((nb, 64), np.int16)
+        if self.prefix == "orc_":
+            for c, dst in ((1, u), (2, v)):
+                px = self.to_float_pixels(co[c], w, h)
+                assert self._set_downsampled(_ptr(px), w, h, fx, fy, _ptr(dst)) == nb
+        else:
+            assert self._downsample_plain(_ptr(co), w, h, fx, fy, _ptr(u), _ptr(v)) == nb
+        return u, v
 
     # ---- butteraugli ----------------------------------------------------------
     def compute_kernel(self, sigma):
@@ -267,7 +303,7 @@ def _load():
     src = os.path.join(ORACLE_DIR, "gz_oracle.cc")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
-    orc = Checker(so, "orc_")
+    orc = Checker(so, "orc_", _ORC_ONLY)
     refso = os.path.join(ORACLE_DIR, "_ref", "libgz_ref.so")
     rf = Checker(refso, "ref_", _REF_ONLY) if os.path.exists(refso) else None
     return orc, rf

@@ -30,6 +30,36 @@ def case_block_kernels(L, n=1500):
     assert_bits_equal(got, exp, "fdct blocks")
 
 
+def case_dct_double(L, n=1500):
+    """dct_double.cc: FP64 block transforms, bit for bit."""
+    rng = np.random.default_rng(RNG_SEED + 8)
+    blocks = np.concatenate([
+        rng.integers(-2048, 2048, size=(n, 64)).astype(np.float64),          # coefficient-like
+        rng.random((n // 2, 64)) * 255.0,                                      # pixel-like
+        rng.standard_normal((n // 2, 64)) * 10.0 ** rng.integers(-30, 30, (n // 2, 64)),
+        np.zeros((1, 64)), -np.zeros((1, 64)), np.full((1, 64), 255.0)])
+    for inverse in (False, True):
+        got = L.dct_double_blocks(blocks, inverse=inverse)
+        exp = np.stack([oracle.dct_double(b, inverse) for b in blocks])
+        assert_bits_equal(got, exp, f"dct_double inverse={inverse}")
+
+
+def case_downsample_component(L, w, h, x0=0, y0=0):
+    """ToFloatPixels + SetDownsampledCoefficients (output_image.cc:99-121,265-300), the two
+    users of dct_double.cc on the YUV420 path, for the subsampling factors guetzli uses."""
+    rgb = images.crop(w, h, x0, y0)
+    co = oracle.encode_rgb(rgb)
+    for c in range(3):
+        px = L.component_to_float_pixels(co[c], w, h)
+        assert_bits_equal(px, oracle.to_float_pixels(co[c], w, h), f"ToFloatPixels c={c}")
+    for fx, fy in ((2, 2), (1, 1)):
+        eu, ev = oracle.downsample_chroma(co, w, h, fx, fy)
+        for c, exp in ((1, eu), (2, ev)):
+            px = L.component_to_float_pixels(co[c], w, h)
+            got = L.component_set_downsampled(px, fx, fy)
+            assert_bits_equal(got, exp, f"SetDownsampledCoefficients c={c} {fx}x{fy} {w}x{h}")
+
+
 def case_encode_quantize_reconstruct(L, w, h, x0=0, y0=0):
     rng = np.random.default_rng(RNG_SEED + w)
     rgb = images.crop(w, h, x0, y0)

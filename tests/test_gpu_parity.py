@@ -46,6 +46,35 @@ def test_block_kernels(L):
     pc.case_block_kernels(L, n=20000)
 
 
+def test_dct_double(L):
+    pc.case_dct_double(L, n=20000)
+
+
+@pytest.mark.parametrize("wh", [(444, 258), (61, 43), (32, 32), (8, 8), (129, 9), (1, 1)])
+def test_downsample_component(L, wh):
+    pc.case_downsample_component(L, *wh)
+
+
+def test_dct_double_roundtrip_1080p(L):
+    """Full-size property: IDCTDouble(DCTDouble(x)) == x to ~1e-7 relative (the 10-digit
+    basis is not exactly orthonormal) and ToFloatPixels of the encoder's coefficients is
+    within 1.5 grey levels of the integer IDCT path, over every block of a 1080p plane."""
+    rgb = images.tiled(1920, 1080)
+    with L.context(rgb, 1.0) as ctx:
+        co = ctx.encode_rgb()
+        ctx.quantize(None)
+        srgb, _ = ctx.reconstruct()
+    rng = np.random.default_rng(3)
+    blocks = rng.random((32400, 64)) * 255.0 - 128.0
+    back = L.dct_double_blocks(L.dct_double_blocks(blocks), inverse=True)
+    assert np.abs(back - blocks).max() < 1e-6
+    y = L.component_to_float_pixels(co[0], 1920, 1080)
+    assert y.shape == (1080, 1920) and np.isfinite(y).all()
+    # Y of the integer path: libjpeg colour transform is the identity on Y up to rounding
+    yi = (0.299 * srgb[..., 0] + 0.587 * srgb[..., 1] + 0.114 * srgb[..., 2])
+    assert np.abs(np.clip(y, 0, 255) - yi).max() < 2.5
+
+
 @pytest.mark.parametrize("wh", [(444, 258), (61, 43), (32, 32), (8, 8), (129, 9)])
 def test_encode_quantize_reconstruct(L, wh):
     pc.case_encode_quantize_reconstruct(L, *wh)

@@ -22,6 +22,15 @@ def test_block_kernels(L):
     pc.case_block_kernels(L, n=300)
 
 
+def test_dct_double(L):
+    pc.case_dct_double(L, n=200)
+
+
+@pytest.mark.parametrize("wh", [(61, 43), (32, 32), (17, 9)])
+def test_downsample_component(L, wh):
+    pc.case_downsample_component(L, *wh, x0=100, y0=50)
+
+
 @pytest.mark.parametrize("wh", [(61, 43), (32, 32), (72, 40)])
 def test_encode_quantize_reconstruct(L, wh):
     pc.case_encode_quantize_reconstruct(L, *wh, x0=100, y0=50)

@@ -50,6 +50,34 @@ def test_quantize_blocks():
         assert oc == rc
 
 
+def test_dct_double_blocks():
+    """dct_double.cc:76-85."""
+    blocks = np.concatenate([
+        RNG.integers(-2048, 2048, size=(1500, 64)).astype(np.float64),
+        RNG.random((500, 64)) * 255.0,
+        RNG.standard_normal((500, 64)) * 10.0 ** RNG.integers(-30, 30, (500, 64)),
+        np.zeros((1, 64)), -np.zeros((1, 64))])
+    for b in blocks:
+        assert_bits_equal(oracle.dct_double(b), ref.dct_double(b), "dct_double")
+        assert_bits_equal(oracle.dct_double(b, True), ref.dct_double(b, True), "idct_double")
+
+
+@pytest.mark.parametrize("wh", [(444, 258), (61, 43), (32, 32), (8, 8), (1, 1), (17, 9)])
+def test_to_float_pixels_and_downsample(wh):
+    """OutputImageComponent::ToFloatPixels and OutputImage::Downsample without
+    sharpen/blur (= SetDownsampledCoefficients), output_image.cc:99-121,265-340."""
+    w, h = wh
+    co = ref.encode_rgb(images.tiled(w + 30, h + 40)[40:, 30:].copy())
+    for c in range(3):
+        assert_bits_equal(oracle.to_float_pixels(co[c], w, h), ref.to_float_pixels(co[c], w, h),
+                          "ToFloatPixels")
+    for fx, fy in ((2, 2),):   # the only subsampling UpdatePixelsForBlock supports besides 1x1
+        ou, ov = oracle.downsample_chroma(co, w, h, fx, fy)
+        ru, rv = ref.downsample_chroma(co, w, h, fx, fy)
+        assert_bits_equal(ou, ru, f"downsample U {fx}x{fy}")
+        assert_bits_equal(ov, rv, f"downsample V {fx}x{fy}")
+
+
 def test_color_and_gamma_tables():
     px = np.stack(np.meshgrid(np.arange(0, 256, 5), np.arange(256), np.arange(256),
                               indexing="ij"), -1).reshape(-1, 3).astype(np.uint8)

@@ -44,6 +44,10 @@ SIGNATURES = {
     "gz_block_weights": (_I, [_P, _I, _I, C.c_double, _I, _P]),
     "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
+    "gz_order_build": (_I, [_P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P]),
+    "gz_order_upload": (_I, [_P, _P, C.c_uint64]),
+    "gz_order_partition": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
+    "gz_order_fetch": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
     "gz_jpeg_histograms": (_I, [_P, _P, _P]),
     "gz_jpeg_scan": (_I, [_P, _I, _P, _P, _P]),
     "gz_jpeg_scan_keep": (_I, [_P]),
@@ -264,6 +268,35 @@ class Context:
                                                      _ptr(off), _ptr(idx), _ptr(err), cap))
         n = int(off[-1])
         return off, idx[:n].copy(), err[:n].copy()
+
+    # ---- global candidate order of phase B ----
+    ORDER_DTYPE = np.dtype([("block", np.int32), ("val", np.float32)])
+
+    def order_build(self, direction, next_cand, max_block_error, block_weight, limit=None):
+        nc = np.ascontiguousarray(next_cand, np.int32)
+        me = np.ascontiguousarray(max_block_error, np.float32)
+        bw = np.ascontiguousarray(block_weight, np.float32)
+        assert nc.size == me.size == bw.size == self.nb
+        total, below = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        btc = np.zeros(1, np.int32)
+        self._chk(self.L.lib.gz_order_build(self.handle, direction, _ptr(nc), _ptr(me), _ptr(bw),
+                                            int(limit is not None), float(limit or 0.0),
+                                            _ptr(total), _ptr(btc), _ptr(below)))
+        return int(total[0]), int(btc[0]), int(below[0])
+
+    def order_upload(self, entries):
+        e = np.ascontiguousarray(entries, self.ORDER_DTYPE)
+        self._chk(self.L.lib.gz_order_upload(self.handle, _ptr(e), e.size))
+
+    def order_partition(self, lo, hi):
+        cut = np.zeros(1, np.uint64)
+        self._chk(self.L.lib.gz_order_partition(self.handle, lo, hi, _ptr(cut)))
+        return int(cut[0])
+
+    def order_fetch(self, lo, hi):
+        out = np.zeros(hi - lo, self.ORDER_DTYPE)
+        self._chk(self.L.lib.gz_order_fetch(self.handle, lo, hi, _ptr(out)))
+        return out
 
     # ---- entropy coding of the candidate ----
     def jpeg_histograms(self, q):

@@ -26,6 +26,7 @@
 #include "gz_kernels_search.h"
 #include "gz_kernels_entropy.h"
 #include "gz_kernels_dctd.h"
+#include "gz_kernels_order.h"
 #include "gz_host_weights.h"
 #include "order_tables_generated.h"   // host-side csf/bias of order.inc
 
@@ -198,6 +199,17 @@ struct gz_ctx {
   unsigned* d_words_kept = nullptr; size_t words_kept_cap = 0;
   unsigned long long scan_bits = 0, scan_ff = 0, kept_bits = 0, kept_ff = 0;
   bool have_jq = false, have_scan = false, have_kept = false;
+
+  // global candidate order of phase B (gz_kernels_order.h)
+  OrderEntry* d_order = nullptr; size_t order_cap = 0; size_t order_n = 0;
+  unsigned* d_pos_l = nullptr; unsigned* d_pos_r = nullptr;       // [order_cap]
+  unsigned* d_chunk = nullptr; size_t chunk_cap = 0;              // cnt_l, cnt_r, base_l, base_r
+  PartScalars* d_part = nullptr;
+  unsigned* d_order_nb = nullptr;                                 // [nb]
+  unsigned long long* d_order_off = nullptr;                      // [nb+1]
+  unsigned* d_order_counters = nullptr;                           // [2]
+  int* d_next_cand = nullptr; float* d_weight = nullptr; float* d_max_err = nullptr;   // [nb]
+  bool have_search = false;
 
   bool have_orig = false, have_cand = false, have_distmap = false;
   std::vector<float> h_block_max;
@@ -744,6 +756,10 @@ void gz_destroy(gz_ctx* c) {
   hipFree(c->d_jq); hipFree(c->d_hist); hipFree(c->d_code_depth); hipFree(c->d_code_bits);
   hipFree(c->d_mcu_bits); hipFree(c->d_mcu_off); hipFree(c->d_ff_count);
   hipFree(c->d_words); hipFree(c->d_words_kept);
+  hipFree(c->d_order); hipFree(c->d_pos_l); hipFree(c->d_pos_r); hipFree(c->d_chunk);
+  hipFree(c->d_part); hipFree(c->d_order_nb); hipFree(c->d_order_off);
+  hipFree(c->d_order_counters); hipFree(c->d_next_cand); hipFree(c->d_weight);
+  hipFree(c->d_max_err);
   for (int b = 0; b < B_COUNT; ++b) hipFree(c->blur[b].d_scale);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -915,6 +931,132 @@ int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target
   if (!use_distmap) { zero.assign(c->nb, 0.0f); bmax = zero.data(); }
   block_weights_host(bmax, c->bw, c->bh, c->target, direction, max_block_dist, target_mul,
                      block_weight);
+  return GZ_OK;
+}
+
+
+// ------------------------------------------------- global candidate order (phase B) ----
+static int ensure_order_capacity(gz_ctx* c, size_t n) {
+  if (!c->d_part) {
+    HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(PartScalars)));
+    HIPCHK(c, hipMalloc((void**)&c->d_order_counters, sizeof(unsigned) * 2));
+  }
+  if (n <= c->order_cap) return GZ_OK;
+  (void)hipFree(c->d_order); (void)hipFree(c->d_pos_l); (void)hipFree(c->d_pos_r); (void)hipFree(c->d_chunk);
+  c->d_order = nullptr; c->d_pos_l = nullptr; c->d_pos_r = nullptr; c->d_chunk = nullptr;
+  c->order_cap = 0;
+  const size_t cap = n + n / 8 + 4096;
+  HIPCHK(c, hipMalloc((void**)&c->d_order, sizeof(OrderEntry) * cap));
+  HIPCHK(c, hipMalloc((void**)&c->d_pos_l, sizeof(unsigned) * (cap / 2 + 1)));
+  HIPCHK(c, hipMalloc((void**)&c->d_pos_r, sizeof(unsigned) * (cap / 2 + 1)));
+  c->chunk_cap = cap / kPartChunk + 2;
+  HIPCHK(c, hipMalloc((void**)&c->d_chunk, sizeof(unsigned) * 4 * c->chunk_cap));
+  c->order_cap = cap;
+  return GZ_OK;
+}
+
+int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
+                   const float* max_block_error, const float* block_weight, int count_below,
+                   float limit, uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  if (!c || !next_cand || !max_block_error || !block_weight || !total || !blocks_to_change ||
+      (direction != 1 && direction != -1) || (count_below && !below))
+    return GZ_E_ARG;
+  if (!c->have_search) { c->err = "gz_block_zeroing_orders must precede gz_order_build"; return GZ_E_STATE; }
+  const int nb = c->nb;
+  if (!c->d_order_nb) {
+    HIPCHK(c, hipMalloc((void**)&c->d_order_nb, sizeof(unsigned) * nb));
+    HIPCHK(c, hipMalloc((void**)&c->d_order_off, sizeof(unsigned long long) * (nb + 1)));
+    HIPCHK(c, hipMalloc((void**)&c->d_next_cand, sizeof(int) * nb));
+    HIPCHK(c, hipMalloc((void**)&c->d_weight, sizeof(float) * nb));
+    HIPCHK(c, hipMalloc((void**)&c->d_max_err, sizeof(float) * nb));
+  }
+  TRY(ensure_order_capacity(c, 0));
+  HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_weight, block_weight, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_max_err, max_block_error, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_order_counters, 0, sizeof(unsigned) * 2, c->stream));
+  GZ_LAUNCH(k_order_sizes, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
+            (const int*)c->d_out_cnt, (const int*)c->d_next_cand, (const float*)c->d_weight,
+            direction, nb, c->d_order_nb, c->d_order_counters);
+  KCHK(c);
+  GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), c->stream, (const unsigned*)c->d_order_nb,
+            nb, c->d_order_off);
+  KCHK(c);
+  unsigned long long n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->d_order_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  TRY(ensure_order_capacity(c, (size_t)n));
+  c->order_n = (size_t)n;
+  if (n > 0) {
+    GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, 4)), dim3(256), c->stream,
+              (const float*)c->d_out_err, (const int*)c->d_next_cand, (const float*)c->d_weight,
+              (const float*)c->d_max_err, (const unsigned long long*)c->d_order_off, direction, nb,
+              count_below ? 1 : 0, limit, c->d_order, c->d_order_counters);
+    KCHK(c);
+  }
+  unsigned counters[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(counters, c->d_order_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *total = n;
+  *blocks_to_change = (int32_t)counters[0];
+  if (below) *below = counters[1];
+  return GZ_OK;
+}
+
+int gz_order_upload(gz_ctx* c, const void* entries, uint64_t n) {
+  if (!c || (n > 0 && !entries)) return GZ_E_ARG;
+  TRY(ensure_order_capacity(c, (size_t)n));
+  if (n > 0)
+    HIPCHK(c, hipMemcpyAsync(c->d_order, entries, sizeof(OrderEntry) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->order_n = (size_t)n;
+  return GZ_OK;
+}
+
+int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
+  if (!c || !cut) return GZ_E_ARG;
+  if (hi > c->order_n || lo >= hi || hi - lo <= 3 || hi - lo > 0xfffffff0ull) return GZ_E_ARG;
+  const size_t first = (size_t)lo + 1;
+  const unsigned n = (unsigned)(hi - first);
+  const int nchunks = (int)((n + kPartChunk - 1) / kPartChunk);
+  unsigned* cnt_l = c->d_chunk;
+  unsigned* cnt_r = c->d_chunk + c->chunk_cap;
+  unsigned* base_l = c->d_chunk + 2 * c->chunk_cap;
+  unsigned* base_r = c->d_chunk + 3 * c->chunk_cap;
+  OrderEntry* a = c->d_order;
+  PartScalars* ps = c->d_part;
+  unsigned* pos_l = c->d_pos_l;
+  unsigned* pos_r = c->d_pos_r;
+  const size_t lo_s = (size_t)lo, hi_s = (size_t)hi;
+  GZ_LAUNCH(k_part_median, dim3(1), dim3(1), c->stream, a, lo_s, hi_s, ps);
+  KCHK(c);
+  GZ_LAUNCH(k_part_count, dim3(nchunks), dim3(256), c->stream, (const OrderEntry*)a, first, n,
+            (const PartScalars*)ps, cnt_l, cnt_r);
+  KCHK(c);
+  GZ_LAUNCH(k_part_scan, dim3(1), dim3(1024), c->stream, (const unsigned*)cnt_l,
+            (const unsigned*)cnt_r, nchunks, base_l, base_r);
+  KCHK(c);
+  GZ_LAUNCH(k_part_scatter, dim3(nchunks), dim3(256), c->stream, (const OrderEntry*)a, first, n,
+            ps, (const unsigned*)base_l, (const unsigned*)base_r, pos_l, pos_r);
+  KCHK(c);
+  GZ_LAUNCH(k_part_swap, dim3(gz_div_up((int)(n / 2 + 1), 256)), dim3(256), c->stream, a, first,
+            (const PartScalars*)ps, (const unsigned*)pos_l, (const unsigned*)pos_r);
+  KCHK(c);
+  PartScalars h;
+  HIPCHK(c, hipMemcpyAsync(&h, ps, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  uint64_t r = hi;
+  if (h.cut_l != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_l);
+  if (h.cut_r != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_r);
+  *cut = r;
+  return GZ_OK;
+}
+
+int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
+  if (!c || !out || lo > hi || hi > c->order_n) return GZ_E_ARG;
+  if (hi > lo)
+    HIPCHK(c, hipMemcpyAsync(out, c->d_order + lo, sizeof(OrderEntry) * (hi - lo), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return GZ_OK;
 }
 
@@ -1320,6 +1462,7 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
   a.out_cnt = c->d_out_cnt; a.out_idx = c->d_out_idx; a.out_err = c->d_out_err;
   GZ_LAUNCH(k_block_search, dim3(nb), dim3(64), c->stream, a);
   KCHK(c);
+  c->have_search = true;
   std::vector<int32_t> cnt(nb);
   std::vector<uint8_t> widx((size_t)nb * 192);
   std::vector<float> werr((size_t)nb * 192);

@@ -1,0 +1,289 @@
+// Phase B of Processor::SelectFrequencyMasking on the device: the global candidate order
+// (processor.cc:622-663) and the partition step of the std::sort the reference runs on it
+// (processor.cc:675-678).
+//
+// The reference builds `global_order` = (block, val) for every remaining candidate of
+// every block with a non-zero weight, std::sort-s it by val and consumes a prefix.  Equal
+// vals occur across different blocks, std::sort is not stable, and which tied block is
+// served first feeds the JPEG bytes; so the search driver (guetzli_amd/host/lazy_sort.h)
+// evaluates libstdc++'s introsort lazily from the front.  The expensive part of that --
+// the unguarded Hoare partitions of the multi-million-entry ranges -- runs here, with the
+// identical outcome:
+//
+//   libstdc++'s __unguarded_partition(first, last, pivot) swaps the k-th element from the
+//   left that is not less than the pivot ("left stopper" L_k) with the k-th element from the
+//   right that is not greater ("right stopper" R_k) for k = 0, 1, ... while L_k < R_k.  With
+//   lr(i) = number of left stoppers before i and ra(i) = number of right stoppers after i,
+//   a left stopper i (rank k = lr(i)) is swapped iff ra(i) > k, a right stopper j (rank
+//   k = ra(j)) iff lr(j) > k, and partners share k.  Both conditions are local given two
+//   prefix counts, so the partition is two streaming passes + a pairwise swap.  The cut is
+//   min(first unswapped left stopper, last swapped right stopper) -- where the serial scan
+//   stops.
+//
+// Entries are 8 bytes {int block; float val}, the layout of std::pair<int, float>.
+#pragma once
+#include "gz_common.h"
+
+namespace gz {
+
+struct OrderEntry {
+  int block;
+  float val;
+};
+
+// comp = [](a, b) { return a.second < b.second; }  (processor.cc:676-678)
+GZ_DEVFN bool order_less(const OrderEntry& a, const OrderEntry& b) { return a.val < b.val; }
+
+// ----------------------------------------------------------------- building the order --
+// n_b[b] = number of entries block b contributes (processor.cc:638-661): none if its weight
+// is 0; the candidates from next_cand[b] on for "up"; the next_cand[b] applied ones for
+// "down".  counters[0] += blocks with at least one entry (blocks_to_change).
+__global__ __launch_bounds__(256) void k_order_sizes(const int* __restrict__ cnt,
+                                                     const int* __restrict__ next_cand,
+                                                     const float* __restrict__ weight,
+                                                     int direction, int nb,
+                                                     unsigned* __restrict__ n_b,
+                                                     unsigned* __restrict__ counters) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  int n = 0;
+  if (!(weight[b] == 0)) {
+    const int at = next_cand[b];
+    n = direction > 0 ? cnt[b] - at : at;
+    if (n < 0) n = 0;
+  }
+  n_b[b] = (unsigned)n;
+  if (n > 0) atomicAdd(&counters[0], 1u);
+}
+
+// One wave per block: entry j of block b is (b, (err[at+j] - max_err) / weight) for "up",
+// (b, (max_err - err[at-1-j]) / weight) for "down" (float arithmetic, processor.cc:649-657).
+// err has a fixed stride of 192 per block (k_block_search's layout).  counters[1] += number
+// of vals < limit when count_below (the partition_point of processor.cc:690-696 counts
+// exactly these once the order is sorted).
+__global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ err,
+                                                    const int* __restrict__ next_cand,
+                                                    const float* __restrict__ weight,
+                                                    const float* __restrict__ max_err,
+                                                    const unsigned long long* __restrict__ off,
+                                                    int direction, int nb, int count_below,
+                                                    float limit, OrderEntry* __restrict__ out,
+                                                    unsigned* __restrict__ counters) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= nb) return;
+  const unsigned long long o = off[b];
+  const int n = (int)(off[b + 1] - o);
+  if (n == 0) return;
+  const int at = next_cand[b];
+  const float base = max_err[b], wb = weight[b];
+  const float* e = err + (size_t)b * 192;
+  unsigned below = 0;
+  for (int j = lane; j < n; j += 64) {
+    OrderEntry v;
+    v.block = b;
+    v.val = direction > 0 ? (e[at + j] - base) / wb : (base - e[at - 1 - j]) / wb;
+    out[o + j] = v;
+    below += (count_below && v.val < limit) ? 1u : 0u;
+  }
+  if (count_below && below) atomicAdd(&counters[1], below);
+}
+
+// -------------------------------------------------------------- one introsort partition --
+struct PartScalars {
+  unsigned m;      // number of swapped pairs
+  unsigned cut_l;  // first unswapped left stopper (relative to first), 0xffffffff if none
+  unsigned cut_r;  // last swapped right stopper (the smallest position), 0xffffffff if none
+  unsigned pad;
+  OrderEntry pivot;
+};
+
+constexpr int kPartItems = 8;                       // consecutive entries per thread
+constexpr int kPartChunk = 256 * kPartItems;        // entries per workgroup
+
+GZ_DEVFN void order_swap(OrderEntry* a, size_t i, size_t j) {
+  const OrderEntry t = a[i];
+  a[i] = a[j];
+  a[j] = t;
+}
+
+// std::__move_median_to_first(first, first+1, mid, last-1) of libstdc++'s
+// __unguarded_partition_pivot on [lo, hi), then the pivot value for the passes below.
+__global__ void k_part_median(OrderEntry* __restrict__ a, size_t lo, size_t hi,
+                              PartScalars* __restrict__ s) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const size_t r = lo, x = lo + 1, y = lo + (hi - lo) / 2, z = hi - 1;
+  if (order_less(a[x], a[y])) {
+    if (order_less(a[y], a[z])) order_swap(a, r, y);
+    else if (order_less(a[x], a[z])) order_swap(a, r, z);
+    else order_swap(a, r, x);
+  } else if (order_less(a[x], a[z])) {
+    order_swap(a, r, x);
+  } else if (order_less(a[y], a[z])) {
+    order_swap(a, r, z);
+  } else {
+    order_swap(a, r, y);
+  }
+  s->pivot = a[lo];
+  s->m = 0;
+  s->cut_l = 0xffffffffu;
+  s->cut_r = 0xffffffffu;
+}
+
+// Workgroup-wide inclusive prefix sum of one unsigned per thread (256 threads).
+GZ_DEVFN unsigned wg_inclusive_scan(unsigned v, unsigned* lds) {
+  const int t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    unsigned o = 0;
+    if (t >= d) o = lds[t - d];
+    __syncthreads();
+    lds[t] += o;
+    __syncthreads();
+  }
+  const unsigned r = lds[t];
+  __syncthreads();
+  return r;
+}
+
+// Pass 1: per chunk, the number of left stoppers (!(e < pivot)) and right stoppers
+// (!(pivot < e)) among a[first .. first+n).
+__global__ __launch_bounds__(256) void k_part_count(const OrderEntry* __restrict__ a,
+                                                    size_t first, unsigned n,
+                                                    const PartScalars* __restrict__ s,
+                                                    unsigned* __restrict__ cnt_l,
+                                                    unsigned* __restrict__ cnt_r) {
+  __shared__ unsigned lds[256];
+  const OrderEntry pv = s->pivot;
+  const unsigned base = blockIdx.x * (unsigned)kPartChunk + threadIdx.x * (unsigned)kPartItems;
+  unsigned nl = 0, nr = 0;
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
+    const unsigned p = base + i;
+    if (p < n) {
+      const OrderEntry e = a[first + p];
+      nl += !order_less(e, pv) ? 1u : 0u;
+      nr += !order_less(pv, e) ? 1u : 0u;
+    }
+  }
+  const unsigned tl = wg_inclusive_scan(nl, lds);
+  const unsigned tr = wg_inclusive_scan(nr, lds);
+  if (threadIdx.x == 255) {
+    cnt_l[blockIdx.x] = tl;
+    cnt_r[blockIdx.x] = tr;
+  }
+}
+
+// base_l[c] = left stoppers in chunks before c; base_r[c] = right stoppers in chunks after c.
+// One workgroup of 1024.
+__global__ __launch_bounds__(1024) void k_part_scan(const unsigned* __restrict__ cnt_l,
+                                                    const unsigned* __restrict__ cnt_r,
+                                                    int nchunks, unsigned* __restrict__ base_l,
+                                                    unsigned* __restrict__ base_r) {
+  __shared__ unsigned part[1024];
+  const int t = threadIdx.x;
+  const int per = (nchunks + 1023) / 1024;
+  const int lo = t * per < nchunks ? t * per : nchunks;
+  const int hi = lo + per < nchunks ? lo + per : nchunks;
+  for (int pass = 0; pass < 2; ++pass) {
+    // pass 0: forward over cnt_l; pass 1: the same over cnt_r read back to front
+    unsigned sum = 0;
+    for (int i = lo; i < hi; ++i) sum += pass == 0 ? cnt_l[i] : cnt_r[nchunks - 1 - i];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      unsigned o = 0;
+      if (t >= d) o = part[t - d];
+      __syncthreads();
+      part[t] += o;
+      __syncthreads();
+    }
+    unsigned run = part[t] - sum;
+    for (int i = lo; i < hi; ++i) {
+      if (pass == 0) {
+        base_l[i] = run;
+        run += cnt_l[i];
+      } else {
+        base_r[nchunks - 1 - i] = run;
+        run += cnt_r[nchunks - 1 - i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Pass 2: ranks of the stoppers; swapped ones record their position under their rank.
+__global__ __launch_bounds__(256) void k_part_scatter(const OrderEntry* __restrict__ a,
+                                                      size_t first, unsigned n,
+                                                      PartScalars* __restrict__ s,
+                                                      const unsigned* __restrict__ base_l,
+                                                      const unsigned* __restrict__ base_r,
+                                                      unsigned* __restrict__ pos_l,
+                                                      unsigned* __restrict__ pos_r) {
+  __shared__ unsigned lds[256];
+  __shared__ unsigned red[3];
+  const OrderEntry pv = s->pivot;
+  const int t = threadIdx.x;
+  const unsigned base = blockIdx.x * (unsigned)kPartChunk + t * (unsigned)kPartItems;
+  unsigned fl = 0, fr = 0, nl = 0, nr = 0;   // flag bit masks and counts of this thread
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
+    const unsigned p = base + i;
+    if (p < n) {
+      const OrderEntry e = a[first + p];
+      if (!order_less(e, pv)) { fl |= 1u << i; ++nl; }
+      if (!order_less(pv, e)) { fr |= 1u << i; ++nr; }
+    }
+  }
+  if (t == 0) { red[0] = 0; red[1] = 0xffffffffu; red[2] = 0xffffffffu; }
+  // left stoppers before this thread's first entry / right stoppers after its last one
+  const unsigned incl_l = wg_inclusive_scan(nl, lds);
+  const unsigned incl_r = wg_inclusive_scan(nr, lds);
+  __shared__ unsigned chunk_r;
+  if (t == 255) chunk_r = incl_r;
+  __syncthreads();
+  unsigned lr = base_l[blockIdx.x] + (incl_l - nl);
+  unsigned ra = base_r[blockIdx.x] + (chunk_r - incl_r) + nr;   // + stoppers after entry i, below
+  unsigned my_m = 0, my_cl = 0xffffffffu, my_cr = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
+    const unsigned p = base + i;
+    const bool is_l = (fl >> i) & 1u, is_r = (fr >> i) & 1u;
+    if (is_r) --ra;            // ra = right stoppers strictly after entry i
+    if (is_l) {
+      if (ra > lr) {           // L_k < R_k with k = lr
+        pos_l[lr] = p;
+        my_m = lr + 1;
+      } else if (p < my_cl) {
+        my_cl = p;
+      }
+    }
+    if (is_r && lr > ra) {     // partner exists on the left: k = ra
+      pos_r[ra] = p;
+      if (p < my_cr) my_cr = p;
+    }
+    if (is_l) ++lr;            // lr = left stoppers strictly before the next entry
+  }
+  if (my_m) atomicMax(&red[0], my_m);
+  if (my_cl != 0xffffffffu) atomicMin(&red[1], my_cl);
+  if (my_cr != 0xffffffffu) atomicMin(&red[2], my_cr);
+  __syncthreads();
+  if (t == 0) {
+    if (red[0]) atomicMax(&s->m, red[0]);
+    if (red[1] != 0xffffffffu) atomicMin(&s->cut_l, red[1]);
+    if (red[2] != 0xffffffffu) atomicMin(&s->cut_r, red[2]);
+  }
+}
+
+// Pass 3: swap pair k for k < m.
+__global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, size_t first,
+                                                   const PartScalars* __restrict__ s,
+                                                   const unsigned* __restrict__ pos_l,
+                                                   const unsigned* __restrict__ pos_r) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= s->m) return;
+  order_swap(a, first + pos_l[k], first + pos_r[k]);
+}
+
+}  // namespace gz

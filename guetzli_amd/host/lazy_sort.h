@@ -35,18 +35,33 @@
 
 namespace guetzli_amd {
 
+// Optional back end for an array that starts out on the device (include/guetzli_amd.h,
+// gz_order_*): ranges are partitioned there -- same arrangement and cut as Partition()
+// below -- until they are small, then fetched into the host array and finished here.
+class RangeDevice {
+ public:
+  virtual ~RangeDevice() {}
+  // libstdc++'s __unguarded_partition_pivot on [lo, hi): median of {lo+1, mid, hi-1} to lo,
+  // unguarded partition of [lo+1, hi) around it.
+  virtual bool Partition(size_t lo, size_t hi, size_t* cut) = 0;
+  virtual bool Fetch(size_t lo, size_t hi, void* dst) = 0;
+};
+
 template <class T, class Less>
 class LazySorted {
  public:
   LazySorted(T* data, size_t n, Less less, int depth_override = -1,
-             size_t parallel_threshold = 1 << 17)
-      : a_(data), n_(n), less_(less), done_(0), par_threshold_(parallel_threshold) {
+             size_t parallel_threshold = 1 << 17, RangeDevice* device = nullptr,
+             size_t device_threshold = 1 << 16)
+      : a_(data), n_(n), less_(less), done_(0), par_threshold_(parallel_threshold),
+        dev_(device), dev_threshold_(device_threshold < 16 ? 16 : device_threshold) {
     if (n_ == 0) return;
     int lg = 0;
     for (size_t m = n_; m > 1; m >>= 1) ++lg;
-    pending_.push_back(Range{0, n_, depth_override >= 0 ? depth_override : 2 * lg});
+    pending_.push_back(Range{0, n_, depth_override >= 0 ? depth_override : 2 * lg, dev_ != nullptr});
   }
   size_t size() const { return n_; }
+  bool failed() const { return failed_; }   // a device call failed; contents are undefined
   // Finalises positions [0, i] and returns element i.
   const T& operator[](size_t i) {
     while (done_ <= i) Refine();
@@ -61,6 +76,7 @@ class LazySorted {
   // the serial order of refinement gives.
   void EnsureSorted(size_t upto) {
     if (upto > n_) upto = n_;
+    if (dev_) ResolveDevice(upto);
     WorkerPool& pool = WorkerPool::Get();
     if (upto <= done_ || pool.size() == 1 || upto - done_ < (1u << 16)) {
       while (done_ < upto) Refine();
@@ -72,18 +88,24 @@ class LazySorted {
       pending_.pop_back();
     }
     const size_t grain = std::max<size_t>(8192, (upto - done_) / (8 * (size_t)pool.size()));
+    // Right-hand pieces that start at or beyond `upto` are not needed yet: they go back to
+    // the pending stack (they lie between the needed ranges and what is still pending).
+    std::vector<Range> defer;
     for (size_t i = 0; i < work.size();) {
       const Range r = work[i];
       if (r.hi - r.lo > grain && r.hi - r.lo > 16 && r.depth > 0) {
         const size_t mid = r.lo + (r.hi - r.lo) / 2;
         MoveMedianToFirst(r.lo, r.lo + 1, mid, r.hi - 1);
         const size_t cut = Partition(r.lo + 1, r.hi, r.lo);
-        work[i] = Range{r.lo, cut, r.depth - 1};
-        work.push_back(Range{cut, r.hi, r.depth - 1});
+        work[i] = Range{r.lo, cut, r.depth - 1, false};
+        if (cut < upto) work.push_back(Range{cut, r.hi, r.depth - 1, false});
+        else defer.push_back(Range{cut, r.hi, r.depth - 1, false});
       } else {
         ++i;
       }
     }
+    std::sort(defer.begin(), defer.end(), [](const Range& x, const Range& y) { return x.lo > y.lo; });
+    for (const Range& r : defer) pending_.push_back(r);
     pool.Run((int)work.size(), [&](int w) {
       std::vector<Range> stack(1, work[w]);
       while (!stack.empty()) RefineOn(&stack, false);
@@ -95,7 +117,40 @@ class LazySorted {
   struct Range {
     size_t lo, hi;
     int depth;
+    bool dev;   // still on the device (not yet in a_)
   };
+
+  // One step on a device-resident range: partition it there while it is large, else bring
+  // it to the host.  Pushes the result(s) on `stack`, leftmost on top.
+  void RefineDevice(const Range& r, std::vector<Range>* stack) {
+    if (r.hi - r.lo > dev_threshold_ && r.depth > 0) {
+      size_t cut = 0;
+      if (dev_->Partition(r.lo, r.hi, &cut) && cut > r.lo && cut <= r.hi) {
+        stack->push_back(Range{cut, r.hi, r.depth - 1, true});
+        stack->push_back(Range{r.lo, cut, r.depth - 1, true});
+        return;
+      }
+      failed_ = true;
+    }
+    if (failed_ || !dev_->Fetch(r.lo, r.hi, a_ + r.lo)) {
+      failed_ = true;
+      for (size_t i = r.lo; i < r.hi; ++i) a_[i] = T();
+    }
+    stack->push_back(Range{r.lo, r.hi, r.depth, false});
+  }
+
+  // Brings every range that reaches into [0, upto) to the host (on the calling thread: the
+  // device context is not shared with the pool).
+  void ResolveDevice(size_t upto) {
+    std::vector<Range> host;   // ascending lo
+    while (!pending_.empty() && pending_.back().lo < upto) {
+      const Range r = pending_.back();
+      pending_.pop_back();
+      if (r.dev) RefineDevice(r, &pending_);
+      else host.push_back(r);
+    }
+    for (size_t i = host.size(); i-- > 0;) pending_.push_back(host[i]);
+  }
 
   void MoveMedianToFirst(size_t result, size_t a, size_t b, size_t c) {
     if (less_(a_[a], a_[b])) {
@@ -230,6 +285,10 @@ class LazySorted {
   size_t RefineOn(std::vector<Range>* stack, bool may_use_pool) {
     Range r = stack->back();
     stack->pop_back();
+    if (r.dev) {
+      RefineDevice(r, stack);
+      return 0;
+    }
     if (r.hi - r.lo <= 16) {
       InsertionSort(r.lo, r.hi);
       return r.hi;
@@ -242,8 +301,8 @@ class LazySorted {
     MoveMedianToFirst(r.lo, r.lo + 1, mid, r.hi - 1);
     const size_t cut = may_use_pool ? Partition(r.lo + 1, r.hi, r.lo)
                                     : SerialPartition(r.lo + 1, r.hi, r.lo);
-    stack->push_back(Range{cut, r.hi, r.depth - 1});
-    stack->push_back(Range{r.lo, cut, r.depth - 1});
+    stack->push_back(Range{cut, r.hi, r.depth - 1, false});
+    stack->push_back(Range{r.lo, cut, r.depth - 1, false});
     return 0;
   }
 
@@ -252,6 +311,9 @@ class LazySorted {
   Less less_;
   size_t done_;
   size_t par_threshold_;
+  RangeDevice* dev_;
+  size_t dev_threshold_;
+  bool failed_ = false;
   std::vector<uint32_t> lbuf_, rbuf_;   // per-chunk stopper positions (ParallelPartition)
   std::vector<Range> pending_;   // back() is the leftmost unsorted range
 };

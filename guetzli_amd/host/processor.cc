@@ -152,6 +152,36 @@ inline int16_t QuantizeCoeff(int16_t raw, int quant) {   // quantize.h:24-29
   return (int16_t)(raw + delta);
 }
 
+// "precious" coefficients are never zeroed (processor.cc:722-733): (0,1) and (1,0) of a
+// block whose original value is at least 4 (8 when the block has much high-frequency energy).
+inline bool IsPrecious(const int16_t* orig_blk, int k) {
+  if (k != 1 && k != 8) return false;
+  double sum_of_hf = 0;
+  for (int ii = 3; ii < 64; ++ii) {
+    if ((ii & 7) < 3 && ii < 3 * 8) continue;
+    sum_of_hf += std::abs(orig_blk[ii]);
+  }
+  const int limit = sum_of_hf < 60 ? 4 : 8;
+  return std::abs(orig_blk[k]) >= limit;
+}
+
+// The device-resident global candidate order as LazySorted's back end.
+struct DeviceOrder : RangeDevice {
+  explicit DeviceOrder(gz_ctx* c) : ctx(c) {}
+  bool Partition(size_t lo, size_t hi, size_t* cut) override {
+    uint64_t c64 = 0;
+    rc = gz_order_partition(ctx, lo, hi, &c64);
+    *cut = (size_t)c64;
+    return rc == GZ_OK;
+  }
+  bool Fetch(size_t lo, size_t hi, void* dst) override {
+    rc = gz_order_fetch(ctx, lo, hi, dst);
+    return rc == GZ_OK;
+  }
+  gz_ctx* ctx;
+  int rc = GZ_OK;
+};
+
 // ------------------------------------------------------------------- the encoder ------
 class Encoder {
  public:
@@ -196,6 +226,7 @@ class Encoder {
   long n_fast_ = 0;
   double t_pb_weights_ = 0, t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0;
+  size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device
 };
 
 void Encoder::Log(const char* fmt, ...) {   // GUETZLI_LOG / PrintDebug, debug_print.h
@@ -424,13 +455,11 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   std::vector<float> max_block_error(nb, 0.0f);
   std::vector<int> next_cand(nb, 0);   // last_indexes
   std::vector<float> weight(nb);
-  std::vector<std::pair<int, float> > order;
-  std::vector<size_t> order_off(nb + 1);
+  std::vector<std::pair<int, float> > order;   // host copy of the ranges that were fetched
   std::vector<char> touched(nb);
   std::vector<int32_t> dirty;
   std::vector<int16_t> dirty_blocks;
-  std::vector<char> pending_flag((size_t)3 * nb, 0);
-  std::vector<int> pending;
+  std::vector<int> step_count(nb);
   bool first_up = true;
   const size_t comp_stride = (size_t)nb * 64;
 
@@ -438,64 +467,44 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
     for (;;) {
       int blocks_to_change = 0;
       Stopwatch pw;
+      // `order` (global_order, processor.cc:622-663) is built on the device from the CSR
+      // arrays phase A left there, in the reference's sequence: blocks ascending; within a
+      // block the remaining candidates ascending for "up", the applied ones descending for
+      // "down".
+      uint64_t total = 0, below = 0;
+      const float below_limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
       for (int radius = 1; radius <= 4; ++radius) {
         std::fill(weight.begin(), weight.end(), 0.0f);
         pw.lap();
         rc = gz_block_weights(ctx_, direction, radius, target_mul, first_up ? 0 : 1, weight.data());
         t_pb_weights_ += pw.lap();
         if (rc != GZ_OK) return Fail("gz_block_weights", rc);
-        // `order` in the reference's sequence (blocks ascending; within a block the
-        // remaining candidates ascending for "up", the applied ones descending for "down",
-        // processor.cc:640-673), filled by block ranges in parallel at precomputed offsets.
-        blocks_to_change = 0;
-        size_t total = 0;
-        for (int b = 0; b < nb; ++b) {
-          order_off[b] = total;
-          if (weight[b] == 0) continue;
-          const int at = next_cand[b], count = cand_off[b + 1] - cand_off[b];
-          const int n_b = direction > 0 ? count - at : at;
-          blocks_to_change += n_b > 0 ? 1 : 0;
-          total += (size_t)n_b;
-        }
-        order_off[nb] = total;
-        order.resize(total);
-        {
-          WorkerPool& pool = WorkerPool::Get();
-          const int chunks = total < (1u << 16) ? 1 : 4 * pool.size();
-          const int per = (nb + chunks - 1) / chunks;
-          pool.Run(chunks, [&](int ch) {
-            const int b0 = ch * per, b1 = std::min(nb, b0 + per);
-            for (int b = b0; b < b1; ++b) {
-              if (order_off[b + 1] == order_off[b]) continue;
-              std::pair<int, float>* dst = &order[order_off[b]];
-              const int at = next_cand[b], off = cand_off[b], count = cand_off[b + 1] - off;
-              const float* errs = &cand_err[off];
-              const float base = max_block_error[b];
-              const float wb = weight[b];
-              if (direction > 0) {
-                for (int i = at; i < count; ++i) *dst++ = std::make_pair(b, (errs[i] - base) / wb);
-              } else {
-                for (int i = at - 1; i >= 0; --i) *dst++ = std::make_pair(b, (base - errs[i]) / wb);
-              }
-            }
-          });
-        }
-        if (!order.empty()) break;
+        int32_t btc = 0;
+        rc = gz_order_build(ctx_, direction, next_cand.data(), max_block_error.data(), weight.data(),
+                            first_up ? 1 : 0, below_limit, &total, &btc, &below);
+        if (rc != GZ_OK) return Fail("gz_order_build", rc);
+        blocks_to_change = btc;
+        if (total != 0) break;
       }
       t_pb_order_ += pw.lap();
-      if (order.empty()) break;
-      n_order_ += (long)order.size();
+      if (total == 0) break;
+      n_order_ += (long)total;
+      if (order.size() < total) order.resize(total);
 
       // The reference std::sort-s `order` here (processor.cc:675-678) and then consumes a
       // prefix.  Equal keys occur across different blocks and std::sort is not stable, so
       // the permutation must be libstdc++'s; LazySorted yields exactly that permutation,
-      // front first, without sorting the part the scan never reaches.
+      // front first, without sorting the part the scan never reaches.  The partitions of the
+      // large ranges run on the device (gz_order_partition); ranges that have become small
+      // are fetched and finished here.
       struct KeyLess {
         bool operator()(const std::pair<int, float>& a, const std::pair<int, float>& b) const {
           return a.second < b.second;
         }
       };
-      LazySorted<std::pair<int, float>, KeyLess> sorted(order.data(), order.size(), KeyLess());
+      DeviceOrder dev_order(ctx_);
+      LazySorted<std::pair<int, float>, KeyLess> sorted(order.data(), (size_t)total, KeyLess(), -1,
+                                                         1 << 17, &dev_order, device_threshold_);
       t_pb_sort_ += pw.lap();
 
       double rel_size_delta = direction > 0 ? 0.01 : 0.0005;
@@ -505,10 +514,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       int min_coeffs_to_change = per_block * blocks_to_change;
       if (first_up) {
         // partition_point over the sorted sequence == number of keys below the limit
-        const float limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
-        int below = 0;
-        for (size_t i = 0; i < order.size(); ++i) below += order[i].second < limit ? 1 : 0;
-        min_coeffs_to_change = std::max<int>(min_coeffs_to_change, below);
+        min_coeffs_to_change = std::max<int>(min_coeffs_to_change, (int)below);
         first_up = false;
       }
 
@@ -519,11 +525,9 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       int changed_coeffs = 0;
       int est_size = prev_size;
       // One step of the reference loop (processor.cc:704-750) without its size estimate:
-      // change one coefficient of block b.  `histo_now`: keep ac_histo current after every
-      // step (the reference does); otherwise the block's symbols are taken out at its first
-      // change and put back by FlushPendingBlocks.
-      const size_t n_order = order.size();
-      auto apply_step = [&](size_t i, bool histo_now) {
+      // change one coefficient of block b and keep ac_histo current.
+      const size_t n_order = (size_t)total;
+      auto apply_step = [&](size_t i) {
         const int b = sorted[i].first;
         const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
         const int c = idx / 64, k = idx % 64;
@@ -531,25 +535,9 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         const int16_t* orig_blk = &orig_[c * comp_stride + (size_t)b * 64];
         int16_t* blk = &img_[c * comp_stride + (size_t)b * 64];
         const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
-        if (histo_now) {
-          AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
-        } else if (!pending_flag[(size_t)c * nb + b]) {
-          AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
-          pending_flag[(size_t)c * nb + b] = 1;
-          pending.push_back(c * nb + b);
-        }
-        bool precious = false;
-        if ((k == 1 || k == 8) && newval == 0) {   // the test only matters for these two
-          double sum_of_hf = 0;
-          for (int ii = 3; ii < 64; ++ii) {
-            if ((ii & 7) < 3 && ii < 3 * 8) continue;
-            sum_of_hf += std::abs(orig_blk[ii]);
-          }
-          const int limit = sum_of_hf < 60 ? 4 : 8;
-          precious = std::abs(orig_blk[k]) >= limit;
-        }
-        if (!precious || newval != 0) blk[k] = (int16_t)newval;
-        if (histo_now) AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
+        AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
+        if (!(newval == 0 && IsPrecious(orig_blk, k))) blk[k] = (int16_t)newval;
+        AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
         next_cand[b] += direction;
         if (!touched[b]) {
           touched[b] = 1;
@@ -568,19 +556,60 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         Stopwatch fw;
         sorted.EnsureSorted(fast_until);
         t_pb_ensure_ += fw.lap();
-        for (size_t i = 0; i < fast_until; ++i) apply_step(i, false);
-        t_pb_fast_ += fw.lap();
-        for (size_t j = 0; j < pending.size(); ++j) {
-          const int c = pending[j] / nb, b = pending[j] % nb;
-          AddBlockACSymbols(&img_[c * comp_stride + (size_t)b * 64], quant_[c], 1, &ac_histo[c]);
-          pending_flag[pending[j]] = 0;
+        // Steps [0, fast_until): only how many steps each block takes matters (the n-th step
+        // of a block applies its n-th remaining candidate whatever the key), so they are
+        // applied block by block on the worker pool; each worker keeps its own histogram
+        // delta (sums of +-1 per symbol, order-free).
+        std::fill(step_count.begin(), step_count.end(), 0);
+        for (size_t i = 0; i < fast_until; ++i) {
+          const int b = order[i].first;
+          if (step_count[b]++ == 0) {
+            touched[b] = 1;
+            dirty.push_back(b);
+          }
         }
-        pending.clear();
-        t_pb_flush_ += fw.lap();
+        if (fast_until > 0) {
+          val_threshold = order[fast_until - 1].second;
+          changed_coeffs += (int)fast_until;
+          WorkerPool& pool = WorkerPool::Get();
+          const int chunks = dirty.size() < 2048 ? 1 : 4 * pool.size();
+          const size_t per = (dirty.size() + chunks - 1) / chunks;
+          std::vector<SymbolHistogram> delta((size_t)3 * chunks);
+          for (auto& d : delta) memset(d.counts, 0, sizeof(d.counts));
+          pool.Run(chunks, [&](int ch) {
+            const size_t d0 = ch * per, d1 = std::min(dirty.size(), d0 + per);
+            SymbolHistogram* dl = &delta[(size_t)3 * ch];
+            for (size_t di = d0; di < d1; ++di) {
+              const int b = dirty[di];
+              bool removed[3] = {false, false, false};
+              for (int step = 0; step < step_count[b]; ++step) {
+                const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
+                const int c = idx / 64, k = idx % 64;
+                const int* q = quant_[c];
+                const int16_t* orig_blk = &orig_[c * comp_stride + (size_t)b * 64];
+                int16_t* blk = &img_[c * comp_stride + (size_t)b * 64];
+                if (!removed[c]) {
+                  AddBlockACSymbols(blk, q, -1, &dl[c]);
+                  removed[c] = true;
+                }
+                const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
+                if (!(newval == 0 && IsPrecious(orig_blk, k))) blk[k] = (int16_t)newval;
+                next_cand[b] += direction;
+              }
+              for (int c = 0; c < 3; ++c)
+                if (removed[c])
+                  AddBlockACSymbols(&img_[c * comp_stride + (size_t)b * 64], quant_[c], 1, &dl[c]);
+            }
+          });
+          for (int ch = 0; ch < chunks; ++ch)
+            for (int c = 0; c < 3; ++c)
+              for (int i = 0; i < kHistoSize; ++i) ac_histo[c].counts[i] += delta[(size_t)3 * ch + c].counts[i];
+        }
+        t_pb_fast_ += fw.lap();
         n_steps_ += (long)fast_until;
         n_fast_ += (long)fast_until;
         for (size_t i = fast_until; i < n_order; ++i) {
-          apply_step(i, true);
+          apply_step(i);
           if (i % 10 == 0) {
             Stopwatch cw;
             ac_header = (int)EntropyCodes(ac_histo, ac_depths.data());
@@ -595,7 +624,8 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         }
       }
       t_pb_loop_ += pw.lap();
-      const size_t order_size = order.size();
+      const size_t order_size = (size_t)total;
+      if (sorted.failed()) return Fail("gz_order_partition/fetch", dev_order.rc);
       for (int b = 0; b < nb; ++b) max_block_error[b] += weight[b] * val_threshold * direction;
 
       ++stats_->counters[kNumItersCnt];
@@ -664,6 +694,7 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
 
   // the unquantised original as the fallback output (processor.cc:826-846)
   verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
+  if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
   best_score_ = -1;
   QuantMatrix ones;
   for (int c = 0; c < 3; ++c)

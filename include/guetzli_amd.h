@@ -166,6 +166,34 @@ int gz_block_zeroing_orders(gz_ctx* ctx, int lookahead, int new_model, int32_t* 
 int gz_rank_zeroing_candidates(const int16_t* coeffs, const int16_t* orig, int nb,
                                int new_model, int32_t* offsets, uint8_t* idx);
 
+/* Global candidate order of phase B ------------------------------
+ * Phase B of SelectFrequencyMasking builds `global_order` = (block, val) for every
+ * remaining candidate of every block with a non-zero weight (processor.cc:622-663),
+ * std::sort-s it by val (:675-678) and consumes a prefix.  The order lives on the device:
+ *
+ * gz_order_build: the construction loop (:636-663) over the CSR arrays the last
+ *   gz_block_zeroing_orders left on the device.  next_cand = last_indexes (:608),
+ *   max_block_error (:607), block_weight = the output of gz_block_weights, nb values each.
+ *   *total = global_order.size(), *blocks_to_change as the reference counts it; if
+ *   count_below, *below = number of entries with val < limit (what the partition_point of
+ *   :690-696 yields on the sorted order).
+ * gz_order_upload: replace the device order with n host entries instead.
+ * gz_order_partition: one step of libstdc++'s introsort on [lo, hi) of the device order --
+ *   std::__unguarded_partition_pivot: median of {lo+1, mid, hi-1} to lo, unguarded Hoare
+ *   partition of [lo+1, hi) around it -- with exactly the arrangement and *cut the serial
+ *   algorithm gives (ties across blocks are not stable under std::sort and feed the JPEG
+ *   bytes).  Requires hi - lo > 3.
+ * gz_order_fetch: entries [lo, hi) to the host, 8 bytes each: {int32 block; float val}
+ *   (the layout of std::pair<int, float>).
+ * The search driver (guetzli_amd/host/lazy_sort.h) refines the leading ranges on the
+ * device until they are small, fetches them, and finishes them on the host. */
+int gz_order_build(gz_ctx* ctx, int direction, const int32_t* next_cand,
+                   const float* max_block_error, const float* block_weight, int count_below,
+                   float limit, uint64_t* total, int32_t* blocks_to_change, uint64_t* below);
+int gz_order_upload(gz_ctx* ctx, const void* entries, uint64_t n);
+int gz_order_partition(gz_ctx* ctx, uint64_t lo, uint64_t hi, uint64_t* cut);
+int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);
+
 /* Entropy coding of the candidate -----------------------------------------------------
  * The search needs the exact size of every candidate's JPEG (ScoreJPEG) and the bytes of the
  * winner only.  The candidate's coefficients are resident, so the symbol statistics and the

@@ -122,6 +122,11 @@ inline unsigned atomicMax(unsigned* p, unsigned v) {
   if (v > o) *p = v;
   return o;
 }
+inline unsigned atomicMin(unsigned* p, unsigned v) {
+  unsigned o = *p;
+  if (v < o) *p = v;
+  return o;
+}
 inline int atomicAdd(int* p, int v) {
   int o = *p;
   *p += v;

@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../guetzli_amd/csrc/gz_host_weights.h"
@@ -45,6 +46,9 @@ struct Real {
   decltype(&gz_jpeg_scan) jpeg_scan;
   decltype(&gz_jpeg_scan_keep) jpeg_scan_keep;
   decltype(&gz_jpeg_scan_bytes) jpeg_scan_bytes;
+  decltype(&gz_order_build) order_build;
+  decltype(&gz_order_partition) order_partition;
+  decltype(&gz_order_fetch) order_fetch;
   decltype(&gz_strerror) strerror_;
   decltype(&gz_last_error) last_error;
 };
@@ -71,6 +75,8 @@ Real* real() {
   SYM(last_error, "gz_last_error") SYM(get_coeffs, "gz_get_coeffs")
   SYM(jpeg_histograms, "gz_jpeg_histograms") SYM(jpeg_scan, "gz_jpeg_scan")
   SYM(jpeg_scan_keep, "gz_jpeg_scan_keep") SYM(jpeg_scan_bytes, "gz_jpeg_scan_bytes")
+  SYM(order_build, "gz_order_build") SYM(order_partition, "gz_order_partition")
+  SYM(order_fetch, "gz_order_fetch")
 #undef SYM
   return &r;
 }
@@ -88,6 +94,11 @@ struct gz_ctx {
   std::vector<int16_t> orig;
   std::vector<float> bmax;
   bool have_bmax = false;
+  // replay mode: phase A's CSR arrays and the global candidate order, which are pure
+  // functions of replayed data and are recomputed here with the serial algorithms
+  std::vector<int32_t> cand_off;
+  std::vector<float> cand_err;
+  std::vector<std::pair<int, float> > order;
   std::string err;
 };
 
@@ -235,6 +246,80 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
   if (offsets[c->nb] > cap) return GZ_E_ARG;
   get(c, idx, offsets[c->nb]);
   get(c, err, sizeof(float) * offsets[c->nb]);
+  c->cand_off.assign(offsets, offsets + c->nb + 1);
+  c->cand_err.assign(err, err + offsets[c->nb]);
+  return GZ_OK;
+}
+
+// The global candidate order: forwarded in record mode (nothing to log: it is a function of
+// the logged CSR arrays and the caller's inputs); in replay mode the reference's serial
+// construction (processor.cc:636-663) and libstdc++'s serial partition step.
+int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
+                   const float* max_block_error, const float* block_weight, int count_below,
+                   float limit, uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  if (c->inner)
+    return real()->order_build(c->inner, direction, next_cand, max_block_error, block_weight,
+                               count_below, limit, total, blocks_to_change, below);
+  c->order.clear();
+  int btc = 0;
+  uint64_t nbelow = 0;
+  for (int b = 0; b < c->nb; ++b) {
+    if (block_weight[b] == 0) continue;
+    const int at = next_cand[b], off = c->cand_off[b], count = c->cand_off[b + 1] - off;
+    const float* errs = &c->cand_err[off];
+    if (direction > 0) {
+      for (int i = at; i < count; ++i)
+        c->order.push_back(std::make_pair(b, (errs[i] - max_block_error[b]) / block_weight[b]));
+      btc += at < count ? 1 : 0;
+    } else {
+      for (int i = at - 1; i >= 0; --i)
+        c->order.push_back(std::make_pair(b, (max_block_error[b] - errs[i]) / block_weight[b]));
+      btc += at > 0 ? 1 : 0;
+    }
+  }
+  if (count_below)
+    for (size_t i = 0; i < c->order.size(); ++i) nbelow += c->order[i].second < limit ? 1 : 0;
+  *total = c->order.size();
+  *blocks_to_change = btc;
+  if (below) *below = nbelow;
+  return GZ_OK;
+}
+
+int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
+  if (c->inner) return real()->order_partition(c->inner, lo, hi, cut);
+  if (hi > c->order.size() || hi - lo <= 3) return GZ_E_ARG;
+  auto less = [](const std::pair<int, float>& a, const std::pair<int, float>& b) {
+    return a.second < b.second; };
+  std::pair<int, float>* a = c->order.data();
+  const size_t r = lo, x = lo + 1, y = lo + (hi - lo) / 2, z = hi - 1;
+  if (less(a[x], a[y])) {
+    if (less(a[y], a[z])) std::swap(a[r], a[y]);
+    else if (less(a[x], a[z])) std::swap(a[r], a[z]);
+    else std::swap(a[r], a[x]);
+  } else if (less(a[x], a[z])) {
+    std::swap(a[r], a[x]);
+  } else if (less(a[y], a[z])) {
+    std::swap(a[r], a[z]);
+  } else {
+    std::swap(a[r], a[y]);
+  }
+  size_t first = lo + 1, last = hi;
+  for (;;) {
+    while (less(a[first], a[lo])) ++first;
+    --last;
+    while (less(a[lo], a[last])) --last;
+    if (!(first < last)) break;
+    std::swap(a[first], a[last]);
+    ++first;
+  }
+  *cut = first;
+  return GZ_OK;
+}
+
+int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
+  if (c->inner) return real()->order_fetch(c->inner, lo, hi, out);
+  if (lo > hi || hi > c->order.size()) return GZ_E_ARG;
+  memcpy(out, c->order.data() + lo, (hi - lo) * sizeof(std::pair<int, float>));
   return GZ_OK;
 }
 

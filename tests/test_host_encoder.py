@@ -67,9 +67,12 @@ def test_write_jpeg_bytes(host, wh):
 
 
 @needs_ref
-@pytest.mark.parametrize("case", [(40, 32, 100, 60, 95), (48, 40, 300, 150, 84)])
-def test_whole_encode_matches_reference_in_emulation(host_emu, case):
-    w, h, x0, y0, quality = case
+@pytest.mark.parametrize("case", [(40, 32, 100, 60, 95, None), (48, 40, 300, 150, 84, None),
+                                  (40, 32, 100, 60, 95, 128)])
+def test_whole_encode_matches_reference_in_emulation(host_emu, case, monkeypatch):
+    w, h, x0, y0, quality, dev_threshold = case
+    if dev_threshold:   # partition even these small orders with the device kernels
+        monkeypatch.setenv("GZ_ORDER_DEVICE_THRESHOLD", str(dev_threshold))
     rgb = images.crop(w, h, x0, y0)
     target = ref._butteraugli_score_for_quality(float(quality))
     exp_jpg, exp_trace = ref.process(rgb, target, want_trace=True)

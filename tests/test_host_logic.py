@@ -15,3 +15,18 @@ def test_lazy_sort_is_std_sort(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "lazy_sort: ok" in out.stdout
+
+
+def test_device_partition_is_std_sort_in_emulation(tmp_path):
+    """gz_order_partition (gz_kernels_order.h, here the CPU emulation build of the kernel
+    sources) driven by LazySorted reproduces std::sort's permutation, ties included."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    exe = str(tmp_path / "test_device_order")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread",
+                    os.path.join(ROOT, "tests", "cpp", "test_device_order.cc"), "-o", exe, "-ldl"],
+                   check=True)
+    out = subprocess.run([exe, build_emu.build(), "4097", "512"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "device_order: ok" in out.stdout

@@ -20,4 +20,12 @@
 
 #define GZ_DEVFN __device__ __forceinline__
 
+// A value that is the same in every lane of the wavefront (derived from threadIdx.x >> 6):
+// telling the compiler so turns the branches on it into scalar branches.
+#ifdef GZ_EMU
+#define GZ_WAVE_UNIFORM(x) (x)
+#else
+#define GZ_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 static inline int gz_div_up(int a, int b) { return (a + b - 1) / b; }

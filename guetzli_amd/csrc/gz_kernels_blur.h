@@ -58,59 +58,94 @@ struct CPlanePack {
   const float* p[NC];
 };
 
+// Both passes work on a 64x64 output tile per workgroup of 256 threads and keep the taps'
+// inputs in REGISTERS: a thread produces 16 consecutive outputs along the blur axis from a
+// window of 16 + 2R staged samples, so each staged sample is read from LDS once per thread
+// (not once per tap).  The four waves of a workgroup take the four 16-output groups, so
+// whether an output is a border sample is the same for all lanes of a wave (a scalar
+// branch).  Arithmetic per output is unchanged: f32, ascending taps from 0.0f.
+constexpr int BT = 64;          // tile edge (outputs)
+constexpr int BPT = BT / 4;     // outputs per thread along the blur axis
+
+// One output of a window: interior = pre-scaled taps; border = raw taps, then one multiply.
+template <int R>
+GZ_DEVFN float blur_window_out(const float* win, int i, const Taps<R>& taps, bool border,
+                               float scale) {
+  float sum = 0.0f;
+  if (!border) {
+#pragma unroll
+    for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.ks[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.k[j];
+    sum = sum * scale;
+  }
+  return sum;
+}
+
 // ------------------------------------------------------------------------ row pass --
-// grid = (ceil(w/HW), ceil(h/HH), NC); block = 256 threads; thread = one x, HH rows.
-constexpr int HW = 256;
-constexpr int HH = 4;
+// grid = (ceil(w/64), ceil(h/64), NC).  The (64 rows) x (64 + 2R columns) input tile is
+// staged with coalesced row loads; lane = row, wave = column group, so a lane walks along
+// its row in LDS (odd pitch: conflict-free); the 64x64 results go back through LDS to be
+// stored as full 256-byte row segments.
+constexpr int HW = BT;
+constexpr int HH = BT;
 
 template <int R, class Src, int NC>
 __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<NC> dst,
                                                 int w, int h, int pitch, Taps<R> taps,
                                                 BorderScale bs) {
-  __shared__ float tile[HH][HW + 2 * R];
+  constexpr int TW = BT + 2 * R;                      // staged columns
+  constexpr int P = (TW % 2 == 0) ? TW + 1 : TW;      // odd LDS pitch
+  __shared__ float tile[BT * P];
   const int c = blockIdx.z;
   const Src s = src.s[c];
   float* __restrict__ out = dst.p[c];
-  const int x0 = blockIdx.x * HW, y0 = blockIdx.y * HH;
+  const int x0 = blockIdx.x * BT, y0 = blockIdx.y * BT;
   const int tid = threadIdx.x;
-  // stage rows y0..y0+HH-1, columns x0-R .. x0+HW+R-1 (zero outside the image)
-  for (int i = tid; i < HH * (HW + 2 * R); i += 256) {
-    const int ry = i / (HW + 2 * R), rx = i - ry * (HW + 2 * R);
+  for (int i = tid; i < BT * TW; i += 256) {
+    const int ry = i / TW, rx = i - ry * TW;
     const int x = x0 - R + rx, y = y0 + ry;
     float v = 0.0f;
     if (x >= 0 && x < w && y < h) v = s((size_t)y * pitch + x);
-    tile[ry][rx] = v;
+    tile[ry * P + rx] = v;
   }
   __syncthreads();
-  const int x = x0 + tid;
-  if (x >= w) return;
-  const bool border = x < R || x >= w - R;
-  float scale = 1.0f;
-  if (border) scale = x < R ? bs.lo[x] : bs.hi[w - 1 - x];
+  const int r = tid & 63;
+  const int g = GZ_WAVE_UNIFORM(tid >> 6);
+  float win[BPT + 2 * R];
 #pragma unroll
-  for (int ry = 0; ry < HH; ++ry) {
-    const int y = y0 + ry;
-    if (y >= h) break;
+  for (int i = 0; i < BPT + 2 * R; ++i) win[i] = tile[r * P + g * BPT + i];
+  __syncthreads();   // every window is in registers: the tile can take the results
+  constexpr int PO = BT + 1;
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    const int x = x0 + g * BPT + i;   // wave-uniform
     float sum = 0.0f;
-    if (!border) {
-#pragma unroll
-      for (int j = 0; j <= 2 * R; ++j) sum += tile[ry][tid + j] * taps.ks[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j <= 2 * R; ++j) sum += tile[ry][tid + j] * taps.k[j];
-      sum = sum * scale;
+    if (x < w) {
+      const bool border = x < R || x >= w - R;
+      float scale = 1.0f;
+      if (border) scale = x < R ? bs.lo[x] : bs.hi[w - 1 - x];
+      sum = blur_window_out<R>(win, i, taps, border, scale);
     }
-    out[(size_t)y * pitch + x] = sum;
+    tile[r * PO + g * BPT + i] = sum;
+  }
+  __syncthreads();
+  for (int i = tid; i < BT * BT; i += 256) {
+    const int ry = i >> 6, rx = i & 63;
+    const int x = x0 + rx, y = y0 + ry;
+    if (x < w && y < h) out[(size_t)y * pitch + x] = tile[ry * PO + rx];
   }
 }
 
 // --------------------------------------------------------------------- column pass --
-// grid = (ceil(w/VW), ceil(h/VH)); block = 256 = 64 columns x 4 row groups; each thread
-// produces VH/4 outputs of its column for every one of the NC planes, then hands the NC
-// blurred values of each pixel to the Post functor (which may read/write other planes).
-constexpr int VW = 64;
-constexpr int VH = 64;
-constexpr int VPT = VH / 4;   // outputs per thread
+// grid = (ceil(w/VW), ceil(h/VH)); block = 256 = 64 columns x 4 row groups (one per wave);
+// each thread produces VPT outputs of its column for every one of the NC planes, then hands
+// the NC blurred values of each pixel to the Post functor (which may read/write other
+// planes).
+constexpr int VW = BT;
+constexpr int VH = BT;
+constexpr int VPT = BPT;   // outputs per thread
 
 // With BM = true the values returned by the Post functor are additionally reduced to the
 // per-8x8-block maxima of the tile (the tile origin is 8-aligned) and to one atomicMax per
@@ -129,7 +164,8 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
                                                 int pitch, Taps<R> taps, BorderScale bs,
                                                 BlockMaxOut bm) {
   __shared__ float tile[VH + 2 * R][VW];
-  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63;
+  const int tg = GZ_WAVE_UNIFORM(threadIdx.x >> 6);
   const int x0 = blockIdx.x * VW, y0 = blockIdx.y * VH;
   const int x = x0 + tx;
   float acc[NC][VPT];
@@ -144,21 +180,18 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
       tile[ry][tx] = v;
     }
     __syncthreads();
+    float win[VPT + 2 * R];
+#pragma unroll
+    for (int i = 0; i < VPT + 2 * R; ++i) win[i] = tile[tg * VPT + i][tx];
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int ly = tg * VPT + i;   // local output row
-      const int y = y0 + ly;
+      const int y = y0 + tg * VPT + i;   // wave-uniform
       float sum = 0.0f;
       if (y < h) {
         const bool border = y < R || y >= h - R;
-        if (!border) {
-#pragma unroll
-          for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.ks[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.k[j];
-          sum = sum * (y < R ? bs.lo[y] : bs.hi[h - 1 - y]);
-        }
+        float scale = 1.0f;
+        if (border) scale = y < R ? bs.lo[y] : bs.hi[h - 1 - y];
+        sum = blur_window_out<R>(win, i, taps, border, scale);
       }
       acc[c][i] = sum;
     }

@@ -277,6 +277,20 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   return GZ_OK;
 }
 
+template <int R, int NC, class Src, class Post, bool BM = false>
+int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurCfg& cfg,
+           BlockMaxOut bm = BlockMaxOut{nullptr, nullptr, 0}) {
+  if (cfg.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
+  dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, T2));
+  const Taps<R> tp = taps_of<R>(cfg);
+  const BorderScale bx = cfg.bx, by = cfg.by;
+  const int w = c->w, h = c->h, pitch = c->pitch;
+  GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM>), grid, dim3(256), c->stream, src, post, w, h, pitch,
+            tp, bx, by, bm);
+  KCHK(c);
+  return GZ_OK;
+}
+
 #define TRY(x) do { int rc_ = (x); if (rc_ != GZ_OK) return rc_; } while (0)
 
 int setup_blur_cfg(gz_ctx* c, BlurCfg* cfg, float sigma, float border_ratio) {
@@ -304,19 +318,17 @@ int setup_blur_cfg(gz_ctx* c, BlurCfg* cfg, float sigma, float border_ratio) {
 // OpsinDynamicsImage: lin[3] -> xyb[3]
 int stage_opsin(gz_ctx* c) {
   SrcPack<SrcPlain, 3> s;
-  PlanePack<3> t;
-  CPlanePack<3> ct;
-  for (int i = 0; i < 3; ++i) { s.s[i].p = c->lin[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
-  TRY((blur_h<2, SrcPlain, 3>(c, s, t, c->blur[B_OPSIN])));
+  for (int i = 0; i < 3; ++i) s.s[i].p = c->lin[i];
   PostOpsin post;
   for (int i = 0; i < 3; ++i) { post.lin[i] = c->lin[i]; post.xyb[i] = c->xyb[i]; }
-  TRY((blur_v<2, 3, PostOpsin>(c, ct, post, c->blur[B_OPSIN])));
+  TRY((blur2d<2, 3, SrcPlain, PostOpsin>(c, s, post, c->blur[B_OPSIN])));
   return GZ_OK;
 }
 
 // SeparateFrequencies: xyb[3] -> Psycho planes
 int stage_separate(gz_ctx* c, Psycho* ps) {
-  {  // LF
+  {  // LF (radius 16: separate row and column passes -- the fused kernel's extra row-pass
+     // arithmetic costs more than the intermediate plane at this radius)
     SrcPack<SrcPlain, 3> s;
     PlanePack<3> t;
     CPlanePack<3> ct;
@@ -330,15 +342,10 @@ int stage_separate(gz_ctx* c, Psycho* ps) {
   }
   {  // MF (X, Y)
     SrcPack<SrcDiff, 2> s;
-    PlanePack<2> t;
-    CPlanePack<2> ct;
     for (int i = 0; i < 2; ++i) {
       s.s[i].a = c->xyb[i];
       s.s[i].b = c->lf_raw[i];
-      t.p[i] = c->tmp[i];
-      ct.p[i] = c->tmp[i];
     }
-    TRY((blur_h<8, SrcDiff, 2>(c, s, t, c->blur[B_MF])));
     PostMF post;
     for (int i = 0; i < 2; ++i) {
       post.xyb[i] = c->xyb[i];
@@ -346,14 +353,11 @@ int stage_separate(gz_ctx* c, Psycho* ps) {
       post.mf[i] = ps->mf[i];
       post.hf_pre[i] = c->hfp[i];
     }
-    TRY((blur_v<8, 2, PostMF>(c, ct, post, c->blur[B_MF])));
+    TRY((blur2d<8, 2, SrcDiff, PostMF>(c, s, post, c->blur[B_MF])));
   }
   {  // HF / UHF
     SrcPack<SrcPlain, 2> s;
-    PlanePack<2> t;
-    CPlanePack<2> ct;
-    for (int i = 0; i < 2; ++i) { s.s[i].p = c->hfp[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
-    TRY((blur_h<4, SrcPlain, 2>(c, s, t, c->blur[B_HF])));
+    for (int i = 0; i < 2; ++i) s.s[i].p = c->hfp[i];
     PostHF post;
     for (int i = 0; i < 2; ++i) {
       post.hf_pre[i] = c->hfp[i];
@@ -361,14 +365,14 @@ int stage_separate(gz_ctx* c, Psycho* ps) {
       post.uhf[i] = ps->uhf[i];
     }
     post.lf_raw_y = c->lf_raw[1];
-    TRY((blur_v<4, 2, PostHF>(c, ct, post, c->blur[B_HF])));
+    TRY((blur2d<4, 2, SrcPlain, PostHF>(c, s, post, c->blur[B_HF])));
   }
   return GZ_OK;
 }
 
 // Mask first half: DiffPrecompute + three blurs -> mxb, myb1, myb2
 int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk) {
-  dim3 grid(gz_div_up(c->w, 256), c->h, 2);
+  dim3 grid(gz_div_up(c->w, 1024), c->h, 2);
   GZ_LAUNCH(k_mask_pre, grid, dim3(256), c->stream, pk, c->w, c->h, c->pitch);
   KCHK(c);
   {  // X: sigma r2 = 9.24 ; Y second: sigma r1 = 9.04 -- both radius 20, separate taps
@@ -379,11 +383,9 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk) {
     TRY((blur_v<20, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKX])));
   }
   {
-    SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
-    s.s[0].p = c->diffy; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
-    TRY((blur_h<5, SrcPlain, 1>(c, s, t, c->blur[B_MASKY0])));
+    SrcPack<SrcPlain, 1> s; s.s[0].p = c->diffy;
     PostStore<1> post; post.out[0] = c->myb1;
-    TRY((blur_v<5, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKY0])));
+    TRY((blur2d<5, 1, SrcPlain, PostStore<1>>(c, s, post, c->blur[B_MASKY0])));
   }
   {
     SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
@@ -479,13 +481,11 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     KCHK(c);
   }
   {  // CalculateDiffmap second half: blur(sigma 1.725, border_ratio 1.0) + mix
-    SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
-    s.s[0].p = c->dsq; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
-    TRY((blur_h<3, SrcPlain, 1>(c, s, t, c->blur[B_FINAL])));
+    SrcPack<SrcPlain, 1> s; s.s[0].p = c->dsq;
     PostDiffmapMix post; post.d = c->dsq; post.out = c->distmap;
     HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
     BlockMaxOut bm{want_block_max ? c->d_block_max : nullptr, c->d_max_bits, c->bw};
-    TRY((blur_v<3, 1, PostDiffmapMix, true>(c, ct, post, c->blur[B_FINAL], bm)));
+    TRY((blur2d<3, 1, SrcPlain, PostDiffmapMix, true>(c, s, post, c->blur[B_FINAL], bm)));
   }
   return GZ_OK;
 }
@@ -1183,21 +1183,29 @@ int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, f
   TRY(setup_blur_cfg(c, &cfg, sigma, border_ratio));
   float* src = c->xyb[0];
   TRY(upload_planes(c, in, &src, 1));
-  SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
-  s.s[0].p = src; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+  SrcPack<SrcPlain, 1> s;
+  s.s[0].p = src;
   PostStore<1> post; post.out[0] = c->xyb[1];
   int rc = GZ_OK;
+  // the same kernels gz_compare uses for each radius: fused below 16, two passes from 16 up
+  PlanePack<1> t; CPlanePack<1> ct;
+  t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
 #define GZ_BLUR_CASE(R)                                                     \
+  case R:                                                                   \
+    rc = blur2d<R, 1, SrcPlain, PostStore<1>>(c, s, post, cfg);             \
+    break;
+#define GZ_BLUR_CASE2(R)                                                    \
   case R:                                                                   \
     rc = blur_h<R, SrcPlain, 1>(c, s, t, cfg);                              \
     if (rc == GZ_OK) rc = blur_v<R, 1, PostStore<1>>(c, ct, post, cfg);     \
     break;
   switch (cfg.r) {
     GZ_BLUR_CASE(2) GZ_BLUR_CASE(3) GZ_BLUR_CASE(4) GZ_BLUR_CASE(5) GZ_BLUR_CASE(8)
-    GZ_BLUR_CASE(16) GZ_BLUR_CASE(20) GZ_BLUR_CASE(23)
+    GZ_BLUR_CASE2(16) GZ_BLUR_CASE2(20) GZ_BLUR_CASE2(23)
     default: c->err = "unsupported blur radius"; rc = GZ_E_ARG;
   }
 #undef GZ_BLUR_CASE
+#undef GZ_BLUR_CASE2
   if (rc == GZ_OK) rc = download_plane(c, c->xyb[1], out);
   hipStreamSynchronize(c->stream);
   hipFree(cfg.d_scale);

@@ -20,6 +20,47 @@
 
 #define GZ_DEVFN __device__ __forceinline__
 
+// Load through a pointer that is known to point to device global memory (a pointer picked
+// from the kernel arguments with a run-time index is otherwise treated as generic, and the
+// load becomes a flat load).
+#ifdef GZ_EMU
+#define GZ_LDG(p, i) ((p)[i])
+#else
+#define GZ_LDG(p, i) (((const __attribute__((address_space(1))) float*)(p))[i])
+#endif
+
+// Four consecutive floats moved as one 16-byte access (global_load/store_dwordx4,
+// ds_read/write_b128): a dword per lane reaches about two thirds of the streaming rate of
+// 16 bytes per lane on gfx950 (tools/ubench/bw.hip).
+struct alignas(16) gz_f4 {
+  float v[4];
+};
+#ifdef GZ_EMU
+#define GZ_LDG4(p, i) (*reinterpret_cast<const gz_f4*>((p) + (i)))
+#else
+typedef float gz_vec4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ gz_f4 gz_f4_from(gz_vec4 x) {
+  gz_f4 r;
+  r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w;
+  return r;
+}
+#define GZ_LDG4(p, i)                                                          \
+  gz_f4_from(*reinterpret_cast<const __attribute__((address_space(1))) gz_vec4*>( \
+      (const __attribute__((address_space(1))) float*)(p) + (i)))
+#endif
+
+#ifdef GZ_EMU
+#define GZ_STG4(p, i, val) (*reinterpret_cast<gz_f4*>((p) + (i)) = (val))
+#else
+static __device__ __forceinline__ void gz_stg4(float* p, size_t i, const gz_f4& x) {
+  gz_vec4 t;
+  t.x = x.v[0]; t.y = x.v[1]; t.z = x.v[2]; t.w = x.v[3];
+  *reinterpret_cast<__attribute__((address_space(1))) gz_vec4*>(
+      (__attribute__((address_space(1))) float*)(p) + i) = t;
+}
+#define GZ_STG4(p, i, val) gz_stg4((p), (i), (val))
+#endif
+
 // A value that is the same in every lane of the wavefront (derived from threadIdx.x >> 6):
 // telling the compiler so turns the branches on it into scalar branches.
 #ifdef GZ_EMU

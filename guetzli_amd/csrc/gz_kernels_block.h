@@ -51,26 +51,33 @@ __global__ __launch_bounds__(256) void k_reconstruct(
     const int16_t* __restrict__ coeffs, int w, int h, int bw, int nb, int pitch,
     size_t pstride, const float* __restrict__ srgb_lut, float* __restrict__ lin,
     uint8_t* __restrict__ srgb) {
-  __shared__ int s_in[kBlocksPerWG][64];
-  __shared__ int s_col[kBlocksPerWG][64];
+  __shared__ int s_in[3][kBlocksPerWG][64];
+  __shared__ int s_col[3][kBlocksPerWG][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blk = blockIdx.x * kBlocksPerWG + wave;
   const bool live = blk < nb;
   const int iy = lane >> 3, ix = lane & 7;
   int px[3];
+  // the three components together: one memory latency and two barriers, not three and six
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    s_in[c][wave][lane] = live ? (int)coeffs[((size_t)c * nb + blk) * 64 + lane] : 0;
+  __syncthreads();
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
-    s_in[wave][lane] = live ? (int)coeffs[((size_t)c * nb + blk) * 64 + lane] : 0;
-    __syncthreads();
     // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
     int acc = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[wave][8 * u + ix];
-    s_col[wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
-    __syncthreads();
-    // row pass (:150-160): out = clamp((sum + (257 << 17)) >> 18)
-    acc = 0;
+    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[c][wave][8 * u + ix];
+    s_col[c][wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  }
+  __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[wave][8 * iy + u];
+  for (int c = 0; c < 3; ++c) {
+    // row pass (:150-160): out = clamp((sum + (257 << 17)) >> 18)
+    int acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[c][wave][8 * iy + u];
     px[c] = clamp255((acc + (257 << 17)) >> 18);
   }
   if (!live) return;

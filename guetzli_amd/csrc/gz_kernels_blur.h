@@ -33,17 +33,32 @@ struct BorderScale {
 // A source yields the input sample at flat index `idx` (= y*pitch + x).
 struct SrcPlain {
   const float* p;
-  GZ_DEVFN float operator()(size_t idx) const { return p[idx]; }
+  GZ_DEVFN float operator()(size_t idx) const { return GZ_LDG(p, idx); }
+  GZ_DEVFN gz_f4 load4(size_t idx) const { return GZ_LDG4(p, idx); }
 };
 struct SrcDiff {   // xyb - lf  (SeparateFrequencies, butteraugli.cc:512-517)
   const float* a;
   const float* b;
-  GZ_DEVFN float operator()(size_t idx) const { return a[idx] - b[idx]; }
+  GZ_DEVFN float operator()(size_t idx) const { return GZ_LDG(a, idx) - GZ_LDG(b, idx); }
+  GZ_DEVFN gz_f4 load4(size_t idx) const {
+    const gz_f4 u = GZ_LDG4(a, idx), v = GZ_LDG4(b, idx);
+    gz_f4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = u.v[i] - v.v[i];
+    return r;
+  }
 };
 struct SrcSameNoise {   // butteraugli.cc:631-641
   const float* a;
   const float* b;
-  GZ_DEVFN float operator()(size_t idx) const { return same_noise_pre(a[idx], b[idx]); }
+  GZ_DEVFN float operator()(size_t idx) const { return same_noise_pre(GZ_LDG(a, idx), GZ_LDG(b, idx)); }
+  GZ_DEVFN gz_f4 load4(size_t idx) const {
+    const gz_f4 u = GZ_LDG4(a, idx), v = GZ_LDG4(b, idx);
+    gz_f4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = same_noise_pre(u.v[i], v.v[i]);
+    return r;
+  }
 };
 template <class Src, int NC>
 struct SrcPack {
@@ -58,94 +73,104 @@ struct CPlanePack {
   const float* p[NC];
 };
 
-// Both passes work on a 64x64 output tile per workgroup of 256 threads and keep the taps'
-// inputs in REGISTERS: a thread produces 16 consecutive outputs along the blur axis from a
-// window of 16 + 2R staged samples, so each staged sample is read from LDS once per thread
-// (not once per tap).  The four waves of a workgroup take the four 16-output groups, so
-// whether an output is a border sample is the same for all lanes of a wave (a scalar
-// branch).  Arithmetic per output is unchanged: f32, ascending taps from 0.0f.
-constexpr int BT = 64;          // tile edge (outputs)
-constexpr int BPT = BT / 4;     // outputs per thread along the blur axis
-
-// One output of a window: interior = pre-scaled taps; border = raw taps, then one multiply.
-template <int R>
-GZ_DEVFN float blur_window_out(const float* win, int i, const Taps<R>& taps, bool border,
-                               float scale) {
-  float sum = 0.0f;
-  if (!border) {
-#pragma unroll
-    for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.ks[j];
-  } else {
-#pragma unroll
-    for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.k[j];
-    sum = sum * scale;
-  }
-  return sum;
-}
-
 // ------------------------------------------------------------------------ row pass --
-// grid = (ceil(w/64), ceil(h/64), NC).  The (64 rows) x (64 + 2R columns) input tile is
-// staged with coalesced row loads; lane = row, wave = column group, so a lane walks along
-// its row in LDS (odd pitch: conflict-free); the 64x64 results go back through LDS to be
-// stored as full 256-byte row segments.
-constexpr int HW = BT;
-constexpr int HH = BT;
+// grid = (ceil(w/HW), ceil(h/HH), NC); block = 256 threads; thread = one x, HH rows.
+constexpr int HW = 256;
+constexpr int HH = 4;
 
 template <int R, class Src, int NC>
 __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<NC> dst,
                                                 int w, int h, int pitch, Taps<R> taps,
                                                 BorderScale bs) {
-  constexpr int TW = BT + 2 * R;                      // staged columns
-  constexpr int P = (TW % 2 == 0) ? TW + 1 : TW;      // odd LDS pitch
-  __shared__ float tile[BT * P];
+  constexpr int RA = (R + 3) & ~3;      // halo rounded up to whole 16-byte vectors
+  constexpr int TP = HW + 2 * RA;       // staged columns (multiple of 4)
+  constexpr int OFF = RA - R;
+  __shared__ __attribute__((aligned(16))) float tile[HH][TP];
   const int c = blockIdx.z;
-  const Src s = src.s[c];
-  float* __restrict__ out = dst.p[c];
-  const int x0 = blockIdx.x * BT, y0 = blockIdx.y * BT;
+  // constant indices into the kernel arguments (a dynamic one would make the pointers generic)
+  Src s = src.s[0];
+  float* __restrict__ out = dst.p[0];
+#pragma unroll
+  for (int i = 1; i < NC; ++i)
+    if (c == i) {
+      s = src.s[i];
+      out = dst.p[i];
+    }
+  const int x0 = blockIdx.x * HW, y0 = blockIdx.y * HH;
   const int tid = threadIdx.x;
-  for (int i = tid; i < BT * TW; i += 256) {
-    const int ry = i / TW, rx = i - ry * TW;
+  // Interior tile (no border column, every staged sample inside the image, rows 16-byte
+  // aligned): staged with aligned 16-byte loads; every thread produces 4 consecutive outputs
+  // of one row from a register window of the staged samples -- each sample is read from LDS
+  // once per thread instead of once per tap -- and stores them as one 16-byte vector.  Same
+  // arithmetic per output: ascending taps from 0.0f.
+  if (x0 >= RA && x0 + HW + RA <= w && y0 + HH <= h && (pitch & 3) == 0) {
+    constexpr int NV = HH * (TP / 4);
+#pragma unroll
+    for (int k = 0; k < (NV + 255) / 256; ++k) {
+      const int i = 256 * k + tid;
+      if (256 * k + 255 < NV || i < NV) {
+        const int ry = i / (TP / 4), q = i - ry * (TP / 4);
+        const gz_f4 v = s.load4((size_t)(y0 + ry) * pitch + (x0 - RA + 4 * q));
+        *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = v;
+      }
+    }
+    __syncthreads();
+    const int ry = tid >> 6, xq = (tid & 63) * 4;
+    float win[4 + 2 * RA];
+#pragma unroll
+    for (int i = 0; i < (4 + 2 * RA) / 4; ++i) {
+      const gz_f4 v = *reinterpret_cast<const gz_f4*>(&tile[ry][xq + 4 * i]);
+      win[4 * i] = v.v[0]; win[4 * i + 1] = v.v[1]; win[4 * i + 2] = v.v[2]; win[4 * i + 3] = v.v[3];
+    }
+    gz_f4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int j = 0; j <= 2 * R; ++j) sum += win[OFF + i + j] * taps.ks[j];
+      o.v[i] = sum;
+    }
+    GZ_STG4(out, (size_t)(y0 + ry) * pitch + x0 + xq, o);
+    return;
+  }
+  // generic tile: rows y0..y0+HH-1, columns x0-R .. x0+HW+R-1 (zero outside the image)
+  for (int i = tid; i < HH * (HW + 2 * R); i += 256) {
+    const int ry = i / (HW + 2 * R), rx = i - ry * (HW + 2 * R);
     const int x = x0 - R + rx, y = y0 + ry;
     float v = 0.0f;
     if (x >= 0 && x < w && y < h) v = s((size_t)y * pitch + x);
-    tile[ry * P + rx] = v;
+    tile[ry][rx] = v;
   }
   __syncthreads();
-  const int r = tid & 63;
-  const int g = GZ_WAVE_UNIFORM(tid >> 6);
-  float win[BPT + 2 * R];
+  const int x = x0 + tid;
+  if (x >= w) return;
+  const bool border = x < R || x >= w - R;
+  float scale = 1.0f;
+  if (border) scale = x < R ? bs.lo[x] : bs.hi[w - 1 - x];
 #pragma unroll
-  for (int i = 0; i < BPT + 2 * R; ++i) win[i] = tile[r * P + g * BPT + i];
-  __syncthreads();   // every window is in registers: the tile can take the results
-  constexpr int PO = BT + 1;
-#pragma unroll
-  for (int i = 0; i < BPT; ++i) {
-    const int x = x0 + g * BPT + i;   // wave-uniform
+  for (int ry = 0; ry < HH; ++ry) {
+    const int y = y0 + ry;
+    if (y >= h) break;
     float sum = 0.0f;
-    if (x < w) {
-      const bool border = x < R || x >= w - R;
-      float scale = 1.0f;
-      if (border) scale = x < R ? bs.lo[x] : bs.hi[w - 1 - x];
-      sum = blur_window_out<R>(win, i, taps, border, scale);
+    if (!border) {
+#pragma unroll
+      for (int j = 0; j <= 2 * R; ++j) sum += tile[ry][tid + j] * taps.ks[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j <= 2 * R; ++j) sum += tile[ry][tid + j] * taps.k[j];
+      sum = sum * scale;
     }
-    tile[r * PO + g * BPT + i] = sum;
-  }
-  __syncthreads();
-  for (int i = tid; i < BT * BT; i += 256) {
-    const int ry = i >> 6, rx = i & 63;
-    const int x = x0 + rx, y = y0 + ry;
-    if (x < w && y < h) out[(size_t)y * pitch + x] = tile[ry * PO + rx];
+    out[(size_t)y * pitch + x] = sum;
   }
 }
 
 // --------------------------------------------------------------------- column pass --
-// grid = (ceil(w/VW), ceil(h/VH)); block = 256 = 64 columns x 4 row groups (one per wave);
-// each thread produces VPT outputs of its column for every one of the NC planes, then hands
-// the NC blurred values of each pixel to the Post functor (which may read/write other
-// planes).
-constexpr int VW = BT;
-constexpr int VH = BT;
-constexpr int VPT = BPT;   // outputs per thread
+// grid = (ceil(w/VW), ceil(h/VH)); block = 256 = 64 columns x 4 row groups; each thread
+// produces VH/4 outputs of its column for every one of the NC planes, then hands the NC
+// blurred values of each pixel to the Post functor (which may read/write other planes).
+constexpr int VW = 64;
+constexpr int VH = 64;
+constexpr int VPT = VH / 4;   // outputs per thread
 
 // With BM = true the values returned by the Post functor are additionally reduced to the
 // per-8x8-block maxima of the tile (the tile origin is 8-aligned) and to one atomicMax per
@@ -163,39 +188,249 @@ template <int R, int NC, class Post, bool BM>
 __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, int w, int h,
                                                 int pitch, Taps<R> taps, BorderScale bs,
                                                 BlockMaxOut bm) {
-  __shared__ float tile[VH + 2 * R][VW];
-  const int tx = threadIdx.x & 63;
-  const int tg = GZ_WAVE_UNIFORM(threadIdx.x >> 6);
+  __shared__ __attribute__((aligned(16))) float tile[VH + 2 * R][VW];
+  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int x0 = blockIdx.x * VW, y0 = blockIdx.y * VH;
   const int x = x0 + tx;
+  // staging with one aligned 16-byte load per lane when the tile's columns are all inside
+  // the image and rows are 16-byte aligned (rows outside the image are zero)
+  const bool vec = x0 + VW <= w && (pitch & 3) == 0;
+  const int vq = (threadIdx.x & 15) * 4, vr = threadIdx.x >> 4;
   float acc[NC][VPT];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float* __restrict__ in = src.p[c];
     if (c > 0) __syncthreads();
-    for (int ry = tg; ry < VH + 2 * R; ry += 4) {
-      const int y = y0 - R + ry;
-      float v = 0.0f;
-      if (x < w && y >= 0 && y < h) v = in[(size_t)y * pitch + x];
-      tile[ry][tx] = v;
+    if (vec) {
+#pragma unroll
+      for (int k = 0; k < (VH + 2 * R + 15) / 16; ++k) {
+        const int ry = vr + 16 * k;
+        if ((k + 1) * 16 <= VH + 2 * R || ry < VH + 2 * R) {
+          const int y = y0 - R + ry;
+          gz_f4 v;
+          v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
+          if (y >= 0 && y < h) v = GZ_LDG4(in, (size_t)y * pitch + x0 + vq);
+          *reinterpret_cast<gz_f4*>(&tile[ry][vq]) = v;
+        }
+      }
+    } else {
+      for (int ry = tg; ry < VH + 2 * R; ry += 4) {
+        const int y = y0 - R + ry;
+        float v = 0.0f;
+        if (x < w && y >= 0 && y < h) v = in[(size_t)y * pitch + x];
+        tile[ry][tx] = v;
+      }
     }
     __syncthreads();
-    float win[VPT + 2 * R];
-#pragma unroll
-    for (int i = 0; i < VPT + 2 * R; ++i) win[i] = tile[tg * VPT + i][tx];
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int y = y0 + tg * VPT + i;   // wave-uniform
+      const int ly = tg * VPT + i;   // local output row
+      const int y = y0 + ly;
       float sum = 0.0f;
       if (y < h) {
         const bool border = y < R || y >= h - R;
-        float scale = 1.0f;
-        if (border) scale = y < R ? bs.lo[y] : bs.hi[h - 1 - y];
-        sum = blur_window_out<R>(win, i, taps, border, scale);
+        if (!border) {
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.ks[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.k[j];
+          sum = sum * (y < R ? bs.lo[y] : bs.hi[h - 1 - y]);
+        }
       }
       acc[c][i] = sum;
     }
   }
+  float res[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int y = y0 + tg * VPT + i;
+    res[i] = 0.0f;
+    if (x < w && y < h) {
+      float v[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[c] = acc[c][i];
+      res[i] = post((size_t)y * pitch + x, v);
+    }
+  }
+  if (BM) {
+    __shared__ float s_bmax[64];
+    __syncthreads();   // all column reads of the last plane are done
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) tile[tg * VPT + i][tx] = res[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int bxl = threadIdx.x & 7, byl = threadIdx.x >> 3;
+      float m = 0.0f;
+      for (int yy = 0; yy < 8; ++yy)
+        for (int xx = 0; xx < 8; ++xx) {
+          const float t = tile[8 * byl + yy][8 * bxl + xx];
+          m = t > m ? t : m;
+        }
+      s_bmax[threadIdx.x] = m;
+      const int gbx = x0 / 8 + bxl, gby = y0 / 8 + byl;
+      if (bm.block_max && 8 * gbx < w && 8 * gby < h) bm.block_max[gby * bm.bw + gbx] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.0f;
+      for (int i = 0; i < 64; ++i) m = s_bmax[i] > m ? s_bmax[i] : m;
+      atomicMax(bm.image_max_bits, __float_as_uint(m));
+    }
+  }
+}
+
+// ------------------------------------------------------ fused row + column pass (2-D) --
+// Blur = Convolution along x, then along y (butteraugli.cc:229-233), for one 64x64 output
+// tile per workgroup without the intermediate plane ever leaving the chip:
+//   1. the (64 + 2R) x (64 + 2RA) input tile (RA = R rounded up to 4, so that every row is
+//      staged with aligned 16-byte loads) goes to LDS, with the source functor applied;
+//   2. row pass, in place: a thread takes 4 consecutive outputs of a row from a register
+//      window of the staged samples and writes them over the row's first 64 columns (a row is
+//      only ever touched by lanes of one wave, whose loads precede its stores);
+//   3. column pass from LDS: lane = column, 16 consecutive rows per thread from a register
+//      window of 16 + 2R row-pass results; the NC blurred values of each pixel go to the Post
+//      functor.
+// Each output is computed with exactly the operations of the separate passes: f32, taps in
+// ascending order from 0.0f; interior samples use the pre-scaled taps, border samples the raw
+// taps and one multiply by the host-computed scale.  Tiles that touch the image border
+// region (or images whose row pitch is not a multiple of 4) take a generic path with
+// per-output border handling.  Compared with two passes this saves writing and re-reading
+// the intermediate plane (2 of 4 plane passes per blur) at the price of (64+2R)/64 x the row
+// pass arithmetic.
+constexpr int T2 = 64;   // tile edge
+
+template <int R, int NC, class Src, class Post, bool BM>
+__global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post, int w, int h,
+                                                int pitch, Taps<R> taps, BorderScale bsx,
+                                                BorderScale bsy, BlockMaxOut bm) {
+  constexpr int RA = (R + 3) & ~3;
+  constexpr int IW = T2 + 2 * RA;   // staged columns, multiple of 4
+  constexpr int IH = T2 + 2 * R;    // staged rows
+  constexpr int OFF = RA - R;       // window offset inside the aligned row
+  __shared__ __attribute__((aligned(16))) float tile[IH][IW];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * T2, y0 = blockIdx.y * T2;
+  const bool interior = x0 >= RA && x0 + T2 + RA <= w && y0 >= R && y0 + T2 + R <= h &&
+                        (pitch & 3) == 0;
+  const int tx = tid & 63, tg = tid >> 6;   // column pass: lane = column, wave = row group
+  const int hq = (tid & 15) * 4, hr = tid >> 4;   // row pass: 4 columns, rows hr + 16k
+  float acc[NC][VPT];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const Src s = src.s[c];
+    if (c > 0) __syncthreads();   // the column pass of the previous plane is done with the tile
+    if (interior) {
+      // ---- stage: aligned 16-byte loads, all of a thread's loads in flight before the
+      // first LDS store (compile-time trip counts: the loads are issued back to back)
+      constexpr int NV = IH * (IW / 4);            // 16-byte vectors in the tile
+      constexpr int SB = 8;                        // vectors per thread per batch
+#pragma unroll
+      for (int b0 = 0; b0 < NV; b0 += 256 * SB) {
+        gz_f4 buf[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+          const int i = b0 + 256 * k + tid;
+          if (b0 + 256 * k + 255 < NV || i < NV) {
+            const int ry = i / (IW / 4), q = i - ry * (IW / 4);
+            buf[k] = s.load4((size_t)(y0 - R + ry) * pitch + (x0 - RA + 4 * q));
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+          const int i = b0 + 256 * k + tid;
+          if (b0 + 256 * k + 255 < NV || i < NV) {
+            const int ry = i / (IW / 4), q = i - ry * (IW / 4);
+            *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = buf[k];
+          }
+        }
+      }
+      __syncthreads();
+      // ---- row pass (pre-scaled taps)
+#pragma unroll 1
+      for (int ry = hr; ry < IH; ry += 16) {
+        float win[4 + 2 * RA];
+#pragma unroll
+        for (int i = 0; i < (4 + 2 * RA) / 4; ++i) {
+          const gz_f4 v = *reinterpret_cast<const gz_f4*>(&tile[ry][hq + 4 * i]);
+          win[4 * i] = v.v[0]; win[4 * i + 1] = v.v[1]; win[4 * i + 2] = v.v[2]; win[4 * i + 3] = v.v[3];
+        }
+        gz_f4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float sum = 0.0f;
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) sum += win[OFF + i + j] * taps.ks[j];
+          o.v[i] = sum;
+        }
+        *reinterpret_cast<gz_f4*>(&tile[ry][hq]) = o;
+      }
+      __syncthreads();
+      // ---- column pass (pre-scaled taps)
+      float win[VPT + 2 * R];
+#pragma unroll
+      for (int i = 0; i < VPT + 2 * R; ++i) win[i] = tile[tg * VPT + i][tx];
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.ks[j];
+        acc[c][i] = sum;
+      }
+    } else {
+      // ---- generic tile: zero outside the image, per-output border handling
+      for (int i = tid; i < IH * IW; i += 256) {
+        const int ry = i / IW, rx = i - ry * IW;
+        const int x = x0 - RA + rx, y = y0 - R + ry;
+        float v = 0.0f;
+        if (x >= 0 && x < w && y >= 0 && y < h) v = s((size_t)y * pitch + x);
+        tile[ry][rx] = v;
+      }
+      __syncthreads();
+      for (int ry = hr; ry < IH; ry += 16) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int x = x0 + hq + i;
+          float sum = 0.0f;
+          if (x < w) {
+            const bool border = x < R || x >= w - R;
+            if (!border) {
+#pragma unroll
+              for (int j = 0; j <= 2 * R; ++j) sum += tile[ry][hq + OFF + i + j] * taps.ks[j];
+            } else {
+#pragma unroll
+              for (int j = 0; j <= 2 * R; ++j) sum += tile[ry][hq + OFF + i + j] * taps.k[j];
+              sum = sum * (x < R ? bsx.lo[x] : bsx.hi[w - 1 - x]);
+            }
+          }
+          o[i] = sum;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[ry][hq + i] = o[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) {
+        const int ly = tg * VPT + i;
+        const int y = y0 + ly;
+        float sum = 0.0f;
+        if (y < h) {
+          const bool border = y < R || y >= h - R;
+          if (!border) {
+#pragma unroll
+            for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.ks[j];
+          } else {
+#pragma unroll
+            for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.k[j];
+            sum = sum * (y < R ? bsy.lo[y] : bsy.hi[h - 1 - y]);
+          }
+        }
+        acc[c][i] = sum;
+      }
+    }
+  }
+  const int x = x0 + tx;
   float res[VPT];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {

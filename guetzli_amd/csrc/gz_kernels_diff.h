@@ -20,10 +20,21 @@ struct MaskIn {
   const float* hf;
   double a, b;
   int plain;          // 1: value = hf[idx] unchanged
+  GZ_DEVFN float mix(float u, float v) const {   // u = uhf sample (unused when uhf == null)
+    if (plain) return v;
+    if (uhf == nullptr) return (float)(b * (double)v);
+    return (float)(a * (double)u + b * (double)v);
+  }
   GZ_DEVFN float operator()(size_t idx) const {
-    if (plain) return hf[idx];
-    if (uhf == nullptr) return (float)(b * (double)hf[idx]);
-    return (float)(a * (double)uhf[idx] + b * (double)hf[idx]);
+    return mix(uhf ? GZ_LDG(uhf, idx) : 0.0f, GZ_LDG(hf, idx));
+  }
+  GZ_DEVFN gz_f4 load4(size_t idx) const {
+    const gz_f4 v = GZ_LDG4(hf, idx);
+    gz_f4 u = v, r;
+    if (uhf) u = GZ_LDG4(uhf, idx);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = mix(u.v[i], v.v[i]);
+    return r;
   }
 };
 struct MaskPrePack {
@@ -32,17 +43,38 @@ struct MaskPrePack {
   float* out[2];
 };
 
-// grid = (ceil(w/256), h, 2)
+// grid = (ceil(w/1024), h, 2): a thread takes 4 consecutive pixels of a row -- 16-byte
+// loads of the row and of the row below, one 16-byte store -- when the row pitch allows it.
 __global__ __launch_bounds__(256) void k_mask_pre(MaskPrePack pk, int w, int h, int pitch) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
+  const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
   if (x >= w || y >= h) return;
+  const int c = blockIdx.z;
+  MaskIn a = pk.in0[0], b = pk.in1[0];
+  float* out = pk.out[0];
+  if (c == 1) { a = pk.in0[1]; b = pk.in1[1]; out = pk.out[1]; }
   // mirrored neighbour at the last column / row (butteraugli.cc:1706-1725)
-  const int x2 = x + 1 < w ? x + 1 : (x > 0 ? x - 1 : x);
   const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
-  const size_t i = (size_t)y * pitch + x, ir = (size_t)y * pitch + x2,
-               id = (size_t)y2 * pitch + x;
-  const MaskIn a = pk.in0[c], b = pk.in1[c];
-  pk.out[c][i] = diff_precompute_px(a(i), a(ir), a(id), b(i), b(ir), b(id));
+  if ((pitch & 3) == 0 && x + 3 < w) {
+    const size_t i = (size_t)y * pitch + x, id = (size_t)y2 * pitch + x;
+    const gz_f4 a0 = a.load4(i), ad = a.load4(id), b0 = b.load4(i), bd = b.load4(id);
+    // right neighbour of the 4th pixel: the next column, or mirrored at the last column
+    const int xr = x + 4 < w ? x + 4 : x + 2;
+    const float ar = a((size_t)y * pitch + xr), br = b((size_t)y * pitch + xr);
+    gz_f4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o.v[k] = diff_precompute_px(a0.v[k], k < 3 ? a0.v[k < 3 ? k + 1 : 3] : ar, ad.v[k], b0.v[k],
+                                  k < 3 ? b0.v[k < 3 ? k + 1 : 3] : br, bd.v[k]);
+    GZ_STG4(out, i, o);
+    return;
+  }
+  for (int k = 0; k < 4 && x + k < w; ++k) {
+    const int xx = x + k;
+    const int x2 = xx + 1 < w ? xx + 1 : (xx > 0 ? xx - 1 : xx);
+    const size_t i = (size_t)y * pitch + xx, ir = (size_t)y * pitch + x2,
+                 id = (size_t)y2 * pitch + xx;
+    out[i] = diff_precompute_px(a(i), a(ir), a(id), b(i), b(ir), b(id));
+  }
 }
 
 // ---------------------------------------------------------------------------- Malta --

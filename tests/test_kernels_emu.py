@@ -36,12 +36,15 @@ def test_encode_quantize_reconstruct(L, wh):
     pc.case_encode_quantize_reconstruct(L, *wh, x0=100, y0=50)
 
 
-@pytest.mark.parametrize("wh", [(70, 67), (300, 9), (33, 130)])
+# (256, 200) and (200, 160) have tiles that take the interior (vector-load, register-window)
+# path of k_blur2d for every radius; (258, 200): pitch not a multiple of 4 -> generic path
+# (600, 70): tiles on the interior path of k_blur_h (radius >= 16)
+@pytest.mark.parametrize("wh", [(70, 67), (300, 9), (33, 130), (256, 200), (258, 200), (600, 70)])
 def test_blur(L, wh):
     pc.case_blur(L, *wh)
 
 
-@pytest.mark.parametrize("wh", [(72, 48), (35, 41)])
+@pytest.mark.parametrize("wh", [(72, 48), (35, 41), (200, 160)])
 def test_stages(L, wh):
     pc.case_stages(L, *wh)
 

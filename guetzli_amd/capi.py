@@ -45,6 +45,10 @@ SIGNATURES = {
     "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
     "gz_order_build": (_I, [_P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P]),
+    "gz_order_reset": (_I, [_P]),
+    "gz_order_build_auto": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float, _P, _P, _P]),
+    "gz_order_advance": (_I, [_P, C.c_float, _I]),
+    "gz_apply_coeff_edits": (_I, [_P, _P, _P, _I]),
     "gz_order_upload": (_I, [_P, _P, C.c_uint64]),
     "gz_order_partition": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
     "gz_order_fetch": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
@@ -283,6 +287,30 @@ class Context:
                                             int(limit is not None), float(limit or 0.0),
                                             _ptr(total), _ptr(btc), _ptr(below)))
         return int(total[0]), int(btc[0]), int(below[0])
+
+    def order_reset(self):
+        self._chk(self.L.lib.gz_order_reset(self.handle))
+
+    def order_build_auto(self, direction, max_block_dist, target_mul, use_distmap, next_cand,
+                         limit=None):
+        nc = np.ascontiguousarray(next_cand, np.int32)
+        assert nc.size == self.nb
+        total, below = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        btc = np.zeros(1, np.int32)
+        self._chk(self.L.lib.gz_order_build_auto(self.handle, direction, max_block_dist,
+                                                 target_mul, int(use_distmap), _ptr(nc),
+                                                 int(limit is not None), float(limit or 0.0),
+                                                 _ptr(total), _ptr(btc), _ptr(below)))
+        return int(total[0]), int(btc[0]), int(below[0])
+
+    def order_advance(self, val_threshold, direction):
+        self._chk(self.L.lib.gz_order_advance(self.handle, float(val_threshold), direction))
+
+    def apply_coeff_edits(self, pos, val):
+        p = np.ascontiguousarray(pos, np.int32)
+        v = np.ascontiguousarray(val, np.int16)
+        assert p.size == v.size
+        self._chk(self.L.lib.gz_apply_coeff_edits(self.handle, _ptr(p), _ptr(v), p.size))
 
     def order_upload(self, entries):
         e = np.ascontiguousarray(entries, self.ORDER_DTYPE)

@@ -210,6 +210,8 @@ struct gz_ctx {
   unsigned* d_order_counters = nullptr;                           // [2]
   int* d_next_cand = nullptr; float* d_weight = nullptr; float* d_max_err = nullptr;   // [nb]
   bool have_search = false;
+  unsigned char* d_wflag = nullptr;                               // [nb]
+  int* d_edit_pos = nullptr; short* d_edit_val = nullptr; size_t edit_cap = 0;
 
   bool have_orig = false, have_cand = false, have_distmap = false;
   std::vector<float> h_block_max;
@@ -759,7 +761,7 @@ void gz_destroy(gz_ctx* c) {
   hipFree(c->d_order); hipFree(c->d_pos_l); hipFree(c->d_pos_r); hipFree(c->d_chunk);
   hipFree(c->d_part); hipFree(c->d_order_nb); hipFree(c->d_order_off);
   hipFree(c->d_order_counters); hipFree(c->d_next_cand); hipFree(c->d_weight);
-  hipFree(c->d_max_err);
+  hipFree(c->d_max_err); hipFree(c->d_wflag); hipFree(c->d_edit_pos); hipFree(c->d_edit_val);
   for (int b = 0; b < B_COUNT; ++b) hipFree(c->blur[b].d_scale);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
@@ -955,25 +957,24 @@ static int ensure_order_capacity(gz_ctx* c, size_t n) {
   return GZ_OK;
 }
 
-int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
-                   const float* max_block_error, const float* block_weight, int count_below,
-                   float limit, uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
-  if (!c || !next_cand || !max_block_error || !block_weight || !total || !blocks_to_change ||
-      (direction != 1 && direction != -1) || (count_below && !below))
-    return GZ_E_ARG;
-  if (!c->have_search) { c->err = "gz_block_zeroing_orders must precede gz_order_build"; return GZ_E_STATE; }
+static int ensure_order_block_arrays(gz_ctx* c) {
+  if (c->d_order_nb) return GZ_OK;
   const int nb = c->nb;
-  if (!c->d_order_nb) {
-    HIPCHK(c, hipMalloc((void**)&c->d_order_nb, sizeof(unsigned) * nb));
-    HIPCHK(c, hipMalloc((void**)&c->d_order_off, sizeof(unsigned long long) * (nb + 1)));
-    HIPCHK(c, hipMalloc((void**)&c->d_next_cand, sizeof(int) * nb));
-    HIPCHK(c, hipMalloc((void**)&c->d_weight, sizeof(float) * nb));
-    HIPCHK(c, hipMalloc((void**)&c->d_max_err, sizeof(float) * nb));
-  }
+  HIPCHK(c, hipMalloc((void**)&c->d_order_nb, sizeof(unsigned) * nb));
+  HIPCHK(c, hipMalloc((void**)&c->d_order_off, sizeof(unsigned long long) * (nb + 1)));
+  HIPCHK(c, hipMalloc((void**)&c->d_next_cand, sizeof(int) * nb));
+  HIPCHK(c, hipMalloc((void**)&c->d_weight, sizeof(float) * nb));
+  HIPCHK(c, hipMalloc((void**)&c->d_max_err, sizeof(float) * nb));
+  HIPCHK(c, hipMalloc((void**)&c->d_wflag, nb));
+  HIPCHK(c, hipMemsetAsync(c->d_max_err, 0, sizeof(float) * nb, c->stream));
+  return GZ_OK;
+}
+
+// d_next_cand / d_weight / d_max_err are in place: sizes, offsets, entries, counters.
+static int order_build_device(gz_ctx* c, int direction, int count_below, float limit,
+                              uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  const int nb = c->nb;
   TRY(ensure_order_capacity(c, 0));
-  HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_weight, block_weight, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_max_err, max_block_error, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_order_counters, 0, sizeof(unsigned) * 2, c->stream));
   GZ_LAUNCH(k_order_sizes, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
             (const int*)c->d_out_cnt, (const int*)c->d_next_cand, (const float*)c->d_weight,
@@ -1000,6 +1001,83 @@ int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
   *total = n;
   *blocks_to_change = (int32_t)counters[0];
   if (below) *below = counters[1];
+  return GZ_OK;
+}
+
+int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
+                   const float* max_block_error, const float* block_weight, int count_below,
+                   float limit, uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  if (!c || !next_cand || !max_block_error || !block_weight || !total || !blocks_to_change ||
+      (direction != 1 && direction != -1) || (count_below && !below))
+    return GZ_E_ARG;
+  if (!c->have_search) { c->err = "gz_block_zeroing_orders must precede gz_order_build"; return GZ_E_STATE; }
+  const int nb = c->nb;
+  TRY(ensure_order_block_arrays(c));
+  HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_weight, block_weight, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_max_err, max_block_error, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
+  return order_build_device(c, direction, count_below, limit, total, blocks_to_change, below);
+}
+
+int gz_order_reset(gz_ctx* c) {
+  if (!c) return GZ_E_ARG;
+  TRY(ensure_order_block_arrays(c));
+  HIPCHK(c, hipMemsetAsync(c->d_max_err, 0, sizeof(float) * c->nb, c->stream));
+  return GZ_OK;
+}
+
+int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double target_mul,
+                        int use_distmap, const int32_t* next_cand, int count_below, float limit,
+                        uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  if (!c || !next_cand || !total || !blocks_to_change || (direction != 1 && direction != -1) ||
+      max_block_dist < 0 || (count_below && !below))
+    return GZ_E_ARG;
+  if (!c->have_search) { c->err = "gz_block_zeroing_orders must precede gz_order_build_auto"; return GZ_E_STATE; }
+  if (use_distmap && !c->have_distmap) { c->err = "no distance map yet"; return GZ_E_STATE; }
+  const int nb = c->nb;
+  TRY(ensure_order_block_arrays(c));
+  HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
+  const int bw = c->bw, bh = c->bh;
+  const float target = c->target;
+  GZ_LAUNCH(k_weights_flag, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
+            (const float*)c->d_block_max, use_distmap ? 1 : 0, bw, bh, target, target_mul,
+            direction, max_block_dist, c->d_wflag);
+  KCHK(c);
+  GZ_LAUNCH(k_weights_gather, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
+            (const unsigned char*)c->d_wflag, bw, bh, direction, max_block_dist, c->d_weight);
+  KCHK(c);
+  return order_build_device(c, direction, count_below, limit, total, blocks_to_change, below);
+}
+
+int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
+  if (!c || (direction != 1 && direction != -1)) return GZ_E_ARG;
+  if (!c->d_weight) { c->err = "gz_order_build_auto must precede gz_order_advance"; return GZ_E_STATE; }
+  GZ_LAUNCH(k_order_advance, dim3(gz_div_up(c->nb, 256)), dim3(256), c->stream, c->d_max_err,
+            (const float*)c->d_weight, val_threshold, direction, c->nb);
+  KCHK(c);
+  return GZ_OK;
+}
+
+int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int n) {
+  if (!c || n < 0 || (n > 0 && (!pos || !val))) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  if (n == 0) return GZ_OK;
+  const int limit = 3 * c->nb * 64;
+  for (int i = 0; i < n; ++i)
+    if (pos[i] < 0 || pos[i] >= limit) return GZ_E_ARG;
+  if ((size_t)n > c->edit_cap) {
+    (void)hipFree(c->d_edit_pos); (void)hipFree(c->d_edit_val);
+    c->d_edit_pos = nullptr; c->d_edit_val = nullptr;
+    c->edit_cap = (size_t)n + (size_t)n / 2 + 4096;
+    HIPCHK(c, hipMalloc((void**)&c->d_edit_pos, sizeof(int) * c->edit_cap));
+    HIPCHK(c, hipMalloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_edit_pos, pos, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_edit_val, val, sizeof(short) * n, hipMemcpyHostToDevice, c->stream));
+  GZ_LAUNCH(k_apply_coeff_edits, dim3(gz_div_up(n, 256)), dim3(256), c->stream,
+            (const int*)c->d_edit_pos, (const short*)c->d_edit_val, n, c->d_cand);
+  KCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
   return GZ_OK;
 }
 

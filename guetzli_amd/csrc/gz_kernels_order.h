@@ -89,6 +89,85 @@ __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ er
   if (count_below && below) atomicAdd(&counters[1], below);
 }
 
+// ------------------------------------------------ block weights on the device (a19) --
+// ComputeBlockErrorAdjustmentWeights (butteraugli_comparator.cc:521-557) from the per-block
+// maxima of the distance map, as two gather passes (the reference scatters 1/(d+1) around
+// every block that exceeds its local limit; the maximum a block receives is 1/(dmin+1) for
+// the nearest such block within max_block_dist, since 1/(d+1) decreases with d).
+//   pass 1: flag[b] = direction > 0 ? (bmax <= td && local <= 1.1 td)
+//                                   : (bmax > 0.5 td + 0.5 local),   local = max(td_f, nbhd max)
+//   pass 2: weight[b] = direction > 0 ? flag : 1/(dmin+1) or 0
+// td = target * target_mul in double, td_f = (float)td; comparisons promote as the reference
+// does.  use_bmax == 0: the distance map is all zero (first "up" iteration, processor.cc:627).
+__global__ __launch_bounds__(256) void k_weights_flag(const float* __restrict__ bmax, int use_bmax,
+                                                      int bw, int bh, float target,
+                                                      double target_mul, int direction, int r,
+                                                      unsigned char* __restrict__ flag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bw * bh) return;
+  const int bx = b % bw, by = b / bw;
+  const double td = target * target_mul;
+  float local = static_cast<float>(td);
+  const int x0 = bx - r > 0 ? bx - r : 0, y0 = by - r > 0 ? by - r : 0;
+  const int x1 = bx + 1 + r < bw ? bx + 1 + r : bw, y1 = by + 1 + r < bh ? by + 1 + r : bh;
+  if (use_bmax)
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        const float v = bmax[y * bw + x];
+        local = v > local ? v : local;   // std::max(local, v)
+      }
+  const float own = use_bmax ? bmax[b] : 0.0f;
+  bool f;
+  if (direction > 0) {
+    f = (double)own <= td && (double)local <= 1.1 * td;
+  } else {
+    const double kLocalMaxWeight = 0.5;
+    f = !((double)own <= (1 - kLocalMaxWeight) * td + kLocalMaxWeight * (double)local);
+  }
+  flag[b] = f ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __restrict__ flag,
+                                                        int bw, int bh, int direction, int r,
+                                                        float* __restrict__ weight) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bw * bh) return;
+  if (direction > 0) {
+    weight[b] = flag[b] ? 1.0f : 0.0f;
+    return;
+  }
+  const int bx = b % bw, by = b / bw;
+  const int x0 = bx - r > 0 ? bx - r : 0, y0 = by - r > 0 ? by - r : 0;
+  const int x1 = bx + 1 + r < bw ? bx + 1 + r : bw, y1 = by + 1 + r < bh ? by + 1 + r : bh;
+  int dmin = r + 1;
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x)
+      if (flag[y * bw + x]) {
+        const int dy = y > by ? y - by : by - y, dx = x > bx ? x - bx : bx - x;
+        const int d = dy > dx ? dy : dx;
+        dmin = d < dmin ? d : dmin;
+      }
+  weight[b] = dmin <= r ? 1.0f / (dmin + 1.0f) : 0.0f;
+}
+
+// max_block_error[i] += block_weight[i] * val_threshold * direction  (processor.cc:754-756)
+__global__ __launch_bounds__(256) void k_order_advance(float* __restrict__ max_err,
+                                                       const float* __restrict__ weight,
+                                                       float val_threshold, int direction, int nb) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  max_err[b] += weight[b] * val_threshold * direction;
+}
+
+// OutputImageComponent::SetCoeffBlock for single coefficients: coeffs[pos[i]] = val[i]
+// (positions distinct).
+__global__ __launch_bounds__(256) void k_apply_coeff_edits(const int* __restrict__ pos,
+                                                           const short* __restrict__ val, int n,
+                                                           short* __restrict__ coeffs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) coeffs[pos[i]] = val[i];
+}
+
 // -------------------------------------------------------------- one introsort partition --
 struct PartScalars {
   unsigned m;      // number of swapped pairs

@@ -452,13 +452,14 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
                         (int)EntropyDataSize(ac_histo, ac_depths.data());
   int prev_size = base_size;
 
-  std::vector<float> max_block_error(nb, 0.0f);
+  rc = gz_order_reset(ctx_);           // max_block_error := 0, kept on the device
+  if (rc != GZ_OK) return Fail("gz_order_reset", rc);
   std::vector<int> next_cand(nb, 0);   // last_indexes
-  std::vector<float> weight(nb);
+  std::vector<int32_t> edit_pos;       // coefficient changes of one iteration
+  std::vector<int16_t> edit_val;
   std::vector<std::pair<int, float> > order;   // host copy of the ranges that were fetched
   std::vector<char> touched(nb);
   std::vector<int32_t> dirty;
-  std::vector<int16_t> dirty_blocks;
   std::vector<int> step_count(nb);
   bool first_up = true;
   const size_t comp_stride = (size_t)nb * 64;
@@ -474,15 +475,13 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       uint64_t total = 0, below = 0;
       const float below_limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
       for (int radius = 1; radius <= 4; ++radius) {
-        std::fill(weight.begin(), weight.end(), 0.0f);
-        pw.lap();
-        rc = gz_block_weights(ctx_, direction, radius, target_mul, first_up ? 0 : 1, weight.data());
-        t_pb_weights_ += pw.lap();
-        if (rc != GZ_OK) return Fail("gz_block_weights", rc);
+        // block weights (ComputeBlockErrorAdjustmentWeights) and max_block_error stay on the
+        // device; the host only supplies how far each block has advanced
         int32_t btc = 0;
-        rc = gz_order_build(ctx_, direction, next_cand.data(), max_block_error.data(), weight.data(),
-                            first_up ? 1 : 0, below_limit, &total, &btc, &below);
-        if (rc != GZ_OK) return Fail("gz_order_build", rc);
+        rc = gz_order_build_auto(ctx_, direction, radius, target_mul, first_up ? 0 : 1,
+                                 next_cand.data(), first_up ? 1 : 0, below_limit, &total, &btc,
+                                 &below);
+        if (rc != GZ_OK) return Fail("gz_order_build_auto", rc);
         blocks_to_change = btc;
         if (total != 0) break;
       }
@@ -521,6 +520,8 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       t_pb_sort_ += pw.lap();
       std::fill(touched.begin(), touched.end(), 0);
       dirty.clear();
+      edit_pos.clear();
+      edit_val.clear();
       float val_threshold = 0.0;
       int changed_coeffs = 0;
       int est_size = prev_size;
@@ -536,7 +537,11 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         int16_t* blk = &img_[c * comp_stride + (size_t)b * 64];
         const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
         AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
-        if (!(newval == 0 && IsPrecious(orig_blk, k))) blk[k] = (int16_t)newval;
+        if (!(newval == 0 && IsPrecious(orig_blk, k))) {
+          blk[k] = (int16_t)newval;
+          edit_pos.push_back((int32_t)(c * comp_stride + (size_t)b * 64 + k));
+          edit_val.push_back((int16_t)newval);
+        }
         AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
         next_cand[b] += direction;
         if (!touched[b]) {
@@ -576,6 +581,8 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
           const size_t per = (dirty.size() + chunks - 1) / chunks;
           std::vector<SymbolHistogram> delta((size_t)3 * chunks);
           for (auto& d : delta) memset(d.counts, 0, sizeof(d.counts));
+          std::vector<std::vector<int32_t> > chunk_pos(chunks);
+          std::vector<std::vector<int16_t> > chunk_val(chunks);
           pool.Run(chunks, [&](int ch) {
             const size_t d0 = ch * per, d1 = std::min(dirty.size(), d0 + per);
             SymbolHistogram* dl = &delta[(size_t)3 * ch];
@@ -593,7 +600,11 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
                   removed[c] = true;
                 }
                 const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
-                if (!(newval == 0 && IsPrecious(orig_blk, k))) blk[k] = (int16_t)newval;
+                if (!(newval == 0 && IsPrecious(orig_blk, k))) {
+                  blk[k] = (int16_t)newval;
+                  chunk_pos[ch].push_back((int32_t)(c * comp_stride + (size_t)b * 64 + k));
+                  chunk_val[ch].push_back((int16_t)newval);
+                }
                 next_cand[b] += direction;
               }
               for (int c = 0; c < 3; ++c)
@@ -601,9 +612,12 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
                   AddBlockACSymbols(&img_[c * comp_stride + (size_t)b * 64], quant_[c], 1, &dl[c]);
             }
           });
-          for (int ch = 0; ch < chunks; ++ch)
+          for (int ch = 0; ch < chunks; ++ch) {
             for (int c = 0; c < 3; ++c)
               for (int i = 0; i < kHistoSize; ++i) ac_histo[c].counts[i] += delta[(size_t)3 * ch + c].counts[i];
+            edit_pos.insert(edit_pos.end(), chunk_pos[ch].begin(), chunk_pos[ch].end());
+            edit_val.insert(edit_val.end(), chunk_val[ch].begin(), chunk_val[ch].end());
+          }
         }
         t_pb_fast_ += fw.lap();
         n_steps_ += (long)fast_until;
@@ -626,20 +640,18 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       t_pb_loop_ += pw.lap();
       const size_t order_size = (size_t)total;
       if (sorted.failed()) return Fail("gz_order_partition/fetch", dev_order.rc);
-      for (int b = 0; b < nb; ++b) max_block_error[b] += weight[b] * val_threshold * direction;
+      rc = gz_order_advance(ctx_, val_threshold, direction);   // max_block_error += weight * ...
+      if (rc != GZ_OK) return Fail("gz_order_advance", rc);
 
       ++stats_->counters[kNumItersCnt];
       ++stats_->counters[direction > 0 ? kNumItersUpCnt : kNumItersDownCnt];
       t_phaseb_ += sw.lap();
 
-      // push the edited blocks to the device image
-      dirty_blocks.resize(dirty.size() * 192);
-      for (size_t i = 0; i < dirty.size(); ++i)
-        for (int c = 0; c < 3; ++c)
-          memcpy(&dirty_blocks[(i * 3 + c) * 64], &img_[c * comp_stride + (size_t)dirty[i] * 64], 128);
-      rc = gz_set_coeff_blocks(ctx_, dirty.data(), (int)dirty.size(), dirty_blocks.data());
+      // push the changed coefficients to the device image (positions are distinct: a block's
+      // candidates are distinct coefficients and a block advances in one direction)
+      rc = gz_apply_coeff_edits(ctx_, edit_pos.data(), edit_val.data(), (int)edit_pos.size());
       t_upload_ += sw.lap();
-      if (rc != GZ_OK) return Fail("gz_set_coeff_blocks", rc);
+      if (rc != GZ_OK) return Fail("gz_apply_coeff_edits", rc);
 
       size_t jpg_size = 0;
       if (!Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;

@@ -91,6 +91,9 @@ int gz_set_coeffs(gz_ctx* ctx, const int16_t* coeffs);
 int gz_set_coeff_blocks(gz_ctx* ctx, const int32_t* block_index, int n,
                         const int16_t* blocks);
 int gz_get_coeffs(gz_ctx* ctx, int16_t* coeffs_out);
+/* Single-coefficient form of SetCoeffBlock: candidate[pos[i]] = val[i] for n distinct
+ * positions pos = (c*nb + block)*64 + k (what one phase-B iteration changes). */
+int gz_apply_coeff_edits(gz_ctx* ctx, const int32_t* pos, const int16_t* val, int n);
 
 /* Candidate -> pixels, for parity checks and for callers that want the decoded image:
  * OutputImage::ToSRGB (output_image.cc:411-425) and ToLinearRGB (:427-440).
@@ -190,6 +193,19 @@ int gz_rank_zeroing_candidates(const int16_t* coeffs, const int16_t* orig, int n
 int gz_order_build(gz_ctx* ctx, int direction, const int32_t* next_cand,
                    const float* max_block_error, const float* block_weight, int count_below,
                    float limit, uint64_t* total, int32_t* blocks_to_change, uint64_t* below);
+/* The same with the per-block state kept on the device across iterations:
+ * gz_order_reset: max_block_error := 0 (processor.cc:607).
+ * gz_order_build_auto: block_weight = ComputeBlockErrorAdjustmentWeights(direction,
+ *   max_block_dist, target_mul) of the last gz_compare (all-zero distance map if
+ *   use_distmap == 0) computed on the device (butteraugli_comparator.cc:494-558), then the
+ *   construction loop as gz_order_build with the device-resident max_block_error.
+ * gz_order_advance: max_block_error[i] += block_weight[i] * val_threshold * direction
+ *   (processor.cc:754-756) with the weights of the last gz_order_build_auto. */
+int gz_order_reset(gz_ctx* ctx);
+int gz_order_build_auto(gz_ctx* ctx, int direction, int max_block_dist, double target_mul,
+                        int use_distmap, const int32_t* next_cand, int count_below, float limit,
+                        uint64_t* total, int32_t* blocks_to_change, uint64_t* below);
+int gz_order_advance(gz_ctx* ctx, float val_threshold, int direction);
 int gz_order_upload(gz_ctx* ctx, const void* entries, uint64_t n);
 int gz_order_partition(gz_ctx* ctx, uint64_t lo, uint64_t hi, uint64_t* cut);
 int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);

@@ -176,6 +176,74 @@ def case_block_search(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
     oc.close()
 
 
+def case_global_order(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
+    """Phase B's global candidate order on the device (processor.cc:622-663): the construction
+    from the reference's definition, the device-side block weights
+    (ComputeBlockErrorAdjustmentWeights, pinned through the oracle) and max_block_error
+    bookkeeping, and single-coefficient edits."""
+    rng = np.random.default_rng(RNG_SEED + 3 * w + h)
+    rgb = images.crop(w, h, x0, y0) if max(w, h) <= 444 else images.tiled(w, h)
+    oc = oracle.comparator(rgb, target)
+    with L.context(rgb, target) as ctx:
+        ctx.encode_rgb()
+        cq = ctx.quantize(np.full((3, 64), qs, np.int32))
+        off, idx, err = ctx.block_zeroing_orders()
+        dist, dm, bmax = ctx.compare()
+        nb = ctx.nb
+        cnt = np.diff(off)
+        max_err = np.zeros(nb, np.float32)
+        ctx.order_reset()
+        for direction, use_dm in ((1, False), (1, True), (-1, True), (-1, True)):
+            next_cand = (rng.integers(0, 1000, nb) % (cnt + 1)).astype(np.int32)
+            for radius in (1, 2, 4):
+                zero = np.zeros_like(dm)
+                wgt = oc.block_weights(direction, radius, 1.0, dm if use_dm else zero)
+                # the reference's construction loop
+                exp = []
+                btc = 0
+                for b in range(nb):
+                    if wgt[b] == 0:
+                        continue
+                    e = err[off[b]:off[b + 1]]
+                    at = next_cand[b]
+                    if direction > 0:
+                        vals = (e[at:] - max_err[b]) / wgt[b]
+                        btc += at < cnt[b]
+                    else:
+                        vals = (max_err[b] - e[:at][::-1]) / wgt[b]
+                        btc += at > 0
+                    exp.extend((b, v) for v in vals.astype(np.float32))
+                limit = np.float32(0.75) * np.float32(target)
+                total, got_btc, below = ctx.order_build_auto(direction, radius, 1.0, use_dm,
+                                                             next_cand, limit=float(limit))
+                assert total == len(exp) and got_btc == btc, (total, len(exp), got_btc, btc)
+                got = ctx.order_fetch(0, total)
+                if total:
+                    eb = np.array([b for b, _ in exp], np.int32)
+                    ev = np.array([v for _, v in exp], np.float32)
+                    assert_bits_equal(got["block"], eb, "order blocks")
+                    assert_bits_equal(got["val"], ev, "order vals")
+                    assert below == int((ev < limit).sum())
+                # explicit-weights entry point gives the same order
+                t2, b2, _ = ctx.order_build(direction, next_cand, max_err, wgt)
+                assert (t2, b2) == (total, btc)
+                assert_bits_equal(ctx.order_fetch(0, t2), got, "gz_order_build vs _auto")
+            # leave the last radius' weights in place and advance, as the driver does
+            thr = np.float32(rng.random() * 0.3)
+            ctx.order_build_auto(direction, 4, 1.0, use_dm, next_cand)
+            ctx.order_advance(float(thr), direction)
+            wgt = oc.block_weights(direction, 4, 1.0, dm if use_dm else np.zeros_like(dm))
+            max_err = (max_err + (wgt * thr) * np.float32(direction)).astype(np.float32)
+        # single-coefficient edits == block scatter
+        pos = rng.choice(3 * nb * 64, size=min(500, nb), replace=False).astype(np.int32)
+        val = rng.integers(-50, 50, pos.size).astype(np.int16)
+        ctx.apply_coeff_edits(pos, val)
+        expc = cq.copy().reshape(-1)
+        expc[pos] = val
+        assert_bits_equal(ctx.get_coeffs().reshape(-1), expc, "apply_coeff_edits")
+    oc.close()
+
+
 ZIGZAG_NATURAL = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
                   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,

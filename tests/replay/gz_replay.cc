@@ -47,6 +47,10 @@ struct Real {
   decltype(&gz_jpeg_scan_keep) jpeg_scan_keep;
   decltype(&gz_jpeg_scan_bytes) jpeg_scan_bytes;
   decltype(&gz_order_build) order_build;
+  decltype(&gz_order_reset) order_reset;
+  decltype(&gz_order_build_auto) order_build_auto;
+  decltype(&gz_order_advance) order_advance;
+  decltype(&gz_apply_coeff_edits) apply_coeff_edits;
   decltype(&gz_order_partition) order_partition;
   decltype(&gz_order_fetch) order_fetch;
   decltype(&gz_strerror) strerror_;
@@ -76,7 +80,9 @@ Real* real() {
   SYM(jpeg_histograms, "gz_jpeg_histograms") SYM(jpeg_scan, "gz_jpeg_scan")
   SYM(jpeg_scan_keep, "gz_jpeg_scan_keep") SYM(jpeg_scan_bytes, "gz_jpeg_scan_bytes")
   SYM(order_build, "gz_order_build") SYM(order_partition, "gz_order_partition")
-  SYM(order_fetch, "gz_order_fetch")
+  SYM(order_fetch, "gz_order_fetch") SYM(order_reset, "gz_order_reset")
+  SYM(order_build_auto, "gz_order_build_auto") SYM(order_advance, "gz_order_advance")
+  SYM(apply_coeff_edits, "gz_apply_coeff_edits")
 #undef SYM
   return &r;
 }
@@ -99,6 +105,7 @@ struct gz_ctx {
   std::vector<int32_t> cand_off;
   std::vector<float> cand_err;
   std::vector<std::pair<int, float> > order;
+  std::vector<float> max_err, weight;
   std::string err;
 };
 
@@ -282,6 +289,38 @@ int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
   *total = c->order.size();
   *blocks_to_change = btc;
   if (below) *below = nbelow;
+  return GZ_OK;
+}
+
+int gz_order_reset(gz_ctx* c) {
+  if (c->inner) return real()->order_reset(c->inner);
+  c->max_err.assign(c->nb, 0.0f);
+  return GZ_OK;
+}
+
+int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double target_mul,
+                        int use_distmap, const int32_t* next_cand, int count_below, float limit,
+                        uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  if (c->inner)
+    return real()->order_build_auto(c->inner, direction, max_block_dist, target_mul, use_distmap,
+                                    next_cand, count_below, limit, total, blocks_to_change, below);
+  c->weight.assign(c->nb, 0.0f);
+  if (c->max_err.empty()) c->max_err.assign(c->nb, 0.0f);
+  gz_block_weights(c, direction, max_block_dist, target_mul, use_distmap, c->weight.data());
+  return gz_order_build(c, direction, next_cand, c->max_err.data(), c->weight.data(), count_below,
+                        limit, total, blocks_to_change, below);
+}
+
+int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
+  if (c->inner) return real()->order_advance(c->inner, val_threshold, direction);
+  for (int b = 0; b < c->nb; ++b) c->max_err[b] += c->weight[b] * val_threshold * direction;
+  return GZ_OK;
+}
+
+int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int n) {
+  if (c->inner) return real()->apply_coeff_edits(c->inner, pos, val, n);
+  for (int i = 0; i < n; ++i)
+    if (pos[i] < 0 || pos[i] >= 3 * c->nb * 64) return GZ_E_ARG;
   return GZ_OK;
 }
 

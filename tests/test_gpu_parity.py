@@ -46,6 +46,11 @@ def test_block_kernels(L):
     pc.case_block_kernels(L, n=20000)
 
 
+@pytest.mark.parametrize("wh", [(444, 258), (61, 43)])
+def test_global_order(L, wh):
+    pc.case_global_order(L, *wh, x0=0, y0=0)
+
+
 def test_device_partition_is_std_sort(L, tmp_path):
     """gz_order_partition on the GPU, driven by the product's LazySorted, against std::sort
     itself: every size / tie pattern up to 5M entries, two device thresholds."""

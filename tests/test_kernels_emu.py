@@ -66,3 +66,7 @@ def host_emu():
 @pytest.mark.parametrize("wh", [(61, 43), (32, 32), (129, 9), (8, 8)])
 def test_jpeg_entropy(L, host_emu, wh):
     pc.case_jpeg_entropy(L, host_emu, *wh, x0=100, y0=50)
+
+
+def test_global_order(L):
+    pc.case_global_order(L, 40, 32, x0=100, y0=60)

@@ -24,6 +24,10 @@ Also on the JSON line:
                   metric): SURVEY.md 8(d) algorithmic bytes of one Compare (494 B/px) /
                   average duration of one Compare chain measured with HIP events on the
                   stream the kernels run on (gz_time_compare), same process, same image.
+                  `traffic` = HBM bytes of one chain from the rocprofv3 FETCH_SIZE /
+                  WRITE_SIZE passes committed under profiles/ (the counters cannot be read
+                  from inside this process).  `roofline_4k` = the same measurement on
+                  BASELINE.json configs[2] (3840x2160), the size the chain fills the chip at.
   cpu_baseline -- the unmodified reference guetzli::Process (oracle/_ref, 1 thread) on this
                   box's host CPU, rank 0, N=1 only, on a bounded sample: tests/golden/bees.png
                   (444x258, config 0), --quality 95.
@@ -35,6 +39,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -45,6 +51,8 @@ QUALITY = 95.0
 TARGET_Q95 = 0.971769              # ButteraugliScoreForQuality(95), quality.cc:31-85
 W, H = 1920, 1080
 GOLDEN_SHA_1080P_Q95 = "9c0eb414b8e73f4372c0b089eafe2350e6ff2ae83926d1c0c5f35cb5f7919729"
+CHAIN = ("butteraugli Compare chain (18 launches per Compare: k_reconstruct, 5 fused k_blur2d "
+         "(radius < 16), 4 k_blur_h + 4 k_blur_v (radius >= 16), 2 k_malta, k_mask_pre, k_combine)")
 
 
 def cpu_baseline():
@@ -119,12 +127,23 @@ def main():
     L = guetzli_amd.load()
     with L.context(rgb, TARGET_Q95, device=local_rank) as ctx:
         ctx.encode_rgb(download=False)
-        import numpy as np
         ctx.quantize(np.full((3, 64), 3, np.int32), download=False)
         ctx.time_compare(5)
         iters = 50
         ms = ctx.time_compare(iters) / iters
     achieved = ALGO_BYTES_PER_PX * W * H / (ms * 1e-3) / 1e9
+    ms_4k = None
+    if rank == 0:
+        with L.context(images.tiled(3840, 2160), TARGET_Q95, device=local_rank) as ctx:
+            ctx.encode_rgb(download=False)
+            ctx.quantize(np.full((3, 64), 3, np.int32), download=False)
+            ctx.time_compare(3)
+            ms_4k = ctx.time_compare(20) / 20
+    traffic = {}
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v2.json")))
+    except Exception:
+        pass
 
     if rank == 0:
         sha = hashlib.sha256(jpg).hexdigest()
@@ -145,12 +164,19 @@ def main():
                        "output_bytes": len(jpg), "output_sha256_matches_reference": True,
                        "iterations": info["counters"].get("number of iterations")},
             "roofline": {"bound": "hbm",
-                         "kernel": "butteraugli Compare chain (21 launches per Compare: "
-                                   "k_reconstruct, 9 k_blur_h, 9 k_blur_v, 2 k_malta, k_mask_pre, k_combine)",
+                         "kernel": CHAIN,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic.get("1080p", {}).get("traffic_bytes"),
                          "ms_per_compare": round(ms, 4),
                          "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W * H},
+            "roofline_4k": {"bound": "hbm", "kernel": CHAIN, "workload": "3840x2160 (configs[2])",
+                            "achieved": round(ALGO_BYTES_PER_PX * 3840 * 2160 / (ms_4k * 1e-3) / 1e9, 1),
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(ALGO_BYTES_PER_PX * 3840 * 2160 / (ms_4k * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "traffic": traffic.get("4k", {}).get("traffic_bytes"),
+                            "ms_per_compare": round(ms_4k, 4),
+                            "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * 3840 * 2160},
             "host_timers_s": {k: round(v, 3) for k, v in info["timers"].items()
                               if k in ("total", "phase_b_host", "compare", "block_search",
                                        "jpeg_write", "create+encode", "select_quant_matrix")},

@@ -49,6 +49,7 @@ SIGNATURES = {
     "gz_order_build_auto": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float, _P, _P, _P]),
     "gz_order_advance": (_I, [_P, C.c_float, _I]),
     "gz_apply_coeff_edits": (_I, [_P, _P, _P, _I]),
+    "gz_apply_candidate_steps": (_I, [_P, _I, _P, _P, _I]),
     "gz_order_upload": (_I, [_P, _P, C.c_uint64]),
     "gz_order_partition": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
     "gz_order_fetch": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
@@ -311,6 +312,13 @@ class Context:
         v = np.ascontiguousarray(val, np.int16)
         assert p.size == v.size
         self._chk(self.L.lib.gz_apply_coeff_edits(self.handle, _ptr(p), _ptr(v), p.size))
+
+    def apply_candidate_steps(self, direction, blocks, counts):
+        b = np.ascontiguousarray(blocks, np.int32)
+        n = np.ascontiguousarray(counts, np.int32)
+        assert b.size == n.size
+        self._chk(self.L.lib.gz_apply_candidate_steps(self.handle, direction, _ptr(b), _ptr(n),
+                                                      b.size))
 
     def order_upload(self, entries):
         e = np.ascontiguousarray(entries, self.ORDER_DTYPE)

@@ -1058,6 +1058,38 @@ int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
   return GZ_OK;
 }
 
+int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
+                             const int32_t* counts, int n) {
+  if (!c || n < 0 || (n > 0 && (!blocks || !counts)) || (direction != 1 && direction != -1))
+    return GZ_E_ARG;
+  if (!c->have_search || !c->d_next_cand || !c->have_cand || !c->have_orig) {
+    c->err = "gz_order_build must precede gz_apply_candidate_steps";
+    return GZ_E_STATE;
+  }
+  if (n == 0) return GZ_OK;
+  for (int i = 0; i < n; ++i)
+    if (blocks[i] < 0 || blocks[i] >= c->nb || counts[i] < 0 || counts[i] > 192) return GZ_E_ARG;
+  if ((size_t)2 * n > c->edit_cap) {   // the edit buffers double as (blocks, counts) staging
+    (void)hipFree(c->d_edit_pos); (void)hipFree(c->d_edit_val);
+    c->d_edit_pos = nullptr; c->d_edit_val = nullptr;
+    c->edit_cap = (size_t)2 * n + (size_t)n + 4096;
+    HIPCHK(c, hipMalloc((void**)&c->d_edit_pos, sizeof(int) * c->edit_cap));
+    HIPCHK(c, hipMalloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
+  }
+  int* d_blocks = c->d_edit_pos;
+  int* d_counts = c->d_edit_pos + n;
+  HIPCHK(c, hipMemcpyAsync(d_blocks, blocks, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_counts, counts, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+  const int nb = c->nb;
+  GZ_LAUNCH(k_apply_steps, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
+            (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
+            (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
+            (const int*)c->d_q, nb);
+  KCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
+  return GZ_OK;
+}
+
 int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int n) {
   if (!c || n < 0 || (n > 0 && (!pos || !val))) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }

@@ -168,6 +168,51 @@ __global__ __launch_bounds__(256) void k_apply_coeff_edits(const int* __restrict
   if (i < n) coeffs[pos[i]] = val[i];
 }
 
+// The coefficient changes of phase B's global loop (processor.cc:704-736) for whole blocks:
+// entry i advances block blocks[i] by counts[i] steps in `direction`.  Step j of a block
+// applies its candidate next_cand + j ("up": the coefficient is zeroed) or next_cand - 1 - j
+// ("down": the coefficient gets its quantised original value back), unless it is one of the
+// two "precious" coefficients.  A block's candidates are distinct coefficients, so its steps
+// are independent: one wave per block, one lane per step.
+__global__ __launch_bounds__(256) void k_apply_steps(const int* __restrict__ blocks,
+                                                     const int* __restrict__ counts, int n,
+                                                     int direction, const int* __restrict__ next_cand,
+                                                     const unsigned char* __restrict__ cand_idx,
+                                                     const short* __restrict__ orig,
+                                                     short* __restrict__ cand,
+                                                     const int* __restrict__ q, int nb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const int b = blocks[i], cnt = counts[i], nx = next_cand[b];
+  for (int j = lane; j < cnt; j += 64) {
+    const int p = direction > 0 ? nx + j : nx - 1 - j;
+    const int idx = cand_idx[(size_t)b * 192 + p];
+    const int c = idx >> 6, k = idx & 63;
+    const short* ob = orig + ((size_t)c * nb + b) * 64;
+    int newval = 0;
+    if (direction < 0) {   // Quantize(), quantize.h:24-29
+      const int quant = q[c * 64 + k], raw = ob[k];
+      const int r = raw % quant;
+      const int delta = 2 * r > quant ? quant - r : ((-2) * r > quant ? -quant - r : -r);
+      newval = (short)(raw + (int)(short)delta);
+    }
+    bool precious = false;
+    if (newval == 0 && (k == 1 || k == 8)) {   // processor.cc:722-733
+      int sum_of_hf = 0;
+      for (int ii = 3; ii < 64; ++ii) {
+        if ((ii & 7) < 3 && ii < 3 * 8) continue;
+        const int v = ob[ii];
+        sum_of_hf += v < 0 ? -v : v;
+      }
+      const int limit = sum_of_hf < 60 ? 4 : 8;
+      const int v = ob[k];
+      precious = (v < 0 ? -v : v) >= limit;
+    }
+    if (!precious) cand[((size_t)c * nb + b) * 64 + k] = (short)newval;
+  }
+}
+
 // -------------------------------------------------------------- one introsort partition --
 struct PartScalars {
   unsigned m;      // number of swapped pairs

@@ -70,6 +70,33 @@ class LazySorted {
   void SortAll() {
     while (done_ < n_) Refine();
   }
+  // Makes positions [0, upto) hold exactly the elements std::sort would place there, WITHOUT
+  // ordering them (quickselect along introsort's own partitions), except that position
+  // upto - 1 and everything after it up to the next range boundary is final and sorted.
+  // Ranges that end at or below upto - 1 are dropped from the work list unsorted: a consumer
+  // that only needs the SET of the first `upto` elements and element upto - 1 itself (phase
+  // B's fast steps) saves the O(upto log upto) sort.  Afterwards operator[] is valid for
+  // i >= upto - 1 only.
+  void SelectPrefix(size_t upto) {
+    if (upto == 0 || n_ == 0) return;
+    if (upto > n_) upto = n_;
+    const size_t last = upto - 1;
+    while (!pending_.empty() && pending_.back().lo <= last) {
+      const Range r = pending_.back();
+      if (r.hi <= last) {            // entirely below: only its content matters
+        pending_.pop_back();
+        if (r.dev && !(dev_->Fetch(r.lo, r.hi, a_ + r.lo))) {
+          failed_ = true;
+          for (size_t i = r.lo; i < r.hi; ++i) a_[i] = T();
+        }
+        done_ = std::max(done_, r.hi);
+        continue;
+      }
+      const size_t fin = RefineOn(&pending_, true);   // the range holding `last`: one step
+      if (fin) done_ = std::max(done_, fin);
+    }
+  }
+
   // Finalises positions [0, upto) using the worker pool: the pending ranges that reach into
   // the prefix are split (in parallel) down to a grain, then finished independently -- the
   // ranges are disjoint and refining one never touches another, so the result is the one

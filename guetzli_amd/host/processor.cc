@@ -218,7 +218,8 @@ class Encoder {
   JpegHead head_;                // marker segments + codes of the last Serialize
   std::string best_head_;        // GuetzliOutput: head of the best candidate; its scan is
                                  // kept on the device (gz_jpeg_scan_keep)
-  bool verify_ = false;          // GZ_VERIFY_ENTROPY=1: cross-check against the host writer
+  bool verify_ = false;
+  bool mirror_valid_ = false;    // img_ mirrors the device image (phase B)          // GZ_VERIFY_ENTROPY=1: cross-check against the host writer
   double best_score_ = -1;
   double t_write_ = 0, t_compare_ = 0, t_quant_ = 0, t_blocksearch_ = 0, t_phaseb_ = 0,
          t_upload_ = 0;
@@ -303,6 +304,14 @@ bool Encoder::VerifyAgainstHostWriter(const int (*q)[64], size_t size) {
   std::vector<int16_t> co(img_.size());
   int rc = gz_get_coeffs(ctx_, co.data());
   if (rc != GZ_OK) return Fail("gz_get_coeffs", rc);
+  if (q && mirror_valid_ && co != img_) {
+    size_t nd = 0, first = 0;
+    for (size_t i = 0; i < co.size(); ++i)
+      if (co[i] != img_[i]) { if (!nd) first = i; ++nd; }
+    fprintf(stderr, "guetzli_amd: host mirror of the image differs from the device image "
+            "(%zu coefficients, first at %zu: device %d host %d)\n", nd, first, co[first], img_[first]);
+    return false;
+  }
   Frame f;
   if (q) FrameFromImage(co.data(), q, w_, h_, &f);
   else FrameFromOriginal(co.data(), w_, h_, &f);
@@ -559,7 +568,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         const size_t last_needed = std::min<size_t>((size_t)std::max(min_coeffs_to_change, 0), n_order - 1);
         const size_t fast_until = last_needed / 10 * 10;
         Stopwatch fw;
-        sorted.EnsureSorted(fast_until);
+        sorted.SelectPrefix(fast_until);   // the set [0, fast_until) and element fast_until - 1
         t_pb_ensure_ += fw.lap();
         // Steps [0, fast_until): only how many steps each block takes matters (the n-th step
         // of a block applies its n-th remaining candidate whatever the key), so they are
@@ -576,48 +585,42 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         if (fast_until > 0) {
           val_threshold = order[fast_until - 1].second;
           changed_coeffs += (int)fast_until;
+          // the device applies the same steps to its image (and advances its next_cand) ...
+          std::vector<int32_t> counts(dirty.size());
+          for (size_t di = 0; di < dirty.size(); ++di) counts[di] = step_count[dirty[di]];
+          rc = gz_apply_candidate_steps(ctx_, direction, dirty.data(), counts.data(), (int)dirty.size());
+          if (rc != GZ_OK) return Fail("gz_apply_candidate_steps", rc);
+          if (getenv("GZ_DEBUG_STEPS")) {
+            std::vector<int16_t> co(img_.size());
+            gz_get_coeffs(ctx_, co.data());
+            size_t nd = 0;
+            for (size_t i = 0; i < co.size(); ++i) nd += co[i] != img_[i];
+            long tot = 0; for (size_t di = 0; di < dirty.size(); ++di) tot += counts[di];
+            fprintf(stderr, "debug: after device steps: %zu coefficients differ from the host mirror (before host edits), %ld steps in %zu blocks, dir %d\n", nd, tot, dirty.size(), direction);
+          }
+          // ... while the host mirror is edited block by block on the worker pool
           WorkerPool& pool = WorkerPool::Get();
           const int chunks = dirty.size() < 2048 ? 1 : 4 * pool.size();
           const size_t per = (dirty.size() + chunks - 1) / chunks;
-          std::vector<SymbolHistogram> delta((size_t)3 * chunks);
-          for (auto& d : delta) memset(d.counts, 0, sizeof(d.counts));
-          std::vector<std::vector<int32_t> > chunk_pos(chunks);
-          std::vector<std::vector<int16_t> > chunk_val(chunks);
           pool.Run(chunks, [&](int ch) {
             const size_t d0 = ch * per, d1 = std::min(dirty.size(), d0 + per);
-            SymbolHistogram* dl = &delta[(size_t)3 * ch];
             for (size_t di = d0; di < d1; ++di) {
               const int b = dirty[di];
-              bool removed[3] = {false, false, false};
               for (int step = 0; step < step_count[b]; ++step) {
                 const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
                 const int c = idx / 64, k = idx % 64;
-                const int* q = quant_[c];
                 const int16_t* orig_blk = &orig_[c * comp_stride + (size_t)b * 64];
-                int16_t* blk = &img_[c * comp_stride + (size_t)b * 64];
-                if (!removed[c]) {
-                  AddBlockACSymbols(blk, q, -1, &dl[c]);
-                  removed[c] = true;
-                }
-                const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
-                if (!(newval == 0 && IsPrecious(orig_blk, k))) {
-                  blk[k] = (int16_t)newval;
-                  chunk_pos[ch].push_back((int32_t)(c * comp_stride + (size_t)b * 64 + k));
-                  chunk_val[ch].push_back((int16_t)newval);
-                }
+                const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], quant_[c][k]);
+                if (!(newval == 0 && IsPrecious(orig_blk, k)))
+                  img_[c * comp_stride + (size_t)b * 64 + k] = (int16_t)newval;
                 next_cand[b] += direction;
               }
-              for (int c = 0; c < 3; ++c)
-                if (removed[c])
-                  AddBlockACSymbols(&img_[c * comp_stride + (size_t)b * 64], quant_[c], 1, &dl[c]);
             }
           });
-          for (int ch = 0; ch < chunks; ++ch) {
-            for (int c = 0; c < 3; ++c)
-              for (int i = 0; i < kHistoSize; ++i) ac_histo[c].counts[i] += delta[(size_t)3 * ch + c].counts[i];
-            edit_pos.insert(edit_pos.end(), chunk_pos[ch].begin(), chunk_pos[ch].end());
-            edit_val.insert(edit_val.end(), chunk_val[ch].begin(), chunk_val[ch].end());
-          }
+          // the symbol statistics of the edited image come from the device (BuildACHistograms
+          // over the resident coefficients) instead of per-block bookkeeping here
+          SymbolHistogram dc_now[3];
+          if (!DeviceHistograms(quant_, dc_now, ac_histo)) return false;
         }
         t_pb_fast_ += fw.lap();
         n_steps_ += (long)fast_until;
@@ -726,6 +729,7 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   if (!SelectMatrix(best_q)) return false;
   stats_->timers["select_quant_matrix"] = sw.lap();
   if (!SetImageFromQuantization(best_q, true)) return false;
+  mirror_valid_ = true;
   if (!SelectFrequencyMasking(1.0)) return false;
   stats_->timers["select_frequency_masking"] = sw.lap();
   stats_->timers["jpeg_write"] = t_write_;

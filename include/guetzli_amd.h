@@ -206,6 +206,14 @@ int gz_order_build_auto(gz_ctx* ctx, int direction, int max_block_dist, double t
                         int use_distmap, const int32_t* next_cand, int count_below, float limit,
                         uint64_t* total, int32_t* blocks_to_change, uint64_t* below);
 int gz_order_advance(gz_ctx* ctx, float val_threshold, int direction);
+/* gz_apply_candidate_steps: the coefficient side of the global loop's steps
+ * (processor.cc:704-736) for whole blocks: block blocks[i] advances by counts[i] steps in
+ * `direction` from the next_cand the last gz_order_build* call uploaded -- each step zeroes
+ * ("up") or restores ("down") the block's next candidate coefficient unless it is
+ * "precious" (:722-733).  blocks distinct; the device copy of next_cand is left as uploaded
+ * (the next gz_order_build* call brings the caller's). */
+int gz_apply_candidate_steps(gz_ctx* ctx, int direction, const int32_t* blocks,
+                             const int32_t* counts, int n);
 int gz_order_upload(gz_ctx* ctx, const void* entries, uint64_t n);
 int gz_order_partition(gz_ctx* ctx, uint64_t lo, uint64_t hi, uint64_t* cut);
 int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);

@@ -56,8 +56,25 @@ static int check(const std::vector<E>& v, const char* what, size_t threshold, si
   Dev dev;
   guetzli_amd::LazySorted<E, Less> lazy(host.data(), host.size(), Less(), -1, 1 << 17, &dev, threshold);
   const size_t upto = prefix_only ? std::min(prefix_only, v.size()) : v.size();
-  if (ensure) lazy.EnsureSorted(ensure == 1 ? upto : upto / 2);
-  for (size_t i = 0; i < upto; ++i) {
+  size_t from = 0;
+  if (ensure == 3) {   // SelectPrefix: the right set below f, exact from f-1 on
+    const size_t f = upto / 2;
+    lazy.SelectPrefix(f);
+    if (f > 0) {
+      std::vector<std::pair<float, int> > a, b;
+      for (size_t i = 0; i < f; ++i) {
+        a.push_back(std::make_pair(host[i].second, host[i].first));
+        b.push_back(std::make_pair(ref[i].second, ref[i].first));
+      }
+      std::sort(a.begin(), a.end());
+      std::sort(b.begin(), b.end());
+      if (a != b) { printf("FAIL %s n=%zu thr=%zu: SelectPrefix(%zu) set differs\n", what, v.size(), threshold, f); return 1; }
+      from = f - 1;
+    }
+  } else if (ensure) {
+    lazy.EnsureSorted(ensure == 1 ? upto : upto / 2);
+  }
+  for (size_t i = from; i < upto; ++i) {
     const E& e = lazy[i];
     if (lazy.failed()) { printf("FAIL %s: device call failed\n", what); return 1; }
     if (e.first != ref[i].first || e.second != ref[i].second) {
@@ -117,6 +134,7 @@ int main(int argc, char** argv) {
           fails += check(v, "prefix", thr, n / 50 + 3, 0);
           fails += check(v, "ensure", thr, n / 20 + 3, 1);
           fails += check(v, "ensure-half", thr, n / 20 + 3, 2);
+          fails += check(v, "select-prefix", thr, n / 10 + 3, 3);
         }
         if (fails > 5) goto done;
       }

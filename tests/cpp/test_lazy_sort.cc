@@ -25,8 +25,26 @@ static int check(std::vector<E> v, const char* what, size_t prefix_only = 0) {
   std::sort(ref.begin(), ref.end(), Less());
   guetzli_amd::LazySorted<E, Less> lazy(v.data(), v.size(), Less(), -1, g_par_threshold);
   const size_t upto = prefix_only ? std::min(prefix_only, v.size()) : v.size();
-  if (g_ensure) lazy.EnsureSorted(g_ensure == 1 ? upto : upto / 2);
-  for (size_t i = 0; i < upto; ++i) {
+  size_t from = 0;
+  if (g_ensure == 3) {
+    // SelectPrefix: [0, f) is the right SET, element f-1 and everything read after it exact
+    const size_t f = upto / 2;
+    lazy.SelectPrefix(f);
+    if (f > 0) {
+      std::vector<std::pair<float, int> > a, b;
+      for (size_t i = 0; i < f; ++i) {
+        a.push_back(std::make_pair(v[i].second, v[i].first));
+        b.push_back(std::make_pair(ref[i].second, ref[i].first));
+      }
+      std::sort(a.begin(), a.end());
+      std::sort(b.begin(), b.end());
+      if (a != b) { printf("FAIL %s n=%zu: SelectPrefix(%zu) set differs\n", what, v.size(), f); return 1; }
+      from = f - 1;
+    }
+  } else if (g_ensure) {
+    lazy.EnsureSorted(g_ensure == 1 ? upto : upto / 2);
+  }
+  for (size_t i = from; i < upto; ++i) {
     const E& e = lazy[i];
     if (e.first != ref[i].first || e.second != ref[i].second) {
       printf("FAIL %s n=%zu at %zu: lazy (%d,%g) std (%d,%g)\n", what, v.size(), i, e.first,
@@ -46,6 +64,8 @@ int main() {
   g_ensure = 1;                   // pool-parallel EnsureSorted over the whole prefix
   fails += run_all();
   g_ensure = 2;                   // ... over half of it, the rest lazily
+  fails += run_all();
+  g_ensure = 3;                   // SelectPrefix over half of it (unordered set), the rest lazily
   fails += run_all();
   printf(fails ? "lazy_sort: %d FAILURES\n" : "lazy_sort: ok\n", fails);
   return fails ? 1 : 0;

@@ -234,6 +234,40 @@ def case_global_order(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
             ctx.order_advance(float(thr), direction)
             wgt = oc.block_weights(direction, 4, 1.0, dm if use_dm else np.zeros_like(dm))
             max_err = (max_err + (wgt * thr) * np.float32(direction)).astype(np.float32)
+        # whole-block steps (processor.cc:704-736): zero / restore the next candidates
+        def quantize(raw, q):
+            r = int(np.fmod(raw, q))
+            d = q - r if 2 * r > q else (-q - r if -2 * r > q else -r)
+            return np.int16(raw + d)
+        co = ctx.get_coeffs()
+        orig = ctx.encode_rgb()
+        for direction in (1, -1):
+            exp = co.copy()
+            if direction > 0:
+                next_cand = (rng.integers(0, 1000, nb) % (cnt + 1)).astype(np.int32)
+                counts = (rng.integers(0, 1000, nb) % (cnt - next_cand + 1)).astype(np.int32)
+            else:
+                next_cand = (rng.integers(0, 1000, nb) % (cnt + 1)).astype(np.int32)
+                counts = (rng.integers(0, 1000, nb) % (next_cand + 1)).astype(np.int32)
+            sel = np.flatnonzero(counts > 0).astype(np.int32)
+            for b in sel:
+                for j in range(counts[b]):
+                    p = next_cand[b] + j if direction > 0 else next_cand[b] - 1 - j
+                    ix = int(idx[off[b] + p])
+                    c, k = ix // 64, ix % 64
+                    ob = orig[c, b].astype(np.int64)
+                    newval = 0 if direction > 0 else int(quantize(int(ob[k]), qs))
+                    precious = False
+                    if newval == 0 and k in (1, 8):
+                        hf = sum(abs(int(ob[i])) for i in range(3, 64) if not ((i & 7) < 3 and i < 24))
+                        precious = abs(int(ob[k])) >= (4 if hf < 60 else 8)
+                    if not precious:
+                        exp[c, b, k] = newval
+            ctx.order_build_auto(direction, 1, 1.0, True, next_cand)   # uploads next_cand
+            ctx.apply_candidate_steps(direction, sel, counts[sel])
+            co = ctx.get_coeffs()
+            assert_bits_equal(co, exp, f"apply_candidate_steps direction {direction}")
+        cq = co
         # single-coefficient edits == block scatter
         pos = rng.choice(3 * nb * 64, size=min(500, nb), replace=False).astype(np.int32)
         val = rng.integers(-50, 50, pos.size).astype(np.int16)

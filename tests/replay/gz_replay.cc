@@ -51,6 +51,7 @@ struct Real {
   decltype(&gz_order_build_auto) order_build_auto;
   decltype(&gz_order_advance) order_advance;
   decltype(&gz_apply_coeff_edits) apply_coeff_edits;
+  decltype(&gz_apply_candidate_steps) apply_candidate_steps;
   decltype(&gz_order_partition) order_partition;
   decltype(&gz_order_fetch) order_fetch;
   decltype(&gz_strerror) strerror_;
@@ -83,6 +84,7 @@ Real* real() {
   SYM(order_fetch, "gz_order_fetch") SYM(order_reset, "gz_order_reset")
   SYM(order_build_auto, "gz_order_build_auto") SYM(order_advance, "gz_order_advance")
   SYM(apply_coeff_edits, "gz_apply_coeff_edits")
+  SYM(apply_candidate_steps, "gz_apply_candidate_steps")
 #undef SYM
   return &r;
 }
@@ -322,6 +324,12 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
   for (int i = 0; i < n; ++i)
     if (pos[i] < 0 || pos[i] >= 3 * c->nb * 64) return GZ_E_ARG;
   return GZ_OK;
+}
+
+int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
+                             const int32_t* counts, int n) {
+  if (c->inner) return real()->apply_candidate_steps(c->inner, direction, blocks, counts, n);
+  return GZ_OK;   // the host driver keeps its own mirror of the image; nothing to replay
 }
 
 int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {

@@ -202,6 +202,8 @@ GOLDEN_JPEG_SHA = {
     (444, 258, 95): "f2673f12a4856e020627fa151493a80b1cb2ee4dc81e28afc62dc089baf50242",
     (444, 258, 84): "95f509f457ce8ddd85087c804664539e0ef7b1f3a6c6ca1cbedcd9ba29a89379",
     (1920, 1080, 95): "9c0eb414b8e73f4372c0b089eafe2350e6ff2ae83926d1c0c5f35cb5f7919729",
+    (3840, 2160, 95): "481507d21e4d37f296ae6a2a93a84d950c4a135df310b3408a64390b25d59c05",
+    (3840, 2160, 84): "f3be1e4385a977853f7cd224e1722a728c1fa0bc68f1115c27e657c23a028ac0",
 }
 GOLDEN_TRACE_SHA = {
     (444, 258, 95): "954ec7623366bc3c345fc5b0748017f9a5e0128aba0917a249cca390a615f787",
@@ -228,4 +230,26 @@ def test_whole_encode_1080p_bit_identical_jpeg():
     rgb = images.tiled(1920, 1080)
     jpg, info = guetzli_amd.process(rgb, quality=95)
     assert len(jpg) == 721187
+    assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(1920, 1080, 95)]
+
+
+@pytest.mark.parametrize("q,size", [(95, 2895866), (84, 1430837)])
+def test_whole_encode_4k_bit_identical_jpeg(q, size):
+    """BASELINE configs 3 and 4 (3840x2160, quality 95 and 84): byte-identical to the
+    reference output."""
+    import hashlib
+    import guetzli_amd
+    rgb = images.tiled(3840, 2160)
+    jpg, info = guetzli_amd.process(rgb, quality=q)
+    assert len(jpg) == size
+    assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(3840, 2160, q)]
+
+
+def test_whole_encode_with_self_checks_1080p(monkeypatch):
+    """GZ_VERIFY_ENTROPY=1: every candidate's device scan equals the host writer's bytes and
+    the host mirror of the image equals the device image after every iteration."""
+    import hashlib
+    import guetzli_amd
+    monkeypatch.setenv("GZ_VERIFY_ENTROPY", "1")
+    jpg, info = guetzli_amd.process(images.tiled(1920, 1080), quality=95)
     assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(1920, 1080, 95)]

@@ -45,13 +45,56 @@ int SymbolHistogram::NumSymbols() const {
 // tree_limit, all counts are raised to a doubling floor and the construction repeats --
 // exactly the procedure of CreateHuffmanTree / SetDepth (entropy_encode.cc:25-145), whose
 // tie rules decide the code lengths and therefore the bytes.
+namespace {
+struct HuffNode {
+  uint32_t weight;
+  int left;    // -1 for a leaf
+  int right;   // child index, or the symbol for a leaf
+};
+// The size model of phase B asks for the depths of the same few histograms over and over
+// (every 10 coefficient steps, processor.cc:741-743), and most steps touch one component:
+// remember the last answers per thread.
+struct HuffMemo {
+  static const int kSlots = 8;
+  uint32_t counts[kSlots][kHistoSize];
+  uint8_t depth[kSlots][kHistoSize];
+  int limit[kSlots];
+  bool valid[kSlots];
+  int next;
+};
+}  // namespace
+
+static void HuffmanDepthsUncached(const uint32_t* counts, size_t length, int tree_limit,
+                                  uint8_t* depth);
+
 void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth) {
-  struct Node {
-    uint32_t weight;
-    int left;    // -1 for a leaf
-    int right;   // child index, or the symbol for a leaf
-  };
-  std::vector<Node> node(2 * length + 2);
+  if (length != (size_t)kHistoSize) {
+    HuffmanDepthsUncached(counts, length, tree_limit, depth);
+    return;
+  }
+  static thread_local HuffMemo memo = {};
+  for (int s = 0; s < HuffMemo::kSlots; ++s)
+    if (memo.valid[s] && memo.limit[s] == tree_limit &&
+        memcmp(memo.counts[s], counts, sizeof(memo.counts[s])) == 0) {
+      // depth[] entries of absent symbols are left untouched by the construction: same here
+      for (int i = 0; i < kHistoSize; ++i)
+        if (counts[i]) depth[i] = memo.depth[s][i];
+      return;
+    }
+  HuffmanDepthsUncached(counts, length, tree_limit, depth);
+  const int s = memo.next;
+  memo.next = (memo.next + 1) % HuffMemo::kSlots;
+  memcpy(memo.counts[s], counts, sizeof(memo.counts[s]));
+  memcpy(memo.depth[s], depth, sizeof(memo.depth[s]));
+  memo.limit[s] = tree_limit;
+  memo.valid[s] = true;
+}
+
+static void HuffmanDepthsUncached(const uint32_t* counts, size_t length, int tree_limit,
+                                  uint8_t* depth) {
+  typedef HuffNode Node;
+  static thread_local std::vector<Node> node;
+  if (node.size() < 2 * length + 2) node.resize(2 * length + 2);
   for (uint32_t floor_count = 1;; floor_count *= 2) {
     size_t n = 0;
     for (size_t i = length; i-- > 0;)
@@ -80,7 +123,8 @@ void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_
     }
     // depth assignment with the limit check
     bool ok = true;
-    std::vector<std::pair<int, int> > stack;   // (node, level)
+    static thread_local std::vector<std::pair<int, int> > stack;   // (node, level)
+    stack.clear();
     stack.push_back(std::make_pair((int)(2 * n - 1), 0));
     while (!stack.empty() && ok) {
       const std::pair<int, int> top = stack.back();

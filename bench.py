@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-images", type=int, default=8,
+                    help="images of the extra concurrent-batch leg (0 = skip)")
+    ap.add_argument("--batch-workers", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -139,6 +142,26 @@ def main():
             ctx.quantize(np.full((3, 64), 3, np.int32), download=False)
             ctx.time_compare(3)
             ms_4k = ctx.time_compare(20) / 20
+    # batch leg (BASELINE config 5 in miniature, rank 0): independent images in flight on one
+    # GPU at the same time, one host thread each; reported beside `value`, never instead of it
+    batch = None
+    if rank == 0 and args.batch_images > 0:
+        from guetzli_amd.batch import encode_concurrent
+        imgs = [images.shifted(images.tiled(W, H), k) for k in range(args.batch_images)]
+        proc = lambda im: host.process(im, quality=QUALITY, device=local_rank)
+        encode_concurrent(imgs[:args.batch_workers], proc, args.batch_workers)   # warm-up
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        outs = encode_concurrent(imgs, proc, args.batch_workers)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        assert hashlib.sha256(outs[0][0]).hexdigest() == GOLDEN_SHA_1080P_Q95
+        batch = {"images": args.batch_images, "in_flight": args.batch_workers,
+                 "value": round(args.batch_images * W * H / 1e6 / tb, 4), "unit": "MPix/s",
+                 "seconds": round(tb, 3),
+                 "note": "independent 1920x1080 images, several in flight on ONE GPU (one host "
+                         "thread + one device context each); output 0 checked against the "
+                         "reference JPEG"}
     traffic = {}
     try:
         traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v2.json")))
@@ -181,6 +204,8 @@ def main():
                               if k in ("total", "phase_b_host", "compare", "block_search",
                                        "jpeg_write", "create+encode", "select_quant_matrix")},
         }
+        if batch is not None:
+            out["batch_one_gpu"] = batch
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -37,3 +37,14 @@ def encode_batch(get_image, n_images, process, rank=0, world=1, dist=None):
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     return sorted((r for part in gathered for r in part), key=lambda r: r["index"])
+
+
+def encode_concurrent(images, process, workers=4):
+    """Several independent images on ONE GPU at the same time: one host thread per image in
+    flight (the C++ driver releases the GIL for the whole encode; every image has its own
+    device context and stream).  A single encode keeps the GPU busy about a third of the time
+    -- the rest is the serial search logic on the host -- so images in flight overlap one
+    image's host work with another's kernels.  Returns [(jpeg_bytes, info)] in input order."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        return list(ex.map(process, images))

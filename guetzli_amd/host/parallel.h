@@ -27,6 +27,13 @@ class WorkerPool {
       for (int i = 0; i < n; ++i) fn(i);
       return;
     }
+    // One job at a time: when several images are encoded concurrently (one host thread per
+    // image, batch mode) a caller that finds the pool busy simply runs its job itself.
+    std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+    if (!job.owns_lock()) {
+      for (int i = 0; i < n; ++i) fn(i);
+      return;
+    }
     {
       std::lock_guard<std::mutex> lk(mu_);
       fn_ = &fn;
@@ -88,6 +95,7 @@ class WorkerPool {
 
   std::vector<std::thread> workers_;
   std::mutex mu_;
+  std::mutex job_mu_;
   std::condition_variable cv_, done_cv_;
   const std::function<void(int)>* fn_ = nullptr;
   int next_ = 0, total_ = 0, pending_ = 0;

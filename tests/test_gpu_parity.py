@@ -253,3 +253,18 @@ def test_whole_encode_with_self_checks_1080p(monkeypatch):
     monkeypatch.setenv("GZ_VERIFY_ENTROPY", "1")
     jpg, info = guetzli_amd.process(images.tiled(1920, 1080), quality=95)
     assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(1920, 1080, 95)]
+
+
+def test_concurrent_encodes_on_one_gpu_are_deterministic():
+    """Batch mode (guetzli_amd.batch.encode_concurrent): several images in flight on one GPU,
+    one host thread and one device context each, give exactly the bytes of encoding them one
+    after the other."""
+    import guetzli_amd
+    from guetzli_amd.batch import encode_concurrent
+    host = guetzli_amd.load_host()
+    imgs = [images.shifted(images.bees(), k) for k in range(6)]
+    proc = lambda im: host.process(im, quality=95)
+    seq = [proc(im)[0] for im in imgs]
+    con = [j for j, _ in encode_concurrent(imgs, proc, workers=3)]
+    assert con == seq
+    assert len(set(seq)) == len(seq)   # they really are different images

@@ -184,28 +184,30 @@ struct BlockMaxOut {
   int bw;
 };
 
-template <int R, int NC, class Post, bool BM>
+template <int R, int NC, class Post, bool BM, int TH = 64>
 __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, int w, int h,
                                                 int pitch, Taps<R> taps, BorderScale bs,
                                                 BlockMaxOut bm) {
-  __shared__ __attribute__((aligned(16))) float tile[VH + 2 * R][VW];
+  // TH = tile height (64, or 32 for small images: twice the workgroups to fill the chip)
+  constexpr int VHt = TH, VPTt = TH / 4;
+  __shared__ __attribute__((aligned(16))) float tile[VHt + 2 * R][VW];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int x0 = blockIdx.x * VW, y0 = blockIdx.y * VH;
+  const int x0 = blockIdx.x * VW, y0 = blockIdx.y * VHt;
   const int x = x0 + tx;
   // staging with one aligned 16-byte load per lane when the tile's columns are all inside
   // the image and rows are 16-byte aligned (rows outside the image are zero)
   const bool vec = x0 + VW <= w && (pitch & 3) == 0;
   const int vq = (threadIdx.x & 15) * 4, vr = threadIdx.x >> 4;
-  float acc[NC][VPT];
+  float acc[NC][VPTt];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float* __restrict__ in = src.p[c];
     if (c > 0) __syncthreads();
     if (vec) {
 #pragma unroll
-      for (int k = 0; k < (VH + 2 * R + 15) / 16; ++k) {
+      for (int k = 0; k < (VHt + 2 * R + 15) / 16; ++k) {
         const int ry = vr + 16 * k;
-        if ((k + 1) * 16 <= VH + 2 * R || ry < VH + 2 * R) {
+        if ((k + 1) * 16 <= VHt + 2 * R || ry < VHt + 2 * R) {
           const int y = y0 - R + ry;
           gz_f4 v;
           v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
         }
       }
     } else {
-      for (int ry = tg; ry < VH + 2 * R; ry += 4) {
+      for (int ry = tg; ry < VHt + 2 * R; ry += 4) {
         const int y = y0 - R + ry;
         float v = 0.0f;
         if (x < w && y >= 0 && y < h) v = in[(size_t)y * pitch + x];
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int ly = tg * VPT + i;   // local output row
+    for (int i = 0; i < VPTt; ++i) {
+      const int ly = tg * VPTt + i;   // local output row
       const int y = y0 + ly;
       float sum = 0.0f;
       if (y < h) {
@@ -241,10 +243,10 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
       acc[c][i] = sum;
     }
   }
-  float res[VPT];
+  float res[VPTt];
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
-    const int y = y0 + tg * VPT + i;
+  for (int i = 0; i < VPTt; ++i) {
+    const int y = y0 + tg * VPTt + i;
     res[i] = 0.0f;
     if (x < w && y < h) {
       float v[NC];
@@ -257,9 +259,9 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
     __shared__ float s_bmax[64];
     __syncthreads();   // all column reads of the last plane are done
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) tile[tg * VPT + i][tx] = res[i];
+    for (int i = 0; i < VPTt; ++i) tile[tg * VPTt + i][tx] = res[i];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 8 * (TH / 8)) {
       const int bxl = threadIdx.x & 7, byl = threadIdx.x >> 3;
       float m = 0.0f;
       for (int yy = 0; yy < 8; ++yy)
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
     __syncthreads();
     if (threadIdx.x == 0) {
       float m = 0.0f;
-      for (int i = 0; i < 64; ++i) m = s_bmax[i] > m ? s_bmax[i] : m;
+      for (int i = 0; i < 8 * (TH / 8); ++i) m = s_bmax[i] > m ? s_bmax[i] : m;
       atomicMax(bm.image_max_bits, __float_as_uint(m));
     }
   }
@@ -300,22 +302,23 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
 // pass arithmetic.
 constexpr int T2 = 64;   // tile edge
 
-template <int R, int NC, class Src, class Post, bool BM>
+template <int R, int NC, class Src, class Post, bool BM, int TH = 64>
 __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post, int w, int h,
                                                 int pitch, Taps<R> taps, BorderScale bsx,
                                                 BorderScale bsy, BlockMaxOut bm) {
   constexpr int RA = (R + 3) & ~3;
   constexpr int IW = T2 + 2 * RA;   // staged columns, multiple of 4
-  constexpr int IH = T2 + 2 * R;    // staged rows
+  constexpr int IH = TH + 2 * R;    // staged rows (TH = tile height: 64, or 32 for small images)
+  constexpr int VPTt = TH / 4;      // column-pass outputs per thread
   constexpr int OFF = RA - R;       // window offset inside the aligned row
   __shared__ __attribute__((aligned(16))) float tile[IH][IW];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * T2, y0 = blockIdx.y * T2;
-  const bool interior = x0 >= RA && x0 + T2 + RA <= w && y0 >= R && y0 + T2 + R <= h &&
+  const int x0 = blockIdx.x * T2, y0 = blockIdx.y * TH;
+  const bool interior = x0 >= RA && x0 + T2 + RA <= w && y0 >= R && y0 + TH + R <= h &&
                         (pitch & 3) == 0;
   const int tx = tid & 63, tg = tid >> 6;   // column pass: lane = column, wave = row group
   const int hq = (tid & 15) * 4, hr = tid >> 4;   // row pass: 4 columns, rows hr + 16k
-  float acc[NC][VPT];
+  float acc[NC][VPTt];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const Src s = src.s[c];
@@ -367,11 +370,11 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
       }
       __syncthreads();
       // ---- column pass (pre-scaled taps)
-      float win[VPT + 2 * R];
+      float win[VPTt + 2 * R];
 #pragma unroll
-      for (int i = 0; i < VPT + 2 * R; ++i) win[i] = tile[tg * VPT + i][tx];
+      for (int i = 0; i < VPTt + 2 * R; ++i) win[i] = tile[tg * VPTt + i][tx];
 #pragma unroll
-      for (int i = 0; i < VPT; ++i) {
+      for (int i = 0; i < VPTt; ++i) {
         float sum = 0.0f;
 #pragma unroll
         for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.ks[j];
@@ -411,8 +414,8 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < VPT; ++i) {
-        const int ly = tg * VPT + i;
+      for (int i = 0; i < VPTt; ++i) {
+        const int ly = tg * VPTt + i;
         const int y = y0 + ly;
         float sum = 0.0f;
         if (y < h) {
@@ -431,10 +434,10 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
     }
   }
   const int x = x0 + tx;
-  float res[VPT];
+  float res[VPTt];
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
-    const int y = y0 + tg * VPT + i;
+  for (int i = 0; i < VPTt; ++i) {
+    const int y = y0 + tg * VPTt + i;
     res[i] = 0.0f;
     if (x < w && y < h) {
       float v[NC];
@@ -447,9 +450,9 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
     __shared__ float s_bmax[64];
     __syncthreads();   // all column reads of the last plane are done
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) tile[tg * VPT + i][tx] = res[i];
+    for (int i = 0; i < VPTt; ++i) tile[tg * VPTt + i][tx] = res[i];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 8 * (TH / 8)) {
       const int bxl = threadIdx.x & 7, byl = threadIdx.x >> 3;
       float m = 0.0f;
       for (int yy = 0; yy < 8; ++yy)
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
     __syncthreads();
     if (threadIdx.x == 0) {
       float m = 0.0f;
-      for (int i = 0; i < 64; ++i) m = s_bmax[i] > m ? s_bmax[i] : m;
+      for (int i = 0; i < 8 * (TH / 8); ++i) m = s_bmax[i] > m ? s_bmax[i] : m;
       atomicMax(bm.image_max_bits, __float_as_uint(m));
     }
   }

@@ -141,24 +141,48 @@ struct MaltaArgs {
 // grid = (ceil(w/MW), ceil(h/MH))
 template <int NPASS>
 __global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a, int w, int h, int pitch) {
-  __shared__ float tile[MH + 8][MW + 8];
+  __shared__ __attribute__((aligned(16))) float tile[MH + 8][MW + 8];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
   float acc[MPT];
 #pragma unroll
   for (int i = 0; i < MPT; ++i) acc[i] = 0.0f;
+  // the haloed tile starts at x0 - 4: rows can be staged with aligned 16-byte loads when the
+  // tile lies inside the image horizontally and the pitch allows it
+  const bool vec = x0 >= 4 && x0 + MW + 4 <= w && (pitch & 3) == 0;
   for (int ps = 0; ps < NPASS; ++ps) {
     const MaltaPass P = a.pass[ps];
     if (ps > 0) __syncthreads();
-    for (int i = threadIdx.x; i < (MH + 8) * (MW + 8); i += 256) {
-      const int ry = i / (MW + 8), rx = i - ry * (MW + 8);
-      const int x = x0 - 4 + rx, y = y0 - 4 + ry;
-      float v = 0.0f;
-      if (x >= 0 && x < w && y >= 0 && y < h) {
-        const size_t idx = (size_t)y * pitch + x;
-        v = malta_diff(P.p0[idx], P.p1[idx], P.nm);
+    if (vec) {
+      constexpr int NV = (MH + 8) * ((MW + 8) / 4);   // 16-byte vectors in the tile
+#pragma unroll 1
+      for (int k = 0; k < (NV + 255) / 256; ++k) {
+        const int i = 256 * k + (int)threadIdx.x;
+        if (i < NV) {
+          const int ry = i / ((MW + 8) / 4), q = i - ry * ((MW + 8) / 4);
+          const int y = y0 - 4 + ry;
+          gz_f4 v;
+          v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
+          if (y >= 0 && y < h) {
+            const size_t idx = (size_t)y * pitch + (x0 - 4 + 4 * q);
+            const gz_f4 u0 = GZ_LDG4(P.p0, idx), u1 = GZ_LDG4(P.p1, idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], P.nm);
+          }
+          *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = v;
+        }
       }
-      tile[ry][rx] = v;
+    } else {
+      for (int i = threadIdx.x; i < (MH + 8) * (MW + 8); i += 256) {
+        const int ry = i / (MW + 8), rx = i - ry * (MW + 8);
+        const int x = x0 - 4 + rx, y = y0 - 4 + ry;
+        float v = 0.0f;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+          const size_t idx = (size_t)y * pitch + x;
+          v = malta_diff(P.p0[idx], P.p1[idx], P.nm);
+        }
+        tile[ry][rx] = v;
+      }
     }
     __syncthreads();
 #pragma unroll

@@ -457,9 +457,10 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
   const double wMfMalta = 6841.81248144, norm1Mf = 0.0135134962487;
   const double wMfMaltaX = 813.901703816, norm1MfX = 16792.9322251;
   const float sqrt_asym = sqrtf(hf_asymmetry_);   // float sqrt overload in the reference
-  dim3 mgrid(gz_div_up(c->w, MW), gz_div_up(c->h, MH));
+  dim3 mgrid(gz_div_up(c->w, MW), gz_div_up(c->h, MH), 2);
+  MaltaArgs<3> ay, ax;
   {  // Y channel
-    MaltaArgs<3> a;
+    MaltaArgs<3>& a = ay;
     a.pass[0] = {p0.uhf[1], p1.uhf[1],
                  malta_norm(false, wUhfMalta * hf_asymmetry_, wUhfMalta / hf_asymmetry_, norm1Uhf), 0};
     a.pass[1] = {p0.hf[1], p1.hf[1],
@@ -473,11 +474,9 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.tail.w_0gt1 = (wmul1 * hf_asymmetry_) * 0.8;   // L2DiffAsymmetric: w *= 0.8 (:678-679)
     a.tail.w_0lt1 = (wmul1 / hf_asymmetry_) * 0.8;
     a.out = c->ac[1];
-    GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, a, c->w, c->h, c->pitch);
-    KCHK(c);
   }
   {  // X channel
-    MaltaArgs<3> a;
+    MaltaArgs<3>& a = ax;
     a.pass[0] = {p0.uhf[0], p1.uhf[0],
                  malta_norm(false, wUhfMaltaX * hf_asymmetry_, wUhfMaltaX / hf_asymmetry_, norm1UhfX), 0};
     a.pass[1] = {p0.hf[0], p1.hf[0],
@@ -487,9 +486,9 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.tail.hf0 = a.tail.hf1 = nullptr;
     a.tail.w_sn = a.tail.w_0gt1 = a.tail.w_0lt1 = 0;
     a.out = c->ac[0];
-    GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, a, c->w, c->h, c->pitch);
-    KCHK(c);
   }
+  GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
+  KCHK(c);
   TRY(stage_mask_blurs(c, mask_pack_psycho(c, p0, p1)));
   {
     CombineArgs a;

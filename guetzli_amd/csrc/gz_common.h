@@ -61,6 +61,12 @@ static __device__ __forceinline__ void gz_stg4(float* p, size_t i, const gz_f4& 
 #define GZ_STG4(p, i, val) gz_stg4((p), (i), (val))
 #endif
 
+#ifdef GZ_EMU
+#define GZ_STG(p, i, val) ((p)[i] = (val))
+#else
+#define GZ_STG(p, i, val) (((__attribute__((address_space(1))) float*)(p))[i] = (val))
+#endif
+
 // A value that is the same in every lane of the wavefront (derived from threadIdx.x >> 6):
 // telling the compiler so turns the branches on it into scalar branches.
 #ifdef GZ_EMU

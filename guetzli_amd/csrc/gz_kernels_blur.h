@@ -184,6 +184,48 @@ struct BlockMaxOut {
   int bw;
 };
 
+// Per-8x8-block maxima and image maximum of the tile's results, straight from registers: a
+// thread holds NR consecutive rows of one column (NR a multiple of 8, the tile origin is
+// 8-aligned), i.e. one column of NR/8 blocks; the 8 columns of a block are 8 adjacent lanes.
+// Values are >= 0, so their bit patterns order like the floats.
+template <int NR>
+GZ_DEVFN void block_max_from_registers(const float* res, int tx, int row0, int x0, int y0, int w,
+                                       int h, const BlockMaxOut& bm) {
+  int wave_max = 0;
+#pragma unroll
+  for (int g = 0; g < NR / 8; ++g) {
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = res[8 * g + i] > m ? res[8 * g + i] : m;
+    int bits = (int)__float_as_uint(m);
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      const int o = __shfl(bits, tx ^ d);
+      bits = o > bits ? o : bits;
+    }
+    const int gbx = (x0 + tx) / 8, gby = (y0 + row0) / 8 + g;
+    if ((tx & 7) == 0 && bm.block_max && 8 * gbx < w && 8 * gby < h)
+      bm.block_max[gby * bm.bw + gbx] = __uint_as_float((unsigned)bits);
+    wave_max = bits > wave_max ? bits : wave_max;
+  }
+#pragma unroll
+  for (int d = 8; d < 64; d <<= 1) {
+    const int o = __shfl(wave_max, tx ^ d);
+    wave_max = o > wave_max ? o : wave_max;
+  }
+  // one atomic per workgroup (thousands of atomics on one address serialise in L2)
+  __shared__ int s_wave_max[4];
+  if (tx == 0) s_wave_max[threadIdx.x >> 6] = wave_max;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int m = s_wave_max[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) m = s_wave_max[i] > m ? s_wave_max[i] : m;
+    // the maximum only grows: a workgroup that cannot raise the value it sees skips the atomic
+    if ((unsigned)m > *(volatile unsigned*)bm.image_max_bits) atomicMax(bm.image_max_bits, (unsigned)m);
+  }
+}
+
 template <int R, int NC, class Post, bool BM, int TH = 64>
 __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, int w, int h,
                                                 int pitch, Taps<R> taps, BorderScale bs,
@@ -255,31 +297,7 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
       res[i] = post((size_t)y * pitch + x, v);
     }
   }
-  if (BM) {
-    __shared__ float s_bmax[64];
-    __syncthreads();   // all column reads of the last plane are done
-#pragma unroll
-    for (int i = 0; i < VPTt; ++i) tile[tg * VPTt + i][tx] = res[i];
-    __syncthreads();
-    if (threadIdx.x < 8 * (TH / 8)) {
-      const int bxl = threadIdx.x & 7, byl = threadIdx.x >> 3;
-      float m = 0.0f;
-      for (int yy = 0; yy < 8; ++yy)
-        for (int xx = 0; xx < 8; ++xx) {
-          const float t = tile[8 * byl + yy][8 * bxl + xx];
-          m = t > m ? t : m;
-        }
-      s_bmax[threadIdx.x] = m;
-      const int gbx = x0 / 8 + bxl, gby = y0 / 8 + byl;
-      if (bm.block_max && 8 * gbx < w && 8 * gby < h) bm.block_max[gby * bm.bw + gbx] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float m = 0.0f;
-      for (int i = 0; i < 8 * (TH / 8); ++i) m = s_bmax[i] > m ? s_bmax[i] : m;
-      atomicMax(bm.image_max_bits, __float_as_uint(m));
-    }
-  }
+  if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
 }
 
 // ------------------------------------------------------ fused row + column pass (2-D) --
@@ -446,31 +464,7 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
       res[i] = post((size_t)y * pitch + x, v);
     }
   }
-  if (BM) {
-    __shared__ float s_bmax[64];
-    __syncthreads();   // all column reads of the last plane are done
-#pragma unroll
-    for (int i = 0; i < VPTt; ++i) tile[tg * VPTt + i][tx] = res[i];
-    __syncthreads();
-    if (threadIdx.x < 8 * (TH / 8)) {
-      const int bxl = threadIdx.x & 7, byl = threadIdx.x >> 3;
-      float m = 0.0f;
-      for (int yy = 0; yy < 8; ++yy)
-        for (int xx = 0; xx < 8; ++xx) {
-          const float t = tile[8 * byl + yy][8 * bxl + xx];
-          m = t > m ? t : m;
-        }
-      s_bmax[threadIdx.x] = m;
-      const int gbx = x0 / 8 + bxl, gby = y0 / 8 + byl;
-      if (bm.block_max && 8 * gbx < w && 8 * gby < h) bm.block_max[gby * bm.bw + gbx] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float m = 0.0f;
-      for (int i = 0; i < 8 * (TH / 8); ++i) m = s_bmax[i] > m ? s_bmax[i] : m;
-      atomicMax(bm.image_max_bits, __float_as_uint(m));
-    }
-  }
+  if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
 }
 
 // ------------------------------------------------------------------- post functors --

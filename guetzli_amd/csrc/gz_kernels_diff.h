@@ -138,9 +138,12 @@ struct MaltaArgs {
   float* out;
 };
 
-// grid = (ceil(w/MW), ceil(h/MH))
+// grid = (ceil(w/MW), ceil(h/MH), 2): blockIdx.z = channel (a0: Y, a1: X) -- the two
+// channels are independent, one launch fills the chip better than two
 template <int NPASS>
-__global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a, int w, int h, int pitch) {
+__global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs<NPASS> a1, int w,
+                                               int h, int pitch) {
+  const MaltaArgs<NPASS>& a = blockIdx.z ? a1 : a0;
   __shared__ __attribute__((aligned(16))) float tile[MH + 8][MW + 8];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a, int w, int h,
         float v = 0.0f;
         if (x >= 0 && x < w && y >= 0 && y < h) {
           const size_t idx = (size_t)y * pitch + x;
-          v = malta_diff(P.p0[idx], P.p1[idx], P.nm);
+          v = malta_diff(GZ_LDG(P.p0, idx), GZ_LDG(P.p1, idx), P.nm);
         }
         tile[ry][rx] = v;
       }
@@ -202,12 +205,12 @@ __global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a, int w, int h,
     const size_t idx = (size_t)y * pitch + x;
     float v = acc[i];
     if (a.tail.sn_blur) {
-      const double d = (double)a.tail.sn_blur[idx];
+      const double d = (double)GZ_LDG(a.tail.sn_blur, idx);
       v = (float)((double)v + (a.tail.w_sn * d) * d);
-      v = l2diff_asym_acc(v, a.tail.hf0[idx], a.tail.hf1[idx], a.tail.w_0gt1,
+      v = l2diff_asym_acc(v, GZ_LDG(a.tail.hf0, idx), GZ_LDG(a.tail.hf1, idx), a.tail.w_0gt1,
                           a.tail.w_0lt1);
     }
-    a.out[idx] = v;
+    GZ_STG(a.out, idx, v);
   }
 }
 

@@ -36,3 +36,21 @@ def crop(w, h, x0=0, y0=0):
 def shifted(img, k):
     """C5 batch member k: circular shift by (37k rows, 53k cols)."""
     return np.ascontiguousarray(np.roll(img, (37 * k, 53 * k), axis=(0, 1)))
+
+
+def synthetic(w, h):
+    """A deterministic non-photographic test image (no RNG): smooth gradients, a sinusoidal
+    texture, hard-edged ellipses and a fine checker patch -- content unlike bees.png, to
+    exercise the search on other statistics."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    r = 127.5 + 127.5 * np.sin(x / 37.0) * np.cos(y / 53.0)
+    g = 255.0 * (x / max(w - 1, 1)) * 0.6 + 60.0 * np.sin((x + 2 * y) / 11.0) ** 2
+    b = 255.0 * (y / max(h - 1, 1))
+    for cx, cy, rx, ry, col in ((0.3, 0.4, 0.18, 0.12, (230, 40, 60)), (0.7, 0.6, 0.1, 0.2, (20, 200, 120)),
+                                (0.55, 0.25, 0.07, 0.07, (250, 250, 250))):
+        m = ((x - cx * w) / (rx * w)) ** 2 + ((y - cy * h) / (ry * h)) ** 2 < 1.0
+        r[m], g[m], b[m] = col
+    ck = (x > 0.8 * w) & (y < 0.25 * h)
+    v = 255.0 * (((x.astype(np.int64) // 2) + (y.astype(np.int64) // 2)) % 2)
+    r[ck], g[ck], b[ck] = v[ck], v[ck], 255.0 - v[ck]
+    return np.ascontiguousarray(np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8))

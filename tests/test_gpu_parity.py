@@ -268,3 +268,26 @@ def test_concurrent_encodes_on_one_gpu_are_deterministic():
     con = [j for j, _ in encode_concurrent(imgs, proc, workers=3)]
     assert con == seq
     assert len(set(seq)) == len(seq)   # they really are different images
+
+
+def _golden_cases():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_hashes.json")
+    return sorted(json.load(open(path)).items())
+
+
+@pytest.mark.parametrize("key,exp", _golden_cases())
+def test_whole_encode_golden_hashes(key, exp):
+    """Whole encodes against hashes the UNMODIFIED reference produced (tools/gen_golden_hashes.py,
+    minutes of CPU each): odd sizes (width not a multiple of 4 or 8 -> the kernels' generic
+    paths), other qualities, and a synthetic image with statistics unlike bees.png."""
+    import hashlib
+    import guetzli_amd
+    kind, size, q = key.split("_")
+    w, h = (int(v) for v in size.split("x"))
+    rgb = images.tiled(w, h) if kind == "tiled" else images.synthetic(w, h)
+    assert hashlib.sha256(rgb.tobytes()).hexdigest() == exp["rgb_sha256"]
+    jpg, _ = guetzli_amd.process(rgb, quality=float(q[1:]))
+    assert len(jpg) == exp["bytes"]
+    assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]

@@ -153,6 +153,10 @@ struct gz_ctx {
   float target = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // second stream for the branch of Compare that does not depend on the Malta path (the
+  // mask: DiffPrecompute + three blurs), forked and joined with events
+  hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
   std::string err;
 
   uint8_t* d_rgb = nullptr;
@@ -401,7 +405,7 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk) {
   KCHK(c);
   {  // X: sigma r2 = 9.24 ; Y second: sigma r1 = 9.04 -- both radius 20, separate taps
     SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
-    s.s[0].p = c->diffx; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    s.s[0].p = c->diffx; t.p[0] = c->tmp[1]; ct.p[0] = c->tmp[1];
     TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKX])));
     PostStore<1> post; post.out[0] = c->mxb;
     TRY((blur_v<20, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKX])));
@@ -413,7 +417,7 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk) {
   }
   {
     SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
-    s.s[0].p = c->diffy; t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    s.s[0].p = c->diffy; t.p[0] = c->tmp[2]; ct.p[0] = c->tmp[2];
     TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKY1])));
     PostStore<1> post; post.out[0] = c->myb2;
     TRY((blur_v<20, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKY1])));
@@ -439,17 +443,44 @@ MaskPrePack mask_pack_psycho(gz_ctx* c, const Psycho& a, const Psycho& b) {
   return pk;
 }
 
-// DiffmapPsychoImage (butteraugli.cc:817-908) + score: p0 = original, p1 = candidate.
-int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block_max) {
-  const float hf_asymmetry_ = 0.8f;
+// The SameNoise blur and the mask branch (DiffPrecompute + three blurs; scratch planes
+// tmp[0..2], snb, diffx, diffy, mxb, myb1, myb2) read only the two PsychoImages, so they run
+// on the side stream while the main stream does Malta; k_combine needs both.  At 1080p a launch is
+// ~1000 workgroups for 256 CUs and the kernels are latency-bound: the overlap is worth ~10 %.
+int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+  HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_fork, 0));
+  hipStream_t main_stream = c->stream;
+  int rc = GZ_OK;
+  c->stream = c->side_stream2;
   {  // SameNoiseLevels blur input + blur (sigma 10.67)
     SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].a = p0.hf[1]; s.s[0].b = p1.hf[1];
     t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
-    TRY((blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN])));
+    rc = blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN]);
     PostStore<1> post; post.out[0] = c->snb;
-    TRY((blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN])));
+    if (rc == GZ_OK) rc = blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN]);
   }
+  c->stream = c->side_stream;
+  if (rc == GZ_OK) rc = stage_mask_blurs(c, mask_pack_psycho(c, p0, p1));
+  c->stream = main_stream;
+  TRY(rc);
+  HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+  HIPCHK(c, hipEventRecord(c->ev_join2, c->side_stream2));
+  return GZ_OK;
+}
+int join_mask_branch(gz_ctx* c) {
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+  return GZ_OK;
+}
+
+// DiffmapPsychoImage (butteraugli.cc:817-908) + score: p0 = original, p1 = candidate.
+int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block_max) {
+  const float hf_asymmetry_ = 0.8f;
+  // side stream: SameNoise blur + the mask branch; main stream: Malta
+  TRY(fork_side_branch(c, p0, p1));
   const double wUhfMalta = 5.1409625726, norm1Uhf = 58.5001247061;
   const double wUhfMaltaX = 4.91743441556, norm1UhfX = 687196.39002;
   const double wHfMalta = 153.671655716, norm1Hf = 83150785.9592;
@@ -466,13 +497,6 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[1] = {p0.hf[1], p1.hf[1],
                  malta_norm(true, wHfMalta * sqrt_asym, wHfMalta / sqrt_asym, norm1Hf), 1};
     a.pass[2] = {p0.mf[1], p1.mf[1], malta_norm(true, wMfMalta, wMfMalta, norm1Mf), 1};
-    const double wmul1 = 32.4449876135;
-    a.tail.sn_blur = c->snb;
-    a.tail.hf0 = p0.hf[1];
-    a.tail.hf1 = p1.hf[1];
-    a.tail.w_sn = 884.809801415;
-    a.tail.w_0gt1 = (wmul1 * hf_asymmetry_) * 0.8;   // L2DiffAsymmetric: w *= 0.8 (:678-679)
-    a.tail.w_0lt1 = (wmul1 / hf_asymmetry_) * 0.8;
     a.out = c->ac[1];
   }
   {  // X channel
@@ -482,14 +506,11 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[1] = {p0.hf[0], p1.hf[0],
                  malta_norm(true, wHfMaltaX * sqrt_asym, wHfMaltaX / sqrt_asym, norm1HfX), 1};
     a.pass[2] = {p0.mf[0], p1.mf[0], malta_norm(true, wMfMaltaX, wMfMaltaX, norm1MfX), 1};
-    a.tail.sn_blur = nullptr;
-    a.tail.hf0 = a.tail.hf1 = nullptr;
-    a.tail.w_sn = a.tail.w_0gt1 = a.tail.w_0lt1 = 0;
     a.out = c->ac[0];
   }
   GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);
-  TRY(stage_mask_blurs(c, mask_pack_psycho(c, p0, p1)));
+  TRY(join_mask_branch(c));
   {
     CombineArgs a;
     a.mask_x_blur = c->mxb; a.mask_y_blur1 = c->myb1; a.mask_y_blur2 = c->myb2;
@@ -497,6 +518,13 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.lf0_x = p0.lfv[0]; a.lf1_x = p1.lfv[0];
     a.lf0_b = p0.lfv[2]; a.lf1_b = p1.lfv[2];
     a.luts = c->d_mask_luts;
+    const double wmul1 = 32.4449876135;
+    a.sn_blur = c->snb;
+    a.hf0_y = p0.hf[1];
+    a.hf1_y = p1.hf[1];
+    a.w_sn = 884.809801415;
+    a.w_0gt1 = (wmul1 * hf_asymmetry_) * 0.8;   // L2DiffAsymmetric: w *= 0.8 (:678-679)
+    a.w_0lt1 = (wmul1 / hf_asymmetry_) * 0.8;
     a.out = c->dsq;
     for (int i = 0; i < 3; ++i) a.mask_out[i] = a.mask_dc_out[i] = nullptr;
     dim3 grid(gz_div_up(c->w, 256), c->h);
@@ -703,6 +731,11 @@ gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, in
 #define CHK0(call) do { if ((call) != hipSuccess) { return fail(GZ_E_HIP); } } while (0)
   CHK0(hipStreamCreate(&c->own_stream));
   c->stream = c->own_stream;
+  CHK0(hipStreamCreate(&c->side_stream));
+  CHK0(hipStreamCreate(&c->side_stream2));
+  CHK0(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  CHK0(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  CHK0(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
   const size_t ncoef = (size_t)3 * c->nb * 64;
   CHK0(hipMalloc((void**)&c->d_rgb, (size_t)3 * w * h));
   CHK0(hipMalloc((void**)&c->d_orig, ncoef * 2));
@@ -784,6 +817,11 @@ void gz_destroy(gz_ctx* c) {
   hipFree(c->d_order_counters); hipFree(c->d_next_cand); hipFree(c->d_weight);
   hipFree(c->d_max_err); hipFree(c->d_wflag); hipFree(c->d_edit_pos); hipFree(c->d_edit_val);
   for (int b = 0; b < B_COUNT; ++b) hipFree(c->blur[b].d_scale);
+  if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+  if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); (void)hipStreamDestroy(c->side_stream2); }
+  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }

@@ -122,19 +122,9 @@ GZ_DEVFN float malta_unit(const float (*t)[MW + 8], int ly, int lx) {
   return ret;
 }
 
-struct MaltaTail {
-  // Y channel only (null for X): SameNoiseLevels second half (butteraugli.cc:644-651) and
-  // L2DiffAsymmetric on HF-Y (:672-714).
-  const float* sn_blur;
-  const float* hf0;
-  const float* hf1;
-  double w_sn, w_0gt1, w_0lt1;
-};
-
 template <int NPASS>
 struct MaltaArgs {
   MaltaPass pass[NPASS];
-  MaltaTail tail;
   float* out;
 };
 
@@ -203,13 +193,7 @@ __global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs<NP
     const int y = y0 + tg * MPT + i;
     if (y >= h) break;
     const size_t idx = (size_t)y * pitch + x;
-    float v = acc[i];
-    if (a.tail.sn_blur) {
-      const double d = (double)GZ_LDG(a.tail.sn_blur, idx);
-      v = (float)((double)v + (a.tail.w_sn * d) * d);
-      v = l2diff_asym_acc(v, GZ_LDG(a.tail.hf0, idx), GZ_LDG(a.tail.hf1, idx), a.tail.w_0gt1,
-                          a.tail.w_0lt1);
-    }
+    const float v = acc[i];
     GZ_STG(a.out, idx, v);
   }
 }
@@ -227,6 +211,13 @@ struct CombineArgs {
   const float* lf1_x;
   const float* lf0_b;         // pi0.lf[2] / pi1.lf[2]
   const float* lf1_b;
+  // Y channel only: SameNoiseLevels second half (butteraugli.cc:644-651) and L2DiffAsymmetric
+  // on HF-Y (:672-714), added to block_diff_ac[1] after its three Malta passes.  Applied here
+  // rather than in k_malta so that Malta does not wait for the SameNoise blur.
+  const float* sn_blur;       // may be null: ac1 is used as is
+  const float* hf0_y;
+  const float* hf1_y;
+  double w_sn, w_0gt1, w_0lt1;
   const double* luts;         // [4][512]: MaskX, MaskY, MaskDcX, MaskDcY
   float* out;                 // sqrt-stage diffmap (input of the final blur)
   float* mask_out[3];         // optional: mask planes (block search / probes), may be null
@@ -273,7 +264,13 @@ __global__ __launch_bounds__(256) void k_combine(CombineArgs a, int w, int h, in
   const float dc0 = l2diff_acc(0.0f, a.lf0_x[i], a.lf1_x[i], 1.01370836411);
   const float dc1 = 0.0f;
   const float dc2 = l2diff_acc(0.0f, a.lf0_b[i], a.lf1_b[i], 1.74566011615);
-  const float ac0 = a.ac0[i], ac1 = a.ac1[i], ac2 = 0.0f;
+  const float ac0 = a.ac0[i], ac2 = 0.0f;
+  float ac1 = a.ac1[i];
+  if (a.sn_blur) {
+    const double d = (double)a.sn_blur[i];
+    ac1 = (float)((double)ac1 + (a.w_sn * d) * d);
+    ac1 = l2diff_asym_acc(ac1, a.hf0_y[i], a.hf1_y[i], a.w_0gt1, a.w_0lt1);
+  }
   const float m2 = (float)(w_ytob_hf * my);
   // CombineChannels: DotProduct(diff_dc, dc_mask) + DotProduct(diff_ac, mask)
   const float sdc = (dc0 * mdc0 + dc1 * mdc1) + dc2 * mdc2;

@@ -51,8 +51,9 @@ QUALITY = 95.0
 TARGET_Q95 = 0.971769              # ButteraugliScoreForQuality(95), quality.cc:31-85
 W, H = 1920, 1080
 GOLDEN_SHA_1080P_Q95 = "9c0eb414b8e73f4372c0b089eafe2350e6ff2ae83926d1c0c5f35cb5f7919729"
-CHAIN = ("butteraugli Compare chain (18 launches per Compare: k_reconstruct, 5 fused k_blur2d "
-         "(radius < 16), 4 k_blur_h + 4 k_blur_v (radius >= 16), 2 k_malta, k_mask_pre, k_combine)")
+CHAIN = ("butteraugli Compare chain (17 launches per Compare on 3 streams: k_reconstruct, 5 fused "
+         "k_blur2d (radius < 16), 4 k_blur_h + 4 k_blur_v (radius >= 16), k_malta (both channels), "
+         "k_mask_pre, k_combine)")
 
 
 def cpu_baseline():
@@ -164,7 +165,7 @@ def main():
                          "reference JPEG"}
     traffic = {}
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v2.json")))
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v3.json")))
     except Exception:
         pass
 

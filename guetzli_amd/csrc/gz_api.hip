@@ -447,7 +447,20 @@ MaskPrePack mask_pack_psycho(gz_ctx* c, const Psycho& a, const Psycho& b) {
 // tmp[0..2], snb, diffx, diffy, mxb, myb1, myb2) read only the two PsychoImages, so they run
 // on the side stream while the main stream does Malta; k_combine needs both.  At 1080p a launch is
 // ~1000 workgroups for 256 CUs and the kernels are latency-bound: the overlap is worth ~10 %.
+static bool single_stream() {   // GZ_SINGLE_STREAM=1: no overlap, for per-kernel profiling
+  static const char* e = getenv("GZ_SINGLE_STREAM");
+  return e && atoi(e) != 0;
+}
 int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
+  if (single_stream()) {
+    SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
+    s.s[0].a = p0.hf[1]; s.s[0].b = p1.hf[1];
+    t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    TRY((blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN])));
+    PostStore<1> post; post.out[0] = c->snb;
+    TRY((blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN])));
+    return stage_mask_blurs(c, mask_pack_psycho(c, p0, p1));
+  }
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
   HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_fork, 0));
@@ -471,6 +484,7 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
   return GZ_OK;
 }
 int join_mask_branch(gz_ctx* c) {
+  if (single_stream()) return GZ_OK;
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
   return GZ_OK;

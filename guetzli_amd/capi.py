@@ -31,6 +31,7 @@ SIGNATURES = {
     "gz_synchronize": (_I, [_P]),
     "gz_set_stream": (_I, [_P, _P]),
     "gz_encode_rgb": (_I, [_P, _P]),
+    "gz_encode_rgb_only": (_I, [_I, _P, _I, _I, _P]),
     "gz_set_orig_coeffs": (_I, [_P, _P]),
     "gz_quantize": (_I, [_P, _P, _P]),
     "gz_set_coeffs": (_I, [_P, _P]),
@@ -115,6 +116,15 @@ class Library:
         b = np.ascontiguousarray(blocks, np.int16).reshape(-1, 64).copy()
         self.check(self.lib.gz_probe_fdct_blocks(device, _ptr(b), b.shape[0]))
         return b
+
+    def encode_rgb_only(self, rgb, device=0):
+        """EncodeRGBToJpeg's transform (q = 1) without a context, any size >= 1x1."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        h, w, _ = rgb.shape
+        nb = ((w + 7) // 8) * ((h + 7) // 8)
+        out = np.zeros((3, nb, 64), np.int16)
+        self.check(self.lib.gz_encode_rgb_only(device, _ptr(rgb), w, h, _ptr(out)))
+        return out
 
     def dct_double_blocks(self, blocks, inverse=False, device=0):
         """ComputeBlockDCTDouble / ComputeBlockIDCTDouble (dct_double.cc:76-85) per block."""

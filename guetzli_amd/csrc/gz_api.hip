@@ -1520,6 +1520,23 @@ struct DevBuf {   // scoped device allocation for the context-free entry points
 };
 }  // namespace
 
+int gz_encode_rgb_only(int device, const uint8_t* rgb, int w, int h, int16_t* coeffs_out) {
+  if (!rgb || !coeffs_out || w <= 0 || h <= 0 || w >= (1 << 16) || h >= (1 << 16)) return GZ_E_ARG;
+  if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8, nb = bw * bh;
+  DevBuf drgb, dco;
+  if (!drgb.alloc((size_t)3 * w * h) || !dco.alloc((size_t)3 * nb * 128)) return GZ_E_NOMEM;
+  if (hipMemcpy(drgb.p, rgb, (size_t)3 * w * h, hipMemcpyHostToDevice) != hipSuccess) return GZ_E_HIP;
+  const uint8_t* d_rgb = (const uint8_t*)drgb.p;
+  int16_t* d_co = (int16_t*)dco.p;
+  GZ_LAUNCH(k_encode_rgb, dim3(gz_div_up(nb, kBlocksPerWG)), dim3(256), (hipStream_t)0, d_rgb, w, h,
+            bw, nb, d_co);
+  if (hipGetLastError() != hipSuccess) return GZ_E_HIP;
+  if (hipMemcpy(coeffs_out, dco.p, (size_t)3 * nb * 128, hipMemcpyDeviceToHost) != hipSuccess)
+    return GZ_E_HIP;
+  return GZ_OK;
+}
+
 int gz_dct_double_blocks(int device, double* blocks, int n, int inverse) {
   if (!blocks || n <= 0) return GZ_E_ARG;
   if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;

@@ -693,10 +693,20 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   bw_ = (w + 7) / 8; bh_ = (h + 7) / 8; nb_ = bw_ * bh_;
   if (w < 32 || h < 32) {
     // "image too small for Butteraugli" (processor.cc:832-838, :940): the reference emits
-    // the unquantised JPEG; that needs the forward DCT only.  Images this small are not a
-    // GPU workload; refuse rather than add a CPU path.
-    fprintf(stderr, "guetzli_amd: images smaller than 32x32 are not supported\n");
-    return false;
+    // the unquantised JPEG of EncodeRGBToJpeg; the forward transform runs on the device.
+    if (w < 1 || h < 1) {
+      fprintf(stderr, "Could not create jpg data from rgb pixels\n");
+      return false;
+    }
+    orig_.resize((size_t)3 * nb_ * 64);
+    const int rc0 = gz_encode_rgb_only(params_.device, rgb.data(), w, h, orig_.data());
+    if (rc0 != GZ_OK) return Fail("gz_encode_rgb_only", rc0);
+    Frame f;
+    FrameFromOriginal(orig_.data(), w, h, &f);
+    if (!WriteJpeg(f, out)) return Fail("WriteJpeg", GZ_E_STATE);
+    Log("Original Out[%7zd]", out->size());
+    Log(" <image too small for Butteraugli>\n");
+    return true;
   }
   int err = 0;
   ctx_ = gz_create(params_.device, w, h, rgb.data(), params_.butteraugli_target, &err);

@@ -72,6 +72,11 @@ int gz_set_stream(gz_ctx* ctx, void* hip_stream);
  * copied to the host. */
 int gz_encode_rgb(gz_ctx* ctx, int16_t* coeffs_out);
 
+/* The same transform without a context, for images too small for butteraugli (w or h < 32:
+ * Process() emits the unquantised JPEG, processor.cc:832-838, and gz_create needs >= 8):
+ * rgb w*h*3 -> coeffs [3][nb][64].  0 < w, h < 65536. */
+int gz_encode_rgb_only(int device, const uint8_t* rgb, int w, int h, int16_t* coeffs_out);
+
 /* Upload original (unquantised) coefficients computed elsewhere (JPEG input path:
  * JPEGData after RemoveOriginalQuantization, processor.cc:84-97). */
 int gz_set_orig_coeffs(gz_ctx* ctx, const int16_t* coeffs);

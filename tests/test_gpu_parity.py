@@ -291,3 +291,19 @@ def test_whole_encode_golden_hashes(key, exp):
     jpg, _ = guetzli_amd.process(rgb, quality=float(q[1:]))
     assert len(jpg) == exp["bytes"]
     assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]
+
+
+@pytest.mark.parametrize("wh", [(24, 40), (31, 64), (1, 1)])
+def test_small_images_emit_the_unquantised_jpeg(wh):
+    """w or h < 32 (no butteraugli, processor.cc:832-838): the forward transform runs on the
+    device through gz_encode_rgb_only; bytes equal the reference's when oracle/_ref is present,
+    else the oracle restatement's coefficients through the host writer."""
+    import guetzli_amd
+    w, h = wh
+    rgb = images.crop(w, h, 200, 100)
+    jpg, _ = guetzli_amd.process(rgb, quality=95)
+    if ref is not None:
+        exp, _ = ref.process(rgb, ref._butteraugli_score_for_quality(95.0))
+        assert jpg == exp
+    host = guetzli_amd.load_host()
+    assert jpg == host.write_jpeg(oracle.encode_rgb(rgb), w, h, None)

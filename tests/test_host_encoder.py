@@ -83,3 +83,17 @@ def test_whole_encode_matches_reference_in_emulation(host_emu, case, monkeypatch
     assert len(exp_lines) == len(got_lines)
     assert hashlib.sha256(got_jpg).hexdigest() == hashlib.sha256(exp_jpg).hexdigest()
     assert info["counters"]["number of iterations"] >= 3
+
+
+@needs_ref
+@pytest.mark.parametrize("wh", [(24, 40), (31, 64), (8, 8), (1, 1), (5, 3)])
+def test_small_images_emit_the_unquantised_jpeg(host_emu, wh):
+    """w or h < 32: no butteraugli; Process() returns the q = 1 JPEG of EncodeRGBToJpeg
+    (processor.cc:832-838).  Same bytes and trace as the reference."""
+    w, h = wh
+    rgb = images.crop(w, h, 200, 100)
+    target = ref._butteraugli_score_for_quality(95.0)
+    exp_jpg, exp_trace = ref.process(rgb, target, want_trace=True)
+    got_jpg, info = host_emu.process(rgb, quality=95, want_trace=True)
+    assert got_jpg == exp_jpg
+    assert info["trace"] == exp_trace

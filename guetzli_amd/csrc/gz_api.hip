@@ -815,28 +815,28 @@ gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, in
 
 void gz_destroy(gz_ctx* c) {
   if (!c) return;
-  if (c->own_stream) hipStreamSynchronize(c->own_stream);
-  hipFree(c->d_rgb); hipFree(c->d_orig); hipFree(c->d_cand); hipFree(c->d_q);
-  hipFree(c->d_srgb_lut); hipFree(c->d_mask_luts); hipFree(c->d_block_max);
-  hipFree(c->d_max_bits); hipFree(c->d_srgb_out); hipFree(c->arena);
-  hipFree(c->d_blkidx); hipFree(c->d_blkdata);
-  hipFree(c->extra_arena);
-  hipFree(c->d_block_mask); hipFree(c->d_rank_off); hipFree(c->d_rank_idx);
-  hipFree(c->d_out_cnt); hipFree(c->d_out_idx); hipFree(c->d_out_err);
-  hipFree(c->d_jq); hipFree(c->d_hist); hipFree(c->d_code_depth); hipFree(c->d_code_bits);
-  hipFree(c->d_mcu_bits); hipFree(c->d_mcu_off); hipFree(c->d_ff_count);
-  hipFree(c->d_words); hipFree(c->d_words_kept);
-  hipFree(c->d_order); hipFree(c->d_pos_l); hipFree(c->d_pos_r); hipFree(c->d_chunk);
-  hipFree(c->d_part); hipFree(c->d_order_nb); hipFree(c->d_order_off);
-  hipFree(c->d_order_counters); hipFree(c->d_next_cand); hipFree(c->d_weight);
-  hipFree(c->d_max_err); hipFree(c->d_wflag); hipFree(c->d_edit_pos); hipFree(c->d_edit_val);
-  for (int b = 0; b < B_COUNT; ++b) hipFree(c->blur[b].d_scale);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  (void)hipFree(c->d_rgb); (void)hipFree(c->d_orig); (void)hipFree(c->d_cand); (void)hipFree(c->d_q);
+  (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_mask_luts); (void)hipFree(c->d_block_max);
+  (void)hipFree(c->d_max_bits); (void)hipFree(c->d_srgb_out); (void)hipFree(c->arena);
+  (void)hipFree(c->d_blkidx); (void)hipFree(c->d_blkdata);
+  (void)hipFree(c->extra_arena);
+  (void)hipFree(c->d_block_mask); (void)hipFree(c->d_rank_off); (void)hipFree(c->d_rank_idx);
+  (void)hipFree(c->d_out_cnt); (void)hipFree(c->d_out_idx); (void)hipFree(c->d_out_err);
+  (void)hipFree(c->d_jq); (void)hipFree(c->d_hist); (void)hipFree(c->d_code_depth); (void)hipFree(c->d_code_bits);
+  (void)hipFree(c->d_mcu_bits); (void)hipFree(c->d_mcu_off); (void)hipFree(c->d_ff_count);
+  (void)hipFree(c->d_words); (void)hipFree(c->d_words_kept);
+  (void)hipFree(c->d_order); (void)hipFree(c->d_pos_l); (void)hipFree(c->d_pos_r); (void)hipFree(c->d_chunk);
+  (void)hipFree(c->d_part); (void)hipFree(c->d_order_nb); (void)hipFree(c->d_order_off);
+  (void)hipFree(c->d_order_counters); (void)hipFree(c->d_next_cand); (void)hipFree(c->d_weight);
+  (void)hipFree(c->d_max_err); (void)hipFree(c->d_wflag); (void)hipFree(c->d_edit_pos); (void)hipFree(c->d_edit_val);
+  for (int b = 0; b < B_COUNT; ++b) (void)hipFree(c->blur[b].d_scale);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
   if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); (void)hipStreamDestroy(c->side_stream2); }
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -912,7 +912,7 @@ int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int1
   for (int i = 0; i < n; ++i)
     if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;
   if ((size_t)n > c->blkidx_cap) {
-    hipFree(c->d_blkidx); hipFree(c->d_blkdata);
+    (void)hipFree(c->d_blkidx); (void)hipFree(c->d_blkdata);
     c->d_blkidx = nullptr; c->d_blkdata = nullptr;
     c->blkidx_cap = std::max<size_t>((size_t)n, std::min<size_t>((size_t)c->nb, 2 * c->blkidx_cap + 1024));
     HIPCHK(c, hipMalloc((void**)&c->d_blkidx, sizeof(int32_t) * c->blkidx_cap));
@@ -990,13 +990,13 @@ int gz_time_compare(gz_ctx* c, int iters, float* total_ms) {
   HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipEventSynchronize(e1));
   HIPCHK(c, hipEventElapsedTime(total_ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return GZ_OK;
 }
 
 // ComputeBlockErrorAdjustmentWeights, butteraugli_comparator.cc:521-557 (the per-block
-// maxima of :505-520 come from k_block_max).  O(nb) host work on nb floats.
+// maxima of :505-520 come out of the final blur kernel).  O(nb) host work on nb floats.
 int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target_mul,
                      int use_distmap, float* block_weight) {
   if (!c || !block_weight || max_block_dist < 0) return GZ_E_ARG;
@@ -1293,7 +1293,7 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   const unsigned long long nbytes = (total_bits + 7) / 8;
   const size_t need_words = (size_t)(nbytes / 4 + 4);
   if (need_words > c->words_cap) {
-    hipFree(c->d_words);
+    (void)hipFree(c->d_words);
     c->d_words = nullptr;
     c->words_cap = need_words + need_words / 4 + 1024;
     HIPCHK(c, hipMalloc((void**)&c->d_words, sizeof(unsigned) * c->words_cap));
@@ -1323,7 +1323,7 @@ int gz_jpeg_scan_keep(gz_ctx* c) {
   if (!c->have_scan) { c->err = "no scan to keep"; return GZ_E_STATE; }
   const size_t need_words = (size_t)((c->scan_bits + 7) / 8 / 4 + 4);
   if (need_words > c->words_kept_cap) {
-    hipFree(c->d_words_kept);
+    (void)hipFree(c->d_words_kept);
     c->d_words_kept = nullptr;
     c->words_kept_cap = need_words + need_words / 4 + 1024;
     HIPCHK(c, hipMalloc((void**)&c->d_words_kept, sizeof(unsigned) * c->words_kept_cap));
@@ -1390,8 +1390,8 @@ int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, f
 #undef GZ_BLUR_CASE
 #undef GZ_BLUR_CASE2
   if (rc == GZ_OK) rc = download_plane(c, c->xyb[1], out);
-  hipStreamSynchronize(c->stream);
-  hipFree(cfg.d_scale);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(cfg.d_scale);
   return rc;
 }
 
@@ -1486,12 +1486,12 @@ int gz_probe_idct_blocks(int device, const int16_t* blocks, int n, uint8_t* out)
   if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
   int16_t* d_in = nullptr; uint8_t* d_out = nullptr;
   if (hipMalloc((void**)&d_in, (size_t)n * 128) != hipSuccess) return GZ_E_HIP;
-  if (hipMalloc((void**)&d_out, (size_t)n * 64) != hipSuccess) { hipFree(d_in); return GZ_E_HIP; }
-  hipMemcpy(d_in, blocks, (size_t)n * 128, hipMemcpyHostToDevice);
+  if (hipMalloc((void**)&d_out, (size_t)n * 64) != hipSuccess) { (void)hipFree(d_in); return GZ_E_HIP; }
+  if (hipMemcpy(d_in, blocks, (size_t)n * 128, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_in); (void)hipFree(d_out); return GZ_E_HIP; }
   GZ_LAUNCH(k_idct_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0, d_in, n, d_out);
   int rc = hipGetLastError() == hipSuccess ? GZ_OK : GZ_E_HIP;
   if (hipMemcpy(out, d_out, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
-  hipFree(d_in); hipFree(d_out);
+  (void)hipFree(d_in); (void)hipFree(d_out);
   return rc;
 }
 
@@ -1500,11 +1500,11 @@ int gz_probe_fdct_blocks(int device, int16_t* blocks, int n) {
   if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
   int16_t* d = nullptr;
   if (hipMalloc((void**)&d, (size_t)n * 128) != hipSuccess) return GZ_E_HIP;
-  hipMemcpy(d, blocks, (size_t)n * 128, hipMemcpyHostToDevice);
+  if (hipMemcpy(d, blocks, (size_t)n * 128, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return GZ_E_HIP; }
   GZ_LAUNCH(k_fdct_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0, d, n);
   int rc = hipGetLastError() == hipSuccess ? GZ_OK : GZ_E_HIP;
   if (hipMemcpy(blocks, d, (size_t)n * 128, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
-  hipFree(d);
+  (void)hipFree(d);
   return rc;
 }
 
@@ -1602,15 +1602,20 @@ int gz_probe_arith(int device, int op, const void* a, const void* b, const void*
   const size_t es = (op == 2 || op == 3 || op == 5 || op == 6) ? 8 : 4;
   const size_t os = (op == 2 || op == 3 || op == 5) ? 8 : 4;
   void *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
-  hipMalloc(&da, es * n); hipMalloc(&db, es * n); hipMalloc(&dc, es * n); hipMalloc(&dout, os * n);
-  hipMemcpy(da, a, es * n, hipMemcpyHostToDevice);
-  if (b) hipMemcpy(db, b, es * n, hipMemcpyHostToDevice);
-  if (c) hipMemcpy(dc, c, es * n, hipMemcpyHostToDevice);
+  bool ok = hipMalloc(&da, es * n) == hipSuccess && hipMalloc(&db, es * n) == hipSuccess &&
+            hipMalloc(&dc, es * n) == hipSuccess && hipMalloc(&dout, os * n) == hipSuccess;
+  ok = ok && hipMemcpy(da, a, es * n, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && b) ok = hipMemcpy(db, b, es * n, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && c) ok = hipMemcpy(dc, c, es * n, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
+    return GZ_E_HIP;
+  }
   GZ_LAUNCH(k_probe_arith, dim3(gz_div_up(n, 256)), dim3(256), (hipStream_t)0, op,
             (const void*)da, (const void*)db, (const void*)dc, dout, n);
   int rc = hipGetLastError() == hipSuccess ? GZ_OK : GZ_E_HIP;
   if (hipMemcpy(out, dout, os * n, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
-  hipFree(da); hipFree(db); hipFree(dc); hipFree(dout);
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
   return rc;
 }
 

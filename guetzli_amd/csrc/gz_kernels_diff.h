@@ -280,47 +280,6 @@ __global__ __launch_bounds__(256) void k_combine(CombineArgs a, int w, int h, in
   a.out[i] = v < (1.0f / (kInitialSlope * kInitialSlope)) ? kInitialSlope * v : sqrtf(v);
 }
 
-// ------------------------------------------------------------- block max + image max --
-// One wave per 8x8 block (lane = pixel): per-block maximum of the distance map (first loop
-// of ComputeBlockErrorAdjustmentWeights, butteraugli_comparator.cc:505-520) and the
-// global maximum (ButteraugliScoreFromDiffmap, butteraugli.cc:1623-1633).  max is exact
-// and order-free; values are >= 0 so the float order equals the order of their bits.
-__global__ __launch_bounds__(256) void k_block_max(const float* __restrict__ dm, int w,
-                                                   int h, int pitch, int bw, int nb,
-                                                   float* __restrict__ block_max,
-                                                   unsigned* __restrict__ global_max_bits) {
-  __shared__ float s[256];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int blk = blockIdx.x * 4 + wave;
-  float v = 0.0f;
-  if (blk < nb) {
-    const int x = 8 * (blk % bw) + (lane & 7), y = 8 * (blk / bw) + (lane >> 3);
-    if (x < w && y < h) v = dm[(size_t)y * pitch + x];
-  }
-  s[threadIdx.x] = v;
-  __syncthreads();
-  for (int off = 32; off > 0; off >>= 1) {
-    if (lane < off) {
-      const float o = s[threadIdx.x + off];
-      if (o > s[threadIdx.x]) s[threadIdx.x] = o;
-    }
-    __syncthreads();
-  }
-  if (lane == 0 && blk < nb) {
-    const float m = s[threadIdx.x];
-    if (block_max) block_max[blk] = m;
-    atomicMax(global_max_bits, __float_as_uint(m));
-  }
-}
-
-// Pitched device plane -> packed (w-stride) plane, for host download; and back.
-__global__ __launch_bounds__(256) void k_copy_plane(const float* __restrict__ src,
-                                                    int src_pitch, float* __restrict__ dst,
-                                                    int dst_pitch, int w, int h) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x < w && y < h) dst[(size_t)y * dst_pitch + x] = src[(size_t)y * src_pitch + x];
-}
-
 // Arithmetic self-check (gz_probe_arith).
 __global__ void k_probe_arith(int op, const void* a, const void* b, const void* c, void* out,
                               int n) {

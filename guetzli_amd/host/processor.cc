@@ -223,9 +223,9 @@ class Encoder {
   double best_score_ = -1;
   double t_write_ = 0, t_compare_ = 0, t_quant_ = 0, t_blocksearch_ = 0, t_phaseb_ = 0,
          t_upload_ = 0;
-  double t_pb_ensure_ = 0, t_pb_fast_ = 0, t_pb_flush_ = 0;
+  double t_pb_ensure_ = 0, t_pb_fast_ = 0;
   long n_fast_ = 0;
-  double t_pb_weights_ = 0, t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
+  double t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0;
   size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device
 };
@@ -535,7 +535,8 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       int changed_coeffs = 0;
       int est_size = prev_size;
       // One step of the reference loop (processor.cc:704-750) without its size estimate:
-      // change one coefficient of block b and keep ac_histo current.
+      // change one coefficient of block b (host mirror + edit list for the device) and keep
+      // ac_histo current.
       const size_t n_order = (size_t)total;
       auto apply_step = [&](size_t i) {
         const int b = sorted[i].first;
@@ -563,7 +564,8 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       // The stopping rule can only fire once changed_coeffs > min_coeffs_to_change, and the
       // size estimate of step i uses the Huffman depths refreshed at the last multiple of 10
       // not above i.  Up to that refresh point nothing the estimate produces is observable,
-      // so those steps only edit coefficients; their histogram effect is applied per block.
+      // so those steps only edit coefficients ("fast steps"); the symbol statistics are
+      // rebuilt once after them.
       {
         const size_t last_needed = std::min<size_t>((size_t)std::max(min_coeffs_to_change, 0), n_order - 1);
         const size_t fast_until = last_needed / 10 * 10;
@@ -572,8 +574,8 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         t_pb_ensure_ += fw.lap();
         // Steps [0, fast_until): only how many steps each block takes matters (the n-th step
         // of a block applies its n-th remaining candidate whatever the key), so they are
-        // applied block by block on the worker pool; each worker keeps its own histogram
-        // delta (sums of +-1 per symbol, order-free).
+        // applied block by block: on the device image by gz_apply_candidate_steps, on the
+        // host mirror by the worker pool.
         std::fill(step_count.begin(), step_count.end(), 0);
         for (size_t i = 0; i < fast_until; ++i) {
           const int b = order[i].first;
@@ -590,14 +592,6 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
           for (size_t di = 0; di < dirty.size(); ++di) counts[di] = step_count[dirty[di]];
           rc = gz_apply_candidate_steps(ctx_, direction, dirty.data(), counts.data(), (int)dirty.size());
           if (rc != GZ_OK) return Fail("gz_apply_candidate_steps", rc);
-          if (getenv("GZ_DEBUG_STEPS")) {
-            std::vector<int16_t> co(img_.size());
-            gz_get_coeffs(ctx_, co.data());
-            size_t nd = 0;
-            for (size_t i = 0; i < co.size(); ++i) nd += co[i] != img_[i];
-            long tot = 0; for (size_t di = 0; di < dirty.size(); ++di) tot += counts[di];
-            fprintf(stderr, "debug: after device steps: %zu coefficients differ from the host mirror (before host edits), %ld steps in %zu blocks, dir %d\n", nd, tot, dirty.size(), direction);
-          }
           // ... while the host mirror is edited block by block on the worker pool
           WorkerPool& pool = WorkerPool::Get();
           const int chunks = dirty.size() < 2048 ? 1 : 4 * pool.size();
@@ -748,14 +742,12 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   stats_->timers["block_search"] = t_blocksearch_;
   stats_->timers["phase_b_host"] = t_phaseb_;
   stats_->timers["block_upload"] = t_upload_;
-  stats_->timers["pb_weights"] = t_pb_weights_;
   stats_->timers["pb_order"] = t_pb_order_;
   stats_->timers["pb_sort"] = t_pb_sort_;
   stats_->timers["pb_loop"] = t_pb_loop_;
   stats_->timers["pb_loop_codes"] = t_pb_codes_;
   stats_->timers["pb_loop_ensure_sorted"] = t_pb_ensure_;
   stats_->timers["pb_loop_fast_steps"] = t_pb_fast_;
-  stats_->timers["pb_loop_flush"] = t_pb_flush_;
   stats_->counters["phase B fast steps"] = (int)n_fast_;
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);

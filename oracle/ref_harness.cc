@@ -33,6 +33,7 @@
 #include "guetzli/gamma_correct.h"
 #include "guetzli/idct.h"
 #include "guetzli/jpeg_data_encoder.h"
+#include "guetzli/jpeg_data_reader.h"
 #include "guetzli/jpeg_data_writer.h"
 #include "guetzli/output_image.h"
 #include "guetzli/quality.h"
@@ -418,6 +419,53 @@ long ref_write_jpeg(const int16_t* coeffs, int w, int h, const int* q, uint8_t* 
   if (!guetzli::WriteJpeg(jpg, true, o)) return -1;
   if ((long)s.size() <= cap) memcpy(out, s.data(), s.size());
   return (long)s.size();
+}
+
+// ReadJpeg(data, JPEG_READ_ALL) as the canonical dump gzh_read_jpeg also produces (see
+// guetzli_amd/host/processor.cc); -1 if the reference rejects the stream.
+long ref_read_jpeg(const uint8_t* data, long len, uint8_t* out, long cap) {
+  guetzli::JPEGData jpg;
+  if (!guetzli::ReadJpeg(data, (size_t)len, guetzli::JPEG_READ_ALL, &jpg)) return -1;
+  std::string d;
+  auto put32 = [&](int32_t v) { d.append((const char*)&v, 4); };
+  auto puts = [&](const std::string& s) { put32((int32_t)s.size()); d.append(s); };
+  put32(jpg.width); put32(jpg.height); put32((int32_t)jpg.components.size());
+  for (const auto& c : jpg.components) {
+    put32(c.id); put32(c.h_samp_factor); put32(c.v_samp_factor); put32((int32_t)c.quant_idx);
+    put32(c.width_in_blocks); put32(c.height_in_blocks);
+  }
+  put32((int32_t)jpg.quant.size());
+  for (const auto& q : jpg.quant) {
+    put32(q.index); put32(q.precision);
+    for (int k = 0; k < 64; ++k) put32(q.values[k]);
+  }
+  put32((int32_t)jpg.app_data.size());
+  for (const auto& a : jpg.app_data) puts(a);
+  put32((int32_t)jpg.com_data.size());
+  for (const auto& a : jpg.com_data) puts(a);
+  puts(jpg.tail_data);
+  for (const auto& c : jpg.components) d.append((const char*)c.coeffs.data(), c.coeffs.size() * 2);
+  if ((long)d.size() <= cap) memcpy(out, d.data(), d.size());
+  return (long)d.size();
+}
+
+// guetzli::Process(params, stats, jpeg_data, &out) (processor.cc:890-924), optional trace.
+long ref_process_jpeg(const uint8_t* data, long len, float butteraugli_target, uint8_t* out,
+                      long cap, char* trace, long trace_cap) {
+  guetzli::Params params;
+  params.butteraugli_target = butteraugli_target;
+  guetzli::ProcessStats stats;
+  std::string dbg;
+  if (trace) stats.debug_output = &dbg;
+  std::string in((const char*)data, (size_t)len), jpg;
+  if (!guetzli::Process(params, &stats, in, &jpg)) return -1;
+  if ((long)jpg.size() <= cap) memcpy(out, jpg.data(), jpg.size());
+  if (trace && trace_cap > 0) {
+    const size_t n = std::min<size_t>(dbg.size(), (size_t)trace_cap - 1);
+    memcpy(trace, dbg.data(), n);
+    trace[n] = 0;
+  }
+  return (long)jpg.size();
 }
 
 }  // extern "C"

@@ -28,6 +28,7 @@ SIGNATURES = {
     "gz_last_error": (C.c_char_p, [_P]),
     "gz_create": (_P, [_I, _I, _I, _P, C.c_float, C.POINTER(_I)]),
     "gz_destroy": (None, [_P]),
+    "gz_set_rgb": (_I, [_P, _P]),
     "gz_synchronize": (_I, [_P]),
     "gz_set_stream": (_I, [_P, _P]),
     "gz_encode_rgb": (_I, [_P, _P]),
@@ -201,6 +202,12 @@ class Context:
 
     def _coeff_buf(self):
         return np.zeros((3, self.nb, 64), np.int16)
+
+    def set_rgb(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        assert rgb.shape == (self.h, self.w, 3)
+        self.rgb = rgb
+        self._chk(self.L.lib.gz_set_rgb(self.handle, _ptr(rgb)))
 
     def synchronize(self):
         self._chk(self.L.lib.gz_synchronize(self.handle))

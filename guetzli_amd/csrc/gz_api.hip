@@ -797,20 +797,25 @@ gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, in
     if (rc != GZ_OK) return fail(rc);
     if (c->blur[b].r != kBlurSpecs[b].r) return fail(GZ_E_STATE);
   }
-  CHK0(hipMemcpy(c->d_rgb, rgb, (size_t)3 * w * h, hipMemcpyHostToDevice));
-  // pi0_ = SeparateFrequencies(OpsinDynamicsImage(LinearRgb(rgb)))
-  {
-    dim3 grid(gz_div_up(w, 256), h);
-    GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, w, h, c->pitch,
-              c->plane, c->d_srgb_lut, c->lin[0]);
-    if (hipGetLastError() != hipSuccess) return fail(GZ_E_HIP);
-    int rc = stage_opsin(c);
-    if (rc == GZ_OK) rc = stage_separate(c, &c->pi0);
-    if (rc != GZ_OK) return fail(rc);
-    CHK0(hipStreamSynchronize(c->stream));
-  }
+  if (gz_set_rgb(c, rgb) != GZ_OK) return fail(GZ_E_HIP);
 #undef CHK0
   return c;
+}
+
+int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
+  if (!c || !rgb) return GZ_E_ARG;
+  HIPCHK(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)3 * c->w * c->h, hipMemcpyHostToDevice, c->stream));
+  // pi0_ = SeparateFrequencies(OpsinDynamicsImage(LinearRgb(rgb)))
+  dim3 grid(gz_div_up(c->w, 256), c->h);
+  GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, c->w, c->h, c->pitch,
+            c->plane, c->d_srgb_lut, c->lin[0]);
+  KCHK(c);
+  TRY(stage_opsin(c));
+  TRY(stage_separate(c, &c->pi0));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_block_mask = false;   // StartBlockComparisons' mask belongs to the old original
+  c->have_distmap = false;
+  return GZ_OK;
 }
 
 void gz_destroy(gz_ctx* c) {

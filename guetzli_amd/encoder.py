@@ -20,6 +20,9 @@ class HostLibrary:
         self.lib.gzh_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_float,
                                          C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
                                          C.c_void_p, C.c_long]
+        self.lib.gzh_process_jpeg.restype = C.c_long
+        self.lib.gzh_process_jpeg.argtypes = [C.c_void_p, C.c_long, C.c_double, C.c_float, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
         self.lib.gzh_write_jpeg.restype = C.c_long
         self.lib.gzh_write_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_long]
@@ -56,6 +59,23 @@ class HostLibrary:
                     timers[k] = float(v)
         return out[:n].tobytes(), {"trace": tr.value.decode() if tr else None,
                                    "timers": timers, "counters": counters}
+
+    def process_jpeg(self, data, quality=95.0, target=None, device=0, clear_metadata=True,
+                     want_trace=False):
+        """guetzli::Process(params, stats, jpeg_data, &out) for a YUV 4:4:4 JPEG.  Returns
+        (jpeg_bytes, trace) or raises if the input is refused (message on stderr)."""
+        buf = np.frombuffer(data, np.uint8)
+        cap = max(4 * len(data), 1 << 20)
+        out = np.zeros(cap, np.uint8)
+        tr = C.create_string_buffer(1 << 24) if want_trace else None
+        n = self.lib.gzh_process_jpeg(buf.ctypes.data, len(data),
+                                      -1.0 if target is not None else float(quality),
+                                      float(target or 0.0), device, int(clear_metadata),
+                                      out.ctypes.data, cap, tr, len(tr) if tr else 0)
+        if n < 0:
+            raise RuntimeError("guetzli_amd.Process(jpeg) failed (see stderr)")
+        assert n <= cap
+        return out[:n].tobytes(), (tr.value.decode() if tr else None)
 
     def write_jpeg(self, coeffs, w, h, q=None):
         """WriteJpeg of dequantised coefficients [3][nb][64] with quant matrices q[3][64];

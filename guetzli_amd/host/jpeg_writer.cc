@@ -328,7 +328,14 @@ void BuildACHistograms(const Frame& f, SymbolHistogram* histo) {
 }
 
 size_t HeaderSize(const Frame& f) {
-  size_t n = 2 + 18 + 4;   // SOI, APP0, DQT marker + length
+  size_t n = 2 + 4;        // SOI, DQT marker + length
+  if (f.meta && !f.meta->strip) {
+    for (const std::string& a : f.meta->app_data) n += 1 + a.size();
+    for (const std::string& a : f.meta->com_data) n += 2 + a.size();
+  } else {
+    n += 18;               // the fixed APP0
+  }
+  if (f.meta) n += f.meta->tail_data.size();   // counted whether or not it is written (:291)
   for (size_t i = 0; i < f.quant.size(); ++i) n += 1 + (f.quant[i].precision ? 2 : 1) * 64;
   n += 10 + 3 * f.ncomp;   // SOF
   n += 4;                  // DHT without the code data
@@ -475,9 +482,21 @@ bool BuildJpegHead(const Frame& f, const SymbolHistogram* dc_histo,
   memset(head->code, 0, sizeof(head->code));
   out->push_back((char)0xff);
   out->push_back((char)0xd8);
-  static const unsigned char kApp0[] = {0xff, 0xe0, 0x00, 0x10, 0x4a, 0x46, 0x49, 0x46, 0x00,
-                                        0x01, 0x01, 0x00, 0x00, 0x01, 0x00, 0x01, 0x00, 0x00};
-  out->append((const char*)kApp0, sizeof(kApp0));
+  if (f.meta && !f.meta->strip) {   // EncodeMetadata (:52-72)
+    for (const std::string& a : f.meta->app_data) {
+      out->push_back((char)0xff);
+      out->append(a);
+    }
+    for (const std::string& a : f.meta->com_data) {
+      out->push_back((char)0xff);
+      out->push_back((char)0xfe);
+      out->append(a);
+    }
+  } else {
+    static const unsigned char kApp0[] = {0xff, 0xe0, 0x00, 0x10, 0x4a, 0x46, 0x49, 0x46, 0x00,
+                                          0x01, 0x01, 0x00, 0x00, 0x01, 0x00, 0x01, 0x00, 0x00};
+    out->append((const char*)kApp0, sizeof(kApp0));
+  }
   {  // DQT (EncodeDQT :74-98)
     size_t len = 2;
     for (size_t i = 0; i < f.quant.size(); ++i) len += 1 + (f.quant[i].precision ? 2 : 1) * 64;
@@ -503,7 +522,7 @@ bool BuildJpegHead(const Frame& f, const SymbolHistogram* dc_histo,
     Push16(out, (size_t)f.width);
     out->push_back((char)nc);
     for (int c = 0; c < nc; ++c) {
-      out->push_back((char)c);
+      out->push_back((char)f.comp_id[c]);
       out->push_back((char)0x11);
       if (f.quant_idx[c] >= (int)f.quant.size()) return false;
       out->push_back((char)f.quant[f.quant_idx[c]].index);
@@ -556,7 +575,7 @@ bool BuildJpegHead(const Frame& f, const SymbolHistogram* dc_histo,
     Push16(out, 6 + 2 * nc);
     out->push_back((char)nc);
     for (int c = 0; c < nc; ++c) {
-      out->push_back((char)c);
+      out->push_back((char)f.comp_id[c]);
       out->push_back((char)((dc_index[c] << 4) | ac_index[c]));
     }
     out->push_back((char)0);
@@ -594,6 +613,7 @@ bool WriteJpeg(const Frame& f, std::string* out) {
   }
   out->push_back((char)0xff);
   out->push_back((char)0xd9);
+  if (f.meta && !f.meta->strip) out->append(f.meta->tail_data);
   return true;
 }
 

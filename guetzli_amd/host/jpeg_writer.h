@@ -55,9 +55,21 @@ struct QuantTable {
   int precision;   // 0: 8 bit, 1: 16 bit
   int index;
 };
+// What a JPEG INPUT contributes to every file written for it (JPEGData fields that
+// WriteJpeg / JpegHeaderSize read, jpeg_data_writer.cc:52-72,269-293,540-553); null for RGB
+// input, whose JPEGData carries only the fixed JFIF APP0 and component ids 0, 1, 2.
+struct FrameMeta {
+  bool strip = true;                    // Params::clear_metadata
+  std::vector<std::string> app_data;    // marker byte + segment
+  std::vector<std::string> com_data;    // segment with its length
+  std::string tail_data;                // bytes after EOI
+};
 struct Frame {
   int width = 0, height = 0, bw = 0, bh = 0;
   int ncomp = 3;
+  int comp_id[3] = {0, 1, 2};           // SaveToJpegData numbers them (output_image.cc:376); the
+                                        // input JPEG as read keeps its own
+  const FrameMeta* meta = nullptr;
   std::vector<int16_t> coeffs[3];    // [nb][64], quantised values (coeff / quant)
   std::vector<QuantTable> quant;
   int quant_idx[3] = {0, 0, 0};
@@ -93,8 +105,9 @@ struct JpegHead {
 bool BuildJpegHead(const Frame& f, const SymbolHistogram* dc_histo,
                    const SymbolHistogram* ac_histo, JpegHead* head);
 
-// WriteJpeg (jpeg_data_writer.cc:540-553) with strip_metadata semantics (a fixed JFIF
-// APP0).  Returns false on an internal inconsistency.
+// WriteJpeg (jpeg_data_writer.cc:540-553): a fixed JFIF APP0 unless the frame carries the
+// metadata of a JPEG input that is to be kept, in which case its APPn / COM segments and its
+// tail follow the reference's order.  Returns false on an internal inconsistency.
 bool WriteJpeg(const Frame& f, std::string* out);
 
 }  // namespace guetzli_amd

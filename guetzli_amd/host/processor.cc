@@ -189,6 +189,7 @@ class Encoder {
   Encoder(const Params& p, ProcessStats* s) : params_(p), stats_(s) {}
   ~Encoder() { if (ctx_) gz_destroy(ctx_); }
   bool Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* out);
+  bool RunJpeg(const std::string& jpeg_data, std::string* out);
 
  private:
   void Log(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -207,6 +208,11 @@ class Encoder {
   bool SelectMatrix(QuantMatrix best);
   bool SelectFrequencyMasking(double target_mul);
   bool SetImageFromQuantization(const QuantMatrix q, bool download);
+  // The tables of a frame of this image: quant matrices q, or null for the "original" (the
+  // q = 1 frame of EncodeRGBToJpeg, or the input JPEG's own tables), plus the metadata a JPEG
+  // input carries into every output.
+  void Tables(const int (*q)[64], int ncomp, Frame* f) const;
+  bool Search(const QuantMatrix first_q, std::string* out);   // ProcessJpegData from :826 on
 
   Params params_;
   ProcessStats* stats_;
@@ -219,6 +225,12 @@ class Encoder {
   JpegHead head_;                // marker segments + codes of the last Serialize
   std::string best_head_;        // GuetzliOutput: head of the best candidate; its scan is
                                  // kept on the device (gz_jpeg_scan_keep)
+  bool jpeg_input_ = false;      // Process(jpeg_data): tables / metadata of the input below
+  FrameMeta meta_;
+  std::vector<QuantTable> in_quant_;
+  int in_quant_idx_[3] = {0, 0, 0};
+  int in_comp_id_[3] = {0, 1, 2};
+  QuantMatrix q_in_;             // the input's quantisation per component (processor.cc:84-97)
   bool verify_ = false;
   bool mirror_valid_ = false;    // img_ mirrors the device image (phase B)          // GZ_VERIFY_ENTROPY=1: cross-check against the host writer
   double best_score_ = -1;
@@ -258,6 +270,19 @@ bool Encoder::Fail(const char* what, int rc) {
   return false;
 }
 
+void Encoder::Tables(const int (*q)[64], int ncomp, Frame* f) const {
+  FrameTables(q, w_, h_, ncomp, f);
+  if (!jpeg_input_) return;
+  f->meta = &meta_;
+  if (q == nullptr) {   // jpg_in as read: its own DQT tables in file order, its component ids
+    f->quant = in_quant_;
+    for (int c = 0; c < 3; ++c) {
+      f->quant_idx[c] = in_quant_idx_[c];
+      f->comp_id[c] = in_comp_id_[c];
+    }
+  }
+}
+
 static bool ChromaAllZero(const SymbolHistogram* dc, const SymbolHistogram* ac) {
   // all DC differences zero (so every DC is zero) and nothing but end-of-block in AC
   for (int c = 1; c < 3; ++c)
@@ -287,13 +312,14 @@ bool Encoder::Serialize(const int (*q)[64], const SymbolHistogram* dc, const Sym
   Frame f;
   // a single component is written when both chroma planes are entirely zero
   // (OutputImage::SaveToJpegData, output_image.cc:348-409); the q=1 original always has 3
-  FrameTables(q, w_, h_, q && ChromaAllZero(dc, ac) ? 1 : 3, &f);
+  Tables(q, q && ChromaAllZero(dc, ac) ? 1 : 3, &f);
   if (!BuildJpegHead(f, dc, ac, &head_)) return Fail("BuildJpegHead", GZ_E_STATE);
   uint64_t scan_bytes = 0;
   const int rc = gz_jpeg_scan(ctx_, head_.ncomp, &head_.depth[0][0][0], &head_.code[0][0][0],
                               &scan_bytes);
   if (rc != GZ_OK) return Fail("gz_jpeg_scan", rc);
   *size = head_.bytes.size() + (size_t)scan_bytes + 2;   // + EOI
+  if (jpeg_input_ && !meta_.strip) *size += meta_.tail_data.size();
   t_write_ += sw.lap();
   if (verify_ && !VerifyAgainstHostWriter(q, *size)) return false;
   return true;
@@ -314,8 +340,20 @@ bool Encoder::VerifyAgainstHostWriter(const int (*q)[64], size_t size) {
     return false;
   }
   Frame f;
-  if (q) FrameFromImage(co.data(), q, w_, h_, &f);
-  else FrameFromOriginal(co.data(), w_, h_, &f);
+  if (q) {
+    FrameFromImage(co.data(), q, w_, h_, &f);
+  } else if (jpeg_input_) {   // the input as read: quantised by its own tables
+    FrameFromImage(co.data(), q_in_, w_, h_, &f);
+    f.ncomp = 3;
+    f.quant = in_quant_;
+    for (int c = 0; c < 3; ++c) {
+      f.quant_idx[c] = in_quant_idx_[c];
+      f.comp_id[c] = in_comp_id_[c];
+    }
+  } else {
+    FrameFromOriginal(co.data(), w_, h_, &f);
+  }
+  if (jpeg_input_) f.meta = &meta_;
   std::string ref;
   WriteJpeg(f, &ref);
   std::string got = head_.bytes;
@@ -326,6 +364,7 @@ bool Encoder::VerifyAgainstHostWriter(const int (*q)[64], size_t size) {
   got.append((const char*)scan.data(), n);
   got.push_back((char)0xff);
   got.push_back((char)0xd9);
+  if (jpeg_input_ && !meta_.strip) got.append(meta_.tail_data);
   if (got != ref || got.size() != size) {
     fprintf(stderr, "guetzli_amd: device entropy coder mismatch (device %zu/%zu bytes, host %zu)\n",
             got.size(), size, ref.size());
@@ -448,7 +487,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   {
     if (!DeviceHistograms(quant_, dc_histo, ac_histo)) return false;
     Frame f;
-    FrameTables(quant_, w_, h_, ChromaAllZero(dc_histo, ac_histo) ? 1 : 3, &f);
+    Tables(quant_, ChromaAllZero(dc_histo, ac_histo) ? 1 : 3, &f);
     header_size = (int)HeaderSize(f);
     SymbolHistogram dcs[3] = {dc_histo[0], dc_histo[1], dc_histo[2]};
     size_t num = f.ncomp;
@@ -667,6 +706,185 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   return true;
 }
 
+bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
+  Stopwatch sw;
+  int rc = GZ_OK;
+  const int w = w_, h = h_;
+  // the original as the fallback output (processor.cc:826-846)
+  verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
+  if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
+  best_score_ = -1;
+  QuantMatrix ones;
+  for (int c = 0; c < 3; ++c)
+    for (int k = 0; k < 64; ++k) ones[c][k] = 1;
+  if (!SetImageFromQuantization(ones, false)) return false;
+  {
+    // symbols of the original: coefficient / its quantiser (1 for RGB input, the input's own
+    // tables for a JPEG input, whose coefficients are held dequantised)
+    SymbolHistogram dc[3], ac[3];
+    size_t size = 0;
+    if (!DeviceHistograms(jpeg_input_ ? q_in_ : ones, dc, ac) || !Serialize(nullptr, dc, ac, &size))
+      return false;
+    Log("Original Out[%7zd]", size);
+    if (!CompareCurrent()) return false;
+    if (!MaybeOutput(size)) return false;
+  }
+
+  QuantMatrix best_q;
+  memcpy(best_q, first_q, sizeof(best_q));
+  if (!SelectMatrix(best_q)) return false;
+  stats_->timers["select_quant_matrix"] = sw.lap();
+  if (!SetImageFromQuantization(best_q, true)) return false;
+  mirror_valid_ = true;
+  if (!SelectFrequencyMasking(1.0)) return false;
+  stats_->timers["select_frequency_masking"] = sw.lap();
+  stats_->timers["jpeg_write"] = t_write_;
+  stats_->timers["compare"] = t_compare_;
+  stats_->timers["quantize"] = t_quant_;
+  stats_->timers["block_search"] = t_blocksearch_;
+  stats_->timers["phase_b_host"] = t_phaseb_;
+  stats_->timers["block_upload"] = t_upload_;
+  stats_->timers["pb_order"] = t_pb_order_;
+  stats_->timers["pb_sort"] = t_pb_sort_;
+  stats_->timers["pb_loop"] = t_pb_loop_;
+  stats_->timers["pb_loop_codes"] = t_pb_codes_;
+  stats_->timers["pb_loop_ensure_sorted"] = t_pb_ensure_;
+  stats_->timers["pb_loop_fast_steps"] = t_pb_fast_;
+  stats_->counters["phase B fast steps"] = (int)n_fast_;
+  stats_->counters["phase B coefficient steps"] = (int)n_steps_;
+  stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
+  {  // the winner: its head from the host, its scan from the device
+    std::vector<uint8_t> scan((size_t)6 * w * h + 4096);
+    size_t n = 0;
+    rc = gz_jpeg_scan_bytes(ctx_, 1, scan.data(), scan.size(), &n);
+    if (rc != GZ_OK) return Fail("gz_jpeg_scan_bytes", rc);
+    *out = best_head_;
+    out->append((const char*)scan.data(), n);
+    out->push_back((char)0xff);
+    out->push_back((char)0xd9);
+    if (jpeg_input_ && !meta_.strip) out->append(meta_.tail_data);
+  }
+  return true;
+}
+
+// libjpeg's colour-space guess for three-component files (jpeg_data_decoder.cc:23-43): JFIF
+// means YCbCr, an Adobe marker decides by its transform byte, else the ids 'R','G','B' mean RGB.
+static bool HasYCbCrColorSpace(const JpegInput& jpg) {
+  bool adobe = false;
+  uint8_t transform = 0;
+  for (const std::string& app : jpg.app_data) {
+    if ((uint8_t)app[0] == 0xe0) return true;
+    if ((uint8_t)app[0] == 0xee && app.size() >= 15) {
+      adobe = true;
+      transform = (uint8_t)app[14];
+    }
+  }
+  if (adobe) return transform != 0;
+  return jpg.components[0].id != 'R' || jpg.components[1].id != 'G' || jpg.components[2].id != 'B';
+}
+
+// guetzli::Process(params, stats, jpeg_data, &out) (processor.cc:890-924) for YUV 4:4:4 input.
+bool Encoder::RunJpeg(const std::string& data, std::string* out) {
+  Stopwatch total, sw;
+  JpegInput jpg;
+  if (!ReadJpeg((const uint8_t*)data.data(), data.size(), &jpg)) {
+    fprintf(stderr, "Can't read jpg data from input file\n");
+    return false;
+  }
+  for (const JpegComponentIn& comp : jpg.components) {   // CheckJpegSanity, :117-131
+    const int* q = jpg.quant[comp.quant_idx].values;
+    for (size_t i = 0; i < comp.coeffs.size(); ++i)
+      if (std::abs((int64_t)comp.coeffs[i] * q[i % 64]) > (1 << 12)) {
+        fprintf(stderr, "Unsupported input JPEG (unexpectedly large coefficient values).\n");
+        return false;
+      }
+  }
+  const size_t ncomp = jpg.components.size();
+  const bool ycbcr3 = ncomp == 3 && HasYCbCrColorSpace(jpg);
+  if (!(ncomp == 1 || (ycbcr3 && (jpg.Is420() || jpg.Is444())))) {   // DecodeJpegToRGB is empty
+    fprintf(stderr, "Unsupported input JPEG file (e.g. unsupported downsampling mode).\n"
+                    "Please provide the input image as a PNG file.\n");
+    return false;
+  }
+  if (params_.butteraugli_target > 2.0f) {   // ProcessJpegData, :800-806
+    fprintf(stderr,
+            "Guetzli should be called with quality >= 84, otherwise the\n"
+            "output will have noticeable artifacts. If you want to\n"
+            "proceed anyway, please edit the source code.\n");
+    return false;
+  }
+  if (!ycbcr3) {
+    fprintf(stderr, "Only YUV color space input jpeg is supported\n");
+    return false;
+  }
+  if (!jpg.Is444() || params_.try_420 || params_.force_420) {
+    fprintf(stderr, "guetzli_amd: YUV420 input and the YUV420 modes are not implemented on the "
+                    "device path\n");
+    return false;
+  }
+  const int w = jpg.width, h = jpg.height;
+  w_ = w; h_ = h;
+  bw_ = (w + 7) / 8; bh_ = (h + 7) / 8; nb_ = bw_ * bh_;
+  jpeg_input_ = true;
+  meta_.strip = params_.clear_metadata;
+  meta_.app_data = jpg.app_data;
+  meta_.com_data = jpg.com_data;
+  meta_.tail_data = jpg.tail_data;
+  in_quant_.clear();
+  for (const JpegQuant& t : jpg.quant) {
+    QuantTable q;
+    memcpy(q.values, t.values, sizeof(q.values));
+    q.precision = t.precision;
+    q.index = t.index;
+    in_quant_.push_back(q);
+  }
+  // RemoveOriginalQuantization (:84-97): coefficients are held dequantised
+  orig_.resize((size_t)3 * nb_ * 64);
+  for (int c = 0; c < 3; ++c) {
+    const JpegComponentIn& comp = jpg.components[c];
+    in_comp_id_[c] = comp.id;
+    in_quant_idx_[c] = comp.quant_idx;
+    memcpy(q_in_[c], jpg.quant[comp.quant_idx].values, sizeof(q_in_[c]));
+    if (comp.width_in_blocks != bw_ || comp.height_in_blocks != bh_) return Fail("block grid", GZ_E_STATE);
+    int16_t* dst = &orig_[(size_t)c * nb_ * 64];
+    for (size_t i = 0; i < comp.coeffs.size(); ++i) dst[i] = (int16_t)(comp.coeffs[i] * q_in_[c][i % 64]);
+  }
+  if (w < 32 || h < 32) {
+    // no butteraugli (:832-838): the input re-written with optimised Huffman codes
+    Frame f;
+    FrameFromImage(orig_.data(), q_in_, w, h, &f);
+    f.ncomp = 3;
+    f.quant = in_quant_;
+    for (int c = 0; c < 3; ++c) {
+      f.quant_idx[c] = in_quant_idx_[c];
+      f.comp_id[c] = in_comp_id_[c];
+    }
+    f.meta = &meta_;
+    if (!WriteJpeg(f, out)) return Fail("WriteJpeg", GZ_E_STATE);
+    Log("Original Out[%7zd]", out->size());
+    Log(" <image too small for Butteraugli>\n");
+    return true;
+  }
+  // The comparator's original is DecodeJpegToRGB(jpg) (jpeg_data_decoder.cc:45-54): the
+  // integer IDCT of the input, computed by the context itself.
+  int err = 0;
+  {
+    std::vector<uint8_t> blank((size_t)3 * w * h, 0);
+    ctx_ = gz_create(params_.device, w, h, blank.data(), params_.butteraugli_target, &err);
+    if (!ctx_) return Fail("gz_create", err);
+    int rc = gz_set_orig_coeffs(ctx_, orig_.data());
+    if (rc == GZ_OK) rc = gz_quantize(ctx_, nullptr, nullptr);
+    if (rc == GZ_OK) rc = gz_reconstruct(ctx_, blank.data(), nullptr);
+    if (rc == GZ_OK) rc = gz_set_rgb(ctx_, blank.data());
+    if (rc != GZ_OK) return Fail("decode of the input JPEG", rc);
+  }
+  img_.resize(orig_.size());
+  stats_->timers["create+encode"] = sw.lap();
+  if (!Search(q_in_, out)) return false;
+  stats_->timers["total"] = total.lap();
+  return true;
+}
+
 bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* out) {
   Stopwatch total, sw;
   if (params_.butteraugli_target > 2.0f) {   // processor.cc:800-806
@@ -712,56 +930,10 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   if (rc != GZ_OK) return Fail("gz_encode_rgb", rc);
   stats_->timers["create+encode"] = sw.lap();
 
-  // the unquantised original as the fallback output (processor.cc:826-846)
-  verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
-  if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
-  best_score_ = -1;
   QuantMatrix ones;
   for (int c = 0; c < 3; ++c)
     for (int k = 0; k < 64; ++k) ones[c][k] = 1;
-  if (!SetImageFromQuantization(ones, false)) return false;
-  {
-    SymbolHistogram dc[3], ac[3];
-    size_t size = 0;
-    if (!DeviceHistograms(ones, dc, ac) || !Serialize(nullptr, dc, ac, &size)) return false;
-    Log("Original Out[%7zd]", size);
-    if (!CompareCurrent()) return false;
-    if (!MaybeOutput(size)) return false;
-  }
-
-  QuantMatrix best_q;
-  memcpy(best_q, ones, sizeof(best_q));
-  if (!SelectMatrix(best_q)) return false;
-  stats_->timers["select_quant_matrix"] = sw.lap();
-  if (!SetImageFromQuantization(best_q, true)) return false;
-  mirror_valid_ = true;
-  if (!SelectFrequencyMasking(1.0)) return false;
-  stats_->timers["select_frequency_masking"] = sw.lap();
-  stats_->timers["jpeg_write"] = t_write_;
-  stats_->timers["compare"] = t_compare_;
-  stats_->timers["quantize"] = t_quant_;
-  stats_->timers["block_search"] = t_blocksearch_;
-  stats_->timers["phase_b_host"] = t_phaseb_;
-  stats_->timers["block_upload"] = t_upload_;
-  stats_->timers["pb_order"] = t_pb_order_;
-  stats_->timers["pb_sort"] = t_pb_sort_;
-  stats_->timers["pb_loop"] = t_pb_loop_;
-  stats_->timers["pb_loop_codes"] = t_pb_codes_;
-  stats_->timers["pb_loop_ensure_sorted"] = t_pb_ensure_;
-  stats_->timers["pb_loop_fast_steps"] = t_pb_fast_;
-  stats_->counters["phase B fast steps"] = (int)n_fast_;
-  stats_->counters["phase B coefficient steps"] = (int)n_steps_;
-  stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
-  {  // the winner: its head from the host, its scan from the device
-    std::vector<uint8_t> scan((size_t)6 * w * h + 4096);
-    size_t n = 0;
-    rc = gz_jpeg_scan_bytes(ctx_, 1, scan.data(), scan.size(), &n);
-    if (rc != GZ_OK) return Fail("gz_jpeg_scan_bytes", rc);
-    *out = best_head_;
-    out->append((const char*)scan.data(), n);
-    out->push_back((char)0xff);
-    out->push_back((char)0xd9);
-  }
+  if (!Search(ones, out)) return false;
   stats_->timers["total"] = total.lap();
   return true;
 }
@@ -774,6 +946,14 @@ bool Process(const Params& params, ProcessStats* stats, const std::vector<uint8_
   if (stats == nullptr) stats = &dummy;
   Encoder enc(params, stats);
   return enc.Run(rgb, w, h, out);
+}
+
+bool Process(const Params& params, ProcessStats* stats, const std::string& jpeg_data,
+             std::string* out) {
+  ProcessStats dummy;
+  if (stats == nullptr) stats = &dummy;
+  Encoder enc(params, stats);
+  return enc.RunJpeg(jpeg_data, out);
 }
 
 }  // namespace guetzli_amd
@@ -816,6 +996,28 @@ long gzh_process(const uint8_t* rgb, int w, int h, double quality, float target,
     const size_t n = std::min<size_t>(s.size(), (size_t)timers_cap - 1);
     memcpy(timers, s.data(), n);
     timers[n] = 0;
+  }
+  return (long)jpg.size();
+}
+
+// Process(params, stats, jpeg_data, &out); clear_metadata as Params::clear_metadata.
+long gzh_process_jpeg(const uint8_t* data, long len, double quality, float target, int device,
+                      int clear_metadata, uint8_t* out, long cap, char* trace, long trace_cap) {
+  guetzli_amd::Params params;
+  params.butteraugli_target =
+      quality >= 0 ? (float)guetzli_amd::ButteraugliScoreForQuality(quality) : target;
+  params.device = device;
+  params.clear_metadata = clear_metadata != 0;
+  guetzli_amd::ProcessStats stats;
+  std::string dbg;
+  if (trace) stats.debug_output = &dbg;
+  std::string in((const char*)data, (size_t)len), jpg;
+  if (!guetzli_amd::Process(params, &stats, in, &jpg)) return -1;
+  if ((long)jpg.size() <= cap) memcpy(out, jpg.data(), jpg.size());
+  if (trace && trace_cap > 0) {
+    const size_t n = std::min<size_t>(dbg.size(), (size_t)trace_cap - 1);
+    memcpy(trace, dbg.data(), n);
+    trace[n] = 0;
   }
   return (long)jpg.size();
 }

@@ -9,9 +9,9 @@
 //
 // What stays on the host is the serial decision logic of the reference (quant-matrix
 // bisection, global coefficient ordering, entropy-size model) and the JPEG writer; it is
-// written from scratch around flat coefficient arrays.  Scope: RGB input, YUV 4:4:4 (the
-// BASELINE configurations); try_420 / force_420 are refused with an error (SURVEY.md 8f
-// row 4), JPEG input is out of scope (row 3).
+// written from scratch around flat coefficient arrays.  Scope: RGB input (the BASELINE
+// configurations) and YUV 4:4:4 JPEG input; try_420 / force_420 and 4:2:0 input are refused
+// with an error.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -53,5 +53,13 @@ double ScoreJPEG(double butteraugli_distance, int size, double target);  // scor
 // (packed 8-bit sRGB, w*h*3).  Returns false (message on stderr) on failure.
 bool Process(const Params& params, ProcessStats* stats, const std::vector<uint8_t>& rgb,
              int w, int h, std::string* out);
+
+// The same from an existing JPEG (guetzli::Process(params, stats, jpeg_data, &out),
+// processor.h:39-41): the input is parsed on the host (jpeg_reader.h), its coefficients become
+// the original, its decoded pixels the comparator's reference image, its quantisation the
+// first candidate; Params::clear_metadata decides whether APPn / COM / trailing bytes are
+// carried over.  YUV 4:4:4 input only this round (4:2:0 is refused).
+bool Process(const Params& params, ProcessStats* stats, const std::string& jpeg_data,
+             std::string* out);
 
 }  // namespace guetzli_amd

@@ -58,6 +58,11 @@ const char* gz_last_error(const gz_ctx* ctx);
  * comparator when w,h >= 32 (processor.cc:940).  Returns NULL on failure, *err set. */
 gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, int* err);
 void gz_destroy(gz_ctx* ctx);
+/* Replace the original image of an existing context (same w, h): what constructing a new
+ * ButteraugliComparator on other pixels does.  Used by the JPEG-input path, whose original is
+ * DecodeJpegToRGB(jpg) (jpeg_data_decoder.cc:45-54) -- an IDCT of the input's coefficients
+ * that the context itself computes (gz_set_orig_coeffs, gz_quantize(NULL), gz_reconstruct). */
+int gz_set_rgb(gz_ctx* ctx, const uint8_t* rgb);
 int gz_synchronize(gz_ctx* ctx);
 /* Run subsequent work of this context on an externally owned hipStream_t (e.g. torch's
  * current stream, so that torch.cuda.Event timing sees the kernels).  NULL restores the

@@ -450,10 +450,11 @@ long ref_read_jpeg(const uint8_t* data, long len, uint8_t* out, long cap) {
 }
 
 // guetzli::Process(params, stats, jpeg_data, &out) (processor.cc:890-924), optional trace.
-long ref_process_jpeg(const uint8_t* data, long len, float butteraugli_target, uint8_t* out,
-                      long cap, char* trace, long trace_cap) {
+long ref_process_jpeg(const uint8_t* data, long len, float butteraugli_target,
+                      int clear_metadata, uint8_t* out, long cap, char* trace, long trace_cap) {
   guetzli::Params params;
   params.butteraugli_target = butteraugli_target;
+  params.clear_metadata = clear_metadata != 0;
   guetzli::ProcessStats stats;
   std::string dbg;
   if (trace) stats.debug_output = &dbg;

@@ -50,6 +50,7 @@ _REF_ONLY = {
     "dct_double": (None, [_P]),
     "idct_double": (None, [_P]),
     "downsample_plain": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "process_jpeg": (C.c_long, [_P, C.c_long, C.c_float, C.c_int, _P, C.c_long, _P, C.c_long]),
 }
 _ORC_ONLY = {
     "dct_double": (None, [_P, C.c_int]),
@@ -227,6 +228,19 @@ class Checker:
         n = self._process(_ptr(rgb), w, h, target, _ptr(out), cap, tr,
                           len(tr) if tr else 0)
         assert 0 <= n <= cap, n
+        return out[:n].tobytes(), (tr.value.decode() if tr else None)
+
+    def process_jpeg(self, data, target, clear_metadata=True, want_trace=False):
+        """guetzli::Process(params, stats, jpeg_data, &out); None if it returns false."""
+        buf = np.frombuffer(data, np.uint8)
+        cap = max(4 * len(data), 1 << 20)
+        out = np.zeros(cap, np.uint8)
+        tr = C.create_string_buffer(1 << 22) if want_trace else None
+        n = self._process_jpeg(_ptr(buf), len(data), target, int(clear_metadata), _ptr(out), cap,
+                               tr, len(tr) if tr else 0)
+        if n < 0:
+            return None, None
+        assert n <= cap
         return out[:n].tobytes(), (tr.value.decode() if tr else None)
 
     def write_jpeg(self, coeffs, w, h, q):

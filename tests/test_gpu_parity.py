@@ -307,3 +307,33 @@ def test_small_images_emit_the_unquantised_jpeg(wh):
         assert jpg == exp
     host = guetzli_amd.load_host()
     assert jpg == host.write_jpeg(oracle.encode_rgb(rgb), w, h, None)
+
+
+def _jpeg_input_cases():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_input_hashes.json")
+    return sorted(json.load(open(path)).items()) if os.path.exists(path) else []
+
+
+@pytest.mark.parametrize("name,exp", _jpeg_input_cases())
+def test_jpeg_input_golden_hashes(name, exp):
+    """guetzli::Process(params, stats, jpeg_data, &out): hashes from the unmodified reference
+    (tools/gen_golden_hashes.py).  The input stream is written by Pillow here; if this box's
+    libjpeg writes it differently the case cannot be compared and is skipped."""
+    import hashlib
+    import io
+    from PIL import Image
+    import guetzli_amd
+    kw = dict(exp["pil"])
+    if "comment" in kw:
+        kw["comment"] = kw["comment"].encode()
+    b = io.BytesIO()
+    Image.fromarray(images.tiled(exp["w"], exp["h"])).save(b, "JPEG", **kw)
+    data = b.getvalue() + (b"" if exp["clear_metadata"] else b"TAIL")
+    if hashlib.sha256(data).hexdigest() != exp["input_sha256"]:
+        pytest.skip("Pillow writes a different input stream on this machine")
+    host = guetzli_amd.load_host()
+    jpg, _ = host.process_jpeg(data, quality=exp["quality"], clear_metadata=exp["clear_metadata"])
+    assert len(jpg) == exp["bytes"]
+    assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]

@@ -97,3 +97,50 @@ def test_small_images_emit_the_unquantised_jpeg(host_emu, wh):
     got_jpg, info = host_emu.process(rgb, quality=95, want_trace=True)
     assert got_jpg == exp_jpg
     assert info["trace"] == exp_trace
+
+
+def _pil_jpeg(rgb, **kw):
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(rgb).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+@needs_ref
+@pytest.mark.parametrize("case", [
+    (48, 40, dict(quality=97, subsampling=0), True),
+    (40, 32, dict(quality=99, subsampling=0, progressive=True, comment=b"hello"), True),
+    (40, 32, dict(quality=98, subsampling=0, optimize=True, comment=b"kept", dpi=(72, 72)), False),
+    (24, 40, dict(quality=95, subsampling=0), True),      # too small for butteraugli
+    (24, 40, dict(quality=95, subsampling=0, comment=b"x"), False),
+])
+def test_jpeg_input_matches_reference_in_emulation(host_emu, case):
+    """guetzli::Process(params, stats, jpeg_data, &out) (processor.cc:890-924) for 4:4:4
+    input: the same bytes and the same --verbose trace as the reference, with and without
+    clear_metadata."""
+    w, h, kw, clear = case
+    data = _pil_jpeg(images.crop(w, h, 100, 60), **kw) + (b"" if clear else b"tail!")
+    target = ref._butteraugli_score_for_quality(95.0)
+    exp_jpg, exp_trace = ref.process_jpeg(data, target, clear_metadata=clear, want_trace=True)
+    assert exp_jpg is not None
+    got_jpg, got_trace = host_emu.process_jpeg(data, quality=95, clear_metadata=clear, want_trace=True)
+    for i, (a, b) in enumerate(zip(exp_trace.splitlines(), got_trace.splitlines())):
+        assert a == b, f"trace line {i}:\n ref: {a}\n got: {b}"
+    assert got_trace == exp_trace
+    assert got_jpg == exp_jpg
+
+
+@needs_ref
+def test_jpeg_input_refusals(host_emu):
+    """What the reference rejects is rejected; 4:2:0 input is refused here (not implemented)."""
+    rgb = images.crop(48, 40, 100, 60)
+    target = ref._butteraugli_score_for_quality(95.0)
+    grey = _pil_jpeg(np.ascontiguousarray(rgb[:, :, 1]), quality=95)
+    assert ref.process_jpeg(grey, target)[0] is None
+    with pytest.raises(RuntimeError):
+        host_emu.process_jpeg(grey, quality=95)
+    with pytest.raises(RuntimeError):
+        host_emu.process_jpeg(b"not a jpeg", quality=95)
+    with pytest.raises(RuntimeError):
+        host_emu.process_jpeg(_pil_jpeg(rgb, quality=95, subsampling=2), quality=95)

@@ -219,6 +219,7 @@ struct gz_ctx {
 
   bool have_orig = false, have_cand = false, have_distmap = false;
   std::vector<float> h_block_max;
+  bool h_block_max_valid = false;
   float last_distance = 0.0f;
 };
 
@@ -957,13 +958,21 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
   unsigned bits = 0;
   HIPCHK(c, hipMemcpyAsync(&bits, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
   if (distmap) TRY(download_plane(c, c->distmap, distmap));
-  c->h_block_max.resize(c->nb);
-  HIPCHK(c, hipMemcpyAsync(c->h_block_max.data(), c->d_block_max, sizeof(float) * c->nb,
-                           hipMemcpyDeviceToHost, c->stream));
+  // the per-block maxima stay on the device (phase B's weights are computed there); they
+  // come to the host only when asked for, here or by gz_block_weights
+  c->h_block_max_valid = false;
+  if (block_max) {
+    c->h_block_max.resize(c->nb);
+    HIPCHK(c, hipMemcpyAsync(c->h_block_max.data(), c->d_block_max, sizeof(float) * c->nb,
+                             hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   memcpy(&c->last_distance, &bits, 4);
   *distance = c->last_distance;
-  if (block_max) memcpy(block_max, c->h_block_max.data(), sizeof(float) * c->nb);
+  if (block_max) {
+    memcpy(block_max, c->h_block_max.data(), sizeof(float) * c->nb);
+    c->h_block_max_valid = true;
+  }
   c->have_distmap = true;
   return GZ_OK;
 }
@@ -1007,6 +1016,13 @@ int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target
   if (!c || !block_weight || max_block_dist < 0) return GZ_E_ARG;
   if (use_distmap && !c->have_distmap) { c->err = "no distance map yet"; return GZ_E_STATE; }
   std::vector<float> zero;
+  if (use_distmap && !c->h_block_max_valid) {
+    c->h_block_max.resize(c->nb);
+    HIPCHK(c, hipMemcpyAsync(c->h_block_max.data(), c->d_block_max, sizeof(float) * c->nb,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_block_max_valid = true;
+  }
   const float* bmax = c->h_block_max.data();
   if (!use_distmap) { zero.assign(c->nb, 0.0f); bmax = zero.data(); }
   block_weights_host(bmax, c->bw, c->bh, c->target, direction, max_block_dist, target_mul,

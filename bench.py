@@ -146,7 +146,7 @@ def main():
     # batch leg (BASELINE config 5 in miniature, rank 0): independent images in flight on one
     # GPU at the same time, one host thread each; reported beside `value`, never instead of it
     batch = None
-    if rank == 0 and args.batch_images > 0:
+    if rank == 0 and world == 1 and args.batch_images > 0:
         from guetzli_amd.batch import encode_concurrent
         imgs = [images.shifted(images.tiled(W, H), k) for k in range(args.batch_images)]
         proc = lambda im: host.process(im, quality=QUALITY, device=local_rank)
@@ -211,6 +211,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()   # rank 0 has the extra legs: leave together
         dist.destroy_process_group()
 
 

@@ -273,12 +273,8 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
 // Column-pass tiles are 64 columns x 32 rows: measured faster than 64x64 at 1080p (0.47 vs
 // 0.54 ms per Compare: twice the workgroups for 256 CUs) and at 4K (1.37 vs 1.40 ms), and
 // much less sensitive to boxes whose memory is mapped with small pages (a 64-row tile of the
-// radius-20 pass touches 104 rows 15 KB apart).  GZ_TILE_ROWS=64 (tests) pins the tall variant.
-static bool small_image_tiles(const gz_ctx* c) {
-  (void)c;
-  static const char* force = getenv("GZ_TILE_ROWS");
-  return !(force && atoi(force) == 64);
-}
+// radius-20 pass touches 104 rows 15 KB apart).
+constexpr int kTileRows = 32;
 
 template <int R, int NC, class Post, bool BM = false>
 int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg& cfg,
@@ -287,15 +283,9 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (small_image_tiles(c)) {
-    dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, 32));
-    GZ_LAUNCH((k_blur_v<R, NC, Post, BM, 32>), grid, dim3(256), c->stream, src, post, w, h, pitch,
-              tp, bs, bm);
-  } else {
-    dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, 64));
-    GZ_LAUNCH((k_blur_v<R, NC, Post, BM, 64>), grid, dim3(256), c->stream, src, post, w, h, pitch,
-              tp, bs, bm);
-  }
+  dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
+  GZ_LAUNCH((k_blur_v<R, NC, Post, BM, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
+            pitch, tp, bs, bm);
   KCHK(c);
   return GZ_OK;
 }
@@ -307,15 +297,9 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bx = cfg.bx, by = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (small_image_tiles(c)) {
-    dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, 32));
-    GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, 32>), grid, dim3(256), c->stream, src, post, w, h,
-              pitch, tp, bx, by, bm);
-  } else {
-    dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, 64));
-    GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, 64>), grid, dim3(256), c->stream, src, post, w, h,
-              pitch, tp, bx, by, bm);
-  }
+  dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
+  GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, kTileRows>), grid, dim3(256), c->stream, src, post, w,
+            h, pitch, tp, bx, by, bm);
   KCHK(c);
   return GZ_OK;
 }

@@ -72,17 +72,3 @@ def test_jpeg_entropy(L, host_emu, wh):
 
 def test_global_order(L):
     pc.case_global_order(L, 40, 32, x0=100, y0=60)
-
-
-def test_tall_tile_variant_in_a_fresh_process():
-    """The 64x32-tile kernels are the default; GZ_TILE_ROWS=64 (read once per process) pins the
-    64x64 variants, which stay in the library as a tuning option, so they are covered too."""
-    import subprocess
-    code = ("import sys, os; sys.path.insert(0, os.path.join(%r, 'tests')); "
-            "sys.path.insert(0, os.path.join(%r, 'tests', 'emu')); sys.path.insert(0, %r); "
-            "import build_emu, parity_cases as pc; from guetzli_amd.capi import Library; "
-            "L = Library(build_emu.build()); pc.case_blur(L, 256, 200); pc.case_stages(L, 200, 160); "
-            "pc.case_compare(L, 136, 88, x0=220, y0=120); print('tall tiles ok')") % (ROOT, ROOT, ROOT)
-    env = dict(os.environ, GZ_TILE_ROWS="64")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-    assert out.returncode == 0 and "tall tiles ok" in out.stdout, out.stdout + out.stderr

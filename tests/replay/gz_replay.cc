@@ -38,8 +38,6 @@ struct Real {
   decltype(&gz_encode_rgb) encode_rgb;
   decltype(&gz_quantize) quantize;
   decltype(&gz_compare) compare;
-  decltype(&gz_compare_begin) compare_begin;
-  decltype(&gz_compare_end) compare_end;
   decltype(&gz_block_weights) block_weights;
   decltype(&gz_block_zeroing_orders) block_zeroing_orders;
   decltype(&gz_set_coeff_blocks) set_coeff_blocks;
@@ -54,10 +52,6 @@ struct Real {
   decltype(&gz_order_advance) order_advance;
   decltype(&gz_apply_coeff_edits) apply_coeff_edits;
   decltype(&gz_apply_candidate_steps) apply_candidate_steps;
-  decltype(&gz_set_rgb) set_rgb;
-  decltype(&gz_set_orig_coeffs) set_orig_coeffs;
-  decltype(&gz_reconstruct) reconstruct;
-  decltype(&gz_encode_rgb_only) encode_rgb_only;
   decltype(&gz_order_partition) order_partition;
   decltype(&gz_order_fetch) order_fetch;
   decltype(&gz_strerror) strerror_;
@@ -80,8 +74,7 @@ Real* real() {
   }
 #define SYM(field, name) r.field = (decltype(r.field))dlsym(r.h, name); if (!r.field) abort();
   SYM(create, "gz_create") SYM(destroy, "gz_destroy") SYM(encode_rgb, "gz_encode_rgb")
-  SYM(quantize, "gz_quantize") SYM(compare, "gz_compare")
-  SYM(compare_begin, "gz_compare_begin") SYM(compare_end, "gz_compare_end") SYM(block_weights, "gz_block_weights")
+  SYM(quantize, "gz_quantize") SYM(compare, "gz_compare") SYM(block_weights, "gz_block_weights")
   SYM(block_zeroing_orders, "gz_block_zeroing_orders")
   SYM(set_coeff_blocks, "gz_set_coeff_blocks") SYM(strerror_, "gz_strerror")
   SYM(last_error, "gz_last_error") SYM(get_coeffs, "gz_get_coeffs")
@@ -92,8 +85,6 @@ Real* real() {
   SYM(order_build_auto, "gz_order_build_auto") SYM(order_advance, "gz_order_advance")
   SYM(apply_coeff_edits, "gz_apply_coeff_edits")
   SYM(apply_candidate_steps, "gz_apply_candidate_steps")
-  SYM(set_rgb, "gz_set_rgb") SYM(set_orig_coeffs, "gz_set_orig_coeffs")
-  SYM(reconstruct, "gz_reconstruct") SYM(encode_rgb_only, "gz_encode_rgb_only")
 #undef SYM
   return &r;
 }
@@ -235,31 +226,6 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
   return GZ_OK;
 }
 
-// The split form: in record mode the evaluation really runs between the two calls; the log
-// entry (distance + block maxima, as for gz_compare) is written / read at _end.
-int gz_compare_begin(gz_ctx* c) { return c->inner ? real()->compare_begin(c->inner) : GZ_OK; }
-int gz_compare_end(gz_ctx* c, float* distance) {
-  c->bmax.resize(c->nb);
-  if (c->inner) {
-    int rc = real()->compare_end(c->inner, distance);
-    if (rc != GZ_OK) return rc;
-    // block maxima for the log: what gz_block_weights would fetch (all-ones weights query)
-    std::vector<float> w(c->nb);
-    put_tag(c, T_COMPARE);
-    put(c, distance, 4);
-    // the maxima are not needed by the driver any more (weights are computed on the device);
-    // zeros keep the log format
-    std::fill(c->bmax.begin(), c->bmax.end(), 0.0f);
-    put(c, c->bmax.data(), sizeof(float) * c->nb);
-  } else {
-    expect_tag(c, T_COMPARE);
-    get(c, distance, 4);
-    get(c, c->bmax.data(), sizeof(float) * c->nb);
-  }
-  c->have_bmax = true;
-  return GZ_OK;
-}
-
 int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target_mul,
                      int use_distmap, float* block_weight) {
   if (c->inner)
@@ -358,26 +324,6 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
   for (int i = 0; i < n; ++i)
     if (pos[i] < 0 || pos[i] >= 3 * c->nb * 64) return GZ_E_ARG;
   return GZ_OK;
-}
-
-// Entry points of the JPEG-input and small-image paths: forwarded when recording; those
-// paths are not logged, so they cannot be replayed.
-static int not_logged(const char* what) {
-  fprintf(stderr, "gz_replay: %s is not logged\n", what);
-  abort();
-}
-int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
-  return c->inner ? real()->set_rgb(c->inner, rgb) : not_logged("gz_set_rgb");
-}
-int gz_set_orig_coeffs(gz_ctx* c, const int16_t* coeffs) {
-  return c->inner ? real()->set_orig_coeffs(c->inner, coeffs) : not_logged("gz_set_orig_coeffs");
-}
-int gz_reconstruct(gz_ctx* c, uint8_t* srgb, float* linear) {
-  return c->inner ? real()->reconstruct(c->inner, srgb, linear) : not_logged("gz_reconstruct");
-}
-int gz_encode_rgb_only(int device, const uint8_t* rgb, int w, int h, int16_t* coeffs_out) {
-  return recording() ? real()->encode_rgb_only(device, rgb, w, h, coeffs_out)
-                     : not_logged("gz_encode_rgb_only");
 }
 
 int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,

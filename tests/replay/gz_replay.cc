@@ -52,6 +52,10 @@ struct Real {
   decltype(&gz_order_advance) order_advance;
   decltype(&gz_apply_coeff_edits) apply_coeff_edits;
   decltype(&gz_apply_candidate_steps) apply_candidate_steps;
+  decltype(&gz_set_rgb) set_rgb;
+  decltype(&gz_set_orig_coeffs) set_orig_coeffs;
+  decltype(&gz_reconstruct) reconstruct;
+  decltype(&gz_encode_rgb_only) encode_rgb_only;
   decltype(&gz_order_partition) order_partition;
   decltype(&gz_order_fetch) order_fetch;
   decltype(&gz_strerror) strerror_;
@@ -85,6 +89,8 @@ Real* real() {
   SYM(order_build_auto, "gz_order_build_auto") SYM(order_advance, "gz_order_advance")
   SYM(apply_coeff_edits, "gz_apply_coeff_edits")
   SYM(apply_candidate_steps, "gz_apply_candidate_steps")
+  SYM(set_rgb, "gz_set_rgb") SYM(set_orig_coeffs, "gz_set_orig_coeffs")
+  SYM(reconstruct, "gz_reconstruct") SYM(encode_rgb_only, "gz_encode_rgb_only")
 #undef SYM
   return &r;
 }
@@ -324,6 +330,26 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
   for (int i = 0; i < n; ++i)
     if (pos[i] < 0 || pos[i] >= 3 * c->nb * 64) return GZ_E_ARG;
   return GZ_OK;
+}
+
+// Entry points of the JPEG-input and small-image paths: forwarded when recording; those
+// paths are not logged, so they cannot be replayed.
+static int not_logged(const char* what) {
+  fprintf(stderr, "gz_replay: %s is not logged\n", what);
+  abort();
+}
+int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
+  return c->inner ? real()->set_rgb(c->inner, rgb) : not_logged("gz_set_rgb");
+}
+int gz_set_orig_coeffs(gz_ctx* c, const int16_t* coeffs) {
+  return c->inner ? real()->set_orig_coeffs(c->inner, coeffs) : not_logged("gz_set_orig_coeffs");
+}
+int gz_reconstruct(gz_ctx* c, uint8_t* srgb, float* linear) {
+  return c->inner ? real()->reconstruct(c->inner, srgb, linear) : not_logged("gz_reconstruct");
+}
+int gz_encode_rgb_only(int device, const uint8_t* rgb, int w, int h, int16_t* coeffs_out) {
+  return recording() ? real()->encode_rgb_only(device, rgb, w, h, coeffs_out)
+                     : not_logged("gz_encode_rgb_only");
 }
 
 int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,

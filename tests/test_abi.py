@@ -94,3 +94,29 @@ def test_host_side_candidate_ranking(lib_path):
         exp = [cand[j] for j in np.argsort(score, kind="stable")]
         assert idx[off[b]:off[b + 1]].tolist() == exp, b
     assert off[-1] > 500
+
+
+def test_new_entry_points_reject_bad_arguments(lib_path):
+    """Phase-B / JPEG-input / dct_double entry points: null context or buffers give GZ_E_ARG
+    (never a crash, never a fallback)."""
+    L = capi.Library(lib_path)
+    lib = L.lib
+    z = np.zeros(64, np.int32)
+    u64 = np.zeros(1, np.uint64)
+    assert lib.gz_order_reset(None) == -1
+    assert lib.gz_order_build(None, 1, z.ctypes.data, z.ctypes.data, z.ctypes.data, 0, 0.0,
+                              u64.ctypes.data, z.ctypes.data, None) == -1
+    assert lib.gz_order_build_auto(None, 1, 1, 1.0, 0, z.ctypes.data, 0, 0.0, u64.ctypes.data,
+                                   z.ctypes.data, None) == -1
+    assert lib.gz_order_partition(None, 0, 10, u64.ctypes.data) == -1
+    assert lib.gz_order_fetch(None, 0, 0, z.ctypes.data) == -1
+    assert lib.gz_order_advance(None, 0.0, 1) == -1
+    assert lib.gz_order_upload(None, None, 0) == -1
+    assert lib.gz_apply_candidate_steps(None, 1, z.ctypes.data, z.ctypes.data, 1) == -1
+    assert lib.gz_apply_coeff_edits(None, z.ctypes.data, z.ctypes.data, 1) == -1
+    assert lib.gz_set_rgb(None, z.ctypes.data) == -1
+    assert lib.gz_dct_double_blocks(0, None, 1, 0) == -1
+    assert lib.gz_component_to_float_pixels(0, None, 8, 8, None) == -1
+    assert lib.gz_component_set_downsampled(0, z.ctypes.data, 8, 8, 9, 1, z.ctypes.data) == -1
+    assert lib.gz_encode_rgb_only(0, None, 8, 8, None) == -1
+    assert lib.gz_encode_rgb_only(0, z.ctypes.data, 0, 8, z.ctypes.data) == -1

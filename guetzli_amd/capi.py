@@ -40,6 +40,8 @@ SIGNATURES = {
     "gz_get_coeffs": (_I, [_P, _P]),
     "gz_reconstruct": (_I, [_P, _P, _P]),
     "gz_compare": (_I, [_P, _P, _P, _P]),
+    "gz_compare_begin": (_I, [_P]),
+    "gz_compare_end": (_I, [_P, _P]),
     "gz_compare_enqueue": (_I, [_P, _I]),
     "gz_last_distance": (_I, [_P, _P]),
     "gz_time_compare": (_I, [_P, _I, _P]),
@@ -259,6 +261,14 @@ class Context:
         bm = np.zeros(self.nb, np.float32) if want_block_max else None
         self._chk(self.L.lib.gz_compare(self.handle, _ptr(dist), _ptr(dm), _ptr(bm)))
         return float(dist[0]), dm, bm
+
+    def compare_begin(self):
+        self._chk(self.L.lib.gz_compare_begin(self.handle))
+
+    def compare_end(self):
+        d = np.zeros(1, np.float32)
+        self._chk(self.L.lib.gz_compare_end(self.handle, _ptr(d)))
+        return float(d[0])
 
     def compare_enqueue(self, iters):
         self._chk(self.L.lib.gz_compare_enqueue(self.handle, iters))

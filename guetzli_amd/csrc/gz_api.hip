@@ -220,6 +220,7 @@ struct gz_ctx {
   bool have_orig = false, have_cand = false, have_distmap = false;
   std::vector<float> h_block_max;
   bool h_block_max_valid = false;
+  bool compare_pending = false;
   float last_distance = 0.0f;
 };
 
@@ -958,6 +959,28 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
     c->h_block_max_valid = true;
   }
   c->have_distmap = true;
+  return GZ_OK;
+}
+
+int gz_compare_begin(gz_ctx* c) {
+  if (!c) return GZ_E_ARG;
+  if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  TRY(enqueue_compare(c, true));
+  c->h_block_max_valid = false;
+  c->compare_pending = true;
+  return GZ_OK;
+}
+
+int gz_compare_end(gz_ctx* c, float* distance) {
+  if (!c || !distance) return GZ_E_ARG;
+  if (!c->compare_pending) { c->err = "gz_compare_begin must precede gz_compare_end"; return GZ_E_STATE; }
+  unsigned bits = 0;
+  HIPCHK(c, hipMemcpyAsync(&bits, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(&c->last_distance, &bits, 4);
+  *distance = c->last_distance;
+  c->have_distmap = true;
+  c->compare_pending = false;
   return GZ_OK;
 }
 

@@ -200,6 +200,7 @@ class Encoder {
   bool DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolHistogram* ac);
   bool Serialize(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac,
                  size_t* size);
+  bool CompareBegin();
   bool CompareCurrent();
   bool MaybeOutput(size_t size);
   bool VerifyAgainstHostWriter(const int (*q)[64], size_t size);
@@ -373,11 +374,20 @@ bool Encoder::VerifyAgainstHostWriter(const int (*q)[64], size_t size) {
   return true;
 }
 
-bool Encoder::CompareCurrent() {   // comparator_->Compare(*img)
+// comparator_->Compare(*img) in two halves: the evaluation is enqueued before the candidate's
+// Huffman codes are built on the host (Serialize) and collected afterwards.
+bool Encoder::CompareBegin() {
   Stopwatch sw;
-  const int rc = gz_compare(ctx_, &distance_, nullptr, nullptr);
+  const int rc = gz_compare_begin(ctx_);
   t_compare_ += sw.lap();
-  if (rc != GZ_OK) return Fail("gz_compare", rc);
+  if (rc != GZ_OK) return Fail("gz_compare_begin", rc);
+  return true;
+}
+bool Encoder::CompareCurrent() {
+  Stopwatch sw;
+  const int rc = gz_compare_end(ctx_, &distance_);
+  t_compare_ += sw.lap();
+  if (rc != GZ_OK) return Fail("gz_compare_end", rc);
   Log(" BA[100.00%%] D[%6.4f]", distance_);
   return true;
 }
@@ -411,7 +421,7 @@ bool Encoder::TryMatrix(float target_mul, const QuantMatrix q, Trial* t) {   // 
   if (!SetImageFromQuantization(q, false)) return false;
   SymbolHistogram dc[3], ac[3];
   size_t size = 0;
-  if (!DeviceHistograms(q, dc, ac) || !Serialize(q, dc, ac, &size)) return false;
+  if (!DeviceHistograms(q, dc, ac) || !CompareBegin() || !Serialize(q, dc, ac, &size)) return false;
   Log("Iter %2d: %s quantization matrix:\n", stats_->counters[kNumItersCnt] + 1, "f111111");
   LogMatrix(q);
   Log("Iter %2d: %s GQ[%5.2f] Out[%7zd]", stats_->counters[kNumItersCnt] + 1, "f111111",
@@ -691,7 +701,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       if (rc != GZ_OK) return Fail("gz_apply_coeff_edits", rc);
 
       size_t jpg_size = 0;
-      if (!Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;
+      if (!CompareBegin() || !Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;
       Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
           "EstErr[%.2f%%]",
           stats_->counters[kNumItersCnt], "f111111", 7, direction > 0 ? "up" : "down",
@@ -723,7 +733,8 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
     // tables for a JPEG input, whose coefficients are held dequantised)
     SymbolHistogram dc[3], ac[3];
     size_t size = 0;
-    if (!DeviceHistograms(jpeg_input_ ? q_in_ : ones, dc, ac) || !Serialize(nullptr, dc, ac, &size))
+    if (!DeviceHistograms(jpeg_input_ ? q_in_ : ones, dc, ac) || !CompareBegin() ||
+        !Serialize(nullptr, dc, ac, &size))
       return false;
     Log("Original Out[%7zd]", size);
     if (!CompareCurrent()) return false;

@@ -142,6 +142,13 @@ int gz_component_set_downsampled(int device, const float* pixels, int w, int h, 
  * With distmap == block_max == NULL only 4 bytes cross PCIe. */
 int gz_compare(gz_ctx* ctx, float* distance, float* distmap, float* block_max);
 
+/* gz_compare in two halves, so that the caller can do host work (e.g. build the Huffman
+ * codes of the same candidate) while the evaluation runs: _begin enqueues it and returns,
+ * _end waits and returns distmap_aggregate().  No other call on the context may come between
+ * them except gz_jpeg_scan / gz_jpeg_scan_keep (same stream, ordered behind the evaluation). */
+int gz_compare_begin(gz_ctx* ctx);
+int gz_compare_end(gz_ctx* ctx, float* distance);
+
 /* Enqueue `iters` back-to-back Compare evaluations of the current candidate on the
  * context's stream without any host transfer or synchronisation (for HIP-event timing
  * of the resident-in-HBM rate).  The distance of the last one is readable with

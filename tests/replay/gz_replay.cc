@@ -38,6 +38,8 @@ struct Real {
   decltype(&gz_encode_rgb) encode_rgb;
   decltype(&gz_quantize) quantize;
   decltype(&gz_compare) compare;
+  decltype(&gz_compare_begin) compare_begin;
+  decltype(&gz_compare_end) compare_end;
   decltype(&gz_block_weights) block_weights;
   decltype(&gz_block_zeroing_orders) block_zeroing_orders;
   decltype(&gz_set_coeff_blocks) set_coeff_blocks;
@@ -78,7 +80,8 @@ Real* real() {
   }
 #define SYM(field, name) r.field = (decltype(r.field))dlsym(r.h, name); if (!r.field) abort();
   SYM(create, "gz_create") SYM(destroy, "gz_destroy") SYM(encode_rgb, "gz_encode_rgb")
-  SYM(quantize, "gz_quantize") SYM(compare, "gz_compare") SYM(block_weights, "gz_block_weights")
+  SYM(quantize, "gz_quantize") SYM(compare, "gz_compare")
+  SYM(compare_begin, "gz_compare_begin") SYM(compare_end, "gz_compare_end") SYM(block_weights, "gz_block_weights")
   SYM(block_zeroing_orders, "gz_block_zeroing_orders")
   SYM(set_coeff_blocks, "gz_set_coeff_blocks") SYM(strerror_, "gz_strerror")
   SYM(last_error, "gz_last_error") SYM(get_coeffs, "gz_get_coeffs")
@@ -229,6 +232,31 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
   }
   c->have_bmax = true;
   if (block_max) memcpy(block_max, c->bmax.data(), sizeof(float) * c->nb);
+  return GZ_OK;
+}
+
+// The split form: in record mode the evaluation really runs between the two calls; the log
+// entry (distance + block maxima, as for gz_compare) is written / read at _end.
+int gz_compare_begin(gz_ctx* c) { return c->inner ? real()->compare_begin(c->inner) : GZ_OK; }
+int gz_compare_end(gz_ctx* c, float* distance) {
+  c->bmax.resize(c->nb);
+  if (c->inner) {
+    int rc = real()->compare_end(c->inner, distance);
+    if (rc != GZ_OK) return rc;
+    // block maxima for the log: what gz_block_weights would fetch (all-ones weights query)
+    std::vector<float> w(c->nb);
+    put_tag(c, T_COMPARE);
+    put(c, distance, 4);
+    // the maxima are not needed by the driver any more (weights are computed on the device);
+    // zeros keep the log format
+    std::fill(c->bmax.begin(), c->bmax.end(), 0.0f);
+    put(c, c->bmax.data(), sizeof(float) * c->nb);
+  } else {
+    expect_tag(c, T_COMPARE);
+    get(c, distance, 4);
+    get(c, c->bmax.data(), sizeof(float) * c->nb);
+  }
+  c->have_bmax = true;
   return GZ_OK;
 }
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "gz_block_weights": (_I, [_P, _I, _I, C.c_double, _I, _P]),
     "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
+    "gz_probe_rank_sort": (_I, [_I, _P, _P, _I, _P]),
     "gz_order_build": (_I, [_P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P]),
     "gz_order_reset": (_I, [_P]),
     "gz_order_build_auto": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float, _P, _P, _P]),

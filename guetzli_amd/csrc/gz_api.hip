@@ -27,6 +27,7 @@
 #include "gz_kernels_entropy.h"
 #include "gz_kernels_dctd.h"
 #include "gz_kernels_order.h"
+#include "gz_kernels_rank.h"
 #include "gz_host_weights.h"
 #include "order_tables_generated.h"   // host-side csf/bias of order.inc
 
@@ -157,6 +158,10 @@ struct gz_ctx {
   // mask: DiffPrecompute + three blurs), forked and joined with events
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  // the entropy coder's kernels (gz_jpeg_scan) run on their own stream, beside a Compare that
+  // gz_compare_begin has put on the main stream: both only read the candidate coefficients
+  hipStream_t entropy_stream = nullptr;
+  hipEvent_t ev_candidate = nullptr;   // main stream: the candidate is in place
   std::string err;
 
   uint8_t* d_rgb = nullptr;
@@ -188,7 +193,7 @@ struct gz_ctx {
 
   float* d_block_mask = nullptr;   // [3][nb] mask_xyz_ at block corners (StartBlockComparisons)
   bool have_block_mask = false;
-  int32_t* d_rank_off = nullptr; uint8_t* d_rank_idx = nullptr;
+  int32_t* d_rank_cnt = nullptr; uint8_t* d_rank_idx = nullptr; float* d_rank_tables = nullptr;
   int32_t* d_out_cnt = nullptr; uint8_t* d_out_idx = nullptr; float* d_out_err = nullptr;
 
   // device entropy coder (gz_kernels_entropy.h)
@@ -733,6 +738,8 @@ gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, in
   c->stream = c->own_stream;
   CHK0(hipStreamCreate(&c->side_stream));
   CHK0(hipStreamCreate(&c->side_stream2));
+  CHK0(hipStreamCreate(&c->entropy_stream));
+  CHK0(hipEventCreateWithFlags(&c->ev_candidate, hipEventDisableTiming));
   CHK0(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   CHK0(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   CHK0(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
@@ -812,7 +819,7 @@ void gz_destroy(gz_ctx* c) {
   (void)hipFree(c->d_max_bits); (void)hipFree(c->d_srgb_out); (void)hipFree(c->arena);
   (void)hipFree(c->d_blkidx); (void)hipFree(c->d_blkdata);
   (void)hipFree(c->extra_arena);
-  (void)hipFree(c->d_block_mask); (void)hipFree(c->d_rank_off); (void)hipFree(c->d_rank_idx);
+  (void)hipFree(c->d_block_mask); (void)hipFree(c->d_rank_cnt); (void)hipFree(c->d_rank_tables); (void)hipFree(c->d_rank_idx);
   (void)hipFree(c->d_out_cnt); (void)hipFree(c->d_out_idx); (void)hipFree(c->d_out_err);
   (void)hipFree(c->d_jq); (void)hipFree(c->d_hist); (void)hipFree(c->d_code_depth); (void)hipFree(c->d_code_bits);
   (void)hipFree(c->d_mcu_bits); (void)hipFree(c->d_mcu_off); (void)hipFree(c->d_ff_count);
@@ -824,6 +831,8 @@ void gz_destroy(gz_ctx* c) {
   for (int b = 0; b < B_COUNT; ++b) (void)hipFree(c->blur[b].d_scale);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
   if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); (void)hipStreamDestroy(c->side_stream2); }
+  if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); (void)hipStreamDestroy(c->entropy_stream); }
+  if (c->ev_candidate) (void)hipEventDestroy(c->ev_candidate);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -965,6 +974,7 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
 int gz_compare_begin(gz_ctx* c) {
   if (!c) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  HIPCHK(c, hipEventRecord(c->ev_candidate, c->stream));   // gz_jpeg_scan waits for this only
   TRY(enqueue_compare(c, true));
   c->h_block_max_valid = false;
   c->compare_pending = true;
@@ -1306,39 +1316,48 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
                  uint64_t* scan_bytes) {
   if (!c || !depth || !code || !scan_bytes || (ncomp != 1 && ncomp != 3)) return GZ_E_ARG;
   if (!c->have_cand || !c->have_jq) { c->err = "gz_jpeg_histograms must precede gz_jpeg_scan"; return GZ_E_STATE; }
-  HIPCHK(c, hipMemcpyAsync(c->d_code_depth, depth, 1536, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_code_bits, code, sizeof(unsigned short) * 1536, hipMemcpyHostToDevice, c->stream));
-  JpegCodes codes{c->d_code_depth, c->d_code_bits};
-  GZ_LAUNCH(k_jpeg_block_bits, dim3(c->nb), dim3(64), c->stream, (const int16_t*)c->d_cand,
-            (const int*)c->d_jq, c->nb, ncomp, codes, c->d_mcu_bits);
-  KCHK(c);
-  GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), c->stream, (const unsigned*)c->d_mcu_bits,
-            c->nb, c->d_mcu_off);
-  KCHK(c);
-  unsigned long long total_bits = 0;
-  HIPCHK(c, hipMemcpyAsync(&total_bits, c->d_mcu_off + c->nb, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // also: depth/code may live on the caller's stack
-  const unsigned long long nbytes = (total_bits + 7) / 8;
-  const size_t need_words = (size_t)(nbytes / 4 + 4);
-  if (need_words > c->words_cap) {
+  // Upper bound of a scan: per coefficient a code of at most 16 bits and at most 16 extra
+  // bits (int16 magnitudes), plus an end-of-block per block, plus the final padding.  Sized
+  // once, so that no host round trip is needed between counting the bits and writing them.
+  const size_t cap_words = (size_t)c->nb * 3 * (64 + 1) + 8;
+  if (cap_words > c->words_cap) {
     (void)hipFree(c->d_words);
     c->d_words = nullptr;
-    c->words_cap = need_words + need_words / 4 + 1024;
-    HIPCHK(c, hipMalloc((void**)&c->d_words, sizeof(unsigned) * c->words_cap));
+    c->words_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_words, sizeof(unsigned) * cap_words));
+    c->words_cap = cap_words;
   }
-  HIPCHK(c, hipMemsetAsync(c->d_words, 0, sizeof(unsigned) * need_words, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_ff_count, 0, 8, c->stream));
-  GZ_LAUNCH(k_jpeg_emit, dim3(c->nb), dim3(64), c->stream, (const int16_t*)c->d_cand,
+  // own stream, behind the candidate (not behind a Compare that gz_compare_begin enqueued)
+  hipStream_t es = c->entropy_stream;
+  if (!c->compare_pending) HIPCHK(c, hipEventRecord(c->ev_candidate, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(es, c->ev_candidate, 0));
+  HIPCHK(c, hipMemcpyAsync(c->d_code_depth, depth, 1536, hipMemcpyHostToDevice, es));
+  HIPCHK(c, hipMemcpyAsync(c->d_code_bits, code, sizeof(unsigned short) * 1536, hipMemcpyHostToDevice, es));
+  JpegCodes codes{c->d_code_depth, c->d_code_bits};
+  GZ_LAUNCH(k_jpeg_block_bits, dim3(c->nb), dim3(64), es, (const int16_t*)c->d_cand,
+            (const int*)c->d_jq, c->nb, ncomp, codes, c->d_mcu_bits);
+  KCHK(c);
+  GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), es, (const unsigned*)c->d_mcu_bits,
+            c->nb, c->d_mcu_off);
+  KCHK(c);
+  const unsigned long long* d_total = c->d_mcu_off + c->nb;
+  const int cgrid = (int)std::min<size_t>(512, (cap_words + 255) / 256);
+  GZ_LAUNCH(k_jpeg_clear_words, dim3(cgrid), dim3(256), es, c->d_words, d_total,
+            (unsigned long long)c->words_cap, c->d_ff_count);
+  KCHK(c);
+  GZ_LAUNCH(k_jpeg_emit, dim3(c->nb), dim3(64), es, (const int16_t*)c->d_cand,
             (const int*)c->d_jq, c->nb, ncomp, codes, (const unsigned long long*)c->d_mcu_off,
-            c->d_words);
+            c->d_words, (unsigned long long)c->words_cap);
   KCHK(c);
-  const int cgrid = (int)std::min<size_t>(1024, (need_words + 255) / 256);
-  GZ_LAUNCH(k_jpeg_count_ff, dim3(cgrid), dim3(256), c->stream, (const unsigned*)c->d_words,
-            nbytes, c->d_ff_count);
+  GZ_LAUNCH(k_jpeg_count_ff, dim3(cgrid), dim3(256), es, (const unsigned*)c->d_words, d_total,
+            c->d_ff_count);
   KCHK(c);
-  unsigned long long ff = 0;
-  HIPCHK(c, hipMemcpyAsync(&ff, c->d_ff_count, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  unsigned long long total_bits = 0, ff = 0;
+  HIPCHK(c, hipMemcpyAsync(&total_bits, d_total, 8, hipMemcpyDeviceToHost, es));
+  HIPCHK(c, hipMemcpyAsync(&ff, c->d_ff_count, 8, hipMemcpyDeviceToHost, es));
+  HIPCHK(c, hipStreamSynchronize(es));   // also: depth/code may live on the caller's stack
+  const unsigned long long nbytes = (total_bits + 7) / 8;
+  if (nbytes / 4 + 4 > c->words_cap) { c->err = "scan larger than its bound (code lengths above 16?)"; return GZ_E_ARG; }
   c->scan_bits = total_bits;
   c->scan_ff = ff;
   c->have_scan = true;
@@ -1623,6 +1642,23 @@ int gz_component_set_downsampled(int device, const float* pixels, int w, int h, 
   return GZ_OK;
 }
 
+int gz_probe_rank_sort(int device, const float* keys, const int32_t* cnt, int narr, uint8_t* perm) {
+  if (!keys || !cnt || !perm || narr <= 0) return GZ_E_ARG;
+  for (int i = 0; i < narr; ++i) if (cnt[i] < 0 || cnt[i] > 192) return GZ_E_ARG;
+  if (probe_device(device) != GZ_OK) return GZ_E_NO_DEVICE;
+  DevBuf dk, dc, dp;
+  if (!dk.alloc(sizeof(float) * narr * 192) || !dc.alloc(sizeof(int32_t) * narr) || !dp.alloc((size_t)narr * 192))
+    return GZ_E_NOMEM;
+  if (hipMemcpy(dk.p, keys, sizeof(float) * narr * 192, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(dc.p, cnt, sizeof(int32_t) * narr, hipMemcpyHostToDevice) != hipSuccess)
+    return GZ_E_HIP;
+  const float* pk = (const float*)dk.p; const int32_t* pc = (const int32_t*)dc.p; uint8_t* pp = (uint8_t*)dp.p;
+  GZ_LAUNCH(k_probe_rank_sort, dim3(gz_div_up(narr, kRankLanes)), dim3(kRankLanes), (hipStream_t)0, pk, pc, narr, pp);
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return GZ_E_HIP;
+  if (hipMemcpy(perm, dp.p, (size_t)narr * 192, hipMemcpyDeviceToHost) != hipSuccess) return GZ_E_HIP;
+  return GZ_OK;
+}
+
 int gz_probe_arith(int device, int op, const void* a, const void* b, const void* c,
                    void* out, int n) {
   if (!a || !out || n <= 0 || op < 0 || op > 6) return GZ_E_ARG;
@@ -1661,30 +1697,31 @@ int gz_rank_zeroing_candidates(const int16_t* coeffs, const int16_t* orig, int n
 
 int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* offsets,
                             uint8_t* idx, float* err, int cap) {
-  if (!c || !offsets || !idx || !err || lookahead < 1 || cap < 0) return GZ_E_ARG;
+  if (!c || !offsets || !idx || lookahead < 1 || cap < 0) return GZ_E_ARG;
   if (!c->have_cand || !c->have_orig) { c->err = "needs original and candidate coefficients"; return GZ_E_STATE; }
   TRY(ensure_block_mask(c));
   const int nb = c->nb;
-  const size_t ncoef = (size_t)3 * nb * 64;
-  std::vector<int16_t> h_cand(ncoef), h_orig(ncoef);
-  HIPCHK(c, hipMemcpyAsync(h_cand.data(), c->d_cand, ncoef * 2, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(h_orig.data(), c->d_orig, ncoef * 2, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  std::vector<int32_t> roff;
-  std::vector<uint8_t> ridx;
-  rank_all(h_cand.data(), h_orig.data(), nb, new_model, &roff, &ridx);
-  if (!c->d_rank_off) {
-    HIPCHK(c, hipMalloc((void**)&c->d_rank_off, sizeof(int32_t) * (nb + 1)));
+  if (!c->d_rank_cnt) {
+    HIPCHK(c, hipMalloc((void**)&c->d_rank_cnt, sizeof(int32_t) * nb));
     HIPCHK(c, hipMalloc((void**)&c->d_rank_idx, (size_t)nb * 192));
+    HIPCHK(c, hipMalloc((void**)&c->d_rank_tables, sizeof(float) * 384));
     HIPCHK(c, hipMalloc((void**)&c->d_out_cnt, sizeof(int32_t) * nb));
     HIPCHK(c, hipMalloc((void**)&c->d_out_idx, (size_t)nb * 192));
     HIPCHK(c, hipMalloc((void**)&c->d_out_err, sizeof(float) * nb * 192));
+    HIPCHK(c, hipMemcpyAsync(c->d_rank_tables, kOrderCsf, sizeof(float) * 192, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_rank_tables + 192, kOrderBias, sizeof(float) * 192, hipMemcpyHostToDevice, c->stream));
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_rank_off, roff.data(), sizeof(int32_t) * (nb + 1), hipMemcpyHostToDevice, c->stream));
-  if (!ridx.empty())
-    HIPCHK(c, hipMemcpyAsync(c->d_rank_idx, ridx.data(), ridx.size(), hipMemcpyHostToDevice, c->stream));
+  {  // input_order of every block, ranked on the device with std::sort's permutation
+    RankArgs r;
+    r.coeffs = c->d_cand; r.orig = c->d_orig;
+    r.csf = c->d_rank_tables; r.bias = c->d_rank_tables + 192;
+    r.nb = nb; r.new_model = new_model;
+    r.cnt = c->d_rank_cnt; r.idx = c->d_rank_idx;
+    GZ_LAUNCH(k_rank_candidates, dim3(gz_div_up(nb, kRankLanes)), dim3(kRankLanes), c->stream, r);
+    KCHK(c);
+  }
   SearchArgs a;
-  a.coeffs = c->d_cand; a.rank_off = c->d_rank_off; a.rank_idx = c->d_rank_idx;
+  a.coeffs = c->d_cand; a.rank_cnt = c->d_rank_cnt; a.rank_idx = c->d_rank_idx;
   a.rgb = c->d_rgb; a.srgb_lut = c->d_srgb_lut; a.block_mask = c->d_block_mask;
   a.w = c->w; a.h = c->h; a.bw = c->bw; a.nb = nb;
   a.lookahead = lookahead;
@@ -1706,10 +1743,11 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
   c->have_search = true;
   std::vector<int32_t> cnt(nb);
   std::vector<uint8_t> widx((size_t)nb * 192);
-  std::vector<float> werr((size_t)nb * 192);
+  std::vector<float> werr(err ? (size_t)nb * 192 : 0);   // the errors stay on the device for gz_order_build
   HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_out_cnt, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(widx.data(), c->d_out_idx, (size_t)nb * 192, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(werr.data(), c->d_out_err, sizeof(float) * nb * 192, hipMemcpyDeviceToHost, c->stream));
+  if (err)
+    HIPCHK(c, hipMemcpyAsync(werr.data(), c->d_out_err, sizeof(float) * nb * 192, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   long total = 0;
   for (int b = 0; b < nb; ++b) total += cnt[b];
@@ -1718,7 +1756,7 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
   for (int b = 0; b < nb; ++b) {
     offsets[b] = t;
     memcpy(idx + t, widx.data() + (size_t)b * 192, cnt[b]);
-    memcpy(err + t, werr.data() + (size_t)b * 192, sizeof(float) * cnt[b]);
+    if (err) memcpy(err + t, werr.data() + (size_t)b * 192, sizeof(float) * cnt[b]);
     t += cnt[b];
   }
   offsets[nb] = t;

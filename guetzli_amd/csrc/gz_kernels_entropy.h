@@ -190,12 +190,16 @@ __global__ __launch_bounds__(64) void k_jpeg_emit(const int16_t* __restrict__ co
                                                   const int* __restrict__ q, int nb, int ncomp,
                                                   JpegCodes codes,
                                                   const unsigned long long* __restrict__ off,
-                                                  unsigned* __restrict__ words) {
+                                                  unsigned* __restrict__ words,
+                                                  unsigned long long cap_words) {
   __shared__ unsigned stage[kStageWords + 2];
   const int lane = threadIdx.x, b = blockIdx.x;
   const unsigned long long start = off[b], end = off[b + 1];
   // the last MCU also writes the 1-padding up to the byte boundary (BitWriter::JumpToByteBoundary)
   const int pad = b == nb - 1 ? (int)((8 - (end & 7)) & 7) : 0;
+  // `words` is sized for valid code lengths (<= 16 bits); with anything else the scan can be
+  // longer, the host reports that afterwards, and nothing is written past the buffer here
+  if (((end + pad + 63) >> 5) + 1 > cap_words) return;
   const unsigned long long word0 = start >> 5;
   const unsigned long long span = (end + pad) - (word0 << 5);   // bits from word0's first bit
   const bool staged = span <= (unsigned long long)kStageWords * 32;
@@ -238,11 +242,29 @@ __global__ __launch_bounds__(64) void k_jpeg_emit(const int16_t* __restrict__ co
   }
 }
 
-// Number of stream bytes (of nbytes) equal to 0xFF, added to *count.
+// The scan's size is only known on the device (off[nb], the scan's bit count) when the words
+// are cleared and counted: both kernels read it there, so that one gz_jpeg_scan needs a single
+// host synchronisation.
+// Clears the words the scan will occupy (k_jpeg_emit ORs into them) and the 0xFF counter.
+__global__ __launch_bounds__(256) void k_jpeg_clear_words(unsigned* __restrict__ words,
+                                                          const unsigned long long* __restrict__ total_bits,
+                                                          unsigned long long cap_words,
+                                                          unsigned long long* __restrict__ count) {
+  const unsigned long long nbytes = (*total_bits + 7) >> 3;
+  unsigned long long nwords = (nbytes >> 2) + 4;
+  if (nwords > cap_words) nwords = cap_words;
+  for (unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;
+       w += (unsigned long long)gridDim.x * blockDim.x)
+    words[w] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0ull;
+}
+
+// Number of stream bytes equal to 0xFF, added to *count.
 __global__ __launch_bounds__(256) void k_jpeg_count_ff(const unsigned* __restrict__ words,
-                                                       unsigned long long nbytes,
+                                                       const unsigned long long* __restrict__ total_bits,
                                                        unsigned long long* __restrict__ count) {
   __shared__ unsigned s_cnt[256];
+  const unsigned long long nbytes = (*total_bits + 7) >> 3;
   const unsigned long long nwords = (nbytes + 3) >> 2;
   unsigned n = 0;
   for (unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;

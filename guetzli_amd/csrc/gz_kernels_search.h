@@ -102,8 +102,8 @@ GZ_DEVFN void fft8(const Cpx* a, Cpx* F) {
 
 struct SearchArgs {
   const int16_t* coeffs;        // candidate image coefficients [3][nb][64]
-  const int32_t* rank_off;      // [nb+1]
-  const uint8_t* rank_idx;      // host-ranked input_order (processor.cc:381-400)
+  const int32_t* rank_cnt;      // [nb]
+  const uint8_t* rank_idx;      // [nb][192]: ranked input_order (processor.cc:381-400), k_rank_candidates
   const uint8_t* rgb;           // original sRGB image
   const float* srgb_lut;        // 256 floats
   const float* block_mask;      // [3][nb]: mask_xyz_[c](8*by, 8*bx)
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(64) void k_block_search(SearchArgs a) {
   const int iy = lane >> 3, ix = lane & 7;
   for (int i = lane; i < 256; i += 64) s.lut[i] = a.srgb_lut[i];
   for (int c = 0; c < 3; ++c) s.coef[64 * c + lane] = a.coeffs[((size_t)c * a.nb + blk) * 64 + lane];
-  const int r0 = a.rank_off[blk];
-  int n = a.rank_off[blk + 1] - r0;
+  const size_t r0 = (size_t)blk * 192;
+  int n = a.rank_cnt[blk];
   for (int i = lane; i < n; i += 64) s.list[i] = a.rank_idx[r0 + i];
   __syncthreads();
   // SwitchBlock (butteraugli_comparator.cc:427-455): original block, clamped gather

@@ -484,10 +484,10 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   // ---- phase A on the device ----
   std::vector<int32_t> cand_off(nb + 1);
   std::vector<uint8_t> cand_idx((size_t)nb * 189);
-  std::vector<float> cand_err((size_t)nb * 189);
+  // the candidates' errors stay on the device, where the global order is built from them
   int rc = gz_block_zeroing_orders(ctx_, params_.zeroing_greedy_lookahead,
                                    params_.new_zeroing_model ? 1 : 0, cand_off.data(),
-                                   cand_idx.data(), cand_err.data(), nb * 189);
+                                   cand_idx.data(), nullptr, nb * 189);
   t_blocksearch_ += sw.lap();
   if (rc != GZ_OK) return Fail("gz_block_zeroing_orders", rc);
 

@@ -144,8 +144,9 @@ int gz_compare(gz_ctx* ctx, float* distance, float* distmap, float* block_max);
 
 /* gz_compare in two halves, so that the caller can do host work (e.g. build the Huffman
  * codes of the same candidate) while the evaluation runs: _begin enqueues it and returns,
- * _end waits and returns distmap_aggregate().  No other call on the context may come between
- * them except gz_jpeg_scan / gz_jpeg_scan_keep (same stream, ordered behind the evaluation). */
+ * _end waits and returns distmap_aggregate().  Between them only calls that leave the
+ * candidate unchanged are allowed: gz_jpeg_scan (which runs on the context's entropy stream,
+ * beside the evaluation), gz_jpeg_scan_keep / _bytes, gz_get_coeffs. */
 int gz_compare_begin(gz_ctx* ctx);
 int gz_compare_end(gz_ctx* ctx, float* distance);
 
@@ -178,13 +179,19 @@ int gz_block_weights(gz_ctx* ctx, int direction, int max_block_dist, double targ
  * Outputs are the reference's CSR arrays: candidate_coeff_offsets[nb+1],
  * candidate_coeffs[], candidate_coeff_errors[] (processor.cc:554-558).  cap = capacity of
  * idx/err in elements (nb*189 always suffices); if too small, GZ_E_ARG is returned and
- * offsets[nb] holds the required size. */
+ * offsets[nb] holds the required size.  err may be NULL: the errors then stay on the device
+ * only, where gz_order_build reads them. */
 int gz_block_zeroing_orders(gz_ctx* ctx, int lookahead, int new_model, int32_t* offsets,
                             uint8_t* idx, float* err, int cap);
 /* Host-only helper, exported for tests: the ranked input_order of
- * ComputeBlockZeroingOrder (processor.cc:381-400) for every block, as CSR. */
+ * ComputeBlockZeroingOrder (processor.cc:381-400) for every block, as CSR, by std::sort
+ * itself.  gz_block_zeroing_orders ranks on the device. */
 int gz_rank_zeroing_candidates(const int16_t* coeffs, const int16_t* orig, int nb,
                                int new_model, int32_t* offsets, uint8_t* idx);
+/* Test hook for the device-side ranking (k_rank_candidates sorts every block's candidates
+ * with libstdc++'s std::sort permutation): narr arrays of cnt[a] <= 192 keys, keys[a][192];
+ * perm[a][i] = index (into array a) of the element std::sort puts at position i. */
+int gz_probe_rank_sort(int device, const float* keys, const int32_t* cnt, int narr, uint8_t* perm);
 
 /* Global candidate order of phase B ------------------------------
  * Phase B of SelectFrequencyMasking builds `global_order` = (block, val) for every
@@ -250,7 +257,9 @@ int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);
  * under the codes depth / code ([2][3][256] each, per component, already resolved through
  * the DC/AC table indexes).  The bit stream stays on the device; *scan_bytes receives its
  * exact length in bytes including the 0x00 stuffed after every 0xFF and the final
- * 1-padding (jpeg_bit_writer.h:31-108).
+ * 1-padding (jpeg_bit_writer.h:31-108).  Codes of used symbols longer than 16 bits can overflow the scan's bound: GZ_E_ARG.  The
+ * kernels run on the context's entropy stream, ordered behind whatever put the candidate in
+ * place; the call returns after its single synchronisation of that stream.
  *
  * gz_jpeg_scan_keep snapshots the last scan on the device (the caller's "best so far",
  * processor.cc:139-148); gz_jpeg_scan_bytes downloads the last (kept = 0) or the kept

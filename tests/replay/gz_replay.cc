@@ -24,6 +24,7 @@
 
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "../../guetzli_amd/csrc/gz_host_weights.h"
@@ -275,6 +276,9 @@ int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target
 
 int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* offsets,
                             uint8_t* idx, float* err, int cap) {
+  // the driver does not ask for the errors (they stay on the device); the log needs them
+  std::vector<float> own;
+  if (!err) { own.resize((size_t)std::max(cap, 0)); err = own.data(); }
   if (c->inner) {
     const int rc = real()->block_zeroing_orders(c->inner, lookahead, new_model, offsets, idx, err, cap);
     if (rc != GZ_OK) return rc;

@@ -66,6 +66,22 @@ def test_device_partition_is_std_sort(L, tmp_path):
     assert "device_order: ok" in out.stdout
 
 
+def test_device_ranking_is_std_sort(L, tmp_path):
+    """k_rank_candidates' per-block std::sort on the GPU (gz_probe_rank_sort) against
+    std::sort itself: 1500 arrays of 0..192 keys, tie-heavy and adversarial ones included."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_rank_sort")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-DGZ_EMU", "-I" + os.path.join(root, "tests", "emu"),
+                    "-I" + os.path.join(root, "guetzli_amd", "csrc"), "-pthread",
+                    os.path.join(root, "tests", "cpp", "test_rank_sort.cc"), "-o", exe, "-ldl"],
+                   check=True)
+    out = subprocess.run([exe, L.path], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "device == std::sort" in out.stdout
+
+
 def test_dct_double(L):
     pc.case_dct_double(L, n=20000)
 

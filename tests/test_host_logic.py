@@ -30,3 +30,24 @@ def test_device_partition_is_std_sort_in_emulation(tmp_path):
     out = subprocess.run([exe, build_emu.build(), "4097", "512"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device_order: ok" in out.stdout
+
+
+def _build_rank_sort(tmp_path):
+    exe = str(tmp_path / "test_rank_sort")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-DGZ_EMU", "-I" + os.path.join(ROOT, "tests", "emu"),
+                    "-I" + os.path.join(ROOT, "guetzli_amd", "csrc"), "-pthread",
+                    os.path.join(ROOT, "tests", "cpp", "test_rank_sort.cc"), "-o", exe, "-ldl"],
+                   check=True)
+    return exe
+
+
+def test_device_ranking_is_std_sort_in_emulation(tmp_path):
+    """gz_kernels_rank.h (the per-block std::sort of the zeroing candidates, heap-sort
+    fall-back included) against std::sort itself: the restatement compiled for the host, and
+    the emulation build's kernel through gz_probe_rank_sort."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    out = subprocess.run([_build_rank_sort(tmp_path), build_emu.build()], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "restatement == std::sort" in out.stdout and "device == std::sort" in out.stdout

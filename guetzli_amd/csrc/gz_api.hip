@@ -147,6 +147,16 @@ struct Psycho {   // device planes of one image's PsychoImage (butteraugli.h:418
 
 }  // namespace
 
+// Pinned host staging for the small per-iteration uploads (step lists, coefficient edits,
+// next_cand, Huffman codes): the caller's buffer is copied here, the H2D copy is asynchronous
+// and nobody has to wait for it -- the buffer is only waited for when it is reused.
+struct HostStage {
+  void* h = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool busy = false;
+};
+
 struct gz_ctx {
   int device = 0;
   int w = 0, h = 0, bw = 0, bh = 0, nb = 0, pitch = 0;
@@ -226,6 +236,9 @@ struct gz_ctx {
   std::vector<float> h_block_max;
   bool h_block_max_valid = false;
   bool compare_pending = false;
+  int h_jq[192] = {0};       // the matrix d_jq holds
+  HostStage stage_main, stage_entropy;
+  size_t search_total = 0;   // candidates phase A produced (bounds every global order)
   float last_distance = 0.0f;
 };
 
@@ -311,6 +324,36 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
 }
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != GZ_OK) return rc_; } while (0)
+
+// Reserves `bytes` of the staging buffer (waiting for its previous upload if that is still
+// running) and returns it; stage_sent() marks the upload that was just enqueued on `stream`.
+static int stage_reserve(gz_ctx* c, HostStage* st, size_t bytes, void** out) {
+  if (!st->ev) HIPCHK(c, hipEventCreateWithFlags(&st->ev, hipEventDisableTiming));
+  if (st->busy) {
+    HIPCHK(c, hipEventSynchronize(st->ev));
+    st->busy = false;
+  }
+  if (bytes > st->cap) {
+    if (st->h) (void)hipHostFree(st->h);
+    st->h = nullptr;
+    st->cap = 0;
+    const size_t cap = bytes + bytes / 2 + 4096;
+    HIPCHK(c, hipHostMalloc(&st->h, cap, 0));
+    st->cap = cap;
+  }
+  *out = st->h;
+  return GZ_OK;
+}
+static int stage_sent(gz_ctx* c, HostStage* st, hipStream_t stream) {
+  HIPCHK(c, hipEventRecord(st->ev, stream));
+  st->busy = true;
+  return GZ_OK;
+}
+static void stage_free(HostStage* st) {
+  if (st->ev) { (void)hipEventSynchronize(st->ev); (void)hipEventDestroy(st->ev); }
+  if (st->h) (void)hipHostFree(st->h);
+  st->h = nullptr; st->ev = nullptr; st->cap = 0; st->busy = false;
+}
 
 int setup_blur_cfg(gz_ctx* c, BlurCfg* cfg, float sigma, float border_ratio) {
   make_taps_host(sigma, cfg);
@@ -482,7 +525,8 @@ int join_mask_branch(gz_ctx* c) {
 }
 
 // DiffmapPsychoImage (butteraugli.cc:817-908) + score: p0 = original, p1 = candidate.
-int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block_max) {
+int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block_max,
+                  bool max_cleared = false) {
   const float hf_asymmetry_ = 0.8f;
   // side stream: SameNoise blur + the mask branch; main stream: Malta
   TRY(fork_side_branch(c, p0, p1));
@@ -539,27 +583,28 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
   {  // CalculateDiffmap second half: blur(sigma 1.725, border_ratio 1.0) + mix
     SrcPack<SrcPlain, 1> s; s.s[0].p = c->dsq;
     PostDiffmapMix post; post.d = c->dsq; post.out = c->distmap;
-    HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
+    if (!max_cleared) HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
     BlockMaxOut bm{want_block_max ? c->d_block_max : nullptr, c->d_max_bits, c->bw};
     TRY((blur2d<3, 1, SrcPlain, PostDiffmapMix, true>(c, s, post, c->blur[B_FINAL], bm)));
   }
   return GZ_OK;
 }
 
-int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* srgb) {
+int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* srgb,
+                      unsigned* clear_word = nullptr) {
   GZ_LAUNCH(k_reconstruct, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream,
             d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
-            srgb);
+            srgb, clear_word);
   KCHK(c);
   return GZ_OK;
 }
 
 // One full Compare of the current candidate, everything on the stream.
 int enqueue_compare(gz_ctx* c, bool want_block_max) {
-  TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr));
+  TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
   TRY(stage_opsin(c));
   TRY(stage_separate(c, &c->pi1));
-  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max));
+  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, true));
   return GZ_OK;
 }
 
@@ -833,6 +878,8 @@ void gz_destroy(gz_ctx* c) {
   if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); (void)hipStreamDestroy(c->side_stream2); }
   if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); (void)hipStreamDestroy(c->entropy_stream); }
   if (c->ev_candidate) (void)hipEventDestroy(c->ev_candidate);
+  stage_free(&c->stage_main);
+  stage_free(&c->stage_entropy);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1085,7 +1132,9 @@ static int ensure_order_block_arrays(gz_ctx* c) {
 static int order_build_device(gz_ctx* c, int direction, int count_below, float limit,
                               uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
   const int nb = c->nb;
-  TRY(ensure_order_capacity(c, 0));
+  // An order never has more entries than phase A produced candidates: sized once, so that the
+  // construction runs through without a host round trip between counting and filling.
+  TRY(ensure_order_capacity(c, std::max<size_t>(c->search_total, 1)));
   HIPCHK(c, hipMemsetAsync(c->d_order_counters, 0, sizeof(unsigned) * 2, c->stream));
   GZ_LAUNCH(k_order_sizes, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
             (const int*)c->d_out_cnt, (const int*)c->d_next_cand, (const float*)c->d_weight,
@@ -1094,21 +1143,18 @@ static int order_build_device(gz_ctx* c, int direction, int count_below, float l
   GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), c->stream, (const unsigned*)c->d_order_nb,
             nb, c->d_order_off);
   KCHK(c);
+  GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, 4)), dim3(256), c->stream,
+            (const float*)c->d_out_err, (const int*)c->d_next_cand, (const float*)c->d_weight,
+            (const float*)c->d_max_err, (const unsigned long long*)c->d_order_off, direction, nb,
+            count_below ? 1 : 0, limit, c->d_order, c->d_order_counters);
+  KCHK(c);
   unsigned long long n = 0;
-  HIPCHK(c, hipMemcpyAsync(&n, c->d_order_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  TRY(ensure_order_capacity(c, (size_t)n));
-  c->order_n = (size_t)n;
-  if (n > 0) {
-    GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, 4)), dim3(256), c->stream,
-              (const float*)c->d_out_err, (const int*)c->d_next_cand, (const float*)c->d_weight,
-              (const float*)c->d_max_err, (const unsigned long long*)c->d_order_off, direction, nb,
-              count_below ? 1 : 0, limit, c->d_order, c->d_order_counters);
-    KCHK(c);
-  }
   unsigned counters[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(&n, c->d_order_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(counters, c->d_order_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n > c->order_cap) { c->err = "order larger than the candidate count"; return GZ_E_STATE; }
+  c->order_n = (size_t)n;
   *total = n;
   *blocks_to_change = (int32_t)counters[0];
   if (below) *below = counters[1];
@@ -1147,7 +1193,13 @@ int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double tar
   if (use_distmap && !c->have_distmap) { c->err = "no distance map yet"; return GZ_E_STATE; }
   const int nb = c->nb;
   TRY(ensure_order_block_arrays(c));
-  HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
+  {
+    void* h = nullptr;
+    TRY(stage_reserve(c, &c->stage_main, sizeof(int) * nb, &h));
+    memcpy(h, next_cand, sizeof(int) * nb);
+    HIPCHK(c, hipMemcpyAsync(c->d_next_cand, h, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
+    TRY(stage_sent(c, &c->stage_main, c->stream));
+  }
   const int bw = c->bw, bh = c->bh;
   const float target = c->target;
   GZ_LAUNCH(k_weights_flag, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
@@ -1189,16 +1241,21 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
   }
   int* d_blocks = c->d_edit_pos;
   int* d_counts = c->d_edit_pos + n;
-  HIPCHK(c, hipMemcpyAsync(d_blocks, blocks, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_counts, counts, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+  {
+    void* h = nullptr;
+    TRY(stage_reserve(c, &c->stage_main, sizeof(int) * 2 * n, &h));
+    memcpy(h, blocks, sizeof(int) * n);
+    memcpy((int*)h + n, counts, sizeof(int) * n);
+    HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(stage_sent(c, &c->stage_main, c->stream));
+  }
   const int nb = c->nb;
   GZ_LAUNCH(k_apply_steps, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
             (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
             (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
             (const int*)c->d_q, nb);
   KCHK(c);
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
-  return GZ_OK;
+  return GZ_OK;   // the caller's buffers were copied to the staging buffer: no wait
 }
 
 int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int n) {
@@ -1215,13 +1272,19 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
     HIPCHK(c, hipMalloc((void**)&c->d_edit_pos, sizeof(int) * c->edit_cap));
     HIPCHK(c, hipMalloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_edit_pos, pos, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_edit_val, val, sizeof(short) * n, hipMemcpyHostToDevice, c->stream));
+  {
+    void* h = nullptr;
+    TRY(stage_reserve(c, &c->stage_main, (sizeof(int) + sizeof(short)) * n, &h));
+    memcpy(h, pos, sizeof(int) * n);
+    memcpy((int*)h + n, val, sizeof(short) * n);
+    HIPCHK(c, hipMemcpyAsync(c->d_edit_pos, h, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_edit_val, (int*)h + n, sizeof(short) * n, hipMemcpyHostToDevice, c->stream));
+    TRY(stage_sent(c, &c->stage_main, c->stream));
+  }
   GZ_LAUNCH(k_apply_coeff_edits, dim3(gz_div_up(n, 256)), dim3(256), c->stream,
             (const int*)c->d_edit_pos, (const short*)c->d_edit_val, n, c->d_cand);
   KCHK(c);
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
-  return GZ_OK;
+  return GZ_OK;   // the caller's buffers were copied to the staging buffer: no wait
 }
 
 int gz_order_upload(gz_ctx* c, const void* entries, uint64_t n) {
@@ -1300,10 +1363,13 @@ int gz_jpeg_histograms(gz_ctx* c, const int* q, uint32_t* counts) {
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   for (int i = 0; i < 192; ++i) if (q[i] <= 0) return GZ_E_ARG;
   TRY(ensure_entropy_buffers(c));
-  HIPCHK(c, hipMemcpyAsync(c->d_jq, q, sizeof(int) * 192, hipMemcpyHostToDevice, c->stream));
+  if (!c->have_jq || memcmp(c->h_jq, q, sizeof(c->h_jq)) != 0) {
+    memcpy(c->h_jq, q, sizeof(c->h_jq));
+    HIPCHK(c, hipMemcpyAsync(c->d_jq, c->h_jq, sizeof(int) * 192, hipMemcpyHostToDevice, c->stream));
+  }
   HIPCHK(c, hipMemsetAsync(c->d_hist, 0, sizeof(unsigned) * 1536, c->stream));
-  const int grid = std::min(c->nb, 2048);
-  GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64), c->stream, (const int16_t*)c->d_cand,
+  const int grid = std::min(gz_div_up(c->nb, kHistWaves), 512);
+  GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
             (const int*)c->d_jq, c->nb, c->d_hist);
   KCHK(c);
   HIPCHK(c, hipMemcpyAsync(counts, c->d_hist, sizeof(unsigned) * 1536, hipMemcpyDeviceToHost, c->stream));
@@ -1331,8 +1397,15 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   hipStream_t es = c->entropy_stream;
   if (!c->compare_pending) HIPCHK(c, hipEventRecord(c->ev_candidate, c->stream));
   HIPCHK(c, hipStreamWaitEvent(es, c->ev_candidate, 0));
-  HIPCHK(c, hipMemcpyAsync(c->d_code_depth, depth, 1536, hipMemcpyHostToDevice, es));
-  HIPCHK(c, hipMemcpyAsync(c->d_code_bits, code, sizeof(unsigned short) * 1536, hipMemcpyHostToDevice, es));
+  {
+    void* h = nullptr;
+    TRY(stage_reserve(c, &c->stage_entropy, 1536 + sizeof(unsigned short) * 1536, &h));
+    memcpy(h, depth, 1536);
+    memcpy((uint8_t*)h + 1536, code, sizeof(unsigned short) * 1536);
+    HIPCHK(c, hipMemcpyAsync(c->d_code_depth, h, 1536, hipMemcpyHostToDevice, es));
+    HIPCHK(c, hipMemcpyAsync(c->d_code_bits, (uint8_t*)h + 1536, sizeof(unsigned short) * 1536, hipMemcpyHostToDevice, es));
+    TRY(stage_sent(c, &c->stage_entropy, es));
+  }
   JpegCodes codes{c->d_code_depth, c->d_code_bits};
   GZ_LAUNCH(k_jpeg_block_bits, dim3(c->nb), dim3(64), es, (const int16_t*)c->d_cand,
             (const int*)c->d_jq, c->nb, ncomp, codes, c->d_mcu_bits);
@@ -1355,7 +1428,7 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   unsigned long long total_bits = 0, ff = 0;
   HIPCHK(c, hipMemcpyAsync(&total_bits, d_total, 8, hipMemcpyDeviceToHost, es));
   HIPCHK(c, hipMemcpyAsync(&ff, c->d_ff_count, 8, hipMemcpyDeviceToHost, es));
-  HIPCHK(c, hipStreamSynchronize(es));   // also: depth/code may live on the caller's stack
+  HIPCHK(c, hipStreamSynchronize(es));
   const unsigned long long nbytes = (total_bits + 7) / 8;
   if (nbytes / 4 + 4 > c->words_cap) { c->err = "scan larger than its bound (code lengths above 16?)"; return GZ_E_ARG; }
   c->scan_bits = total_bits;
@@ -1741,6 +1814,7 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
   GZ_LAUNCH(k_block_search, dim3(nb), dim3(64), c->stream, a);
   KCHK(c);
   c->have_search = true;
+  c->search_total = 0;   // set below, once the counts are on the host
   std::vector<int32_t> cnt(nb);
   std::vector<uint8_t> widx((size_t)nb * 192);
   std::vector<float> werr(err ? (size_t)nb * 192 : 0);   // the errors stay on the device for gz_order_build
@@ -1751,6 +1825,7 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
   HIPCHK(c, hipStreamSynchronize(c->stream));
   long total = 0;
   for (int b = 0; b < nb; ++b) total += cnt[b];
+  c->search_total = (size_t)total;
   if (total > cap) { c->err = "candidate capacity too small, need " + std::to_string(total); offsets[nb] = (int32_t)total; return GZ_E_ARG; }
   int t = 0;
   for (int b = 0; b < nb; ++b) {

@@ -50,7 +50,9 @@ GZ_DEVFN int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 __global__ __launch_bounds__(256) void k_reconstruct(
     const int16_t* __restrict__ coeffs, int w, int h, int bw, int nb, int pitch,
     size_t pstride, const float* __restrict__ srgb_lut, float* __restrict__ lin,
-    uint8_t* __restrict__ srgb) {
+    uint8_t* __restrict__ srgb, unsigned* __restrict__ clear_word) {
+  // first kernel of a Compare: also resets the distance accumulator of its last kernel
+  if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
   __shared__ int s_in[3][kBlocksPerWG][64];
   __shared__ int s_col[3][kBlocksPerWG][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

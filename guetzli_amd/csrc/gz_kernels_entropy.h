@@ -76,25 +76,38 @@ GZ_DEVFN LaneSyms lane_symbols(const int16_t* __restrict__ coeffs, const int* __
 
 // ------------------------------------------------------------------- histograms ------
 // hist: uint32 [2][3][256] (DC, AC) x component, raw occurrence counts; zeroed by the
-// caller.  Persistent workgroups (grid-stride over block positions) with an LDS histogram.
-__global__ __launch_bounds__(64) void k_jpeg_histograms(const int16_t* __restrict__ coeffs,
-                                                        const int* __restrict__ q, int nb,
-                                                        unsigned* __restrict__ hist) {
+// caller.  Persistent workgroups of four wavefronts (each wavefront strides over block
+// positions, one block at a time) sharing one LDS histogram: few workgroups keep the final
+// merge short (its global atomics all land on the same ~300 counters), four wavefronts per
+// workgroup keep enough loads in flight to hide their latency.
+constexpr int kHistWaves = 4;
+
+__global__ __launch_bounds__(64 * kHistWaves) void k_jpeg_histograms(const int16_t* __restrict__ coeffs,
+                                                                     const int* __restrict__ q, int nb,
+                                                                     unsigned* __restrict__ hist) {
   __shared__ unsigned s_hist[2 * 3 * 256];
-  const int lane = threadIdx.x;
-  for (int i = lane; i < 2 * 3 * 256; i += 64) s_hist[i] = 0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2 * 3 * 256; i += 64 * kHistWaves) s_hist[i] = 0;
   __syncthreads();
-  for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+  // the same trip count for the four wavefronts (a wavefront past the end repeats the last
+  // block and drops the result): the lane exchanges inside lane_symbols stay workgroup-uniform
+  for (int b0 = blockIdx.x * kHistWaves; b0 < nb; b0 += gridDim.x * kHistWaves) {
+    const bool live = b0 + wv < nb;
+    const int b = live ? b0 + wv : nb - 1;
+    LaneSyms s[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s[c] = lane_symbols(coeffs, q, nb, c, b, lane);
+    if (!live) continue;
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const LaneSyms s = lane_symbols(coeffs, q, nb, c, b, lane);
-      unsigned* h = &s_hist[((s.is_dc ? 0 : 1) * 3 + c) * 256];
-      if (s.zrl) atomicAdd(&h[0xf0], (unsigned)s.zrl);
-      if (s.sym >= 0) atomicAdd(&h[s.sym], 1u);
-      if (s.eob) atomicAdd(&s_hist[(3 + c) * 256], 1u);
+      unsigned* h = &s_hist[((s[c].is_dc ? 0 : 1) * 3 + c) * 256];
+      if (s[c].zrl) atomicAdd(&h[0xf0], (unsigned)s[c].zrl);
+      if (s[c].sym >= 0) atomicAdd(&h[s[c].sym], 1u);
+      if (s[c].eob) atomicAdd(&s_hist[(3 + c) * 256], 1u);
     }
   }
   __syncthreads();
-  for (int i = lane; i < 2 * 3 * 256; i += 64)
+  for (int i = threadIdx.x; i < 2 * 3 * 256; i += 64 * kHistWaves)
     if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
 }
 
@@ -140,31 +153,58 @@ __global__ __launch_bounds__(64) void k_jpeg_block_bits(const int16_t* __restric
   if (lane == 0) bits[b] = (unsigned)total;
 }
 
-// off[0..nb] = exclusive prefix sums of bits[0..nb) (64-bit).  One workgroup of 1024.
+// off[0..nb] = exclusive prefix sums of bits[0..nb) (64-bit).  One workgroup of 1024 walks
+// the array in tiles of 4096: a lane takes 4 consecutive values (one 16-byte load, issued one
+// tile ahead), the tile is scanned in 32 bits (a value is at most a block's scan bits or its
+// candidate count: 4096 of them stay far below 2^31) with wavefront shuffles plus one LDS
+// exchange between the 16 wavefronts, and the running total is carried in 64 bits.
+constexpr int kScanTile = 4096;
+
+struct alignas(16) ScanU4 { unsigned x, y, z, w; };
+
+GZ_DEVFN void scan_load4(const unsigned* __restrict__ bits, int nb, int at, unsigned v[4]) {
+  if (at + 3 < nb) {
+    const ScanU4 u = *reinterpret_cast<const ScanU4*>(bits + at);
+    v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = at + e < nb ? bits[at + e] : 0u;
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_jpeg_scan_offsets(const unsigned* __restrict__ bits,
                                                             int nb,
                                                             unsigned long long* __restrict__ off) {
-  __shared__ unsigned long long part[1024];
-  const int t = threadIdx.x;
-  const int per = (nb + 1023) / 1024;
-  const int lo = t * per < nb ? t * per : nb, hi = lo + per < nb ? lo + per : nb;
-  unsigned long long sum = 0;
-  for (int i = lo; i < hi; ++i) sum += bits[i];
-  part[t] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    unsigned long long o = 0;
-    if (t >= d) o = part[t - d];
+  __shared__ int wave_total[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  unsigned long long carry = 0;
+  unsigned cur[4], nxt[4];
+  scan_load4(bits, nb, 4 * t, cur);
+  for (int base = 0; base < nb; base += kScanTile) {
+    const int at = base + 4 * t;
+    if (base + kScanTile < nb) scan_load4(bits, nb, at + kScanTile, nxt);
+    const int s0 = (int)cur[0], s1 = s0 + (int)cur[1], s2 = s1 + (int)cur[2], s3 = s2 + (int)cur[3];
+    const int inc = wave_inclusive_sum(s3, lane);
+    if (lane == 63) wave_total[wv] = inc;
     __syncthreads();
-    part[t] += o;
-    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int w = wave_total[k];
+      if (k < wv) before += w;
+      all += w;
+    }
+    const unsigned long long excl = carry + (unsigned long long)(before + inc - s3);
+    if (at < nb) off[at] = excl;
+    if (at + 1 < nb) off[at + 1] = excl + (unsigned long long)s0;
+    if (at + 2 < nb) off[at + 2] = excl + (unsigned long long)s1;
+    if (at + 3 < nb) off[at + 3] = excl + (unsigned long long)s2;
+    carry += (unsigned long long)all;
+    __syncthreads();   // wave_total is rewritten by the next tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
   }
-  unsigned long long run = part[t] - sum;   // exclusive base of this thread's chunk
-  for (int i = lo; i < hi; ++i) {
-    off[i] = run;
-    run += bits[i];
-  }
-  if (t == 1023) off[nb] = part[1023];
+  if (t == 0) off[nb] = carry;
 }
 
 // --------------------------------------------------------------------------- emit ----

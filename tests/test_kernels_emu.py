@@ -55,6 +55,14 @@ def test_compare(L):
     pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(1, 5))
 
 
+def test_stages_and_compare_with_32_row_tiles(L, monkeypatch):
+    """Images this small take the 16-row blur tiles by default; the 32-row instantiations (what
+    1080p and 4K run) are forced here so that both are checked in emulation."""
+    monkeypatch.setenv("GZ_TILE_ROWS", "32")
+    pc.case_stages(L, 72, 48)
+    pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(5,))
+
+
 def test_block_search(L):
     pc.case_block_search(L, 45, 27)
 

@@ -2,6 +2,6 @@
 (block DCT / quantise / IDCT round trip + butteraugli distance map) behind the C ABI of
 include/guetzli_amd.h.  See DESIGN.md."""
 from .capi import Context, GuetzliAmdError, Library, load  # noqa: F401
-from .encoder import HostLibrary, load_host, process  # noqa: F401
+from .encoder import HostLibrary, load_host, process, process_png, read_png  # noqa: F401
 
-__all__ = ["Context", "GuetzliAmdError", "Library", "load", "HostLibrary", "load_host", "process"]
+__all__ = ["Context", "GuetzliAmdError", "Library", "load", "HostLibrary", "load_host", "process", "process_png", "read_png"]

@@ -23,6 +23,8 @@ class HostLibrary:
         self.lib.gzh_process_jpeg.restype = C.c_long
         self.lib.gzh_process_jpeg.argtypes = [C.c_void_p, C.c_long, C.c_double, C.c_float, C.c_int,
                                               C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        self.lib.gzh_read_png.restype = C.c_long
+        self.lib.gzh_read_png.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long]
         self.lib.gzh_write_jpeg.restype = C.c_long
         self.lib.gzh_write_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_long]
@@ -59,6 +61,19 @@ class HostLibrary:
                     timers[k] = float(v)
         return out[:n].tobytes(), {"trace": tr.value.decode() if tr else None,
                                    "timers": timers, "counters": counters}
+
+    def read_png(self, data):
+        """ReadPNG of the reference's front end (guetzli.cc:47-152): PNG bytes -> uint8
+        [h][w][3] with alpha blended on black.  Raises if the stream is rejected."""
+        buf = np.frombuffer(data, np.uint8)
+        wh = (C.c_int * 2)()
+        n = self.lib.gzh_read_png(buf.ctypes.data, len(data), wh, None, 0)
+        if n < 0:
+            raise ValueError("not a readable PNG (see stderr)")
+        out = np.zeros(n, np.uint8)
+        n2 = self.lib.gzh_read_png(buf.ctypes.data, len(data), wh, out.ctypes.data, n)
+        assert n2 == n
+        return out.reshape(wh[1], wh[0], 3)
 
     def process_jpeg(self, data, quality=95.0, target=None, device=0, clear_metadata=True,
                      want_trace=False):
@@ -121,3 +136,13 @@ def load_host():
 
 def process(rgb, quality=95.0, **kw):
     return load_host().process(rgb, quality=quality, **kw)
+
+
+def read_png(data):
+    """PNG bytes -> uint8 [h][w][3], as the reference's front end reads them (alpha on black)."""
+    return load_host().read_png(data)
+
+
+def process_png(data, quality=95.0, **kw):
+    """`guetzli --quality Q in.png out.jpg`: ReadPNG + Process.  Returns (jpeg_bytes, info)."""
+    return load_host().process(load_host().read_png(data), quality=quality, **kw)

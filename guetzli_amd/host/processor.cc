@@ -11,6 +11,7 @@
 
 #include "../../include/guetzli_amd.h"
 #include "jpeg_reader.h"
+#include "png_reader.h"
 #include "jpeg_writer.h"
 #include "lazy_sort.h"
 #include "parallel.h"
@@ -1068,6 +1069,23 @@ long gzh_read_jpeg(const uint8_t* data, long len, uint8_t* out, long cap) {
   for (const auto& c : jpg.components) d.append((const char*)c.coeffs.data(), c.coeffs.size() * 2);
   if ((long)d.size() <= cap) memcpy(out, d.data(), d.size());
   return (long)d.size();
+}
+
+// ReadPNG (guetzli.cc:47-152): PNG bytes -> packed RGB with alpha blended on black.  Returns
+// 3*w*h (copied to out if it fits) and the dimensions in wh[0..1], or -1 if the stream is
+// rejected (message on stderr).
+long gzh_read_png(const uint8_t* data, long len, int* wh, uint8_t* out, long cap) {
+  std::vector<uint8_t> rgb;
+  std::string err;
+  int w = 0, h = 0;
+  if (!guetzli_amd::ReadPng(data, (size_t)len, &w, &h, &rgb, &err)) {
+    fprintf(stderr, "Error reading PNG data from input file: %s\n", err.c_str());
+    return -1;
+  }
+  wh[0] = w;
+  wh[1] = h;
+  if ((long)rgb.size() <= cap) memcpy(out, rgb.data(), rgb.size());
+  return (long)rgb.size();
 }
 
 // WriteJpeg of an image given by dequantised coefficients + quant matrices (test hook).

@@ -239,6 +239,15 @@ def test_whole_encode_bees_bit_identical_jpeg(q):
         assert hashlib.sha256(info["trace"].encode()).hexdigest() == GOLDEN_TRACE_SHA[(444, 258, q)]
 
 
+def test_png_file_in_jpeg_out_matches_the_reference_golden():
+    """`guetzli tests/bees.png out.jpg` end to end: the PNG bytes go through the product's own
+    reader (png_reader.cc) and the JPEG is the reference's."""
+    import hashlib
+    import guetzli_amd
+    jpg, _ = guetzli_amd.process_png(open(images.BEES, "rb").read(), quality=95)
+    assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(444, 258, 95)]
+
+
 def test_whole_encode_1080p_bit_identical_jpeg():
     """BASELINE config 2 (1920x1080, quality 95): byte-identical to the reference output."""
     import hashlib

@@ -238,6 +238,9 @@ struct gz_ctx {
   bool compare_pending = false;
   int h_jq[192] = {0};       // the matrix d_jq holds
   HostStage stage_main, stage_entropy;
+  // pinned landing area for the small results every call waits for (a copy into pageable
+  // memory costs 27 us per round trip on this system, into pinned memory 15)
+  void* h_res = nullptr; size_t h_res_cap = 0;
   size_t search_total = 0;   // candidates phase A produced (bounds every global order)
   float last_distance = 0.0f;
 };
@@ -371,6 +374,18 @@ static int stage_reserve(gz_ctx* c, HostStage* st, size_t bytes, void** out) {
 static int stage_sent(gz_ctx* c, HostStage* st, hipStream_t stream) {
   HIPCHK(c, hipEventRecord(st->ev, stream));
   st->busy = true;
+  return GZ_OK;
+}
+static int result_buffer(gz_ctx* c, size_t bytes, void** out) {
+  if (bytes > c->h_res_cap) {
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    c->h_res = nullptr;
+    c->h_res_cap = 0;
+    const size_t cap = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+    HIPCHK(c, hipHostMalloc(&c->h_res, cap, 0));
+    c->h_res_cap = cap;
+  }
+  *out = c->h_res;
   return GZ_OK;
 }
 static void stage_free(HostStage* st) {
@@ -904,6 +919,7 @@ void gz_destroy(gz_ctx* c) {
   if (c->ev_candidate) (void)hipEventDestroy(c->ev_candidate);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
+  if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1020,8 +1036,9 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
   if (!c || !distance) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   TRY(enqueue_compare(c, true));
-  unsigned bits = 0;
-  HIPCHK(c, hipMemcpyAsync(&bits, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
+  void* res = nullptr;
+  TRY(result_buffer(c, 4, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
   if (distmap) TRY(download_plane(c, c->distmap, distmap));
   // the per-block maxima stay on the device (phase B's weights are computed there); they
   // come to the host only when asked for, here or by gz_block_weights
@@ -1032,7 +1049,7 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
                              hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  memcpy(&c->last_distance, &bits, 4);
+  memcpy(&c->last_distance, res, 4);
   *distance = c->last_distance;
   if (block_max) {
     memcpy(block_max, c->h_block_max.data(), sizeof(float) * c->nb);
@@ -1055,10 +1072,11 @@ int gz_compare_begin(gz_ctx* c) {
 int gz_compare_end(gz_ctx* c, float* distance) {
   if (!c || !distance) return GZ_E_ARG;
   if (!c->compare_pending) { c->err = "gz_compare_begin must precede gz_compare_end"; return GZ_E_STATE; }
-  unsigned bits = 0;
-  HIPCHK(c, hipMemcpyAsync(&bits, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
+  void* res = nullptr;
+  TRY(result_buffer(c, 4, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  memcpy(&c->last_distance, &bits, 4);
+  memcpy(&c->last_distance, res, 4);
   *distance = c->last_distance;
   c->have_distmap = true;
   c->compare_pending = false;
@@ -1172,11 +1190,15 @@ static int order_build_device(gz_ctx* c, int direction, int count_below, float l
             (const float*)c->d_max_err, (const unsigned long long*)c->d_order_off, direction, nb,
             count_below ? 1 : 0, limit, c->d_order, c->d_order_counters);
   KCHK(c);
+  void* res = nullptr;
+  TRY(result_buffer(c, 16, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_order_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync((char*)res + 8, c->d_order_counters, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   unsigned long long n = 0;
   unsigned counters[2] = {0, 0};
-  HIPCHK(c, hipMemcpyAsync(&n, c->d_order_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(counters, c->d_order_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(&n, res, 8);
+  memcpy(counters, (char*)res + 8, 8);
   if (n > c->order_cap) { c->err = "order larger than the candidate count"; return GZ_E_STATE; }
   c->order_n = (size_t)n;
   *total = n;
@@ -1351,8 +1373,11 @@ int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
             (const PartScalars*)ps, (const unsigned*)pos_l, (const unsigned*)pos_r);
   KCHK(c);
   PartScalars h;
-  HIPCHK(c, hipMemcpyAsync(&h, ps, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  void* res = nullptr;
+  TRY(result_buffer(c, sizeof(h), &res));
+  HIPCHK(c, hipMemcpyAsync(res, ps, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(&h, res, sizeof(h));
   uint64_t r = hi;
   if (h.cut_l != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_l);
   if (h.cut_r != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_r);
@@ -1362,8 +1387,17 @@ int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
 
 int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
   if (!c || !out || lo > hi || hi > c->order_n) return GZ_E_ARG;
+  const size_t bytes = sizeof(OrderEntry) * (size_t)(hi - lo);
+  if (bytes > 0 && bytes <= ((size_t)4 << 20)) {   // the usual case: through the pinned landing area
+    void* res = nullptr;
+    TRY(result_buffer(c, bytes, &res));
+    HIPCHK(c, hipMemcpyAsync(res, c->d_order + lo, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out, res, bytes);
+    return GZ_OK;
+  }
   if (hi > lo)
-    HIPCHK(c, hipMemcpyAsync(out, c->d_order + lo, sizeof(OrderEntry) * (hi - lo), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_order + lo, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GZ_OK;
 }
@@ -1397,8 +1431,11 @@ int gz_jpeg_histograms(gz_ctx* c, const int* q, uint32_t* counts) {
   GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
             (const int*)c->d_jq, c->nb, c->d_hist);
   KCHK(c);
-  HIPCHK(c, hipMemcpyAsync(counts, c->d_hist, sizeof(unsigned) * 1536, hipMemcpyDeviceToHost, c->stream));
+  void* res = nullptr;
+  TRY(result_buffer(c, sizeof(unsigned) * 1536, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_hist, sizeof(unsigned) * 1536, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(counts, res, sizeof(unsigned) * 1536);
   c->have_jq = true;
   return GZ_OK;
 }
@@ -1451,9 +1488,13 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
             c->d_ff_count);
   KCHK(c);
   unsigned long long total_bits = 0, ff = 0;
-  HIPCHK(c, hipMemcpyAsync(&total_bits, d_total, 8, hipMemcpyDeviceToHost, es));
-  HIPCHK(c, hipMemcpyAsync(&ff, c->d_ff_count, 8, hipMemcpyDeviceToHost, es));
+  void* res = nullptr;
+  TRY(result_buffer(c, 16, &res));
+  HIPCHK(c, hipMemcpyAsync(res, d_total, 8, hipMemcpyDeviceToHost, es));
+  HIPCHK(c, hipMemcpyAsync((char*)res + 8, c->d_ff_count, 8, hipMemcpyDeviceToHost, es));
   HIPCHK(c, hipStreamSynchronize(es));
+  memcpy(&total_bits, res, 8);
+  memcpy(&ff, (char*)res + 8, 8);
   const unsigned long long nbytes = (total_bits + 7) / 8;
   if (nbytes / 4 + 4 > c->words_cap) { c->err = "scan larger than its bound (code lengths above 16?)"; return GZ_E_ARG; }
   c->scan_bits = total_bits;

@@ -14,8 +14,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <atomic>
-#include <chrono>
 #include <string>
 #include <thread>
 #include <utility>
@@ -152,14 +150,6 @@ struct Psycho {   // device planes of one image's PsychoImage (butteraugli.h:418
 // Pinned host staging for the small per-iteration uploads (step lists, coefficient edits,
 // next_cand, Huffman codes): the caller's buffer is copied here, the H2D copy is asynchronous
 // and nobody has to wait for it -- the buffer is only waited for when it is reused.
-// Mapped pinned memory a tiny kernel (k_post) writes results into; the host polls its flag.
-struct Mailbox {
-  unsigned* h = nullptr;    // words 0-1: sequence flag; payload from word kBoxPayload
-  unsigned* d = nullptr;    // the device's view of h
-  unsigned long long seq = 0;
-};
-constexpr unsigned kBoxPayload = 4, kBoxWords = 2048;
-
 struct HostStage {
   void* h = nullptr;
   size_t cap = 0;
@@ -251,7 +241,6 @@ struct gz_ctx {
   // pinned landing area for the small results every call waits for (a copy into pageable
   // memory costs 27 us per round trip on this system, into pinned memory 15)
   void* h_res = nullptr; size_t h_res_cap = 0;
-  Mailbox box_main, box_entropy;
   size_t search_total = 0;   // candidates phase A produced (bounds every global order)
   float last_distance = 0.0f;
 };
@@ -398,58 +387,6 @@ static int result_buffer(gz_ctx* c, size_t bytes, void** out) {
   }
   *out = c->h_res;
   return GZ_OK;
-}
-static bool use_mailbox() {   // GZ_NO_MAILBOX=1: plain copies + stream waits
-  static const char* e = getenv("GZ_NO_MAILBOX");
-  return !(e && atoi(e) != 0);
-}
-// Brings up to three small device ranges (4-byte words; dst_word = where in the result) to the
-// host after everything enqueued on `stream`, and waits for them.  *res = the result words.
-static int fetch_small(gz_ctx* c, Mailbox* m, hipStream_t stream, PostSrc p, const unsigned** res) {
-  unsigned total = 0;
-  for (int k = 0; k < 3; ++k) total = std::max(total, p.words[k] ? p.dst_word[k] + p.words[k] : 0u);
-  if (!use_mailbox() || total + kBoxPayload > kBoxWords) {
-    void* r = nullptr;
-    TRY(result_buffer(c, sizeof(unsigned) * std::max(total, 1u), &r));
-    for (int k = 0; k < 3; ++k)
-      if (p.words[k])
-        HIPCHK(c, hipMemcpyAsync((unsigned*)r + p.dst_word[k], p.src[k], sizeof(unsigned) * p.words[k],
-                                 hipMemcpyDeviceToHost, stream));
-    HIPCHK(c, hipStreamSynchronize(stream));
-    *res = (const unsigned*)r;
-    return GZ_OK;
-  }
-  if (!m->h) {
-    HIPCHK(c, hipHostMalloc((void**)&m->h, sizeof(unsigned) * kBoxWords, hipHostMallocMapped));
-    memset(m->h, 0, sizeof(unsigned) * kBoxWords);
-    HIPCHK(c, hipHostGetDevicePointer((void**)&m->d, m->h, 0));
-  }
-  for (int k = 0; k < 3; ++k) p.dst_word[k] += kBoxPayload;
-  const unsigned long long seq = ++m->seq;
-  unsigned* box = m->d;
-  unsigned long long* flag = (unsigned long long*)m->d;
-  GZ_LAUNCH(k_post, dim3(1), dim3(256), stream, p, box, flag, seq);
-  KCHK(c);
-  volatile unsigned long long* seen = (volatile unsigned long long*)m->h;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 1; *seen != seq; ++spins) {
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#endif
-    if ((spins & 0xffff) == 0 &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
-      // not a latency matter any more: let the runtime report what happened
-      HIPCHK(c, hipStreamSynchronize(stream));
-      if (*seen != seq) { c->err = "result mailbox was not written"; return GZ_E_HIP; }
-    }
-  }
-  std::atomic_thread_fence(std::memory_order_acquire);
-  *res = m->h + kBoxPayload;
-  return GZ_OK;
-}
-static void mailbox_free(Mailbox* m) {
-  if (m->h) (void)hipHostFree(m->h);
-  m->h = nullptr; m->d = nullptr;
 }
 static void stage_free(HostStage* st) {
   if (st->ev) { (void)hipEventSynchronize(st->ev); (void)hipEventDestroy(st->ev); }
@@ -983,8 +920,6 @@ void gz_destroy(gz_ctx* c) {
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
   if (c->h_res) (void)hipHostFree(c->h_res);
-  mailbox_free(&c->box_main);
-  mailbox_free(&c->box_entropy);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1101,16 +1036,6 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
   if (!c || !distance) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   TRY(enqueue_compare(c, true));
-  if (!distmap && !block_max) {   // the search driver's case: four bytes back
-    PostSrc p = {{(const unsigned*)c->d_max_bits, nullptr, nullptr}, {1u, 0u, 0u}, {0u, 0u, 0u}};
-    const unsigned* r = nullptr;
-    TRY(fetch_small(c, &c->box_main, c->stream, p, &r));
-    memcpy(&c->last_distance, r, 4);
-    *distance = c->last_distance;
-    c->h_block_max_valid = false;
-    c->have_distmap = true;
-    return GZ_OK;
-  }
   void* res = nullptr;
   TRY(result_buffer(c, 4, &res));
   HIPCHK(c, hipMemcpyAsync(res, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1147,9 +1072,10 @@ int gz_compare_begin(gz_ctx* c) {
 int gz_compare_end(gz_ctx* c, float* distance) {
   if (!c || !distance) return GZ_E_ARG;
   if (!c->compare_pending) { c->err = "gz_compare_begin must precede gz_compare_end"; return GZ_E_STATE; }
-  PostSrc p = {{(const unsigned*)c->d_max_bits, nullptr, nullptr}, {1u, 0u, 0u}, {0u, 0u, 0u}};
-  const unsigned* res = nullptr;
-  TRY(fetch_small(c, &c->box_main, c->stream, p, &res));
+  void* res = nullptr;
+  TRY(result_buffer(c, 4, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   memcpy(&c->last_distance, res, 4);
   *distance = c->last_distance;
   c->have_distmap = true;
@@ -1264,14 +1190,15 @@ static int order_build_device(gz_ctx* c, int direction, int count_below, float l
             (const float*)c->d_max_err, (const unsigned long long*)c->d_order_off, direction, nb,
             count_below ? 1 : 0, limit, c->d_order, c->d_order_counters);
   KCHK(c);
-  PostSrc p = {{(const unsigned*)(c->d_order_off + nb), (const unsigned*)c->d_order_counters, nullptr},
-               {2u, 2u, 0u}, {0u, 2u, 0u}};
-  const unsigned* res = nullptr;
-  TRY(fetch_small(c, &c->box_main, c->stream, p, &res));
+  void* res = nullptr;
+  TRY(result_buffer(c, 16, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_order_off + nb, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync((char*)res + 8, c->d_order_counters, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   unsigned long long n = 0;
   unsigned counters[2] = {0, 0};
   memcpy(&n, res, 8);
-  memcpy(counters, res + 2, 8);
+  memcpy(counters, (char*)res + 8, 8);
   if (n > c->order_cap) { c->err = "order larger than the candidate count"; return GZ_E_STATE; }
   c->order_n = (size_t)n;
   *total = n;
@@ -1446,10 +1373,10 @@ int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
             (const PartScalars*)ps, (const unsigned*)pos_l, (const unsigned*)pos_r);
   KCHK(c);
   PartScalars h;
-  static_assert(sizeof(PartScalars) % 4 == 0, "PartScalars is copied in words");
-  PostSrc p = {{(const unsigned*)ps, nullptr, nullptr}, {(unsigned)(sizeof(h) / 4), 0u, 0u}, {0u, 0u, 0u}};
-  const unsigned* res = nullptr;
-  TRY(fetch_small(c, &c->box_main, c->stream, p, &res));
+  void* res = nullptr;
+  TRY(result_buffer(c, sizeof(h), &res));
+  HIPCHK(c, hipMemcpyAsync(res, ps, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   memcpy(&h, res, sizeof(h));
   uint64_t r = hi;
   if (h.cut_l != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_l);
@@ -1504,9 +1431,10 @@ int gz_jpeg_histograms(gz_ctx* c, const int* q, uint32_t* counts) {
   GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
             (const int*)c->d_jq, c->nb, c->d_hist);
   KCHK(c);
-  PostSrc p = {{(const unsigned*)c->d_hist, nullptr, nullptr}, {1536u, 0u, 0u}, {0u, 0u, 0u}};
-  const unsigned* res = nullptr;
-  TRY(fetch_small(c, &c->box_main, c->stream, p, &res));
+  void* res = nullptr;
+  TRY(result_buffer(c, sizeof(unsigned) * 1536, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_hist, sizeof(unsigned) * 1536, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   memcpy(counts, res, sizeof(unsigned) * 1536);
   c->have_jq = true;
   return GZ_OK;
@@ -1560,11 +1488,13 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
             c->d_ff_count);
   KCHK(c);
   unsigned long long total_bits = 0, ff = 0;
-  PostSrc p = {{(const unsigned*)d_total, (const unsigned*)c->d_ff_count, nullptr}, {2u, 2u, 0u}, {0u, 2u, 0u}};
-  const unsigned* res = nullptr;
-  TRY(fetch_small(c, &c->box_entropy, es, p, &res));
+  void* res = nullptr;
+  TRY(result_buffer(c, 16, &res));
+  HIPCHK(c, hipMemcpyAsync(res, d_total, 8, hipMemcpyDeviceToHost, es));
+  HIPCHK(c, hipMemcpyAsync((char*)res + 8, c->d_ff_count, 8, hipMemcpyDeviceToHost, es));
+  HIPCHK(c, hipStreamSynchronize(es));
   memcpy(&total_bits, res, 8);
-  memcpy(&ff, res + 2, 8);
+  memcpy(&ff, (char*)res + 8, 8);
   const unsigned long long nbytes = (total_bits + 7) / 8;
   if (nbytes / 4 + 4 > c->words_cap) { c->err = "scan larger than its bound (code lengths above 16?)"; return GZ_E_ARG; }
   c->scan_bits = total_bits;

@@ -410,29 +410,4 @@ __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, s
   order_swap(a, first + pos_l[k], first + pos_r[k]);
 }
 
-// ------------------------------------------------------------- result mailbox ------
-// The host driver waits ~10 times per iteration for a few bytes (a cut, a count, a
-// distance).  A copy into pinned memory plus a stream wait costs 15 us per round trip on this
-// system; a kernel that writes the bytes into mapped host memory and raises a flag the host
-// polls costs 7 (tools/ubench/sync.hip).  k_post copies up to three small device ranges into
-// the mailbox (4-byte words) and then publishes the sequence number.
-struct PostSrc {
-  const unsigned* src[3];
-  unsigned words[3];
-  unsigned dst_word[3];
-};
-__global__ __launch_bounds__(256) void k_post(PostSrc p, unsigned* __restrict__ box,
-                                              unsigned long long* __restrict__ flag,
-                                              unsigned long long seq) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    for (unsigned i = threadIdx.x; i < p.words[k]; i += 256) box[p.dst_word[k] + i] = p.src[k][i];
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    *flag = seq;
-    __threadfence_system();
-  }
-}
-
 }  // namespace gz

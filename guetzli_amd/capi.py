@@ -39,6 +39,7 @@ SIGNATURES = {
     "gz_set_coeff_blocks": (_I, [_P, _P, _I, _P]),
     "gz_get_coeffs": (_I, [_P, _P]),
     "gz_reconstruct": (_I, [_P, _P, _P]),
+    "gz_trim_pool": (_I, []),
     "gz_compare": (_I, [_P, _P, _P, _P]),
     "gz_compare_begin": (_I, [_P]),
     "gz_compare_end": (_I, [_P, _P]),

@@ -14,6 +14,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <string>
 #include <thread>
 #include <utility>
@@ -145,6 +148,93 @@ struct Psycho {   // device planes of one image's PsychoImage (butteraugli.h:418
   float* uhf[2];
 };
 
+}  // namespace
+
+// ------------------------------------------------------------ caching allocator ------
+// One image = one context = ~45 device allocations (0.5 GB at 1080p, 2 GB at 4K) and three
+// pinned host buffers; hipMalloc / hipFree (which also synchronises the device) of those cost
+// ~10 ms per image.  Freed blocks are kept in exact-size free lists per device and handed to
+// the next context that asks for the same size -- a batch of same-sized images allocates once.
+// GZ_POOL_MB bounds the cached device bytes per device (default 16384; 0 = no caching);
+// gz_trim_pool() releases everything cached.  The emulation build allocates directly, so that
+// its poisoning of fresh memory keeps catching reads of never-written buffers.
+namespace {
+struct MemPool {
+  std::mutex mu;
+  std::unordered_map<void*, std::pair<int, size_t> > live;          // ptr -> (device, bytes)
+  std::multimap<std::pair<int, size_t>, void*> idle;                // (device, bytes) -> ptr
+  std::unordered_map<int, size_t> idle_bytes;                       // per device
+};
+MemPool& dev_pool() { static MemPool p; return p; }
+MemPool& host_pool() { static MemPool p; return p; }
+size_t pool_limit_bytes() {
+  static const size_t lim = [] {
+    const char* e = getenv("GZ_POOL_MB");
+    return (size_t)(e ? std::max(0L, atol(e)) : 16384L) << 20;
+  }();
+  return lim;
+}
+void pool_release_idle(MemPool& p, bool host, int device /* -1: all */) {
+  for (auto it = p.idle.begin(); it != p.idle.end();) {
+    if (device >= 0 && it->first.first != device) { ++it; continue; }
+    if (host) (void)hipHostFree(it->second); else (void)hipFree(it->second);
+    p.idle_bytes[it->first.first] -= it->first.second;
+    it = p.idle.erase(it);
+  }
+}
+hipError_t pool_alloc(MemPool& p, bool host, void** out, size_t bytes) {
+  if (bytes == 0) bytes = 1;
+#ifdef GZ_EMU
+  return host ? hipHostMalloc(out, bytes, 0) : hipMalloc(out, bytes);
+#else
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::lock_guard<std::mutex> lk(p.mu);
+  auto it = p.idle.find(std::make_pair(device, bytes));
+  if (it != p.idle.end()) {
+    *out = it->second;
+    p.idle.erase(it);
+    p.idle_bytes[device] -= bytes;
+    p.live[*out] = std::make_pair(device, bytes);
+    return hipSuccess;
+  }
+  hipError_t e = host ? hipHostMalloc(out, bytes, 0) : hipMalloc(out, bytes);
+  if (e != hipSuccess) {   // make room: drop what is cached on this device and try once more
+    (void)hipGetLastError();
+    pool_release_idle(p, host, device);
+    e = host ? hipHostMalloc(out, bytes, 0) : hipMalloc(out, bytes);
+  }
+  if (e == hipSuccess) p.live[*out] = std::make_pair(device, bytes);
+  return e;
+#endif
+}
+void pool_release(MemPool& p, bool host, void* ptr) {
+  if (!ptr) return;
+#ifdef GZ_EMU
+  if (host) (void)hipHostFree(ptr); else (void)hipFree(ptr);
+#else
+  std::lock_guard<std::mutex> lk(p.mu);
+  auto it = p.live.find(ptr);
+  if (it == p.live.end()) {   // not ours
+    if (host) (void)hipHostFree(ptr); else (void)hipFree(ptr);
+    return;
+  }
+  const std::pair<int, size_t> key = it->second;
+  p.live.erase(it);
+  if (p.idle_bytes[key.first] + key.second <= pool_limit_bytes()) {
+    p.idle.insert(std::make_pair(key, ptr));
+    p.idle_bytes[key.first] += key.second;
+  } else if (host) {
+    (void)hipHostFree(ptr);
+  } else {
+    (void)hipFree(ptr);
+  }
+#endif
+}
+inline hipError_t pool_malloc(void** out, size_t bytes) { return pool_alloc(dev_pool(), false, out, bytes); }
+inline void pool_free(void* ptr) { pool_release(dev_pool(), false, ptr); }
+inline hipError_t pool_host_malloc(void** out, size_t bytes) { return pool_alloc(host_pool(), true, out, bytes); }
+inline void pool_host_free(void* ptr) { pool_release(host_pool(), true, ptr); }
 }  // namespace
 
 // Pinned host staging for the small per-iteration uploads (step lists, coefficient edits,
@@ -361,11 +451,11 @@ static int stage_reserve(gz_ctx* c, HostStage* st, size_t bytes, void** out) {
     st->busy = false;
   }
   if (bytes > st->cap) {
-    if (st->h) (void)hipHostFree(st->h);
+    if (st->h) (void)pool_host_free(st->h);
     st->h = nullptr;
     st->cap = 0;
     const size_t cap = bytes + bytes / 2 + 4096;
-    HIPCHK(c, hipHostMalloc(&st->h, cap, 0));
+    HIPCHK(c, pool_host_malloc(&st->h, cap));
     st->cap = cap;
   }
   *out = st->h;
@@ -378,11 +468,11 @@ static int stage_sent(gz_ctx* c, HostStage* st, hipStream_t stream) {
 }
 static int result_buffer(gz_ctx* c, size_t bytes, void** out) {
   if (bytes > c->h_res_cap) {
-    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_res) (void)pool_host_free(c->h_res);
     c->h_res = nullptr;
     c->h_res_cap = 0;
     const size_t cap = std::max<size_t>(bytes + bytes / 2, 1 << 16);
-    HIPCHK(c, hipHostMalloc(&c->h_res, cap, 0));
+    HIPCHK(c, pool_host_malloc(&c->h_res, cap));
     c->h_res_cap = cap;
   }
   *out = c->h_res;
@@ -390,7 +480,7 @@ static int result_buffer(gz_ctx* c, size_t bytes, void** out) {
 }
 static void stage_free(HostStage* st) {
   if (st->ev) { (void)hipEventSynchronize(st->ev); (void)hipEventDestroy(st->ev); }
-  if (st->h) (void)hipHostFree(st->h);
+  if (st->h) (void)pool_host_free(st->h);
   st->h = nullptr; st->ev = nullptr; st->cap = 0; st->busy = false;
 }
 
@@ -401,7 +491,7 @@ int setup_blur_cfg(gz_ctx* c, BlurCfg* cfg, float sigma, float border_ratio) {
   border_scales_host(*cfg, c->w, &xl, &xh);
   border_scales_host(*cfg, c->h, &yl, &yh);
   const int r = cfg->r;
-  if (cfg->d_scale == nullptr) HIPCHK(c, hipMalloc((void**)&cfg->d_scale, sizeof(float) * 4 * r));
+  if (cfg->d_scale == nullptr) HIPCHK(c, pool_malloc((void**)&cfg->d_scale, sizeof(float) * 4 * r));
   std::vector<float> all;
   all.insert(all.end(), xl.begin(), xl.end());
   all.insert(all.end(), xh.begin(), xh.end());
@@ -661,7 +751,7 @@ int download_plane(gz_ctx* c, const float* dev, float* host) {
 
 int ensure_pip(gz_ctx* c) {
   if (c->have_pip) return GZ_OK;
-  HIPCHK(c, hipMalloc((void**)&c->extra_arena, sizeof(float) * c->plane * 15));
+  HIPCHK(c, pool_malloc((void**)&c->extra_arena, sizeof(float) * c->plane * 15));
   for (int i = 0; i < 15; ++i) c->free_planes.push_back(c->extra_arena + (size_t)i * c->plane);
   alloc_psycho(c, &c->pip);
   for (int i = 0; i < 3; ++i) { c->mask_out[i] = take_plane(c); c->mask_dc_out[i] = take_plane(c); }
@@ -676,7 +766,7 @@ int ensure_pip(gz_ctx* c) {
 int ensure_block_mask(gz_ctx* c) {
   if (c->have_block_mask) return GZ_OK;
   TRY(ensure_pip(c));
-  if (!c->d_block_mask) HIPCHK(c, hipMalloc((void**)&c->d_block_mask, sizeof(float) * 3 * c->nb));
+  if (!c->d_block_mask) HIPCHK(c, pool_malloc((void**)&c->d_block_mask, sizeof(float) * 3 * c->nb));
   dim3 grid(gz_div_up(c->w, 256), c->h);
   GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, c->w, c->h, c->pitch,
             c->plane, c->d_srgb_lut, c->lin[0]);
@@ -778,6 +868,18 @@ extern "C" {
 
 int gz_abi_version(void) { return 1; }
 
+int gz_trim_pool(void) {
+  {
+    MemPool& p = dev_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    pool_release_idle(p, false, -1);
+  }
+  MemPool& h = host_pool();
+  std::lock_guard<std::mutex> lk(h.mu);
+  pool_release_idle(h, true, -1);
+  return GZ_OK;
+}
+
 int gz_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return GZ_E_NO_DEVICE;
@@ -828,16 +930,16 @@ gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, in
   CHK0(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   CHK0(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
   const size_t ncoef = (size_t)3 * c->nb * 64;
-  CHK0(hipMalloc((void**)&c->d_rgb, (size_t)3 * w * h));
-  CHK0(hipMalloc((void**)&c->d_orig, ncoef * 2));
-  CHK0(hipMalloc((void**)&c->d_cand, ncoef * 2));
-  CHK0(hipMalloc((void**)&c->d_q, sizeof(int) * 192));
-  CHK0(hipMalloc((void**)&c->d_srgb_lut, sizeof(float) * 256));
-  CHK0(hipMalloc((void**)&c->d_mask_luts, sizeof(double) * 2048));
-  CHK0(hipMalloc((void**)&c->d_block_max, sizeof(float) * c->nb));
-  CHK0(hipMalloc((void**)&c->d_max_bits, sizeof(unsigned)));
-  CHK0(hipMalloc((void**)&c->d_srgb_out, (size_t)3 * w * h));
-  CHK0(hipMalloc((void**)&c->arena, sizeof(float) * c->plane * kNumPlanes));
+  CHK0(pool_malloc((void**)&c->d_rgb, (size_t)3 * w * h));
+  CHK0(pool_malloc((void**)&c->d_orig, ncoef * 2));
+  CHK0(pool_malloc((void**)&c->d_cand, ncoef * 2));
+  CHK0(pool_malloc((void**)&c->d_q, sizeof(int) * 192));
+  CHK0(pool_malloc((void**)&c->d_srgb_lut, sizeof(float) * 256));
+  CHK0(pool_malloc((void**)&c->d_mask_luts, sizeof(double) * 2048));
+  CHK0(pool_malloc((void**)&c->d_block_max, sizeof(float) * c->nb));
+  CHK0(pool_malloc((void**)&c->d_max_bits, sizeof(unsigned)));
+  CHK0(pool_malloc((void**)&c->d_srgb_out, (size_t)3 * w * h));
+  CHK0(pool_malloc((void**)&c->arena, sizeof(float) * c->plane * kNumPlanes));
   for (int i = kNumPlanes - 1; i >= 0; --i) c->free_planes.push_back(c->arena + (size_t)i * c->plane);
   alloc_psycho(c, &c->pi0);
   alloc_psycho(c, &c->pi1);
@@ -898,28 +1000,28 @@ int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
 void gz_destroy(gz_ctx* c) {
   if (!c) return;
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  (void)hipFree(c->d_rgb); (void)hipFree(c->d_orig); (void)hipFree(c->d_cand); (void)hipFree(c->d_q);
-  (void)hipFree(c->d_srgb_lut); (void)hipFree(c->d_mask_luts); (void)hipFree(c->d_block_max);
-  (void)hipFree(c->d_max_bits); (void)hipFree(c->d_srgb_out); (void)hipFree(c->arena);
-  (void)hipFree(c->d_blkidx); (void)hipFree(c->d_blkdata);
-  (void)hipFree(c->extra_arena);
-  (void)hipFree(c->d_block_mask); (void)hipFree(c->d_rank_cnt); (void)hipFree(c->d_rank_tables); (void)hipFree(c->d_rank_idx);
-  (void)hipFree(c->d_out_cnt); (void)hipFree(c->d_out_idx); (void)hipFree(c->d_out_err);
-  (void)hipFree(c->d_jq); (void)hipFree(c->d_hist); (void)hipFree(c->d_code_depth); (void)hipFree(c->d_code_bits);
-  (void)hipFree(c->d_mcu_bits); (void)hipFree(c->d_mcu_off); (void)hipFree(c->d_ff_count);
-  (void)hipFree(c->d_words); (void)hipFree(c->d_words_kept);
-  (void)hipFree(c->d_order); (void)hipFree(c->d_pos_l); (void)hipFree(c->d_pos_r); (void)hipFree(c->d_chunk);
-  (void)hipFree(c->d_part); (void)hipFree(c->d_order_nb); (void)hipFree(c->d_order_off);
-  (void)hipFree(c->d_order_counters); (void)hipFree(c->d_next_cand); (void)hipFree(c->d_weight);
-  (void)hipFree(c->d_max_err); (void)hipFree(c->d_wflag); (void)hipFree(c->d_edit_pos); (void)hipFree(c->d_edit_val);
-  for (int b = 0; b < B_COUNT; ++b) (void)hipFree(c->blur[b].d_scale);
+  (void)pool_free(c->d_rgb); (void)pool_free(c->d_orig); (void)pool_free(c->d_cand); (void)pool_free(c->d_q);
+  (void)pool_free(c->d_srgb_lut); (void)pool_free(c->d_mask_luts); (void)pool_free(c->d_block_max);
+  (void)pool_free(c->d_max_bits); (void)pool_free(c->d_srgb_out); (void)pool_free(c->arena);
+  (void)pool_free(c->d_blkidx); (void)pool_free(c->d_blkdata);
+  (void)pool_free(c->extra_arena);
+  (void)pool_free(c->d_block_mask); (void)pool_free(c->d_rank_cnt); (void)pool_free(c->d_rank_tables); (void)pool_free(c->d_rank_idx);
+  (void)pool_free(c->d_out_cnt); (void)pool_free(c->d_out_idx); (void)pool_free(c->d_out_err);
+  (void)pool_free(c->d_jq); (void)pool_free(c->d_hist); (void)pool_free(c->d_code_depth); (void)pool_free(c->d_code_bits);
+  (void)pool_free(c->d_mcu_bits); (void)pool_free(c->d_mcu_off); (void)pool_free(c->d_ff_count);
+  (void)pool_free(c->d_words); (void)pool_free(c->d_words_kept);
+  (void)pool_free(c->d_order); (void)pool_free(c->d_pos_l); (void)pool_free(c->d_pos_r); (void)pool_free(c->d_chunk);
+  (void)pool_free(c->d_part); (void)pool_free(c->d_order_nb); (void)pool_free(c->d_order_off);
+  (void)pool_free(c->d_order_counters); (void)pool_free(c->d_next_cand); (void)pool_free(c->d_weight);
+  (void)pool_free(c->d_max_err); (void)pool_free(c->d_wflag); (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
+  for (int b = 0; b < B_COUNT; ++b) (void)pool_free(c->blur[b].d_scale);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
   if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); (void)hipStreamDestroy(c->side_stream2); }
   if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); (void)hipStreamDestroy(c->entropy_stream); }
   if (c->ev_candidate) (void)hipEventDestroy(c->ev_candidate);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
-  if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->h_res) (void)pool_host_free(c->h_res);
   if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -999,11 +1101,11 @@ int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int1
   for (int i = 0; i < n; ++i)
     if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;
   if ((size_t)n > c->blkidx_cap) {
-    (void)hipFree(c->d_blkidx); (void)hipFree(c->d_blkdata);
+    (void)pool_free(c->d_blkidx); (void)pool_free(c->d_blkdata);
     c->d_blkidx = nullptr; c->d_blkdata = nullptr;
     c->blkidx_cap = std::max<size_t>((size_t)n, std::min<size_t>((size_t)c->nb, 2 * c->blkidx_cap + 1024));
-    HIPCHK(c, hipMalloc((void**)&c->d_blkidx, sizeof(int32_t) * c->blkidx_cap));
-    HIPCHK(c, hipMalloc((void**)&c->d_blkdata, c->blkidx_cap * 384));
+    HIPCHK(c, pool_malloc((void**)&c->d_blkidx, sizeof(int32_t) * c->blkidx_cap));
+    HIPCHK(c, pool_malloc((void**)&c->d_blkdata, c->blkidx_cap * 384));
   }
   HIPCHK(c, hipMemcpyAsync(c->d_blkidx, block_index, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_blkdata, blocks, (size_t)n * 384, hipMemcpyHostToDevice, c->stream));
@@ -1140,19 +1242,19 @@ int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target
 // ------------------------------------------------- global candidate order (phase B) ----
 static int ensure_order_capacity(gz_ctx* c, size_t n) {
   if (!c->d_part) {
-    HIPCHK(c, hipMalloc((void**)&c->d_part, sizeof(PartScalars)));
-    HIPCHK(c, hipMalloc((void**)&c->d_order_counters, sizeof(unsigned) * 2));
+    HIPCHK(c, pool_malloc((void**)&c->d_part, sizeof(PartScalars)));
+    HIPCHK(c, pool_malloc((void**)&c->d_order_counters, sizeof(unsigned) * 2));
   }
   if (n <= c->order_cap) return GZ_OK;
-  (void)hipFree(c->d_order); (void)hipFree(c->d_pos_l); (void)hipFree(c->d_pos_r); (void)hipFree(c->d_chunk);
+  (void)pool_free(c->d_order); (void)pool_free(c->d_pos_l); (void)pool_free(c->d_pos_r); (void)pool_free(c->d_chunk);
   c->d_order = nullptr; c->d_pos_l = nullptr; c->d_pos_r = nullptr; c->d_chunk = nullptr;
   c->order_cap = 0;
   const size_t cap = n + n / 8 + 4096;
-  HIPCHK(c, hipMalloc((void**)&c->d_order, sizeof(OrderEntry) * cap));
-  HIPCHK(c, hipMalloc((void**)&c->d_pos_l, sizeof(unsigned) * (cap / 2 + 1)));
-  HIPCHK(c, hipMalloc((void**)&c->d_pos_r, sizeof(unsigned) * (cap / 2 + 1)));
+  HIPCHK(c, pool_malloc((void**)&c->d_order, sizeof(OrderEntry) * cap));
+  HIPCHK(c, pool_malloc((void**)&c->d_pos_l, sizeof(unsigned) * (cap / 2 + 1)));
+  HIPCHK(c, pool_malloc((void**)&c->d_pos_r, sizeof(unsigned) * (cap / 2 + 1)));
   c->chunk_cap = cap / kPartChunk + 2;
-  HIPCHK(c, hipMalloc((void**)&c->d_chunk, sizeof(unsigned) * 4 * c->chunk_cap));
+  HIPCHK(c, pool_malloc((void**)&c->d_chunk, sizeof(unsigned) * 4 * c->chunk_cap));
   c->order_cap = cap;
   return GZ_OK;
 }
@@ -1160,12 +1262,12 @@ static int ensure_order_capacity(gz_ctx* c, size_t n) {
 static int ensure_order_block_arrays(gz_ctx* c) {
   if (c->d_order_nb) return GZ_OK;
   const int nb = c->nb;
-  HIPCHK(c, hipMalloc((void**)&c->d_order_nb, sizeof(unsigned) * nb));
-  HIPCHK(c, hipMalloc((void**)&c->d_order_off, sizeof(unsigned long long) * (nb + 1)));
-  HIPCHK(c, hipMalloc((void**)&c->d_next_cand, sizeof(int) * nb));
-  HIPCHK(c, hipMalloc((void**)&c->d_weight, sizeof(float) * nb));
-  HIPCHK(c, hipMalloc((void**)&c->d_max_err, sizeof(float) * nb));
-  HIPCHK(c, hipMalloc((void**)&c->d_wflag, nb));
+  HIPCHK(c, pool_malloc((void**)&c->d_order_nb, sizeof(unsigned) * nb));
+  HIPCHK(c, pool_malloc((void**)&c->d_order_off, sizeof(unsigned long long) * (nb + 1)));
+  HIPCHK(c, pool_malloc((void**)&c->d_next_cand, sizeof(int) * nb));
+  HIPCHK(c, pool_malloc((void**)&c->d_weight, sizeof(float) * nb));
+  HIPCHK(c, pool_malloc((void**)&c->d_max_err, sizeof(float) * nb));
+  HIPCHK(c, pool_malloc((void**)&c->d_wflag, nb));
   HIPCHK(c, hipMemsetAsync(c->d_max_err, 0, sizeof(float) * nb, c->stream));
   return GZ_OK;
 }
@@ -1279,11 +1381,11 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
   for (int i = 0; i < n; ++i)
     if (blocks[i] < 0 || blocks[i] >= c->nb || counts[i] < 0 || counts[i] > 192) return GZ_E_ARG;
   if ((size_t)2 * n > c->edit_cap) {   // the edit buffers double as (blocks, counts) staging
-    (void)hipFree(c->d_edit_pos); (void)hipFree(c->d_edit_val);
+    (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
     c->d_edit_pos = nullptr; c->d_edit_val = nullptr;
     c->edit_cap = (size_t)2 * n + (size_t)n + 4096;
-    HIPCHK(c, hipMalloc((void**)&c->d_edit_pos, sizeof(int) * c->edit_cap));
-    HIPCHK(c, hipMalloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
+    HIPCHK(c, pool_malloc((void**)&c->d_edit_pos, sizeof(int) * c->edit_cap));
+    HIPCHK(c, pool_malloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
   }
   int* d_blocks = c->d_edit_pos;
   int* d_counts = c->d_edit_pos + n;
@@ -1312,11 +1414,11 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
   for (int i = 0; i < n; ++i)
     if (pos[i] < 0 || pos[i] >= limit) return GZ_E_ARG;
   if ((size_t)n > c->edit_cap) {
-    (void)hipFree(c->d_edit_pos); (void)hipFree(c->d_edit_val);
+    (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
     c->d_edit_pos = nullptr; c->d_edit_val = nullptr;
     c->edit_cap = (size_t)n + (size_t)n / 2 + 4096;
-    HIPCHK(c, hipMalloc((void**)&c->d_edit_pos, sizeof(int) * c->edit_cap));
-    HIPCHK(c, hipMalloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
+    HIPCHK(c, pool_malloc((void**)&c->d_edit_pos, sizeof(int) * c->edit_cap));
+    HIPCHK(c, pool_malloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
   }
   {
     void* h = nullptr;
@@ -1406,13 +1508,13 @@ int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
 // ------------------------------------------------------------- device entropy coder ----
 static int ensure_entropy_buffers(gz_ctx* c) {
   if (c->d_jq) return GZ_OK;
-  HIPCHK(c, hipMalloc((void**)&c->d_jq, sizeof(int) * 192));
-  HIPCHK(c, hipMalloc((void**)&c->d_hist, sizeof(unsigned) * 1536));
-  HIPCHK(c, hipMalloc((void**)&c->d_code_depth, 1536));
-  HIPCHK(c, hipMalloc((void**)&c->d_code_bits, sizeof(unsigned short) * 1536));
-  HIPCHK(c, hipMalloc((void**)&c->d_mcu_bits, sizeof(unsigned) * c->nb));
-  HIPCHK(c, hipMalloc((void**)&c->d_mcu_off, sizeof(unsigned long long) * (c->nb + 1)));
-  HIPCHK(c, hipMalloc((void**)&c->d_ff_count, sizeof(unsigned long long)));
+  HIPCHK(c, pool_malloc((void**)&c->d_jq, sizeof(int) * 192));
+  HIPCHK(c, pool_malloc((void**)&c->d_hist, sizeof(unsigned) * 1536));
+  HIPCHK(c, pool_malloc((void**)&c->d_code_depth, 1536));
+  HIPCHK(c, pool_malloc((void**)&c->d_code_bits, sizeof(unsigned short) * 1536));
+  HIPCHK(c, pool_malloc((void**)&c->d_mcu_bits, sizeof(unsigned) * c->nb));
+  HIPCHK(c, pool_malloc((void**)&c->d_mcu_off, sizeof(unsigned long long) * (c->nb + 1)));
+  HIPCHK(c, pool_malloc((void**)&c->d_ff_count, sizeof(unsigned long long)));
   return GZ_OK;
 }
 
@@ -1449,10 +1551,10 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   // once, so that no host round trip is needed between counting the bits and writing them.
   const size_t cap_words = (size_t)c->nb * 3 * (64 + 1) + 8;
   if (cap_words > c->words_cap) {
-    (void)hipFree(c->d_words);
+    (void)pool_free(c->d_words);
     c->d_words = nullptr;
     c->words_cap = 0;
-    HIPCHK(c, hipMalloc((void**)&c->d_words, sizeof(unsigned) * cap_words));
+    HIPCHK(c, pool_malloc((void**)&c->d_words, sizeof(unsigned) * cap_words));
     c->words_cap = cap_words;
   }
   // own stream, behind the candidate (not behind a Compare that gz_compare_begin enqueued)
@@ -1509,10 +1611,10 @@ int gz_jpeg_scan_keep(gz_ctx* c) {
   if (!c->have_scan) { c->err = "no scan to keep"; return GZ_E_STATE; }
   const size_t need_words = (size_t)((c->scan_bits + 7) / 8 / 4 + 4);
   if (need_words > c->words_kept_cap) {
-    (void)hipFree(c->d_words_kept);
+    (void)pool_free(c->d_words_kept);
     c->d_words_kept = nullptr;
     c->words_kept_cap = need_words + need_words / 4 + 1024;
-    HIPCHK(c, hipMalloc((void**)&c->d_words_kept, sizeof(unsigned) * c->words_kept_cap));
+    HIPCHK(c, pool_malloc((void**)&c->d_words_kept, sizeof(unsigned) * c->words_kept_cap));
   }
   HIPCHK(c, hipMemcpyAsync(c->d_words_kept, c->d_words, sizeof(unsigned) * need_words,
                            hipMemcpyDeviceToDevice, c->stream));
@@ -1577,7 +1679,7 @@ int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, f
 #undef GZ_BLUR_CASE2
   if (rc == GZ_OK) rc = download_plane(c, c->xyb[1], out);
   (void)hipStreamSynchronize(c->stream);
-  (void)hipFree(cfg.d_scale);
+  (void)pool_free(cfg.d_scale);
   return rc;
 }
 
@@ -1841,12 +1943,12 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
   TRY(ensure_block_mask(c));
   const int nb = c->nb;
   if (!c->d_rank_cnt) {
-    HIPCHK(c, hipMalloc((void**)&c->d_rank_cnt, sizeof(int32_t) * nb));
-    HIPCHK(c, hipMalloc((void**)&c->d_rank_idx, (size_t)nb * 192));
-    HIPCHK(c, hipMalloc((void**)&c->d_rank_tables, sizeof(float) * 384));
-    HIPCHK(c, hipMalloc((void**)&c->d_out_cnt, sizeof(int32_t) * nb));
-    HIPCHK(c, hipMalloc((void**)&c->d_out_idx, (size_t)nb * 192));
-    HIPCHK(c, hipMalloc((void**)&c->d_out_err, sizeof(float) * nb * 192));
+    HIPCHK(c, pool_malloc((void**)&c->d_rank_cnt, sizeof(int32_t) * nb));
+    HIPCHK(c, pool_malloc((void**)&c->d_rank_idx, (size_t)nb * 192));
+    HIPCHK(c, pool_malloc((void**)&c->d_rank_tables, sizeof(float) * 384));
+    HIPCHK(c, pool_malloc((void**)&c->d_out_cnt, sizeof(int32_t) * nb));
+    HIPCHK(c, pool_malloc((void**)&c->d_out_idx, (size_t)nb * 192));
+    HIPCHK(c, pool_malloc((void**)&c->d_out_err, sizeof(float) * nb * 192));
     HIPCHK(c, hipMemcpyAsync(c->d_rank_tables, kOrderCsf, sizeof(float) * 192, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_rank_tables + 192, kOrderBias, sizeof(float) * 192, hipMemcpyHostToDevice, c->stream));
   }

@@ -45,6 +45,11 @@ typedef struct gz_ctx gz_ctx;
 
 /* Library / device ------------------------------------------------------------ */
 int gz_abi_version(void);                 /* currently 1 */
+/* Device and pinned host memory of destroyed contexts is kept (per device, exact sizes, at
+ * most GZ_POOL_MB megabytes of device memory, default 16384) for the next context of the same
+ * image size: a batch of same-sized images allocates once.  gz_trim_pool releases everything
+ * that is cached; GZ_POOL_MB=0 turns the caching off. */
+int gz_trim_pool(void);
 int gz_device_count(void);                /* number of visible HIP devices, <0 on error */
 const char* gz_strerror(int code);
 const char* gz_last_error(const gz_ctx* ctx);

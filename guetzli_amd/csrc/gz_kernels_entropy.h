@@ -153,42 +153,38 @@ __global__ __launch_bounds__(64) void k_jpeg_block_bits(const int16_t* __restric
   if (lane == 0) bits[b] = (unsigned)total;
 }
 
-// off[0..nb] = exclusive prefix sums of bits[0..nb) (64-bit).  One workgroup of 1024 handles
-// 32768 values at a time through LDS: coalesced loads (32 per lane, all in flight together)
-// into a padded array, each lane then owns 32 CONSECUTIVE values (index i lives at i + i/32, so
-// the lanes' strided reads hit different banks), scans them serially, the 1024 lane sums are
-// scanned with wavefront shuffles plus one exchange between the 16 wavefronts, the prefixes
-// go back through LDS and out with coalesced 8-byte stores.  A value is at most a block's
-// scan bits or its candidate count, so 32 bits suffice inside a tile; the running total across
-// tiles is 64-bit.  (Two earlier versions: a contiguous chunk per lane straight from global
-// memory -- 128-byte-strided loads, 80 us for 32 400 values -- and 4096-value tiles with two
-// barriers each, 22 us.)
-constexpr int kScanLanes = 1024, kScanPer = 32, kScanTile = kScanLanes * kScanPer;
+// off[0..nb] = exclusive prefix sums of bits[0..nb) (64-bit).  One workgroup of 1024 walks
+// the array in tiles of 4096: a lane takes 4 consecutive values (one 16-byte load, issued one
+// tile ahead), the tile is scanned in 32 bits (a value is at most a block's scan bits or its
+// candidate count: 4096 of them stay far below 2^31) with wavefront shuffles plus one LDS
+// exchange between the 16 wavefronts, and the running total is carried in 64 bits.
+constexpr int kScanTile = 4096;
 
-GZ_DEVFN int scan_slot(int i) { return i + (i >> 5); }
+struct alignas(16) ScanU4 { unsigned x, y, z, w; };
+
+GZ_DEVFN void scan_load4(const unsigned* __restrict__ bits, int nb, int at, unsigned v[4]) {
+  if (at + 3 < nb) {
+    const ScanU4 u = *reinterpret_cast<const ScanU4*>(bits + at);
+    v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = at + e < nb ? bits[at + e] : 0u;
+  }
+}
 
 __global__ __launch_bounds__(1024) void k_jpeg_scan_offsets(const unsigned* __restrict__ bits,
                                                             int nb,
                                                             unsigned long long* __restrict__ off) {
-  __shared__ unsigned s_val[kScanTile + kScanLanes];
   __shared__ int wave_total[16];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   unsigned long long carry = 0;
+  unsigned cur[4], nxt[4];
+  scan_load4(bits, nb, 4 * t, cur);
   for (int base = 0; base < nb; base += kScanTile) {
-#pragma unroll
-    for (int j = 0; j < kScanPer; ++j) {
-      const int i = j * kScanLanes + t;
-      s_val[scan_slot(i)] = base + i < nb ? bits[base + i] : 0u;
-    }
-    __syncthreads();
-    unsigned v[kScanPer];
-    int sum = 0;
-#pragma unroll
-    for (int j = 0; j < kScanPer; ++j) {
-      v[j] = s_val[scan_slot(t * kScanPer + j)];
-      sum += (int)v[j];
-    }
-    const int inc = wave_inclusive_sum(sum, lane);
+    const int at = base + 4 * t;
+    if (base + kScanTile < nb) scan_load4(bits, nb, at + kScanTile, nxt);
+    const int s0 = (int)cur[0], s1 = s0 + (int)cur[1], s2 = s1 + (int)cur[2], s3 = s2 + (int)cur[3];
+    const int inc = wave_inclusive_sum(s3, lane);
     if (lane == 63) wave_total[wv] = inc;
     __syncthreads();
     int before = 0, all = 0;
@@ -198,20 +194,15 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan_offsets(const unsigned* __re
       if (k < wv) before += w;
       all += w;
     }
-    unsigned run = (unsigned)(before + inc - sum);   // exclusive prefix of this lane's first value
-#pragma unroll
-    for (int j = 0; j < kScanPer; ++j) {
-      s_val[scan_slot(t * kScanPer + j)] = run;
-      run += v[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kScanPer; ++j) {
-      const int i = j * kScanLanes + t;
-      if (base + i < nb) off[base + i] = carry + (unsigned long long)s_val[scan_slot(i)];
-    }
+    const unsigned long long excl = carry + (unsigned long long)(before + inc - s3);
+    if (at < nb) off[at] = excl;
+    if (at + 1 < nb) off[at + 1] = excl + (unsigned long long)s0;
+    if (at + 2 < nb) off[at + 2] = excl + (unsigned long long)s1;
+    if (at + 3 < nb) off[at + 3] = excl + (unsigned long long)s2;
     carry += (unsigned long long)all;
-    __syncthreads();   // s_val and wave_total are rewritten by the next tile
+    __syncthreads();   // wave_total is rewritten by the next tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
   }
   if (t == 0) off[nb] = carry;
 }

@@ -157,7 +157,10 @@ __global__ __launch_bounds__(64) void k_jpeg_block_bits(const int16_t* __restric
 // the array in tiles of 4096: a lane takes 4 consecutive values (one 16-byte load, issued one
 // tile ahead), the tile is scanned in 32 bits (a value is at most a block's scan bits or its
 // candidate count: 4096 of them stay far below 2^31) with wavefront shuffles plus one LDS
-// exchange between the 16 wavefronts, and the running total is carried in 64 bits.
+// exchange between the 16 wavefronts, and the running total is carried in 64 bits.  (A
+// variant that stages 32768 values at a time in 135 KB of LDS measured 42 us against this
+// one's 22 us inside an encode: a workgroup that needs most of a CU's LDS waits for the
+// Compare kernels that share the GPU with it.)
 constexpr int kScanTile = 4096;
 
 struct alignas(16) ScanU4 { unsigned x, y, z, w; };

@@ -235,6 +235,68 @@ inline hipError_t pool_malloc(void** out, size_t bytes) { return pool_alloc(dev_
 inline void pool_free(void* ptr) { pool_release(dev_pool(), false, ptr); }
 inline hipError_t pool_host_malloc(void** out, size_t bytes) { return pool_alloc(host_pool(), true, out, bytes); }
 inline void pool_host_free(void* ptr) { pool_release(host_pool(), true, ptr); }
+
+// Streams and (timing-less) events are pooled the same way: creating and destroying a
+// context's four streams costs several milliseconds.  Only idle ones come back (the context
+// synchronises its streams before it returns them).
+struct HandlePool {
+  std::mutex mu;
+  std::multimap<int, hipStream_t> streams;   // device -> stream
+  std::multimap<int, hipEvent_t> events;
+};
+HandlePool& handle_pool() { static HandlePool p; return p; }
+hipError_t pool_stream_create(hipStream_t* out) {
+#ifndef GZ_EMU
+  int device = 0;
+  (void)hipGetDevice(&device);
+  {
+    HandlePool& p = handle_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.streams.find(device);
+    if (it != p.streams.end()) { *out = it->second; p.streams.erase(it); return hipSuccess; }
+  }
+#endif
+  return hipStreamCreate(out);
+}
+void pool_stream_destroy(hipStream_t s_) {
+  if (!s_) return;
+#ifndef GZ_EMU
+  if (pool_limit_bytes() != 0) {
+    int device = 0;
+    (void)hipGetDevice(&device);
+    HandlePool& p = handle_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.streams.count(device) < 64) { p.streams.insert(std::make_pair(device, s_)); return; }
+  }
+#endif
+  (void)hipStreamDestroy(s_);
+}
+hipError_t pool_event_create(hipEvent_t* out) {
+#ifndef GZ_EMU
+  int device = 0;
+  (void)hipGetDevice(&device);
+  {
+    HandlePool& p = handle_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.events.find(device);
+    if (it != p.events.end()) { *out = it->second; p.events.erase(it); return hipSuccess; }
+  }
+#endif
+  return hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+void pool_event_destroy(hipEvent_t e_) {
+  if (!e_) return;
+#ifndef GZ_EMU
+  if (pool_limit_bytes() != 0) {
+    int device = 0;
+    (void)hipGetDevice(&device);
+    HandlePool& p = handle_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.events.count(device) < 256) { p.events.insert(std::make_pair(device, e_)); return; }
+  }
+#endif
+  (void)hipEventDestroy(e_);
+}
 }  // namespace
 
 // Pinned host staging for the small per-iteration uploads (step lists, coefficient edits,
@@ -445,7 +507,7 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
 // Reserves `bytes` of the staging buffer (waiting for its previous upload if that is still
 // running) and returns it; stage_sent() marks the upload that was just enqueued on `stream`.
 static int stage_reserve(gz_ctx* c, HostStage* st, size_t bytes, void** out) {
-  if (!st->ev) HIPCHK(c, hipEventCreateWithFlags(&st->ev, hipEventDisableTiming));
+  if (!st->ev) HIPCHK(c, pool_event_create(&st->ev));
   if (st->busy) {
     HIPCHK(c, hipEventSynchronize(st->ev));
     st->busy = false;
@@ -479,7 +541,7 @@ static int result_buffer(gz_ctx* c, size_t bytes, void** out) {
   return GZ_OK;
 }
 static void stage_free(HostStage* st) {
-  if (st->ev) { (void)hipEventSynchronize(st->ev); (void)hipEventDestroy(st->ev); }
+  if (st->ev) { (void)hipEventSynchronize(st->ev); pool_event_destroy(st->ev); }
   if (st->h) (void)pool_host_free(st->h);
   st->h = nullptr; st->ev = nullptr; st->cap = 0; st->busy = false;
 }
@@ -874,9 +936,17 @@ int gz_trim_pool(void) {
     std::lock_guard<std::mutex> lk(p.mu);
     pool_release_idle(p, false, -1);
   }
-  MemPool& h = host_pool();
-  std::lock_guard<std::mutex> lk(h.mu);
-  pool_release_idle(h, true, -1);
+  {
+    MemPool& h = host_pool();
+    std::lock_guard<std::mutex> lk(h.mu);
+    pool_release_idle(h, true, -1);
+  }
+  HandlePool& hp = handle_pool();
+  std::lock_guard<std::mutex> lk(hp.mu);
+  for (auto& kv : hp.streams) (void)hipStreamDestroy(kv.second);
+  for (auto& kv : hp.events) (void)hipEventDestroy(kv.second);
+  hp.streams.clear();
+  hp.events.clear();
   return GZ_OK;
 }
 
@@ -920,15 +990,15 @@ gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, in
   c->target = target;
   auto fail = [&](int code) { *err = code; gz_destroy(c); return (gz_ctx*)nullptr; };
 #define CHK0(call) do { if ((call) != hipSuccess) { return fail(GZ_E_HIP); } } while (0)
-  CHK0(hipStreamCreate(&c->own_stream));
+  CHK0(pool_stream_create(&c->own_stream));
   c->stream = c->own_stream;
-  CHK0(hipStreamCreate(&c->side_stream));
-  CHK0(hipStreamCreate(&c->side_stream2));
-  CHK0(hipStreamCreate(&c->entropy_stream));
-  CHK0(hipEventCreateWithFlags(&c->ev_candidate, hipEventDisableTiming));
-  CHK0(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  CHK0(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  CHK0(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+  CHK0(pool_stream_create(&c->side_stream));
+  CHK0(pool_stream_create(&c->side_stream2));
+  CHK0(pool_stream_create(&c->entropy_stream));
+  CHK0(pool_event_create(&c->ev_candidate));
+  CHK0(pool_event_create(&c->ev_fork));
+  CHK0(pool_event_create(&c->ev_join));
+  CHK0(pool_event_create(&c->ev_join2));
   const size_t ncoef = (size_t)3 * c->nb * 64;
   CHK0(pool_malloc((void**)&c->d_rgb, (size_t)3 * w * h));
   CHK0(pool_malloc((void**)&c->d_orig, ncoef * 2));
@@ -999,7 +1069,13 @@ int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
 
 void gz_destroy(gz_ctx* c) {
   if (!c) return;
+  // everything must be idle before the memory goes back to the pool (another context may get
+  // it at once; hipFree would have waited, the pool does not)
+  if (c->stream && c->stream != c->own_stream) (void)hipStreamSynchronize(c->stream);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+  if (c->side_stream2) (void)hipStreamSynchronize(c->side_stream2);
+  if (c->entropy_stream) (void)hipStreamSynchronize(c->entropy_stream);
   (void)pool_free(c->d_rgb); (void)pool_free(c->d_orig); (void)pool_free(c->d_cand); (void)pool_free(c->d_q);
   (void)pool_free(c->d_srgb_lut); (void)pool_free(c->d_mask_luts); (void)pool_free(c->d_block_max);
   (void)pool_free(c->d_max_bits); (void)pool_free(c->d_srgb_out); (void)pool_free(c->arena);
@@ -1015,17 +1091,17 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->d_order_counters); (void)pool_free(c->d_next_cand); (void)pool_free(c->d_weight);
   (void)pool_free(c->d_max_err); (void)pool_free(c->d_wflag); (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
   for (int b = 0; b < B_COUNT; ++b) (void)pool_free(c->blur[b].d_scale);
-  if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-  if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); (void)hipStreamDestroy(c->side_stream2); }
-  if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); (void)hipStreamDestroy(c->entropy_stream); }
-  if (c->ev_candidate) (void)hipEventDestroy(c->ev_candidate);
+  if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); pool_stream_destroy(c->side_stream); }
+  if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); pool_stream_destroy(c->side_stream2); }
+  if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); pool_stream_destroy(c->entropy_stream); }
+  pool_event_destroy(c->ev_candidate);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
   if (c->h_res) (void)pool_host_free(c->h_res);
-  if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  pool_event_destroy(c->ev_join2);
+  pool_event_destroy(c->ev_fork);
+  pool_event_destroy(c->ev_join);
+  pool_stream_destroy(c->own_stream);   // synchronised at the top of gz_destroy
   delete c;
 }
 

@@ -41,7 +41,7 @@ class HostLibrary:
         h, w, ch = rgb.shape
         assert ch == 3
         cap = 3 * w * h + (1 << 16)
-        out = np.zeros(cap, np.uint8)
+        out = np.empty(cap, np.uint8)
         tr = C.create_string_buffer(1 << 24) if want_trace else None
         tm = C.create_string_buffer(1 << 12)
         n = self.lib.gzh_process(rgb.ctypes.data, w, h,

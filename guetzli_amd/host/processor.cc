@@ -185,10 +185,43 @@ struct DeviceOrder : RangeDevice {
 };
 
 // ------------------------------------------------------------------- the encoder ------
+// The large host arrays of one encode (60 MB at 1080p, 240 MB at 4K).  Fresh std::vectors of
+// this size come from mmap and are paid for in page faults (~15 ms per 1080p encode, measured
+// as the gap between the phase timers and the wall clock of a step): a thread keeps them
+// between encodes instead, and an Encoder borrows them for its lifetime.
+struct HostScratch {
+  std::vector<int16_t> orig, img;
+  std::vector<uint8_t> cand_idx;
+  std::vector<int32_t> cand_off;
+  std::vector<std::pair<int, float> > order;
+  std::vector<uint8_t> scan;
+};
+static HostScratch& ThreadScratch() {
+  static thread_local HostScratch s;
+  return s;
+}
+
 class Encoder {
  public:
-  Encoder(const Params& p, ProcessStats* s) : params_(p), stats_(s) {}
-  ~Encoder() { if (ctx_) gz_destroy(ctx_); }
+  Encoder(const Params& p, ProcessStats* s) : params_(p), stats_(s) {
+    HostScratch& sc = ThreadScratch();
+    orig_.swap(sc.orig);
+    img_.swap(sc.img);
+    cand_idx_.swap(sc.cand_idx);
+    cand_off_.swap(sc.cand_off);
+    order_.swap(sc.order);
+    scan_.swap(sc.scan);
+  }
+  ~Encoder() {
+    if (ctx_) gz_destroy(ctx_);
+    HostScratch& sc = ThreadScratch();
+    orig_.swap(sc.orig);
+    img_.swap(sc.img);
+    cand_idx_.swap(sc.cand_idx);
+    cand_off_.swap(sc.cand_off);
+    order_.swap(sc.order);
+    scan_.swap(sc.scan);
+  }
   bool Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* out);
   bool RunJpeg(const std::string& jpeg_data, std::string* out);
 
@@ -222,6 +255,13 @@ class Encoder {
   int w_ = 0, h_ = 0, bw_ = 0, bh_ = 0, nb_ = 0;
   std::vector<int16_t> orig_;    // unquantised coefficients (JPEGData of EncodeRGBToJpeg)
   std::vector<int16_t> img_;     // coefficients of the working image (OutputImage::coeffs_)
+  // phase A's CSR arrays, the fetched part of phase B's order, the winner's scan (borrowed
+  // from the thread's HostScratch like orig_ / img_; every element that is read was written
+  // by this encode)
+  std::vector<uint8_t> cand_idx_;
+  std::vector<int32_t> cand_off_;
+  std::vector<std::pair<int, float> > order_;
+  std::vector<uint8_t> scan_;
   QuantMatrix quant_;            // its quant matrices
   float distance_ = 0.0f;        // ButteraugliComparator::distance_
   JpegHead head_;                // marker segments + codes of the last Serialize
@@ -483,8 +523,10 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   Stopwatch sw;
   const int nb = nb_;
   // ---- phase A on the device ----
-  std::vector<int32_t> cand_off(nb + 1);
-  std::vector<uint8_t> cand_idx((size_t)nb * 189);
+  std::vector<int32_t>& cand_off = cand_off_;
+  std::vector<uint8_t>& cand_idx = cand_idx_;
+  if (cand_off.size() != (size_t)nb + 1) cand_off.resize((size_t)nb + 1);
+  if (cand_idx.size() != (size_t)nb * 189) cand_idx.resize((size_t)nb * 189);
   // the candidates' errors stay on the device, where the global order is built from them
   int rc = gz_block_zeroing_orders(ctx_, params_.zeroing_greedy_lookahead,
                                    params_.new_zeroing_model ? 1 : 0, cand_off.data(),
@@ -517,7 +559,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   std::vector<int> next_cand(nb, 0);   // last_indexes
   std::vector<int32_t> edit_pos;       // coefficient changes of one iteration
   std::vector<int16_t> edit_val;
-  std::vector<std::pair<int, float> > order;   // host copy of the ranges that were fetched
+  std::vector<std::pair<int, float> >& order = order_;   // host copy of the ranges that were fetched
   std::vector<char> touched(nb);
   std::vector<int32_t> dirty;
   std::vector<int> step_count(nb);
@@ -766,7 +808,8 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
   {  // the winner: its head from the host, its scan from the device
-    std::vector<uint8_t> scan((size_t)6 * w * h + 4096);
+    std::vector<uint8_t>& scan = scan_;
+    if (scan.size() < (size_t)6 * w * h + 4096) scan.resize((size_t)6 * w * h + 4096);
     size_t n = 0;
     rc = gz_jpeg_scan_bytes(ctx_, 1, scan.data(), scan.size(), &n);
     if (rc != GZ_OK) return Fail("gz_jpeg_scan_bytes", rc);
@@ -984,7 +1027,8 @@ long gzh_process(const uint8_t* rgb, int w, int h, double quality, float target,
   guetzli_amd::ProcessStats stats;
   std::string dbg;
   if (trace) stats.debug_output = &dbg;
-  std::vector<uint8_t> v(rgb, rgb + (size_t)3 * w * h);
+  static thread_local std::vector<uint8_t> v;   // Process takes a vector, as the reference's does
+  v.assign(rgb, rgb + (size_t)3 * w * h);
   std::string jpg;
   if (!guetzli_amd::Process(params, &stats, v, w, h, &jpg)) return -1;
   if ((long)jpg.size() <= cap) memcpy(out, jpg.data(), jpg.size());

@@ -51,26 +51,29 @@ QUALITY = 95.0
 TARGET_Q95 = 0.971769              # ButteraugliScoreForQuality(95), quality.cc:31-85
 W, H = 1920, 1080
 GOLDEN_SHA_1080P_Q95 = "9c0eb414b8e73f4372c0b089eafe2350e6ff2ae83926d1c0c5f35cb5f7919729"
+GOLDEN_SHA_4K = {95: "481507d21e4d37f296ae6a2a93a84d950c4a135df310b3408a64390b25d59c05",
+                 84: "f3be1e4385a977853f7cd224e1722a728c1fa0bc68f1115c27e657c23a028ac0"}
 CHAIN = ("butteraugli Compare chain (17 launches per Compare on 3 streams: k_reconstruct, 5 fused "
          "k_blur2d (radius < 16), 4 k_blur_h + 4 k_blur_v (radius >= 16), k_malta (both channels), "
          "k_mask_pre, k_combine)")
 
 
 def cpu_baseline():
-    """Reference guetzli::Process on the host CPU (bounded sample: bees.png)."""
+    """Reference guetzli::Process on the host CPU, bounded sample of the same workload: the
+    bench image's top-left 640x360 (bees.png tiled), ~13 s of one core."""
     import images
     from checkers import ref
     if ref is None:
         return None
-    rgb = images.bees()
+    rgb = images.tiled(640, 360)
     h, w, _ = rgb.shape
     t0 = time.perf_counter()
     jpg, _ = ref.process(rgb, TARGET_Q95)
     dt = time.perf_counter() - t0
     return {"value": round(w * h / 1e6 / dt, 6), "unit": "MPix/s", "cores": 1,
             "kind": "reference",
-            "sample": f"unmodified reference guetzli::Process on tests/golden/bees.png "
-                      f"({w}x{h}), --quality 95: {dt:.1f} s of CPU, single thread "
+            "sample": f"unmodified reference guetzli::Process on the top-left {w}x{h} of the "
+                      f"bench image, --quality 95: {dt:.1f} s of CPU, single thread "
                       f"({os.cpu_count()} host cores present); output {len(jpg)} bytes"}
 
 
@@ -80,6 +83,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-4k", action="store_true", help="skip the 3840x2160 legs (configs[2], [3])")
     ap.add_argument("--batch-images", type=int, default=8,
                     help="images of the extra concurrent-batch leg (0 = skip)")
     ap.add_argument("--batch-workers", type=int, default=4)
@@ -163,6 +167,23 @@ def main():
                  "note": "independent 1920x1080 images, several in flight on ONE GPU (one host "
                          "thread + one device context each); output 0 checked against the "
                          "reference JPEG"}
+    # BASELINE configs[2] and [3] (one 3840x2160 image at quality 95 / 84), steady state:
+    # one untimed and one timed encode each, beside -- never instead of -- `value`
+    other = None
+    if rank == 0 and world == 1 and not args.no_4k:
+        other = {}
+        img4k = images.tiled(3840, 2160)
+        for q, golden in ((95, GOLDEN_SHA_4K[95]), (84, GOLDEN_SHA_4K[84])):
+            host.process(img4k, quality=q, device=local_rank)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            j4, i4 = host.process(img4k, quality=q, device=local_rank)
+            t4 = time.perf_counter() - t4
+            assert hashlib.sha256(j4).hexdigest() == golden
+            other[f"3840x2160_q{q}"] = {"seconds": round(t4, 3),
+                                        "value": round(3840 * 2160 / 1e6 / t4, 3), "unit": "MPix/s",
+                                        "iterations": i4["counters"].get("number of iterations"),
+                                        "output_sha256_matches_reference": True}
     traffic = {}
     try:
         traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v3.json")))
@@ -205,6 +226,8 @@ def main():
                               if k in ("total", "phase_b_host", "compare", "block_search",
                                        "jpeg_write", "create+encode", "select_quant_matrix")},
         }
+        if other is not None:
+            out["other_configs"] = other
         if batch is not None:
             out["batch_one_gpu"] = batch
         if world == 1 and not args.no_cpu_baseline:

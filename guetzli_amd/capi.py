@@ -56,6 +56,7 @@ SIGNATURES = {
     "gz_order_advance": (_I, [_P, C.c_float, _I]),
     "gz_apply_coeff_edits": (_I, [_P, _P, _P, _I]),
     "gz_apply_candidate_steps": (_I, [_P, _I, _P, _P, _I]),
+    "gz_steps_histogram_delta": (_I, [_P, _P]),
     "gz_order_upload": (_I, [_P, _P, C.c_uint64]),
     "gz_order_partition": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
     "gz_order_fetch": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
@@ -348,6 +349,12 @@ class Context:
         assert b.size == n.size
         self._chk(self.L.lib.gz_apply_candidate_steps(self.handle, direction, _ptr(b), _ptr(n),
                                                       b.size))
+
+    def steps_histogram_delta(self):
+        """AC statistics change of the last apply_candidate_steps, int64 [3][256]."""
+        d = np.zeros((3, 256), np.int32)
+        self._chk(self.L.lib.gz_steps_histogram_delta(self.handle, _ptr(d)))
+        return d.astype(np.int64)
 
     def order_upload(self, entries):
         e = np.ascontiguousarray(entries, self.ORDER_DTYPE)

@@ -389,6 +389,7 @@ struct gz_ctx {
   bool h_block_max_valid = false;
   bool compare_pending = false;
   int h_jq[192] = {0};       // the matrix d_jq holds
+  unsigned* d_step_delta = nullptr; bool have_step_delta = false;   // AC statistics change of the last bulk steps
   HostStage stage_main, stage_entropy;
   // pinned landing area for the small results every call waits for (a copy into pageable
   // memory costs 27 us per round trip on this system, into pinned memory 15)
@@ -1083,6 +1084,7 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->extra_arena);
   (void)pool_free(c->d_block_mask); (void)pool_free(c->d_rank_cnt); (void)pool_free(c->d_rank_tables); (void)pool_free(c->d_rank_idx);
   (void)pool_free(c->d_out_cnt); (void)pool_free(c->d_out_idx); (void)pool_free(c->d_out_err);
+  (void)pool_free(c->d_step_delta);
   (void)pool_free(c->d_jq); (void)pool_free(c->d_hist); (void)pool_free(c->d_code_depth); (void)pool_free(c->d_code_bits);
   (void)pool_free(c->d_mcu_bits); (void)pool_free(c->d_mcu_off); (void)pool_free(c->d_ff_count);
   (void)pool_free(c->d_words); (void)pool_free(c->d_words_kept);
@@ -1474,12 +1476,40 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     TRY(stage_sent(c, &c->stage_main, c->stream));
   }
   const int nb = c->nb;
+  c->have_step_delta = false;
+  if (c->have_jq) {
+    // with the symbol statistics' quantiser known, the steps also report what they do to the
+    // AC histograms (gz_steps_histogram_delta)
+    if (!c->d_step_delta) HIPCHK(c, pool_malloc((void**)&c->d_step_delta, sizeof(unsigned) * 768));
+    HIPCHK(c, hipMemsetAsync(c->d_step_delta, 0, sizeof(unsigned) * 768, c->stream));
+    GZ_LAUNCH(k_apply_steps_hist, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
+              (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
+              (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
+              (const int*)c->d_q, (const int*)c->d_jq, nb, c->d_step_delta);
+    KCHK(c);
+    c->have_step_delta = true;
+    return GZ_OK;
+  }
   GZ_LAUNCH(k_apply_steps, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
             (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
             (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
             (const int*)c->d_q, nb);
   KCHK(c);
   return GZ_OK;   // the caller's buffers were copied to the staging buffer: no wait
+}
+
+int gz_steps_histogram_delta(gz_ctx* c, int32_t* ac_delta) {
+  if (!c || !ac_delta) return GZ_E_ARG;
+  if (!c->have_step_delta) {
+    c->err = "gz_apply_candidate_steps (after gz_jpeg_histograms) must precede gz_steps_histogram_delta";
+    return GZ_E_STATE;
+  }
+  void* res = nullptr;
+  TRY(result_buffer(c, sizeof(unsigned) * 768, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_step_delta, sizeof(unsigned) * 768, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(ac_delta, res, sizeof(unsigned) * 768);
+  return GZ_OK;
 }
 
 int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int n) {

@@ -23,6 +23,7 @@
 // Entries are 8 bytes {int block; float val}, the layout of std::pair<int, float>.
 #pragma once
 #include "gz_common.h"
+#include "gz_kernels_entropy.h"   // lane_symbols
 
 namespace gz {
 
@@ -211,6 +212,85 @@ __global__ __launch_bounds__(256) void k_apply_steps(const int* __restrict__ blo
     }
     if (!precious) cand[((size_t)c * nb + b) * 64 + k] = (short)newval;
   }
+}
+
+// The same steps, one wavefront per block, together with what they do to the AC symbol
+// statistics (BuildACHistograms of the image before minus after, for the touched blocks only):
+// the three coefficient blocks go through LDS, their symbols are counted out of the histogram,
+// the steps are applied, the symbols are counted back in.  delta: [3][256] counters (wrapping
+// unsigned arithmetic = signed differences), zeroed by the caller; jq = the quantiser the
+// symbols are defined under (gz_jpeg_histograms' matrix).  After ~6000 steps an iteration the
+// host's size model needs the statistics again; recounting the 32 400 blocks of a 1080p
+// image took 40-50 us, the touched blocks take a fraction of that.
+GZ_DEVFN void steps_count_symbols(const short* blk3, const int* __restrict__ jq, int lane, bool live,
+                                  unsigned sign, unsigned* s_delta) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const LaneSyms s = lane_symbols(blk3, jq, 1, c, 0, lane);
+    if (!live) continue;
+    unsigned* h = &s_delta[c * 256];
+    if (s.zrl) atomicAdd(&h[0xf0], sign * (unsigned)s.zrl);
+    if (s.sym >= 0 && !s.is_dc) atomicAdd(&h[s.sym], sign);
+    if (s.eob) atomicAdd(&h[0], sign);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict__ blocks,
+                                                          const int* __restrict__ counts, int n,
+                                                          int direction, const int* __restrict__ next_cand,
+                                                          const unsigned char* __restrict__ cand_idx,
+                                                          const short* __restrict__ orig,
+                                                          short* __restrict__ cand,
+                                                          const int* __restrict__ q,
+                                                          const int* __restrict__ jq, int nb,
+                                                          unsigned* __restrict__ delta) {
+  __shared__ short s_blk[4][3 * 64];
+  __shared__ unsigned s_delta[3 * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  const bool live = i < n;   // a wavefront past the end repeats the last block and drops the result
+  const int b = blocks[live ? i : n - 1], cnt = live ? counts[i] : 0, nx = next_cand[b];
+  for (int k = threadIdx.x; k < 3 * 256; k += 256) s_delta[k] = 0u;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s_blk[wave][c * 64 + lane] = cand[((size_t)c * nb + b) * 64 + lane];
+  __syncthreads();
+  steps_count_symbols(s_blk[wave], jq, lane, live, 0xffffffffu, s_delta);
+  __syncthreads();
+  for (int j = lane; j < cnt; j += 64) {
+    const int p = direction > 0 ? nx + j : nx - 1 - j;
+    const int idx = cand_idx[(size_t)b * 192 + p];
+    const int c = idx >> 6, k = idx & 63;
+    const short* ob = orig + ((size_t)c * nb + b) * 64;
+    int newval = 0;
+    if (direction < 0) {   // Quantize(), quantize.h:24-29
+      const int quant = q[c * 64 + k], raw = ob[k];
+      const int r = raw % quant;
+      const int dlt = 2 * r > quant ? quant - r : ((-2) * r > quant ? -quant - r : -r);
+      newval = (short)(raw + (int)(short)dlt);
+    }
+    bool precious = false;
+    if (newval == 0 && (k == 1 || k == 8)) {   // processor.cc:722-733
+      int sum_of_hf = 0;
+      for (int ii = 3; ii < 64; ++ii) {
+        if ((ii & 7) < 3 && ii < 3 * 8) continue;
+        const int v = ob[ii];
+        sum_of_hf += v < 0 ? -v : v;
+      }
+      const int limit = sum_of_hf < 60 ? 4 : 8;
+      const int v = ob[k];
+      precious = (v < 0 ? -v : v) >= limit;
+    }
+    if (!precious) s_blk[wave][c * 64 + k] = (short)newval;
+  }
+  __syncthreads();
+  steps_count_symbols(s_blk[wave], jq, lane, live, 1u, s_delta);
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cand[((size_t)c * nb + b) * 64 + lane] = s_blk[wave][c * 64 + lane];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 3 * 256; k += 256)
+    if (s_delta[k]) atomicAdd(&delta[k], s_delta[k]);
 }
 
 // -------------------------------------------------------------- one introsort partition --

@@ -704,10 +704,24 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
               }
             }
           });
-          // the symbol statistics of the edited image come from the device (BuildACHistograms
-          // over the resident coefficients) instead of per-block bookkeeping here
-          SymbolHistogram dc_now[3];
-          if (!DeviceHistograms(quant_, dc_now, ac_histo)) return false;
+          // the symbol statistics of the edited image come from the device: the change the
+          // steps made to BuildACHistograms, counted over the touched blocks (the host's
+          // ac_histo was exact before them: the slow steps below keep it so)
+          std::vector<int32_t> delta(3 * 256);
+          rc = gz_steps_histogram_delta(ctx_, delta.data());
+          if (rc != GZ_OK) return Fail("gz_steps_histogram_delta", rc);
+          for (int c = 0; c < 3; ++c)
+            for (int i = 0; i < 256; ++i)
+              if (delta[c * 256 + i]) ac_histo[c].Add(i, delta[c * 256 + i]);
+          if (verify_) {   // GZ_VERIFY_ENTROPY=1: against a recount of the whole image
+            SymbolHistogram dc_now[3], ac_now[3];
+            if (!DeviceHistograms(quant_, dc_now, ac_now)) return false;
+            for (int c = 0; c < 3; ++c)
+              if (memcmp(ac_now[c].counts, ac_histo[c].counts, sizeof(ac_now[c].counts)) != 0) {
+                fprintf(stderr, "guetzli_amd: incremental AC statistics differ from a recount\n");
+                return false;
+              }
+          }
         }
         t_pb_fast_ += fw.lap();
         n_steps_ += (long)fast_until;

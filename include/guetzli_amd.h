@@ -243,6 +243,12 @@ int gz_order_advance(gz_ctx* ctx, float val_threshold, int direction);
  * (the next gz_order_build* call brings the caller's). */
 int gz_apply_candidate_steps(gz_ctx* ctx, int direction, const int32_t* blocks,
                              const int32_t* counts, int n);
+/* What the last gz_apply_candidate_steps did to the AC symbol statistics: ac_delta[3][256] =
+ * BuildACHistograms (jpeg_data_writer.cc:255-275) of the image after the steps minus before,
+ * raw occurrence counts under the quantiser of the last gz_jpeg_histograms (which must have
+ * been called before the steps).  Computed from the touched blocks only, so that the caller's
+ * size model (processor.cc:471-525) does not need a recount of the whole image. */
+int gz_steps_histogram_delta(gz_ctx* ctx, int32_t* ac_delta);
 int gz_order_upload(gz_ctx* ctx, const void* entries, uint64_t n);
 int gz_order_partition(gz_ctx* ctx, uint64_t lo, uint64_t hi, uint64_t* cut);
 int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);

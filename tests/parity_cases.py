@@ -264,9 +264,16 @@ def case_global_order(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
                     if not precious:
                         exp[c, b, k] = newval
             ctx.order_build_auto(direction, 1, 1.0, True, next_cand)   # uploads next_cand
+            qs_all = np.full((3, 64), qs, np.int32)
+            before = ctx.jpeg_histograms(qs_all)                        # also: the symbols' quantiser
             ctx.apply_candidate_steps(direction, sel, counts[sel])
+            delta = ctx.steps_histogram_delta()
             co = ctx.get_coeffs()
             assert_bits_equal(co, exp, f"apply_candidate_steps direction {direction}")
+            # the statistics change the steps report == a recount of the whole image
+            after = ctx.jpeg_histograms(qs_all)
+            assert_bits_equal(delta, after[1].astype(np.int64) - before[1].astype(np.int64),
+                              f"steps_histogram_delta direction {direction}")
         cq = co
         # single-coefficient edits == block scatter
         pos = rng.choice(3 * nb * 64, size=min(500, nb), replace=False).astype(np.int32)

@@ -55,6 +55,7 @@ struct Real {
   decltype(&gz_order_advance) order_advance;
   decltype(&gz_apply_coeff_edits) apply_coeff_edits;
   decltype(&gz_apply_candidate_steps) apply_candidate_steps;
+  decltype(&gz_steps_histogram_delta) steps_histogram_delta;
   decltype(&gz_set_rgb) set_rgb;
   decltype(&gz_set_orig_coeffs) set_orig_coeffs;
   decltype(&gz_reconstruct) reconstruct;
@@ -92,7 +93,7 @@ Real* real() {
   SYM(order_fetch, "gz_order_fetch") SYM(order_reset, "gz_order_reset")
   SYM(order_build_auto, "gz_order_build_auto") SYM(order_advance, "gz_order_advance")
   SYM(apply_coeff_edits, "gz_apply_coeff_edits")
-  SYM(apply_candidate_steps, "gz_apply_candidate_steps")
+  SYM(apply_candidate_steps, "gz_apply_candidate_steps") SYM(steps_histogram_delta, "gz_steps_histogram_delta")
   SYM(set_rgb, "gz_set_rgb") SYM(set_orig_coeffs, "gz_set_orig_coeffs")
   SYM(reconstruct, "gz_reconstruct") SYM(encode_rgb_only, "gz_encode_rgb_only")
 #undef SYM
@@ -100,7 +101,7 @@ Real* real() {
 }
 
 enum Tag : int32_t { T_CREATE = 1, T_ORIG = 2, T_COMPARE = 3, T_ORDERS = 4, T_HISTO = 5, T_SCAN = 6,
-                     T_BYTES = 7 };
+                     T_BYTES = 7, T_DELTA = 8 };
 
 }  // namespace
 
@@ -388,6 +389,19 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
                              const int32_t* counts, int n) {
   if (c->inner) return real()->apply_candidate_steps(c->inner, direction, blocks, counts, n);
   return GZ_OK;   // the host driver keeps its own mirror of the image; nothing to replay
+}
+
+int gz_steps_histogram_delta(gz_ctx* c, int32_t* ac_delta) {
+  if (c->inner) {
+    const int rc = real()->steps_histogram_delta(c->inner, ac_delta);
+    if (rc != GZ_OK) return rc;
+    put_tag(c, T_DELTA);
+    put(c, ac_delta, sizeof(int32_t) * 768);
+    return GZ_OK;
+  }
+  expect_tag(c, T_DELTA);
+  get(c, ac_delta, sizeof(int32_t) * 768);
+  return GZ_OK;
 }
 
 int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {

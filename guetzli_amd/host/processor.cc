@@ -282,7 +282,7 @@ class Encoder {
   long n_fast_ = 0;
   double t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0;
-  size_t device_threshold_ = 1 << 15;   // ranges above this are partitioned on the device (32 K measured best at 1080p and 4K)
+  size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device (32-64 K measured best at 1080p and 4K)
 };
 
 void Encoder::Log(const char* fmt, ...) {   // GUETZLI_LOG / PrintDebug, debug_print.h

@@ -221,6 +221,8 @@ void pool_release(MemPool& p, bool host, void* ptr) {
   }
   const std::pair<int, size_t> key = it->second;
   p.live.erase(it);
+  if (key.second <= pool_limit_bytes() && p.idle_bytes[key.first] + key.second > pool_limit_bytes())
+    pool_release_idle(p, host, key.first);   // full of sizes nobody asks for any more: start over
   if (p.idle_bytes[key.first] + key.second <= pool_limit_bytes()) {
     p.idle.insert(std::make_pair(key, ptr));
     p.idle_bytes[key.first] += key.second;

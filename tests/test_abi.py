@@ -104,6 +104,10 @@ def test_new_entry_points_reject_bad_arguments(lib_path):
     z = np.zeros(64, np.int32)
     u64 = np.zeros(1, np.uint64)
     assert lib.gz_order_reset(None) == -1
+    assert lib.gz_steps_histogram_delta(None, z.ctypes.data) == -1
+    assert lib.gz_compare_begin(None) == -1 and lib.gz_compare_end(None, z.ctypes.data) == -1
+    assert lib.gz_probe_rank_sort(0, None, None, 1, None) == -1
+    assert lib.gz_trim_pool() == 0          # nothing cached: nothing to release, no device needed
     assert lib.gz_order_build(None, 1, z.ctypes.data, z.ctypes.data, z.ctypes.data, 0, 0.0,
                               u64.ctypes.data, z.ctypes.data, None) == -1
     assert lib.gz_order_build_auto(None, 1, 1, 1.0, 0, z.ctypes.data, 0, 0.0, u64.ctypes.data,

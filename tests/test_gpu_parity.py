@@ -239,6 +239,23 @@ def test_whole_encode_bees_bit_identical_jpeg(q):
         assert hashlib.sha256(info["trace"].encode()).hexdigest() == GOLDEN_TRACE_SHA[(444, 258, q)]
 
 
+def test_memory_pool_reuse_and_trim_do_not_change_results(L):
+    """Contexts of one size reuse the cached device blocks, streams and events of the ones
+    destroyed before them (stale contents, not zeroes); gz_trim_pool releases the cache.  The
+    JPEG is the same every time."""
+    import hashlib
+    import guetzli_amd
+    rgb = images.bees()
+    first, _ = guetzli_amd.process(rgb, quality=95)
+    again, _ = guetzli_amd.process(rgb, quality=90)      # same sizes, different content in the blocks
+    assert L.lib.gz_trim_pool() == 0
+    fresh, _ = guetzli_amd.process(rgb, quality=95)      # allocates anew
+    reused, _ = guetzli_amd.process(rgb, quality=95)     # from the pool
+    assert first == fresh == reused
+    assert hashlib.sha256(first).hexdigest() == GOLDEN_JPEG_SHA[(444, 258, 95)]
+    assert again != first
+
+
 def test_png_file_in_jpeg_out_matches_the_reference_golden():
     """`guetzli tests/bees.png out.jpg` end to end: the PNG bytes go through the product's own
     reader (png_reader.cc) and the JPEG is the reference's."""

@@ -15,3 +15,4 @@ python tools/pmc_summary.py $O/c1080_FETCH_SIZE $O/c1080_WRITE_SIZE > $O/compare
 python tools/pmc_summary.py $O/bw_FETCH_SIZE $O/bw_WRITE_SIZE > $O/bw_pmc.csv
 cat $O/bw_pmc.csv; cat $O/compare_4k_pmc.csv
 find $O -name "*counter_collection.csv" -delete   # keep the summaries only (size)
+python tools/pmc_traffic_json.py $O/compare_4k_pmc.csv $O/compare_1080p_pmc.csv $O/bw_pmc.csv > $O/traffic.json; head -30 $O/traffic.json

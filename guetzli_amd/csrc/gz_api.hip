@@ -1072,6 +1072,7 @@ int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
 
 void gz_destroy(gz_ctx* c) {
   if (!c) return;
+  (void)hipSetDevice(c->device);   // the pools file what comes back under the current device
   // everything must be idle before the memory goes back to the pool (another context may get
   // it at once; hipFree would have waited, the pool does not)
   if (c->stream && c->stream != c->own_stream) (void)hipStreamSynchronize(c->stream);

@@ -60,7 +60,10 @@ const char* gz_last_error(const gz_ctx* ctx);
  * linear RGB (LinearRgb, :33-47) and precomputes the original's PsychoImage pi0_
  * (butteraugli.cc:784-791).  `target` is Params::butteraugli_target
  * (processor.h:30).  Requires w,h >= 8 (butteraugli) -- Process() itself only builds a
- * comparator when w,h >= 32 (processor.cc:940).  Returns NULL on failure, *err set. */
+ * comparator when w,h >= 32 (processor.cc:940).  Returns NULL on failure, *err set.
+ * gz_create makes `device` the calling thread's current HIP device; later calls on the
+ * context (and gz_destroy) expect it to be current still -- true for the usual one thread per
+ * image, or one process per GPU. */
 gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, int* err);
 void gz_destroy(gz_ctx* ctx);
 /* Replace the original image of an existing context (same w, h): what constructing a new

@@ -76,3 +76,25 @@ static __device__ __forceinline__ void gz_stg4(float* p, size_t i, const gz_f4& 
 #endif
 
 static inline int gz_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// ---- XCD-aware tile order ---------------------------------------------------------------
+// MI355X has 8 XCDs with a private 4 MB L2 each, and the dispatcher is observed to place block
+// b on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement"): neighbouring tiles
+// -- which share their halo rows / columns -- would land on eight different L2s and fetch the
+// shared samples eight times.  gz_xcd_tile() maps the hardware block id to a tile id such that
+// XCD k works through the k-th contiguous eighth of the (z, y, x) tile sequence: a band of
+// consecutive tile rows per XCD.  A bijection for every grid size, so placement is a matter
+// of speed only (nothing depends on which XCD a block really runs on).
+struct GzTile { int x, y, z; };
+GZ_DEVFN GzTile gz_xcd_tile() {
+  const int gx = (int)gridDim.x, gy = (int)gridDim.y, n = gx * gy * (int)gridDim.z;
+  const int b = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+  const int xcd = b & 7, idx = b >> 3;
+  const int q = n >> 3, r = n & 7;
+  const int t = xcd * q + (xcd < r ? xcd : r) + idx;
+  GzTile o;
+  o.x = t % gx;
+  o.y = (t / gx) % gy;
+  o.z = t / (gx * gy);
+  return o;
+}

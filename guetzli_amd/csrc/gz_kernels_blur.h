@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<
   constexpr int TP = HW + 2 * RA;       // staged columns (multiple of 4)
   constexpr int OFF = RA - R;
   __shared__ __attribute__((aligned(16))) float tile[HH][TP];
-  const int c = blockIdx.z;
+  const GzTile bid = gz_xcd_tile();
+  const int c = bid.z;
   // constant indices into the kernel arguments (a dynamic one would make the pointers generic)
   Src s = src.s[0];
   float* __restrict__ out = dst.p[0];
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<
       s = src.s[i];
       out = dst.p[i];
     }
-  const int x0 = blockIdx.x * HW, y0 = blockIdx.y * HH;
+  const int x0 = bid.x * HW, y0 = bid.y * HH;
   const int tid = threadIdx.x;
   // Interior tile (no border column, every staged sample inside the image, rows 16-byte
   // aligned): staged with aligned 16-byte loads; every thread produces 4 consecutive outputs
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
   constexpr int VHt = TH, VPTt = TH / 4;
   __shared__ __attribute__((aligned(16))) float tile[VHt + 2 * R][VW];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int x0 = blockIdx.x * VW, y0 = blockIdx.y * VHt;
+  const GzTile bid = gz_xcd_tile();
+  const int x0 = bid.x * VW, y0 = bid.y * VHt;
   const int x = x0 + tx;
   // staging with one aligned 16-byte load per lane when the tile's columns are all inside
   // the image and rows are 16-byte aligned (rows outside the image are zero)
@@ -331,7 +333,8 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
   constexpr int OFF = RA - R;       // window offset inside the aligned row
   __shared__ __attribute__((aligned(16))) float tile[IH][IW];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * T2, y0 = blockIdx.y * TH;
+  const GzTile bid = gz_xcd_tile();
+  const int x0 = bid.x * T2, y0 = bid.y * TH;
   const bool interior = x0 >= RA && x0 + T2 + RA <= w && y0 >= R && y0 + TH + R <= h &&
                         (pitch & 3) == 0;
   const int tx = tid & 63, tg = tid >> 6;   // column pass: lane = column, wave = row group

@@ -133,10 +133,11 @@ struct MaltaArgs {
 template <int NPASS>
 __global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs<NPASS> a1, int w,
                                                int h, int pitch) {
-  const MaltaArgs<NPASS>& a = blockIdx.z ? a1 : a0;
+  const GzTile bid = gz_xcd_tile();
+  const MaltaArgs<NPASS>& a = bid.z ? a1 : a0;
   __shared__ __attribute__((aligned(16))) float tile[MH + 8][MW + 8];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
+  const int x0 = bid.x * MW, y0 = bid.y * MH;
   float acc[MPT];
 #pragma unroll
   for (int i = 0; i < MPT; ++i) acc[i] = 0.0f;

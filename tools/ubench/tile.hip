@@ -1,0 +1,109 @@
+// Why are the LDS-tiled kernels 1.3-1.9x slower on some boxes while a linear copy is not?
+// Hypothesis: the page-table fragments behind hipMalloc are small there, and a 64x72-row tile
+// touches 72 rows that are a row pitch (7.7 / 15 KB) apart -- one translation per row.
+// This tool times (a) a linear plane copy and (b) a column-pass-shaped tile read (64 columns
+// x (32 + 2*20) rows per workgroup) on planes from hipMalloc and on planes mapped through the
+// virtual-memory API (hipMemCreate + hipMemMap) with the recommended granularity.
+//   hipcc --offload-arch=gfx950 -O3 -o tile tile.hip ; ./tile
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int R = 20, TW = 64, TH = 32;
+
+__global__ __launch_bounds__(256) void k_tile(const float* __restrict__ in, float* __restrict__ out,
+                                              int w, int h, int pitch) {
+  __shared__ float tile[TH + 2 * R][TW];
+  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  for (int r = tg; r < TH + 2 * R; r += 4) {
+    int y = y0 - R + r;
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    const int x = x0 + tx < w ? x0 + tx : w - 1;
+    tile[r][tx] = in[(size_t)y * pitch + x];
+  }
+  __syncthreads();
+  for (int i = 0; i < TH / 4; ++i) {
+    const int ly = tg * (TH / 4) + i;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k <= 2 * R; k += 4) s += tile[ly + k][tx];
+    const int x = x0 + tx, y = y0 + ly;
+    if (x < w && y < h) out[(size_t)y * pitch + x] = s;
+  }
+}
+
+__global__ void k_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = in[i];
+}
+
+static int run(const char* what, float* base, int w, int h, int nplanes, int pitch) {
+  const size_t plane = (size_t)pitch * h;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int iters = 64;
+  for (int kind = 0; kind < 2; ++kind) {
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) {
+        const float* in = base + (size_t)((2 * i) % nplanes) * plane;
+        float* out = base + (size_t)((2 * i + 1) % nplanes) * plane;
+        if (kind == 0)
+          hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const float4*)in, (float4*)out, plane / 4);
+        else
+          hipLaunchKernelGGL(k_tile, dim3((w + TW - 1) / TW, (h + TH - 1) / TH), dim3(256), 0, 0, in, out, w, h, pitch);
+      }
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) printf("%-22s %dx%d pitch %d %-10s %7.1f us per launch\n", what, w, h, pitch, kind ? "tile-read" : "copy", ms / iters * 1e3);
+    }
+  }
+  return 0;
+}
+
+int main() {
+  const int nplanes = 16;
+  for (int size = 0; size < 2; ++size) {
+    const int w = size ? 3840 : 1920, h = size ? 2160 : 1080;
+    const size_t bytes = (size_t)(w + 64) * h * sizeof(float) * nplanes;
+    float* a = nullptr;
+    CK(hipMalloc((void**)&a, bytes));
+    CK(hipMemset(a, 0, bytes));
+    for (int pad : {0, 16, 64})
+      if (run("hipMalloc", a, w, h, nplanes, w + pad)) return 1;
+    CK(hipFree(a));
+
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gmin = 0, grec = 0;
+    CK(hipMemGetAllocationGranularity(&gmin, &prop, hipMemAllocationGranularityMinimum));
+    CK(hipMemGetAllocationGranularity(&grec, &prop, hipMemAllocationGranularityRecommended));
+    if (!size) printf("VMM granularity: minimum %zu, recommended %zu\n", gmin, grec);
+    const size_t g = grec > (2u << 20) ? grec : (2u << 20);
+    const size_t padded = (bytes + g - 1) / g * g;
+    hipMemGenericAllocationHandle_t handle;
+    CK(hipMemCreate(&handle, padded, &prop, 0));
+    void* va = nullptr;
+    CK(hipMemAddressReserve(&va, padded, g, nullptr, 0));
+    CK(hipMemMap(va, padded, 0, handle, 0));
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(va, padded, &acc, 1));
+    CK(hipMemset(va, 0, bytes));
+    if (run("hipMemCreate+hipMemMap", (float*)va, w, h, nplanes, w)) return 1;
+    CK(hipMemUnmap(va, padded));
+    CK(hipMemRelease(handle));
+    CK(hipMemAddressFree(va, padded));
+  }
+  return 0;
+}

@@ -46,9 +46,12 @@ struct MaskPrePack {
 // grid = (ceil(w/1024), h, 2): a thread takes 4 consecutive pixels of a row -- 16-byte
 // loads of the row and of the row below, one 16-byte store -- when the row pitch allows it.
 __global__ __launch_bounds__(256) void k_mask_pre(MaskPrePack pk, int w, int h, int pitch) {
-  const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+  // rows in XCD-aware order: row y + 1 (read by this row's workgroups and by the next row's)
+  // then comes from the same L2
+  const GzTile bid = gz_xcd_tile();
+  const int x = (bid.x * (int)blockDim.x + (int)threadIdx.x) * 4, y = bid.y;
   if (x >= w || y >= h) return;
-  const int c = blockIdx.z;
+  const int c = bid.z;
   MaskIn a = pk.in0[0], b = pk.in1[0];
   float* out = pk.out[0];
   if (c == 1) { a = pk.in0[1]; b = pk.in1[1]; out = pk.out[1]; }

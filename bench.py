@@ -186,7 +186,7 @@ def main():
                                         "output_sha256_matches_reference": True}
     traffic = {}
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v5.json")))
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v6.json")))
     except Exception:
         pass
 

@@ -84,9 +84,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the 3840x2160 legs (configs[2], [3])")
-    ap.add_argument("--batch-images", type=int, default=8,
+    ap.add_argument("--batch-images", type=int, default=16,
                     help="images of the extra concurrent-batch leg (0 = skip)")
-    ap.add_argument("--batch-workers", type=int, default=4)
+    ap.add_argument("--batch-workers", type=int, default=8)
     args = ap.parse_args()
 
     import torch

@@ -8,6 +8,8 @@
 // libpng is not part of this code base: the container and the filters are written from the
 // PNG specification (ISO/IEC 15948: chunk layout and CRC 5, IHDR 11.2.2, PLTE 11.2.3, tRNS
 // 11.3.2.1, filtering 9, Adam7 interlace 8.2), the deflate stream is inflated with zlib.
+// tests/test_png_reader.py holds it to the reference's own ReadPNG over libpng 1.6.37
+// (oracle/ref_png_harness.cc), pixels and accept / reject decisions alike.
 // Host code: a deflate stream is serial.
 #pragma once
 #include <stddef.h>

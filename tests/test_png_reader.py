@@ -1,12 +1,13 @@
 """guetzli_amd/host/png_reader.cc = ReadPNG of the reference's front end (guetzli.cc:47-152:
 libpng's png_read_png with PACKING | EXPAND | STRIP_16, then alpha blended on black).
 
-libpng is not in this image, so the reference function itself cannot be run ("parity
-unpinned" against it); the reader is pinned instead against (a) Pillow's independent PNG
-decoder on files written by Pillow and on hand-assembled files of every colour type / bit
-depth / interlace / filter combination, with the reference's post-processing (alpha on black,
-16 -> 8 by the high byte) applied to Pillow's samples, and (b) the raw samples the
-hand-assembled files were made from.  CPU only."""
+Pinned against the reference function itself: oracle/_ref/libgz_ref_png.so is guetzli.cc's
+ReadPNG compiled where it lies, over the image's libpng 1.6.37 (oracle/ref_png_harness.cc) --
+every file of this suite goes through both, pixels and accept / reject decisions must agree.
+Beside that, independent of libpng: (a) Pillow's decoder on files written by Pillow and on
+hand-assembled files of every colour type / bit depth / interlace / filter combination, with
+the reference's post-processing (alpha on black, 16 -> 8 by the high byte) applied to
+Pillow's samples, and (b) the raw samples the hand-assembled files were made from.  CPU only."""
 import ctypes as C
 import io
 import os
@@ -26,7 +27,58 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def host():
     from guetzli_amd import build as gzbuild
     from guetzli_amd.encoder import HostLibrary
-    return HostLibrary(gzbuild.build_host())
+    return CheckedHost(HostLibrary(gzbuild.build_host()))
+
+
+def test_the_reference_reader_is_available():
+    """Where the oracle was built with libpng, say so (the pin of this suite); elsewhere the
+    suite still runs against Pillow and the raw samples."""
+    if REF_PNG is None:
+        pytest.skip("oracle/_ref/libgz_ref_png.so not built: libpng-independent checks only")
+    assert via_reference(open(images.BEES, "rb").read()).shape == (258, 444, 3)
+
+
+REF_PNG = None
+_p = os.path.join(ROOT, "oracle", "_ref", "libgz_ref_png.so")
+if os.path.exists(_p):
+    try:
+        REF_PNG = C.CDLL(_p)
+        REF_PNG.ref_read_png.restype = C.c_long
+        REF_PNG.ref_read_png.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long]
+    except OSError:
+        REF_PNG = None
+
+
+def via_reference(data):
+    """guetzli.cc's ReadPNG (libpng): uint8 [h][w][3], or None if it refuses the stream."""
+    buf = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+    wh = (C.c_int * 2)()
+    n = REF_PNG.ref_read_png(buf.ctypes.data, len(data), wh, None, 0)
+    if n < 0:
+        return None
+    out = np.zeros(n, np.uint8)
+    assert REF_PNG.ref_read_png(buf.ctypes.data, len(data), wh, out.ctypes.data, n) == n
+    return out.reshape(wh[1], wh[0], 3)
+
+
+class CheckedHost:
+    """The product's reader, with every call also checked against the reference's."""
+
+    def __init__(self, host):
+        self.host = host
+
+    def read_png(self, data):
+        try:
+            got = self.host.read_png(data)
+        except ValueError:
+            if REF_PNG is not None:
+                assert via_reference(data) is None, "the reference accepts what the product refuses"
+            raise
+        if REF_PNG is not None:
+            exp = via_reference(data)
+            assert exp is not None, "the reference refuses what the product accepts"
+            assert exp.shape == got.shape and np.array_equal(exp, got), "pixels differ from the reference's ReadPNG"
+        return got
 
 
 def blend(v, a):   # BlendOnBlack, guetzli.cc:42-44
@@ -319,3 +371,50 @@ def test_refusals(host, capfd):
     tall[29:33] = struct.pack(">I", zlib.crc32(bytes(tall[12:29])) & 0xffffffff)
     assert _rejected(host, bytes(tall))
     capfd.readouterr()
+
+
+def test_chunk_order_and_oddities_follow_libpng(host):
+    """Streams on the edges of the specification: whatever the product does, CheckedHost holds
+    it to what the reference's libpng does (accept with the same pixels, or refuse)."""
+    s = rnd((5, 6, 1), 4, 31)
+    pal = rnd((4, 3), 256, 32)
+    plte = chunk(b"PLTE", np.asarray(pal, np.uint8).tobytes())
+    trns = chunk(b"tRNS", bytes([0, 100]))
+    ihdr = chunk(b"IHDR", struct.pack(">IIBBBBB", 6, 5, 2, 3, 0, 0, 0))
+    raw = b"".join(bytes([0]) + pack_row(s[r].reshape(-1), 2) for r in range(5))
+    idat = chunk(b"IDAT", zlib.compress(raw))
+    iend = chunk(b"IEND", b"")
+    sig = b"\x89PNG\r\n\x1a\n"
+    cases = {
+        "plain": sig + ihdr + plte + trns + idat + iend,
+        "tRNS before PLTE": sig + ihdr + trns + plte + idat + iend,
+        "tRNS after IDAT": sig + ihdr + plte + idat + trns + iend,
+        "duplicate tRNS": sig + ihdr + plte + trns + chunk(b"tRNS", bytes([255, 255, 0])) + idat + iend,
+        "duplicate PLTE": sig + ihdr + plte + plte + idat + iend,
+        "PLTE after IDAT": sig + ihdr + idat + plte + iend,
+        "empty IDAT chunks": sig + ihdr + plte + chunk(b"IDAT", b"") + idat + chunk(b"IDAT", b"") + iend,
+        "too much image data": sig + ihdr + plte + chunk(b"IDAT", zlib.compress(raw + b"\0" * 40)) + iend,
+        "palette longer than the depth allows": sig + ihdr + chunk(b"PLTE", bytes(range(30))) + idat + iend,
+        "IHDR twice": sig + ihdr + ihdr + plte + idat + iend,
+        "no IHDR": sig + plte + idat + iend,
+        "bad IHDR length": sig + chunk(b"IHDR", struct.pack(">IIBBBBBB", 6, 5, 2, 3, 0, 0, 0, 0)) + plte + idat + iend,
+        "interlace method 2": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 6, 5, 2, 3, 0, 0, 2)) + plte + idat + iend,
+        "width above the user limit": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 1000001, 1, 8, 0, 0, 0, 0)) +
+                                      chunk(b"IDAT", zlib.compress(bytes(1000002))) + iend,
+    }
+    grey = rnd((4, 7, 1), 256, 33)
+    cases["PLTE in a greyscale image"] = make_png(grey, 0, 8, extra_chunks=[plte])
+    cases["tRNS with an alpha channel"] = make_png(rnd((3, 3, 2), 256, 34), 4, 8, trns=struct.pack(">H", 5))
+    cases["tRNS of the wrong length"] = make_png(grey, 0, 8, trns=b"\0\1\2")
+    cases["bKGD and friends"] = make_png(grey, 0, 8, extra_chunks=[chunk(b"bKGD", struct.pack(">H", 7)),
+                                                                   chunk(b"sBIT", b"\x05"),
+                                                                   chunk(b"tIME", bytes(7))])
+    if REF_PNG is None:
+        pytest.skip("needs the reference's ReadPNG as the judge of these streams")
+    for name, data in cases.items():
+        try:
+            host.read_png(data)
+        except ValueError:
+            pass
+        except AssertionError as e:
+            raise AssertionError(f"{name}: {e}")

@@ -418,3 +418,53 @@ def test_chunk_order_and_oddities_follow_libpng(host):
             pass
         except AssertionError as e:
             raise AssertionError(f"{name}: {e}")
+
+
+def _rechunk(data, mutate):
+    """Applies mutate(type, body) -> body to every chunk and recomputes the CRCs."""
+    out = data[:8]
+    pos = 8
+    while pos + 12 <= len(data):
+        n = struct.unpack(">I", data[pos:pos + 4])[0]
+        kind = data[pos + 4:pos + 8]
+        body = mutate(kind, data[pos + 8:pos + 8 + n])
+        out += chunk(kind, body)
+        pos += 12 + n
+    return out
+
+
+def test_corrupted_streams_get_the_reference_verdict(host):
+    """300 single-byte corruptions inside chunk bodies (CRCs recomputed, so that the damage
+    reaches the parser, the inflater and the filters): accepted with the reference's pixels, or
+    refused like the reference does."""
+    if REF_PNG is None:
+        pytest.skip("needs the reference's ReadPNG as the judge")
+    rs = np.random.RandomState(77)
+    seeds = [make_png(rnd((9, 11, 3), 256, 41), 2, 8, filters=(0, 1, 2, 3, 4)),
+             make_png(rnd((7, 13, 1), 16, 42) % 9, 3, 4, palette=rnd((9, 3), 256, 43), trns=bytes([3, 200]),
+                      interlace=True, filters=(4, 3)),
+             make_png(rnd((6, 5, 2), 65536, 44), 4, 16, interlace=True, idat_split=2)]
+    verdicts = {"accepted": 0, "refused": 0}
+    for k in range(300):
+        base = seeds[k % len(seeds)]
+        target = rs.randint(0, 1 << 30)
+        state = {"i": 0}
+
+        def mutate(kind, body):
+            if not body or kind == b"IEND":
+                return body
+            state["i"] += 1
+            if (target + state["i"]) % 3 != 0:
+                return body
+            b = bytearray(body)
+            j = (target // 7) % len(b)
+            b[j] ^= 1 << ((target // 3) % 8)
+            return bytes(b)
+
+        data = _rechunk(base, mutate)
+        try:
+            host.read_png(data)            # CheckedHost compares with the reference
+            verdicts["accepted"] += 1
+        except ValueError:
+            verdicts["refused"] += 1
+    assert verdicts["accepted"] > 20 and verdicts["refused"] > 20, verdicts

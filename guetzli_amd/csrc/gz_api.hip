@@ -1355,16 +1355,19 @@ static int ensure_order_block_arrays(gz_ctx* c) {
 
 // d_next_cand / d_weight / d_max_err are in place: sizes, offsets, entries, counters.
 static int order_build_device(gz_ctx* c, int direction, int count_below, float limit,
-                              uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+                              uint64_t* total, int32_t* blocks_to_change, uint64_t* below,
+                              bool sizes_done = false) {
   const int nb = c->nb;
   // An order never has more entries than phase A produced candidates: sized once, so that the
   // construction runs through without a host round trip between counting and filling.
   TRY(ensure_order_capacity(c, std::max<size_t>(c->search_total, 1)));
-  HIPCHK(c, hipMemsetAsync(c->d_order_counters, 0, sizeof(unsigned) * 2, c->stream));
-  GZ_LAUNCH(k_order_sizes, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
-            (const int*)c->d_out_cnt, (const int*)c->d_next_cand, (const float*)c->d_weight,
-            direction, nb, c->d_order_nb, c->d_order_counters);
-  KCHK(c);
+  if (!sizes_done) {   // (gz_order_build_auto's weight kernels have done both already)
+    HIPCHK(c, hipMemsetAsync(c->d_order_counters, 0, sizeof(unsigned) * 2, c->stream));
+    GZ_LAUNCH(k_order_sizes, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
+              (const int*)c->d_out_cnt, (const int*)c->d_next_cand, (const float*)c->d_weight,
+              direction, nb, c->d_order_nb, c->d_order_counters);
+    KCHK(c);
+  }
   GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), c->stream, (const unsigned*)c->d_order_nb,
             nb, c->d_order_off);
   KCHK(c);
@@ -1422,6 +1425,7 @@ int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double tar
   if (use_distmap && !c->have_distmap) { c->err = "no distance map yet"; return GZ_E_STATE; }
   const int nb = c->nb;
   TRY(ensure_order_block_arrays(c));
+  TRY(ensure_order_capacity(c, std::max<size_t>(c->search_total, 1)));   // also: the counters
   {
     void* h = nullptr;
     TRY(stage_reserve(c, &c->stage_main, sizeof(int) * nb, &h));
@@ -1433,12 +1437,13 @@ int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double tar
   const float target = c->target;
   GZ_LAUNCH(k_weights_flag, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
             (const float*)c->d_block_max, use_distmap ? 1 : 0, bw, bh, target, target_mul,
-            direction, max_block_dist, c->d_wflag);
+            direction, max_block_dist, c->d_wflag, c->d_order_counters);
   KCHK(c);
   GZ_LAUNCH(k_weights_gather, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
-            (const unsigned char*)c->d_wflag, bw, bh, direction, max_block_dist, c->d_weight);
+            (const unsigned char*)c->d_wflag, bw, bh, direction, max_block_dist, c->d_weight,
+            (const int*)c->d_out_cnt, (const int*)c->d_next_cand, c->d_order_nb, c->d_order_counters);
   KCHK(c);
-  return order_build_device(c, direction, count_below, limit, total, blocks_to_change, below);
+  return order_build_device(c, direction, count_below, limit, total, blocks_to_change, below, true);
 }
 
 int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {

@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ er
 __global__ __launch_bounds__(256) void k_weights_flag(const float* __restrict__ bmax, int use_bmax,
                                                       int bw, int bh, float target,
                                                       double target_mul, int direction, int r,
-                                                      unsigned char* __restrict__ flag) {
+                                                      unsigned char* __restrict__ flag,
+                                                      unsigned* __restrict__ clear2) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  // first kernel of an order build: also resets the build's two counters
+  if (clear2 && b == 0) { clear2[0] = 0u; clear2[1] = 0u; }
   if (b >= bw * bh) return;
   const int bx = b % bw, by = b / bw;
   const double td = target * target_mul;
@@ -128,13 +131,33 @@ __global__ __launch_bounds__(256) void k_weights_flag(const float* __restrict__ 
   flag[b] = f ? 1 : 0;
 }
 
+// The entry count of the block (k_order_sizes) comes out of the same pass when cnt is given.
+GZ_DEVFN void order_size_of(int b, float w, const int* __restrict__ cnt,
+                            const int* __restrict__ next_cand, int direction,
+                            unsigned* __restrict__ n_b, unsigned* __restrict__ counters) {
+  int n = 0;
+  if (!(w == 0)) {
+    const int at = next_cand[b];
+    n = direction > 0 ? cnt[b] - at : at;
+    if (n < 0) n = 0;
+  }
+  n_b[b] = (unsigned)n;
+  if (n > 0) atomicAdd(&counters[0], 1u);
+}
+
 __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __restrict__ flag,
                                                         int bw, int bh, int direction, int r,
-                                                        float* __restrict__ weight) {
+                                                        float* __restrict__ weight,
+                                                        const int* __restrict__ cnt,
+                                                        const int* __restrict__ next_cand,
+                                                        unsigned* __restrict__ n_b,
+                                                        unsigned* __restrict__ counters) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= bw * bh) return;
   if (direction > 0) {
-    weight[b] = flag[b] ? 1.0f : 0.0f;
+    const float w = flag[b] ? 1.0f : 0.0f;
+    weight[b] = w;
+    if (cnt) order_size_of(b, w, cnt, next_cand, direction, n_b, counters);
     return;
   }
   const int bx = b % bw, by = b / bw;
@@ -148,7 +171,9 @@ __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __r
         const int d = dy > dx ? dy : dx;
         dmin = d < dmin ? d : dmin;
       }
-  weight[b] = dmin <= r ? 1.0f / (dmin + 1.0f) : 0.0f;
+  const float w = dmin <= r ? 1.0f / (dmin + 1.0f) : 0.0f;
+  weight[b] = w;
+  if (cnt) order_size_of(b, w, cnt, next_cand, direction, n_b, counters);
 }
 
 // max_block_error[i] += block_weight[i] * val_threshold * direction  (processor.cc:754-756)

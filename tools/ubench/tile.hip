@@ -41,6 +41,46 @@ __global__ void k_copy(const float4* __restrict__ in, float4* __restrict__ out, 
     out[i] = in[i];
 }
 
+// Pure-VALU and pure-LDS kernels: no global traffic to speak of, so their time follows the
+// shader clock (and the LDS pipeline) only.
+__global__ __launch_bounds__(256) void k_valu(float* out, int iters) {
+  float a = threadIdx.x * 0.001f, b = 1.0001f, c = 0.5f, d = 0.25f;
+  for (int i = 0; i < iters; ++i) {
+    a = a * b + c; b = b * 0.99999f + d; c = c * a + 0.1f; d = d * 1.00001f + a;
+  }
+  if (a + b + c + d == 12345.678f) out[0] = a;
+}
+__global__ __launch_bounds__(256) void k_lds(float* out, int iters) {
+  __shared__ float s[64 * 72];
+  for (int i = threadIdx.x; i < 64 * 72; i += 256) s[i] = (float)i;
+  __syncthreads();
+  float acc = 0.0f;
+  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  for (int i = 0; i < iters; ++i)
+#pragma unroll
+    for (int k = 0; k < 40; ++k) acc += s[((tg * 8 + k + (i & 7)) % 72) * 64 + tx];
+  if (acc == 12345.678f) out[0] = acc;
+}
+static int run_compute(float* scratch) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int kind = 0; kind < 2; ++kind)
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 20; ++i) {
+        if (kind == 0) hipLaunchKernelGGL(k_valu, dim3(4096), dim3(256), 0, 0, scratch, 2000);
+        else hipLaunchKernelGGL(k_lds, dim3(4096), dim3(256), 0, 0, scratch, 100);
+      }
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) printf("%-10s %7.1f us per launch\n", kind ? "lds-only" : "valu-only", ms / 20 * 1e3);
+    }
+  return 0;
+}
+
 static int run(const char* what, float* base, int w, int h, int nplanes, int pitch) {
   const size_t plane = (size_t)pitch * h;
   hipEvent_t e0, e1;
@@ -70,6 +110,12 @@ static int run(const char* what, float* base, int w, int h, int nplanes, int pit
 
 int main() {
   const int nplanes = 16;
+  {
+    float* scratch = nullptr;
+    CK(hipMalloc((void**)&scratch, 4096));
+    if (run_compute(scratch)) return 1;
+    CK(hipFree(scratch));
+  }
   for (int size = 0; size < 2; ++size) {
     const int w = size ? 3840 : 1920, h = size ? 2160 : 1080;
     const size_t bytes = (size_t)(w + 64) * h * sizeof(float) * nplanes;

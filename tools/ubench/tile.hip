@@ -61,22 +61,49 @@ __global__ __launch_bounds__(256) void k_lds(float* out, int iters) {
     for (int k = 0; k < 40; ++k) acc += s[((tg * 8 + k + (i & 7)) % 72) * 64 + tx];
   if (acc == 12345.678f) out[0] = acc;
 }
+// The same 8192 dependent multiply-adds once as straight-line code (~64 KB of instructions,
+// every wavefront streams through them once -- like the fully unrolled blur kernels) and once
+// as a loop (a few hundred bytes): if only the former is slow on a box, instruction fetch is.
+#define GZ_R8(x) x x x x x x x x
+#define GZ_R64(x) GZ_R8(GZ_R8(x))
+#define GZ_R512(x) GZ_R8(GZ_R64(x))
+__global__ __launch_bounds__(256) void k_straight(float* out, float b, float c) {
+  float a0 = threadIdx.x * 0.001f, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f;
+  GZ_R512(a0 = a0 * b + c; a1 = a1 * b + c; a2 = a2 * b + c; a3 = a3 * b + c;)
+  GZ_R512(a0 = a0 * c + b; a1 = a1 * c + b; a2 = a2 * c + b; a3 = a3 * c + b;)
+  GZ_R512(a0 = a0 * b + c; a1 = a1 * b + c; a2 = a2 * b + c; a3 = a3 * b + c;)
+  GZ_R512(a0 = a0 * c + b; a1 = a1 * c + b; a2 = a2 * c + b; a3 = a3 * c + b;)
+  if (a0 + a1 + a2 + a3 == 12345.678f) out[0] = a0;
+}
+__global__ __launch_bounds__(256) void k_looped(float* out, float b, float c) {
+  float a0 = threadIdx.x * 0.001f, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f;
+#pragma unroll 1
+  for (int i = 0; i < 1024; ++i) {
+    a0 = a0 * b + c; a1 = a1 * b + c; a2 = a2 * b + c; a3 = a3 * b + c;
+    a0 = a0 * c + b; a1 = a1 * c + b; a2 = a2 * c + b; a3 = a3 * c + b;
+  }
+  if (a0 + a1 + a2 + a3 == 12345.678f) out[0] = a0;
+}
+
 static int run_compute(float* scratch) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int kind = 0; kind < 2; ++kind)
+  for (int kind = 0; kind < 4; ++kind)
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0, 0));
       for (int i = 0; i < 20; ++i) {
         if (kind == 0) hipLaunchKernelGGL(k_valu, dim3(4096), dim3(256), 0, 0, scratch, 2000);
-        else hipLaunchKernelGGL(k_lds, dim3(4096), dim3(256), 0, 0, scratch, 100);
+        else if (kind == 1) hipLaunchKernelGGL(k_lds, dim3(4096), dim3(256), 0, 0, scratch, 100);
+        else if (kind == 2) hipLaunchKernelGGL(k_straight, dim3(1024), dim3(256), 0, 0, scratch, 1.0001f, 0.5f);
+        else hipLaunchKernelGGL(k_looped, dim3(1024), dim3(256), 0, 0, scratch, 1.0001f, 0.5f);
       }
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       float ms = 0;
       CK(hipEventElapsedTime(&ms, e0, e1));
-      if (rep) printf("%-10s %7.1f us per launch\n", kind ? "lds-only" : "valu-only", ms / 20 * 1e3);
+      static const char* names[] = {"valu-only", "lds-only", "straight-line 8192 fma", "looped 8192 fma"};
+      if (rep) printf("%-24s %7.1f us per launch\n", names[kind], ms / 20 * 1e3);
     }
   return 0;
 }

@@ -85,24 +85,48 @@ __global__ __launch_bounds__(256) void k_looped(float* out, float b, float c) {
   if (a0 + a1 + a2 + a3 == 12345.678f) out[0] = a0;
 }
 
+// 512 bytes of per-launch constants read by every wavefront: from the kernel-argument segment
+// (where the blur taps and border scales of the product's kernels live) or from device memory.
+struct BigArgs { float v[128]; };
+__global__ __launch_bounds__(256) void k_kernarg(float* out, BigArgs a) {
+  float s = threadIdx.x * 0.5f;
+#pragma unroll
+  for (int i = 0; i < 128; ++i) s = s * 0.999f + a.v[i];
+  if (s == 12345.678f) out[0] = s;
+}
+__global__ __launch_bounds__(256) void k_devarg(float* out, const float* __restrict__ a) {
+  float s = threadIdx.x * 0.5f;
+#pragma unroll
+  for (int i = 0; i < 128; ++i) s = s * 0.999f + a[i];
+  if (s == 12345.678f) out[0] = s;
+}
+
 static int run_compute(float* scratch) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int kind = 0; kind < 4; ++kind)
+  BigArgs big;
+  for (int i = 0; i < 128; ++i) big.v[i] = 0.01f * i;
+  float* dev_args = nullptr;
+  CK(hipMalloc((void**)&dev_args, sizeof(big)));
+  CK(hipMemcpy(dev_args, &big, sizeof(big), hipMemcpyHostToDevice));
+  for (int kind = 0; kind < 6; ++kind)
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0, 0));
       for (int i = 0; i < 20; ++i) {
         if (kind == 0) hipLaunchKernelGGL(k_valu, dim3(4096), dim3(256), 0, 0, scratch, 2000);
         else if (kind == 1) hipLaunchKernelGGL(k_lds, dim3(4096), dim3(256), 0, 0, scratch, 100);
         else if (kind == 2) hipLaunchKernelGGL(k_straight, dim3(1024), dim3(256), 0, 0, scratch, 1.0001f, 0.5f);
-        else hipLaunchKernelGGL(k_looped, dim3(1024), dim3(256), 0, 0, scratch, 1.0001f, 0.5f);
+        else if (kind == 3) hipLaunchKernelGGL(k_looped, dim3(1024), dim3(256), 0, 0, scratch, 1.0001f, 0.5f);
+        else if (kind == 4) hipLaunchKernelGGL(k_kernarg, dim3(1024), dim3(256), 0, 0, scratch, big);
+        else hipLaunchKernelGGL(k_devarg, dim3(1024), dim3(256), 0, 0, scratch, (const float*)dev_args);
       }
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       float ms = 0;
       CK(hipEventElapsedTime(&ms, e0, e1));
-      static const char* names[] = {"valu-only", "lds-only", "straight-line 8192 fma", "looped 8192 fma"};
+      static const char* names[] = {"valu-only", "lds-only", "straight-line 8192 fma", "looped 8192 fma",
+                                    "512 B from kernarg", "512 B from device mem"};
       if (rep) printf("%-24s %7.1f us per launch\n", names[kind], ms / 20 * 1e3);
     }
   return 0;

@@ -470,6 +470,14 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
+  static const char* compact = getenv("GZ_COMPACT_BLUR_V");
+  if (!BM && compact && atoi(compact) != 0) {   // experiment: small-code variant (32-row tiles)
+    dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
+    GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
+              pitch, tp, bs, bm);
+    KCHK(c);
+    return GZ_OK;
+  }
   if (!BM && small_tiles(c)) {
     dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
     GZ_LAUNCH((k_blur_v<R, NC, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,

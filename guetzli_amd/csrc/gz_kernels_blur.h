@@ -302,6 +302,93 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
   if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
 }
 
+template <int R, int NC, class Post, bool BM, int TH = 64>
+__global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post post, int w, int h,
+                                                int pitch, Taps<R> taps, BorderScale bs,
+                                                BlockMaxOut bm) {
+  // TH = tile height (64, or 32 for small images: twice the workgroups to fill the chip)
+  constexpr int VHt = TH, VPTt = TH / 4;
+  __shared__ __attribute__((aligned(16))) float tile[VHt + 2 * R][VW];
+  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const GzTile bid = gz_xcd_tile();
+  const int x0 = bid.x * VW, y0 = bid.y * VHt;
+  const int x = x0 + tx;
+  // staging with one aligned 16-byte load per lane when the tile's columns are all inside
+  // the image and rows are 16-byte aligned (rows outside the image are zero)
+  const bool vec = x0 + VW <= w && (pitch & 3) == 0;
+  const int vq = (threadIdx.x & 15) * 4, vr = threadIdx.x >> 4;
+  // Compact code on purpose: the channel and row loops stay loops (only the taps are
+  // unrolled) and the per-channel results wait in LDS instead of registers: 5 KB of
+  // instructions instead of 34 KB for <16, 3>.  Experiment for the boxes whose
+  // SQC_ICACHE_MISSES are 3x higher (profiles/r01_sq_counters_*_box.csv); selected with
+  // GZ_COMPACT_BLUR_V=1.
+  __shared__ float outv[NC][VHt][VW];
+#pragma unroll 1
+  for (int c = 0; c < NC; ++c) {
+    const float* __restrict__ in = src.p[0];
+#pragma unroll
+    for (int k = 1; k < NC; ++k)
+      if (c == k) in = src.p[k];
+    if (c > 0) __syncthreads();
+    if (vec) {
+#pragma unroll 1
+      for (int k = 0; k < (VHt + 2 * R + 15) / 16; ++k) {
+        const int ry = vr + 16 * k;
+        if (ry < VHt + 2 * R) {
+          const int y = y0 - R + ry;
+          gz_f4 v;
+          v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
+          if (y >= 0 && y < h) v = GZ_LDG4(in, (size_t)y * pitch + x0 + vq);
+          *reinterpret_cast<gz_f4*>(&tile[ry][vq]) = v;
+        }
+      }
+    } else {
+      for (int ry = tg; ry < VHt + 2 * R; ry += 4) {
+        const int y = y0 - R + ry;
+        float v = 0.0f;
+        if (x < w && y >= 0 && y < h) v = in[(size_t)y * pitch + x];
+        tile[ry][tx] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < VPTt; ++i) {
+      const int ly = tg * VPTt + i;   // local output row
+      const int y = y0 + ly;
+      float sum = 0.0f;
+      if (y < h) {
+        const bool border = y < R || y >= h - R;
+        const float* col = &tile[ly][tx];
+        if (!border) {
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) sum += col[j * VW] * taps.ks[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) sum += col[j * VW] * taps.k[j];
+          sum = sum * (y < R ? bs.lo[y] : bs.hi[h - 1 - y]);
+        }
+      }
+      outv[c][ly][tx] = sum;
+    }
+  }
+  // (each lane reads back what it wrote itself: no barrier needed)
+  float res[VPTt];
+#pragma unroll
+  for (int i = 0; i < VPTt; ++i) {
+    const int ly = tg * VPTt + i;
+    const int y = y0 + ly;
+    res[i] = 0.0f;
+    if (x < w && y < h) {
+      float v[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[c] = outv[c][ly][tx];
+      res[i] = post((size_t)y * pitch + x, v);
+    }
+  }
+  if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
+}
+
+
 // ------------------------------------------------------ fused row + column pass (2-D) --
 // Blur = Convolution along x, then along y (butteraugli.cc:229-233), for one 64x64 output
 // tile per workgroup without the intermediate plane ever leaving the chip:

@@ -470,8 +470,10 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
+  // GZ_COMPACT_BLUR_V: 1 = compact variant for every column pass, 2 = for the
+  // single-channel ones only (experiment, see k_blur_v_compact)
   static const char* compact = getenv("GZ_COMPACT_BLUR_V");
-  if (!BM && compact && atoi(compact) != 0) {   // experiment: small-code variant (32-row tiles)
+  if (!BM && compact && (atoi(compact) == 1 || (atoi(compact) == 2 && NC == 1))) {
     dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
     GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
               pitch, tp, bs, bm);

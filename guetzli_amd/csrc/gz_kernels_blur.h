@@ -322,7 +322,10 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
   // instructions instead of 34 KB for <16, 3>.  Experiment for the boxes whose
   // SQC_ICACHE_MISSES are 3x higher (profiles/r01_sq_counters_*_box.csv); selected with
   // GZ_COMPACT_BLUR_V=1.
-  __shared__ float outv[NC][VHt][VW];
+  // one channel: a row's result goes straight to the Post functor; several channels: the
+  // per-channel results wait in LDS until the last channel is done
+  __shared__ float outv[NC > 1 ? NC : 1][NC > 1 ? VHt : 1][VW];
+  float res[VPTt];
 #pragma unroll 1
   for (int c = 0; c < NC; ++c) {
     const float* __restrict__ in = src.p[0];
@@ -368,17 +371,23 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
           sum = sum * (y < R ? bs.lo[y] : bs.hi[h - 1 - y]);
         }
       }
-      outv[c][ly][tx] = sum;
+      if (NC > 1) {
+        outv[c][ly][tx] = sum;
+      } else if (!BM) {
+        float v1[1] = {sum};
+        if (x < w && y < h) post((size_t)y * pitch + x, v1);
+      } else {
+        outv[0][0][tx] = 0.0f;   // (BM kernels are never compact)
+      }
     }
   }
   // (each lane reads back what it wrote itself: no barrier needed)
-  float res[VPTt];
 #pragma unroll
   for (int i = 0; i < VPTt; ++i) {
     const int ly = tg * VPTt + i;
     const int y = y0 + ly;
     res[i] = 0.0f;
-    if (x < w && y < h) {
+    if (NC > 1 && x < w && y < h) {
       float v[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) v[c] = outv[c][ly][tx];

@@ -501,6 +501,14 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bx = cfg.bx, by = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
+  static const char* roll = getenv("GZ_COMPACT_BLUR2D");
+  if (!BM && NC > 1 && roll && atoi(roll) != 0) {   // experiment: rolled channel loop (32-row tiles)
+    dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
+    GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w,
+              h, pitch, tp, bx, by, bm);
+    KCHK(c);
+    return GZ_OK;
+  }
   if (!BM && small_tiles(c)) {
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
     GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w,

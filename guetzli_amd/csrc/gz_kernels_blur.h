@@ -418,7 +418,10 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
 // pass arithmetic.
 constexpr int T2 = 64;   // tile edge
 
-template <int R, int NC, class Src, class Post, bool BM, int TH = 64>
+// ROLL = true: the channel loop stays a loop and the per-channel results wait in LDS instead
+// of registers -- the kernel's code shrinks by about NC x (experiment for the boxes with the
+// high instruction-cache miss counts, GZ_COMPACT_BLUR2D=1).
+template <int R, int NC, class Src, class Post, bool BM, int TH = 64, bool ROLL = false>
 __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post, int w, int h,
                                                 int pitch, Taps<R> taps, BorderScale bsx,
                                                 BorderScale bsy, BlockMaxOut bm) {
@@ -435,10 +438,15 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
                         (pitch & 3) == 0;
   const int tx = tid & 63, tg = tid >> 6;   // column pass: lane = column, wave = row group
   const int hq = (tid & 15) * 4, hr = tid >> 4;   // row pass: 4 columns, rows hr + 16k
-  float acc[NC][VPTt];
-#pragma unroll
+  float acc[ROLL ? 1 : NC][VPTt];
+  __shared__ float outv[ROLL ? NC : 1][ROLL ? TH : 1][T2];
+  constexpr int kChannelUnroll = ROLL ? 1 : NC;
+#pragma unroll kChannelUnroll
   for (int c = 0; c < NC; ++c) {
-    const Src s = src.s[c];
+    Src s = src.s[0];   // constant indices into the kernel arguments
+#pragma unroll
+    for (int k = 1; k < NC; ++k)
+      if (c == k) s = src.s[k];
     if (c > 0) __syncthreads();   // the column pass of the previous plane is done with the tile
     if (interior) {
       // ---- stage: aligned 16-byte loads, all of a thread's loads in flight before the
@@ -495,7 +503,7 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
         float sum = 0.0f;
 #pragma unroll
         for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.ks[j];
-        acc[c][i] = sum;
+        if (ROLL) outv[c][tg * VPTt + i][tx] = sum; else acc[c][i] = sum;
       }
     } else {
       // ---- generic tile: zero outside the image, per-output border handling
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
             sum = sum * (y < R ? bsy.lo[y] : bsy.hi[h - 1 - y]);
           }
         }
-        acc[c][i] = sum;
+        if (ROLL) outv[c][ly][tx] = sum; else acc[c][i] = sum;
       }
     }
   }
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
     if (x < w && y < h) {
       float v[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) v[c] = acc[c][i];
+      for (int c = 0; c < NC; ++c) v[c] = ROLL ? outv[c][tg * VPTt + i][tx] : acc[c][i];   // (own writes)
       res[i] = post((size_t)y * pitch + x, v);
     }
   }

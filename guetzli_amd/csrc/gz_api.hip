@@ -453,6 +453,20 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
 // radius-20 pass touches 104 rows 15 KB apart).
 constexpr int kTileRows = 32;
 constexpr int kSmallTileRows = 16;
+// Compact-code variants of the column pass (k_blur_v_compact) and of the multi-channel fused
+// blurs (k_blur2d<..., ROLL>): loops instead of 20-40 KB of straight-line code.  About one box
+// in eight has 2-3x the instruction-cache misses in these kernels (SQC_ICACHE_MISSES,
+// profiles/r01_sq_counters_*_box.csv) and runs a 1080p chain in 0.55 instead of 0.42 ms; the
+// compact variants bring that back to 0.49 there and cost nothing measurable on the other
+// boxes at 1080p, but 2-3 % at 4K, where the long kernels amortise their instruction fetch
+// (profiles/r01_slow_box_diagnostics_7_compact_ab.log).  Hence: used between 1.5 and 4 MPix;
+// GZ_COMPACT_BLUR_V / GZ_COMPACT_BLUR2D = 0 / 1 force either.
+static bool compact_code(const gz_ctx* c, const char* knob) {
+  const char* e = getenv(knob);
+  if (e) return atoi(e) != 0;
+  const size_t px = (size_t)c->w * c->h;
+  return px >= 1500000 && px < 4000000;
+}
 // Images below ~1.5 MPix use 16-row tiles for the passes without block maxima: twice the
 // workgroups again (720p: 0.290 -> 0.257 ms per Compare; no gain at 1080p, a small loss at 4K).
 // GZ_TILE_ROWS=16 / 32 forces either.
@@ -470,10 +484,7 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  // GZ_COMPACT_BLUR_V: 1 = compact variant for every column pass, 2 = for the
-  // single-channel ones only (experiment, see k_blur_v_compact)
-  static const char* compact = getenv("GZ_COMPACT_BLUR_V");
-  if (!BM && compact && (atoi(compact) == 1 || (atoi(compact) == 2 && NC == 1))) {
+  if (!BM && compact_code(c, "GZ_COMPACT_BLUR_V")) {
     dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
     GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
               pitch, tp, bs, bm);
@@ -501,8 +512,7 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bx = cfg.bx, by = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  static const char* roll = getenv("GZ_COMPACT_BLUR2D");
-  if (!BM && NC > 1 && roll && atoi(roll) != 0) {   // experiment: rolled channel loop (32-row tiles)
+  if (!BM && NC > 1 && compact_code(c, "GZ_COMPACT_BLUR2D")) {   // rolled channel loop
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
     GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w,
               h, pitch, tp, bx, by, bm);

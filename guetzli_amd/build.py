@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libguetzli_amd.so")
 SOURCES = ["gz_api.hip"]
 HEADERS = ["gz_common.h", "gz_math.h", "gz_kernels_block.h", "gz_kernels_blur.h",
-           "gz_kernels_diff.h", "gz_kernels_search.h", "gz_kernels_entropy.h", "gz_kernels_dctd.h",
+           "gz_kernels_diff.h", "gz_kernels_search.h", "gz_kernels_entropy.h", "gz_kernels_dctd.h", "gz_kernels_downsample.h",
            "gz_kernels_order.h", "gz_kernels_rank.h", "gz_host_weights.h", "tables_generated.h", "order_tables_generated.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

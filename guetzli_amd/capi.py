@@ -34,6 +34,9 @@ SIGNATURES = {
     "gz_encode_rgb": (_I, [_P, _P]),
     "gz_encode_rgb_only": (_I, [_I, _P, _I, _I, _P]),
     "gz_set_orig_coeffs": (_I, [_P, _P]),
+    "gz_set_orig_coeffs_420": (_I, [_P, _P]),
+    "gz_downsample": (_I, [_P, _P]),
+    "gz_frame_layout": (_I, [_P, _P, _P, _P]),
     "gz_quantize": (_I, [_P, _P, _P]),
     "gz_set_coeffs": (_I, [_P, _P]),
     "gz_set_coeff_blocks": (_I, [_P, _P, _I, _P]),
@@ -47,7 +50,9 @@ SIGNATURES = {
     "gz_last_distance": (_I, [_P, _P]),
     "gz_time_compare": (_I, [_P, _I, _P]),
     "gz_block_weights": (_I, [_P, _I, _I, C.c_double, _I, _P]),
+    "gz_block_weights_factor": (_I, [_P, _I, _I, C.c_double, _I, _I, _P]),
     "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
+    "gz_block_zeroing_orders_masked": (_I, [_P, _I, _I, _I, _P, _P, _P, _I]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
     "gz_probe_rank_sort": (_I, [_I, _P, _P, _I, _P]),
     "gz_order_build": (_I, [_P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P]),
@@ -61,6 +66,7 @@ SIGNATURES = {
     "gz_order_partition": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
     "gz_order_fetch": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
     "gz_jpeg_histograms": (_I, [_P, _P, _P]),
+    "gz_jpeg_histograms_ncomp": (_I, [_P, _P, _I, _P]),
     "gz_jpeg_scan": (_I, [_P, _I, _P, _P, _P]),
     "gz_jpeg_scan_keep": (_I, [_P]),
     "gz_jpeg_scan_bytes": (_I, [_P, _I, _P, C.c_size_t, _P]),
@@ -182,6 +188,11 @@ class Context:
         assert ch == 3
         self.bw, self.bh = (self.w + 7) // 8, (self.h + 7) // 8
         self.nb = self.bw * self.bh
+        # the frame: 4:4:4 (coefficient arrays [3][nb][64]) until downsample() /
+        # set_orig_coeffs_420() make it 4:2:0 (flat [nb + 2*nbc][64]: Y, Cb, Cr)
+        self.cfac = 1
+        self.cbw, self.cbh = (self.w + 15) // 16, (self.h + 15) // 16
+        self.nbc = self.cbw * self.cbh
         err = C.c_int(0)
         self.handle = library.lib.gz_create(device, self.w, self.h, _ptr(self.rgb),
                                             float(target), C.byref(err))
@@ -206,7 +217,23 @@ class Context:
         self.L.check(rc, self.handle)
 
     def _coeff_buf(self):
+        if self.cfac == 2:
+            return np.zeros((self.nb + 2 * self.nbc, 64), np.int16)
         return np.zeros((3, self.nb, 64), np.int16)
+
+    @property
+    def nblk(self):
+        return self.nb + 2 * self.nbc if self.cfac == 2 else 3 * self.nb
+
+    def split420(self, coeffs):
+        """(Y [nb][64], Cb [nbc][64], Cr [nbc][64]) views of a 4:2:0 coefficient array."""
+        co = np.asarray(coeffs).reshape(-1, 64)
+        return co[:self.nb], co[self.nb:self.nb + self.nbc], co[self.nb + self.nbc:]
+
+    def frame_layout(self):
+        f, a, b = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.L.lib.gz_frame_layout(self.handle, C.byref(f), C.byref(a), C.byref(b)))
+        return f.value, a.value, b.value
 
     def set_rgb(self, rgb):
         rgb = np.ascontiguousarray(rgb, np.uint8)
@@ -221,6 +248,7 @@ class Context:
         self._chk(self.L.lib.gz_set_stream(self.handle, stream_ptr))
 
     def encode_rgb(self, download=True):
+        self.cfac = 1
         out = self._coeff_buf() if download else None
         self._chk(self.L.lib.gz_encode_rgb(self.handle, _ptr(out)))
         return out
@@ -228,7 +256,21 @@ class Context:
     def set_orig_coeffs(self, coeffs):
         co = np.ascontiguousarray(coeffs, np.int16)
         assert co.size == 3 * self.nb * 64
+        self.cfac = 1
         self._chk(self.L.lib.gz_set_orig_coeffs(self.handle, _ptr(co)))
+
+    def set_orig_coeffs_420(self, coeffs):
+        co = np.ascontiguousarray(coeffs, np.int16)
+        assert co.size == (self.nb + 2 * self.nbc) * 64
+        self.cfac = 2
+        self._chk(self.L.lib.gz_set_orig_coeffs_420(self.handle, _ptr(co)))
+
+    def downsample(self, download=True):
+        """OutputImage::Downsample on the original: the frame becomes 4:2:0."""
+        self.cfac = 2
+        out = self._coeff_buf() if download else None
+        self._chk(self.L.lib.gz_downsample(self.handle, _ptr(out)))
+        return out
 
     def quantize(self, q=None, download=True):
         qq = None if q is None else np.ascontiguousarray(q, np.int32)
@@ -238,7 +280,7 @@ class Context:
 
     def set_coeffs(self, coeffs):
         co = np.ascontiguousarray(coeffs, np.int16)
-        assert co.size == 3 * self.nb * 64
+        assert co.size == self.nblk * 64
         self._chk(self.L.lib.gz_set_coeffs(self.handle, _ptr(co)))
 
     def set_coeff_blocks(self, block_index, blocks):
@@ -294,13 +336,25 @@ class Context:
                                               target_mul, int(use_distmap), _ptr(wgt)))
         return wgt
 
-    def block_zeroing_orders(self, lookahead=3, new_model=True):
-        cap = self.nb * 189
-        off = np.zeros(self.nb + 1, np.int32)
+    def block_weights_factor(self, direction, max_block_dist, target_mul, factor,
+                             use_distmap=True, weights=None):
+        n = self.nbc if factor == 2 else self.nb
+        wgt = np.zeros(n, np.float32) if weights is None else \
+            np.ascontiguousarray(weights, np.float32).copy()
+        self._chk(self.L.lib.gz_block_weights_factor(self.handle, direction, max_block_dist,
+                                                     target_mul, int(use_distmap), factor, _ptr(wgt)))
+        return wgt
+
+    def block_zeroing_orders(self, lookahead=3, new_model=True, comp_mask=7):
+        gn = self.nbc if (self.cfac == 2 and comp_mask == 6) else self.nb
+        self.search_blocks = gn
+        cap = gn * 189
+        off = np.zeros(gn + 1, np.int32)
         idx = np.zeros(cap, np.uint8)
         err = np.zeros(cap, np.float32)
-        self._chk(self.L.lib.gz_block_zeroing_orders(self.handle, lookahead, int(new_model),
-                                                     _ptr(off), _ptr(idx), _ptr(err), cap))
+        self._chk(self.L.lib.gz_block_zeroing_orders_masked(self.handle, comp_mask, lookahead,
+                                                            int(new_model), _ptr(off), _ptr(idx),
+                                                            _ptr(err), cap))
         n = int(off[-1])
         return off, idx[:n].copy(), err[:n].copy()
 
@@ -311,7 +365,7 @@ class Context:
         nc = np.ascontiguousarray(next_cand, np.int32)
         me = np.ascontiguousarray(max_block_error, np.float32)
         bw = np.ascontiguousarray(block_weight, np.float32)
-        assert nc.size == me.size == bw.size == self.nb
+        assert nc.size == me.size == bw.size == getattr(self, "search_blocks", self.nb)
         total, below = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
         btc = np.zeros(1, np.int32)
         self._chk(self.L.lib.gz_order_build(self.handle, direction, _ptr(nc), _ptr(me), _ptr(bw),
@@ -325,7 +379,7 @@ class Context:
     def order_build_auto(self, direction, max_block_dist, target_mul, use_distmap, next_cand,
                          limit=None):
         nc = np.ascontiguousarray(next_cand, np.int32)
-        assert nc.size == self.nb
+        assert nc.size == getattr(self, "search_blocks", self.nb)
         total, below = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
         btc = np.zeros(1, np.int32)
         self._chk(self.L.lib.gz_order_build_auto(self.handle, direction, max_block_dist,
@@ -371,12 +425,12 @@ class Context:
         return out
 
     # ---- entropy coding of the candidate ----
-    def jpeg_histograms(self, q):
+    def jpeg_histograms(self, q, ncomp=3):
         """(DC, AC) x component x symbol occurrence counts, uint32 [2][3][256]."""
         qq = np.ascontiguousarray(q, np.int32)
         assert qq.shape == (3, 64)
         counts = np.zeros((2, 3, 256), np.uint32)
-        self._chk(self.L.lib.gz_jpeg_histograms(self.handle, _ptr(qq), _ptr(counts)))
+        self._chk(self.L.lib.gz_jpeg_histograms_ncomp(self.handle, _ptr(qq), ncomp, _ptr(counts)))
         return counts
 
     def jpeg_scan(self, ncomp, depth, code):

@@ -29,6 +29,7 @@
 #include "gz_kernels_search.h"
 #include "gz_kernels_entropy.h"
 #include "gz_kernels_dctd.h"
+#include "gz_kernels_downsample.h"
 #include "gz_kernels_order.h"
 #include "gz_kernels_rank.h"
 #include "gz_host_weights.h"
@@ -315,6 +316,14 @@ struct gz_ctx {
   int device = 0;
   int w = 0, h = 0, bw = 0, bh = 0, nb = 0, pitch = 0;
   size_t plane = 0;   // floats per plane
+  // The current frame (OutputImage's component layout): chroma subsampling factor 1 (4:4:4)
+  // or 2 (4:2:0: OutputImageComponent::Reset(2, 2), output_image.cc:40-49), the chroma block
+  // grid under it, the first block of every component in d_orig / d_cand, blocks in total.
+  int cfac = 1, cbw = 0, cbh = 0, nbc = 0, coff[3] = {0, 0, 0}, nblk = 0;
+  uint8_t* d_csamp = nullptr;      // 4:2:0: IDCT samples of the two chroma components (k_chroma_samples)
+  // grid of the last block search (gz_block_zeroing_orders*), which phase B's order works on
+  int sg_w = 0, sg_h = 0, sg_n = 0, sg_factor = 1, sg_mask = 7;
+  float* d_gmax = nullptr;         // per-16x16 maxima of the distance map (sg_factor == 2)
   float target = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -400,6 +409,25 @@ struct gz_ctx {
   float last_distance = 0.0f;
 };
 
+// Every context entry point runs with the context's device current and leaves the caller's
+// device as it found it: a thread may own contexts on several GPUs (the pools key on the
+// current device, kernels launch on it).
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(const gz_ctx* c) {
+    if (!c) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+    if (cur != c->device) {
+      (void)hipSetDevice(c->device);
+      prev = cur;
+    }
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 namespace {
 
 #define HIPCHK(ctx, call)                                                            \
@@ -421,6 +449,21 @@ namespace {
   } while (0)
 
 const int kNumPlanes = 9 + 9 + 3 + 3 + 3 + 2 + 2 + 10;   // pi0, pi1, lin, tmp, xyb, lf_raw, hfp, 10 singles
+
+void set_frame(gz_ctx* c, int factor) {
+  c->cfac = factor;
+  c->cbw = (c->w + 8 * factor - 1) / (8 * factor);
+  c->cbh = (c->h + 8 * factor - 1) / (8 * factor);
+  c->nbc = c->cbw * c->cbh;
+  c->coff[0] = 0;
+  c->coff[1] = c->nb;
+  c->coff[2] = c->nb + c->nbc;
+  c->nblk = c->nb + 2 * c->nbc;
+  c->have_search = false;
+}
+size_t csamp_plane(const gz_ctx* c) {   // bytes of one chroma sample plane of a 4:2:0 frame
+  return (size_t)((c->w + 15) / 16 * 8) * (size_t)((c->h + 15) / 16 * 8);
+}
 
 float* take_plane(gz_ctx* c) {
   float* p = c->free_planes.back();
@@ -812,8 +855,25 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
   return GZ_OK;
 }
 
+int stage_chroma_samples(gz_ctx* c, const int16_t* d_coeffs) {
+  if (!c->d_csamp) HIPCHK(c, pool_malloc((void**)&c->d_csamp, 2 * csamp_plane(c)));
+  GZ_LAUNCH(k_chroma_samples, dim3(gz_div_up(c->nbc, kBlocksPerWG)), dim3(256), c->stream,
+            d_coeffs + (size_t)c->coff[1] * 64, d_coeffs + (size_t)c->coff[2] * 64, c->cbw, c->nbc,
+            c->d_csamp);
+  KCHK(c);
+  return GZ_OK;
+}
+
 int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* srgb,
                       unsigned* clear_word = nullptr) {
+  if (c->cfac == 2) {
+    TRY(stage_chroma_samples(c, d_coeffs));
+    GZ_LAUNCH(k_reconstruct420, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream,
+              d_coeffs, (const uint8_t*)c->d_csamp, c->w, c->h, c->bw, c->nb, c->cbw, c->cbh,
+              c->pitch, c->plane, c->d_srgb_lut, lin0, srgb, clear_word);
+    KCHK(c);
+    return GZ_OK;
+  }
   GZ_LAUNCH(k_reconstruct, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream,
             d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
             srgb, clear_word);
@@ -959,7 +1019,7 @@ void rank_all(const int16_t* coeffs, const int16_t* orig, int nb, int new_model,
 // ===================================================================== C surface ======
 extern "C" {
 
-int gz_abi_version(void) { return 1; }
+int gz_abi_version(void) { return 2; }
 
 int gz_trim_pool(void) {
   {
@@ -1001,7 +1061,15 @@ const char* gz_strerror(int code) {
 
 const char* gz_last_error(const gz_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
+static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, float target, int* err);
 gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, int* err) {
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+  gz_ctx* c = create_context(device, w, h, rgb, target, err);
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);   // the caller's device stays current
+  return c;
+}
+static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, float target, int* err) {
   int dummy;
   if (!err) err = &dummy;
   *err = GZ_OK;
@@ -1019,6 +1087,7 @@ gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, in
   c->pitch = w;
   c->plane = (size_t)c->pitch * h;
   c->target = target;
+  set_frame(c, 1);
   auto fail = [&](int code) { *err = code; gz_destroy(c); return (gz_ctx*)nullptr; };
 #define CHK0(call) do { if ((call) != hipSuccess) { return fail(GZ_E_HIP); } } while (0)
   CHK0(pool_stream_create(&c->own_stream));
@@ -1083,6 +1152,7 @@ gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, in
 }
 
 int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
+  DeviceScope ds_(c);
   if (!c || !rgb) return GZ_E_ARG;
   HIPCHK(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)3 * c->w * c->h, hipMemcpyHostToDevice, c->stream));
   // pi0_ = SeparateFrequencies(OpsinDynamicsImage(LinearRgb(rgb)))
@@ -1100,7 +1170,7 @@ int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
 
 void gz_destroy(gz_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);   // the pools file what comes back under the current device
+  DeviceScope ds_(c);   // the pools file what comes back under the current device
   // everything must be idle before the memory goes back to the pool (another context may get
   // it at once; hipFree would have waited, the pool does not)
   if (c->stream && c->stream != c->own_stream) (void)hipStreamSynchronize(c->stream);
@@ -1115,7 +1185,7 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->extra_arena);
   (void)pool_free(c->d_block_mask); (void)pool_free(c->d_rank_cnt); (void)pool_free(c->d_rank_tables); (void)pool_free(c->d_rank_idx);
   (void)pool_free(c->d_out_cnt); (void)pool_free(c->d_out_idx); (void)pool_free(c->d_out_err);
-  (void)pool_free(c->d_step_delta);
+  (void)pool_free(c->d_step_delta); (void)pool_free(c->d_csamp); (void)pool_free(c->d_gmax);
   (void)pool_free(c->d_jq); (void)pool_free(c->d_hist); (void)pool_free(c->d_code_depth); (void)pool_free(c->d_code_bits);
   (void)pool_free(c->d_mcu_bits); (void)pool_free(c->d_mcu_off); (void)pool_free(c->d_ff_count);
   (void)pool_free(c->d_words); (void)pool_free(c->d_words_kept);
@@ -1139,12 +1209,14 @@ void gz_destroy(gz_ctx* c) {
 }
 
 int gz_synchronize(gz_ctx* c) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GZ_OK;
 }
 
 int gz_set_stream(gz_ctx* c, void* s) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -1152,7 +1224,12 @@ int gz_set_stream(gz_ctx* c, void* s) {
 }
 
 int gz_encode_rgb(gz_ctx* c, int16_t* coeffs_out) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
+  if (c->cfac != 1) {   // back to 4:4:4: the candidate and the search belonged to the other frame
+    set_frame(c, 1);
+    c->have_cand = false;
+  }
   GZ_LAUNCH(k_encode_rgb, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream, c->d_rgb,
             c->w, c->h, c->bw, c->nb, c->d_orig);
   KCHK(c);
@@ -1165,16 +1242,37 @@ int gz_encode_rgb(gz_ctx* c, int16_t* coeffs_out) {
   return GZ_OK;
 }
 
-int gz_set_orig_coeffs(gz_ctx* c, const int16_t* coeffs) {
+static int set_orig(gz_ctx* c, const int16_t* coeffs, int factor) {
   if (!c || !coeffs) return GZ_E_ARG;
-  HIPCHK(c, hipMemcpyAsync(c->d_orig, coeffs, (size_t)3 * c->nb * 128, hipMemcpyHostToDevice,
+  if (c->cfac != factor) {   // the candidate and the search belonged to the other frame
+    set_frame(c, factor);
+    c->have_cand = false;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_orig, coeffs, (size_t)c->nblk * 128, hipMemcpyHostToDevice,
                            c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_orig = true;
   return GZ_OK;
 }
+int gz_set_orig_coeffs(gz_ctx* c, const int16_t* coeffs) {
+  DeviceScope ds_(c);
+  return set_orig(c, coeffs, 1);
+}
+int gz_set_orig_coeffs_420(gz_ctx* c, const int16_t* coeffs) {
+  DeviceScope ds_(c);
+  return set_orig(c, coeffs, 2);
+}
+
+int gz_frame_layout(gz_ctx* c, int* chroma_factor, int* luma_blocks, int* chroma_blocks) {
+  if (!c) return GZ_E_ARG;
+  if (chroma_factor) *chroma_factor = c->cfac;
+  if (luma_blocks) *luma_blocks = c->nb;
+  if (chroma_blocks) *chroma_blocks = c->nbc;
+  return GZ_OK;
+}
 
 int gz_quantize(gz_ctx* c, const int* q, int16_t* coeffs_out) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   if (!c->have_orig) { c->err = "no original coefficients"; return GZ_E_STATE; }
   int ones[192];
@@ -1182,9 +1280,10 @@ int gz_quantize(gz_ctx* c, const int* q, int16_t* coeffs_out) {
   for (int i = 0; i < 192; ++i) if (q[i] <= 0) return GZ_E_ARG;
   HIPCHK(c, hipMemcpyAsync(c->d_q, q, sizeof(int) * 192, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // q may live on the caller's stack
-  const size_t total = (size_t)3 * c->nb * 64;
+  const size_t total = (size_t)c->nblk * 64;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-  GZ_LAUNCH(k_quantize, dim3(blocks), dim3(256), c->stream, c->d_orig, c->d_cand, c->nb, c->d_q);
+  GZ_LAUNCH(k_quantize, dim3(blocks), dim3(256), c->stream, c->d_orig, c->d_cand, c->coff[1],
+            c->coff[2], c->nblk, c->d_q);
   KCHK(c);
   c->have_cand = true;
   if (coeffs_out) {
@@ -1195,8 +1294,9 @@ int gz_quantize(gz_ctx* c, const int* q, int16_t* coeffs_out) {
 }
 
 int gz_set_coeffs(gz_ctx* c, const int16_t* coeffs) {
+  DeviceScope ds_(c);
   if (!c || !coeffs) return GZ_E_ARG;
-  HIPCHK(c, hipMemcpyAsync(c->d_cand, coeffs, (size_t)3 * c->nb * 128, hipMemcpyHostToDevice,
+  HIPCHK(c, hipMemcpyAsync(c->d_cand, coeffs, (size_t)c->nblk * 128, hipMemcpyHostToDevice,
                            c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_cand = true;
@@ -1204,12 +1304,15 @@ int gz_set_coeffs(gz_ctx* c, const int16_t* coeffs) {
 }
 
 int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int16_t* blocks) {
+  DeviceScope ds_(c);
   if (!c || n < 0 || (n > 0 && (!block_index || !blocks))) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
+  if (c->cfac != 1) { c->err = "gz_set_coeff_blocks needs a 4:4:4 frame"; return GZ_E_STATE; }
   if (n == 0) return GZ_OK;
   for (int i = 0; i < n; ++i)
     if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;
   if ((size_t)n > c->blkidx_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the pool hands memory on without waiting
     (void)pool_free(c->d_blkidx); (void)pool_free(c->d_blkdata);
     c->d_blkidx = nullptr; c->d_blkdata = nullptr;
     c->blkidx_cap = std::max<size_t>((size_t)n, std::min<size_t>((size_t)c->nb, 2 * c->blkidx_cap + 1024));
@@ -1226,14 +1329,16 @@ int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int1
 }
 
 int gz_get_coeffs(gz_ctx* c, int16_t* out) {
+  DeviceScope ds_(c);
   if (!c || !out) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
-  HIPCHK(c, hipMemcpyAsync(out, c->d_cand, (size_t)3 * c->nb * 128, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out, c->d_cand, (size_t)c->nblk * 128, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GZ_OK;
 }
 
 int gz_reconstruct(gz_ctx* c, uint8_t* srgb, float* linear) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   TRY(stage_reconstruct(c, c->d_cand, linear ? c->lin[0] : nullptr, srgb ? c->d_srgb_out : nullptr));
@@ -1244,6 +1349,7 @@ int gz_reconstruct(gz_ctx* c, uint8_t* srgb, float* linear) {
 }
 
 int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
+  DeviceScope ds_(c);
   if (!c || !distance) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   TRY(enqueue_compare(c, true));
@@ -1271,6 +1377,7 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
 }
 
 int gz_compare_begin(gz_ctx* c) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   HIPCHK(c, hipEventRecord(c->ev_candidate, c->stream));   // gz_jpeg_scan waits for this only
@@ -1281,6 +1388,7 @@ int gz_compare_begin(gz_ctx* c) {
 }
 
 int gz_compare_end(gz_ctx* c, float* distance) {
+  DeviceScope ds_(c);
   if (!c || !distance) return GZ_E_ARG;
   if (!c->compare_pending) { c->err = "gz_compare_begin must precede gz_compare_end"; return GZ_E_STATE; }
   void* res = nullptr;
@@ -1295,6 +1403,7 @@ int gz_compare_end(gz_ctx* c, float* distance) {
 }
 
 int gz_compare_enqueue(gz_ctx* c, int iters) {
+  DeviceScope ds_(c);
   if (!c || iters < 0) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   for (int i = 0; i < iters; ++i) TRY(enqueue_compare(c, true));
@@ -1302,6 +1411,7 @@ int gz_compare_enqueue(gz_ctx* c, int iters) {
 }
 
 int gz_last_distance(gz_ctx* c, float* distance) {
+  DeviceScope ds_(c);
   if (!c || !distance) return GZ_E_ARG;
   unsigned bits = 0;
   HIPCHK(c, hipMemcpyAsync(&bits, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1311,6 +1421,7 @@ int gz_last_distance(gz_ctx* c, float* distance) {
 }
 
 int gz_time_compare(gz_ctx* c, int iters, float* total_ms) {
+  DeviceScope ds_(c);
   if (!c || iters <= 0 || !total_ms) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   hipEvent_t e0, e1;
@@ -1330,7 +1441,13 @@ int gz_time_compare(gz_ctx* c, int iters, float* total_ms) {
 // maxima of :505-520 come out of the final blur kernel).  O(nb) host work on nb floats.
 int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target_mul,
                      int use_distmap, float* block_weight) {
-  if (!c || !block_weight || max_block_dist < 0) return GZ_E_ARG;
+  return gz_block_weights_factor(c, direction, max_block_dist, target_mul, use_distmap, 1, block_weight);
+}
+
+int gz_block_weights_factor(gz_ctx* c, int direction, int max_block_dist, double target_mul,
+                            int use_distmap, int factor, float* block_weight) {
+  DeviceScope ds_(c);
+  if (!c || !block_weight || max_block_dist < 0 || (factor != 1 && factor != 2)) return GZ_E_ARG;
   if (use_distmap && !c->have_distmap) { c->err = "no distance map yet"; return GZ_E_STATE; }
   std::vector<float> zero;
   if (use_distmap && !c->h_block_max_valid) {
@@ -1342,7 +1459,19 @@ int gz_block_weights(gz_ctx* c, int direction, int max_block_dist, double target
   }
   const float* bmax = c->h_block_max.data();
   if (!use_distmap) { zero.assign(c->nb, 0.0f); bmax = zero.data(); }
-  block_weights_host(bmax, c->bw, c->bh, c->target, direction, max_block_dist, target_mul,
+  int gw = c->bw, gh = c->bh;
+  std::vector<float> grouped;
+  if (factor == 2) {   // maxima over 16x16 areas (butteraugli_comparator.cc:502-520)
+    gw = (c->w + 15) / 16; gh = (c->h + 15) / 16;
+    grouped.assign((size_t)gw * gh, 0.0f);
+    for (int by = 0; by < c->bh; ++by)
+      for (int bx = 0; bx < c->bw; ++bx) {
+        float& m = grouped[(size_t)(by / 2) * gw + bx / 2];
+        m = std::max(m, bmax[(size_t)by * c->bw + bx]);
+      }
+    bmax = grouped.data();
+  }
+  block_weights_host(bmax, gw, gh, c->target, direction, max_block_dist, target_mul,
                      block_weight);
   return GZ_OK;
 }
@@ -1355,6 +1484,7 @@ static int ensure_order_capacity(gz_ctx* c, size_t n) {
     HIPCHK(c, pool_malloc((void**)&c->d_order_counters, sizeof(unsigned) * 2));
   }
   if (n <= c->order_cap) return GZ_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the pool hands memory on without waiting
   (void)pool_free(c->d_order); (void)pool_free(c->d_pos_l); (void)pool_free(c->d_pos_r); (void)pool_free(c->d_chunk);
   c->d_order = nullptr; c->d_pos_l = nullptr; c->d_pos_r = nullptr; c->d_chunk = nullptr;
   c->order_cap = 0;
@@ -1385,7 +1515,7 @@ static int ensure_order_block_arrays(gz_ctx* c) {
 static int order_build_device(gz_ctx* c, int direction, int count_below, float limit,
                               uint64_t* total, int32_t* blocks_to_change, uint64_t* below,
                               bool sizes_done = false) {
-  const int nb = c->nb;
+  const int nb = c->sg_n;
   // An order never has more entries than phase A produced candidates: sized once, so that the
   // construction runs through without a host round trip between counting and filling.
   TRY(ensure_order_capacity(c, std::max<size_t>(c->search_total, 1)));
@@ -1424,11 +1554,12 @@ static int order_build_device(gz_ctx* c, int direction, int count_below, float l
 int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
                    const float* max_block_error, const float* block_weight, int count_below,
                    float limit, uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  DeviceScope ds_(c);
   if (!c || !next_cand || !max_block_error || !block_weight || !total || !blocks_to_change ||
       (direction != 1 && direction != -1) || (count_below && !below))
     return GZ_E_ARG;
   if (!c->have_search) { c->err = "gz_block_zeroing_orders must precede gz_order_build"; return GZ_E_STATE; }
-  const int nb = c->nb;
+  const int nb = c->sg_n;
   TRY(ensure_order_block_arrays(c));
   HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_weight, block_weight, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
@@ -1437,6 +1568,7 @@ int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
 }
 
 int gz_order_reset(gz_ctx* c) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   TRY(ensure_order_block_arrays(c));
   HIPCHK(c, hipMemsetAsync(c->d_max_err, 0, sizeof(float) * c->nb, c->stream));
@@ -1446,12 +1578,13 @@ int gz_order_reset(gz_ctx* c) {
 int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double target_mul,
                         int use_distmap, const int32_t* next_cand, int count_below, float limit,
                         uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  DeviceScope ds_(c);
   if (!c || !next_cand || !total || !blocks_to_change || (direction != 1 && direction != -1) ||
       max_block_dist < 0 || (count_below && !below))
     return GZ_E_ARG;
   if (!c->have_search) { c->err = "gz_block_zeroing_orders must precede gz_order_build_auto"; return GZ_E_STATE; }
   if (use_distmap && !c->have_distmap) { c->err = "no distance map yet"; return GZ_E_STATE; }
-  const int nb = c->nb;
+  const int nb = c->sg_n;
   TRY(ensure_order_block_arrays(c));
   TRY(ensure_order_capacity(c, std::max<size_t>(c->search_total, 1)));   // also: the counters
   {
@@ -1461,10 +1594,18 @@ int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double tar
     HIPCHK(c, hipMemcpyAsync(c->d_next_cand, h, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
     TRY(stage_sent(c, &c->stage_main, c->stream));
   }
-  const int bw = c->bw, bh = c->bh;
+  const int bw = c->sg_w, bh = c->sg_h;
   const float target = c->target;
+  const float* d_bmax = c->d_block_max;
+  if (c->sg_factor == 2 && use_distmap) {   // search grid of 16x16 areas: group the 8x8 maxima
+    if (!c->d_gmax) HIPCHK(c, pool_malloc((void**)&c->d_gmax, sizeof(float) * ((c->w + 15) / 16) * ((c->h + 15) / 16)));
+    GZ_LAUNCH(k_block_max_group, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
+              (const float*)c->d_block_max, c->bw, c->bh, bw, bh, 2, c->d_gmax);
+    KCHK(c);
+    d_bmax = c->d_gmax;
+  }
   GZ_LAUNCH(k_weights_flag, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
-            (const float*)c->d_block_max, use_distmap ? 1 : 0, bw, bh, target, target_mul,
+            d_bmax, use_distmap ? 1 : 0, bw, bh, target, target_mul,
             direction, max_block_dist, c->d_wflag, c->d_order_counters);
   KCHK(c);
   GZ_LAUNCH(k_weights_gather, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
@@ -1475,16 +1616,18 @@ int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double tar
 }
 
 int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
+  DeviceScope ds_(c);
   if (!c || (direction != 1 && direction != -1)) return GZ_E_ARG;
   if (!c->d_weight) { c->err = "gz_order_build_auto must precede gz_order_advance"; return GZ_E_STATE; }
-  GZ_LAUNCH(k_order_advance, dim3(gz_div_up(c->nb, 256)), dim3(256), c->stream, c->d_max_err,
-            (const float*)c->d_weight, val_threshold, direction, c->nb);
+  GZ_LAUNCH(k_order_advance, dim3(gz_div_up(c->sg_n, 256)), dim3(256), c->stream, c->d_max_err,
+            (const float*)c->d_weight, val_threshold, direction, c->sg_n);
   KCHK(c);
   return GZ_OK;
 }
 
 int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
                              const int32_t* counts, int n) {
+  DeviceScope ds_(c);
   if (!c || n < 0 || (n > 0 && (!blocks || !counts)) || (direction != 1 && direction != -1))
     return GZ_E_ARG;
   if (!c->have_search || !c->d_next_cand || !c->have_cand || !c->have_orig) {
@@ -1493,8 +1636,9 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
   }
   if (n == 0) return GZ_OK;
   for (int i = 0; i < n; ++i)
-    if (blocks[i] < 0 || blocks[i] >= c->nb || counts[i] < 0 || counts[i] > 192) return GZ_E_ARG;
+    if (blocks[i] < 0 || blocks[i] >= c->sg_n || counts[i] < 0 || counts[i] > 192) return GZ_E_ARG;
   if ((size_t)2 * n > c->edit_cap) {   // the edit buffers double as (blocks, counts) staging
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the pool hands memory on without waiting
     (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
     c->d_edit_pos = nullptr; c->d_edit_val = nullptr;
     c->edit_cap = (size_t)2 * n + (size_t)n + 4096;
@@ -1511,7 +1655,9 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
     TRY(stage_sent(c, &c->stage_main, c->stream));
   }
-  const int nb = c->nb;
+  StepGeom sg;
+  for (int i = 0; i < 3; ++i) sg.coff[i] = c->coff[i];
+  sg.comp_mask = c->sg_mask;
   c->have_step_delta = false;
   if (c->have_jq) {
     // with the symbol statistics' quantiser known, the steps also report what they do to the
@@ -1521,7 +1667,7 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     GZ_LAUNCH(k_apply_steps_hist, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
               (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
               (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
-              (const int*)c->d_q, (const int*)c->d_jq, nb, c->d_step_delta);
+              (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta);
     KCHK(c);
     c->have_step_delta = true;
     return GZ_OK;
@@ -1529,12 +1675,13 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
   GZ_LAUNCH(k_apply_steps, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
             (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
             (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
-            (const int*)c->d_q, nb);
+            (const int*)c->d_q, sg);
   KCHK(c);
   return GZ_OK;   // the caller's buffers were copied to the staging buffer: no wait
 }
 
 int gz_steps_histogram_delta(gz_ctx* c, int32_t* ac_delta) {
+  DeviceScope ds_(c);
   if (!c || !ac_delta) return GZ_E_ARG;
   if (!c->have_step_delta) {
     c->err = "gz_apply_candidate_steps (after gz_jpeg_histograms) must precede gz_steps_histogram_delta";
@@ -1549,13 +1696,15 @@ int gz_steps_histogram_delta(gz_ctx* c, int32_t* ac_delta) {
 }
 
 int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int n) {
+  DeviceScope ds_(c);
   if (!c || n < 0 || (n > 0 && (!pos || !val))) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   if (n == 0) return GZ_OK;
-  const int limit = 3 * c->nb * 64;
+  const int limit = c->nblk * 64;
   for (int i = 0; i < n; ++i)
     if (pos[i] < 0 || pos[i] >= limit) return GZ_E_ARG;
   if ((size_t)n > c->edit_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the pool hands memory on without waiting
     (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
     c->d_edit_pos = nullptr; c->d_edit_val = nullptr;
     c->edit_cap = (size_t)n + (size_t)n / 2 + 4096;
@@ -1578,6 +1727,7 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
 }
 
 int gz_order_upload(gz_ctx* c, const void* entries, uint64_t n) {
+  DeviceScope ds_(c);
   if (!c || (n > 0 && !entries)) return GZ_E_ARG;
   TRY(ensure_order_capacity(c, (size_t)n));
   if (n > 0)
@@ -1588,6 +1738,7 @@ int gz_order_upload(gz_ctx* c, const void* entries, uint64_t n) {
 }
 
 int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
+  DeviceScope ds_(c);
   if (!c || !cut) return GZ_E_ARG;
   if (hi > c->order_n || lo >= hi || hi - lo <= 3 || hi - lo > 0xfffffff0ull) return GZ_E_ARG;
   const size_t first = (size_t)lo + 1;
@@ -1630,6 +1781,7 @@ int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
 }
 
 int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
+  DeviceScope ds_(c);
   if (!c || !out || lo > hi || hi > c->order_n) return GZ_E_ARG;
   const size_t bytes = sizeof(OrderEntry) * (size_t)(hi - lo);
   if (bytes > 0 && bytes <= ((size_t)4 << 20)) {   // the usual case: through the pinned landing area
@@ -1660,8 +1812,30 @@ static int ensure_entropy_buffers(gz_ctx* c) {
   return GZ_OK;
 }
 
+// The frame as the JPEG sees it: ncomp == 3: the current layout with its MCUs; ncomp == 1: the
+// luma component alone, one block per MCU, no padding (SaveToJpegData writes a single
+// component when both chroma components are entirely zero, output_image.cc:357-365).
+static FrameGeom frame_geom(const gz_ctx* c, int ncomp) {
+  FrameGeom g;
+  g.ncomp = ncomp;
+  for (int i = 0; i < 3; ++i) {
+    g.bw[i] = i == 0 ? c->bw : c->cbw;
+    g.bh[i] = i == 0 ? c->bh : c->cbh;
+    g.coff[i] = c->coff[i];
+    g.samp[i] = (i == 0 && ncomp == 3) ? c->cfac : 1;
+  }
+  g.mcu_cols = ncomp == 3 ? c->cbw : c->bw;
+  g.mcu_rows = ncomp == 3 ? c->cbh : c->bh;
+  return g;
+}
+
 int gz_jpeg_histograms(gz_ctx* c, const int* q, uint32_t* counts) {
-  if (!c || !q || !counts) return GZ_E_ARG;
+  return gz_jpeg_histograms_ncomp(c, q, 3, counts);
+}
+
+int gz_jpeg_histograms_ncomp(gz_ctx* c, const int* q, int ncomp, uint32_t* counts) {
+  DeviceScope ds_(c);
+  if (!c || !q || !counts || (ncomp != 1 && ncomp != 3)) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
   for (int i = 0; i < 192; ++i) if (q[i] <= 0) return GZ_E_ARG;
   TRY(ensure_entropy_buffers(c));
@@ -1671,9 +1845,10 @@ int gz_jpeg_histograms(gz_ctx* c, const int* q, uint32_t* counts) {
   }
   HIPCHK(c, hipMemsetAsync(c->d_hist, 0, sizeof(unsigned) * 1536, c->stream));
   static const char* hg = getenv("GZ_HIST_GRID");
-  const int grid = std::min(gz_div_up(c->nb, kHistWaves), hg ? atoi(hg) : 1024);
+  const FrameGeom geom = frame_geom(c, ncomp);
+  const int grid = std::min(gz_div_up(geom.mcu_cols * geom.mcu_rows, kHistWaves), hg ? atoi(hg) : 1024);
   GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
-            (const int*)c->d_jq, c->nb, c->d_hist);
+            (const int*)c->d_jq, geom, c->d_hist);
   KCHK(c);
   void* res = nullptr;
   TRY(result_buffer(c, sizeof(unsigned) * 1536, &res));
@@ -1686,6 +1861,7 @@ int gz_jpeg_histograms(gz_ctx* c, const int* q, uint32_t* counts) {
 
 int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* code,
                  uint64_t* scan_bytes) {
+  DeviceScope ds_(c);
   if (!c || !depth || !code || !scan_bytes || (ncomp != 1 && ncomp != 3)) return GZ_E_ARG;
   if (!c->have_cand || !c->have_jq) { c->err = "gz_jpeg_histograms must precede gz_jpeg_scan"; return GZ_E_STATE; }
   // Upper bound of a scan: per coefficient a code of at most 16 bits and at most 16 extra
@@ -1693,6 +1869,8 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   // once, so that no host round trip is needed between counting the bits and writing them.
   const size_t cap_words = (size_t)c->nb * 3 * (64 + 1) + 8;
   if (cap_words > c->words_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->entropy_stream));   // the pool hands memory on without waiting
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)pool_free(c->d_words);
     c->d_words = nullptr;
     c->words_cap = 0;
@@ -1713,19 +1891,21 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
     TRY(stage_sent(c, &c->stage_entropy, es));
   }
   JpegCodes codes{c->d_code_depth, c->d_code_bits};
-  GZ_LAUNCH(k_jpeg_block_bits, dim3(c->nb), dim3(64), es, (const int16_t*)c->d_cand,
-            (const int*)c->d_jq, c->nb, ncomp, codes, c->d_mcu_bits);
+  const FrameGeom geom = frame_geom(c, ncomp);
+  const int nmcu = geom.mcu_cols * geom.mcu_rows;
+  GZ_LAUNCH(k_jpeg_block_bits, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
+            (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
   KCHK(c);
   GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), es, (const unsigned*)c->d_mcu_bits,
-            c->nb, c->d_mcu_off);
+            nmcu, c->d_mcu_off);
   KCHK(c);
-  const unsigned long long* d_total = c->d_mcu_off + c->nb;
+  const unsigned long long* d_total = c->d_mcu_off + nmcu;
   const int cgrid = (int)std::min<size_t>(512, (cap_words + 255) / 256);
   GZ_LAUNCH(k_jpeg_clear_words, dim3(cgrid), dim3(256), es, c->d_words, d_total,
             (unsigned long long)c->words_cap, c->d_ff_count);
   KCHK(c);
-  GZ_LAUNCH(k_jpeg_emit, dim3(c->nb), dim3(64), es, (const int16_t*)c->d_cand,
-            (const int*)c->d_jq, c->nb, ncomp, codes, (const unsigned long long*)c->d_mcu_off,
+  GZ_LAUNCH(k_jpeg_emit, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
+            (const int*)c->d_jq, geom, codes, (const unsigned long long*)c->d_mcu_off,
             c->d_words, (unsigned long long)c->words_cap);
   KCHK(c);
   GZ_LAUNCH(k_jpeg_count_ff, dim3(cgrid), dim3(256), es, (const unsigned*)c->d_words, d_total,
@@ -1749,10 +1929,12 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
 }
 
 int gz_jpeg_scan_keep(gz_ctx* c) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   if (!c->have_scan) { c->err = "no scan to keep"; return GZ_E_STATE; }
   const size_t need_words = (size_t)((c->scan_bits + 7) / 8 / 4 + 4);
   if (need_words > c->words_kept_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the pool hands memory on without waiting
     (void)pool_free(c->d_words_kept);
     c->d_words_kept = nullptr;
     c->words_kept_cap = need_words + need_words / 4 + 1024;
@@ -1767,6 +1949,7 @@ int gz_jpeg_scan_keep(gz_ctx* c) {
 }
 
 int gz_jpeg_scan_bytes(gz_ctx* c, int kept, uint8_t* out, size_t cap, size_t* n) {
+  DeviceScope ds_(c);
   if (!c || !out || !n) return GZ_E_ARG;
   if (kept ? !c->have_kept : !c->have_scan) { c->err = "no scan"; return GZ_E_STATE; }
   const unsigned long long bits = kept ? c->kept_bits : c->scan_bits;
@@ -1791,6 +1974,7 @@ int gz_jpeg_scan_bytes(gz_ctx* c, int kept, uint8_t* out, size_t cap, size_t* n)
 
 // ------------------------------------------------------------------- stage probes -----
 int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, float* out) {
+  DeviceScope ds_(c);
   if (!c || !in || !out) return GZ_E_ARG;
   BlurCfg cfg;
   TRY(setup_blur_cfg(c, &cfg, sigma, border_ratio));
@@ -1826,6 +2010,7 @@ int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, f
 }
 
 int gz_probe_opsin(gz_ctx* c, const float* rgb3, float* xyb3) {
+  DeviceScope ds_(c);
   if (!c || !rgb3 || !xyb3) return GZ_E_ARG;
   TRY(upload_planes(c, rgb3, c->lin, 3));
   TRY(stage_opsin(c));
@@ -1835,6 +2020,7 @@ int gz_probe_opsin(gz_ctx* c, const float* rgb3, float* xyb3) {
 }
 
 int gz_probe_separate_frequencies(gz_ctx* c, const float* xyb3, float* out10) {
+  DeviceScope ds_(c);
   if (!c || !xyb3 || !out10) return GZ_E_ARG;
   TRY(ensure_pip(c));
   TRY(upload_planes(c, xyb3, c->xyb, 3));
@@ -1851,6 +2037,7 @@ int gz_probe_separate_frequencies(gz_ctx* c, const float* xyb3, float* out10) {
 
 int gz_probe_diffmap(gz_ctx* c, const float* rgb0, const float* rgb1, float* diffmap,
                      float* score) {
+  DeviceScope ds_(c);
   if (!c || !rgb0 || !rgb1) return GZ_E_ARG;
   TRY(ensure_pip(c));
   TRY(upload_planes(c, rgb0, c->lin, 3));
@@ -1870,6 +2057,7 @@ int gz_probe_diffmap(gz_ctx* c, const float* rgb0, const float* rgb1, float* dif
 
 int gz_probe_mask(gz_ctx* c, const float* xyb0, const float* xyb1, float* mask3,
                   float* mask_dc3) {
+  DeviceScope ds_(c);
   if (!c || !xyb0 || !xyb1 || !mask3) return GZ_E_ARG;
   TRY(ensure_pip(c));
   // Mask(xyb0, xyb1) reads planes 0 and 1 of each image unchanged (butteraugli.cc:1765,1777)
@@ -2080,10 +2268,29 @@ int gz_rank_zeroing_candidates(const int16_t* coeffs, const int16_t* orig, int n
 
 int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* offsets,
                             uint8_t* idx, float* err, int cap) {
-  if (!c || !offsets || !idx || lookahead < 1 || cap < 0) return GZ_E_ARG;
+  return gz_block_zeroing_orders_masked(c, 7, lookahead, new_model, offsets, idx, err, cap);
+}
+
+int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int new_model,
+                                   int32_t* offsets, uint8_t* idx, float* err, int cap) {
+  DeviceScope ds_(c);
+  if (!c || !offsets || !idx || lookahead < 1 || cap < 0 || comp_mask < 1 || comp_mask > 7) return GZ_E_ARG;
   if (!c->have_cand || !c->have_orig) { c->err = "needs original and candidate coefficients"; return GZ_E_STATE; }
+  // SelectFrequencyMasking's grid (processor.cc:546-552) is that of the mask's last component
+  int mode = 0;
+  if (c->cfac == 2) {
+    if (comp_mask == 1) mode = 1;
+    else if (comp_mask == 6) mode = 2;
+    else { c->err = "a 4:2:0 frame is searched with component mask 1 or 6"; return GZ_E_ARG; }
+  }
   TRY(ensure_block_mask(c));
-  const int nb = c->nb;
+  const int nb = c->nb;   // capacity of the per-block arrays: the luma grid
+  const int gn = mode == 2 ? c->nbc : c->nb;
+  c->sg_w = mode == 2 ? c->cbw : c->bw;
+  c->sg_h = mode == 2 ? c->cbh : c->bh;
+  c->sg_n = gn;
+  c->sg_factor = mode == 2 ? 2 : 1;
+  c->sg_mask = comp_mask;
   if (!c->d_rank_cnt) {
     HIPCHK(c, pool_malloc((void**)&c->d_rank_cnt, sizeof(int32_t) * nb));
     HIPCHK(c, pool_malloc((void**)&c->d_rank_idx, (size_t)nb * 192));
@@ -2098,15 +2305,23 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
     RankArgs r;
     r.coeffs = c->d_cand; r.orig = c->d_orig;
     r.csf = c->d_rank_tables; r.bias = c->d_rank_tables + 192;
-    r.nb = nb; r.new_model = new_model;
+    r.nb = gn; r.new_model = new_model; r.comp_mask = comp_mask;
+    for (int i = 0; i < 3; ++i) r.coff[i] = c->coff[i];
     r.cnt = c->d_rank_cnt; r.idx = c->d_rank_idx;
-    GZ_LAUNCH(k_rank_candidates, dim3(gz_div_up(nb, kRankLanes)), dim3(kRankLanes), c->stream, r);
+    GZ_LAUNCH(k_rank_candidates, dim3(gz_div_up(gn, kRankLanes)), dim3(kRankLanes), c->stream, r);
     KCHK(c);
   }
   SearchArgs a;
   a.coeffs = c->d_cand; a.rank_cnt = c->d_rank_cnt; a.rank_idx = c->d_rank_idx;
   a.rgb = c->d_rgb; a.srgb_lut = c->d_srgb_lut; a.block_mask = c->d_block_mask;
   a.w = c->w; a.h = c->h; a.bw = c->bw; a.nb = nb;
+  for (int i = 0; i < 3; ++i) a.coff[i] = c->coff[i];
+  a.cbw = c->cbw;
+  a.samples = nullptr;
+  if (mode != 0) {   // the chroma samples of the image as it stands
+    TRY(stage_chroma_samples(c, c->d_cand));
+    a.samples = c->d_csamp;
+  }
   a.lookahead = lookahead;
   a.limit = c->target;
   {
@@ -2121,30 +2336,124 @@ int gz_block_zeroing_orders(gz_ctx* c, int lookahead, int new_model, int32_t* of
     a.scale_hi[0] = hi[0]; a.scale_hi[1] = hi[1];
   }
   a.out_cnt = c->d_out_cnt; a.out_idx = c->d_out_idx; a.out_err = c->d_out_err;
-  GZ_LAUNCH(k_block_search, dim3(nb), dim3(64), c->stream, a);
+  if (mode == 0) GZ_LAUNCH(k_block_search<0>, dim3(gn), dim3(64), c->stream, a);
+  else if (mode == 1) GZ_LAUNCH(k_block_search<1>, dim3(gn), dim3(64), c->stream, a);
+  else GZ_LAUNCH(k_block_search<2>, dim3(gn), dim3(256), c->stream, a);
   KCHK(c);
   c->have_search = true;
   c->search_total = 0;   // set below, once the counts are on the host
-  std::vector<int32_t> cnt(nb);
-  std::vector<uint8_t> widx((size_t)nb * 192);
-  std::vector<float> werr(err ? (size_t)nb * 192 : 0);   // the errors stay on the device for gz_order_build
-  HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_out_cnt, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(widx.data(), c->d_out_idx, (size_t)nb * 192, hipMemcpyDeviceToHost, c->stream));
+  std::vector<int32_t> cnt(gn);
+  std::vector<uint8_t> widx((size_t)gn * 192);
+  std::vector<float> werr(err ? (size_t)gn * 192 : 0);   // the errors stay on the device for gz_order_build
+  HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_out_cnt, sizeof(int32_t) * gn, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(widx.data(), c->d_out_idx, (size_t)gn * 192, hipMemcpyDeviceToHost, c->stream));
   if (err)
-    HIPCHK(c, hipMemcpyAsync(werr.data(), c->d_out_err, sizeof(float) * nb * 192, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(werr.data(), c->d_out_err, sizeof(float) * gn * 192, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   long total = 0;
-  for (int b = 0; b < nb; ++b) total += cnt[b];
+  for (int b = 0; b < gn; ++b) total += cnt[b];
   c->search_total = (size_t)total;
-  if (total > cap) { c->err = "candidate capacity too small, need " + std::to_string(total); offsets[nb] = (int32_t)total; return GZ_E_ARG; }
+  if (total > cap) { c->err = "candidate capacity too small, need " + std::to_string(total); offsets[gn] = (int32_t)total; return GZ_E_ARG; }
   int t = 0;
-  for (int b = 0; b < nb; ++b) {
+  for (int b = 0; b < gn; ++b) {
     offsets[b] = t;
     memcpy(idx + t, widx.data() + (size_t)b * 192, cnt[b]);
     if (err) memcpy(err + t, werr.data() + (size_t)b * 192, sizeof(float) * cnt[b]);
     t += cnt[b];
   }
-  offsets[nb] = t;
+  offsets[gn] = t;
+  return GZ_OK;
+}
+
+// OutputImage::Downsample (output_image.cc:304-340), cfg defaults of Processor::DownsampleImage
+// (processor.cc:97-104) without the silver-screen option, on the ORIGINAL coefficients of a
+// 4:4:4 frame: ToFloatPixels of the three components, PreProcessChannel on V then on U
+// (preprocess_downsample.cc:157-279), SetDownsampledCoefficients of U and V by 2 x 2.
+static void normal_taps(double sigma, float k[5], float* mul) {   // Normal(), :85-88; Sharpen / Blur :92-100,138-146
+  double kernel[5], sum = 0;
+  for (size_t i = 0; i < 5; ++i) {
+    const double x = 1.0 * i - 5 / 2;
+    static const double kInvSqrt2Pi = 0.3989422804014327;
+    kernel[i] = exp(-x * x / (2 * sigma * sigma)) * kInvSqrt2Pi / sigma;
+  }
+  for (size_t i = 0; i < 5; ++i) sum += kernel[i];
+  for (size_t i = 0; i < 5; ++i) k[i] = static_cast<float>(kernel[i]);
+  *mul = static_cast<float>(1.0 / sum);
+}
+
+int gz_downsample(gz_ctx* c, int16_t* coeffs_out) {
+  DeviceScope ds_(c);
+  if (!c) return GZ_E_ARG;
+  if (!c->have_orig || c->cfac != 1) { c->err = "gz_downsample needs the original coefficients of a 4:4:4 frame"; return GZ_E_STATE; }
+  const int w = c->w, h = c->h;
+  const size_t n = (size_t)w * h;
+  // scratch: planes of the candidate's evaluation (nothing of it is in flight here)
+  float* yuv[3] = {c->xyb[0], c->xyb[1], c->xyb[2]};
+  float* tmp_s = c->tmp[0];
+  float* tmp_b = c->tmp[1];
+  // byte planes: four per float plane
+  uint8_t* bp0 = reinterpret_cast<uint8_t*>(c->tmp[2]);
+  uint8_t* bp1 = reinterpret_cast<uint8_t*>(c->lf_raw[0]);
+  uint8_t* dark_a = bp0; uint8_t* dark_b = bp0 + n; uint8_t* red_a = bp0 + 2 * n; uint8_t* red_b = bp0 + 3 * n;
+  uint8_t* sharpen = bp1; uint8_t* blurm = bp1 + n; uint8_t* blur_t = bp1 + 2 * n;
+  for (int i = 0; i < 3; ++i) {
+    GZ_LAUNCH(k_to_float_pixels, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream,
+              (const int16_t*)(c->d_orig + (size_t)c->coff[i] * 64), w, h, c->bw, c->nb, yuv[i]);
+    KCHK(c);
+  }
+  PPTaps taps;
+  normal_taps((double)1.3f, taps.ks, &taps.mul_s);   // Sharpen(sigma = 1.3f)
+  normal_taps(1.3, taps.kb, &taps.mul_b);            // Blur: kSigma = 1.3
+  const dim3 g1(gz_div_up((int)std::min<size_t>(n, 0x7fffffff), 256)), g2(gz_div_up(w, 256), h);
+  const int channels[2] = {2, 1};   // :326-329
+  for (int pass = 0; pass < 2; ++pass) {
+    const int channel = channels[pass];
+    GZ_LAUNCH(k_pp_normalize, g1, dim3(256), c->stream, yuv[0], yuv[1], yuv[2], n);
+    KCHK(c);
+    GZ_LAUNCH(k_pp_maps, g1, dim3(256), c->stream, (const float*)yuv[0], (const float*)yuv[1],
+              (const float*)yuv[2], n, channel, dark_a, red_a);
+    KCHK(c);
+    // Erode x3 (darkmap, :194-196): a -> b -> a -> b; Dilate x3 (redmap, :217-219) likewise
+    for (int i = 0; i < 3; ++i) {
+      GZ_LAUNCH(k_pp_morph, g2, dim3(256), c->stream, (const uint8_t*)(i & 1 ? dark_b : dark_a),
+                i & 1 ? dark_a : dark_b, w, h, 1);
+      KCHK(c);
+      GZ_LAUNCH(k_pp_morph, g2, dim3(256), c->stream, (const uint8_t*)(i & 1 ? red_b : red_a),
+                i & 1 ? red_a : red_b, w, h, 0);
+      KCHK(c);
+    }
+    const double threshold = (channel == 2 ? 0.02 : 1.0) * 127.5;
+    GZ_LAUNCH(k_pp_edge_maps, g2, dim3(256), c->stream, (const float*)yuv[channel], (const float*)yuv[1],
+              (const float*)yuv[2], (const uint8_t*)dark_b, (const uint8_t*)red_b, w, h,
+              threshold, sharpen, blurm);
+    KCHK(c);
+    // Erode x2 (blurmap, :254-255)
+    GZ_LAUNCH(k_pp_morph, g2, dim3(256), c->stream, (const uint8_t*)blurm, blur_t, w, h, 1);
+    KCHK(c);
+    GZ_LAUNCH(k_pp_morph, g2, dim3(256), c->stream, (const uint8_t*)blur_t, blurm, w, h, 1);
+    KCHK(c);
+    GZ_LAUNCH(k_pp_conv_h, g2, dim3(256), c->stream, (const float*)yuv[channel], w, h, taps, tmp_s, tmp_b);
+    KCHK(c);
+    GZ_LAUNCH(k_pp_conv_v_select, g2, dim3(256), c->stream, yuv[channel], (const float*)tmp_s,
+              (const float*)tmp_b, (const uint8_t*)sharpen, (const uint8_t*)blurm, w, h, taps, 0.5f, 1, 1);
+    KCHK(c);
+    GZ_LAUNCH(k_pp_denormalize, g1, dim3(256), c->stream, yuv[0], yuv[1], yuv[2], n);
+    KCHK(c);
+  }
+  // the two chroma components, 2 x 2 subsampled, replace the 4:4:4 ones (luma is kept as it is)
+  const int cbw = (w + 15) / 16, cbh = (h + 15) / 16, nbc = cbw * cbh;
+  for (int i = 1; i < 3; ++i) {
+    int16_t* dst = c->d_orig + ((size_t)c->nb + (size_t)(i - 1) * nbc) * 64;
+    GZ_LAUNCH(k_set_downsampled_coeffs, dim3(gz_div_up(nbc, kBlocksPerWG)), dim3(256), c->stream,
+              (const float*)yuv[i], w, h, 2, 2, cbw, nbc, dst);
+    KCHK(c);
+  }
+  set_frame(c, 2);
+  c->have_cand = false;
+  c->have_distmap = false;
+  if (coeffs_out)
+    HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_orig, (size_t)c->nblk * 128, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return GZ_OK;
 }
 

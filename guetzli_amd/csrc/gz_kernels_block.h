@@ -124,15 +124,130 @@ __global__ __launch_bounds__(256) void k_idct_blocks(const int16_t* __restrict__
   if (live) out[(size_t)blk * 64 + lane] = (uint8_t)clamp255((acc + (257 << 17)) >> 18);
 }
 
+// ---------------------------------------------------------------- 4:2:0 reconstruct --
+// A 2x2-subsampled component's pixel cache (OutputImageComponent::UpdatePixelsForBlock,
+// output_image.cc:146-203) is a pure function of its coefficients: every update recovers the
+// neighbouring subsampled samples from the upsampled pixels by inverting the "fancy
+// upsampler", and because every sample is idct << 4 -- a multiple of 16 -- the 9-3-3-1
+// sums are multiples of 16, the >> 4 is exact and so is the recovery.  Hence
+//   pixels_[y][x] = (9 S(kx,ky) + 3 S(kx,ky+dy) + 3 S(kx+dx,ky) + S(kx+dx,ky+dy)) >> 4,
+//   kx = x/2, dx = x odd ? +1 : -1 (likewise y), S = idct << 4 of the block the sample lies
+//   in, sample coordinates clamped to [0, (w-1)/2] x [0, (h-1)/2] (the replication rules of
+//   :162-169),
+// whatever sequence of SetCoeffBlock calls produced the image (checked against the reference
+// with random update orders, tests/test_oracle_vs_ref.py).  ToPixels (:82) then rounds:
+// (p + 8 - (x & 1)) >> 4.
+//
+// k_chroma_samples: integer IDCT of every block of the two subsampled components into two
+// u8 sample planes [cbh*8][cbw*8] (Cb, then Cr, plane stride cbw*8*cbh*8).
+__global__ __launch_bounds__(256) void k_chroma_samples(const int16_t* __restrict__ cb_blocks,
+                                                        const int16_t* __restrict__ cr_blocks,
+                                                        int cbw, int nbc,
+                                                        uint8_t* __restrict__ samples) {
+  __shared__ int s_in[2][kBlocksPerWG][64];
+  __shared__ int s_col[2][kBlocksPerWG][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * kBlocksPerWG + wave;
+  const bool live = blk < nbc;
+  const int iy = lane >> 3, ix = lane & 7;
+  s_in[0][wave][lane] = live ? (int)cb_blocks[(size_t)blk * 64 + lane] : 0;
+  s_in[1][wave][lane] = live ? (int)cr_blocks[(size_t)blk * 64 + lane] : 0;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    int acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[c][wave][8 * u + ix];
+    s_col[c][wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  }
+  __syncthreads();
+  if (!live) return;
+  const int sw = cbw * 8;
+  const size_t pl = (size_t)sw * (size_t)(nbc / cbw) * 8;
+  const size_t o = (size_t)(8 * (blk / cbw) + iy) * sw + 8 * (blk % cbw) + ix;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    int acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[c][wave][8 * iy + u];
+    samples[c * pl + o] = (uint8_t)clamp255((acc + (257 << 17)) >> 18);
+  }
+}
+
+// Upsampled, rounded pixel (ToPixels) of a 2x2-subsampled component at (x, y) from its sample
+// plane (row pitch sw); mxs, mys = (w-1)/2, (h-1)/2.
+GZ_DEVFN int chroma420_pixel(const uint8_t* __restrict__ sp, int sw, int mxs, int mys, int x, int y) {
+  const int kx = x >> 1, ky = y >> 1;
+  int kx2 = (x & 1) ? kx + 1 : kx - 1, ky2 = (y & 1) ? ky + 1 : ky - 1;
+  kx2 = kx2 < 0 ? 0 : (kx2 > mxs ? mxs : kx2);
+  ky2 = ky2 < 0 ? 0 : (ky2 > mys ? mys : ky2);
+  const int a = (int)sp[(size_t)ky * sw + kx] << 4, b = (int)sp[(size_t)ky2 * sw + kx] << 4;
+  const int c = (int)sp[(size_t)ky * sw + kx2] << 4, d = (int)sp[(size_t)ky2 * sw + kx2] << 4;
+  const int p = (a * 9 + b * 3 + c * 3 + d) >> 4;
+  return (p + 8 - (x & 1)) >> 4;
+}
+
+// k_reconstruct for a 4:2:0 frame: luma IDCT per 8x8 block as above, chroma from the sample
+// planes of k_chroma_samples.
+__global__ __launch_bounds__(256) void k_reconstruct420(
+    const int16_t* __restrict__ ycoeffs, const uint8_t* __restrict__ samples, int w, int h, int bw,
+    int nb, int cbw, int cbh, int pitch, size_t pstride, const float* __restrict__ srgb_lut,
+    float* __restrict__ lin, uint8_t* __restrict__ srgb, unsigned* __restrict__ clear_word) {
+  if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
+  __shared__ int s_in[kBlocksPerWG][64];
+  __shared__ int s_col[kBlocksPerWG][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * kBlocksPerWG + wave;
+  const bool live = blk < nb;
+  const int iy = lane >> 3, ix = lane & 7;
+  s_in[wave][lane] = live ? (int)ycoeffs[(size_t)blk * 64 + lane] : 0;
+  __syncthreads();
+  int acc = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[wave][8 * u + ix];
+  s_col[wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  __syncthreads();
+  acc = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[wave][8 * iy + u];
+  const int yy = clamp255((acc + (257 << 17)) >> 18);
+  if (!live) return;
+  const int x = 8 * (blk % bw) + ix, y = 8 * (blk / bw) + iy;
+  if (x >= w || y >= h) return;
+  const int sw = cbw * 8;
+  const size_t pl = (size_t)sw * cbh * 8;
+  const int mxs = (w - 1) >> 1, mys = (h - 1) >> 1;
+  const int cb = chroma420_pixel(samples, sw, mxs, mys, x, y) - 128;
+  const int cr = chroma420_pixel(samples + pl, sw, mxs, mys, x, y) - 128;
+  const int half = 1 << 15;
+  const int r = clamp255(yy + ((91881 * cr + half) >> 16));
+  const int g = clamp255(yy + ((-46802 * cr + (-22554 * cb + half)) >> 16));
+  const int b = clamp255(yy + ((116130 * cb + half) >> 16));
+  if (lin) {
+    const size_t o = (size_t)y * pitch + x;
+    lin[o] = srgb_lut[r];
+    lin[pstride + o] = srgb_lut[g];
+    lin[2 * pstride + o] = srgb_lut[b];
+  }
+  if (srgb) {
+    uint8_t* p = srgb + ((size_t)y * w + x) * 3;
+    p[0] = (uint8_t)r;
+    p[1] = (uint8_t)g;
+    p[2] = (uint8_t)b;
+  }
+}
+
 // ------------------------------------------------------------------------ quantize --
-// quantize.h:24-29 applied to every coefficient of the original; q = int[3][64].
+// quantize.h:24-29 applied to every coefficient of the original; q = int[3][64].  b1, b2 =
+// first block of components 1 and 2 in the arrays, nblk = blocks of all three components.
 __global__ __launch_bounds__(256) void k_quantize(const int16_t* __restrict__ orig,
-                                                  int16_t* __restrict__ cand, int nb,
-                                                  const int* __restrict__ q) {
-  const size_t total = (size_t)3 * nb * 64;
+                                                  int16_t* __restrict__ cand, int b1, int b2,
+                                                  int nblk, const int* __restrict__ q) {
+  const size_t total = (size_t)nblk * 64;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i / ((size_t)nb * 64));
+    const int blk = (int)(i >> 6);
+    const int c = blk >= b2 ? 2 : (blk >= b1 ? 1 : 0);
     const int quant = q[c * 64 + (int)(i & 63)];
     const int raw = orig[i];
     const int r = raw % quant;

@@ -1,7 +1,8 @@
 // Baseline-sequential JPEG entropy coding of the candidate image on the device: what
 // BuildDCHistograms / BuildACHistograms (jpeg_data_writer.cc:241-275) count and what
 // EncodeScan / EncodeDCTBlockSequential (:446-536) emit through the BitWriter
-// (jpeg_bit_writer.h:31-108), for a 4:4:4 frame (one block per component per MCU).
+// (jpeg_bit_writer.h:31-108), for 4:4:4 frames (one block per component per MCU) and 4:2:0
+// frames (2 x 2 luma blocks + one block of each chroma component per MCU, padded).
 //
 // The search evaluates ~150 candidates per image and needs the EXACT size of each one's
 // JPEG (it feeds ScoreJPEG); the bytes themselves are only wanted for the winner.  The
@@ -10,7 +11,7 @@
 //   k_jpeg_block_bits   bits per MCU under those codes       -> exclusive scan = bit offsets
 //   k_jpeg_emit         every MCU writes its bits at its offset (MSB-first)
 //   k_jpeg_count_ff     bytes equal to 0xFF (each costs one stuffed 0x00)
-// One 64-lane wavefront per block position; lane = zig-zag position; runs of zeros come
+// One 64-lane wavefront per MCU; lane = zig-zag position; runs of zeros come
 // from a ballot over "coefficient != 0", bit positions inside the MCU from a wavefront
 // prefix sum.  Integer work only; byte-exact by contract.
 #pragma once
@@ -27,7 +28,40 @@ GZ_CONST unsigned char kNaturalOrderDev[64] = {   // kJPEGNaturalOrder, jpeg_dat
 
 GZ_DEVFN int bit_length(unsigned v) { return v == 0 ? 0 : 32 - __clz((int)v); }
 
-// What lane k contributes for component c of block b.
+// Geometry of the frame the coefficient arrays describe: per component a grid of real blocks
+// (bw x bh, first block coff) and the number of blocks it has per MCU along each axis (samp;
+// 4:4:4: 1,1,1 -- 4:2:0: 2,1,1).  A component's blocks in the JPEG cover whole MCUs
+// (mcu_cols*samp x mcu_rows*samp); the blocks beyond the real grid are the padding
+// OutputImage::SaveToJpegData writes (output_image.cc:386-404): all AC zero, DC = the DC of
+// the block before it in raster order of the padded grid.
+struct FrameGeom {
+  int bw[3], bh[3], coff[3], samp[3];
+  int mcu_cols, mcu_rows, ncomp;
+};
+
+// Blocks ("units") of one MCU in scan order: component, sub-block position.
+GZ_DEVFN int geom_units_per_mcu(const FrameGeom& g) {
+  int n = 0;
+  for (int c = 0; c < g.ncomp; ++c) n += g.samp[c] * g.samp[c];
+  return n;
+}
+GZ_DEVFN void geom_unit(const FrameGeom& g, int u, int* c, int* ix, int* iy) {
+  int cc = 0;
+  while (u >= g.samp[cc] * g.samp[cc]) { u -= g.samp[cc] * g.samp[cc]; ++cc; }
+  *c = cc;
+  *ix = u % g.samp[cc];
+  *iy = u / g.samp[cc];
+}
+
+// Quantised DC of block (bx, by) of component c in the padded grid.
+GZ_DEVFN int geom_dc(const int16_t* __restrict__ coeffs, const int* __restrict__ q,
+                     const FrameGeom& g, int c, int bx, int by) {
+  int rx = bx < g.bw[c] ? bx : g.bw[c] - 1, ry = by;
+  if (by >= g.bh[c]) { rx = g.bw[c] - 1; ry = g.bh[c] - 1; }
+  return (int)coeffs[((size_t)g.coff[c] + (size_t)ry * g.bw[c] + rx) * 64] / q[c * 64];
+}
+
+// What lane k contributes for one block.
 struct LaneSyms {
   int zrl;      // number of 0xF0 symbols in front (run / 16)
   int sym;      // Huffman symbol, -1: nothing (zero AC coefficient)
@@ -37,25 +71,13 @@ struct LaneSyms {
   int is_dc;
 };
 
-// coeffs: dequantised [3][nb][64]; q: int[3][64].  quantised value = coeff / q (C++ `/`,
-// FrameFromImage == OutputImage::SaveToJpegData, output_image.cc:348-409).
-GZ_DEVFN LaneSyms lane_symbols(const int16_t* __restrict__ coeffs, const int* __restrict__ q,
-                               int nb, int c, int b, int lane) {
-  const int nat = kNaturalOrderDev[lane];
-  const int16_t* blk = coeffs + ((size_t)c * nb + b) * 64;
-  const int v = (int)blk[nat] / q[c * 64 + nat];
+// The AC symbols of one block (lanes 1..63; lane 0 gets an empty entry marked is_dc) from
+// this lane's quantised value v (0 everywhere for a padding block).
+GZ_DEVFN LaneSyms lane_ac_symbols(int v, int lane) {
   const unsigned long long mask = __ballot(lane >= 1 && v != 0);
   LaneSyms s;
   s.zrl = 0; s.sym = -1; s.nbits = 0; s.extra = 0; s.eob = 0; s.is_dc = lane == 0;
-  if (lane == 0) {
-    const int prev = b > 0 ? (int)blk[-64] / q[c * 64] : 0;
-    const int diff = (int)(short)(v - prev);   // int16 arithmetic of the writer (:448-455)
-    const int mag = diff < 0 ? -diff : diff;
-    const int low = diff < 0 ? diff - 1 : diff;
-    s.nbits = bit_length((unsigned)mag);
-    s.sym = s.nbits;
-    s.extra = (unsigned)low & ((1u << s.nbits) - 1u);
-  } else if (v != 0) {
+  if (lane >= 1 && v != 0) {
     const unsigned long long below = mask & ((1ull << lane) - 1ull);
     const int prev = below ? 63 - __clzll((long long)below) : 0;
     const int run = lane - prev - 1;
@@ -74,6 +96,40 @@ GZ_DEVFN LaneSyms lane_symbols(const int16_t* __restrict__ coeffs, const int* __
   return s;
 }
 
+GZ_DEVFN void lane_set_dc(LaneSyms* s, int dc, int prev) {
+  const int diff = (int)(short)(dc - prev);   // int16 arithmetic of the writer (:448-455)
+  const int mag = diff < 0 ? -diff : diff;
+  const int low = diff < 0 ? diff - 1 : diff;
+  s->nbits = bit_length((unsigned)mag);
+  s->sym = s->nbits;
+  s->extra = (unsigned)low & ((1u << s->nbits) - 1u);
+}
+
+// coeffs: dequantised blocks of the frame; q: int[3][64].  quantised value = coeff / q (C++
+// `/`, OutputImage::SaveToJpegData, output_image.cc:395-400).  Unit (c, ix, iy) of MCU
+// (mx, my); the DC difference is taken against the component's previous block in scan order
+// (EncodeScan, jpeg_data_writer.cc:499-536; BuildDCHistograms, :241-265).
+GZ_DEVFN LaneSyms lane_symbols(const int16_t* __restrict__ coeffs, const int* __restrict__ q,
+                               const FrameGeom& g, int c, int ix, int iy, int mx, int my, int lane) {
+  const int sp = g.samp[c];
+  const int bx = mx * sp + ix, by = my * sp + iy;
+  const bool real = bx < g.bw[c] && by < g.bh[c];
+  const int nat = kNaturalOrderDev[lane];
+  int v = 0;
+  if (real) v = (int)coeffs[((size_t)g.coff[c] + (size_t)by * g.bw[c] + bx) * 64 + nat] / q[c * 64 + nat];
+  LaneSyms s = lane_ac_symbols(v, lane);
+  if (lane == 0) {
+    const int dc = real ? v : geom_dc(coeffs, q, g, c, bx, by);
+    int prev = 0;
+    if (ix > 0) prev = geom_dc(coeffs, q, g, c, bx - 1, by);
+    else if (iy > 0) prev = geom_dc(coeffs, q, g, c, mx * sp + sp - 1, by - 1);
+    else if (mx > 0) prev = geom_dc(coeffs, q, g, c, mx * sp - 1, my * sp + sp - 1);
+    else if (my > 0) prev = geom_dc(coeffs, q, g, c, g.mcu_cols * sp - 1, my * sp - 1);
+    lane_set_dc(&s, dc, prev);
+  }
+  return s;
+}
+
 // ------------------------------------------------------------------- histograms ------
 // hist: uint32 [2][3][256] (DC, AC) x component, raw occurrence counts; zeroed by the
 // caller.  Persistent workgroups of four wavefronts (each wavefront strides over block
@@ -83,27 +139,28 @@ GZ_DEVFN LaneSyms lane_symbols(const int16_t* __restrict__ coeffs, const int* __
 constexpr int kHistWaves = 4;
 
 __global__ __launch_bounds__(64 * kHistWaves) void k_jpeg_histograms(const int16_t* __restrict__ coeffs,
-                                                                     const int* __restrict__ q, int nb,
+                                                                     const int* __restrict__ q, FrameGeom g,
                                                                      unsigned* __restrict__ hist) {
   __shared__ unsigned s_hist[2 * 3 * 256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 2 * 3 * 256; i += 64 * kHistWaves) s_hist[i] = 0;
   __syncthreads();
+  const int nmcu = g.mcu_cols * g.mcu_rows, upm = geom_units_per_mcu(g);
   // the same trip count for the four wavefronts (a wavefront past the end repeats the last
-  // block and drops the result): the lane exchanges inside lane_symbols stay workgroup-uniform
-  for (int b0 = blockIdx.x * kHistWaves; b0 < nb; b0 += gridDim.x * kHistWaves) {
-    const bool live = b0 + wv < nb;
-    const int b = live ? b0 + wv : nb - 1;
-    LaneSyms s[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) s[c] = lane_symbols(coeffs, q, nb, c, b, lane);
-    if (!live) continue;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      unsigned* h = &s_hist[((s[c].is_dc ? 0 : 1) * 3 + c) * 256];
-      if (s[c].zrl) atomicAdd(&h[0xf0], (unsigned)s[c].zrl);
-      if (s[c].sym >= 0) atomicAdd(&h[s[c].sym], 1u);
-      if (s[c].eob) atomicAdd(&s_hist[(3 + c) * 256], 1u);
+  // MCU and drops the result): the lane exchanges inside lane_symbols stay workgroup-uniform
+  for (int m0 = blockIdx.x * kHistWaves; m0 < nmcu; m0 += gridDim.x * kHistWaves) {
+    const bool live = m0 + wv < nmcu;
+    const int m = live ? m0 + wv : nmcu - 1;
+    const int mx = m % g.mcu_cols, my = m / g.mcu_cols;
+    for (int u = 0; u < upm; ++u) {
+      int c, ix, iy;
+      geom_unit(g, u, &c, &ix, &iy);
+      const LaneSyms s = lane_symbols(coeffs, q, g, c, ix, iy, mx, my, lane);
+      if (!live) continue;
+      unsigned* h = &s_hist[((s.is_dc ? 0 : 1) * 3 + c) * 256];
+      if (s.zrl) atomicAdd(&h[0xf0], (unsigned)s.zrl);
+      if (s.sym >= 0) atomicAdd(&h[s.sym], 1u);
+      if (s.eob) atomicAdd(&s_hist[(3 + c) * 256], 1u);
     }
   }
   __syncthreads();
@@ -138,19 +195,22 @@ GZ_DEVFN int wave_inclusive_sum(int v, int lane) {
   return v;
 }
 
-// bits[b] = number of scan bits of MCU b (ncomp components).
+// bits[m] = number of scan bits of MCU m.
 __global__ __launch_bounds__(64) void k_jpeg_block_bits(const int16_t* __restrict__ coeffs,
-                                                        const int* __restrict__ q, int nb,
-                                                        int ncomp, JpegCodes codes,
+                                                        const int* __restrict__ q, FrameGeom g,
+                                                        JpegCodes codes,
                                                         unsigned* __restrict__ bits) {
-  const int lane = threadIdx.x, b = blockIdx.x;
+  const int lane = threadIdx.x, m = blockIdx.x;
+  const int mx = m % g.mcu_cols, my = m / g.mcu_cols, upm = geom_units_per_mcu(g);
   int total = 0;
-  for (int c = 0; c < ncomp; ++c) {
-    const LaneSyms s = lane_symbols(coeffs, q, nb, c, b, lane);
+  for (int u = 0; u < upm; ++u) {
+    int c, ix, iy;
+    geom_unit(g, u, &c, &ix, &iy);
+    const LaneSyms s = lane_symbols(coeffs, q, g, c, ix, iy, mx, my, lane);
     const int len = lane_bits(s, codes.depth + c * 256, codes.depth + (3 + c) * 256);
     total += __shfl(wave_inclusive_sum(len, lane), 63);
   }
-  if (lane == 0) bits[b] = (unsigned)total;
+  if (lane == 0) bits[m] = (unsigned)total;
 }
 
 // off[0..nb] = exclusive prefix sums of bits[0..nb) (64-bit).  One workgroup of 1024 walks
@@ -230,16 +290,18 @@ GZ_DEVFN void or_bits(unsigned* words, bool lds, unsigned long long pos, unsigne
 }
 
 __global__ __launch_bounds__(64) void k_jpeg_emit(const int16_t* __restrict__ coeffs,
-                                                  const int* __restrict__ q, int nb, int ncomp,
+                                                  const int* __restrict__ q, FrameGeom g,
                                                   JpegCodes codes,
                                                   const unsigned long long* __restrict__ off,
                                                   unsigned* __restrict__ words,
                                                   unsigned long long cap_words) {
   __shared__ unsigned stage[kStageWords + 2];
-  const int lane = threadIdx.x, b = blockIdx.x;
-  const unsigned long long start = off[b], end = off[b + 1];
+  const int lane = threadIdx.x, m = blockIdx.x;
+  const int nmcu = g.mcu_cols * g.mcu_rows, upm = geom_units_per_mcu(g);
+  const int mx = m % g.mcu_cols, my = m / g.mcu_cols;
+  const unsigned long long start = off[m], end = off[m + 1];
   // the last MCU also writes the 1-padding up to the byte boundary (BitWriter::JumpToByteBoundary)
-  const int pad = b == nb - 1 ? (int)((8 - (end & 7)) & 7) : 0;
+  const int pad = m == nmcu - 1 ? (int)((8 - (end & 7)) & 7) : 0;
   // `words` is sized for valid code lengths (<= 16 bits); with anything else the scan can be
   // longer, the host reports that afterwards, and nothing is written past the buffer here
   if (((end + pad + 63) >> 5) + 1 > cap_words) return;
@@ -252,8 +314,10 @@ __global__ __launch_bounds__(64) void k_jpeg_emit(const int16_t* __restrict__ co
   }
   unsigned* dst = staged ? stage : words;
   unsigned long long base = staged ? start - (word0 << 5) : start;
-  for (int c = 0; c < ncomp; ++c) {
-    const LaneSyms s = lane_symbols(coeffs, q, nb, c, b, lane);
+  for (int u = 0; u < upm; ++u) {
+    int c, ix, iy;
+    geom_unit(g, u, &c, &ix, &iy);
+    const LaneSyms s = lane_symbols(coeffs, q, g, c, ix, iy, mx, my, lane);
     const unsigned char* ddc = codes.depth + c * 256;
     const unsigned char* dac = codes.depth + (3 + c) * 256;
     const unsigned short* cdc = codes.code + c * 256;

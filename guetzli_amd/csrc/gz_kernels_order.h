@@ -200,13 +200,44 @@ __global__ __launch_bounds__(256) void k_apply_coeff_edits(const int* __restrict
 // ("down": the coefficient gets its quantised original value back), unless it is one of the
 // two "precious" coefficients.  A block's candidates are distinct coefficients, so its steps
 // are independent: one wave per block, one lane per step.
+// Blocks are positions of the search grid (gz_block_zeroing_orders): component c's block of
+// grid position b is block coff[c] + b of the coefficient arrays (4:4:4, any mask: the three
+// components share the grid; 4:2:0: the luma grid for mask 1, the chroma grid for mask 6).
+struct StepGeom {
+  int coff[3];
+  int comp_mask;
+};
+
+GZ_DEVFN int step_new_value(int direction, const short* __restrict__ ob, int k, int quant) {
+  int newval = 0;
+  if (direction < 0) {   // Quantize(), quantize.h:24-29
+    const int raw = ob[k];
+    const int r = raw % quant;
+    const int delta = 2 * r > quant ? quant - r : ((-2) * r > quant ? -quant - r : -r);
+    newval = (short)(raw + (int)(short)delta);
+  }
+  return newval;
+}
+GZ_DEVFN bool step_is_precious(const short* __restrict__ ob, int k) {   // processor.cc:722-733
+  if (k != 1 && k != 8) return false;
+  int sum_of_hf = 0;
+  for (int ii = 3; ii < 64; ++ii) {
+    if ((ii & 7) < 3 && ii < 3 * 8) continue;
+    const int v = ob[ii];
+    sum_of_hf += v < 0 ? -v : v;
+  }
+  const int limit = sum_of_hf < 60 ? 4 : 8;
+  const int v = ob[k];
+  return (v < 0 ? -v : v) >= limit;
+}
+
 __global__ __launch_bounds__(256) void k_apply_steps(const int* __restrict__ blocks,
                                                      const int* __restrict__ counts, int n,
                                                      int direction, const int* __restrict__ next_cand,
                                                      const unsigned char* __restrict__ cand_idx,
                                                      const short* __restrict__ orig,
                                                      short* __restrict__ cand,
-                                                     const int* __restrict__ q, int nb) {
+                                                     const int* __restrict__ q, StepGeom sg) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
   if (i >= n) return;
@@ -215,43 +246,27 @@ __global__ __launch_bounds__(256) void k_apply_steps(const int* __restrict__ blo
     const int p = direction > 0 ? nx + j : nx - 1 - j;
     const int idx = cand_idx[(size_t)b * 192 + p];
     const int c = idx >> 6, k = idx & 63;
-    const short* ob = orig + ((size_t)c * nb + b) * 64;
-    int newval = 0;
-    if (direction < 0) {   // Quantize(), quantize.h:24-29
-      const int quant = q[c * 64 + k], raw = ob[k];
-      const int r = raw % quant;
-      const int delta = 2 * r > quant ? quant - r : ((-2) * r > quant ? -quant - r : -r);
-      newval = (short)(raw + (int)(short)delta);
-    }
-    bool precious = false;
-    if (newval == 0 && (k == 1 || k == 8)) {   // processor.cc:722-733
-      int sum_of_hf = 0;
-      for (int ii = 3; ii < 64; ++ii) {
-        if ((ii & 7) < 3 && ii < 3 * 8) continue;
-        const int v = ob[ii];
-        sum_of_hf += v < 0 ? -v : v;
-      }
-      const int limit = sum_of_hf < 60 ? 4 : 8;
-      const int v = ob[k];
-      precious = (v < 0 ? -v : v) >= limit;
-    }
-    if (!precious) cand[((size_t)c * nb + b) * 64 + k] = (short)newval;
+    const short* ob = orig + ((size_t)sg.coff[c] + b) * 64;
+    const int newval = step_new_value(direction, ob, k, q[c * 64 + k]);
+    if (!(newval == 0 && step_is_precious(ob, k))) cand[((size_t)sg.coff[c] + b) * 64 + k] = (short)newval;
   }
 }
 
 // The same steps, one wavefront per block, together with what they do to the AC symbol
 // statistics (BuildACHistograms of the image before minus after, for the touched blocks only):
-// the three coefficient blocks go through LDS, their symbols are counted out of the histogram,
-// the steps are applied, the symbols are counted back in.  delta: [3][256] counters (wrapping
-// unsigned arithmetic = signed differences), zeroed by the caller; jq = the quantiser the
-// symbols are defined under (gz_jpeg_histograms' matrix).  After ~6000 steps an iteration the
-// host's size model needs the statistics again; recounting the 32 400 blocks of a 1080p
+// the block's coefficient blocks go through LDS, their symbols are counted out of the
+// histogram, the steps are applied, the symbols are counted back in.  delta: [3][256] counters
+// (wrapping unsigned arithmetic = signed differences), zeroed by the caller; jq = the quantiser
+// the symbols are defined under (gz_jpeg_histograms' matrix).  After ~6000 steps an iteration
+// the host's size model needs the statistics again; recounting the 32 400 blocks of a 1080p
 // image took 40-50 us, the touched blocks take a fraction of that.
-GZ_DEVFN void steps_count_symbols(const short* blk3, const int* __restrict__ jq, int lane, bool live,
-                                  unsigned sign, unsigned* s_delta) {
+GZ_DEVFN void steps_count_symbols(const short* blk3, const int* __restrict__ jq, int comp_mask,
+                                  int lane, bool live, unsigned sign, unsigned* s_delta) {
+  const int nat = kNaturalOrderDev[lane];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const LaneSyms s = lane_symbols(blk3, jq, 1, c, 0, lane);
+    if (!((comp_mask >> c) & 1)) continue;   // (uniform)
+    const LaneSyms s = lane_ac_symbols((int)blk3[c * 64 + nat] / jq[c * 64 + nat], lane);
     if (!live) continue;
     unsigned* h = &s_delta[c * 256];
     if (s.zrl) atomicAdd(&h[0xf0], sign * (unsigned)s.zrl);
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
                                                           const short* __restrict__ orig,
                                                           short* __restrict__ cand,
                                                           const int* __restrict__ q,
-                                                          const int* __restrict__ jq, int nb,
+                                                          const int* __restrict__ jq, StepGeom sg,
                                                           unsigned* __restrict__ delta) {
   __shared__ short s_blk[4][3 * 64];
   __shared__ unsigned s_delta[3 * 256];
@@ -277,45 +292,47 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
   const int b = blocks[live ? i : n - 1], cnt = live ? counts[i] : 0, nx = next_cand[b];
   for (int k = threadIdx.x; k < 3 * 256; k += 256) s_delta[k] = 0u;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) s_blk[wave][c * 64 + lane] = cand[((size_t)c * nb + b) * 64 + lane];
+  for (int c = 0; c < 3; ++c)
+    if ((sg.comp_mask >> c) & 1) s_blk[wave][c * 64 + lane] = cand[((size_t)sg.coff[c] + b) * 64 + lane];
   __syncthreads();
-  steps_count_symbols(s_blk[wave], jq, lane, live, 0xffffffffu, s_delta);
+  steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 0xffffffffu, s_delta);
   __syncthreads();
   for (int j = lane; j < cnt; j += 64) {
     const int p = direction > 0 ? nx + j : nx - 1 - j;
     const int idx = cand_idx[(size_t)b * 192 + p];
     const int c = idx >> 6, k = idx & 63;
-    const short* ob = orig + ((size_t)c * nb + b) * 64;
-    int newval = 0;
-    if (direction < 0) {   // Quantize(), quantize.h:24-29
-      const int quant = q[c * 64 + k], raw = ob[k];
-      const int r = raw % quant;
-      const int dlt = 2 * r > quant ? quant - r : ((-2) * r > quant ? -quant - r : -r);
-      newval = (short)(raw + (int)(short)dlt);
-    }
-    bool precious = false;
-    if (newval == 0 && (k == 1 || k == 8)) {   // processor.cc:722-733
-      int sum_of_hf = 0;
-      for (int ii = 3; ii < 64; ++ii) {
-        if ((ii & 7) < 3 && ii < 3 * 8) continue;
-        const int v = ob[ii];
-        sum_of_hf += v < 0 ? -v : v;
-      }
-      const int limit = sum_of_hf < 60 ? 4 : 8;
-      const int v = ob[k];
-      precious = (v < 0 ? -v : v) >= limit;
-    }
-    if (!precious) s_blk[wave][c * 64 + k] = (short)newval;
+    const short* ob = orig + ((size_t)sg.coff[c] + b) * 64;
+    const int newval = step_new_value(direction, ob, k, q[c * 64 + k]);
+    if (!(newval == 0 && step_is_precious(ob, k))) s_blk[wave][c * 64 + k] = (short)newval;
   }
   __syncthreads();
-  steps_count_symbols(s_blk[wave], jq, lane, live, 1u, s_delta);
+  steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 1u, s_delta);
   if (live) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) cand[((size_t)c * nb + b) * 64 + lane] = s_blk[wave][c * 64 + lane];
+    for (int c = 0; c < 3; ++c)
+      if ((sg.comp_mask >> c) & 1) cand[((size_t)sg.coff[c] + b) * 64 + lane] = s_blk[wave][c * 64 + lane];
   }
   __syncthreads();
   for (int k = threadIdx.x; k < 3 * 256; k += 256)
     if (s_delta[k]) atomicAdd(&delta[k], s_delta[k]);
+}
+
+// Per-block maxima of the distance map over fx x fy groups of 8x8 blocks: the first loop of
+// ComputeBlockErrorAdjustmentWeights (butteraugli_comparator.cc:505-520) for a subsampled
+// search grid, from the 8x8 maxima the final blur kernel leaves (max is exact in any order).
+__global__ __launch_bounds__(256) void k_block_max_group(const float* __restrict__ bmax, int bw, int bh,
+                                                         int gw, int gh, int f,
+                                                         float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= gw * gh) return;
+  const int gx = b % gw, gy = b / gw;
+  float m = 0.0f;
+  for (int y = gy * f; y < gy * f + f && y < bh; ++y)
+    for (int x = gx * f; x < gx * f + f && x < bw; ++x) {
+      const float v = bmax[y * bw + x];
+      m = v > m ? v : m;
+    }
+  out[b] = m;
 }
 
 // -------------------------------------------------------------- one introsort partition --

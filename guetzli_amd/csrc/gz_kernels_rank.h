@@ -181,11 +181,13 @@ GZ_DEVFN void rank_std_sort(const RankArr& a, int n) {
 }
 
 struct RankArgs {
-  const int16_t* coeffs;   // candidate, dequantised [3][nb][64]
-  const int16_t* orig;     // original coefficients [3][nb][64]
+  const int16_t* coeffs;   // candidate, dequantised (frame layout)
+  const int16_t* orig;     // original coefficients (same layout)
   const float* csf;        // kOrderCsf[192]  (order.inc)
   const float* bias;       // kOrderBias[192]
-  int nb;
+  int nb;                  // blocks of the search grid
+  int coff[3];             // component c's block of grid position b = coff[c] + b
+  int comp_mask;           // components that take part (processor.cc:382-383)
   int new_model;
   int32_t* cnt;            // [nb]
   uint8_t* idx;            // [nb][192]
@@ -220,8 +222,9 @@ __global__ __launch_bounds__(kRankLanes) void k_rank_candidates(RankArgs a) {
   RankArr arr{s_key, s_id, t};
   int n = 0;
   for (int ch = 0; ch < 3; ++ch) {
-    const int16_t* blk = a.coeffs + ((size_t)ch * a.nb + b) * 64;
-    const int16_t* ob = a.orig + ((size_t)ch * a.nb + b) * 64;
+    if (!((a.comp_mask >> ch) & 1)) continue;
+    const int16_t* blk = a.coeffs + ((size_t)a.coff[ch] + b) * 64;
+    const int16_t* ob = a.orig + ((size_t)a.coff[ch] + b) * 64;
     for (int k = 1; k < 64; ++k) {
       if (blk[k] == 0) continue;
       const int i = ch * 64 + k;

@@ -101,20 +101,23 @@ GZ_DEVFN void fft8(const Cpx* a, Cpx* F) {
 }
 
 struct SearchArgs {
-  const int16_t* coeffs;        // candidate image coefficients [3][nb][64]
-  const int32_t* rank_cnt;      // [nb]
-  const uint8_t* rank_idx;      // [nb][192]: ranked input_order (processor.cc:381-400), k_rank_candidates
+  const int16_t* coeffs;        // candidate image coefficients (frame layout, coff[] below)
+  const int32_t* rank_cnt;      // [grid blocks]
+  const uint8_t* rank_idx;      // [grid blocks][192]: ranked input_order (processor.cc:381-400), k_rank_candidates
   const uint8_t* rgb;           // original sRGB image
   const float* srgb_lut;        // 256 floats
-  const float* block_mask;      // [3][nb]: mask_xyz_[c](8*by, 8*bx)
-  int w, h, bw, nb;
+  const float* block_mask;      // [3][nb]: mask_xyz_[c](8*by, 8*bx) on the 8x8 (luma) grid
+  int w, h, bw, nb;             // luma grid
+  int coff[3];                  // first block of each component in coeffs
+  int cbw;                      // 4:2:0 frames: width of the chroma block grid
+  const uint8_t* samples;       // 4:2:0 frames: the chroma sample planes of k_chroma_samples
   int lookahead;                // Params::zeroing_greedy_lookahead
   float limit;                  // Comparator::BlockErrorLimit()
   Taps<2> taps;                 // sigma 1.2
   float scale_lo[2], scale_hi[2];   // border scales for an axis of length 8, border_ratio 0
-  int32_t* out_cnt;             // [nb]
-  uint8_t* out_idx;             // [nb][192]
-  float* out_err;               // [nb][192]
+  int32_t* out_cnt;             // [grid blocks]
+  uint8_t* out_idx;             // [grid blocks][192]
+  float* out_err;               // [grid blocks][192]
 };
 
 struct SearchLds {
@@ -133,6 +136,10 @@ struct SearchLds {
   unsigned char list[192];
   unsigned char oidx[192];
   float oerr[192];
+  // 4:2:0 chroma search only: the 10x10 subsampled samples around the 16x16 block
+  // (UpdatePixelsForBlock's `subsampled`, output_image.cc:150-183) per chroma component
+  int s10[2][100];
+  short cellsrc[100];   // >= 0: the cell is sample cellsrc of the block itself; -1: a neighbour's
 };
 
 // Integer IDCT of s.coef[c] with coefficient `zero_k` forced to 0 (or -1: none); result of
@@ -184,19 +191,63 @@ GZ_DEVFN void opsin8x8(SearchLds& s, int lane, const SearchArgs& a, float* ox, f
   __syncthreads();
 }
 
-// CompareBlock for the current block with coefficient `ci` (= c*64+k) zeroed.
+// 4:2:0 chroma search: the 10x10 sample array of chroma component cc (1, 2) with the block's
+// own samples taken from `own` (an 8x8 IDCT result), and this lane's upsampled + rounded pixel
+// (UpdatePixelsForBlock's fancy upsampler :192-203, then ToPixels :82) of the 8x8 sub-block
+// (off_x, off_y) of the 16x16 area.
+GZ_DEVFN void fill_s10(SearchLds& s, int cc, const int* own, const int* ring, int lane) {
+  for (int cell = lane; cell < 100; cell += 64) {
+    const int src = s.cellsrc[cell];
+    s.s10[cc - 1][cell] = src >= 0 ? own[src] : ring[cell];
+  }
+  __syncthreads();
+}
+GZ_DEVFN int upsampled_pixel(const int* s10, int lx, int ly) {
+  const int col = (lx >> 1) + 1, row = (ly >> 1) + 1;
+  const int dx = (lx & 1) ? 1 : -1, dy = (ly & 1) ? 10 : -10;
+  const int i = row * 10 + col;
+  // the reference keeps samples as idct << 4, which makes the >> 4 of its 9-3-3-1 sum exact:
+  // pixels_ = 9a + 3b + 3c + d on the plain idct values; ToPixels rounds that
+  const int p = s10[i] * 9 + s10[i + dy] * 3 + s10[i + dx] * 3 + s10[i + dx + dy];
+  return (p + 8 - (lx & 1)) >> 4;
+}
+
+// What differs between the three searches.
+//   MODE 0: 4:4:4 frame (any component mask: the candidate list decides) -- 8x8 grid
+//   MODE 1: 4:2:0 frame, luma candidates -- 8x8 grid, chroma pixels fixed
+//   MODE 2: 4:2:0 frame, chroma candidates -- 16x16 grid, four wavefronts per block, one per
+//           8x8 sub-block; the block's error is the maximum over its in-image sub-blocks
+//           (processor.cc:420-430)
+struct SearchView {
+  int vw, vh;            // in-image width / height of this wavefront's 8x8 window
+  int off_x, off_y;      // MODE 2: sub-block
+  float m0, m1, m2;      // mask at the window's corner
+  bool in_image;         // MODE 2: the sub-block is compared at all
+};
+
+// CompareBlock for this wavefront's 8x8 window with coefficient `ci` (= c*64+k) zeroed.
 // Uniform result (every lane returns the same value).
-GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, int vw, int vh, float m0,
-                              float m1, float m2, const SearchArgs& a) {
+template <int MODE>
+GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, const SearchView& v, const int* ring,
+                              const SearchArgs& a) {
   const int cc = ci >> 6, kk = ci & 63;
   idct_component(s, cc, kk, lane, s.cpx);
   // edge replication + colour + LUT
   const int iy = lane >> 3, ix = lane & 7;
-  const int sx = ix < vw ? ix : vw - 1, sy = iy < vh ? iy : vh - 1;
+  const int sx = ix < v.vw ? ix : v.vw - 1, sy = iy < v.vh ? iy : v.vh - 1;
   const int sp = 8 * sy + sx;
-  const int py = cc == 0 ? s.cpx[sp] : s.ycc[0][sp];
-  const int pcb = (cc == 1 ? s.cpx[sp] : s.ycc[1][sp]) - 128;
-  const int pcr = (cc == 2 ? s.cpx[sp] : s.ycc[2][sp]) - 128;
+  int py, pcb, pcr;
+  if (MODE == 2) {
+    fill_s10(s, cc, s.cpx, ring + 100 * (cc - 1), lane);
+    const int px = upsampled_pixel(s.s10[cc - 1], 8 * v.off_x + sx, 8 * v.off_y + sy);
+    py = s.ycc[0][sp];
+    pcb = (cc == 1 ? px : s.ycc[1][sp]) - 128;
+    pcr = (cc == 2 ? px : s.ycc[2][sp]) - 128;
+  } else {
+    py = cc == 0 ? s.cpx[sp] : s.ycc[0][sp];
+    pcb = (cc == 1 ? s.cpx[sp] : s.ycc[1][sp]) - 128;
+    pcr = (cc == 2 ? s.cpx[sp] : s.ycc[2][sp]) - 128;
+  }
   const int half = 1 << 15;
   const int r = clamp255(py + ((91881 * pcr + half) >> 16));
   const int g = clamp255(py + ((-46802 * pcr + (-22554 * pcb + half)) >> 16));
@@ -243,9 +294,9 @@ GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, int vw, int vh, fl
     }
 #pragma unroll
     for (int x2 = 0; x2 < 8; ++x2) {
-      double v = F[x2].re * F[x2].re + F[x2].im * F[x2].im;
-      v = v * 0.000064;
-      s.pw[ch][8 * k + x2] = v;
+      double pv = F[x2].re * F[x2].re + F[x2].im * F[x2].im;
+      pv = pv * 0.000064;
+      s.pw[ch][8 * k + x2] = pv;
     }
   }
   __syncthreads();
@@ -256,25 +307,42 @@ GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, int vw, int vh, fl
   }
   __syncthreads();
   double diff = 0.0;
-  diff += s.red[0] * (double)m0;
-  diff += s.red[1] * (double)m1;
-  diff += s.red[2] * (double)m2;
+  diff += s.red[0] * (double)v.m0;
+  diff += s.red[1] * (double)v.m1;
+  diff += s.red[2] * (double)v.m2;
   const float err = (float)sqrt(diff);
   __syncthreads();
   return err;
 }
 
-// grid = nb workgroups of 64 threads.
-__global__ __launch_bounds__(64) void k_block_search(SearchArgs a) {
-  __shared__ SearchLds s;
-  const int blk = blockIdx.x, lane = threadIdx.x;
-  const int bx = blk % a.bw, by = blk / a.bw;
+// grid = one workgroup per block of the search grid; 64 threads (MODE 0, 1) or 256 (MODE 2).
+template <int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArgs a) {
+  constexpr int NW = MODE == 2 ? 4 : 1;
+  __shared__ SearchLds sh[NW];
+  __shared__ int s_ring[MODE == 2 ? 200 : 1];      // neighbours' samples around the block, fixed
+  __shared__ float s_err[4];
+  const int wave = MODE == 2 ? (int)(threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
+  SearchLds& s = sh[wave];
+  const int blk = blockIdx.x;
+  const int gw = MODE == 2 ? a.cbw : a.bw;      // width of the search grid
+  const int gbx = blk % gw, gby = blk / gw;
+  SearchView v;
+  v.off_x = wave & 1;
+  v.off_y = wave >> 1;
+  const int bx = MODE == 2 ? 2 * gbx + v.off_x : gbx, by = MODE == 2 ? 2 * gby + v.off_y : gby;
   const int xmin = 8 * bx, ymin = 8 * by;
-  const int vw = a.w - xmin < 8 ? a.w - xmin : 8;   // in-image width / height of the block
-  const int vh = a.h - ymin < 8 ? a.h - ymin : 8;
+  v.in_image = xmin < a.w && ymin < a.h;
+  v.vw = a.w - xmin < 8 ? a.w - xmin : 8;   // in-image width / height of the window
+  v.vh = a.h - ymin < 8 ? a.h - ymin : 8;
+  if (v.vw < 1) v.vw = 1;                   // (sub-blocks outside the image: evaluated, ignored)
+  if (v.vh < 1) v.vh = 1;
   const int iy = lane >> 3, ix = lane & 7;
   for (int i = lane; i < 256; i += 64) s.lut[i] = a.srgb_lut[i];
-  for (int c = 0; c < 3; ++c) s.coef[64 * c + lane] = a.coeffs[((size_t)c * a.nb + blk) * 64 + lane];
+  for (int c = 0; c < 3; ++c) {
+    const bool mine = MODE == 0 || (MODE == 1 && c == 0) || (MODE == 2 && c > 0);
+    s.coef[64 * c + lane] = mine ? a.coeffs[((size_t)a.coff[c] + blk) * 64 + lane] : (short)0;
+  }
   const size_t r0 = (size_t)blk * 192;
   int n = a.rank_cnt[blk];
   for (int i = lane; i < n; i += 64) s.list[i] = a.rank_idx[r0 + i];
@@ -294,17 +362,82 @@ __global__ __launch_bounds__(64) void k_block_search(SearchArgs a) {
     s.x0[1][lane] = y0;
     s.x0[2][lane] = z0;
   }
-  for (int c = 0; c < 3; ++c) idct_component(s, c, -1, lane, s.ycc[c]);
-  const float m0 = a.block_mask[blk], m1 = a.block_mask[a.nb + blk],
-              m2 = a.block_mask[2 * a.nb + blk];
+  const int mxs = (a.w - 1) >> 1, mys = (a.h - 1) >> 1;
+  if (MODE == 0) {
+    for (int c = 0; c < 3; ++c) idct_component(s, c, -1, lane, s.ycc[c]);
+  } else if (MODE == 1) {
+    idct_component(s, 0, -1, lane, s.ycc[0]);
+    const int sw = a.cbw * 8;
+    const size_t pl = (size_t)sw * (size_t)(((a.h + 15) >> 4) * 8);
+    const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
+    const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
+    s.ycc[1][lane] = chroma420_pixel(a.samples, sw, mxs, mys, x, y);
+    s.ycc[2][lane] = chroma420_pixel(a.samples + pl, sw, mxs, mys, x, y);
+    __syncthreads();
+  } else {
+    // luma pixels of this wavefront's 8x8 sub-block (fixed during the chroma search)
+    {
+      const int lb = v.in_image ? by * a.bw + bx : 0;
+      s.in[lane] = (int)a.coeffs[((size_t)a.coff[0] + lb) * 64 + lane];
+      __syncthreads();
+      int acc = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s.in[8 * u + ix];
+      s.col[lane] = (int)(short)((acc + (1 << 10)) >> 11);
+      __syncthreads();
+      acc = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s.col[8 * iy + u];
+      s.ycc[0][lane] = clamp255((acc + (257 << 17)) >> 18);
+      __syncthreads();
+    }
+    // the 10x10 neighbourhood: which cells are the block's own samples (after the replication
+    // rules, i.e. clamping the sample coordinates into the image), and the others' values
+    const int sw = a.cbw * 8;
+    const size_t pl = (size_t)sw * (size_t)(((a.h + 15) >> 4) * 8);
+    for (int cell = lane; cell < 100; cell += 64) {
+      int gx = 8 * gbx + cell % 10 - 1, gy = 8 * gby + cell / 10 - 1;
+      gx = gx < 0 ? 0 : (gx > mxs ? mxs : gx);
+      gy = gy < 0 ? 0 : (gy > mys ? mys : gy);
+      const int lx = gx - 8 * gbx, ly = gy - 8 * gby;
+      const bool own = lx >= 0 && lx < 8 && ly >= 0 && ly < 8;
+      s.cellsrc[cell] = own ? (short)(8 * ly + lx) : (short)-1;
+      if (wave == 0) {
+        s_ring[cell] = (int)a.samples[(size_t)gy * sw + gx];
+        s_ring[100 + cell] = (int)a.samples[pl + (size_t)gy * sw + gx];
+      }
+    }
+    __syncthreads();
+    for (int c = 1; c < 3; ++c) {
+      idct_component(s, c, -1, lane, s.cpx);
+      fill_s10(s, c, s.cpx, s_ring + 100 * (c - 1), lane);
+      s.ycc[c][lane] = upsampled_pixel(s.s10[c - 1], 8 * v.off_x + ix, 8 * v.off_y + iy);
+      __syncthreads();
+    }
+  }
+  {
+    const int mb = v.in_image ? by * a.bw + bx : 0;
+    v.m0 = a.block_mask[mb];
+    v.m1 = a.block_mask[a.nb + mb];
+    v.m2 = a.block_mask[2 * a.nb + mb];
+  }
   int m = 0;
   while (n > 0) {
     float best_err = 1e17f;
     int best_i = 0;
     const int tries = n < a.lookahead ? n : a.lookahead;
     for (int i = 0; i < tries; ++i) {
-      const float e = eval_candidate(s, (int)s.list[i], lane, vw, vh, m0, m1, m2, a);
-      const float max_err = e > 0.0f ? e : 0.0f;   // std::max(0, err)
+      float max_err = 0.0f;
+      if (MODE == 2) {
+        const float e = eval_candidate<MODE>(s, (int)s.list[i], lane, v, s_ring, a);
+        if (lane == 0) s_err[wave] = v.in_image ? e : 0.0f;
+        __syncthreads();
+        for (int k = 0; k < 4; ++k) max_err = s_err[k] > max_err ? s_err[k] : max_err;   // std::max(max_err, err)
+        __syncthreads();
+      } else {
+        const float e = eval_candidate<MODE>(s, (int)s.list[i], lane, v, s_ring, a);
+        max_err = e > 0.0f ? e : 0.0f;   // std::max(0, err)
+      }
       if (max_err < best_err) {
         best_err = max_err;
         best_i = i;
@@ -320,19 +453,28 @@ __global__ __launch_bounds__(64) void k_block_search(SearchArgs a) {
     // erase list[best_i]
     for (int base = 0; base < n; base += 64) {
       const int j = base + lane;
-      unsigned char v = 0;
+      unsigned char vv = 0;
       const bool mv = j >= best_i && j < n - 1;
-      if (mv) v = s.list[j + 1];
+      if (mv) vv = s.list[j + 1];
       __syncthreads();
-      if (mv) s.list[j] = v;
+      if (mv) s.list[j] = vv;
       __syncthreads();
     }
     ++m;
     --n;
-    idct_component(s, ci >> 6, -1, lane, s.ycc[ci >> 6]);
+    if (MODE == 2) {
+      const int c = ci >> 6;
+      idct_component(s, c, -1, lane, s.cpx);
+      fill_s10(s, c, s.cpx, s_ring + 100 * (c - 1), lane);
+      s.ycc[c][lane] = upsampled_pixel(s.s10[c - 1], 8 * v.off_x + ix, 8 * v.off_y + iy);
+      __syncthreads();
+    } else {
+      idct_component(s, ci >> 6, -1, lane, s.ycc[ci >> 6]);
+    }
   }
   __syncthreads();
   // monotone minimum from the end + cut at the block error limit (processor.cc:447-459)
+  // (MODE 2: the four wavefronts hold identical lists; the first one writes the result)
   if (lane == 0) {
     float min_err = 1e10f;
     for (int i = m - 1; i >= 0; --i) {
@@ -342,10 +484,10 @@ __global__ __launch_bounds__(64) void k_block_search(SearchArgs a) {
     int num = 0;
     while (num < m && s.oerr[num] <= a.limit) ++num;
     s.red[3] = (double)num;
-    a.out_cnt[blk] = num;
+    if (wave == 0) a.out_cnt[blk] = num;
   }
   __syncthreads();
-  const int num = (int)s.red[3];
+  const int num = wave == 0 ? (int)s.red[3] : 0;
   for (int i = lane; i < num; i += 64) {
     a.out_idx[(size_t)blk * 192 + i] = s.oidx[i];
     a.out_err[(size_t)blk * 192 + i] = s.oerr[i];

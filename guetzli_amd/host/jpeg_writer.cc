@@ -281,30 +281,63 @@ bool AllZero(const int16_t* p, size_t n) {
 
 }  // namespace
 
-void FrameFromImage(const int16_t* coeffs, const int q[3][64], int w, int h, Frame* f) {
-  f->width = w;
-  f->height = h;
-  f->bw = (w + 7) / 8;
-  f->bh = (h + 7) / 8;
-  const size_t n = (size_t)f->bw * f->bh * 64;
-  // a single component is written when both chroma planes are entirely zero
-  f->ncomp = AllZero(coeffs + n, n) && AllZero(coeffs + 2 * n, n) ? 1 : 3;
-  for (int c = 0; c < 3; ++c) f->coeffs[c].clear();
-  for (int c = 0; c < f->ncomp; ++c) {
-    f->coeffs[c].resize(n);
-    const int16_t* src = coeffs + (size_t)c * n;
-    int16_t* dst = f->coeffs[c].data();
-    for (size_t i = 0; i < n; ++i) dst[i] = (int16_t)(src[i] / q[c][i & 63]);
-  }
-  AssignQuantTables(q, f);
-}
-
-void FrameTables(const int q[3][64], int w, int h, int ncomp, Frame* f) {
+// Sampling geometry of a frame with `ncomp` components written and chroma factor `factor`
+// (SaveToJpegData :353-380: with one component everything is 1 x 1).
+static void SetGeometry(int w, int h, int ncomp, int factor, Frame* f) {
   f->width = w;
   f->height = h;
   f->bw = (w + 7) / 8;
   f->bh = (h + 7) / 8;
   f->ncomp = ncomp;
+  const int fac = ncomp == 1 ? 1 : factor;
+  f->mcu_cols = (w + 8 * fac - 1) / (8 * fac);
+  f->mcu_rows = (h + 8 * fac - 1) / (8 * fac);
+  for (int c = 0; c < 3; ++c) {
+    f->samp[c] = c == 0 ? fac : 1;
+    f->cw[c] = f->mcu_cols * f->samp[c];
+    f->ch[c] = f->mcu_rows * f->samp[c];
+  }
+}
+
+void FrameFromImage(const int16_t* coeffs, const int q[3][64], int w, int h, Frame* f) {
+  FrameFromImageFactor(coeffs, q, w, h, 1, f);
+}
+
+void FrameFromImageFactor(const int16_t* coeffs, const int q[3][64], int w, int h, int factor,
+                          Frame* f) {
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8;
+  const int cbw = (w + 8 * factor - 1) / (8 * factor), cbh = (h + 8 * factor - 1) / (8 * factor);
+  const size_t nb = (size_t)bw * bh, nbc = (size_t)cbw * cbh;
+  // a single component is written when both chroma planes are entirely zero
+  const int ncomp = AllZero(coeffs + nb * 64, 2 * nbc * 64) ? 1 : 3;
+  SetGeometry(w, h, ncomp, factor, f);
+  for (int c = 0; c < 3; ++c) f->coeffs[c].clear();
+  for (int c = 0; c < ncomp; ++c) {
+    const int rw = c == 0 ? bw : cbw, rh = c == 0 ? bh : cbh;   // the component's real blocks
+    const int16_t* src = coeffs + (c == 0 ? 0 : (nb + (size_t)(c - 1) * nbc)) * 64;
+    f->coeffs[c].assign((size_t)f->cw[c] * f->ch[c] * 64, 0);
+    int16_t* dst = f->coeffs[c].data();
+    int last_dc = 0;
+    for (int by = 0; by < f->ch[c]; ++by)
+      for (int bx = 0; bx < f->cw[c]; ++bx, dst += 64) {
+        if (by >= rh || bx >= rw) {
+          dst[0] = (int16_t)last_dc;   // the AC part stays zero
+        } else {
+          const int16_t* s = src + ((size_t)by * rw + bx) * 64;
+          for (int k = 0; k < 64; ++k) dst[k] = (int16_t)(s[k] / q[c][k]);
+        }
+        last_dc = dst[0];
+      }
+  }
+  AssignQuantTables(q, f);
+}
+
+void FrameTables(const int q[3][64], int w, int h, int ncomp, Frame* f) {
+  FrameTablesFactor(q, w, h, ncomp, 1, f);
+}
+
+void FrameTablesFactor(const int q[3][64], int w, int h, int ncomp, int factor, Frame* f) {
+  SetGeometry(w, h, ncomp, factor, f);
   for (int c = 0; c < 3; ++c) f->coeffs[c].clear();
   if (q) {
     AssignQuantTables(q, f);
@@ -322,11 +355,7 @@ void FrameTables(const int q[3][64], int w, int h, int ncomp, Frame* f) {
 }
 
 void FrameFromOriginal(const int16_t* coeffs, int w, int h, Frame* f) {
-  f->width = w;
-  f->height = h;
-  f->bw = (w + 7) / 8;
-  f->bh = (h + 7) / 8;
-  f->ncomp = 3;
+  SetGeometry(w, h, 3, 1, f);
   const size_t n = (size_t)f->bw * f->bh * 64;
   f->quant.clear();
   for (int c = 0; c < 3; ++c) {
@@ -341,22 +370,27 @@ void FrameFromOriginal(const int16_t* coeffs, int w, int h, Frame* f) {
 }
 
 void BuildDCHistograms(const Frame& f, SymbolHistogram* histo) {
-  const size_t nb = (size_t)f.bw * f.bh;
   for (int c = 0; c < f.ncomp; ++c) {
     int last = 0;
     const int16_t* p = f.coeffs[c].data();
-    for (size_t b = 0; b < nb; ++b) {
-      const int dc = p[b * 64];
-      histo[c].Add(BitLength((uint32_t)std::abs(dc - last)));
-      last = dc;
-    }
+    const int sp = f.samp[c];
+    for (int my = 0; my < f.mcu_rows; ++my)
+      for (int mx = 0; mx < f.mcu_cols; ++mx)
+        for (int iy = 0; iy < sp; ++iy)
+          for (int ix = 0; ix < sp; ++ix) {
+            const size_t b = (size_t)(my * sp + iy) * f.cw[c] + (mx * sp + ix);
+            const int dc = p[b * 64];
+            histo[c].Add(BitLength((uint32_t)std::abs(dc - last)));
+            last = dc;
+          }
   }
 }
 
 void BuildACHistograms(const Frame& f, SymbolHistogram* histo) {
-  const size_t nb = (size_t)f.bw * f.bh;
-  for (int c = 0; c < f.ncomp; ++c)
+  for (int c = 0; c < f.ncomp; ++c) {
+    const size_t nb = (size_t)f.cw[c] * f.ch[c];   // padding blocks count too (an EOB each)
     for (size_t b = 0; b < nb; ++b) AddBlockACSymbols(&f.coeffs[c][b * 64], nullptr, 1, &histo[c]);
+  }
 }
 
 size_t HeaderSize(const Frame& f) {
@@ -555,7 +589,7 @@ bool BuildJpegHead(const Frame& f, const SymbolHistogram* dc_histo,
     out->push_back((char)nc);
     for (int c = 0; c < nc; ++c) {
       out->push_back((char)f.comp_id[c]);
-      out->push_back((char)0x11);
+      out->push_back((char)((f.samp[c] << 4) | f.samp[c]));
       if (f.quant_idx[c] >= (int)f.quant.size()) return false;
       out->push_back((char)f.quant[f.quant_idx[c]].index);
     }
@@ -619,7 +653,6 @@ bool BuildJpegHead(const Frame& f, const SymbolHistogram* dc_histo,
 
 bool WriteJpeg(const Frame& f, std::string* out) {
   const int nc = f.ncomp;
-  const size_t nb = (size_t)f.bw * f.bh;
   SymbolHistogram dc_histo[3], ac_histo[3];
   BuildDCHistograms(f, dc_histo);
   BuildACHistograms(f, ac_histo);
@@ -634,13 +667,18 @@ bool WriteJpeg(const Frame& f, std::string* out) {
       ac_table[c].depth[j] = head.depth[1][c][j];
       ac_table[c].code[j] = head.code[1][c][j];
     }
-  // scan (EncodeScan :499-536), 4:4:4: one block per component per MCU
+  // scan (EncodeScan :499-536): MCU by MCU, per component its samp x samp blocks
   {
     BitSink sink(out);
     int last_dc[3] = {0, 0, 0};
-    for (size_t b = 0; b < nb; ++b)
-      for (int c = 0; c < nc; ++c)
-        PutBlock(&f.coeffs[c][b * 64], dc_table[c], ac_table[c], &last_dc[c], &sink);
+    for (int my = 0; my < f.mcu_rows; ++my)
+      for (int mx = 0; mx < f.mcu_cols; ++mx)
+        for (int c = 0; c < nc; ++c)
+          for (int iy = 0; iy < f.samp[c]; ++iy)
+            for (int ix = 0; ix < f.samp[c]; ++ix) {
+              const size_t b = (size_t)(my * f.samp[c] + iy) * f.cw[c] + (mx * f.samp[c] + ix);
+              PutBlock(&f.coeffs[c][b * 64], dc_table[c], ac_table[c], &last_dc[c], &sink);
+            }
     sink.Finish();
   }
   out->push_back((char)0xff);

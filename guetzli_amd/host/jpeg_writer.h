@@ -65,8 +65,14 @@ struct FrameMeta {
   std::string tail_data;                // bytes after EOI
 };
 struct Frame {
-  int width = 0, height = 0, bw = 0, bh = 0;
+  int width = 0, height = 0, bw = 0, bh = 0;   // bw x bh: the 8x8 (luma) grid of the image
   int ncomp = 3;
+  // Sampling: component c has samp[c] x samp[c] blocks per MCU (4:4:4: 1,1,1 -- 4:2:0: 2,1,1),
+  // its coefficient plane holds cw[c] x ch[c] blocks = whole MCUs (mcu_cols * samp[c] ...),
+  // padding included (OutputImage::SaveToJpegData, output_image.cc:348-409).
+  int samp[3] = {1, 1, 1};
+  int mcu_cols = 0, mcu_rows = 0;
+  int cw[3] = {0, 0, 0}, ch[3] = {0, 0, 0};
   int comp_id[3] = {0, 1, 2};           // SaveToJpegData numbers them (output_image.cc:376); the
                                         // input JPEG as read keeps its own
   const FrameMeta* meta = nullptr;
@@ -78,6 +84,11 @@ struct Frame {
 // OutputImage::SaveToJpegData + SaveQuantTables for a 4:4:4 image given by dequantised
 // coefficients (device layout, [3][nb][64]) and its quant matrices.
 void FrameFromImage(const int16_t* coeffs, const int q[3][64], int w, int h, Frame* f);
+// The same for a frame with chroma subsampling factor `factor` (1: as above; 2: YUV 4:2:0,
+// coefficients = nb luma blocks, nbc Cb, nbc Cr): luma padded to whole MCUs with the
+// reference's padding blocks (all AC zero, DC = the DC of the block before in raster order).
+void FrameFromImageFactor(const int16_t* coeffs, const int q[3][64], int w, int h, int factor,
+                          Frame* f);
 // The q=1 "original" JPEGData of EncodeRGBToJpeg (jpeg_data_encoder.cc:66-117): three
 // separate all-ones tables that all carry table index 0.
 void FrameFromOriginal(const int16_t* coeffs, int w, int h, Frame* f);
@@ -85,6 +96,7 @@ void FrameFromOriginal(const int16_t* coeffs, int w, int h, Frame* f);
 // The tables of a frame without its coefficients (enough for HeaderSize / BuildJpegHead):
 // q = the image's quant matrices, or null for the q=1 "original" flavour.
 void FrameTables(const int q[3][64], int w, int h, int ncomp, Frame* f);
+void FrameTablesFactor(const int q[3][64], int w, int h, int ncomp, int factor, Frame* f);
 
 void BuildDCHistograms(const Frame& f, SymbolHistogram* histo);   // :241-265
 void BuildACHistograms(const Frame& f, SymbolHistogram* histo);   // :267-275

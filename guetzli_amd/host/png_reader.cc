@@ -267,6 +267,11 @@ bool ReadPng(const uint8_t* data, size_t len, int* xsize, int* ysize, std::vecto
   }
 
   // ---- inflate ----
+  // deflate expands by at most ~1032:1 (a stored/RLE limit of the format), so a header that
+  // declares more samples than the IDAT data can possibly inflate to is rejected before
+  // anything of that size is allocated (a 60-byte file declaring 10^6 x 10^6 RGBA16 would
+  // otherwise ask for 8 TB here); 3 * width * height <= 24 * total is bounded with it.
+  if (total / 1040 > idat.size() + 64) return Fail(error, "not enough image data");
   std::vector<uint8_t> raw(total);
   {
     z_stream zs;

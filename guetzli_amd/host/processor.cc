@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <exception>
 #include <utility>
 
 #include "../../include/guetzli_amd.h"
@@ -89,7 +90,7 @@ struct Trial {
 
 class MatrixSearch {
  public:
-  MatrixSearch() : lo_(-1.0), hi_(-1.0), total_(0.0) {
+  explicit MatrixSearch(bool downsample) : downsample_(downsample), lo_(-1.0), hi_(-1.0), total_(0.0) {
     for (int k = 0; k < 64; ++k) total_ += 3.0 * Csf(k);
   }
   bool Next(QuantMatrix q) {
@@ -97,7 +98,7 @@ class MatrixSearch {
       double h;
       if (hi_ == -1.0) {
         if (lo_ == -1.0) {
-          h = total_;
+          h = downsample_ ? 0.0 : total_;
         } else {
           h = lo_ < 5.0 * total_ ? lo_ + total_ : 2 * (lo_ + total_);
         }
@@ -144,6 +145,7 @@ class MatrixSearch {
       score -= 3.0 * Csf(nat);
     }
   }
+  const bool downsample_;
   double lo_, hi_, total_;
   std::vector<Trial> tried_;
 };
@@ -231,7 +233,10 @@ class Encoder {
   bool Fail(const char* what, int rc);
   // SaveToJpegData + WriteJpeg of the current image: marker segments and Huffman codes
   // on the host from the symbol statistics, the scan on the device.  *size = jpg.size().
-  bool DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolHistogram* ac);
+  bool DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolHistogram* ac, int ncomp = 3);
+  bool SetFrame(int factor);
+  const char* FrameStr() const { return fac_ == 2 ? "f112222" : "f111111"; }   // OutputImage::FrameTypeStr
+  size_t Pos(int c, int block, int k) const { return ((size_t)coff_[c] + block) * 64 + k; }
   bool Serialize(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac,
                  size_t* size);
   bool CompareBegin();
@@ -240,8 +245,8 @@ class Encoder {
   bool VerifyAgainstHostWriter(const int (*q)[64], size_t size);
   bool DistanceOK(double target_mul) const { return distance_ <= target_mul * params_.butteraugli_target; }
   bool TryMatrix(float target_mul, const QuantMatrix q, Trial* t);
-  bool SelectMatrix(QuantMatrix best);
-  bool SelectFrequencyMasking(double target_mul);
+  bool SelectMatrix(QuantMatrix best, bool downsample, bool* dist_ok);
+  bool SelectFrequencyMasking(int comp_mask, double target_mul, bool stop_early);
   bool SetImageFromQuantization(const QuantMatrix q, bool download);
   // The tables of a frame of this image: quant matrices q, or null for the "original" (the
   // q = 1 frame of EncodeRGBToJpeg, or the input JPEG's own tables), plus the metadata a JPEG
@@ -253,6 +258,13 @@ class Encoder {
   ProcessStats* stats_;
   gz_ctx* ctx_ = nullptr;
   int w_ = 0, h_ = 0, bw_ = 0, bh_ = 0, nb_ = 0;
+  // the frame (OutputImage's component layout): chroma factor 1 (4:4:4) or 2 (4:2:0), blocks
+  // per chroma component, first block of every component in orig_ / img_, blocks in total
+  int fac_ = 1, cbw_ = 0, cbh_ = 0, nbc_ = 0, coff_[3] = {0, 0, 0}, nblk_ = 0;
+  int jpg_ncomp_ = 3;            // jpg.components.size() of the round (1: greyscale after Downsample)
+  size_t best_size_ = 0;         // final_output_->jpeg_data.size()
+  std::string best_full_;        // a best candidate written on the host (the 4:2:0 input as read)
+  bool best_on_host_ = false;
   std::vector<int16_t> orig_;    // unquantised coefficients (JPEGData of EncodeRGBToJpeg)
   std::vector<int16_t> img_;     // coefficients of the working image (OutputImage::coeffs_)
   // phase A's CSR arrays, the fetched part of phase B's order, the winner's scan (borrowed
@@ -269,6 +281,7 @@ class Encoder {
                                  // kept on the device (gz_jpeg_scan_keep)
   bool jpeg_input_ = false;      // Process(jpeg_data): tables / metadata of the input below
   FrameMeta meta_;
+  Frame in_frame_;               // a 4:2:0 input as read (its own padding blocks)
   std::vector<QuantTable> in_quant_;
   int in_quant_idx_[3] = {0, 0, 0};
   int in_comp_id_[3] = {0, 1, 2};
@@ -312,8 +325,20 @@ bool Encoder::Fail(const char* what, int rc) {
   return false;
 }
 
+bool Encoder::SetFrame(int factor) {
+  fac_ = factor;
+  cbw_ = (w_ + 8 * factor - 1) / (8 * factor);
+  cbh_ = (h_ + 8 * factor - 1) / (8 * factor);
+  nbc_ = cbw_ * cbh_;
+  coff_[0] = 0;
+  coff_[1] = nb_;
+  coff_[2] = nb_ + nbc_;
+  nblk_ = nb_ + 2 * nbc_;
+  return true;
+}
+
 void Encoder::Tables(const int (*q)[64], int ncomp, Frame* f) const {
-  FrameTables(q, w_, h_, ncomp, f);
+  FrameTablesFactor(q, w_, h_, ncomp, fac_, f);
   if (!jpeg_input_) return;
   f->meta = &meta_;
   if (q == nullptr) {   // jpg_in as read: its own DQT tables in file order, its component ids
@@ -333,9 +358,13 @@ static bool ChromaAllZero(const SymbolHistogram* dc, const SymbolHistogram* ac) 
   return true;
 }
 
-bool Encoder::DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolHistogram* ac) {
+// BuildDCHistograms + BuildACHistograms of the frame SaveToJpegData would write.  In a 4:2:0
+// frame the luma statistics depend on whether chroma is written at all (MCU order and padding
+// blocks, or luma alone in raster order): asked for three components first, and again for one
+// if both chroma components turn out to be all zero.
+bool Encoder::DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolHistogram* ac, int ncomp) {
   std::vector<uint32_t> counts(2 * 3 * 256);
-  const int rc = gz_jpeg_histograms(ctx_, &q[0][0], counts.data());
+  const int rc = gz_jpeg_histograms_ncomp(ctx_, &q[0][0], ncomp, counts.data());
   if (rc != GZ_OK) return Fail("gz_jpeg_histograms", rc);
   for (int c = 0; c < 3; ++c) {
     dc[c].Clear();
@@ -345,6 +374,7 @@ bool Encoder::DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolH
       ac[c].Add(i, (int)counts[(1 * 3 + c) * 256 + i]);
     }
   }
+  if (ncomp == 3 && fac_ == 2 && ChromaAllZero(dc, ac)) return DeviceHistograms(q, dc, ac, 1);
   return true;
 }
 
@@ -354,7 +384,17 @@ bool Encoder::Serialize(const int (*q)[64], const SymbolHistogram* dc, const Sym
   Frame f;
   // a single component is written when both chroma planes are entirely zero
   // (OutputImage::SaveToJpegData, output_image.cc:348-409); the q=1 original always has 3
-  Tables(q, q && ChromaAllZero(dc, ac) ? 1 : 3, &f);
+  const int nc = q && ChromaAllZero(dc, ac) ? 1 : 3;
+  Tables(q, nc, &f);
+  SymbolHistogram dc1[3], ac1[3];
+  if (nc == 1 && fac_ == 2) {
+    // luma alone is written in raster order without padding blocks: its statistics are not
+    // those of the 4:2:0 MCU order the caller may hold (chroma that became all zero during
+    // the search); recounted
+    if (!DeviceHistograms(q, dc1, ac1, 1)) return false;
+    dc = dc1;
+    ac = ac1;
+  }
   if (!BuildJpegHead(f, dc, ac, &head_)) return Fail("BuildJpegHead", GZ_E_STATE);
   uint64_t scan_bytes = 0;
   const int rc = gz_jpeg_scan(ctx_, head_.ncomp, &head_.depth[0][0][0], &head_.code[0][0][0],
@@ -370,10 +410,10 @@ bool Encoder::Serialize(const int (*q)[64], const SymbolHistogram* dc, const Sym
 // Test hook (GZ_VERIFY_ENTROPY=1): the device scan + host head must equal the serial host
 // writer on the same coefficients, byte for byte.
 bool Encoder::VerifyAgainstHostWriter(const int (*q)[64], size_t size) {
-  std::vector<int16_t> co(img_.size());
+  std::vector<int16_t> co((size_t)nblk_ * 64);
   int rc = gz_get_coeffs(ctx_, co.data());
   if (rc != GZ_OK) return Fail("gz_get_coeffs", rc);
-  if (q && mirror_valid_ && co != img_) {
+  if (q && mirror_valid_ && memcmp(co.data(), img_.data(), co.size() * 2) != 0) {
     size_t nd = 0, first = 0;
     for (size_t i = 0; i < co.size(); ++i)
       if (co[i] != img_[i]) { if (!nd) first = i; ++nd; }
@@ -383,10 +423,10 @@ bool Encoder::VerifyAgainstHostWriter(const int (*q)[64], size_t size) {
   }
   Frame f;
   if (q) {
-    FrameFromImage(co.data(), q, w_, h_, &f);
+    FrameFromImageFactor(co.data(), q, w_, h_, fac_, &f);
   } else if (jpeg_input_) {   // the input as read: quantised by its own tables
-    FrameFromImage(co.data(), q_in_, w_, h_, &f);
-    f.ncomp = 3;
+    FrameFromImageFactor(co.data(), q_in_, w_, h_, fac_, &f);
+    if (f.ncomp != 3) return true;   // (all-zero chroma in the input: not comparable this way)
     f.quant = in_quant_;
     for (int c = 0; c < 3; ++c) {
       f.quant_idx[c] = in_quant_idx_[c];
@@ -441,6 +481,8 @@ bool Encoder::MaybeOutput(size_t size) {   // processor.cc:139-148
     const int rc = gz_jpeg_scan_keep(ctx_);
     if (rc != GZ_OK) return Fail("gz_jpeg_scan_keep", rc);
     best_score_ = score;
+    best_size_ = size;
+    best_on_host_ = false;
     Log(" (*)");
   }
   Log("\n");
@@ -463,9 +505,9 @@ bool Encoder::TryMatrix(float target_mul, const QuantMatrix q, Trial* t) {   // 
   SymbolHistogram dc[3], ac[3];
   size_t size = 0;
   if (!DeviceHistograms(q, dc, ac) || !CompareBegin() || !Serialize(q, dc, ac, &size)) return false;
-  Log("Iter %2d: %s quantization matrix:\n", stats_->counters[kNumItersCnt] + 1, "f111111");
+  Log("Iter %2d: %s quantization matrix:\n", stats_->counters[kNumItersCnt] + 1, FrameStr());
   LogMatrix(q);
-  Log("Iter %2d: %s GQ[%5.2f] Out[%7zd]", stats_->counters[kNumItersCnt] + 1, "f111111",
+  Log("Iter %2d: %s GQ[%5.2f] Out[%7zd]", stats_->counters[kNumItersCnt] + 1, FrameStr(),
       HeuristicScore(q), size);
   ++stats_->counters[kNumItersCnt];
   if (!CompareCurrent()) return false;
@@ -474,8 +516,8 @@ bool Encoder::TryMatrix(float target_mul, const QuantMatrix q, Trial* t) {   // 
   return MaybeOutput(size);
 }
 
-bool Encoder::SelectMatrix(QuantMatrix best_q) {   // SelectQuantMatrix, :328-360
-  MatrixSearch search;
+bool Encoder::SelectMatrix(QuantMatrix best_q, bool downsample, bool* dist_ok) {   // SelectQuantMatrix, :328-360
+  MatrixSearch search(downsample);
   const float target_mul_high = 0.97f, target_mul_low = 0.95f;
   Trial best;
   if (!TryMatrix(target_mul_high, best_q, &best)) return false;
@@ -492,45 +534,50 @@ bool Encoder::SelectMatrix(QuantMatrix best_q) {   // SelectQuantMatrix, :328-36
     }
   }
   memcpy(best_q, best.q, sizeof(QuantMatrix));
-  Log("\n%s selected quantization matrix:\n", "YUV444");
+  Log("\n%s selected quantization matrix:\n", downsample ? "YUV420" : "YUV444");
   LogMatrix(best_q);
-  if (!best.dist_ok)
-    for (int c = 0; c < 3; ++c)
-      for (int k = 0; k < 64; ++k) best_q[c][k] = 1;
+  *dist_ok = best.dist_ok;
   return true;
 }
 
 // Entropy-size model of the AC coefficients (processor.cc:497-525).
-size_t EntropyCodes(const SymbolHistogram* histo, uint8_t* depths /*3*257*/) {
+size_t EntropyCodes(const SymbolHistogram* histo, int n, uint8_t* depths /*3*257*/) {
   SymbolHistogram clustered[3] = {histo[0], histo[1], histo[2]};
-  size_t num = 3;
+  size_t num = (size_t)n;
   int indexes[3];
   uint8_t cdepths[3 * kHistoSize];
   ClusterHistograms(clustered, &num, indexes, cdepths);
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < n; ++i)
     memcpy(&depths[i * kHistoSize], &cdepths[indexes[i] * kHistoSize], kHistoSize);
   size_t header = 0;
   for (size_t i = 0; i < num; ++i) header += HistogramHeaderBits(clustered[i]) / 8;
   return header;
 }
-size_t EntropyDataSize(const SymbolHistogram* histo, const uint8_t* depths) {
+size_t EntropyDataSize(const SymbolHistogram* histo, int n, const uint8_t* depths) {
   size_t bits = 0;
-  for (int i = 0; i < 3; ++i) bits += HistogramEntropyBits(histo[i], &depths[i * kHistoSize]);
+  for (int i = 0; i < n; ++i) bits += HistogramEntropyBits(histo[i], &depths[i * kHistoSize]);
   return (bits + 7) / 8;
 }
 
-bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-780, mask 7
+bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop_early) {   // processor.cc:539-780
   Stopwatch sw;
-  const int nb = nb_;
+  int last_c = 0;
+  for (int c = 0; c < 3; ++c)
+    if (comp_mask & (1 << c)) last_c = c;
+  if (last_c >= jpg_ncomp_) return true;   // :546-547
+  // the grid of the mask's last component (:548-552)
+  const int factor = last_c > 0 ? fac_ : 1;
+  const int nb = factor == 2 ? nbc_ : nb_;
+  const int ncomp = jpg_ncomp_;
   // ---- phase A on the device ----
   std::vector<int32_t>& cand_off = cand_off_;
   std::vector<uint8_t>& cand_idx = cand_idx_;
   if (cand_off.size() != (size_t)nb + 1) cand_off.resize((size_t)nb + 1);
   if (cand_idx.size() != (size_t)nb * 189) cand_idx.resize((size_t)nb * 189);
   // the candidates' errors stay on the device, where the global order is built from them
-  int rc = gz_block_zeroing_orders(ctx_, params_.zeroing_greedy_lookahead,
-                                   params_.new_zeroing_model ? 1 : 0, cand_off.data(),
-                                   cand_idx.data(), nullptr, nb * 189);
+  int rc = gz_block_zeroing_orders_masked(ctx_, comp_mask, params_.zeroing_greedy_lookahead,
+                                          params_.new_zeroing_model ? 1 : 0, cand_off.data(),
+                                          cand_idx.data(), nullptr, nb * 189);
   t_blocksearch_ += sw.lap();
   if (rc != GZ_OK) return Fail("gz_block_zeroing_orders", rc);
 
@@ -547,11 +594,14 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
     int indexes[3];
     uint8_t depths[3 * kHistoSize];
     dc_size = (int)ClusterHistograms(dcs, &num, indexes, depths);   // EstimateDCSize
+    // BuildACHistograms fills one histogram per component SaveToJpegData wrote: with all-zero
+    // chroma that is luma only, and the other entries of ac_histograms(ncomp) stay empty (:592-600)
+    if (f.ncomp == 1) { ac_histo[1].Clear(); ac_histo[2].Clear(); }
   }
   std::vector<uint8_t> ac_depths(3 * kHistoSize);
-  int ac_header = (int)EntropyCodes(ac_histo, ac_depths.data());
+  int ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
   const int base_size = header_size + dc_size + ac_header +
-                        (int)EntropyDataSize(ac_histo, ac_depths.data());
+                        (int)EntropyDataSize(ac_histo, ncomp, ac_depths.data());
   int prev_size = base_size;
 
   rc = gz_order_reset(ctx_);           // max_block_error := 0, kept on the device
@@ -564,10 +614,13 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
   std::vector<int32_t> dirty;
   std::vector<int> step_count(nb);
   bool first_up = true;
-  const size_t comp_stride = (size_t)nb * 64;
 
   for (int direction = 1; direction >= -1; direction -= 2) {
     for (;;) {
+      if (stop_early && direction == -1) {
+        // down-adjusting only makes the output larger (:613-621)
+        if (prev_size > 1.01 * (double)best_size_) break;
+      }
       int blocks_to_change = 0;
       Stopwatch pw;
       // `order` (global_order, processor.cc:622-663) is built on the device from the CSR
@@ -611,7 +664,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       double rel_size_delta = direction > 0 ? 0.01 : 0.0005;
       if (direction > 0 && DistanceOK(1.0)) rel_size_delta = 0.05;
       const double min_size_delta = base_size * rel_size_delta;
-      const float per_block = direction > 0 ? 2.0f : 1 * 1 * 0.2f;
+      const float per_block = direction > 0 ? 2.0f : factor * factor * 0.2f;
       int min_coeffs_to_change = per_block * blocks_to_change;
       if (first_up) {
         // partition_point over the sorted sequence == number of keys below the limit
@@ -636,13 +689,13 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
         const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
         const int c = idx / 64, k = idx % 64;
         const int* q = quant_[c];
-        const int16_t* orig_blk = &orig_[c * comp_stride + (size_t)b * 64];
-        int16_t* blk = &img_[c * comp_stride + (size_t)b * 64];
+        const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
+        int16_t* blk = &img_[Pos(c, b, 0)];
         const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
         AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
         if (!(newval == 0 && IsPrecious(orig_blk, k))) {
           blk[k] = (int16_t)newval;
-          edit_pos.push_back((int32_t)(c * comp_stride + (size_t)b * 64 + k));
+          edit_pos.push_back((int32_t)Pos(c, b, k));
           edit_val.push_back((int16_t)newval);
         }
         AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
@@ -696,10 +749,10 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
               for (int step = 0; step < step_count[b]; ++step) {
                 const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
                 const int c = idx / 64, k = idx % 64;
-                const int16_t* orig_blk = &orig_[c * comp_stride + (size_t)b * 64];
+                const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
                 const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], quant_[c][k]);
                 if (!(newval == 0 && IsPrecious(orig_blk, k)))
-                  img_[c * comp_stride + (size_t)b * 64 + k] = (int16_t)newval;
+                  img_[Pos(c, b, k)] = (int16_t)newval;
                 next_cand[b] += direction;
               }
             }
@@ -716,7 +769,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
           if (verify_) {   // GZ_VERIFY_ENTROPY=1: against a recount of the whole image
             SymbolHistogram dc_now[3], ac_now[3];
             if (!DeviceHistograms(quant_, dc_now, ac_now)) return false;
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < ncomp; ++c)
               if (memcmp(ac_now[c].counts, ac_histo[c].counts, sizeof(ac_now[c].counts)) != 0) {
                 fprintf(stderr, "guetzli_amd: incremental AC statistics differ from a recount\n");
                 return false;
@@ -730,12 +783,12 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
           apply_step(i);
           if (i % 10 == 0) {
             Stopwatch cw;
-            ac_header = (int)EntropyCodes(ac_histo, ac_depths.data());
+            ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
             t_pb_codes_ += cw.lap();
           }
           ++n_steps_;
           est_size = header_size + dc_size + ac_header +
-                     (int)EntropyDataSize(ac_histo, ac_depths.data());
+                     (int)EntropyDataSize(ac_histo, ncomp, ac_depths.data());
           if (changed_coeffs > min_coeffs_to_change &&
               std::abs(est_size - prev_size) > min_size_delta)
             break;
@@ -761,7 +814,7 @@ bool Encoder::SelectFrequencyMasking(double target_mul) {   // processor.cc:539-
       if (!CompareBegin() || !Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;
       Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
           "EstErr[%.2f%%]",
-          stats_->counters[kNumItersCnt], "f111111", 7, direction > 0 ? "up" : "down",
+          stats_->counters[kNumItersCnt], FrameStr(), comp_mask, direction > 0 ? "up" : "down",
           changed_coeffs, order_size, dirty.size(), blocks_to_change, nb, val_threshold,
           jpg_size, 100.0 - (100.0 * est_size) / jpg_size);
       if (!CompareCurrent()) return false;
@@ -785,7 +838,20 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   for (int c = 0; c < 3; ++c)
     for (int k = 0; k < 64; ++k) ones[c][k] = 1;
   if (!SetImageFromQuantization(ones, false)) return false;
-  {
+  if (jpeg_input_ && fac_ == 2) {
+    // OutputJpeg(jpg_in) of a 4:2:0 input: the file is written from the input's own blocks,
+    // MCU padding included (the device frame leaves the padding out): on the host, once
+    if (!WriteJpeg(in_frame_, &best_full_)) return Fail("WriteJpeg", GZ_E_STATE);
+    const size_t size = best_full_.size();
+    Log("Original Out[%7zd]", size);
+    if (!CompareBegin() || !CompareCurrent()) return false;
+    const double score = ScoreJPEG(distance_, (int)size, params_.butteraugli_target);
+    Log(" Score[%.4f]", score);
+    best_score_ = score;   // final_output_->score < 0: always taken (:142)
+    best_size_ = size;
+    best_on_host_ = true;
+    Log(" (*)\n");
+  } else {
     // symbols of the original: coefficient / its quantiser (1 for RGB input, the input's own
     // tables for a JPEG input, whose coefficients are held dequantised)
     SymbolHistogram dc[3], ac[3];
@@ -798,14 +864,45 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
     if (!MaybeOutput(size)) return false;
   }
 
-  QuantMatrix best_q;
-  memcpy(best_q, first_q, sizeof(best_q));
-  if (!SelectMatrix(best_q)) return false;
-  stats_->timers["select_quant_matrix"] = sw.lap();
-  if (!SetImageFromQuantization(best_q, true)) return false;
-  mirror_valid_ = true;
-  if (!SelectFrequencyMasking(1.0)) return false;
-  stats_->timers["select_frequency_masking"] = sw.lap();
+  // ProcessJpegData's loop over the sampling modes (:847-878)
+  bool grey = true;   // IsGrayscale(jpg_in), :782-790
+  for (size_t i = (size_t)coff_[1] * 64; i < (size_t)nblk_ * 64 && grey; ++i) grey = orig_[i] == 0;
+  const bool input_is_420 = fac_ == 2;
+  const int try_420 = (input_is_420 || params_.force_420 || (params_.try_420 && !grey)) ? 1 : 0;
+  const int force_420 = (input_is_420 || params_.force_420) ? 1 : 0;
+  for (int downsample = force_420; downsample <= try_420; ++downsample) {
+    jpg_ncomp_ = 3;
+    mirror_valid_ = false;   // img_ follows the device image from SetImageFromQuantization(best_q) on
+    if (downsample && fac_ == 1) {   // DownsampleImage (:97-104) + SaveToJpegData
+      if (grey) {
+        jpg_ncomp_ = 1;   // Downsample does nothing (output_image.cc:305-308); one component is saved
+      } else {
+        Stopwatch dw;
+        rc = gz_downsample(ctx_, orig_.data());
+        if (rc != GZ_OK) return Fail("gz_downsample", rc);
+        SetFrame(2);
+        stats_->timers["downsample"] = dw.lap();
+      }
+    }
+    QuantMatrix best_q;
+    memcpy(best_q, first_q, sizeof(best_q));
+    bool dist_ok = false;
+    if (!SelectMatrix(best_q, downsample != 0, &dist_ok)) return false;
+    if (!dist_ok)
+      for (int c = 0; c < 3; ++c)
+        for (int k = 0; k < 64; ++k) best_q[c][k] = 1;
+    stats_->timers["select_quant_matrix"] += sw.lap();
+    if (!SetImageFromQuantization(best_q, true)) return false;
+    mirror_valid_ = true;
+    if (!downsample) {
+      if (!SelectFrequencyMasking(7, 1.0, false)) return false;
+    } else {
+      const float ymul = jpg_ncomp_ == 1 ? 1.0f : 0.97f;
+      if (!SelectFrequencyMasking(1, ymul, false)) return false;
+      if (!SelectFrequencyMasking(6, 1.0, true)) return false;
+    }
+    stats_->timers["select_frequency_masking"] += sw.lap();
+  }
   stats_->timers["jpeg_write"] = t_write_;
   stats_->timers["compare"] = t_compare_;
   stats_->timers["quantize"] = t_quant_;
@@ -821,7 +918,9 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->counters["phase B fast steps"] = (int)n_fast_;
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
-  {  // the winner: its head from the host, its scan from the device
+  if (best_on_host_) {
+    *out = best_full_;
+  } else {  // the winner: its head from the host, its scan from the device
     std::vector<uint8_t>& scan = scan_;
     if (scan.size() < (size_t)6 * w * h + 4096) scan.resize((size_t)6 * w * h + 4096);
     size_t n = 0;
@@ -886,14 +985,20 @@ bool Encoder::RunJpeg(const std::string& data, std::string* out) {
     fprintf(stderr, "Only YUV color space input jpeg is supported\n");
     return false;
   }
-  if (!jpg.Is444() || params_.try_420 || params_.force_420) {
-    fprintf(stderr, "guetzli_amd: YUV420 input and the YUV420 modes are not implemented on the "
-                    "device path\n");
+  if (!jpg.Is444() && !jpg.Is420()) {   // ProcessJpegData, :811-824
+    fprintf(stderr, "Unsupported sampling factors:");
+    for (const JpegComponentIn& comp : jpg.components) fprintf(stderr, " %dx%d", comp.h_samp, comp.v_samp);
+    fprintf(stderr, "\n");
+    return false;
+  }
+  if (params_.use_silver_screen && !jpg.Is420() && (params_.try_420 || params_.force_420)) {
+    fprintf(stderr, "guetzli_amd: Params::use_silver_screen is not implemented\n");
     return false;
   }
   const int w = jpg.width, h = jpg.height;
   w_ = w; h_ = h;
   bw_ = (w + 7) / 8; bh_ = (h + 7) / 8; nb_ = bw_ * bh_;
+  SetFrame(jpg.Is420() ? 2 : 1);
   jpeg_input_ = true;
   meta_.strip = params_.clear_metadata;
   meta_.app_data = jpg.app_data;
@@ -907,28 +1012,54 @@ bool Encoder::RunJpeg(const std::string& data, std::string* out) {
     q.index = t.index;
     in_quant_.push_back(q);
   }
-  // RemoveOriginalQuantization (:84-97): coefficients are held dequantised
+  // RemoveOriginalQuantization (:84-97): coefficients are held dequantised; of a 4:2:0
+  // input's blocks those inside the image (CopyFromJpegComponent, output_image.cc:211-230)
   orig_.resize((size_t)3 * nb_ * 64);
   for (int c = 0; c < 3; ++c) {
     const JpegComponentIn& comp = jpg.components[c];
     in_comp_id_[c] = comp.id;
     in_quant_idx_[c] = comp.quant_idx;
     memcpy(q_in_[c], jpg.quant[comp.quant_idx].values, sizeof(q_in_[c]));
-    if (comp.width_in_blocks != bw_ || comp.height_in_blocks != bh_) return Fail("block grid", GZ_E_STATE);
-    int16_t* dst = &orig_[(size_t)c * nb_ * 64];
-    for (size_t i = 0; i < comp.coeffs.size(); ++i) dst[i] = (int16_t)(comp.coeffs[i] * q_in_[c][i % 64]);
+    const int rw = c == 0 ? bw_ : cbw_, rh = c == 0 ? bh_ : cbh_;
+    if (comp.width_in_blocks < rw || comp.height_in_blocks < rh) return Fail("block grid", GZ_E_STATE);
+    int16_t* dst = &orig_[(size_t)coff_[c] * 64];
+    for (int by = 0; by < rh; ++by)
+      for (int bx = 0; bx < rw; ++bx, dst += 64) {
+        const int16_t* src = &comp.coeffs[((size_t)by * comp.width_in_blocks + bx) * 64];
+        for (int k = 0; k < 64; ++k) dst[k] = (int16_t)(src[k] * q_in_[c][k]);
+      }
   }
-  if (w < 32 || h < 32) {
-    // no butteraugli (:832-838): the input re-written with optimised Huffman codes
-    Frame f;
-    FrameFromImage(orig_.data(), q_in_, w, h, &f);
+  if (fac_ == 2) {   // the input as read, for OutputJpeg(jpg_in)
+    Frame& f = in_frame_;
+    f.width = w; f.height = h; f.bw = bw_; f.bh = bh_;
     f.ncomp = 3;
-    f.quant = in_quant_;
+    f.mcu_cols = jpg.mcu_cols; f.mcu_rows = jpg.mcu_rows;
     for (int c = 0; c < 3; ++c) {
+      const JpegComponentIn& comp = jpg.components[c];
+      f.samp[c] = comp.h_samp;
+      f.cw[c] = comp.width_in_blocks;
+      f.ch[c] = comp.height_in_blocks;
+      f.coeffs[c] = comp.coeffs;
       f.quant_idx[c] = in_quant_idx_[c];
       f.comp_id[c] = in_comp_id_[c];
     }
+    f.quant = in_quant_;
     f.meta = &meta_;
+  }
+  if (w < 32 || h < 32) {
+    // no butteraugli (:832-838): the input re-written with optimised Huffman codes
+    Frame f444;
+    if (fac_ == 1) {
+      FrameFromImage(orig_.data(), q_in_, w, h, &f444);
+      f444.ncomp = 3;
+      f444.quant = in_quant_;
+      for (int c = 0; c < 3; ++c) {
+        f444.quant_idx[c] = in_quant_idx_[c];
+        f444.comp_id[c] = in_comp_id_[c];
+      }
+      f444.meta = &meta_;
+    }
+    const Frame& f = fac_ == 2 ? in_frame_ : f444;
     if (!WriteJpeg(f, out)) return Fail("WriteJpeg", GZ_E_STATE);
     Log("Original Out[%7zd]", out->size());
     Log(" <image too small for Butteraugli>\n");
@@ -941,7 +1072,7 @@ bool Encoder::RunJpeg(const std::string& data, std::string* out) {
     std::vector<uint8_t> blank((size_t)3 * w * h, 0);
     ctx_ = gz_create(params_.device, w, h, blank.data(), params_.butteraugli_target, &err);
     if (!ctx_) return Fail("gz_create", err);
-    int rc = gz_set_orig_coeffs(ctx_, orig_.data());
+    int rc = fac_ == 2 ? gz_set_orig_coeffs_420(ctx_, orig_.data()) : gz_set_orig_coeffs(ctx_, orig_.data());
     if (rc == GZ_OK) rc = gz_quantize(ctx_, nullptr, nullptr);
     if (rc == GZ_OK) rc = gz_reconstruct(ctx_, blank.data(), nullptr);
     if (rc == GZ_OK) rc = gz_set_rgb(ctx_, blank.data());
@@ -963,8 +1094,8 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
             "proceed anyway, please edit the source code.\n");
     return false;
   }
-  if (params_.try_420 || params_.force_420) {
-    fprintf(stderr, "guetzli_amd: the YUV420 modes are not implemented on the device path\n");
+  if (params_.use_silver_screen && (params_.try_420 || params_.force_420)) {
+    fprintf(stderr, "guetzli_amd: Params::use_silver_screen is not implemented\n");
     return false;
   }
   if (w < 0 || w >= 1 << 16 || h < 0 || h >= 1 << 16 || rgb.size() != (size_t)3 * w * h) {
@@ -973,6 +1104,7 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
   }
   w_ = w; h_ = h;
   bw_ = (w + 7) / 8; bh_ = (h + 7) / 8; nb_ = bw_ * bh_;
+  SetFrame(1);
   if (w < 32 || h < 32) {
     // "image too small for Butteraugli" (processor.cc:832-838, :940): the reference emits
     // the unquantised JPEG of EncodeRGBToJpeg; the forward transform runs on the device.
@@ -1030,66 +1162,97 @@ bool Process(const Params& params, ProcessStats* stats, const std::string& jpeg_
 // ---------------------------------------------------------------- C wrapper (ctypes) ---
 extern "C" {
 
-// quality < 0: `target` is used as the butteraugli target directly.
-long gzh_process(const uint8_t* rgb, int w, int h, double quality, float target, int device,
-                 uint8_t* out, long cap, char* trace, long trace_cap, char* timers,
-                 long timers_cap) {
+long gzh_write_jpeg_factor(const int16_t* coeffs, int w, int h, const int* q, int original,
+                           int factor, uint8_t* out, long cap);
+long gzh_jpeg_head_factor(const uint32_t* counts, const int* q, int w, int h, int ncomp, int factor,
+                          uint8_t* head_out, long cap, uint8_t* depth, uint16_t* code);
+
+// Every entry point below catches what the C++ underneath may throw (std::bad_alloc on a huge
+// declared image, ...): nothing propagates through the C boundary.  Return values: >= 0 the
+// size of the result (copied only if it fits the caller's buffer: a larger size asks for a
+// retry with that much room), -1 failure (message on stderr), -2 exception.
+#define GZH_GUARD_BEGIN try {
+#define GZH_GUARD_END                                                        \
+  } catch (const std::exception& e) {                                        \
+    fprintf(stderr, "guetzli_amd: %s\n", e.what());                          \
+    return -2;                                                               \
+  } catch (...) {                                                            \
+    fprintf(stderr, "guetzli_amd: unknown exception\n");                     \
+    return -2;                                                               \
+  }
+
+static void CopyText(const std::string& s, char* dst, long cap) {
+  if (!dst || cap <= 0) return;
+  const size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+  memcpy(dst, s.data(), n);
+  dst[n] = 0;
+}
+
+// guetzli::Process with every field of Params.  jpeg_len < 0: `data` is packed RGB of w x h,
+// otherwise JPEG bytes.  quality < 0: `target` is the butteraugli target directly.
+// iparams: device, clear_metadata, try_420, force_420, use_silver_screen,
+// zeroing_greedy_lookahead, new_zeroing_model.
+long gzh_process_params(const uint8_t* data, long jpeg_len, int w, int h, double quality,
+                        float target, const int* iparams, uint8_t* out, long cap, char* trace,
+                        long trace_cap, char* timers, long timers_cap) {
+  GZH_GUARD_BEGIN
   guetzli_amd::Params params;
   params.butteraugli_target =
       quality >= 0 ? (float)guetzli_amd::ButteraugliScoreForQuality(quality) : target;
-  params.device = device;
+  params.device = iparams[0];
+  params.clear_metadata = iparams[1] != 0;
+  params.try_420 = iparams[2] != 0;
+  params.force_420 = iparams[3] != 0;
+  params.use_silver_screen = iparams[4] != 0;
+  params.zeroing_greedy_lookahead = iparams[5];
+  params.new_zeroing_model = iparams[6] != 0;
   guetzli_amd::ProcessStats stats;
   std::string dbg;
   if (trace) stats.debug_output = &dbg;
-  static thread_local std::vector<uint8_t> v;   // Process takes a vector, as the reference's does
-  v.assign(rgb, rgb + (size_t)3 * w * h);
   std::string jpg;
-  if (!guetzli_amd::Process(params, &stats, v, w, h, &jpg)) return -1;
-  if ((long)jpg.size() <= cap) memcpy(out, jpg.data(), jpg.size());
-  if (trace && trace_cap > 0) {
-    const size_t n = std::min<size_t>(dbg.size(), (size_t)trace_cap - 1);
-    memcpy(trace, dbg.data(), n);
-    trace[n] = 0;
+  bool ok;
+  if (jpeg_len < 0) {
+    static thread_local std::vector<uint8_t> v;   // Process takes a vector, as the reference's does
+    v.assign(data, data + (size_t)3 * w * h);
+    ok = guetzli_amd::Process(params, &stats, v, w, h, &jpg);
+  } else {
+    std::string in((const char*)data, (size_t)jpeg_len);
+    ok = guetzli_amd::Process(params, &stats, in, &jpg);
   }
+  if (!ok) return -1;
+  if ((long)jpg.size() <= cap) memcpy(out, jpg.data(), jpg.size());
+  CopyText(dbg, trace, trace_cap);
   if (timers && timers_cap > 0) {
-    std::string s;
+    std::string t;
     for (const auto& kv : stats.timers) {
       char buf[128];
       snprintf(buf, sizeof(buf), "%s=%.6f;", kv.first.c_str(), kv.second);
-      s += buf;
+      t += buf;
     }
     for (const auto& kv : stats.counters) {
       char buf[128];
       snprintf(buf, sizeof(buf), "#%s=%d;", kv.first.c_str(), kv.second);
-      s += buf;
+      t += buf;
     }
-    const size_t n = std::min<size_t>(s.size(), (size_t)timers_cap - 1);
-    memcpy(timers, s.data(), n);
-    timers[n] = 0;
+    CopyText(t, timers, timers_cap);
   }
   return (long)jpg.size();
+  GZH_GUARD_END
+}
+
+long gzh_process(const uint8_t* rgb, int w, int h, double quality, float target, int device,
+                 uint8_t* out, long cap, char* trace, long trace_cap, char* timers,
+                 long timers_cap) {
+  const int ip[7] = {device, 1, 0, 0, 0, 3, 1};
+  return gzh_process_params(rgb, -1, w, h, quality, target, ip, out, cap, trace, trace_cap, timers,
+                            timers_cap);
 }
 
 // Process(params, stats, jpeg_data, &out); clear_metadata as Params::clear_metadata.
 long gzh_process_jpeg(const uint8_t* data, long len, double quality, float target, int device,
                       int clear_metadata, uint8_t* out, long cap, char* trace, long trace_cap) {
-  guetzli_amd::Params params;
-  params.butteraugli_target =
-      quality >= 0 ? (float)guetzli_amd::ButteraugliScoreForQuality(quality) : target;
-  params.device = device;
-  params.clear_metadata = clear_metadata != 0;
-  guetzli_amd::ProcessStats stats;
-  std::string dbg;
-  if (trace) stats.debug_output = &dbg;
-  std::string in((const char*)data, (size_t)len), jpg;
-  if (!guetzli_amd::Process(params, &stats, in, &jpg)) return -1;
-  if ((long)jpg.size() <= cap) memcpy(out, jpg.data(), jpg.size());
-  if (trace && trace_cap > 0) {
-    const size_t n = std::min<size_t>(dbg.size(), (size_t)trace_cap - 1);
-    memcpy(trace, dbg.data(), n);
-    trace[n] = 0;
-  }
-  return (long)jpg.size();
+  const int ip[7] = {device, clear_metadata, 0, 0, 0, 3, 1};
+  return gzh_process_params(data, len, 0, 0, quality, target, ip, out, cap, trace, trace_cap, nullptr, 0);
 }
 
 double gzh_butteraugli_score_for_quality(double q) {
@@ -1103,6 +1266,7 @@ double gzh_butteraugli_score_for_quality(double q) {
 // then the int16 coefficients of every component.  Returns the dump size (copied if it fits),
 // or -1 if the stream is rejected.
 long gzh_read_jpeg(const uint8_t* data, long len, uint8_t* out, long cap) {
+  GZH_GUARD_BEGIN
   guetzli_amd::JpegInput jpg;
   std::string err;
   if (!guetzli_amd::ReadJpeg(data, (size_t)len, &jpg, &err)) return -1;
@@ -1127,12 +1291,14 @@ long gzh_read_jpeg(const uint8_t* data, long len, uint8_t* out, long cap) {
   for (const auto& c : jpg.components) d.append((const char*)c.coeffs.data(), c.coeffs.size() * 2);
   if ((long)d.size() <= cap) memcpy(out, d.data(), d.size());
   return (long)d.size();
+  GZH_GUARD_END
 }
 
 // ReadPNG (guetzli.cc:47-152): PNG bytes -> packed RGB with alpha blended on black.  Returns
 // 3*w*h (copied to out if it fits) and the dimensions in wh[0..1], or -1 if the stream is
 // rejected (message on stderr).
 long gzh_read_png(const uint8_t* data, long len, int* wh, uint8_t* out, long cap) {
+  GZH_GUARD_BEGIN
   std::vector<uint8_t> rgb;
   std::string err;
   int w = 0, h = 0;
@@ -1144,23 +1310,33 @@ long gzh_read_png(const uint8_t* data, long len, int* wh, uint8_t* out, long cap
   wh[1] = h;
   if ((long)rgb.size() <= cap) memcpy(out, rgb.data(), rgb.size());
   return (long)rgb.size();
+  GZH_GUARD_END
 }
 
 // WriteJpeg of an image given by dequantised coefficients + quant matrices (test hook).
 long gzh_write_jpeg(const int16_t* coeffs, int w, int h, const int* q, int original,
                     uint8_t* out, long cap) {
+  return gzh_write_jpeg_factor(coeffs, w, h, q, original, 1, out, cap);
+}
+
+// The same for a frame with chroma subsampling factor 1 or 2 (coefficients in the frame layout
+// of include/guetzli_amd.h).
+long gzh_write_jpeg_factor(const int16_t* coeffs, int w, int h, const int* q, int original,
+                           int factor, uint8_t* out, long cap) {
+  GZH_GUARD_BEGIN
   guetzli_amd::Frame f;
   if (original) {
     guetzli_amd::FrameFromOriginal(coeffs, w, h, &f);
   } else {
     int qq[3][64];
     memcpy(qq, q, sizeof(qq));
-    guetzli_amd::FrameFromImage(coeffs, qq, w, h, &f);
+    guetzli_amd::FrameFromImageFactor(coeffs, qq, w, h, factor, &f);
   }
   std::string s;
   if (!guetzli_amd::WriteJpeg(f, &s)) return -1;
   if ((long)s.size() <= cap) memcpy(out, s.data(), s.size());
   return (long)s.size();
+  GZH_GUARD_END
 }
 
 // Marker segments + Huffman codes from symbol counts (test hook of BuildJpegHead):
@@ -1169,6 +1345,13 @@ long gzh_write_jpeg(const int16_t* coeffs, int w, int h, const int* q, int origi
 long gzh_jpeg_head(const uint32_t* counts, const int* q, int w, int h, int ncomp,
                    uint8_t* head_out, long cap, uint8_t* depth /*[2][3][256]*/,
                    uint16_t* code /*[2][3][256]*/) {
+  return gzh_jpeg_head_factor(counts, q, w, h, ncomp, 1, head_out, cap, depth, code);
+}
+
+long gzh_jpeg_head_factor(const uint32_t* counts, const int* q, int w, int h, int ncomp, int factor,
+                          uint8_t* head_out, long cap, uint8_t* depth /*[2][3][256]*/,
+                          uint16_t* code /*[2][3][256]*/) {
+  GZH_GUARD_BEGIN
   guetzli_amd::SymbolHistogram dc[3], ac[3];
   for (int c = 0; c < 3; ++c)
     for (int i = 0; i < 256; ++i) {
@@ -1178,13 +1361,14 @@ long gzh_jpeg_head(const uint32_t* counts, const int* q, int w, int h, int ncomp
   guetzli_amd::Frame f;
   int qq[3][64];
   if (q) memcpy(qq, q, sizeof(qq));
-  guetzli_amd::FrameTables(q ? qq : nullptr, w, h, ncomp, &f);
+  guetzli_amd::FrameTablesFactor(q ? qq : nullptr, w, h, ncomp, factor, &f);
   guetzli_amd::JpegHead head;
   if (!guetzli_amd::BuildJpegHead(f, dc, ac, &head)) return -1;
   if ((long)head.bytes.size() <= cap) memcpy(head_out, head.bytes.data(), head.bytes.size());
   memcpy(depth, head.depth, sizeof(head.depth));
   memcpy(code, head.code, sizeof(head.code));
   return (long)head.bytes.size();
+  GZH_GUARD_END
 }
 
 }  // extern "C"

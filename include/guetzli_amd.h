@@ -17,10 +17,15 @@
  *   - host pointers are ordinary pageable memory unless named `dev_*`.
  *   - layouts
  *       rgb     : uint8 packed, rgb[(y*w + x)*3 + c]                (guetzli.cc ReadPNG)
- *       coeffs  : int16 DEQUANTISED DCT coefficients, component-major then block-major,
- *                 coeffs[(c*nb + by*bw + bx)*64 + k], bw=ceil(w/8), bh=ceil(h/8), nb=bw*bh
+ *       coeffs  : int16 DEQUANTISED DCT coefficients, component-major then block-major
  *                 (= OutputImageComponent::coeffs_, output_image.h:33-40, one after the
- *                 other for c = 0,1,2; 4:4:4 only)
+ *                 other for c = 0,1,2).  4:4:4 frame: coeffs[(c*nb + by*bw + bx)*64 + k],
+ *                 bw=ceil(w/8), bh=ceil(h/8), nb=bw*bh.  4:2:0 frame (the two chroma
+ *                 components Reset(2, 2), output_image.cc:40-49): nb luma blocks, then
+ *                 nbc = ceil(w/16)*ceil(h/16) blocks of Cb, then nbc of Cr -- no MCU padding
+ *                 (SaveToJpegData's padding blocks, :386-404, are implied).  A context starts
+ *                 in 4:4:4; gz_downsample / gz_set_orig_coeffs_420 switch it to 4:2:0,
+ *                 gz_encode_rgb / gz_set_orig_coeffs back; gz_frame_layout tells.
  *       q       : int[3][64] quantisation matrices in natural (row-major) order
  *       planes  : float, plane[y*w + x] (no row padding on the host side)
  */
@@ -44,7 +49,7 @@ extern "C" {
 typedef struct gz_ctx gz_ctx;
 
 /* Library / device ------------------------------------------------------------ */
-int gz_abi_version(void);                 /* currently 1 */
+int gz_abi_version(void);                 /* currently 2 */
 /* Device and pinned host memory of destroyed contexts is kept (per device, exact sizes, at
  * most GZ_POOL_MB megabytes of device memory, default 16384) for the next context of the same
  * image size: a batch of same-sized images allocates once.  gz_trim_pool releases everything
@@ -61,9 +66,8 @@ const char* gz_last_error(const gz_ctx* ctx);
  * (butteraugli.cc:784-791).  `target` is Params::butteraugli_target
  * (processor.h:30).  Requires w,h >= 8 (butteraugli) -- Process() itself only builds a
  * comparator when w,h >= 32 (processor.cc:940).  Returns NULL on failure, *err set.
- * gz_create makes `device` the calling thread's current HIP device; later calls on the
- * context (and gz_destroy) expect it to be current still -- true for the usual one thread per
- * image, or one process per GPU. */
+ * Every entry point that takes a context runs on the context's device and leaves the calling
+ * thread's current HIP device as it found it (a thread may own contexts on several GPUs). */
 gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, int* err);
 void gz_destroy(gz_ctx* ctx);
 /* Replace the original image of an existing context (same w, h): what constructing a new
@@ -93,6 +97,23 @@ int gz_encode_rgb_only(int device, const uint8_t* rgb, int w, int h, int16_t* co
 /* Upload original (unquantised) coefficients computed elsewhere (JPEG input path:
  * JPEGData after RemoveOriginalQuantization, processor.cc:84-97). */
 int gz_set_orig_coeffs(gz_ctx* ctx, const int16_t* coeffs);
+/* The same for a YUV 4:2:0 input (jpg.Is420(), processor.cc:814-815): luma blocks on the
+ * 8x8 grid, then the two chroma components on the 16x16 grid (the input's MCU padding left
+ * out, as OutputImageComponent::CopyFromJpegComponent does, output_image.cc:211-230).  The
+ * context's frame becomes 4:2:0. */
+int gz_set_orig_coeffs_420(gz_ctx* ctx, const int16_t* coeffs);
+/* OutputImage::Downsample (output_image.cc:304-340) as Processor::DownsampleImage calls it
+ * (processor.cc:97-104; use_silver_screen == false) on the ORIGINAL coefficients of a 4:4:4
+ * frame: ToFloatPixels (:99-121) of the three components, PreProcessChannel
+ * (preprocess_downsample.cc:157-279) on V, then on U -- sharpen the channel where the image
+ * is red and dark, blur it where it is smooth -- and SetDownsampledCoefficients (:265-300) of
+ * U and V by 2 x 2.  Luma is kept.  The context's frame becomes 4:2:0; coeffs_out (may be NULL)
+ * receives the new original, nb + 2*nbc blocks.  The caller skips the call for a greyscale
+ * image, as the reference does (:305-308). */
+int gz_downsample(gz_ctx* ctx, int16_t* coeffs_out);
+/* Current frame: chroma subsampling factor (1 or 2), luma blocks, blocks per chroma
+ * component.  Any pointer may be NULL. */
+int gz_frame_layout(gz_ctx* ctx, int* chroma_factor, int* luma_blocks, int* chroma_blocks);
 
 /* Candidate := original, then OutputImage::ApplyGlobalQuantization(q)
  * (output_image.cc:232-243,342-346; Quantize quantize.h:24-29).  This is the coefficient
@@ -106,11 +127,13 @@ int gz_quantize(gz_ctx* ctx, const int* q, int16_t* coeffs_out);
  * by*bw + bx, all distinct; blocks holds n * 3 * 64 int16 (component-major per block:
  * Y,Cb,Cr). */
 int gz_set_coeffs(gz_ctx* ctx, const int16_t* coeffs);
+/* (4:4:4 frames only) */
 int gz_set_coeff_blocks(gz_ctx* ctx, const int32_t* block_index, int n,
                         const int16_t* blocks);
 int gz_get_coeffs(gz_ctx* ctx, int16_t* coeffs_out);
 /* Single-coefficient form of SetCoeffBlock: candidate[pos[i]] = val[i] for n distinct
- * positions pos = (c*nb + block)*64 + k (what one phase-B iteration changes). */
+ * positions in the frame's coefficient array: pos = (first block of component c + block)*64 + k
+ * (what one phase-B iteration changes). */
 int gz_apply_coeff_edits(gz_ctx* ctx, const int32_t* pos, const int16_t* val, int n);
 
 /* Candidate -> pixels, for parity checks and for callers that want the decoded image:
@@ -174,6 +197,11 @@ int gz_time_compare(gz_ctx* ctx, int iters, float* total_ms);
  * block_weight: nb floats, in/out exactly like the reference's vector. */
 int gz_block_weights(gz_ctx* ctx, int direction, int max_block_dist, double target_mul,
                      int use_distmap, float* block_weight);
+/* The same for blocks of 8*factor x 8*factor pixels (factor_x = factor_y = factor, 1 or 2:
+ * the chroma grid of a 4:2:0 frame); block_weight has ceil(w/(8 factor))*ceil(h/(8 factor))
+ * entries. */
+int gz_block_weights_factor(gz_ctx* ctx, int direction, int max_block_dist, double target_mul,
+                            int use_distmap, int factor, float* block_weight);
 
 /* Per-block zeroing search ---------------------------------------------------------
  * gz_block_zeroing_orders: phase A of Processor::SelectFrequencyMasking
@@ -191,6 +219,17 @@ int gz_block_weights(gz_ctx* ctx, int direction, int max_block_dist, double targ
  * only, where gz_order_build reads them. */
 int gz_block_zeroing_orders(gz_ctx* ctx, int lookahead, int new_model, int32_t* offsets,
                             uint8_t* idx, float* err, int cap);
+/* The same for any comp_mask of SelectFrequencyMasking (processor.cc:539-590): candidates come
+ * from the components in the mask only, and the grid is that of the mask's last component
+ * (:546-552).  4:4:4 frame: any mask, the 8x8 grid.  4:2:0 frame: mask 1 (luma; 8x8 grid,
+ * chroma pixels fixed) or mask 6 (chroma; ceil(w/16) x ceil(h/16) grid -- every candidate is
+ * compared on the up to four 8x8 blocks of its 16x16 area and scored by the largest error,
+ * processor.cc:420-430, with the 2x2-subsampled pixel model of
+ * OutputImageComponent::UpdatePixelsForBlock, output_image.cc:146-203).  offsets has one
+ * entry per block of that grid plus one.  Phase B's order functions below then work on the
+ * same grid and mask. */
+int gz_block_zeroing_orders_masked(gz_ctx* ctx, int comp_mask, int lookahead, int new_model,
+                                   int32_t* offsets, uint8_t* idx, float* err, int cap);
 /* Host-only helper, exported for tests: the ranked input_order of
  * ComputeBlockZeroingOrder (processor.cc:381-400) for every block, as CSR, by std::sort
  * itself.  gz_block_zeroing_orders ranks on the device. */
@@ -279,6 +318,10 @@ int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);
  * processor.cc:139-148); gz_jpeg_scan_bytes downloads the last (kept = 0) or the kept
  * (kept = 1) scan as stuffed bytes. */
 int gz_jpeg_histograms(gz_ctx* ctx, const int* q, uint32_t* counts);
+/* In a 4:2:0 frame the luma DC statistics depend on whether the chroma components are
+ * written (MCU order and padding blocks, output_image.cc:357-404) or not (ncomp == 1: luma
+ * alone in raster order): this variant says which.  gz_jpeg_histograms == ncomp 3. */
+int gz_jpeg_histograms_ncomp(gz_ctx* ctx, const int* q, int ncomp, uint32_t* counts);
 int gz_jpeg_scan(gz_ctx* ctx, int ncomp, const uint8_t* depth, const uint16_t* code,
                  uint64_t* scan_bytes);
 int gz_jpeg_scan_keep(gz_ctx* ctx);

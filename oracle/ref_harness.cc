@@ -469,4 +469,219 @@ long ref_process_jpeg(const uint8_t* data, long len, float butteraugli_target,
   return (long)jpg.size();
 }
 
+
+// ------------------------------------------------------------------ YUV 4:2:0 ----
+// Frame layout used across this repo for a 4:2:0 image: nb luma blocks (8x8 grid), then
+// nbc = ceil(w/16)*ceil(h/16) blocks of Cb, then nbc of Cr.
+namespace {
+void FillOutputImage420(guetzli::OutputImage* img, const int16_t* coeffs) {
+  size_t at = 0;
+  for (int c = 0; c < 3; ++c) {
+    guetzli::OutputImageComponent& comp = img->component(c);
+    if (c > 0) comp.Reset(2, 2);
+    const int bw = comp.width_in_blocks(), bh = comp.height_in_blocks();
+    for (int by = 0; by < bh; ++by)
+      for (int bx = 0; bx < bw; ++bx, ++at) comp.SetCoeffBlock(bx, by, coeffs + at * 64);
+  }
+}
+void DumpOutputImage(const guetzli::OutputImage& img, int16_t* out) {
+  size_t at = 0;
+  for (int c = 0; c < 3; ++c) {
+    const guetzli::OutputImageComponent& comp = img.component(c);
+    const size_t n = (size_t)comp.width_in_blocks() * comp.height_in_blocks() * 64;
+    memcpy(out + at, comp.coeffs(), n * sizeof(int16_t));
+    at += n;
+  }
+}
+}  // namespace
+
+// OutputImage::Downsample with Processor::DownsampleImage's configuration
+// (processor.cc:97-104): 4:4:4 coefficients in, 4:2:0 frame out.  Returns the number of
+// blocks written (nb + 2*nbc; 3*nb if the image is greyscale and nothing happens).
+int ref_downsample(const int16_t* coeffs, int w, int h, int use_silver_screen, int16_t* out) {
+  guetzli::OutputImage img(w, h);
+  FillOutputImage(&img, coeffs);
+  guetzli::OutputImage::DownsampleConfig cfg;
+  cfg.use_silver_screen = use_silver_screen != 0;
+  img.Downsample(cfg);
+  DumpOutputImage(img, out);
+  int n = 0;
+  for (int c = 0; c < 3; ++c) n += img.component(c).width_in_blocks() * img.component(c).height_in_blocks();
+  return n;
+}
+
+// 4:2:0 coefficients -> optional quantisation -> pixels (OutputImage::ToSRGB / ToLinearRGB with
+// the 2x2 pixel model of UpdatePixelsForBlock).  `shuffle` != 0 first applies random extra
+// SetCoeffBlock calls (garbage, then the real block again) in a random order: the pixel cache
+// must not depend on the update history.
+void ref_reconstruct420(const int16_t* coeffs, int w, int h, const int* q, int shuffle,
+                        int16_t* coeffs_out, uint8_t* srgb, float* linear) {
+  guetzli::OutputImage img(w, h);
+  FillOutputImage420(&img, coeffs);
+  if (shuffle) {
+    unsigned rng = (unsigned)shuffle;
+    auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+    const int nb = img.component(0).width_in_blocks() * img.component(0).height_in_blocks();
+    for (int rep = 0; rep < 3; ++rep)
+      for (int c = 1; c < 3; ++c) {
+        guetzli::OutputImageComponent& comp = img.component(c);
+        const int bw = comp.width_in_blocks(), bh = comp.height_in_blocks();
+        const int16_t* base = coeffs + ((size_t)nb + (size_t)(c - 1) * bw * bh) * 64;
+        for (int t = 0; t < bw * bh; ++t) {
+          const int b = next() % (bw * bh);
+          int16_t junk[64];
+          for (int k = 0; k < 64; ++k) junk[k] = (int16_t)((int)(next() % 401) - 200);
+          comp.SetCoeffBlock(b % bw, b / bw, junk);
+          const int b2 = next() % (bw * bh);
+          comp.SetCoeffBlock(b2 % bw, b2 / bw, base + (size_t)b2 * 64);
+          comp.SetCoeffBlock(b % bw, b / bw, base + (size_t)b * 64);
+        }
+      }
+  }
+  if (q) {
+    int qq[3][guetzli::kDCTBlockSize];
+    memcpy(qq, q, sizeof(qq));
+    img.ApplyGlobalQuantization(qq);
+  }
+  if (coeffs_out) DumpOutputImage(img, coeffs_out);
+  if (srgb) {
+    std::vector<uint8_t> v = img.ToSRGB();
+    memcpy(srgb, v.data(), v.size());
+  }
+  if (linear) {
+    std::vector<std::vector<float> > rgb(3, std::vector<float>((size_t)w * h));
+    img.ToLinearRGB(&rgb);
+    for (int c = 0; c < 3; ++c)
+      memcpy(linear + (size_t)c * w * h, rgb[c].data(), sizeof(float) * w * h);
+  }
+}
+
+float ref_comparator_compare420(void* p, const int16_t* coeffs, float* distmap) {
+  RefComparator* r = (RefComparator*)p;
+  guetzli::OutputImage img(r->w, r->h);
+  FillOutputImage420(&img, coeffs);
+  r->cmp->Compare(img);
+  if (distmap) {
+    std::vector<float> d = r->cmp->distmap();
+    memcpy(distmap, d.data(), d.size() * sizeof(float));
+  }
+  return r->cmp->distmap_aggregate();
+}
+
+void ref_comparator_block_weights_factor(void* p, int direction, int max_block_dist,
+                                         double target_mul, int factor, const float* distmap,
+                                         float* block_weight) {
+  RefComparator* r = (RefComparator*)p;
+  std::vector<float> d(distmap, distmap + (size_t)r->w * r->h);
+  const int s = 8 * factor;
+  const int bw = (r->w + s - 1) / s, bh = (r->h + s - 1) / s;
+  std::vector<float> wgt(block_weight, block_weight + (size_t)bw * bh);
+  r->cmp->ComputeBlockErrorAdjustmentWeights(direction, max_block_dist, target_mul,
+                                             factor, factor, d, &wgt);
+  memcpy(block_weight, wgt.data(), wgt.size() * sizeof(float));
+}
+
+// Phase A of SelectFrequencyMasking (processor.cc:554-590) for any comp_mask on a 4:4:4
+// (frame420 == 0) or 4:2:0 frame: CSR arrays over the grid of the mask's last component.
+int ref_block_zeroing_orders_masked(void* p, const int16_t* coeffs, const int16_t* orig,
+                                    int frame420, int comp_mask, int lookahead, int new_model,
+                                    int32_t* offsets, uint8_t* idx, float* err, int cap) {
+  RefComparator* r = (RefComparator*)p;
+  const int w = r->w, h = r->h;
+  guetzli::OutputImage img(w, h);
+  if (frame420) FillOutputImage420(&img, coeffs); else FillOutputImage(&img, coeffs);
+  int last_c = 0;
+  for (int c = 0; c < 3; ++c) if (comp_mask & (1 << c)) last_c = c;
+  const int factor = img.component(last_c).factor_x();
+  const int gw = (w + 8 * factor - 1) / (8 * factor), gh = (h + 8 * factor - 1) / (8 * factor);
+  size_t coff[3] = {0, 0, 0};
+  for (int c = 1; c < 3; ++c)
+    coff[c] = coff[c - 1] + (size_t)img.component(c - 1).width_in_blocks() * img.component(c - 1).height_in_blocks();
+  guetzli::Processor proc;
+  proc.params_.zeroing_greedy_lookahead = lookahead;
+  proc.params_.new_zeroing_model = new_model != 0;
+  proc.comparator_ = r->cmp;
+  proc.stats_ = &r->stats;
+  r->cmp->StartBlockComparisons();
+  std::vector<guetzli::CoeffData> order;
+  int total = 0;
+  for (int by = 0, bix = 0; by < gh; ++by) {
+    for (int bx = 0; bx < gw; ++bx, ++bix) {
+      int16_t block[192] = {0}, oblock[192] = {0};
+      for (int c = 0; c < 3; ++c) {
+        if (!(comp_mask & (1 << c))) continue;
+        memcpy(block + 64 * c, coeffs + (coff[c] + bix) * 64, 128);
+        memcpy(oblock + 64 * c, orig + (coff[c] + bix) * 64, 128);
+      }
+      order.clear();
+      proc.ComputeBlockZeroingOrder(block, oblock, bx, by, factor, factor, (uint8_t)comp_mask, &img, &order);
+      offsets[bix] = total;
+      for (size_t i = 0; i < order.size(); ++i) {
+        if (total < cap) {
+          idx[total] = (uint8_t)order[i].idx;
+          err[total] = order[i].block_err;
+        }
+        ++total;
+      }
+    }
+  }
+  offsets[gw * gh] = total;
+  r->cmp->FinishBlockComparisons();
+  return total <= cap ? total : -total;
+}
+
+// SaveToJpegData + WriteJpeg of a 4:2:0 image (coefficients before quantisation by q).
+long ref_write_jpeg420(const int16_t* coeffs, int w, int h, const int* q, uint8_t* out, long cap) {
+  guetzli::OutputImage img(w, h);
+  FillOutputImage420(&img, coeffs);
+  int qq[3][guetzli::kDCTBlockSize];
+  memcpy(qq, q, sizeof(qq));
+  img.ApplyGlobalQuantization(qq);
+  guetzli::JPEGData jpg;
+  std::vector<int16_t> zero((size_t)3 * ((w + 7) / 8) * ((h + 7) / 8) * 64);
+  JpegDataFromCoeffs(zero.data(), w, h, &jpg);
+  img.SaveToJpegData(&jpg);
+  std::string s;
+  guetzli::JPEGOutput o(guetzli::GuetzliStringOut, &s);
+  if (!guetzli::WriteJpeg(jpg, true, o)) return -1;
+  if ((long)s.size() <= cap) memcpy(out, s.data(), s.size());
+  return (long)s.size();
+}
+
+// guetzli::Process with every field of Params (processor.h:29-37).  jpeg_len < 0: `data` is
+// packed RGB of w x h; otherwise JPEG bytes.
+long ref_process_params(const uint8_t* data, long jpeg_len, int w, int h, float butteraugli_target,
+                        int clear_metadata, int try_420, int force_420, int use_silver_screen,
+                        int lookahead, int new_model, uint8_t* out, long cap, char* trace,
+                        long trace_cap) {
+  guetzli::Params params;
+  params.butteraugli_target = butteraugli_target;
+  params.clear_metadata = clear_metadata != 0;
+  params.try_420 = try_420 != 0;
+  params.force_420 = force_420 != 0;
+  params.use_silver_screen = use_silver_screen != 0;
+  params.zeroing_greedy_lookahead = lookahead;
+  params.new_zeroing_model = new_model != 0;
+  guetzli::ProcessStats stats;
+  std::string dbg;
+  if (trace) stats.debug_output = &dbg;
+  std::string jpg;
+  bool ok;
+  if (jpeg_len < 0) {
+    std::vector<uint8_t> v(data, data + (size_t)3 * w * h);
+    ok = guetzli::Process(params, &stats, v, w, h, &jpg);
+  } else {
+    std::string in((const char*)data, (size_t)jpeg_len);
+    ok = guetzli::Process(params, &stats, in, &jpg);
+  }
+  if (!ok) return -1;
+  if ((long)jpg.size() <= cap) memcpy(out, jpg.data(), jpg.size());
+  if (trace && trace_cap > 0) {
+    const size_t n = std::min<size_t>(dbg.size(), (size_t)trace_cap - 1);
+    memcpy(trace, dbg.data(), n);
+    trace[n] = 0;
+  }
+  return (long)jpg.size();
+}
+
 }  // extern "C"

@@ -51,6 +51,15 @@ _REF_ONLY = {
     "idct_double": (None, [_P]),
     "downsample_plain": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "process_jpeg": (C.c_long, [_P, C.c_long, C.c_float, C.c_int, _P, C.c_long, _P, C.c_long]),
+    "downsample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "reconstruct420": (None, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "comparator_compare420": (C.c_float, [_P, _P, _P]),
+    "comparator_block_weights_factor": (None, [_P, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P]),
+    "block_zeroing_orders_masked": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
+                                              _P, C.c_int]),
+    "write_jpeg420": (C.c_long, [_P, C.c_int, C.c_int, _P, _P, C.c_long]),
+    "process_params": (C.c_long, [_P, C.c_long, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_long, _P, C.c_long]),
 }
 _ORC_ONLY = {
     "dct_double": (None, [_P, C.c_int]),
@@ -243,6 +252,63 @@ class Checker:
         assert n <= cap
         return out[:n].tobytes(), (tr.value.decode() if tr else None)
 
+    # ---- YUV 4:2:0 (frame layout: nb luma blocks, nbc Cb, nbc Cr) ----------------
+    @staticmethod
+    def blocks420(w, h):
+        nb = ((w + 7) // 8) * ((h + 7) // 8)
+        nbc = ((w + 15) // 16) * ((h + 15) // 16)
+        return nb, nbc
+
+    def downsample(self, coeffs, w, h, silver=False):
+        """OutputImage::Downsample as Processor::DownsampleImage configures it."""
+        co = np.ascontiguousarray(coeffs, np.int16)
+        nb, nbc = self.blocks420(w, h)
+        out = np.zeros((3 * nb, 64), np.int16)
+        n = self._downsample(_ptr(co), w, h, int(silver), _ptr(out))
+        return out[:n].copy()
+
+    def reconstruct420(self, coeffs, w, h, q=None, shuffle=0):
+        co = np.ascontiguousarray(coeffs, np.int16)
+        qq = None if q is None else np.ascontiguousarray(q, np.int32)
+        cout = np.zeros_like(co)
+        srgb = np.zeros((h, w, 3), np.uint8)
+        lin = np.zeros((3, h, w), np.float32)
+        self._reconstruct420(_ptr(co), w, h, _ptr(qq), shuffle, _ptr(cout), _ptr(srgb), _ptr(lin))
+        return cout, srgb, lin
+
+    def write_jpeg420(self, coeffs, w, h, q):
+        co = np.ascontiguousarray(coeffs, np.int16)
+        qq = np.ascontiguousarray(q, np.int32)
+        cap = w * h * 3 + (1 << 16)
+        out = np.zeros(cap, np.uint8)
+        n = self._write_jpeg420(_ptr(co), w, h, _ptr(qq), _ptr(out), cap)
+        assert 0 <= n <= cap
+        return out[:n].tobytes()
+
+    def process_params(self, data, target, w=0, h=0, clear_metadata=True, try_420=False,
+                       force_420=False, silver=False, lookahead=3, new_model=True,
+                       want_trace=False):
+        """guetzli::Process with all of Params; data = uint8 [h][w][3] array or JPEG bytes.
+        Returns (jpeg or None, trace)."""
+        if isinstance(data, (bytes, bytearray)):
+            buf = np.frombuffer(data, np.uint8)
+            jl = len(data)
+            cap = max(4 * len(data), 1 << 20)
+        else:
+            buf = np.ascontiguousarray(data, np.uint8)
+            h, w, _ = buf.shape
+            jl = -1
+            cap = w * h * 3 + (1 << 16)
+        out = np.zeros(cap, np.uint8)
+        tr = C.create_string_buffer(1 << 22) if want_trace else None
+        n = self._process_params(_ptr(buf), jl, w, h, target, int(clear_metadata), int(try_420),
+                                 int(force_420), int(silver), lookahead, int(new_model),
+                                 _ptr(out), cap, tr, len(tr) if tr else 0)
+        if n < 0:
+            return None, None
+        assert n <= cap
+        return out[:n].tobytes(), (tr.value.decode() if tr else None)
+
     def write_jpeg(self, coeffs, w, h, q):
         co = np.ascontiguousarray(coeffs, np.int16)
         qq = np.ascontiguousarray(q, np.int32)
@@ -291,6 +357,39 @@ class CheckerComparator:
     def compare_block(self, coeffs, bx, by):
         co = np.ascontiguousarray(coeffs, np.int16)
         return self.chk._comparator_compare_block(self.handle, _ptr(co), bx, by)
+
+    def compare420(self, coeffs):
+        co = np.ascontiguousarray(coeffs, np.int16)
+        d = np.zeros((self.h, self.w), np.float32)
+        dist = self.chk._comparator_compare420(self.handle, _ptr(co), _ptr(d))
+        return dist, d
+
+    def block_weights_factor(self, direction, max_block_dist, target_mul, factor, distmap,
+                             weights=None):
+        d = np.ascontiguousarray(distmap, np.float32)
+        s = 8 * factor
+        n = ((self.w + s - 1) // s) * ((self.h + s - 1) // s)
+        wgt = np.zeros(n, np.float32) if weights is None else \
+            np.ascontiguousarray(weights, np.float32).copy()
+        self.chk._comparator_block_weights_factor(self.handle, direction, max_block_dist,
+                                                  target_mul, factor, _ptr(d), _ptr(wgt))
+        return wgt
+
+    def block_zeroing_orders_masked(self, coeffs, orig, frame420, comp_mask, lookahead=3,
+                                    new_model=True):
+        co = np.ascontiguousarray(coeffs, np.int16)
+        og = np.ascontiguousarray(orig, np.int16)
+        f = 2 if (frame420 and comp_mask & 6) else 1
+        gn = ((self.w + 8 * f - 1) // (8 * f)) * ((self.h + 8 * f - 1) // (8 * f))
+        cap = gn * 192
+        off = np.zeros(gn + 1, np.int32)
+        idx = np.zeros(cap, np.uint8)
+        err = np.zeros(cap, np.float32)
+        n = self.chk._block_zeroing_orders_masked(self.handle, _ptr(co), _ptr(og), int(frame420),
+                                                  comp_mask, lookahead, int(new_model), _ptr(off),
+                                                  _ptr(idx), _ptr(err), cap)
+        assert n >= 0
+        return off, idx[:n].copy(), err[:n].copy()
 
     def block_zeroing_orders(self, coeffs, orig, lookahead=3, new_model=True):
         co = np.ascontiguousarray(coeffs, np.int16)

@@ -217,6 +217,7 @@ inline const char* hipGetErrorString(hipError_t e) { return e ? "emu error" : "s
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) {
   *p = malloc(n ? n : 1);
   // poison so that reads of never-written device memory are visible in tests

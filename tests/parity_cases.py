@@ -365,3 +365,202 @@ def case_jpeg_entropy(L, host, w, h, x0=0, y0=0, check_histograms=True):
                 assert got == ref.write_jpeg(co, w, h, q)
             ctx.jpeg_scan_keep()
             assert ctx.jpeg_scan_bytes(kept=True) == scan
+
+
+# ------------------------------------------------------------------ YUV 4:2:0 (row f4) --
+def colourful(w, h):
+    """Saturated reds / blues over dark and bright backgrounds with soft and hard edges: makes
+    every branch of PreProcessChannel (sharpen map, blur map, neither) non-trivial."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    r = 60 + 150 * (np.sin(x / 9.0) > 0) * (y < 0.6 * h) + 40 * np.sin(y / 7.0)
+    g = 40 + 30 * np.cos((x + y) / 13.0) + 120 * (x > 0.7 * w)
+    b = 50 + 160 * (np.cos(y / 11.0) > 0.3) * (x < 0.5 * w) + 100 * (x > 0.7 * w)
+    m = ((x - 0.5 * w) ** 2 + (y - 0.5 * h) ** 2) < (0.2 * min(w, h)) ** 2
+    r[m], g[m], b[m] = 220, 30, 40
+    return np.ascontiguousarray(np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8))
+
+
+def case_frame420(L, w, h, chk, x0=0, y0=0, rgb=None):
+    """gz_downsample (OutputImage::Downsample + PreProcessChannel), the 4:2:0 pixel model
+    (gz_reconstruct), gz_compare and gz_block_weights_factor on a 4:2:0 frame against `chk`."""
+    rng = np.random.default_rng(RNG_SEED + 11 * w + h)
+    if rgb is None:
+        rgb = images.crop(w, h, x0, y0)
+    co = chk.encode_rgb(rgb)
+    exp = chk.downsample(co, w, h)
+    oc = chk.comparator(rgb, 1.0)
+    with L.context(rgb, 1.0) as ctx:
+        ctx.encode_rgb()
+        got = ctx.downsample()
+        assert ctx.frame_layout() == (2, ctx.nb, ctx.nbc)
+        assert_bits_equal(got, exp, f"downsample {w}x{h}")
+        q = np.stack([rng.integers(1, 8, 64), rng.integers(1, 12, 64),
+                      rng.integers(1, 12, 64)]).astype(np.int32)
+        for qq in (None, q):
+            cq = ctx.quantize(qq)
+            ecq, esrgb, elin = chk.reconstruct420(exp, w, h, qq, shuffle=7)
+            assert_bits_equal(cq, ecq, "quantize (4:2:0)")
+            srgb, lin = ctx.reconstruct()
+            assert_bits_equal(srgb, esrgb, "reconstruct srgb (4:2:0)")
+            assert_bits_equal(lin, elin, "reconstruct linear (4:2:0)")
+        dist, dm, _ = ctx.compare()
+        edist, edm = oc.compare420(cq)
+        assert_bits_equal(dm, edm, "distance map (4:2:0)")
+        assert dist == edist
+        for direction in (1, -1):
+            for factor in (1, 2):
+                for radius in (1, 3):
+                    gotw = ctx.block_weights_factor(direction, radius, 0.97, factor)
+                    expw = oc.block_weights_factor(direction, radius, 0.97, factor, edm)
+                    assert_bits_equal(gotw, expw, f"block weights factor {factor} dir {direction}")
+        # back to 4:4:4
+        ctx.encode_rgb()
+        assert ctx.frame_layout()[0] == 1
+    oc.close()
+
+
+def case_block_search420(L, w, h, chk, x0=0, y0=0, qs=3, lookahead=3, new_model=True):
+    """Phase A on a 4:2:0 frame: luma candidates on the 8x8 grid (mask 1), chroma candidates on
+    the 16x16 grid with the 2x2 pixel model and the maximum over the sub-blocks (mask 6)."""
+    rgb = images.crop(w, h, x0, y0)
+    co = chk.encode_rgb(rgb)
+    orig = chk.downsample(co, w, h)
+    oc = chk.comparator(rgb, 0.971769)
+    with L.context(rgb, 0.971769) as ctx:
+        ctx.encode_rgb()
+        ctx.downsample(download=False)
+        cq = ctx.quantize(np.full((3, 64), qs, np.int32))
+        for mask in (1, 6):
+            off, idx, err = ctx.block_zeroing_orders(lookahead, new_model, comp_mask=mask)
+            eoff, eidx, eerr = oc.block_zeroing_orders_masked(cq, orig, True, mask, lookahead, new_model)
+            assert_bits_equal(off, eoff, f"offsets mask {mask}")
+            assert_bits_equal(idx, eidx, f"candidates mask {mask}")
+            assert_bits_equal(err, eerr, f"errors mask {mask}")
+    oc.close()
+
+
+def case_block_search_masks444(L, w, h, chk, x0=0, y0=0, qs=3, lookahead=3, new_model=True):
+    """Component masks and non-default Params on a 4:4:4 frame."""
+    rgb = images.crop(w, h, x0, y0)
+    orig = chk.encode_rgb(rgb)
+    oc = chk.comparator(rgb, 0.971769)
+    with L.context(rgb, 0.971769) as ctx:
+        ctx.encode_rgb()
+        cq = ctx.quantize(np.full((3, 64), qs, np.int32))
+        for mask in (7, 1, 6):
+            off, idx, err = ctx.block_zeroing_orders(lookahead, new_model, comp_mask=mask)
+            eoff, eidx, eerr = oc.block_zeroing_orders_masked(cq, orig, False, mask, lookahead, new_model)
+            assert_bits_equal(off, eoff, f"offsets mask {mask}")
+            assert_bits_equal(idx, eidx, f"candidates mask {mask}")
+            assert_bits_equal(err, eerr, f"errors mask {mask}")
+    oc.close()
+
+
+def case_jpeg_entropy420(L, H, w, h, chk, x0=0, y0=0):
+    """The device entropy coder on a 4:2:0 frame (MCUs of 2x2 luma + Cb + Cr blocks, padding
+    blocks, DC prediction in scan order) + the host head == the reference's WriteJpeg."""
+    rng = np.random.default_rng(RNG_SEED + 5 * w + h)
+    rgb = images.crop(w, h, x0, y0)
+    co = chk.encode_rgb(rgb)
+    orig = chk.downsample(co, w, h)
+    with L.context(rgb, 1.0) as ctx:
+        ctx.encode_rgb()
+        ctx.downsample(download=False)
+        qs = [np.full((3, 64), 2, np.int32),
+              np.stack([rng.integers(1, 9, 64), rng.integers(1, 30, 64), rng.integers(1, 30, 64)]).astype(np.int32),
+              np.stack([np.full(64, 3), np.full(64, 4000), np.full(64, 4000)]).astype(np.int32)]   # chroma -> all zero
+        for q in qs:
+            cq = ctx.quantize(q)
+            exp = chk.write_jpeg420(orig, w, h, q)
+            assert H.write_jpeg(cq, w, h, q, factor=2) == exp, "host writer (4:2:0)"
+            y, cb, cr = ctx.split420(cq)
+            ncomp = 3 if (cb.any() or cr.any()) else 1
+            counts = ctx.jpeg_histograms(q, ncomp)
+            head, depth, code = H.jpeg_head(counts, w, h, q, ncomp=ncomp, factor=2)
+            n = ctx.jpeg_scan(ncomp, depth, code)
+            scan = ctx.jpeg_scan_bytes()
+            assert len(scan) == n
+            got = head + scan + b"\xff\xd9"
+            assert got == exp, (len(got), len(exp), ncomp)
+
+
+def case_global_order420(L, w, h, chk, x0=0, y0=0, qs=3, target=0.971769):
+    """Phase B's order on the chroma grid of a 4:2:0 frame: device-side weights over 16x16
+    areas, the construction loop, whole-block steps on components 1 and 2 with their
+    statistics change."""
+    rng = np.random.default_rng(RNG_SEED + 13 * w + h)
+    rgb = images.crop(w, h, x0, y0)
+    oc = chk.comparator(rgb, target)
+    with L.context(rgb, target) as ctx:
+        ctx.encode_rgb()
+        orig = ctx.downsample()
+        q = np.full((3, 64), qs, np.int32)
+        cq = ctx.quantize(q)
+        off, idx, err = ctx.block_zeroing_orders(comp_mask=6)
+        dist, dm, _ = ctx.compare()
+        gn = ctx.nbc
+        cnt = np.diff(off)
+        max_err = np.zeros(gn, np.float32)
+        ctx.order_reset()
+        for direction in (1, -1):
+            next_cand = (rng.integers(0, 1000, gn) % (cnt + 1)).astype(np.int32)
+            for radius in (1, 2):
+                wgt = oc.block_weights_factor(direction, radius, 1.0, 2, dm)
+                exp = []
+                btc = 0
+                for b in range(gn):
+                    if wgt[b] == 0:
+                        continue
+                    e = err[off[b]:off[b + 1]]
+                    at = next_cand[b]
+                    if direction > 0:
+                        vals = (e[at:] - max_err[b]) / wgt[b]
+                        btc += at < cnt[b]
+                    else:
+                        vals = (max_err[b] - e[:at][::-1]) / wgt[b]
+                        btc += at > 0
+                    exp.extend((b, v) for v in vals.astype(np.float32))
+                total, got_btc, _ = ctx.order_build_auto(direction, radius, 1.0, True, next_cand)
+                assert total == len(exp) and got_btc == btc, (total, len(exp), got_btc, btc)
+                got = ctx.order_fetch(0, total)
+                if total:
+                    assert_bits_equal(got["block"], np.array([b for b, _ in exp], np.int32), "order blocks")
+                    assert_bits_equal(got["val"], np.array([v for _, v in exp], np.float32), "order vals")
+        # whole-block steps
+        def quantize(raw, qq):
+            r = int(np.fmod(raw, qq))
+            d = qq - r if 2 * r > qq else (-qq - r if -2 * r > qq else -r)
+            return np.int16(raw + d)
+        co = ctx.get_coeffs()
+        coff = [0, ctx.nb, ctx.nb + ctx.nbc]
+        for direction in (1, -1):
+            exp = co.copy()
+            next_cand = (rng.integers(0, 1000, gn) % (cnt + 1)).astype(np.int32)
+            if direction > 0:
+                counts = (rng.integers(0, 1000, gn) % (cnt - next_cand + 1)).astype(np.int32)
+            else:
+                counts = (rng.integers(0, 1000, gn) % (next_cand + 1)).astype(np.int32)
+            sel = np.flatnonzero(counts > 0).astype(np.int32)
+            for b in sel:
+                for j in range(counts[b]):
+                    p = next_cand[b] + j if direction > 0 else next_cand[b] - 1 - j
+                    ix = int(idx[off[b] + p])
+                    c, k = ix // 64, ix % 64
+                    ob = orig[coff[c] + b].astype(np.int64)
+                    newval = 0 if direction > 0 else int(quantize(int(ob[k]), qs))
+                    precious = False
+                    if newval == 0 and k in (1, 8):
+                        hf = sum(abs(int(ob[i])) for i in range(3, 64) if not ((i & 7) < 3 and i < 24))
+                        precious = abs(int(ob[k])) >= (4 if hf < 60 else 8)
+                    if not precious:
+                        exp[coff[c] + b, k] = newval
+            ctx.order_build_auto(direction, 1, 1.0, True, next_cand)
+            before = ctx.jpeg_histograms(q)
+            ctx.apply_candidate_steps(direction, sel, counts[sel])
+            delta = ctx.steps_histogram_delta()
+            co = ctx.get_coeffs()
+            assert_bits_equal(co, exp, f"apply_candidate_steps (4:2:0) direction {direction}")
+            after = ctx.jpeg_histograms(q)
+            assert_bits_equal(delta, after[1].astype(np.int64) - before[1].astype(np.int64),
+                              f"steps_histogram_delta (4:2:0) direction {direction}")
+    oc.close()

@@ -133,7 +133,7 @@ def test_jpeg_input_matches_reference_in_emulation(host_emu, case):
 
 @needs_ref
 def test_jpeg_input_refusals(host_emu):
-    """What the reference rejects is rejected; 4:2:0 input is refused here (not implemented)."""
+    """What the reference rejects is rejected."""
     rgb = images.crop(48, 40, 100, 60)
     target = ref._butteraugli_score_for_quality(95.0)
     grey = _pil_jpeg(np.ascontiguousarray(rgb[:, :, 1]), quality=95)
@@ -142,5 +142,91 @@ def test_jpeg_input_refusals(host_emu):
         host_emu.process_jpeg(grey, quality=95)
     with pytest.raises(RuntimeError):
         host_emu.process_jpeg(b"not a jpeg", quality=95)
+    y422 = _pil_jpeg(rgb, quality=95, subsampling=1)   # 4:2:2: neither Is444 nor Is420
+    assert ref.process_jpeg(y422, target)[0] is None
     with pytest.raises(RuntimeError):
-        host_emu.process_jpeg(_pil_jpeg(rgb, quality=95, subsampling=2), quality=95)
+        host_emu.process_jpeg(y422, quality=95)
+
+
+# ------------------------------------------------- non-default guetzli::Params (row f4) --
+@needs_ref
+@pytest.mark.parametrize("case", [
+    (40, 32, 100, 60, 95, dict(force_420=True)),
+    (48, 40, 300, 150, 84, dict(try_420=True)),
+    (33, 35, 200, 100, 90, dict(force_420=True)),          # odd size: MCU padding on both axes
+    (40, 32, 100, 60, 95, dict(lookahead=1)),
+    (40, 32, 100, 60, 90, dict(lookahead=5, new_model=False)),
+    (48, 33, 10, 10, 95, dict(try_420=True, lookahead=2)),
+])
+def test_whole_encode_with_params_matches_reference_in_emulation(host_emu, case, monkeypatch):
+    """Params::try_420 / force_420 (OutputImage::Downsample, the 4:2:0 pixel model, the
+    comp_mask 1 / 6 searches, processor.cc:847-878), zeroing_greedy_lookahead and
+    new_zeroing_model: bytes and --verbose trace of the unmodified reference.  The device
+    entropy coder is cross-checked against the serial host writer on every candidate."""
+    w, h, x0, y0, quality, kw = case
+    monkeypatch.setenv("GZ_VERIFY_ENTROPY", "1")
+    rgb = images.crop(w, h, x0, y0)
+    target = ref._butteraugli_score_for_quality(float(quality))
+    exp_jpg, exp_trace = ref.process_params(rgb, target, want_trace=True, **kw)
+    got_jpg, info = host_emu.process(rgb, quality=quality, want_trace=True, **kw)
+    for i, (a, b) in enumerate(zip(exp_trace.splitlines(), info["trace"].splitlines())):
+        assert a == b, f"trace line {i}:\n ref: {a}\n got: {b}"
+    assert info["trace"] == exp_trace
+    assert got_jpg == exp_jpg
+    if kw.get("force_420") or kw.get("try_420"):
+        assert "f112222" in exp_trace and "YUV420 selected" in exp_trace
+
+
+@needs_ref
+@pytest.mark.parametrize("case", [(40, 32, 95, dict()), (64, 48, 90, dict()), (40, 32, 95, dict(force_420=True)),
+                                  (48, 40, 90, dict(try_420=True))])
+def test_grey_image_matches_reference_in_emulation(host_emu, case):
+    """r = g = b input: SaveToJpegData writes one component, BuildACHistograms leaves the chroma
+    statistics of phase B's size model empty (processor.cc:592-600), Downsample does nothing
+    (output_image.cc:305-308) and the chroma search is skipped (:546-547)."""
+    w, h, quality, kw = case
+    rgb = np.repeat(images.crop(w, h, 120, 80)[:, :, 1:2], 3, axis=2).copy()
+    target = ref._butteraugli_score_for_quality(float(quality))
+    exp_jpg, exp_trace = ref.process_params(rgb, target, want_trace=True, **kw)
+    got_jpg, info = host_emu.process(rgb, quality=quality, want_trace=True, **kw)
+    for i, (a, b) in enumerate(zip(exp_trace.splitlines(), info["trace"].splitlines())):
+        assert a == b, f"trace line {i}:\n ref: {a}\n got: {b}"
+    assert info["trace"] == exp_trace
+    assert got_jpg == exp_jpg
+
+
+@needs_ref
+@pytest.mark.parametrize("case", [
+    (48, 40, dict(quality=97, subsampling=2), True, dict()),
+    (41, 35, dict(quality=98, subsampling=2, progressive=True, comment=b"hi"), False, dict()),
+    (24, 40, dict(quality=95, subsampling=2), True, dict()),          # too small for butteraugli
+    (40, 32, dict(quality=97, subsampling=0), True, dict(try_420=True)),   # 4:4:4 input, both modes
+])
+def test_jpeg_420_input_matches_reference_in_emulation(host_emu, case, monkeypatch):
+    """YUV 4:2:0 JPEG input (processor.cc:811-815,847-849): decoded with the 2x2 pixel model,
+    the original written from the input's own (padded) blocks, then the 4:2:0 search."""
+    w, h, kw, clear, params = case
+    monkeypatch.setenv("GZ_VERIFY_ENTROPY", "1")
+    data = _pil_jpeg(images.crop(w, h, 100, 60), **kw) + (b"" if clear else b"tail!")
+    target = ref._butteraugli_score_for_quality(95.0)
+    exp_jpg, exp_trace = ref.process_params(data, target, clear_metadata=clear, want_trace=True, **params)
+    assert exp_jpg is not None
+    got_jpg, got_trace = host_emu.process_jpeg(data, quality=95, clear_metadata=clear, want_trace=True, **params)
+    for i, (a, b) in enumerate(zip(exp_trace.splitlines(), got_trace.splitlines())):
+        assert a == b, f"trace line {i}:\n ref: {a}\n got: {b}"
+    assert got_trace == exp_trace
+    assert got_jpg == exp_jpg
+
+
+def test_c_wrappers_do_not_let_exceptions_through(host_emu):
+    """A PNG header that declares an absurd size is rejected without allocating for it, and a
+    C++ exception inside any gzh_* entry point comes back as an error code."""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 1000000, 1000000, 16, 6, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+    with pytest.raises(ValueError):
+        host_emu.read_png(bomb)

@@ -379,3 +379,107 @@ def test_jpeg_input_golden_hashes(name, exp):
     jpg, _ = host.process_jpeg(data, quality=exp["quality"], clear_metadata=exp["clear_metadata"])
     assert len(jpg) == exp["bytes"]
     assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]
+
+
+# ------------------------------------------------------------------ YUV 4:2:0 (row f4) --
+needs_ref = pytest.mark.skipif(ref is None, reason="oracle/_ref/libgz_ref.so not built")
+
+
+@needs_ref
+@pytest.mark.parametrize("wh", [(48, 40), (33, 35), (47, 31), (444, 258), (129, 70)])
+def test_frame420(L, wh):
+    """OutputImage::Downsample with PreProcessChannel, the 2x2 pixel model (against the
+    reference image after shuffled update histories), Compare and the 16x16 block weights."""
+    pc.case_frame420(L, *wh, ref)
+
+
+@needs_ref
+def test_frame420_preprocessing_branches(L):
+    rgb = pc.colourful(200, 136)
+    pc.case_frame420(L, 200, 136, ref, rgb=rgb)
+
+
+@needs_ref
+def test_block_search420(L):
+    pc.case_block_search420(L, 45, 27, ref, x0=100, y0=60)
+    pc.case_block_search420(L, 130, 75, ref, x0=10, y0=10, qs=2)
+    pc.case_block_search420(L, 64, 48, ref, x0=10, y0=10, qs=2, lookahead=2, new_model=False)
+
+
+@needs_ref
+def test_block_search_masks_and_params(L):
+    """Params::zeroing_greedy_lookahead in {1, 2, 5}, new_zeroing_model = false and every
+    component mask on a 4:4:4 frame (processor.cc:364-467)."""
+    pc.case_block_search_masks444(L, 96, 64, ref, x0=100, y0=60)
+    pc.case_block_search_masks444(L, 61, 43, ref, x0=50, y0=60, lookahead=1)
+    pc.case_block_search_masks444(L, 61, 43, ref, x0=50, y0=60, lookahead=2)
+    pc.case_block_search_masks444(L, 61, 43, ref, x0=50, y0=60, lookahead=5, new_model=False)
+
+
+@needs_ref
+@pytest.mark.parametrize("wh", [(444, 258), (61, 43), (32, 32), (129, 9)])
+def test_jpeg_entropy420(L, wh):
+    import guetzli_amd
+    pc.case_jpeg_entropy420(L, guetzli_amd.load_host(), *wh, ref)
+
+
+@needs_ref
+def test_global_order420(L):
+    pc.case_global_order420(L, 130, 75, ref, x0=100, y0=60)
+
+
+def _params_cases():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "params_hashes.json")
+    return sorted(json.load(open(path)).items()) if os.path.exists(path) else []
+
+
+@pytest.mark.parametrize("name,exp", _params_cases())
+def test_whole_encode_params_golden_hashes(name, exp, monkeypatch):
+    """Whole encodes with non-default guetzli::Params -- try_420 / force_420, zeroing
+    look-ahead, the old zeroing model -- greyscale input and YUV 4:2:0 JPEG input, against
+    hashes the UNMODIFIED reference produced (tools/gen_golden_hashes_r2.py)."""
+    import hashlib
+    import io
+    from PIL import Image
+    import guetzli_amd
+    kind, w, h = exp["image"]
+    if kind == "bees":
+        rgb = images.bees()
+    elif kind == "grey":
+        rgb = np.repeat(images.tiled(w, h)[:, :, 1:2], 3, axis=2).copy()
+    else:
+        rgb = images.tiled(w, h) if kind == "tiled" else images.synthetic(w, h)
+    params = dict(exp["params"])
+    host = guetzli_amd.load_host()
+    if "pil" in exp:
+        kw = dict(exp["pil"])
+        if "comment" in kw:
+            kw["comment"] = kw["comment"].encode()
+        b = io.BytesIO()
+        Image.fromarray(rgb).save(b, "JPEG", **kw)
+        data = b.getvalue() + (b"" if params.get("clear_metadata", True) else b"TAIL")
+        if hashlib.sha256(data).hexdigest() != exp["input_sha256"]:
+            pytest.skip("Pillow writes a different input stream on this machine")
+        jpg, _ = host.process_jpeg(data, quality=exp["quality"], **params)
+    else:
+        assert hashlib.sha256(rgb.tobytes()).hexdigest() == exp["rgb_sha256"]
+        jpg, _ = host.process(rgb, quality=exp["quality"], **params)
+    assert len(jpg) == exp["bytes"]
+    assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]
+
+
+@needs_ref
+def test_contexts_on_a_foreign_current_device_are_safe(L):
+    """Every entry point runs on its context's device and restores the caller's:
+    with one GPU this checks at least that nothing changes the current device."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    dev = ctypes.c_int(-1)
+    rgb = images.crop(64, 48)
+    with L.context(rgb, 1.0) as ctx:
+        ctx.encode_rgb()
+        ctx.quantize(None)
+        ctx.compare()
+        assert hip.hipGetDevice(ctypes.byref(dev)) == 0 and dev.value == 0

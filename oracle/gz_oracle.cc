@@ -1320,4 +1320,489 @@ int orc_block_zeroing_orders(void* p, const int16_t* coeffs, const int16_t* orig
   return total <= cap ? total : -total;
 }
 
+
+// =============================================================== YUV 4:2:0 ==
+// Frame layout of a 4:2:0 image across this repository: nb luma blocks (8x8 grid), then
+// nbc = ceil(w/16)*ceil(h/16) blocks of Cb, then nbc of Cr.
+//
+// The restatement keeps the reference's STATEFUL pixel cache: every SetCoeffBlock of a 2x2
+// component rebuilds the neighbouring subsampled samples from the current upsampled pixels and
+// rewrites an 18x18 window (output_image.cc:146-203).  The product computes the same pixels in
+// closed form (gz_kernels_block.h); agreeing with this restatement after arbitrary update
+// sequences is what shows that the closed form is right.
+namespace {
+
+struct Comp {   // OutputImageComponent, output_image.h:27-97
+  int w, h, f, bw, bh;
+  std::vector<int16_t> coeffs;
+  std::vector<uint16_t> pixels;
+  void reset(int w_, int h_, int factor) {   // :35-49
+    w = w_; h = h_; f = factor;
+    bw = (w + 8 * f - 1) / (8 * f);
+    bh = (h + 8 * f - 1) / (8 * f);
+    coeffs.assign((size_t)bw * bh * 64, 0);
+    pixels.assign((size_t)w * h, 128 << 4);
+  }
+  // ref: output_image.cc:123-209
+  void set_block(int bx, int by, const int16_t* block) {
+    memcpy(&coeffs[((size_t)by * bw + bx) * 64], block, 128);
+    uint8_t idct[64];
+    orc_idct_block(block, idct);
+    if (f == 1) {
+      for (int iy = 0; iy < 8; ++iy)
+        for (int ix = 0; ix < 8; ++ix) {
+          const int x = 8 * bx + ix, y = 8 * by + iy;
+          if (x < w && y < h) pixels[(size_t)y * w + x] = (uint16_t)(idct[8 * iy + ix] << 4);
+        }
+      return;
+    }
+    // the 10x10 subsampled area: rows = the 8 of the block, the one below, the one above;
+    // columns = the 8 of the block, the one to the right, the one to the left (:150-183)
+    uint16_t sub[100];
+    for (int j = 0; j < 10; ++j) {
+      const int y0 = by * 16 + (j < 9 ? j * 2 : -2);
+      for (int i = 0; i < 10; ++i) {
+        const int ix = (j < 9 ? (j + 1) * 10 : 0) + (i < 9 ? i + 1 : 0);
+        const int x0 = bx * 16 + (i < 9 ? i * 2 : -2);
+        if (x0 < 0) sub[ix] = sub[ix + 1];
+        else if (y0 < 0) sub[ix] = sub[ix + 10];
+        else if (x0 >= w) sub[ix] = sub[ix - 1];
+        else if (y0 >= h) sub[ix] = sub[ix - 10];
+        else if (i < 8 && j < 8) sub[ix] = (uint16_t)(idct[j * 8 + i] << 4);
+        else {   // the inverse of the fancy upsampler on the pixels as they stand
+          const int y1 = std::max(y0 - 1, 0), x1 = std::max(x0 - 1, 0);
+          sub[ix] = (uint16_t)((pixels[(size_t)y0 * w + x0] * 9 + pixels[(size_t)y1 * w + x1] +
+                                pixels[(size_t)y0 * w + x1] * -3 + pixels[(size_t)y1 * w + x0] * -3) >> 2);
+        }
+      }
+    }
+    const int xmin = std::max(bx * 16 - 1, 0), xmax = std::min(bx * 16 + 16, w - 1);
+    const int ymin = std::max(by * 16 - 1, 0), ymax = std::min(by * 16 + 16, h - 1);
+    for (int y = ymin; y <= ymax; ++y) {
+      const int r0 = ((y & ~1) / 2 - by * 8 + 1) * 10;
+      const int dy = ((y & 1) * 2 - 1) * 10;
+      for (int x = xmin; x <= xmax; ++x) {
+        const int c0 = (x & ~1) / 2 - bx * 8 + 1;
+        const int dx = (x & 1) * 2 - 1;
+        const int ix = c0 + r0;
+        pixels[(size_t)y * w + x] =
+            (uint16_t)((sub[ix] * 9 + sub[ix + dy] * 3 + sub[ix + dx] * 3 + sub[ix + dx + dy]) >> 4);
+      }
+    }
+  }
+  // ref: output_image.cc:67-97 (ToPixels): window may extend past the image, edge replicated
+  void to_pixels(int xmin, int ymin, int xs, int ys, uint8_t* out, int stride) const {
+    for (int iy = 0; iy < ys; ++iy)
+      for (int ix = 0; ix < xs; ++ix) {
+        const int x = std::min(xmin + ix, w - 1), y = std::min(ymin + iy, h - 1);
+        out[(size_t)(iy * xs + ix) * stride] = (uint8_t)((pixels[(size_t)y * w + x] + 8 - (x & 1)) >> 4);
+      }
+  }
+};
+
+struct Image3 {   // OutputImage
+  int w, h;
+  Comp c[3];
+  size_t off[3];   // first block of each component in the frame layout
+  void init(int w_, int h_, int chroma_factor) {
+    w = w_; h = h_;
+    size_t at = 0;
+    for (int i = 0; i < 3; ++i) {
+      c[i].reset(w, h, i == 0 ? 1 : chroma_factor);
+      off[i] = at;
+      at += (size_t)c[i].bw * c[i].bh;
+    }
+  }
+  size_t nblocks() const { return off[2] + (size_t)c[2].bw * c[2].bh; }
+  void fill(const int16_t* coeffs) {
+    for (int i = 0; i < 3; ++i)
+      for (int by = 0; by < c[i].bh; ++by)
+        for (int bx = 0; bx < c[i].bw; ++bx)
+          c[i].set_block(bx, by, coeffs + (off[i] + (size_t)by * c[i].bw + bx) * 64);
+  }
+  // ref: output_image.cc:232-243,342-346
+  void quantize(const int* q) {
+    for (int i = 0; i < 3; ++i)
+      for (int by = 0; by < c[i].bh; ++by)
+        for (int bx = 0; bx < c[i].bw; ++bx) {
+          int16_t blk[64];
+          memcpy(blk, &c[i].coeffs[((size_t)by * c[i].bw + bx) * 64], 128);
+          if (orc_quantize_block(blk, q + 64 * i)) c[i].set_block(bx, by, blk);
+        }
+  }
+  void dump(int16_t* out) const {
+    for (int i = 0; i < 3; ++i) memcpy(out + off[i] * 64, c[i].coeffs.data(), c[i].coeffs.size() * 2);
+  }
+  // ref: output_image.cc:411-440 (ToSRGB / ToLinearRGB of a window)
+  void to_srgb(int xmin, int ymin, int xs, int ys, uint8_t* rgb) const {
+    for (int i = 0; i < 3; ++i) c[i].to_pixels(xmin, ymin, xs, ys, rgb + i, 3);
+    orc_ycbcr_to_rgb(rgb, xs * ys);
+  }
+};
+
+// CompareBlock (butteraugli_comparator.cc:457-488) of the 8x8 window at (8*bxx, 8*byy) of an
+// image, against the original block switch_block() prepared.
+double compare_block_image(const BlockSearch* bs, const Image3& img, int bxx, int byy) {
+  const Comparator* c = bs->cmp;
+  const double* lut = srgb_table();
+  uint8_t rgb[192];
+  img.to_srgb(8 * bxx, 8 * byy, 8, 8, rgb);
+  float lin[192];
+  for (int i = 0; i < 64; ++i)
+    for (int ch = 0; ch < 3; ++ch) lin[64 * ch + i] = static_cast<float>(lut[rgb[3 * i + ch]]);
+  float xyb1[192];
+  opsin8x8(lin, xyb1);
+  double b0[192], b1[192];
+  for (int i = 0; i < 192; ++i) {
+    b0[i] = bs->orig_xyb[i];
+    b1[i] = xyb1[i];
+  }
+  double diff_xyz[3] = {0.0, 0.0, 0.0};
+  block_diff(b0, b1, diff_xyz);
+  const size_t n = (size_t)c->w * c->h;
+  double diff = 0.0;
+  for (int ch = 0; ch < 3; ++ch)
+    diff += diff_xyz[ch] * bs->mask[ch * n + (size_t)(8 * byy) * c->w + 8 * bxx];
+  return sqrt(diff);
+}
+
+// ---- preprocess_downsample.cc:28-279 ----
+typedef std::vector<float> Fl;
+
+Fl convolve2x(const Fl& image, int w, int h, const double* kernel, double mul) {   // :53-83, size 5
+  Fl temp = image;
+  for (size_t i = 0; i < image.size(); ++i) {
+    const int x = (int)(i % w), y = (int)(i / w);
+    if (x < 2 || x + 2 >= w) continue;
+    float v = 0;
+    for (int j = 0; j < 5; ++j) v += static_cast<float>(kernel[j]) * image[(size_t)y * w + x + j - 2];
+    temp[i] = v * static_cast<float>(mul);
+  }
+  Fl result = temp;
+  for (size_t i = 0; i < temp.size(); ++i) {
+    const int x = (int)(i % w), y = (int)(i / w);
+    if (y < 2 || y + 2 >= h) continue;
+    float v = 0;
+    for (int j = 0; j < 5; ++j) v += static_cast<float>(kernel[j]) * temp[(size_t)(y + j - 2) * w + x];
+    result[i] = v * static_cast<float>(mul);
+  }
+  return result;
+}
+void normal_kernel(double sigma, double kernel[5], double* mul) {   // :85-100
+  double sum = 0;
+  for (int i = 0; i < 5; ++i) {
+    const double x = 1.0 * i - 2;
+    kernel[i] = std::exp(-x * x / (2 * sigma * sigma)) * 0.3989422804014327 / sigma;
+    sum += kernel[i];
+  }
+  *mul = 1.0 / sum;
+}
+void morph(int w, int h, std::vector<char>* image, bool erode) {   // :110-134
+  const std::vector<char> t = *image;
+  for (int y = 1; y + 1 < h; ++y)
+    for (int x = 1; x + 1 < w; ++x) {
+      const size_t i = (size_t)y * w + x;
+      const bool all = t[i] && t[i - 1] && t[i + 1] && t[i - w] && t[i + w];
+      const bool any = t[i] || t[i - 1] || t[i + 1] || t[i - w] || t[i + w];
+      if (erode) { if (!all) (*image)[i] = 0; }
+      else if (any) (*image)[i] = 1;
+    }
+}
+// ref: PreProcessChannel, :157-279, with blur and sharpen both on
+void preprocess_channel(int w, int h, int channel, float sigma, float amount, Fl yuv[3]) {
+  const size_t n = (size_t)w * h;
+  for (size_t i = 0; i < n; ++i) {
+    yuv[0][i] /= 255.0;
+    yuv[1][i] = yuv[1][i] / 255.0f - 0.5f;
+    yuv[2][i] = yuv[2][i] / 255.0f - 0.5f;
+  }
+  std::vector<char> dark(n, 0), red(n, 0), sharp(n, 0), blurm(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const float y = yuv[0][i], u = yuv[1][i], v = yuv[2][i];
+    const float r = y + 1.402f * v;
+    const float g = y - 0.34414f * u - 0.71414f * v;
+    const float b = y + 1.772f * u;
+    if (channel == 2 && g < 0.85 && b < 0.85 && r < 0.9) dark[i] = 1;
+    if (channel == 1 && r < 0.85 && g < 0.85 && b < 0.9) dark[i] = 1;
+    if (channel == 2 && 2.116 * v > -0.34414 * u + 0.2 && 1.402 * v > 1.772 * u + 0.2) red[i] = 1;
+    if (channel == 1 && v < 1.263 * u - 0.1 && u > -0.33741 * v) red[i] = 1;
+  }
+  for (int k = 0; k < 3; ++k) morph(w, h, &dark, true);
+  for (int k = 0; k < 3; ++k) morph(w, h, &red, false);
+  for (size_t i = 0; i < n; ++i) sharp[i] = red[i] && dark[i];
+  const double threshold = (channel == 2 ? 0.02 : 1.0) * 127.5;
+  static const double kEdge[9] = {0, -1, 0, -1, 4, -1, 0, -1, 0};
+  Fl edge = yuv[channel];   // Convolve2D, :29-50
+  for (int y = 1; y + 1 < h; ++y)
+    for (int x = 1; x + 1 < w; ++x) {
+      float v = 0;
+      for (int j = 0; j < 9; ++j)
+        v += static_cast<float>(kEdge[j]) * yuv[channel][(size_t)(y + j / 3 - 1) * w + x + j % 3 - 1];
+      edge[(size_t)y * w + x] = v;
+    }
+  for (size_t i = 0; i < n; ++i) {
+    if (sharp[i] || !dark[i]) continue;
+    if (fabs(edge[i]) < threshold && yuv[2][i] < -0.162 * yuv[1][i]) blurm[i] = 1;
+  }
+  morph(w, h, &blurm, true);
+  morph(w, h, &blurm, true);
+  double ks[5], kb[5], ms, mb;
+  normal_kernel(sigma, ks, &ms);   // Sharpen: float sigma promoted
+  normal_kernel(1.3, kb, &mb);     // Blur: kSigma
+  Fl sharpened = convolve2x(yuv[channel], w, h, ks, ms);
+  for (size_t i = 0; i < n; ++i) sharpened[i] = yuv[channel][i] + (yuv[channel][i] - sharpened[i]) * amount;
+  const Fl blurred = convolve2x(yuv[channel], w, h, kb, mb);
+  for (size_t i = 0; i < n; ++i) {
+    if (sharp[i]) yuv[channel][i] = sharpened[i];
+    else if (blurm[i]) yuv[channel][i] = blurred[i];
+  }
+  for (size_t i = 0; i < n; ++i) {
+    yuv[0][i] *= 255.0;
+    yuv[1][i] = (yuv[1][i] + 0.5f) * 255.0f;
+    yuv[2][i] = (yuv[2][i] + 0.5f) * 255.0f;
+  }
+}
+
+}  // namespace
+
+// ref: OutputImage::Downsample (output_image.cc:304-340) with the default DownsampleConfig and
+// use_silver_screen == false.  In: 4:4:4 coefficients; out: the 4:2:0 frame (or the unchanged
+// 4:4:4 one for a greyscale image).  Returns the number of blocks written.
+int orc_downsample(const int16_t* coeffs, int w, int h, int use_silver_screen, int16_t* out) {
+  const int bw = (w + 7) / 8, bh = (h + 7) / 8, nb = bw * bh;
+  if (use_silver_screen) return -1;   // not restated
+  bool grey = true;
+  for (size_t i = (size_t)nb * 64; i < (size_t)3 * nb * 64 && grey; ++i) grey = coeffs[i] == 0;
+  if (grey) {
+    memcpy(out, coeffs, (size_t)3 * nb * 128);
+    return 3 * nb;
+  }
+  Fl yuv[3];
+  for (int c = 0; c < 3; ++c) {
+    yuv[c].resize((size_t)w * h);
+    orc_to_float_pixels(coeffs + (size_t)c * nb * 64, w, h, yuv[c].data());
+  }
+  preprocess_channel(w, h, 2, 1.3f, 0.5f, yuv);
+  preprocess_channel(w, h, 1, 1.3f, 0.5f, yuv);
+  memcpy(out, coeffs, (size_t)nb * 128);
+  const int nbc = ((w + 15) / 16) * ((h + 15) / 16);
+  orc_set_downsampled(yuv[1].data(), w, h, 2, 2, out + (size_t)nb * 64);
+  orc_set_downsampled(yuv[2].data(), w, h, 2, 2, out + ((size_t)nb + nbc) * 64);
+  return nb + 2 * nbc;
+}
+
+void orc_reconstruct420(const int16_t* coeffs, int w, int h, const int* q, int shuffle,
+                        int16_t* coeffs_out, uint8_t* srgb, float* linear) {
+  Image3 img;
+  img.init(w, h, 2);
+  img.fill(coeffs);
+  if (shuffle) {   // extra updates in a scrambled order: the result must not depend on them
+    unsigned rng = (unsigned)shuffle;
+    auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+    for (int rep = 0; rep < 2; ++rep)
+      for (int c = 1; c < 3; ++c) {
+        Comp& comp = img.c[c];
+        const int n = comp.bw * comp.bh;
+        for (int t = 0; t < n; ++t) {
+          const int b = next() % n;
+          int16_t junk[64];
+          for (int k = 0; k < 64; ++k) junk[k] = (int16_t)((int)(next() % 301) - 150);
+          comp.set_block(b % comp.bw, b / comp.bw, junk);
+          comp.set_block(b % comp.bw, b / comp.bw, coeffs + (img.off[c] + b) * 64);
+        }
+      }
+  }
+  if (q) img.quantize(q);
+  if (coeffs_out) img.dump(coeffs_out);
+  const size_t n = (size_t)w * h;
+  std::vector<uint8_t> rgb(3 * n);
+  img.to_srgb(0, 0, w, h, rgb.data());
+  if (srgb) memcpy(srgb, rgb.data(), 3 * n);
+  if (linear) {
+    const double* lut = srgb_table();
+    for (int c = 0; c < 3; ++c)
+      for (size_t p = 0; p < n; ++p) linear[c * n + p] = static_cast<float>(lut[rgb[3 * p + c]]);
+  }
+}
+
+float orc_comparator_compare420(void* p, const int16_t* coeffs, float* distmap) {
+  Comparator* c = (Comparator*)p;
+  const size_t n = (size_t)c->w * c->h;
+  Plane lin(3 * n), xyb(3 * n), d(n);
+  orc_reconstruct420(coeffs, c->w, c->h, nullptr, 0, nullptr, nullptr, lin.data());
+  opsin(lin.data(), c->w, c->h, xyb.data());
+  Psycho p1;
+  separate_frequencies(xyb.data(), c->w, c->h, &p1);
+  diffmap_psycho(c->pi0, p1, c->w, c->h, d.data());
+  float mx = 0.0f;
+  for (size_t i = 0; i < n; ++i) mx = std::max(mx, d[i]);
+  if (distmap) memcpy(distmap, d.data(), n * 4);
+  return mx;
+}
+
+// ref: butteraugli_comparator.cc:494-558 with factor_x = factor_y = factor
+void orc_comparator_block_weights_factor(void* p, int direction, int max_block_dist,
+                                         double target_mul, int factor, const float* distmap,
+                                         float* block_weight) {
+  Comparator* c = (Comparator*)p;
+  const int w = c->w, h = c->h, s = 8 * factor;
+  const double target_distance = c->target * target_mul;
+  const int bw = (w + s - 1) / s, bh = (h + s - 1) / s;
+  std::vector<float> bmax((size_t)bw * bh);
+  for (int by = 0; by < bh; ++by)
+    for (int bx = 0; bx < bw; ++bx) {
+      float m = 0.0;
+      for (int y = s * by; y < std::min(h, s * (by + 1)); ++y)
+        for (int x = s * bx; x < std::min(w, s * (bx + 1)); ++x)
+          m = std::max(m, distmap[(size_t)y * w + x]);
+      bmax[(size_t)by * bw + bx] = m;
+    }
+  for (int by = 0; by < bh; ++by)
+    for (int bx = 0; bx < bw; ++bx) {
+      const int bix = by * bw + bx;
+      float local = static_cast<float>(target_distance);
+      const int x0 = std::max(0, bx - max_block_dist), y0 = std::max(0, by - max_block_dist);
+      const int x1 = std::min(bw, bx + 1 + max_block_dist);
+      const int y1 = std::min(bh, by + 1 + max_block_dist);
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) local = std::max(local, bmax[(size_t)y * bw + x]);
+      if (direction > 0) {
+        if (bmax[bix] <= target_distance && local <= 1.1 * target_distance)
+          block_weight[bix] = 1.0;
+      } else {
+        constexpr double kLocalMaxWeight = 0.5;
+        if (bmax[bix] <= (1 - kLocalMaxWeight) * target_distance + kLocalMaxWeight * local)
+          continue;
+        for (int y = y0; y < y1; ++y)
+          for (int x = x0; x < x1; ++x) {
+            const int d = std::max(std::abs(y - by), std::abs(x - bx));
+            const int ix = y * bw + x;
+            block_weight[ix] = std::max<float>(block_weight[ix], 1.0f / (d + 1.0f));
+          }
+      }
+    }
+}
+
+// ref: processor.cc:364-467 over the grid of SelectFrequencyMasking's phase A (:539-590) for
+// any comp_mask, on a 4:4:4 (frame420 == 0) or 4:2:0 frame: every candidate is set into the
+// image (SetCoeffBlock of each component in the mask), compared on the factor x factor 8x8
+// blocks of its area that lie inside the image, and scored by the largest error.
+int orc_block_zeroing_orders_masked(void* p, const int16_t* coeffs, const int16_t* orig,
+                                    int frame420, int comp_mask, int lookahead, int new_model,
+                                    int32_t* offsets, uint8_t* idx, float* err, int cap) {
+  Comparator* c = (Comparator*)p;
+  Image3 img;
+  img.init(c->w, c->h, frame420 ? 2 : 1);
+  img.fill(coeffs);
+  int last_c = 0;
+  for (int i = 0; i < 3; ++i)
+    if (comp_mask & (1 << i)) last_c = i;
+  const int factor = img.c[last_c].f;
+  const int gw = (c->w + 8 * factor - 1) / (8 * factor), gh = (c->h + 8 * factor - 1) / (8 * factor);
+  BlockSearch bs;
+  init_block_search(&bs, c);
+  static const uint8_t oldCsf[64] = {
+      10, 10, 20, 40, 60, 70, 80, 90, 10, 20, 30, 60, 70, 80, 90, 90,
+      20, 30, 60, 70, 80, 90, 90, 90, 40, 60, 70, 80, 90, 90, 90, 90,
+      60, 70, 80, 90, 90, 90, 90, 90, 70, 80, 90, 90, 90, 90, 90, 90,
+      80, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90, 90};
+  static const int zigzag[64] = {
+      0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42,
+      3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+      10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60,
+      21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+  static const double kWeight[3] = {1.0, 0.22, 0.20};
+  int total = 0;
+  std::vector<std::vector<float> > sub_xyb((size_t)factor * factor, std::vector<float>(192));
+  for (int by = 0, bix = 0; by < gh; ++by) {
+    for (int bx = 0; bx < gw; ++bx, ++bix) {
+      int16_t block[192] = {0}, oblock[192] = {0};
+      for (int ch = 0; ch < 3; ++ch) {
+        if (!(comp_mask & (1 << ch))) continue;
+        memcpy(block + 64 * ch, coeffs + (img.off[ch] + bix) * 64, 128);
+        memcpy(oblock + 64 * ch, orig + (img.off[ch] + bix) * 64, 128);
+      }
+      std::vector<std::pair<int, float> > input_order;
+      for (int ch = 0; ch < 3; ++ch) {
+        if (!(comp_mask & (1 << ch))) continue;
+        for (int k = 1; k < 64; ++k) {
+          const int i = ch * 64 + k;
+          if (block[i] != 0) {
+            float score;
+            if (new_model)
+              score = std::abs(oblock[i]) * kOrderCsf[i] + kOrderBias[i];
+            else
+              score = static_cast<float>((std::abs(oblock[i]) - zigzag[k] / 64.0) *
+                                         kWeight[ch] / oldCsf[k]);
+            input_order.push_back(std::make_pair(i, score));
+          }
+        }
+      }
+      std::sort(input_order.begin(), input_order.end(),
+                [](const std::pair<int, float>& a, const std::pair<int, float>& b) {
+                  return a.second < b.second; });
+      int16_t processed[192];
+      memcpy(processed, block, sizeof(processed));
+      // SwitchBlock: the original's opsin image of every sub-block
+      for (int oy = 0, s = 0; oy < factor; ++oy)
+        for (int ox = 0; ox < factor; ++ox, ++s) {
+          switch_block(&bs, bx * factor + ox, by * factor + oy);
+          memcpy(sub_xyb[s].data(), bs.orig_xyb, sizeof(bs.orig_xyb));
+        }
+      auto set_blocks = [&](const int16_t* b192) {
+        for (int ch = 0; ch < 3; ++ch)
+          if (comp_mask & (1 << ch)) img.c[ch].set_block(bx, by, b192 + 64 * ch);
+      };
+      std::vector<std::pair<int, float> > out;
+      while (!input_order.empty()) {
+        float best_err = 1e17f;
+        int best_i = 0;
+        for (size_t i = 0; i < std::min<size_t>(lookahead, input_order.size()); ++i) {
+          int16_t cand[192];
+          memcpy(cand, processed, sizeof(cand));
+          cand[input_order[i].first] = 0;
+          set_blocks(cand);
+          float max_err = 0;
+          for (int oy = 0, s = 0; oy < factor; ++oy)
+            for (int ox = 0; ox < factor; ++ox, ++s) {
+              const int bxx = bx * factor + ox, byy = by * factor + oy;
+              if (8 * bxx < c->w && 8 * byy < c->h) {
+                memcpy(bs.orig_xyb, sub_xyb[s].data(), sizeof(bs.orig_xyb));
+                const float e = static_cast<float>(compare_block_image(&bs, img, bxx, byy));
+                max_err = std::max(max_err, e);
+              }
+            }
+          if (max_err < best_err) {
+            best_err = max_err;
+            best_i = (int)i;
+          }
+        }
+        const int ci = input_order[best_i].first;
+        processed[ci] = 0;
+        input_order.erase(input_order.begin() + best_i);
+        out.push_back(std::make_pair(ci, best_err));
+        set_blocks(processed);
+      }
+      float min_err = 1e10;
+      for (int i = (int)out.size() - 1; i >= 0; --i) {
+        min_err = std::min(min_err, out[i].second);
+        out[i].second = min_err;
+      }
+      size_t num = 0;
+      while (num < out.size() && out[num].second <= c->target) ++num;
+      offsets[bix] = total;
+      for (size_t i = 0; i < num; ++i) {
+        if (total < cap) {
+          idx[total] = (uint8_t)out[i].first;
+          err[total] = out[i].second;
+        }
+        ++total;
+      }
+      set_blocks(block);   // the image as it was (processor.cc:460-466)
+    }
+  }
+  offsets[gw * gh] = total;
+  return total <= cap ? total : -total;
+}
+
 }  // extern "C"

@@ -58,6 +58,19 @@ double orc_comparator_compare_block(void* c, const int16_t* coeffs, int bx, int 
 int   orc_block_zeroing_orders(void* c, const int16_t* coeffs, const int16_t* orig,
                                int lookahead, int new_model, int32_t* offsets,
                                uint8_t* idx, float* err, int cap);
+
+/* ---- YUV 4:2:0; frame layout: nb luma blocks, nbc Cb, nbc Cr ---- */
+int   orc_downsample(const int16_t* coeffs444, int w, int h, int use_silver_screen,
+                     int16_t* out);                       /* output_image.cc:304-340 */
+void  orc_reconstruct420(const int16_t* coeffs, int w, int h, const int* q, int shuffle,
+                         int16_t* coeffs_out, uint8_t* srgb, float* linear); /* :123-209,411-440 */
+float orc_comparator_compare420(void* c, const int16_t* coeffs, float* distmap);
+void  orc_comparator_block_weights_factor(void* c, int direction, int max_block_dist,
+                                          double target_mul, int factor, const float* distmap,
+                                          float* block_weight);
+int   orc_block_zeroing_orders_masked(void* c, const int16_t* coeffs, const int16_t* orig,
+                                      int frame420, int comp_mask, int lookahead, int new_model,
+                                      int32_t* offsets, uint8_t* idx, float* err, int cap);
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,12 @@ _SIGS = {
     "block_zeroing_orders": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P,
                                        C.c_int]),
     "to_float_pixels": (None, [_P, C.c_int, C.c_int, _P]),
+    "block_zeroing_orders_masked": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
+                                              _P, C.c_int]),
+    "comparator_block_weights_factor": (None, [_P, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P]),
+    "comparator_compare420": (C.c_float, [_P, _P, _P]),
+    "reconstruct420": (None, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
+    "downsample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
 }
 _REF_ONLY = {
     "process": (C.c_long, [_P, C.c_int, C.c_int, C.c_float, _P, C.c_long, _P, C.c_long]),
@@ -51,12 +57,6 @@ _REF_ONLY = {
     "idct_double": (None, [_P]),
     "downsample_plain": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "process_jpeg": (C.c_long, [_P, C.c_long, C.c_float, C.c_int, _P, C.c_long, _P, C.c_long]),
-    "downsample": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
-    "reconstruct420": (None, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P]),
-    "comparator_compare420": (C.c_float, [_P, _P, _P]),
-    "comparator_block_weights_factor": (None, [_P, C.c_int, C.c_int, C.c_double, C.c_int, _P, _P]),
-    "block_zeroing_orders_masked": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
-                                              _P, C.c_int]),
     "write_jpeg420": (C.c_long, [_P, C.c_int, C.c_int, _P, _P, C.c_long]),
     "process_params": (C.c_long, [_P, C.c_long, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_long, _P, C.c_long]),

@@ -385,35 +385,31 @@ def test_jpeg_input_golden_hashes(name, exp):
 needs_ref = pytest.mark.skipif(ref is None, reason="oracle/_ref/libgz_ref.so not built")
 
 
-@needs_ref
 @pytest.mark.parametrize("wh", [(48, 40), (33, 35), (47, 31), (444, 258), (129, 70)])
 def test_frame420(L, wh):
     """OutputImage::Downsample with PreProcessChannel, the 2x2 pixel model (against the
     reference image after shuffled update histories), Compare and the 16x16 block weights."""
-    pc.case_frame420(L, *wh, ref)
+    pc.case_frame420(L, *wh, oracle)
 
 
-@needs_ref
 def test_frame420_preprocessing_branches(L):
     rgb = pc.colourful(200, 136)
-    pc.case_frame420(L, 200, 136, ref, rgb=rgb)
+    pc.case_frame420(L, 200, 136, oracle, rgb=rgb)
 
 
-@needs_ref
 def test_block_search420(L):
-    pc.case_block_search420(L, 45, 27, ref, x0=100, y0=60)
-    pc.case_block_search420(L, 130, 75, ref, x0=10, y0=10, qs=2)
-    pc.case_block_search420(L, 64, 48, ref, x0=10, y0=10, qs=2, lookahead=2, new_model=False)
+    pc.case_block_search420(L, 45, 27, oracle, x0=100, y0=60)
+    pc.case_block_search420(L, 130, 75, oracle, x0=10, y0=10, qs=2)
+    pc.case_block_search420(L, 64, 48, oracle, x0=10, y0=10, qs=2, lookahead=2, new_model=False)
 
 
-@needs_ref
 def test_block_search_masks_and_params(L):
     """Params::zeroing_greedy_lookahead in {1, 2, 5}, new_zeroing_model = false and every
     component mask on a 4:4:4 frame (processor.cc:364-467)."""
-    pc.case_block_search_masks444(L, 96, 64, ref, x0=100, y0=60)
-    pc.case_block_search_masks444(L, 61, 43, ref, x0=50, y0=60, lookahead=1)
-    pc.case_block_search_masks444(L, 61, 43, ref, x0=50, y0=60, lookahead=2)
-    pc.case_block_search_masks444(L, 61, 43, ref, x0=50, y0=60, lookahead=5, new_model=False)
+    pc.case_block_search_masks444(L, 96, 64, oracle, x0=100, y0=60)
+    pc.case_block_search_masks444(L, 61, 43, oracle, x0=50, y0=60, lookahead=1)
+    pc.case_block_search_masks444(L, 61, 43, oracle, x0=50, y0=60, lookahead=2)
+    pc.case_block_search_masks444(L, 61, 43, oracle, x0=50, y0=60, lookahead=5, new_model=False)
 
 
 @needs_ref
@@ -423,9 +419,8 @@ def test_jpeg_entropy420(L, wh):
     pc.case_jpeg_entropy420(L, guetzli_amd.load_host(), *wh, ref)
 
 
-@needs_ref
 def test_global_order420(L):
-    pc.case_global_order420(L, 130, 75, ref, x0=100, y0=60)
+    pc.case_global_order420(L, 130, 75, oracle, x0=100, y0=60)
 
 
 def _params_cases():
@@ -470,7 +465,6 @@ def test_whole_encode_params_golden_hashes(name, exp, monkeypatch):
     assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]
 
 
-@needs_ref
 def test_contexts_on_a_foreign_current_device_are_safe(L):
     """Every entry point runs on its context's device and restores the caller's:
     with one GPU this checks at least that nothing changes the current device."""

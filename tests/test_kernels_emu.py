@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
 import build_emu  # noqa: E402
 import parity_cases as pc  # noqa: E402
-from checkers import ref  # noqa: E402
+from checkers import oracle, ref  # noqa: E402
 from guetzli_amd.capi import Library  # noqa: E402
 
 
@@ -98,36 +98,32 @@ def test_stages_and_compare_with_compact_code_variants(L, monkeypatch):
 needs_ref = pytest.mark.skipif(ref is None, reason="oracle/_ref/libgz_ref.so not built")
 
 
-@needs_ref
 @pytest.mark.parametrize("wh", [(48, 40), (33, 35), (47, 31), (64, 48)])
 def test_frame420(L, wh):
-    pc.case_frame420(L, *wh, ref, x0=100, y0=60)
+    pc.case_frame420(L, *wh, oracle, x0=100, y0=60)
 
 
-@needs_ref
 def test_frame420_preprocessing_branches(L):
     """An image on which PreProcessChannel sharpens and blurs (not just passes through)."""
     rgb = pc.colourful(72, 56)
-    co = ref.encode_rgb(rgb)
-    plain_u, plain_v = ref.downsample_chroma(co, 72, 56, 2, 2)
-    full = ref.downsample(co, 72, 56)
+    co = oracle.encode_rgb(rgb)
+    plain_u, plain_v = oracle.downsample_chroma(co, 72, 56, 2, 2)
+    full = oracle.downsample(co, 72, 56)
     nb = 9 * 7
     assert (full[nb:nb + 20] != plain_u).any() and (full[nb + 20:] != plain_v).any(), \
         "the test image does not exercise the pre-processing"
-    pc.case_frame420(L, 72, 56, ref, rgb=rgb)
+    pc.case_frame420(L, 72, 56, oracle, rgb=rgb)
 
 
-@needs_ref
 def test_block_search420(L):
-    pc.case_block_search420(L, 45, 27, ref, x0=100, y0=60)
-    pc.case_block_search420(L, 40, 33, ref, x0=10, y0=10, qs=2, lookahead=2, new_model=False)
+    pc.case_block_search420(L, 45, 27, oracle, x0=100, y0=60)
+    pc.case_block_search420(L, 40, 33, oracle, x0=10, y0=10, qs=2, lookahead=2, new_model=False)
 
 
-@needs_ref
 def test_block_search_masks_and_params(L):
-    pc.case_block_search_masks444(L, 40, 24, ref, x0=100, y0=60)
-    pc.case_block_search_masks444(L, 33, 17, ref, x0=50, y0=60, lookahead=1)
-    pc.case_block_search_masks444(L, 33, 17, ref, x0=50, y0=60, lookahead=5, new_model=False)
+    pc.case_block_search_masks444(L, 40, 24, oracle, x0=100, y0=60)
+    pc.case_block_search_masks444(L, 33, 17, oracle, x0=50, y0=60, lookahead=1)
+    pc.case_block_search_masks444(L, 33, 17, oracle, x0=50, y0=60, lookahead=5, new_model=False)
 
 
 @needs_ref
@@ -136,6 +132,5 @@ def test_jpeg_entropy420(L, host_emu, wh):
     pc.case_jpeg_entropy420(L, host_emu, *wh, ref, x0=100, y0=50)
 
 
-@needs_ref
 def test_global_order420(L):
-    pc.case_global_order420(L, 48, 40, ref, x0=100, y0=60)
+    pc.case_global_order420(L, 48, 40, oracle, x0=100, y0=60)

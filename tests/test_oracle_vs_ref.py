@@ -239,3 +239,64 @@ def test_compare_block_and_zeroing_orders():
     assert_bits_equal(oi, ri, "candidate coefficient indices")
     assert_bits_equal(oe, re_, "candidate errors")
     assert ro[-1] > 100
+
+
+# ------------------------------------------------------------------ YUV 4:2:0 (row f4) --
+def _colourful(w, h):
+    import parity_cases as pc
+    return pc.colourful(w, h)
+
+
+@pytest.mark.parametrize("wh", [(48, 40), (33, 35), (47, 31), (17, 16), (130, 66)])
+def test_downsample_and_pixel_model_420(wh):
+    """OutputImage::Downsample incl. PreProcessChannel (preprocess_downsample.cc:157-279) and the
+    2x2 pixel model of UpdatePixelsForBlock (output_image.cc:146-203): the restatement keeps
+    the reference's stateful pixel cache and agrees with it after scrambled update sequences
+    on both sides (different ones), i.e. the cache is a function of the coefficients alone."""
+    w, h = wh
+    for rgb in (images.crop(w, h, 100, 60), _colourful(w, h)):
+        co = ref.encode_rgb(rgb)
+        exp = ref.downsample(co, w, h)
+        got = oracle.downsample(co, w, h)
+        assert_bits_equal(got, exp, f"downsample {w}x{h}")
+        q = np.stack([RNG.integers(1, 8, 64), RNG.integers(1, 12, 64), RNG.integers(1, 12, 64)]).astype(np.int32)
+        for qq in (None, q):
+            for shuffle_o, shuffle_r in ((0, 0), (5, 9), (3, 0)):
+                oc, osrgb, olin = oracle.reconstruct420(exp, w, h, qq, shuffle=shuffle_o)
+                rc, rsrgb, rlin = ref.reconstruct420(exp, w, h, qq, shuffle=shuffle_r)
+                assert_bits_equal(oc, rc, "coefficients (4:2:0)")
+                assert_bits_equal(osrgb, rsrgb, "sRGB (4:2:0)")
+                assert_bits_equal(olin, rlin, "linear (4:2:0)")
+    # a greyscale image is left alone (output_image.cc:305-308)
+    grey = np.repeat(images.crop(w, h, 100, 60)[:, :, 1:2], 3, axis=2).copy()
+    cg = ref.encode_rgb(grey)
+    assert_bits_equal(oracle.downsample(cg, w, h), ref.downsample(cg, w, h), "downsample (grey)")
+
+
+def test_comparator_420_compare_weights_and_orders():
+    w, h = 45, 27
+    rgb = images.crop(w, h, 100, 60)
+    co = ref.encode_rgb(rgb)
+    orig = ref.downsample(co, w, h)
+    cq, _, _ = ref.reconstruct420(orig, w, h, np.full((3, 64), 3, np.int32))
+    oc, rc = oracle.comparator(rgb, 0.971769), ref.comparator(rgb, 0.971769)
+    od, odm = oc.compare420(cq)
+    rd, rdm = rc.compare420(cq)
+    assert od == rd
+    assert_bits_equal(odm, rdm, "distance map (4:2:0)")
+    for direction in (1, -1):
+        for factor in (1, 2):
+            for radius in (1, 2, 4):
+                assert_bits_equal(oc.block_weights_factor(direction, radius, 0.97, factor, rdm),
+                                  rc.block_weights_factor(direction, radius, 0.97, factor, rdm),
+                                  "block weights")
+    for frame420, coeffs, og, masks in ((True, cq, orig, (1, 6)),
+                                        (False, ref.reconstruct(co, w, h, np.full((3, 64), 3, np.int32))[0], co, (7, 1, 6))):
+        for mask in masks:
+            for lookahead, new_model in ((3, True), (2, False)):
+                a = oc.block_zeroing_orders_masked(coeffs, og, frame420, mask, lookahead, new_model)
+                b = rc.block_zeroing_orders_masked(coeffs, og, frame420, mask, lookahead, new_model)
+                for x, y, what in zip(a, b, ("offsets", "candidates", "errors")):
+                    assert_bits_equal(x, y, f"{what} frame420={frame420} mask={mask} la={lookahead}")
+    oc.close()
+    rc.close()

@@ -29,8 +29,13 @@ Also on the JSON line:
                   from inside this process).  `roofline_4k` = the same measurement on
                   BASELINE.json configs[2] (3840x2160), the size the chain fills the chip at.
   cpu_baseline -- the unmodified reference guetzli::Process (oracle/_ref, 1 thread) on this
-                  box's host CPU, rank 0, N=1 only, on a bounded sample: tests/golden/bees.png
-                  (444x258, config 0), --quality 95.
+                  box's host CPU, rank 0, N=1 only, on bounded samples: the bench image's top-left
+                  640x360, and BASELINE config 0 verbatim (tests/bees.png, --quality 95).
+  other_configs.config5_slice -- BASELINE config 5's work split on the GPUs this run has:
+                  3840x2160 images, 8 per GPU (image k -> rank k mod N), 8 in flight per GPU,
+                  records all-gathered over the process group; every output whose reference
+                  hash is committed (tests/golden/config5/) is checked.  `--config5` runs only
+                  this leg and reports it as `value`.
 """
 import argparse
 import hashlib
@@ -70,11 +75,64 @@ def cpu_baseline():
     t0 = time.perf_counter()
     jpg, _ = ref.process(rgb, TARGET_Q95)
     dt = time.perf_counter() - t0
+    # BASELINE config 0 verbatim: tests/bees.png --quality 95 on the reference CPU path
+    bees = images.bees()
+    t0 = time.perf_counter()
+    jb, _ = ref.process(bees, TARGET_Q95)
+    db = time.perf_counter() - t0
+    assert hashlib.sha256(jb).hexdigest() == "f2673f12a4856e020627fa151493a80b1cb2ee4dc81e28afc62dc089baf50242"
     return {"value": round(w * h / 1e6 / dt, 6), "unit": "MPix/s", "cores": 1,
             "kind": "reference",
             "sample": f"unmodified reference guetzli::Process on the top-left {w}x{h} of the "
                       f"bench image, --quality 95: {dt:.1f} s of CPU, single thread "
-                      f"({os.cpu_count()} host cores present); output {len(jpg)} bytes"}
+                      f"({os.cpu_count()} host cores present); output {len(jpg)} bytes",
+            "config0": {"workload": "tests/bees.png 444x258 --quality 95 (BASELINE configs[0])",
+                        "seconds": round(db, 2), "value": round(444 * 258 / 1e6 / db, 6),
+                        "unit": "MPix/s", "output_sha256_matches_golden": True}}
+
+
+def config5_goldens():
+    out = {}
+    d = os.path.join(ROOT, "tests", "golden", "config5")
+    if os.path.isdir(d):
+        for f in os.listdir(d):
+            if f.endswith(".json"):
+                r = json.load(open(os.path.join(d, f)))
+                out[(r["k"], r["w"], r["h"])] = r
+    out.setdefault((0, 3840, 2160), {"jpeg_sha256": GOLDEN_SHA_4K[95]})
+    return out
+
+
+def config5_leg(host, images, torch, dist, rank, world, local_rank, images_per_gpu, in_flight, size):
+    """8 images per GPU of config 5's batch; returns the JSON object of the leg (rank 0)."""
+    from guetzli_amd.batch import run_config5
+    w5, h5 = size
+    base = images.tiled(w5, h5)
+    get = lambda k: images.shifted(base, k)
+    proc = lambda im: host.process(im, quality=QUALITY, device=local_rank)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    run_config5(get, min(2, images_per_gpu), proc, rank, world, dist, in_flight, fence, "cuda")   # warm-up
+    recs, secs = run_config5(get, images_per_gpu, proc, rank, world, dist, in_flight, fence, "cuda")
+    gold = config5_goldens()
+    checked = 0
+    for r in recs:
+        g = gold.get((r["index"], w5, h5))
+        if g is not None:
+            assert r["sha256"] == g["jpeg_sha256"], f"config 5 image {r['index']} differs from the reference"
+            checked += 1
+    n = len(recs)
+    return {"workload": f"{n} independent {w5}x{h5} images (the bench image circularly shifted by "
+                        f"(37k, 53k)), --quality 95, {images_per_gpu} per GPU (image k -> rank k mod {world}), "
+                        f"{in_flight} in flight per GPU; records all-gathered",
+            "images": n, "images_per_gpu": images_per_gpu, "in_flight": in_flight,
+            "seconds": round(secs, 3), "value": round(n * w5 * h5 / 1e6 / secs, 3), "unit": "MPix/s",
+            "outputs_checked_against_reference_hashes": checked,
+            "distinct_outputs": len({r["sha256"] for r in recs})}
 
 
 def main():
@@ -87,6 +145,12 @@ def main():
     ap.add_argument("--batch-images", type=int, default=16,
                     help="images of the extra concurrent-batch leg (0 = skip)")
     ap.add_argument("--batch-workers", type=int, default=8)
+    ap.add_argument("--config5", action="store_true",
+                    help="run only BASELINE config 5's slice (8 x 4K per GPU) and report it as value")
+    ap.add_argument("--images-per-gpu", type=int, default=8)
+    ap.add_argument("--in-flight", type=int, default=8)
+    ap.add_argument("--size", default="4k", choices=["4k", "1080p"])
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default run")
     args = ap.parse_args()
 
     import torch
@@ -107,6 +171,22 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     host = guetzli_amd.load_host()        # links the gfx950 C-ABI library; no fallback
+    size5 = (3840, 2160) if args.size == "4k" else (1920, 1080)
+    if args.config5:
+        leg = config5_leg(host, images, torch, dist, rank, world, local_rank, args.images_per_gpu,
+                          args.in_flight, size5)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "MPix/s encoded at --quality 95", "value": leg["value"], "unit": "MPix/s",
+                "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": round(leg["seconds"] * 1e3, 1),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32+f64 (butteraugli), int32/int16 (DCT/quantize/entropy coding)",
+                "data": "synthetic (tests/golden/bees.png tiled, circularly shifted per image, SURVEY 8d)",
+                "config": leg}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     rgb = images.shifted(images.tiled(W, H), rank)
 
     def step():
@@ -184,6 +264,10 @@ def main():
                                         "value": round(3840 * 2160 / 1e6 / t4, 3), "unit": "MPix/s",
                                         "iterations": i4["counters"].get("number of iterations"),
                                         "output_sha256_matches_reference": True}
+    c5 = None
+    if not args.no_4k and not args.no_config5:   # every rank takes part
+        c5 = config5_leg(host, images, torch, dist, rank, world, local_rank, args.images_per_gpu,
+                         args.in_flight, size5)
     traffic = {}
     try:
         traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v6.json")))
@@ -226,6 +310,9 @@ def main():
                               if k in ("total", "phase_b_host", "compare", "block_search",
                                        "jpeg_write", "create+encode", "select_quant_matrix")},
         }
+        if c5 is not None:
+            other = dict(other or {})
+            other["config5_slice"] = c5
         if other is not None:
             out["other_configs"] = other
         if batch is not None:

@@ -48,3 +48,37 @@ def encode_concurrent(images, process, workers=4):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
         return list(ex.map(process, images))
+
+
+def encode_shard_concurrent(get_image, indices, process, workers, rank=0):
+    """This rank's images, `workers` of them in flight on its GPU; records as encode_batch's."""
+    def one(k):
+        t0 = time.perf_counter()
+        jpg, _ = process(get_image(k))
+        return {"index": k, "bytes": len(jpg), "sha256": hashlib.sha256(jpg).hexdigest(),
+                "seconds": time.perf_counter() - t0, "rank": rank}
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        return list(ex.map(one, indices))
+
+
+def run_config5(get_image, images_per_gpu, process, rank=0, world=1, dist=None, workers=8,
+                fence=None, device=None):
+    """BASELINE config 5 ("a batch of independent images sharded 8-per-GPU across the GPUs of
+    one node"): image k -> rank k mod world (k < images_per_gpu * world), every rank keeps
+    `workers` of its images in flight on its GPU, no data-path collective.  The process group
+    serves the work split only: barrier, max-over-ranks of the elapsed time, all-gather of one
+    small record per image.  Returns (records of all images ordered by index, seconds)."""
+    n = images_per_gpu * world
+    if fence:
+        fence()
+    t0 = time.perf_counter()
+    mine = encode_shard_concurrent(get_image, shard(n, rank, world), process, workers, rank)
+    if fence:
+        fence()
+    seconds = max_over_ranks(time.perf_counter() - t0, dist, device)
+    if dist is None or world == 1:
+        return mine, seconds
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    return sorted((r for part in gathered for r in part), key=lambda r: r["index"]), seconds

@@ -23,8 +23,15 @@ get = lambda k: images.shifted(images.crop(32, 32, 300, 150), k)
 recs = batch.encode_batch(get, 3, lambda rgb: host.process(rgb, quality=84), rank, world, dist if world > 1 else None)
 dt = batch.max_over_ranks(float(rank + 1), dist if world > 1 else None)
 assert dt == float(world), dt
+# BASELINE config 5 work split (bench.py --config5): 2 images per rank (one at a time here: the
+# CPU emulation of the kernels is single-threaded; images in flight are a GPU test)
+recs5, secs5 = batch.run_config5(get, 2, lambda rgb: host.process(rgb, quality=84), rank, world,
+                                 dist if world > 1 else None, workers=1)
+assert len(recs5) == 2 * world and [r["index"] for r in recs5] == list(range(2 * world))
+assert all(r["rank"] == r["index"] % world for r in recs5) and secs5 > 0
 if rank == 0:
     print("RECORDS", [(r["index"], r["bytes"], r["sha256"], r["rank"]) for r in recs])
+    print("CONFIG5", [(r["index"], r["sha256"]) for r in recs5])
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
 """
@@ -45,15 +52,19 @@ def _run(world, tmp_path):
                              capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     line = [l for l in out.stdout.splitlines() if l.startswith("RECORDS")][0]
-    return eval(line[len("RECORDS "):])
+    line5 = [l for l in out.stdout.splitlines() if l.startswith("CONFIG5")][0]
+    return eval(line[len("RECORDS "):]), eval(line5[len("CONFIG5 "):])
 
 
 def test_two_ranks_shard_a_batch(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     import build_emu
     build_emu.build_host()
-    single = _run(1, tmp_path)
-    double = _run(2, tmp_path)
+    single, single5 = _run(1, tmp_path)
+    double, double5 = _run(2, tmp_path)
+    # config 5: 2 images per rank -> world 1 encodes images 0, 1; world 2 images 0..3; the
+    # common ones are byte-identical whichever rank (and however many at a time) made them
+    assert double5[:2] == single5 and len({h for _, h in double5}) == 4
     assert [r[:3] for r in single] == [r[:3] for r in double]
     assert [r[3] for r in double] == [0, 1, 0]      # image k -> rank k mod 2
     assert len({r[2] for r in double}) == 3         # three different images

@@ -53,6 +53,7 @@ SIGNATURES = {
     "gz_block_weights_factor": (_I, [_P, _I, _I, C.c_double, _I, _I, _P]),
     "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
     "gz_block_zeroing_orders_masked": (_I, [_P, _I, _I, _I, _P, _P, _P, _I]),
+    "gz_compare_blocks": (_I, [_P, _I, _P, _P, _P]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
     "gz_probe_rank_sort": (_I, [_I, _P, _P, _I, _P]),
     "gz_order_build": (_I, [_P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P]),
@@ -357,6 +358,15 @@ class Context:
                                                             _ptr(err), cap))
         n = int(off[-1])
         return off, idx[:n].copy(), err[:n].copy()
+
+    def compare_blocks(self, block_xy, coeffs):
+        """SwitchBlock + CompareBlock for n (block position, 3x64 coefficients) pairs."""
+        xy = np.ascontiguousarray(block_xy, np.int32).reshape(-1, 2)
+        co = np.ascontiguousarray(coeffs, np.int16).reshape(-1, 3, 64)
+        assert len(xy) == len(co)
+        out = np.zeros(len(xy), np.float64)
+        self._chk(self.L.lib.gz_compare_blocks(self.handle, len(xy), _ptr(xy), _ptr(co), _ptr(out)))
+        return out
 
     # ---- global candidate order of phase B ----
     ORDER_DTYPE = np.dtype([("block", np.int32), ("val", np.float32)])

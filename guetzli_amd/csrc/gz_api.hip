@@ -324,6 +324,9 @@ struct gz_ctx {
   // grid of the last block search (gz_block_zeroing_orders*), which phase B's order works on
   int sg_w = 0, sg_h = 0, sg_n = 0, sg_factor = 1, sg_mask = 7;
   float* d_gmax = nullptr;         // per-16x16 maxima of the distance map (sg_factor == 2)
+  // scratch of k_scan_offsets, one set per stream that runs it (main: order build; entropy: scan)
+  void* d_scan_state[2] = {nullptr, nullptr};
+  unsigned scan_epoch[2] = {0, 0};
   float target = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -855,6 +858,34 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
   return GZ_OK;
 }
 
+// Exclusive 64-bit prefix sums of n 32-bit values on `stream` (which: 0 = the main stream's
+// scratch, 1 = the entropy stream's).
+int enqueue_scan_offsets(gz_ctx* c, int which, hipStream_t stream, const unsigned* d_bits, int n,
+                         unsigned long long* d_off) {
+  const int max_tiles = gz_div_up(c->nb, kScanTile) + 1;
+  const size_t bytes = (size_t)max_tiles * (8 + 8 + 4) + 64;
+  if (!c->d_scan_state[which]) {
+    HIPCHK(c, pool_malloc(&c->d_scan_state[which], bytes));
+    HIPCHK(c, hipMemsetAsync(c->d_scan_state[which], 0, bytes, stream));   // ticket 0, no epoch yet
+    c->scan_epoch[which] = 0;
+  }
+  char* base = (char*)c->d_scan_state[which];
+  ScanState st;
+  st.agg = (unsigned long long*)base;
+  st.incl = st.agg + max_tiles;
+  st.status = (unsigned*)(st.incl + max_tiles);
+  st.ticket = st.status + max_tiles;
+  unsigned ep = ++c->scan_epoch[which];
+  if (ep >= 0x3fffffffu) {   // the epoch field of the flags would wrap: start over
+    HIPCHK(c, hipMemsetAsync(c->d_scan_state[which], 0, bytes, stream));
+    c->scan_epoch[which] = ep = 1;
+  }
+  if (n > max_tiles * kScanTile) { c->err = "scan larger than its scratch"; return GZ_E_STATE; }
+  GZ_LAUNCH(k_scan_offsets, dim3(std::max(1, gz_div_up(n, kScanTile))), dim3(256), stream, d_bits, n, d_off, st, ep);
+  KCHK(c);
+  return GZ_OK;
+}
+
 int stage_chroma_samples(gz_ctx* c, const int16_t* d_coeffs) {
   if (!c->d_csamp) HIPCHK(c, pool_malloc((void**)&c->d_csamp, 2 * csamp_plane(c)));
   GZ_LAUNCH(k_chroma_samples, dim3(gz_div_up(c->nbc, kBlocksPerWG)), dim3(256), c->stream,
@@ -868,13 +899,13 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
                       unsigned* clear_word = nullptr) {
   if (c->cfac == 2) {
     TRY(stage_chroma_samples(c, d_coeffs));
-    GZ_LAUNCH(k_reconstruct420, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream,
+    GZ_LAUNCH(k_reconstruct420, dim3(c->bh * gz_div_up(c->bw, 8)), dim3(256), c->stream,
               d_coeffs, (const uint8_t*)c->d_csamp, c->w, c->h, c->bw, c->nb, c->cbw, c->cbh,
               c->pitch, c->plane, c->d_srgb_lut, lin0, srgb, clear_word);
     KCHK(c);
     return GZ_OK;
   }
-  GZ_LAUNCH(k_reconstruct, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream,
+  GZ_LAUNCH(k_reconstruct, dim3(c->bh * gz_div_up(c->bw, kReconBlocks)), dim3(256), c->stream,
             d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
             srgb, clear_word);
   KCHK(c);
@@ -1186,6 +1217,7 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->d_block_mask); (void)pool_free(c->d_rank_cnt); (void)pool_free(c->d_rank_tables); (void)pool_free(c->d_rank_idx);
   (void)pool_free(c->d_out_cnt); (void)pool_free(c->d_out_idx); (void)pool_free(c->d_out_err);
   (void)pool_free(c->d_step_delta); (void)pool_free(c->d_csamp); (void)pool_free(c->d_gmax);
+  (void)pool_free(c->d_scan_state[0]); (void)pool_free(c->d_scan_state[1]);
   (void)pool_free(c->d_jq); (void)pool_free(c->d_hist); (void)pool_free(c->d_code_depth); (void)pool_free(c->d_code_bits);
   (void)pool_free(c->d_mcu_bits); (void)pool_free(c->d_mcu_off); (void)pool_free(c->d_ff_count);
   (void)pool_free(c->d_words); (void)pool_free(c->d_words_kept);
@@ -1526,9 +1558,7 @@ static int order_build_device(gz_ctx* c, int direction, int count_below, float l
               direction, nb, c->d_order_nb, c->d_order_counters);
     KCHK(c);
   }
-  GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), c->stream, (const unsigned*)c->d_order_nb,
-            nb, c->d_order_off);
-  KCHK(c);
+  TRY(enqueue_scan_offsets(c, 0, c->stream, (const unsigned*)c->d_order_nb, nb, c->d_order_off));
   GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, 4)), dim3(256), c->stream,
             (const float*)c->d_out_err, (const int*)c->d_next_cand, (const float*)c->d_weight,
             (const float*)c->d_max_err, (const unsigned long long*)c->d_order_off, direction, nb,
@@ -1896,9 +1926,7 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   GZ_LAUNCH(k_jpeg_block_bits, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
             (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
   KCHK(c);
-  GZ_LAUNCH(k_jpeg_scan_offsets, dim3(1), dim3(1024), es, (const unsigned*)c->d_mcu_bits,
-            nmcu, c->d_mcu_off);
-  KCHK(c);
+  TRY(enqueue_scan_offsets(c, 1, es, (const unsigned*)c->d_mcu_bits, nmcu, c->d_mcu_off));
   const unsigned long long* d_total = c->d_mcu_off + nmcu;
   const int cgrid = (int)std::min<size_t>(512, (cap_words + 255) / 256);
   GZ_LAUNCH(k_jpeg_clear_words, dim3(cgrid), dim3(256), es, c->d_words, d_total,
@@ -2363,6 +2391,59 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
   }
   offsets[gn] = t;
   return GZ_OK;
+}
+
+static void search_args_common(gz_ctx* c, SearchArgs* a) {
+  a->coeffs = c->d_cand; a->rank_cnt = c->d_rank_cnt; a->rank_idx = c->d_rank_idx;
+  a->rgb = c->d_rgb; a->srgb_lut = c->d_srgb_lut; a->block_mask = c->d_block_mask;
+  a->w = c->w; a->h = c->h; a->bw = c->bw; a->nb = c->nb;
+  for (int i = 0; i < 3; ++i) a->coff[i] = c->coff[i];
+  a->cbw = c->cbw;
+  a->samples = nullptr;
+  a->lookahead = 3;
+  a->limit = c->target;
+  // 8x8 OpsinDynamicsImage: Blur(sigma 1.2, border_ratio 0) on an 8x8 image
+  BlurCfg cfg;
+  make_taps_host((float)kBlurSpecs[B_OPSIN].sigma, &cfg);
+  cfg.border_ratio = 0.0f;
+  a->taps = taps_of<2>(cfg);
+  std::vector<float> lo, hi;
+  border_scales_host(cfg, 8, &lo, &hi);
+  a->scale_lo[0] = lo[0]; a->scale_lo[1] = lo[1];
+  a->scale_hi[0] = hi[0]; a->scale_hi[1] = hi[1];
+  a->out_cnt = c->d_out_cnt; a->out_idx = c->d_out_idx; a->out_err = c->d_out_err;
+}
+
+int gz_compare_blocks(gz_ctx* c, int n, const int32_t* block_xy, const int16_t* coeffs, double* out) {
+  DeviceScope ds_(c);
+  if (!c || n < 0 || (n > 0 && (!block_xy || !coeffs || !out))) return GZ_E_ARG;
+  if (n == 0) return GZ_OK;
+  for (int i = 0; i < n; ++i)
+    if (block_xy[2 * i] < 0 || block_xy[2 * i] >= c->bw || block_xy[2 * i + 1] < 0 || block_xy[2 * i + 1] >= c->bh)
+      return GZ_E_ARG;
+  TRY(ensure_block_mask(c));
+  // staging: positions, coefficients and results share one device block
+  const size_t need = (size_t)n * (8 + 384 + 8);
+  void* dev = nullptr;
+  HIPCHK(c, pool_malloc(&dev, need));
+  int32_t* d_xy = (int32_t*)dev;
+  double* d_out = (double*)((char*)dev + (size_t)n * 8);
+  int16_t* d_blk = (int16_t*)((char*)dev + (size_t)n * 16);
+  int rc = GZ_OK;
+  if (hipMemcpyAsync(d_xy, block_xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemcpyAsync(d_blk, coeffs, (size_t)n * 384, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    rc = GZ_E_HIP;
+  if (rc == GZ_OK) {
+    SearchArgs a;
+    search_args_common(c, &a);
+    GZ_LAUNCH(k_compare_blocks, dim3(n), dim3(64), c->stream, a, (const int32_t*)d_xy, (const int16_t*)d_blk, n, d_out);
+    if (hipGetLastError() != hipSuccess) rc = GZ_E_HIP;
+  }
+  if (rc == GZ_OK && hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = GZ_E_HIP;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) rc = GZ_E_HIP;
+  pool_free(dev);
+  if (rc != GZ_OK) c->err = "gz_compare_blocks: HIP call failed";
+  return rc;
 }
 
 // OutputImage::Downsample (output_image.cc:304-340), cfg defaults of Processor::DownsampleImage

@@ -75,6 +75,25 @@ static __device__ __forceinline__ void gz_stg4(float* p, size_t i, const gz_f4& 
 #define GZ_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
+// Release / acquire accesses at device scope for flags that workgroups of one launch pass to
+// each other through global memory (the decoupled look-back of k_scan_offsets).
+#ifdef GZ_EMU
+#define GZ_STORE_RELEASE(p, v) (*(p) = (v))
+#define GZ_LOAD_ACQUIRE(p) (*(p))
+#else
+#define GZ_STORE_RELEASE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#define GZ_LOAD_ACQUIRE(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
+// a * b for operands that fit 24 bits signed (IDCT: 16-bit coefficients x 14-bit matrix
+// entries; colour conversion: 17-bit constants x 9-bit samples): v_mul_i32_i24 issues at full
+// rate, the general 32-bit v_mul_lo_u32 at a quarter of it.  Same low 32 bits of the product.
+#ifdef GZ_EMU
+#define GZ_MUL24(a, b) ((a) * (b))
+#else
+#define GZ_MUL24(a, b) __mul24((a), (b))
+#endif
+
 static inline int gz_div_up(int a, int b) { return (a + b - 1) / b; }
 
 // ---- XCD-aware tile order ---------------------------------------------------------------

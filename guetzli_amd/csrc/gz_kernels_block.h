@@ -47,60 +47,116 @@ GZ_DEVFN int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 // --------------------------------------------------------------------- reconstruct --
 // coeffs: [3][nb][64] int16.  Outputs (either may be null): lin = 3 float planes with
 // row pitch `pitch`, plane stride `pstride`; srgb = packed u8.
+//
+// One workgroup = 8 blocks side by side = a strip of 64 x 8 pixels: each wavefront runs the
+// integer IDCT of two of the blocks (lane = pixel, three components each), the converted
+// pixels go through LDS, and the strip is written as whole rows: 16 bytes per lane, 256
+// contiguous bytes per row and plane.  (One wavefront per block writing its own 8 x 8 floats
+// -- eight 32-byte fragments per plane, a dword per lane -- ran this streaming kernel at 1.9
+// TB/s; tools/ubench/bw.hip: 3.3 TB/s for dword accesses against 5.0 for 16-byte ones.)
+constexpr int kReconBlocks = 8;   // blocks per workgroup (grid = bh * ceil(bw / 8))
+
+GZ_DEVFN void idct3_to_rgb(const int (*s_in)[64], int (*s_col)[64], int lane, int* r, int* g, int* b) {
+  const int iy = lane >> 3, ix = lane & 7;
+  int px[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    // row pass (idct.cc:150-160): out = clamp((sum + (257 << 17)) >> 18)
+    int acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s_col[c][8 * iy + u]);
+    px[c] = clamp255((acc + (257 << 17)) >> 18);
+  }
+  (void)s_in;
+  // libjpeg YCbCr->RGB (color_transform.h; tables == these formulas, tools/gen_tables.py)
+  const int yy = px[0], cb = px[1] - 128, cr = px[2] - 128, half = 1 << 15;
+  *r = clamp255(yy + ((GZ_MUL24(91881, cr) + half) >> 16));
+  *g = clamp255(yy + ((GZ_MUL24(-46802, cr) + (GZ_MUL24(-22554, cb) + half)) >> 16));
+  *b = clamp255(yy + ((GZ_MUL24(116130, cb) + half) >> 16));
+}
+
 __global__ __launch_bounds__(256) void k_reconstruct(
     const int16_t* __restrict__ coeffs, int w, int h, int bw, int nb, int pitch,
     size_t pstride, const float* __restrict__ srgb_lut, float* __restrict__ lin,
     uint8_t* __restrict__ srgb, unsigned* __restrict__ clear_word) {
   // first kernel of a Compare: also resets the distance accumulator of its last kernel
   if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
-  __shared__ int s_in[3][kBlocksPerWG][64];
-  __shared__ int s_col[3][kBlocksPerWG][64];
+  __shared__ int s_in[kReconBlocks][3][64];
+  __shared__ int s_col[kReconBlocks][3][64];
+  __shared__ __attribute__((aligned(16))) float s_px[3][8][kReconBlocks * 8];   // [plane][row][x]
+  __shared__ uint8_t s_u8[8][kReconBlocks * 8][3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int blk = blockIdx.x * kBlocksPerWG + wave;
-  const bool live = blk < nb;
+  const int strips = (bw + kReconBlocks - 1) / kReconBlocks;
+  const int by = blockIdx.x / strips, bx0 = (blockIdx.x % strips) * kReconBlocks;
   const int iy = lane >> 3, ix = lane & 7;
-  int px[3];
-  // the three components together: one memory latency and two barriers, not three and six
+  // the three components of both blocks together: one memory latency, two barriers
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
-    s_in[c][wave][lane] = live ? (int)coeffs[((size_t)c * nb + blk) * 64 + lane] : 0;
-  __syncthreads();
+  for (int k = 0; k < 2; ++k) {
+    const int j = 2 * wave + k, bx = bx0 + j;
+    const bool live = bx < bw;
+    const size_t blk = (size_t)by * bw + bx;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
-    int acc = 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[c][wave][8 * u + ix];
-    s_col[c][wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+    for (int c = 0; c < 3; ++c)
+      s_in[j][c][lane] = live ? (int)coeffs[((size_t)c * nb + blk) * 64 + lane] : 0;
   }
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    // row pass (:150-160): out = clamp((sum + (257 << 17)) >> 18)
-    int acc = 0;
+  for (int k = 0; k < 2; ++k) {
+    const int j = 2 * wave + k;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[c][wave][8 * iy + u];
-    px[c] = clamp255((acc + (257 << 17)) >> 18);
+    for (int c = 0; c < 3; ++c) {
+      // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
+      int acc = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[j][c][8 * u + ix]);
+      s_col[j][c][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+    }
   }
-  if (!live) return;
-  const int x = 8 * (blk % bw) + ix, y = 8 * (blk / bw) + iy;
-  if (x >= w || y >= h) return;
-  // libjpeg YCbCr->RGB (color_transform.h; tables == these formulas, tools/gen_tables.py)
-  const int yy = px[0], cb = px[1] - 128, cr = px[2] - 128, half = 1 << 15;
-  const int r = clamp255(yy + ((91881 * cr + half) >> 16));
-  const int g = clamp255(yy + ((-46802 * cr + (-22554 * cb + half)) >> 16));
-  const int b = clamp255(yy + ((116130 * cb + half) >> 16));
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int j = 2 * wave + k;
+    int r, g, b;
+    idct3_to_rgb(s_in[j], s_col[j], lane, &r, &g, &b);
+    const int x = 8 * j + ix;
+    if (lin) {
+      s_px[0][iy][x] = srgb_lut[r];
+      s_px[1][iy][x] = srgb_lut[g];
+      s_px[2][iy][x] = srgb_lut[b];
+    }
+    if (srgb) {
+      s_u8[iy][x][0] = (uint8_t)r;
+      s_u8[iy][x][1] = (uint8_t)g;
+      s_u8[iy][x][2] = (uint8_t)b;
+    }
+  }
+  __syncthreads();
+  const int x0 = 8 * bx0, y0 = 8 * by;
   if (lin) {
-    const size_t o = (size_t)y * pitch + x;
-    lin[o] = srgb_lut[r];
-    lin[pstride + o] = srgb_lut[g];
-    lin[2 * pstride + o] = srgb_lut[b];
+    // 3 planes x 8 rows x 16 four-pixel groups = 384 16-byte stores
+    for (int i = threadIdx.x; i < 3 * 8 * (kReconBlocks * 2); i += 256) {
+      const int q = i % (kReconBlocks * 2), row = (i / (kReconBlocks * 2)) % 8, pl = i / (kReconBlocks * 16);
+      const int x = x0 + 4 * q, y = y0 + row;
+      if (y >= h || x >= w) continue;
+      const size_t o = (size_t)pl * pstride + (size_t)y * pitch + x;
+      if (x + 3 < w && (pitch & 3) == 0) {
+        GZ_STG4(lin, o, *reinterpret_cast<const gz_f4*>(&s_px[pl][row][4 * q]));
+      } else {
+        for (int e = 0; e < 4 && x + e < w; ++e) lin[o + e] = s_px[pl][row][4 * q + e];
+      }
+    }
   }
   if (srgb) {
-    uint8_t* p = srgb + ((size_t)y * w + x) * 3;
-    p[0] = (uint8_t)r;
-    p[1] = (uint8_t)g;
-    p[2] = (uint8_t)b;
+    for (int i = threadIdx.x; i < 8 * kReconBlocks * 8; i += 256) {
+      const int xx = i % (kReconBlocks * 8), row = i / (kReconBlocks * 8);
+      const int x = x0 + xx, y = y0 + row;
+      if (x < w && y < h) {
+        uint8_t* p = srgb + ((size_t)y * w + x) * 3;
+        p[0] = s_u8[row][xx][0];
+        p[1] = s_u8[row][xx][1];
+        p[2] = s_u8[row][xx][2];
+      }
+    }
   }
 }
 
@@ -116,11 +172,11 @@ __global__ __launch_bounds__(256) void k_idct_blocks(const int16_t* __restrict__
   s_in[wave][lane] = live ? (int)blocks[(size_t)blk * 64 + lane] : 0;
   __syncthreads();
   int acc = 0;
-  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[wave][8 * u + ix];
+  for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[wave][8 * u + ix]);
   s_col[wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
   __syncthreads();
   acc = 0;
-  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[wave][8 * iy + u];
+  for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s_col[wave][8 * iy + u]);
   if (live) out[(size_t)blk * 64 + lane] = (uint8_t)clamp255((acc + (257 << 17)) >> 18);
 }
 
@@ -157,7 +213,7 @@ __global__ __launch_bounds__(256) void k_chroma_samples(const int16_t* __restric
   for (int c = 0; c < 2; ++c) {
     int acc = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[c][wave][8 * u + ix];
+    for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[c][wave][8 * u + ix]);
     s_col[c][wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
   }
   __syncthreads();
@@ -169,7 +225,7 @@ __global__ __launch_bounds__(256) void k_chroma_samples(const int16_t* __restric
   for (int c = 0; c < 2; ++c) {
     int acc = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[c][wave][8 * iy + u];
+    for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s_col[c][wave][8 * iy + u]);
     samples[c * pl + o] = (uint8_t)clamp255((acc + (257 << 17)) >> 18);
   }
 }
@@ -187,53 +243,95 @@ GZ_DEVFN int chroma420_pixel(const uint8_t* __restrict__ sp, int sw, int mxs, in
   return (p + 8 - (x & 1)) >> 4;
 }
 
-// k_reconstruct for a 4:2:0 frame: luma IDCT per 8x8 block as above, chroma from the sample
-// planes of k_chroma_samples.
+// k_reconstruct for a 4:2:0 frame: luma IDCT of a strip of 8 blocks as in k_reconstruct (which
+// follows below), chroma from the sample planes of k_chroma_samples, whole rows out.
 __global__ __launch_bounds__(256) void k_reconstruct420(
     const int16_t* __restrict__ ycoeffs, const uint8_t* __restrict__ samples, int w, int h, int bw,
     int nb, int cbw, int cbh, int pitch, size_t pstride, const float* __restrict__ srgb_lut,
     float* __restrict__ lin, uint8_t* __restrict__ srgb, unsigned* __restrict__ clear_word) {
   if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
-  __shared__ int s_in[kBlocksPerWG][64];
-  __shared__ int s_col[kBlocksPerWG][64];
+  constexpr int NB = 8;   // blocks per workgroup (== kReconBlocks)
+  __shared__ int s_in[NB][64];
+  __shared__ int s_col[NB][64];
+  __shared__ __attribute__((aligned(16))) float s_px[3][8][NB * 8];
+  __shared__ uint8_t s_u8[8][NB * 8][3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int blk = blockIdx.x * kBlocksPerWG + wave;
-  const bool live = blk < nb;
+  const int strips = (bw + NB - 1) / NB;
+  const int by = blockIdx.x / strips, bx0 = (blockIdx.x % strips) * NB;
   const int iy = lane >> 3, ix = lane & 7;
-  s_in[wave][lane] = live ? (int)ycoeffs[(size_t)blk * 64 + lane] : 0;
-  __syncthreads();
-  int acc = 0;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s_in[wave][8 * u + ix];
-  s_col[wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  for (int k = 0; k < 2; ++k) {
+    const int j = 2 * wave + k, bx = bx0 + j;
+    s_in[j][lane] = bx < bw ? (int)ycoeffs[((size_t)by * bw + bx) * 64 + lane] : 0;
+  }
   __syncthreads();
-  acc = 0;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s_col[wave][8 * iy + u];
-  const int yy = clamp255((acc + (257 << 17)) >> 18);
-  if (!live) return;
-  const int x = 8 * (blk % bw) + ix, y = 8 * (blk / bw) + iy;
-  if (x >= w || y >= h) return;
+  for (int k = 0; k < 2; ++k) {
+    const int j = 2 * wave + k;
+    int acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[j][8 * u + ix]);
+    s_col[j][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  }
+  __syncthreads();
   const int sw = cbw * 8;
-  const size_t pl = (size_t)sw * cbh * 8;
+  const size_t pl_bytes = (size_t)sw * cbh * 8;
   const int mxs = (w - 1) >> 1, mys = (h - 1) >> 1;
-  const int cb = chroma420_pixel(samples, sw, mxs, mys, x, y) - 128;
-  const int cr = chroma420_pixel(samples + pl, sw, mxs, mys, x, y) - 128;
-  const int half = 1 << 15;
-  const int r = clamp255(yy + ((91881 * cr + half) >> 16));
-  const int g = clamp255(yy + ((-46802 * cr + (-22554 * cb + half)) >> 16));
-  const int b = clamp255(yy + ((116130 * cb + half) >> 16));
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int j = 2 * wave + k;
+    int acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s_col[j][8 * iy + u]);
+    const int yy = clamp255((acc + (257 << 17)) >> 18);
+    const int x = 8 * (bx0 + j) + ix, y = 8 * by + iy;
+    int r = 0, g = 0, b = 0;
+    if (x < w && y < h) {
+      const int cb = chroma420_pixel(samples, sw, mxs, mys, x, y) - 128;
+      const int cr = chroma420_pixel(samples + pl_bytes, sw, mxs, mys, x, y) - 128;
+      const int half = 1 << 15;
+      r = clamp255(yy + ((GZ_MUL24(91881, cr) + half) >> 16));
+      g = clamp255(yy + ((GZ_MUL24(-46802, cr) + (GZ_MUL24(-22554, cb) + half)) >> 16));
+      b = clamp255(yy + ((GZ_MUL24(116130, cb) + half) >> 16));
+    }
+    const int xs = 8 * j + ix;
+    if (lin) {
+      s_px[0][iy][xs] = srgb_lut[r];
+      s_px[1][iy][xs] = srgb_lut[g];
+      s_px[2][iy][xs] = srgb_lut[b];
+    }
+    if (srgb) {
+      s_u8[iy][xs][0] = (uint8_t)r;
+      s_u8[iy][xs][1] = (uint8_t)g;
+      s_u8[iy][xs][2] = (uint8_t)b;
+    }
+  }
+  __syncthreads();
+  const int x0 = 8 * bx0, y0 = 8 * by;
   if (lin) {
-    const size_t o = (size_t)y * pitch + x;
-    lin[o] = srgb_lut[r];
-    lin[pstride + o] = srgb_lut[g];
-    lin[2 * pstride + o] = srgb_lut[b];
+    for (int i = threadIdx.x; i < 3 * 8 * (NB * 2); i += 256) {
+      const int q = i % (NB * 2), row = (i / (NB * 2)) % 8, pl = i / (NB * 16);
+      const int x = x0 + 4 * q, y = y0 + row;
+      if (y >= h || x >= w) continue;
+      const size_t o = (size_t)pl * pstride + (size_t)y * pitch + x;
+      if (x + 3 < w && (pitch & 3) == 0) {
+        GZ_STG4(lin, o, *reinterpret_cast<const gz_f4*>(&s_px[pl][row][4 * q]));
+      } else {
+        for (int e = 0; e < 4 && x + e < w; ++e) lin[o + e] = s_px[pl][row][4 * q + e];
+      }
+    }
   }
   if (srgb) {
-    uint8_t* p = srgb + ((size_t)y * w + x) * 3;
-    p[0] = (uint8_t)r;
-    p[1] = (uint8_t)g;
-    p[2] = (uint8_t)b;
+    for (int i = threadIdx.x; i < 8 * NB * 8; i += 256) {
+      const int xx = i % (NB * 8), row = i / (NB * 8);
+      const int x = x0 + xx, y = y0 + row;
+      if (x < w && y < h) {
+        uint8_t* p = srgb + ((size_t)y * w + x) * 3;
+        p[0] = s_u8[row][xx][0];
+        p[1] = s_u8[row][xx][1];
+        p[2] = s_u8[row][xx][2];
+      }
+    }
   }
 }
 

@@ -213,15 +213,24 @@ __global__ __launch_bounds__(64) void k_jpeg_block_bits(const int16_t* __restric
   if (lane == 0) bits[m] = (unsigned)total;
 }
 
-// off[0..nb] = exclusive prefix sums of bits[0..nb) (64-bit).  One workgroup of 1024 walks
-// the array in tiles of 4096: a lane takes 4 consecutive values (one 16-byte load, issued one
-// tile ahead), the tile is scanned in 32 bits (a value is at most a block's scan bits or its
-// candidate count: 4096 of them stay far below 2^31) with wavefront shuffles plus one LDS
-// exchange between the 16 wavefronts, and the running total is carried in 64 bits.  (A
-// variant that stages 32768 values at a time in 135 KB of LDS measured 42 us against this
-// one's 22 us inside an encode: a workgroup that needs most of a CU's LDS waits for the
-// Compare kernels that share the GPU with it.)
-constexpr int kScanTile = 4096;
+// off[0..n] = exclusive prefix sums of bits[0..n) (64-bit), in one pass over the array by
+// ceil(n / 2048) workgroups ("decoupled look-back"): a workgroup scans its tile of 2048 values
+// (8 per thread, two 16-byte loads), publishes the tile's sum, then adds up what the tiles
+// before it have published -- their sums, or from the nearest one that already knows it the
+// inclusive prefix -- 64 predecessors at a time, one per lane.  Tiles are taken in ticket order
+// (a workgroup never waits for one that has not started), the flags carry the launch's epoch so
+// that nothing has to be cleared between launches.  A value is at most an MCU's scan bits or a
+// block's candidate count: a tile's sum stays far below 2^31; prefixes are 64-bit.
+// (Round 1 walked the array with ONE workgroup of 1024: 22-36 us for the 32 400 MCUs of a
+// 1080p image, twice per phase-B iteration on its critical path.)
+constexpr int kScanTile = 2048;
+
+struct ScanState {             // device scratch of one context: ceil(n_max / kScanTile) tiles
+  unsigned long long* agg;     // sum of tile t
+  unsigned long long* incl;    // inclusive prefix up to and including tile t
+  unsigned* status;            // epoch << 2 | {1: agg valid, 2: incl valid too}
+  unsigned* ticket;
+};
 
 struct alignas(16) ScanU4 { unsigned x, y, z, w; };
 
@@ -235,39 +244,85 @@ GZ_DEVFN void scan_load4(const unsigned* __restrict__ bits, int nb, int at, unsi
   }
 }
 
-__global__ __launch_bounds__(1024) void k_jpeg_scan_offsets(const unsigned* __restrict__ bits,
-                                                            int nb,
-                                                            unsigned long long* __restrict__ off) {
-  __shared__ int wave_total[16];
+__global__ __launch_bounds__(256) void k_scan_offsets(const unsigned* __restrict__ bits, int n,
+                                                      unsigned long long* __restrict__ off,
+                                                      ScanState st, unsigned epoch) {
+  __shared__ unsigned s_tile;
+  __shared__ int wave_total[4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  unsigned long long carry = 0;
-  unsigned cur[4], nxt[4];
-  scan_load4(bits, nb, 4 * t, cur);
-  for (int base = 0; base < nb; base += kScanTile) {
-    const int at = base + 4 * t;
-    if (base + kScanTile < nb) scan_load4(bits, nb, at + kScanTile, nxt);
-    const int s0 = (int)cur[0], s1 = s0 + (int)cur[1], s2 = s1 + (int)cur[2], s3 = s2 + (int)cur[3];
-    const int inc = wave_inclusive_sum(s3, lane);
-    if (lane == 63) wave_total[wv] = inc;
-    __syncthreads();
-    int before = 0, all = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int w = wave_total[k];
-      if (k < wv) before += w;
-      all += w;
-    }
-    const unsigned long long excl = carry + (unsigned long long)(before + inc - s3);
-    if (at < nb) off[at] = excl;
-    if (at + 1 < nb) off[at + 1] = excl + (unsigned long long)s0;
-    if (at + 2 < nb) off[at + 2] = excl + (unsigned long long)s1;
-    if (at + 3 < nb) off[at + 3] = excl + (unsigned long long)s2;
-    carry += (unsigned long long)all;
-    __syncthreads();   // wave_total is rewritten by the next tile
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
+  const int ntiles = (int)gridDim.x;
+  if (t == 0) {
+    s_tile = atomicAdd(st.ticket, 1u);
+    if (s_tile == (unsigned)(ntiles - 1)) *st.ticket = 0u;   // every ticket is taken: ready for the next launch
   }
-  if (t == 0) off[nb] = carry;
+  __syncthreads();
+  const int tile = (int)s_tile;
+  const int at = tile * kScanTile + 8 * t;
+  unsigned v[8];
+  scan_load4(bits, n, at, v);
+  scan_load4(bits, n, at + 4, v + 4);
+  int loc[8];
+  int run = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { run += (int)v[e]; loc[e] = run; }   // inclusive within the thread
+  const int inc = wave_inclusive_sum(run, lane);
+  if (lane == 63) wave_total[wv] = inc;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int w = wave_total[k];
+    if (k < wv) before += w;
+    all += w;
+  }
+  if (t == 0) {
+    st.agg[tile] = (unsigned long long)all;
+    if (tile == 0) st.incl[0] = (unsigned long long)all;
+    GZ_STORE_RELEASE(&st.status[tile], (epoch << 2) | (tile == 0 ? 2u : 1u));
+  }
+  // look-back: every wavefront does the same (lane = one predecessor), thread 0 publishes
+  unsigned long long prefix = 0;
+  for (int hi = tile - 1; hi >= 0;) {
+    const int p = hi - lane;
+    unsigned stt = 0;
+    if (p >= 0) {
+      do { stt = GZ_LOAD_ACQUIRE(&st.status[p]); } while ((stt >> 2) != epoch || (stt & 3u) == 0u);
+    }
+    const unsigned long long has_incl = __ballot(p >= 0 && (stt & 3u) == 2u);
+    // lanes nearer than the nearest tile with an inclusive prefix contribute their sums
+    int stop = 64;
+    if (has_incl) {
+      stop = 0;
+      while (!((has_incl >> stop) & 1ull)) ++stop;
+    }
+    unsigned long long mine = 0;
+    if (p >= 0 && lane < stop) mine = st.agg[p];
+    else if (p >= 0 && lane == stop) mine = st.incl[p];
+    // 64-lane sum of 64-bit values through two 32-bit halves
+    unsigned lo32 = (unsigned)mine, hi32 = (unsigned)(mine >> 32);
+    unsigned long long sum = 0;
+    {
+      // wave_inclusive_sum works on int: sum the 16-bit quarters separately (no overflow)
+      const int q0 = (int)(lo32 & 0xffffu), q1 = (int)(lo32 >> 16), q2 = (int)(hi32 & 0xffffu), q3 = (int)(hi32 >> 16);
+      const unsigned long long s0 = (unsigned)__shfl(wave_inclusive_sum(q0, lane), 63);
+      const unsigned long long s1 = (unsigned)__shfl(wave_inclusive_sum(q1, lane), 63);
+      const unsigned long long s2 = (unsigned)__shfl(wave_inclusive_sum(q2, lane), 63);
+      const unsigned long long s3 = (unsigned)__shfl(wave_inclusive_sum(q3, lane), 63);
+      sum = s0 + (s1 << 16) + (s2 << 32) + (s3 << 48);
+    }
+    prefix += sum;
+    if (has_incl) break;
+    hi -= 64;
+  }
+  if (t == 0 && tile > 0) {
+    st.incl[tile] = prefix + (unsigned long long)all;
+    GZ_STORE_RELEASE(&st.status[tile], (epoch << 2) | 2u);
+  }
+  const unsigned long long excl = prefix + (unsigned long long)(before + inc - run);
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (at + e < n) off[at + e] = excl + (unsigned long long)(loc[e] - (int)v[e]);
+  if (tile == ntiles - 1 && t == 255) off[n] = prefix + (unsigned long long)all;
 }
 
 // --------------------------------------------------------------------------- emit ----

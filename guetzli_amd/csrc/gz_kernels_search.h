@@ -150,12 +150,12 @@ GZ_DEVFN void idct_component(SearchLds& s, int c, int zero_k, int lane, int* dst
   __syncthreads();
   int acc = 0;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s.in[8 * u + ix];
+  for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s.in[8 * u + ix]);
   s.col[lane] = (int)(short)((acc + (1 << 10)) >> 11);
   __syncthreads();
   acc = 0;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s.col[8 * iy + u];
+  for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s.col[8 * iy + u]);
   dst[lane] = clamp255((acc + (257 << 17)) >> 18);
   __syncthreads();
 }
@@ -230,7 +230,8 @@ struct SearchView {
 template <int MODE>
 GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, const SearchView& v, const int* ring,
                               const SearchArgs& a) {
-  const int cc = ci >> 6, kk = ci & 63;
+  // ci == 64 * 3: nothing zeroed (the luma component is simply recomputed)
+  const int cc = ci >= 192 ? 0 : ci >> 6, kk = ci >= 192 ? -1 : ci & 63;
   idct_component(s, cc, kk, lane, s.cpx);
   // edge replication + colour + LUT
   const int iy = lane >> 3, ix = lane & 7;
@@ -249,9 +250,9 @@ GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, const SearchView& 
     pcr = (cc == 2 ? s.cpx[sp] : s.ycc[2][sp]) - 128;
   }
   const int half = 1 << 15;
-  const int r = clamp255(py + ((91881 * pcr + half) >> 16));
-  const int g = clamp255(py + ((-46802 * pcr + (-22554 * pcb + half)) >> 16));
-  const int b = clamp255(py + ((116130 * pcb + half) >> 16));
+  const int r = clamp255(py + ((GZ_MUL24(91881, pcr) + half) >> 16));
+  const int g = clamp255(py + ((GZ_MUL24(-46802, pcr) + (GZ_MUL24(-22554, pcb) + half)) >> 16));
+  const int b = clamp255(py + ((GZ_MUL24(116130, pcb) + half) >> 16));
   s.lin[0][lane] = s.lut[r];
   s.lin[1][lane] = s.lut[g];
   s.lin[2][lane] = s.lut[b];
@@ -382,12 +383,12 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
       __syncthreads();
       int acc = 0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += kIdctM[8 * iy + u] * s.in[8 * u + ix];
+      for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s.in[8 * u + ix]);
       s.col[lane] = (int)(short)((acc + (1 << 10)) >> 11);
       __syncthreads();
       acc = 0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += kIdctM[8 * ix + u] * s.col[8 * iy + u];
+      for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s.col[8 * iy + u]);
       s.ycc[0][lane] = clamp255((acc + (257 << 17)) >> 18);
       __syncthreads();
     }
@@ -491,6 +492,56 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
   for (int i = lane; i < num; i += 64) {
     a.out_idx[(size_t)blk * 192 + i] = s.oidx[i];
     a.out_err[(size_t)blk * 192 + i] = s.oerr[i];
+  }
+}
+
+// ButteraugliComparator::SwitchBlock + CompareBlock (butteraugli_comparator.cc:427-488) with
+// factor 1 for n independent (block position, 3 x 64 coefficients) pairs: the per-block form of
+// the Comparator seam (gz_compare_blocks), one wavefront per pair.  Returns the double
+// CompareBlock returns (before the caller's cast to float).
+__global__ __launch_bounds__(64) void k_compare_blocks(SearchArgs a, const int32_t* __restrict__ block_xy,
+                                                       const int16_t* __restrict__ blocks, int n,
+                                                       double* __restrict__ out) {
+  __shared__ SearchLds s;
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int bx = block_xy[2 * i], by = block_xy[2 * i + 1];
+  const int xmin = 8 * bx, ymin = 8 * by;
+  const int iy = lane >> 3, ix = lane & 7;
+  for (int k = lane; k < 256; k += 64) s.lut[k] = a.srgb_lut[k];
+  for (int c = 0; c < 3; ++c) s.coef[64 * c + lane] = blocks[((size_t)i * 3 + c) * 64 + lane];
+  __syncthreads();
+  {
+    const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
+    const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
+    const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
+    s.lin[0][lane] = s.lut[p[0]];
+    s.lin[1][lane] = s.lut[p[1]];
+    s.lin[2][lane] = s.lut[p[2]];
+    __syncthreads();
+    float x0, y0, z0;
+    opsin8x8(s, lane, a, &x0, &y0, &z0);
+    s.x0[0][lane] = x0;
+    s.x0[1][lane] = y0;
+    s.x0[2][lane] = z0;
+  }
+  for (int c = 1; c < 3; ++c) idct_component(s, c, -1, lane, s.ycc[c]);
+  SearchView v;
+  v.off_x = v.off_y = 0;
+  v.in_image = true;
+  v.vw = a.w - xmin < 8 ? a.w - xmin : 8;
+  v.vh = a.h - ymin < 8 ? a.h - ymin : 8;
+  const int mb = by * a.bw + bx;
+  v.m0 = a.block_mask[mb];
+  v.m1 = a.block_mask[a.nb + mb];
+  v.m2 = a.block_mask[2 * a.nb + mb];
+  // candidate index 192: the luma component is recomputed with no coefficient zeroed
+  (void)eval_candidate<0>(s, 192, lane, v, nullptr, a);
+  if (lane == 0) {
+    double diff = 0.0;
+    diff += s.red[0] * (double)v.m0;
+    diff += s.red[1] * (double)v.m1;
+    diff += s.red[2] * (double)v.m2;
+    out[i] = sqrt(diff);
   }
 }
 

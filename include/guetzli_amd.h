@@ -230,6 +230,16 @@ int gz_block_zeroing_orders(gz_ctx* ctx, int lookahead, int new_model, int32_t* 
  * same grid and mask. */
 int gz_block_zeroing_orders_masked(gz_ctx* ctx, int comp_mask, int lookahead, int new_model,
                                    int32_t* offsets, uint8_t* idx, float* err, int cap);
+/* The per-block form of the seam: Comparator::SwitchBlock + CompareBlock
+ * (butteraugli_comparator.cc:427-488; factor_x = factor_y = 1) for n independent pairs of a
+ * block position block_xy[i] = {block_x, block_y} and that block's candidate coefficients
+ * coeffs[i][3][64] (Y, Cb, Cr; dequantised): out[i] = the distance CompareBlock returns.
+ * StartBlockComparisons' mask (:415-421) is computed on first use.  This is what a
+ * `guetzli::Comparator` subclass calls from its CompareBlock (tests/integration/ drives the
+ * UNMODIFIED reference Processor through it); a search that wants speed batches whole blocks'
+ * searches with gz_block_zeroing_orders instead -- one call per block costs a round trip. */
+int gz_compare_blocks(gz_ctx* ctx, int n, const int32_t* block_xy, const int16_t* coeffs,
+                      double* out);
 /* Host-only helper, exported for tests: the ranked input_order of
  * ComputeBlockZeroingOrder (processor.cc:381-400) for every block, as CSR, by std::sort
  * itself.  gz_block_zeroing_orders ranks on the device. */

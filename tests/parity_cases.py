@@ -564,3 +564,26 @@ def case_global_order420(L, w, h, chk, x0=0, y0=0, qs=3, target=0.971769):
             assert_bits_equal(delta, after[1].astype(np.int64) - before[1].astype(np.int64),
                               f"steps_histogram_delta (4:2:0) direction {direction}")
     oc.close()
+
+
+def case_compare_blocks(L, w, h, x0=0, y0=0, qs=3, n=24):
+    """gz_compare_blocks == Comparator::SwitchBlock + CompareBlock (the per-block seam)."""
+    rng = np.random.default_rng(RNG_SEED + 17 * w + h)
+    rgb = images.crop(w, h, x0, y0)
+    oc = oracle.comparator(rgb, 0.971769)
+    with L.context(rgb, 0.971769) as ctx:
+        ctx.encode_rgb()
+        cq = ctx.quantize(np.full((3, 64), qs, np.int32))
+        bw = ctx.bw
+        xy, blocks, exp = [], [], []
+        for _ in range(n):
+            b = int(rng.integers(0, ctx.nb))
+            cand = cq.copy()
+            for _ in range(int(rng.integers(0, 4))):   # zero a few coefficients of the block
+                cand[int(rng.integers(0, 3)), b, int(rng.integers(1, 64))] = 0
+            xy.append((b % bw, b // bw))
+            blocks.append(cand[:, b, :])
+            exp.append(oc.compare_block(cand, b % bw, b // bw))
+        got = ctx.compare_blocks(np.array(xy), np.stack(blocks))
+        assert_bits_equal(got, np.array(exp, np.float64), "CompareBlock")
+    oc.close()

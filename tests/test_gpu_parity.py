@@ -191,6 +191,11 @@ def test_block_search_small_ragged(L):
     pc.case_block_search(L, 64, 40, x0=10, y0=10, qs=2)
 
 
+def test_compare_blocks(L):
+    pc.case_compare_blocks(L, 45, 27, x0=100, y0=60)
+    pc.case_compare_blocks(L, 200, 120, x0=100, y0=60, n=200)
+
+
 def test_block_search_bees(L):
     """Phase A on the whole BASELINE config-1 image (1848 blocks, ~300k CompareBlock
     evaluations) against the oracle, bit for bit."""

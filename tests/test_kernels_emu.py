@@ -68,13 +68,17 @@ def test_block_search(L):
     pc.case_block_search(L, 45, 27)
 
 
+def test_compare_blocks(L):
+    pc.case_compare_blocks(L, 45, 27, x0=100, y0=60)
+
+
 @pytest.fixture(scope="module")
 def host_emu():
     from guetzli_amd.encoder import HostLibrary
     return HostLibrary(build_emu.build_host())
 
 
-@pytest.mark.parametrize("wh", [(61, 43), (32, 32), (129, 9), (8, 8)])
+@pytest.mark.parametrize("wh", [(61, 43), (32, 32), (129, 9), (8, 8), (448, 296)])   # the last: 2072 MCUs = two scan tiles
 def test_jpeg_entropy(L, host_emu, wh):
     pc.case_jpeg_entropy(L, host_emu, *wh, x0=100, y0=50)
 

@@ -511,7 +511,7 @@ static bool compact_code(const gz_ctx* c, const char* knob) {
   const char* e = getenv(knob);
   if (e) return atoi(e) != 0;
   const size_t px = (size_t)c->w * c->h;
-  return px >= 1500000 && px < 4000000;
+  return px < 4000000;
 }
 // Images below ~1.5 MPix use 16-row tiles for the passes without block maxima: twice the
 // workgroups again (720p: 0.290 -> 0.257 ms per Compare; no gain at 1080p, a small loss at 4K).
@@ -531,9 +531,15 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
   if (!BM && compact_code(c, "GZ_COMPACT_BLUR_V")) {
-    dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
-    GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-              pitch, tp, bs, bm);
+    if (small_tiles(c)) {
+      dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
+      GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
+                pitch, tp, bs, bm);
+    } else {
+      dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
+      GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
+                pitch, tp, bs, bm);
+    }
     KCHK(c);
     return GZ_OK;
   }
@@ -558,10 +564,16 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bx = cfg.bx, by = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (!BM && NC > 1 && compact_code(c, "GZ_COMPACT_BLUR2D")) {   // rolled channel loop
-    dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
-    GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w,
-              h, pitch, tp, bx, by, bm);
+  if (!BM && compact_code(c, "GZ_COMPACT_BLUR2D")) {   // rolled channel / post / border-path loops
+    if (small_tiles(c)) {
+      dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
+      GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w,
+                h, pitch, tp, bx, by, bm);
+    } else {
+      dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
+      GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w,
+                h, pitch, tp, bx, by, bm);
+    }
     KCHK(c);
     return GZ_OK;
   }

@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
         tile[ry][rx] = v;
       }
       __syncthreads();
+#pragma unroll 1
       for (int ry = hr; ry < IH; ry += 16) {
         float o[4];
 #pragma unroll
@@ -538,19 +539,22 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
         for (int i = 0; i < 4; ++i) tile[ry][hq + i] = o[i];
       }
       __syncthreads();
-#pragma unroll
+      // (ROLL: the column loop of this rarely taken path stays a loop, results go to LDS)
+      constexpr int kColUnroll = ROLL ? 1 : VPTt;
+#pragma unroll kColUnroll
       for (int i = 0; i < VPTt; ++i) {
         const int ly = tg * VPTt + i;
         const int y = y0 + ly;
         float sum = 0.0f;
         if (y < h) {
           const bool border = y < R || y >= h - R;
+          const float* col = &tile[ly][tx];
           if (!border) {
 #pragma unroll
-            for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.ks[j];
+            for (int j = 0; j <= 2 * R; ++j) sum += col[j * IW] * taps.ks[j];
           } else {
 #pragma unroll
-            for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.k[j];
+            for (int j = 0; j <= 2 * R; ++j) sum += col[j * IW] * taps.k[j];
             sum = sum * (y < R ? bsy.lo[y] : bsy.hi[h - 1 - y]);
           }
         }
@@ -559,6 +563,20 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
     }
   }
   const int x = x0 + tx;
+  if (ROLL && !BM) {
+    // the Post functor once in the code, not once per row of the thread
+#pragma unroll 1
+    for (int i = 0; i < VPTt; ++i) {
+      const int y = y0 + tg * VPTt + i;
+      if (x < w && y < h) {
+        float v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = outv[c][tg * VPTt + i][tx];   // (own writes)
+        (void)post((size_t)y * pitch + x, v);
+      }
+    }
+    return;
+  }
   float res[VPTt];
 #pragma unroll
   for (int i = 0; i < VPTt; ++i) {

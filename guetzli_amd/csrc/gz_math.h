@@ -39,18 +39,34 @@ GZ_DEVFN double clenshaw6(double x, double c0, double c1, double c2, double c3, 
   return (xb - b2) + c0;
 }
 
-// Returns (double)(float)(yp/yq) exactly like RationalPolynomial::operator().
-GZ_DEVFN double gamma_poly(double v) {
+// float(yp / yq) of RationalPolynomial::operator() (butteraugli.h:581-591) -- what its
+// `static_cast<float>` leaves before the caller widens it again.
+//
+// Two of the three FP64 divisions per channel of the reference's sensitivity are evaluated by
+// cheaper sequences that give the SAME bits (tests/cpp/verify_opsin_divisions.cc):
+//  * x01 = (v - kMin) / (kMax - kMin) divides by a constant b: with y = RN(1/b),
+//    q = a*y, r = fma(-b, q, a) (exact), q' = fma(r, y, q) is the correctly rounded a/b --
+//    verified for every finite float v exhaustively (2^32 inputs, 0 mismatches);
+//  * float(double(g) / double(p)) for float g, p is the float quotient g / p: a double has
+//    53 >= 2*24 + 2 digits, which makes the second rounding innocuous (Figueroa); opsin_pixel
+//    below divides in f32 (about 10 instructions against about 30 for an FP64 division).
+// The division yp / yq of two computed doubles stays an FP64 division.
+GZ_DEVFN float gamma_poly_f(double v) {
   const double kMin = 0.971783, kMax = 590.188894;
-  const double x01 = (v - kMin) / (kMax - kMin);
+  const double b = kMax - kMin;
+  const double y = 1.0 / b;
+  const double a = v - kMin;
+  const double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  const double x01 = __builtin_fma(r, y, q);
   const double xc = 2.0 * x01 - 1.0;
   const double yp = clenshaw6(xc, 98.7821300963361, 164.273222212631, 92.948112871376,
                               33.8165311212688, 6.91626704983562, 0.556380877028234);
   const double yq = clenshaw6(xc, 1, 1.64339473427892, 0.89392405219969,
                               0.298947051776379, 0.0507146002577288,
                               0.00226495093949756);
-  if (yq == 0.0) return 0.0;
-  return (double)(float)(yp / yq);
+  if (yq == 0.0) return 0.0f;
+  return (float)(yp / yq);
 }
 
 // One pixel of OpsinDynamicsImage (butteraugli.cc:337-363): blurred rgb -> sensitivity,
@@ -59,9 +75,10 @@ GZ_DEVFN void opsin_pixel(float br, float bg, float bb, float r, float g, float 
                           float* x, float* y, float* z) {
   float p0, p1, p2, c0, c1, c2;
   opsin_absorbance(br, bg, bb, &p0, &p1, &p2);
-  const float s0 = (float)(gamma_poly((double)p0) / (double)p0);
-  const float s1 = (float)(gamma_poly((double)p1) / (double)p1);
-  const float s2 = (float)(gamma_poly((double)p2) / (double)p2);
+  // (float)(Gamma((double)p) / (double)p), butteraugli.cc:351-353
+  const float s0 = gamma_poly_f((double)p0) / p0;
+  const float s1 = gamma_poly_f((double)p1) / p1;
+  const float s2 = gamma_poly_f((double)p2) / p2;
   opsin_absorbance(r, g, b, &c0, &c1, &c2);
   c0 *= s0;
   c1 *= s1;

@@ -51,3 +51,17 @@ def test_device_ranking_is_std_sort_in_emulation(tmp_path):
     out = subprocess.run([_build_rank_sort(tmp_path), build_emu.build()], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "restatement == std::sort" in out.stdout and "device == std::sort" in out.stdout
+
+
+def test_opsin_division_identities_hold_for_every_float(tmp_path):
+    """gz_math.h evaluates two of the reference's three FP64 divisions per channel of the opsin
+    sensitivity by cheaper sequences (a division by a constant through two FMAs; a double
+    quotient of floats rounded to float as the float quotient).  tests/cpp/
+    verify_opsin_divisions.cc checks the first on ALL 2^32 float inputs and the second on 10^9
+    random / in-range pairs against the plain C++ divisions (x86-64, as the reference runs)."""
+    exe = str(tmp_path / "verify_div")
+    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", "-pthread",
+                    os.path.join(ROOT, "tests", "cpp", "verify_opsin_divisions.cc"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(" 0 mismatches") == 2, out.stdout

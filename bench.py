@@ -270,7 +270,7 @@ def main():
                          args.in_flight, size5)
     traffic = {}
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_compare_pmc_traffic_v6.json")))
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_compare_pmc_traffic.json")))
     except Exception:
         pass
 
@@ -306,6 +306,14 @@ def main():
                             "traffic": traffic.get("4k", {}).get("traffic_bytes"),
                             "ms_per_compare": round(ms_4k, 4),
                             "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * 3840 * 2160},
+            # phase A (not HBM-bound -- reported in evaluations, not bytes)
+            "block_search": {"evaluations": info["counters"].get("block search evaluations"),
+                             "seconds": round(info["timers"].get("block_search", 0.0), 4),
+                             "evaluations_per_s": round(info["counters"].get("block search evaluations", 0) /
+                                                        max(info["timers"].get("block_search", 0.0), 1e-9)),
+                             "note": "CompareBlock evaluations (one 8x8 IDCT + colour + opsin + FFT "
+                                     "distance each) of gz_block_zeroing_orders; VALU utilisation of "
+                                     "k_block_search: profiles/r02_block_search_pmc.csv"},
             "host_timers_s": {k: round(v, 3) for k, v in info["timers"].items()
                               if k in ("total", "phase_b_host", "compare", "block_search",
                                        "jpeg_write", "create+encode", "select_quant_matrix")},

@@ -36,6 +36,7 @@ SIGNATURES = {
     "gz_set_orig_coeffs": (_I, [_P, _P]),
     "gz_set_orig_coeffs_420": (_I, [_P, _P]),
     "gz_downsample": (_I, [_P, _P]),
+    "gz_downsample_planes": (_I, [_P, _P, _P, _P, _P]),
     "gz_frame_layout": (_I, [_P, _P, _P, _P]),
     "gz_quantize": (_I, [_P, _P, _P]),
     "gz_set_coeffs": (_I, [_P, _P]),
@@ -54,6 +55,7 @@ SIGNATURES = {
     "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
     "gz_block_zeroing_orders_masked": (_I, [_P, _I, _I, _I, _P, _P, _P, _I]),
     "gz_compare_blocks": (_I, [_P, _I, _P, _P, _P]),
+    "gz_search_evaluations": (_I, [_P, _P]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
     "gz_probe_rank_sort": (_I, [_I, _P, _P, _I, _P]),
     "gz_order_build": (_I, [_P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P]),
@@ -273,6 +275,15 @@ class Context:
         self._chk(self.L.lib.gz_downsample(self.handle, _ptr(out)))
         return out
 
+    def downsample_planes(self, y, u, v, download=True):
+        """The silver-screen branch of OutputImage::Downsample, given RGBToYUV420's planes."""
+        pl = [np.ascontiguousarray(p, np.float32) for p in (y, u, v)]
+        assert all(p.size == self.w * self.h for p in pl)
+        self.cfac = 2
+        out = self._coeff_buf() if download else None
+        self._chk(self.L.lib.gz_downsample_planes(self.handle, _ptr(pl[0]), _ptr(pl[1]), _ptr(pl[2]), _ptr(out)))
+        return out
+
     def quantize(self, q=None, download=True):
         qq = None if q is None else np.ascontiguousarray(q, np.int32)
         out = self._coeff_buf() if download else None
@@ -358,6 +369,11 @@ class Context:
                                                             _ptr(err), cap))
         n = int(off[-1])
         return off, idx[:n].copy(), err[:n].copy()
+
+    def search_evaluations(self):
+        n = np.zeros(1, np.uint64)
+        self._chk(self.L.lib.gz_search_evaluations(self.handle, _ptr(n)))
+        return int(n[0])
 
     def compare_blocks(self, block_xy, coeffs):
         """SwitchBlock + CompareBlock for n (block position, 3x64 coefficients) pairs."""

@@ -409,6 +409,7 @@ struct gz_ctx {
   // memory costs 27 us per round trip on this system, into pinned memory 15)
   void* h_res = nullptr; size_t h_res_cap = 0;
   size_t search_total = 0;   // candidates phase A produced (bounds every global order)
+  unsigned long long search_evaluations = 0;   // CompareBlock evaluations of the last block search
   float last_distance = 0.0f;
 };
 
@@ -2382,7 +2383,8 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
   KCHK(c);
   c->have_search = true;
   c->search_total = 0;   // set below, once the counts are on the host
-  std::vector<int32_t> cnt(gn);
+  std::vector<int32_t> cnt(gn), rcnt(gn);
+  HIPCHK(c, hipMemcpyAsync(rcnt.data(), c->d_rank_cnt, sizeof(int32_t) * gn, hipMemcpyDeviceToHost, c->stream));
   std::vector<uint8_t> widx((size_t)gn * 192);
   std::vector<float> werr(err ? (size_t)gn * 192 : 0);   // the errors stay on the device for gz_order_build
   HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_out_cnt, sizeof(int32_t) * gn, hipMemcpyDeviceToHost, c->stream));
@@ -2393,6 +2395,19 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
   long total = 0;
   for (int b = 0; b < gn; ++b) total += cnt[b];
   c->search_total = (size_t)total;
+  // evaluations: step s of a block with n candidates compares min(lookahead, n - s) of them, on
+  // every 8x8 block of its area that lies inside the image
+  c->search_evaluations = 0;
+  for (int b = 0; b < gn; ++b) {
+    unsigned long long e = 0;
+    for (int s2 = 0; s2 < rcnt[b]; ++s2) e += (unsigned long long)std::min(lookahead, rcnt[b] - s2);
+    int sub = 1;
+    if (mode == 2) {
+      const int bx = b % c->cbw, by = b / c->cbw;
+      sub = ((16 * bx + 8 < c->w) ? 2 : 1) * ((16 * by + 8 < c->h) ? 2 : 1);
+    }
+    c->search_evaluations += e * sub;
+  }
   if (total > cap) { c->err = "candidate capacity too small, need " + std::to_string(total); offsets[gn] = (int32_t)total; return GZ_E_ARG; }
   int t = 0;
   for (int b = 0; b < gn; ++b) {
@@ -2456,6 +2471,12 @@ int gz_compare_blocks(gz_ctx* c, int n, const int32_t* block_xy, const int16_t* 
   pool_free(dev);
   if (rc != GZ_OK) c->err = "gz_compare_blocks: HIP call failed";
   return rc;
+}
+
+int gz_search_evaluations(gz_ctx* c, uint64_t* evaluations) {
+  if (!c || !evaluations) return GZ_E_ARG;
+  *evaluations = c->search_evaluations;
+  return GZ_OK;
 }
 
 // OutputImage::Downsample (output_image.cc:304-340), cfg defaults of Processor::DownsampleImage
@@ -2539,6 +2560,36 @@ int gz_downsample(gz_ctx* c, int16_t* coeffs_out) {
     int16_t* dst = c->d_orig + ((size_t)c->nb + (size_t)(i - 1) * nbc) * 64;
     GZ_LAUNCH(k_set_downsampled_coeffs, dim3(gz_div_up(nbc, kBlocksPerWG)), dim3(256), c->stream,
               (const float*)yuv[i], w, h, 2, 2, cbw, nbc, dst);
+    KCHK(c);
+  }
+  set_frame(c, 2);
+  c->have_cand = false;
+  c->have_distmap = false;
+  if (coeffs_out)
+    HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_orig, (size_t)c->nblk * 128, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_downsample_planes(gz_ctx* c, const float* y, const float* u, const float* v, int16_t* coeffs_out) {
+  DeviceScope ds_(c);
+  if (!c || !y || !u || !v) return GZ_E_ARG;
+  if (!c->have_orig || c->cfac != 1) { c->err = "gz_downsample_planes needs the original coefficients of a 4:4:4 frame"; return GZ_E_STATE; }
+  const int w = c->w, h = c->h;
+  const size_t n = (size_t)w * h;
+  const float* src[3] = {y, u, v};
+  for (int i = 0; i < 3; ++i)
+    HIPCHK(c, hipMemcpyAsync(c->xyb[i], src[i], n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  // output_image.cc:314-316: every component from its plane, luma included (factor 1), the
+  // chroma blocks packed behind the nb luma blocks
+  const int cbw = (w + 15) / 16, cbh = (h + 15) / 16, nbc = cbw * cbh;
+  GZ_LAUNCH(k_set_downsampled_coeffs, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream,
+            (const float*)c->xyb[0], w, h, 1, 1, c->bw, c->nb, c->d_orig);
+  KCHK(c);
+  for (int i = 1; i < 3; ++i) {
+    int16_t* dst = c->d_orig + ((size_t)c->nb + (size_t)(i - 1) * nbc) * 64;
+    GZ_LAUNCH(k_set_downsampled_coeffs, dim3(gz_div_up(nbc, kBlocksPerWG)), dim3(256), c->stream,
+              (const float*)c->xyb[i], w, h, 2, 2, cbw, nbc, dst);
     KCHK(c);
   }
   set_frame(c, 2);

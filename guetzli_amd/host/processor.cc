@@ -13,6 +13,7 @@
 #include "../../include/guetzli_amd.h"
 #include "jpeg_reader.h"
 #include "png_reader.h"
+#include "silver_screen.h"
 #include "jpeg_writer.h"
 #include "lazy_sort.h"
 #include "parallel.h"
@@ -294,7 +295,7 @@ class Encoder {
   double t_pb_ensure_ = 0, t_pb_fast_ = 0;
   long n_fast_ = 0;
   double t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
-  long n_steps_ = 0, n_order_ = 0;
+  long n_steps_ = 0, n_order_ = 0, n_evaluations_ = 0;
   size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device (32-64 K measured best at 1080p and 4K)
 };
 
@@ -580,6 +581,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
                                           cand_idx.data(), nullptr, nb * 189);
   t_blocksearch_ += sw.lap();
   if (rc != GZ_OK) return Fail("gz_block_zeroing_orders", rc);
+  {
+    uint64_t ev = 0;
+    if (gz_search_evaluations(ctx_, &ev) == GZ_OK) n_evaluations_ += (long)ev;
+  }
 
   // ---- size model of the starting point ----
   SymbolHistogram dc_histo[3], ac_histo[3];
@@ -878,8 +883,21 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
         jpg_ncomp_ = 1;   // Downsample does nothing (output_image.cc:305-308); one component is saved
       } else {
         Stopwatch dw;
-        rc = gz_downsample(ctx_, orig_.data());
-        if (rc != GZ_OK) return Fail("gz_downsample", rc);
+        if (params_.use_silver_screen) {
+          // output_image.cc:309-318: ToSRGB() of the unquantised image -> RGBToYUV420 (host:
+          // silver_screen.cc) -> all three components from the planes it returns
+          std::vector<uint8_t> srgb((size_t)3 * w_ * h_);
+          rc = gz_quantize(ctx_, nullptr, nullptr);
+          if (rc == GZ_OK) rc = gz_reconstruct(ctx_, srgb.data(), nullptr);
+          if (rc != GZ_OK) return Fail("gz_reconstruct", rc);
+          std::vector<float> py, pu, pv;
+          SilverScreenYUV420(srgb.data(), w_, h_, &py, &pu, &pv);
+          rc = gz_downsample_planes(ctx_, py.data(), pu.data(), pv.data(), orig_.data());
+          if (rc != GZ_OK) return Fail("gz_downsample_planes", rc);
+        } else {
+          rc = gz_downsample(ctx_, orig_.data());
+          if (rc != GZ_OK) return Fail("gz_downsample", rc);
+        }
         SetFrame(2);
         stats_->timers["downsample"] = dw.lap();
       }
@@ -915,6 +933,7 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->timers["pb_loop_codes"] = t_pb_codes_;
   stats_->timers["pb_loop_ensure_sorted"] = t_pb_ensure_;
   stats_->timers["pb_loop_fast_steps"] = t_pb_fast_;
+  stats_->counters["block search evaluations"] = (int)std::min<long>(n_evaluations_, 2000000000L);
   stats_->counters["phase B fast steps"] = (int)n_fast_;
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
@@ -989,10 +1008,6 @@ bool Encoder::RunJpeg(const std::string& data, std::string* out) {
     fprintf(stderr, "Unsupported sampling factors:");
     for (const JpegComponentIn& comp : jpg.components) fprintf(stderr, " %dx%d", comp.h_samp, comp.v_samp);
     fprintf(stderr, "\n");
-    return false;
-  }
-  if (params_.use_silver_screen && !jpg.Is420() && (params_.try_420 || params_.force_420)) {
-    fprintf(stderr, "guetzli_amd: Params::use_silver_screen is not implemented\n");
     return false;
   }
   const int w = jpg.width, h = jpg.height;
@@ -1092,10 +1107,6 @@ bool Encoder::Run(const std::vector<uint8_t>& rgb, int w, int h, std::string* ou
             "Guetzli should be called with quality >= 84, otherwise the\n"
             "output will have noticeable artifacts. If you want to\n"
             "proceed anyway, please edit the source code.\n");
-    return false;
-  }
-  if (params_.use_silver_screen && (params_.try_420 || params_.force_420)) {
-    fprintf(stderr, "guetzli_amd: Params::use_silver_screen is not implemented\n");
     return false;
   }
   if (w < 0 || w >= 1 << 16 || h < 0 || h >= 1 << 16 || rgb.size() != (size_t)3 * w * h) {

@@ -111,6 +111,14 @@ int gz_set_orig_coeffs_420(gz_ctx* ctx, const int16_t* coeffs);
  * receives the new original, nb + 2*nbc blocks.  The caller skips the call for a greyscale
  * image, as the reference does (:305-308). */
 int gz_downsample(gz_ctx* ctx, int16_t* coeffs_out);
+/* The use_silver_screen branch of OutputImage::Downsample (output_image.cc:309-318): y, u, v
+ * are the three w x h planes RGBToYUV420 returned (preprocess_downsample.cc:452-476; host
+ * work: it is twenty rounds of libm pow(), guetzli_amd/host/silver_screen.cc restates it on
+ * OutputImage::ToSRGB() = gz_quantize(NULL) + gz_reconstruct of the 4:4:4 original).  All three
+ * components become SetDownsampledCoefficients of their plane -- luma by 1 x 1, chroma by
+ * 2 x 2 -- and the context's frame 4:2:0, as after gz_downsample. */
+int gz_downsample_planes(gz_ctx* ctx, const float* y, const float* u, const float* v,
+                         int16_t* coeffs_out);
 /* Current frame: chroma subsampling factor (1 or 2), luma blocks, blocks per chroma
  * component.  Any pointer may be NULL. */
 int gz_frame_layout(gz_ctx* ctx, int* chroma_factor, int* luma_blocks, int* chroma_blocks);
@@ -230,6 +238,10 @@ int gz_block_zeroing_orders(gz_ctx* ctx, int lookahead, int new_model, int32_t* 
  * same grid and mask. */
 int gz_block_zeroing_orders_masked(gz_ctx* ctx, int comp_mask, int lookahead, int new_model,
                                    int32_t* offsets, uint8_t* idx, float* err, int cap);
+/* Number of CompareBlock evaluations (butteraugli_comparator.cc:457-488) the last
+ * gz_block_zeroing_orders* call made -- the unit the search's throughput is reported in
+ * (bench.py: evaluations per second). */
+int gz_search_evaluations(gz_ctx* ctx, uint64_t* evaluations);
 /* The per-block form of the seam: Comparator::SwitchBlock + CompareBlock
  * (butteraugli_comparator.cc:427-488; factor_x = factor_y = 1) for n independent pairs of a
  * block position block_xy[i] = {block_x, block_y} and that block's candidate coefficients

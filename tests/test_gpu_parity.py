@@ -186,6 +186,38 @@ def test_full_size_properties_1080p(L):
         assert d1 == ed
 
 
+def test_large_odd_image_24_mpix(L):
+    """Beyond 4K, neither dimension a multiple of 4 or 8 (6001 x 4003 = 24 MPix: every kernel's
+    generic path at scale, size_t index arithmetic, a 3.9 GB plane arena): the block path, the
+    distance map and its block maxima bit for bit against the oracle, and the exact scan size of
+    the device entropy coder against the serial host writer."""
+    import guetzli_amd
+    w, h = 6001, 4003
+    rgb = images.tiled(w, h)
+    target = 0.971769
+    with L.context(rgb, target) as ctx:
+        co = ctx.encode_rgb()
+        assert_bits_equal(co, oracle.encode_rgb(rgb), "encode_rgb 24 MPix")
+        q = np.full((3, 64), 5, np.int32)
+        cq = ctx.quantize(q)
+        d1, m1, b1 = ctx.compare()
+        oc = oracle.comparator(rgb, target)
+        ed, em = oc.compare(cq)
+        oc.close()
+        assert_bits_equal(m1, em, "24 MPix distmap vs oracle")
+        assert d1 == ed == m1.max()
+        pad = np.zeros((ctx.bh * 8, ctx.bw * 8), np.float32)
+        pad[:h, :w] = m1
+        assert_bits_equal(b1, pad.reshape(ctx.bh, 8, ctx.bw, 8).max(axis=(1, 3)).reshape(-1), "block max")
+        host = guetzli_amd.load_host()
+        counts = ctx.jpeg_histograms(q)
+        head, depth, code = host.jpeg_head(counts, w, h, q)
+        n = ctx.jpeg_scan(3, depth, code)
+        exp = host.write_jpeg(cq, w, h, q)
+        assert len(head) + n + 2 == len(exp)
+        assert head + ctx.jpeg_scan_bytes(cap=n + 16) + b"\xff\xd9" == exp
+
+
 def test_block_search_small_ragged(L):
     pc.case_block_search(L, 45, 27)
     pc.case_block_search(L, 64, 40, x0=10, y0=10, qs=2)
@@ -438,8 +470,8 @@ def _params_cases():
 @pytest.mark.parametrize("name,exp", _params_cases())
 def test_whole_encode_params_golden_hashes(name, exp, monkeypatch):
     """Whole encodes with non-default guetzli::Params -- try_420 / force_420, zeroing
-    look-ahead, the old zeroing model -- greyscale input and YUV 4:2:0 JPEG input, against
-    hashes the UNMODIFIED reference produced (tools/gen_golden_hashes_r2.py)."""
+    look-ahead, the old zeroing model, use_silver_screen -- greyscale input and YUV 4:2:0 JPEG
+    input, against hashes the UNMODIFIED reference produced (tools/gen_golden_hashes_r2.py)."""
     import hashlib
     import io
     from PIL import Image
@@ -452,6 +484,8 @@ def test_whole_encode_params_golden_hashes(name, exp, monkeypatch):
     else:
         rgb = images.tiled(w, h) if kind == "tiled" else images.synthetic(w, h)
     params = dict(exp["params"])
+    if "silver" in params:
+        params["use_silver_screen"] = params.pop("silver")
     host = guetzli_amd.load_host()
     if "pil" in exp:
         kw = dict(exp["pil"])

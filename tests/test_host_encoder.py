@@ -157,6 +157,8 @@ def test_jpeg_input_refusals(host_emu):
     (40, 32, 100, 60, 95, dict(lookahead=1)),
     (40, 32, 100, 60, 90, dict(lookahead=5, new_model=False)),
     (48, 33, 10, 10, 95, dict(try_420=True, lookahead=2)),
+    (40, 32, 100, 60, 95, dict(force_420=True, use_silver_screen=True)),
+    (35, 33, 200, 100, 90, dict(try_420=True, use_silver_screen=True)),   # odd size
 ])
 def test_whole_encode_with_params_matches_reference_in_emulation(host_emu, case, monkeypatch):
     """Params::try_420 / force_420 (OutputImage::Downsample, the 4:2:0 pixel model, the
@@ -167,7 +169,10 @@ def test_whole_encode_with_params_matches_reference_in_emulation(host_emu, case,
     monkeypatch.setenv("GZ_VERIFY_ENTROPY", "1")
     rgb = images.crop(w, h, x0, y0)
     target = ref._butteraugli_score_for_quality(float(quality))
-    exp_jpg, exp_trace = ref.process_params(rgb, target, want_trace=True, **kw)
+    ref_kw = dict(kw)
+    if "use_silver_screen" in ref_kw:
+        ref_kw["silver"] = ref_kw.pop("use_silver_screen")
+    exp_jpg, exp_trace = ref.process_params(rgb, target, want_trace=True, **ref_kw)
     got_jpg, info = host_emu.process(rgb, quality=quality, want_trace=True, **kw)
     for i, (a, b) in enumerate(zip(exp_trace.splitlines(), info["trace"].splitlines())):
         assert a == b, f"trace line {i}:\n ref: {a}\n got: {b}"

@@ -35,6 +35,8 @@ CASES = [
     ("jpegin420_501x333_prog_meta", ("tiled", 501, 333), 90.0, dict(clear_metadata=False),
      dict(quality=97, subsampling=2, progressive=True, comment=b"golden")),
     ("jpegin444_try420_400x300", ("tiled", 400, 300), 95.0, dict(try_420=True), dict(quality=97, subsampling=0)),
+    ("tiled_333x251_force420_silver_q90", ("tiled", 333, 251), 90.0, dict(force_420=True, silver=True), None),
+    ("bees_try420_silver_q95", ("bees", 444, 258), 95.0, dict(try_420=True, silver=True), None),
 ]
 path = os.path.join(ROOT, "tests", "golden", "params_hashes.json")
 out = json.load(open(path)) if os.path.exists(path) and "--all" not in sys.argv else {}

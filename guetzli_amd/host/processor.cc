@@ -172,7 +172,14 @@ inline bool IsPrecious(const int16_t* orig_blk, int k) {
 
 // The device-resident global candidate order as LazySorted's back end.
 struct DeviceOrder : RangeDevice {
-  explicit DeviceOrder(gz_ctx* c) : ctx(c) {}
+  // first_cut != 0: gz_order_build_auto_begin has partitioned [0, total) on the device already
+  DeviceOrder(gz_ctx* c, size_t total, size_t first_cut) : ctx(c), total_(total), first_cut_(first_cut) {}
+  bool KnownCut(size_t lo, size_t hi, size_t* cut) override {
+    if (first_cut_ == 0 || lo != 0 || hi != total_) return false;
+    *cut = first_cut_;
+    first_cut_ = 0;
+    return true;
+  }
   bool Partition(size_t lo, size_t hi, size_t* cut) override {
     uint64_t c64 = 0;
     rc = gz_order_partition(ctx, lo, hi, &c64);
@@ -184,6 +191,7 @@ struct DeviceOrder : RangeDevice {
     return rc == GZ_OK;
   }
   gz_ctx* ctx;
+  size_t total_, first_cut_;
   int rc = GZ_OK;
 };
 
@@ -296,6 +304,7 @@ class Encoder {
   long n_fast_ = 0;
   double t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0, n_evaluations_ = 0;
+  bool build_ahead_ = true;     // GZ_ORDER_AHEAD=0: build each order when the loop asks for it
   size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device (32-64 K measured best at 1080p and 4K)
 };
 
@@ -619,6 +628,11 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   std::vector<int32_t> dirty;
   std::vector<int> step_count(nb);
   bool first_up = true;
+  // The order of the next iteration is constructed on the device right behind the evaluation
+  // of this iteration's candidate (gz_order_build_auto_begin), together with its first
+  // partition: `ahead` says that such a construction is in flight, for which direction.
+  int ahead = 0;
+  uint64_t last_total = 0;
 
   for (int direction = 1; direction >= -1; direction -= 2) {
     for (;;) {
@@ -632,15 +646,21 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       // arrays phase A left there, in the reference's sequence: blocks ascending; within a
       // block the remaining candidates ascending for "up", the applied ones descending for
       // "down".
-      uint64_t total = 0, below = 0;
+      uint64_t total = 0, below = 0, first_cut = 0;
       const float below_limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
       for (int radius = 1; radius <= 4; ++radius) {
         // block weights (ComputeBlockErrorAdjustmentWeights) and max_block_error stay on the
         // device; the host only supplies how far each block has advanced
         int32_t btc = 0;
-        rc = gz_order_build_auto(ctx_, direction, radius, target_mul, first_up ? 0 : 1,
-                                 next_cand.data(), first_up ? 1 : 0, below_limit, &total, &btc,
-                                 &below);
+        first_cut = 0;
+        if (radius == 1 && ahead == direction && !first_up) {
+          rc = gz_order_build_auto_end(ctx_, &total, &btc, &below, &first_cut);
+        } else {
+          rc = gz_order_build_auto(ctx_, direction, radius, target_mul, first_up ? 0 : 1,
+                                   next_cand.data(), first_up ? 1 : 0, below_limit, &total, &btc,
+                                   &below);
+        }
+        ahead = 0;
         if (rc != GZ_OK) return Fail("gz_order_build_auto", rc);
         blocks_to_change = btc;
         if (total != 0) break;
@@ -648,6 +668,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       t_pb_order_ += pw.lap();
       if (total == 0) break;
       n_order_ += (long)total;
+      last_total = total;
       if (order.size() < total) order.resize(total);
 
       // The reference std::sort-s `order` here (processor.cc:675-678) and then consumes a
@@ -661,7 +682,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           return a.second < b.second;
         }
       };
-      DeviceOrder dev_order(ctx_);
+      DeviceOrder dev_order(ctx_, (size_t)total, (size_t)first_cut);
       LazySorted<std::pair<int, float>, KeyLess> sorted(order.data(), (size_t)total, KeyLess(), -1,
                                                          1 << 17, &dev_order, device_threshold_);
       t_pb_sort_ += pw.lap();
@@ -816,7 +837,18 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       if (rc != GZ_OK) return Fail("gz_apply_coeff_edits", rc);
 
       size_t jpg_size = 0;
-      if (!CompareBegin() || !Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;
+      if (!CompareBegin()) return false;
+      if (build_ahead_) {
+        // the next iteration of this direction, radius 1, if it comes to that (processor.cc:
+        // 622-663 behind :767): everything it reads is final -- next_cand, max_block_error
+        // (gz_order_advance above), and the distance map the device is about to produce
+        const uint64_t upto = std::min<uint64_t>((uint64_t)cand_off[nb], std::max<uint64_t>(2 * last_total, 1 << 18));
+        rc = gz_order_build_auto_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
+                                       below_limit, device_threshold_, upto);
+        if (rc != GZ_OK) return Fail("gz_order_build_auto_begin", rc);
+        ahead = direction;
+      }
+      if (!Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;
       Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
           "EstErr[%.2f%%]",
           stats_->counters[kNumItersCnt], FrameStr(), comp_mask, direction > 0 ? "up" : "down",
@@ -837,6 +869,7 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   const int w = w_, h = h_;
   // the original as the fallback output (processor.cc:826-846)
   verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
+  if (const char* e = getenv("GZ_ORDER_AHEAD")) build_ahead_ = atoi(e) != 0;
   if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
   best_score_ = -1;
   QuantMatrix ones;

@@ -61,8 +61,8 @@ SIGNATURES = {
     "gz_order_build": (_I, [_P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P]),
     "gz_order_reset": (_I, [_P]),
     "gz_order_build_auto": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float, _P, _P, _P]),
-    "gz_order_build_auto_begin": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float, C.c_uint64, C.c_uint64]),
-    "gz_order_build_auto_end": (_I, [_P, _P, _P, _P, _P]),
+    "gz_order_build_auto_begin": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float]),
+    "gz_order_build_auto_end": (_I, [_P, _P, _P, _P]),
     "gz_order_advance": (_I, [_P, C.c_float, _I]),
     "gz_apply_coeff_edits": (_I, [_P, _P, _P, _I]),
     "gz_apply_candidate_steps": (_I, [_P, _I, _P, _P, _I]),
@@ -417,19 +417,19 @@ class Context:
         return int(total[0]), int(btc[0]), int(below[0])
 
     def order_build_auto_begin(self, direction, max_block_dist, target_mul, use_distmap, next_cand,
-                               limit=None, partition_above=1 << 16, partition_upto=1 << 40):
+                               limit=None):
         nc = np.ascontiguousarray(next_cand, np.int32)
         assert nc.size == getattr(self, "search_blocks", self.nb)
         self._chk(self.L.lib.gz_order_build_auto_begin(self.handle, direction, max_block_dist, target_mul,
                                                        int(use_distmap), _ptr(nc), int(limit is not None),
-                                                       float(limit or 0.0), partition_above, partition_upto))
+                                                       float(limit or 0.0)))
 
     def order_build_auto_end(self):
-        """(total, blocks_to_change, below, first_cut)."""
-        total, below, cut = np.zeros(1, np.uint64), np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        """(total, blocks_to_change, below)."""
+        total, below = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
         btc = np.zeros(1, np.int32)
-        self._chk(self.L.lib.gz_order_build_auto_end(self.handle, _ptr(total), _ptr(btc), _ptr(below), _ptr(cut)))
-        return int(total[0]), int(btc[0]), int(below[0]), int(cut[0])
+        self._chk(self.L.lib.gz_order_build_auto_end(self.handle, _ptr(total), _ptr(btc), _ptr(below)))
+        return int(total[0]), int(btc[0]), int(below[0])
 
     def order_advance(self, val_threshold, direction):
         self._chk(self.L.lib.gz_order_advance(self.handle, float(val_threshold), direction))

@@ -392,10 +392,9 @@ struct gz_ctx {
   PartScalars* d_part = nullptr;
   // gz_order_build_auto_begin .. _end: results land here (pinned; not the shared landing area,
   // which gz_compare_end uses in between)
-  struct OrderPending { unsigned long long total; unsigned counters[2]; PartScalars part; };
+  struct OrderPending { unsigned long long total; unsigned counters[2]; };
   OrderPending* h_order_pending = nullptr;
   bool order_pending = false;
-  uint64_t order_pending_min = 0, order_pending_max = 0;
   unsigned* d_order_nb = nullptr;                                 // [nb]
   unsigned long long* d_order_off = nullptr;                      // [nb+1]
   unsigned* d_order_counters = nullptr;                           // [2]
@@ -1631,9 +1630,6 @@ int gz_order_reset(gz_ctx* c) {
   return GZ_OK;
 }
 
-static int enqueue_partition(gz_ctx* c, uint64_t lo, uint64_t hi, const PartDyn& dyn);
-static uint64_t partition_cut(const PartScalars& h, uint64_t lo, uint64_t hi);
-
 // The weights and per-block sizes of gz_order_build_auto on the stream (everything up to the
 // offsets scan).
 static int order_auto_enqueue(gz_ctx* c, int direction, int max_block_dist, double target_mul,
@@ -1685,38 +1681,22 @@ int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double tar
 }
 
 int gz_order_build_auto_begin(gz_ctx* c, int direction, int max_block_dist, double target_mul,
-                              int use_distmap, const int32_t* next_cand, int count_below, float limit,
-                              uint64_t partition_above, uint64_t partition_upto) {
+                              int use_distmap, const int32_t* next_cand, int count_below, float limit) {
   DeviceScope ds_(c);
   if (!c || !next_cand || (direction != 1 && direction != -1) || max_block_dist < 0) return GZ_E_ARG;
   c->order_pending = false;
   TRY(order_auto_enqueue(c, direction, max_block_dist, target_mul, use_distmap, next_cand));
   TRY(order_build_enqueue(c, direction, count_below, limit, true));
-  // the first partition std::sort would make of the whole order, if it has more than
-  // partition_above entries (and no more than the grids below are sized for)
-  const uint64_t upto = std::min<uint64_t>({partition_upto, (uint64_t)c->order_cap, 0xfffffff0ull});
-  c->order_pending_min = std::max<uint64_t>(partition_above, 3);
-  c->order_pending_max = upto > c->order_pending_min ? upto : 0;
-  if (c->order_pending_max) {
-    PartDyn dyn;
-    dyn.total_p = c->d_order_off + c->sg_n;
-    dyn.min_n = c->order_pending_min;
-    dyn.max_n = c->order_pending_max;
-    TRY(enqueue_partition(c, 0, 0, dyn));
-  }
   if (!c->h_order_pending) HIPCHK(c, pool_host_malloc((void**)&c->h_order_pending, sizeof(*c->h_order_pending)));
   HIPCHK(c, hipMemcpyAsync(&c->h_order_pending->total, c->d_order_off + c->sg_n, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_order_pending->counters, c->d_order_counters, 8, hipMemcpyDeviceToHost, c->stream));
-  if (c->order_pending_max)
-    HIPCHK(c, hipMemcpyAsync(&c->h_order_pending->part, c->d_part, sizeof(PartScalars), hipMemcpyDeviceToHost, c->stream));
   c->order_pending = true;
   return GZ_OK;
 }
 
-int gz_order_build_auto_end(gz_ctx* c, uint64_t* total, int32_t* blocks_to_change, uint64_t* below,
-                            uint64_t* first_cut) {
+int gz_order_build_auto_end(gz_ctx* c, uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
   DeviceScope ds_(c);
-  if (!c || !total || !blocks_to_change || !below || !first_cut) return GZ_E_ARG;
+  if (!c || !total || !blocks_to_change || !below) return GZ_E_ARG;
   if (!c->order_pending) { c->err = "gz_order_build_auto_begin must precede gz_order_build_auto_end"; return GZ_E_STATE; }
   c->order_pending = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1726,9 +1706,6 @@ int gz_order_build_auto_end(gz_ctx* c, uint64_t* total, int32_t* blocks_to_chang
   *total = r.total;
   *blocks_to_change = (int32_t)r.counters[0];
   *below = r.counters[1];
-  *first_cut = 0;
-  if (c->order_pending_max && r.total > c->order_pending_min && r.total <= c->order_pending_max)
-    *first_cut = partition_cut(r.part, 0, r.total);
   return GZ_OK;
 }
 
@@ -1854,12 +1831,12 @@ int gz_order_upload(gz_ctx* c, const void* entries, uint64_t n) {
   return GZ_OK;
 }
 
-// The five passes of one introsort partition on the context's stream.  dyn.total_p == nullptr:
-// on [lo, hi); else on [0, *dyn.total_p) if that lies in (dyn.min_n, dyn.max_n], grids sized for
-// dyn.max_n.
-static int enqueue_partition(gz_ctx* c, uint64_t lo, uint64_t hi, const PartDyn& dyn) {
+int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
+  DeviceScope ds_(c);
+  if (!c || !cut) return GZ_E_ARG;
+  if (hi > c->order_n || lo >= hi || hi - lo <= 3 || hi - lo > 0xfffffff0ull) return GZ_E_ARG;
   const size_t first = (size_t)lo + 1;
-  const unsigned n = (unsigned)((dyn.total_p ? dyn.max_n : hi) - first);
+  const unsigned n = (unsigned)(hi - first);
   const int nchunks = (int)((n + kPartChunk - 1) / kPartChunk);
   unsigned* cnt_l = c->d_chunk;
   unsigned* cnt_r = c->d_chunk + c->chunk_cap;
@@ -1870,46 +1847,30 @@ static int enqueue_partition(gz_ctx* c, uint64_t lo, uint64_t hi, const PartDyn&
   unsigned* pos_l = c->d_pos_l;
   unsigned* pos_r = c->d_pos_r;
   const size_t lo_s = (size_t)lo, hi_s = (size_t)hi;
-  GZ_LAUNCH(k_part_median, dim3(1), dim3(1), c->stream, a, lo_s, hi_s, ps, dyn);
+  GZ_LAUNCH(k_part_median, dim3(1), dim3(1), c->stream, a, lo_s, hi_s, ps);
   KCHK(c);
   GZ_LAUNCH(k_part_count, dim3(nchunks), dim3(256), c->stream, (const OrderEntry*)a, first, n,
-            (const PartScalars*)ps, cnt_l, cnt_r, dyn);
+            (const PartScalars*)ps, cnt_l, cnt_r);
   KCHK(c);
   GZ_LAUNCH(k_part_scan, dim3(1), dim3(1024), c->stream, (const unsigned*)cnt_l,
-            (const unsigned*)cnt_r, nchunks, base_l, base_r, dyn);
+            (const unsigned*)cnt_r, nchunks, base_l, base_r);
   KCHK(c);
   GZ_LAUNCH(k_part_scatter, dim3(nchunks), dim3(256), c->stream, (const OrderEntry*)a, first, n,
-            ps, (const unsigned*)base_l, (const unsigned*)base_r, pos_l, pos_r, dyn);
+            ps, (const unsigned*)base_l, (const unsigned*)base_r, pos_l, pos_r);
   KCHK(c);
   GZ_LAUNCH(k_part_swap, dim3(gz_div_up((int)(n / 2 + 1), 256)), dim3(256), c->stream, a, first,
-            (const PartScalars*)ps, (const unsigned*)pos_l, (const unsigned*)pos_r, dyn);
+            (const PartScalars*)ps, (const unsigned*)pos_l, (const unsigned*)pos_r);
   KCHK(c);
-  return GZ_OK;
-}
-
-static uint64_t partition_cut(const PartScalars& h, uint64_t lo, uint64_t hi) {
-  const uint64_t first = lo + 1;
-  uint64_t r = hi;
-  if (h.cut_l != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_l);
-  if (h.cut_r != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_r);
-  return r;
-}
-
-int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
-  DeviceScope ds_(c);
-  if (!c || !cut) return GZ_E_ARG;
-  if (hi > c->order_n || lo >= hi || hi - lo <= 3 || hi - lo > 0xfffffff0ull) return GZ_E_ARG;
-  PartDyn none;
-  none.total_p = nullptr;
-  none.min_n = none.max_n = 0;
-  TRY(enqueue_partition(c, lo, hi, none));
   PartScalars h;
   void* res = nullptr;
   TRY(result_buffer(c, sizeof(h), &res));
-  HIPCHK(c, hipMemcpyAsync(res, c->d_part, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(res, ps, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   memcpy(&h, res, sizeof(h));
-  *cut = partition_cut(h, lo, hi);
+  uint64_t r = hi;
+  if (h.cut_l != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_l);
+  if (h.cut_r != 0xffffffffu) r = std::min<uint64_t>(r, first + h.cut_r);
+  *cut = r;
   return GZ_OK;
 }
 

@@ -344,25 +344,6 @@ struct PartScalars {
   OrderEntry pivot;
 };
 
-// A pass of the partition whose range is only known on the device: [0, *total_p), the whole
-// order gz_order_build* has just constructed on the same stream (gz_order_build_auto_begin
-// enqueues the first introsort partition behind the construction, without a host round trip in
-// between).  The pass runs iff min_n < *total_p <= max_n -- the host applies the same rule to
-// the total it reads later; grids are sized for max_n.  total_p == nullptr: the range given by
-// the kernel's own arguments.
-struct PartDyn {
-  const unsigned long long* total_p;
-  unsigned long long min_n, max_n;
-};
-GZ_DEVFN bool part_dyn_range(const PartDyn& d, size_t* lo, size_t* hi) {
-  if (d.total_p == nullptr) return true;
-  const unsigned long long t = *d.total_p;
-  if (t <= d.min_n || t > d.max_n || t <= 3) return false;
-  *lo = 0;
-  *hi = (size_t)t;
-  return true;
-}
-
 constexpr int kPartItems = 8;                       // consecutive entries per thread
 constexpr int kPartChunk = 256 * kPartItems;        // entries per workgroup
 
@@ -375,9 +356,8 @@ GZ_DEVFN void order_swap(OrderEntry* a, size_t i, size_t j) {
 // std::__move_median_to_first(first, first+1, mid, last-1) of libstdc++'s
 // __unguarded_partition_pivot on [lo, hi), then the pivot value for the passes below.
 __global__ void k_part_median(OrderEntry* __restrict__ a, size_t lo, size_t hi,
-                              PartScalars* __restrict__ s, PartDyn dyn) {
+                              PartScalars* __restrict__ s) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (!part_dyn_range(dyn, &lo, &hi)) return;
   const size_t r = lo, x = lo + 1, y = lo + (hi - lo) / 2, z = hi - 1;
   if (order_less(a[x], a[y])) {
     if (order_less(a[y], a[z])) order_swap(a, r, y);
@@ -419,15 +399,8 @@ __global__ __launch_bounds__(256) void k_part_count(const OrderEntry* __restrict
                                                     size_t first, unsigned n,
                                                     const PartScalars* __restrict__ s,
                                                     unsigned* __restrict__ cnt_l,
-                                                    unsigned* __restrict__ cnt_r, PartDyn dyn) {
+                                                    unsigned* __restrict__ cnt_r) {
   __shared__ unsigned lds[256];
-  if (dyn.total_p) {
-    size_t lo = 0, hi = 0;
-    if (!part_dyn_range(dyn, &lo, &hi)) return;
-    first = lo + 1;
-    n = (unsigned)(hi - first);
-    if (blockIdx.x * (unsigned)kPartChunk >= n) return;
-  }
   const OrderEntry pv = s->pivot;
   const unsigned base = blockIdx.x * (unsigned)kPartChunk + threadIdx.x * (unsigned)kPartItems;
   unsigned nl = 0, nr = 0;
@@ -453,13 +426,8 @@ __global__ __launch_bounds__(256) void k_part_count(const OrderEntry* __restrict
 __global__ __launch_bounds__(1024) void k_part_scan(const unsigned* __restrict__ cnt_l,
                                                     const unsigned* __restrict__ cnt_r,
                                                     int nchunks, unsigned* __restrict__ base_l,
-                                                    unsigned* __restrict__ base_r, PartDyn dyn) {
+                                                    unsigned* __restrict__ base_r) {
   __shared__ unsigned part[1024];
-  if (dyn.total_p) {
-    size_t lo = 0, hi = 0;
-    if (!part_dyn_range(dyn, &lo, &hi)) return;
-    nchunks = (int)(((unsigned)(hi - lo - 1) + kPartChunk - 1) / kPartChunk);
-  }
   const int t = threadIdx.x;
   const int per = (nchunks + 1023) / 1024;
   const int lo = t * per < nchunks ? t * per : nchunks;
@@ -498,16 +466,9 @@ __global__ __launch_bounds__(256) void k_part_scatter(const OrderEntry* __restri
                                                       const unsigned* __restrict__ base_l,
                                                       const unsigned* __restrict__ base_r,
                                                       unsigned* __restrict__ pos_l,
-                                                      unsigned* __restrict__ pos_r, PartDyn dyn) {
+                                                      unsigned* __restrict__ pos_r) {
   __shared__ unsigned lds[256];
   __shared__ unsigned red[3];
-  if (dyn.total_p) {
-    size_t lo = 0, hi = 0;
-    if (!part_dyn_range(dyn, &lo, &hi)) return;
-    first = lo + 1;
-    n = (unsigned)(hi - first);
-    if (blockIdx.x * (unsigned)kPartChunk >= n) return;
-  }
   const OrderEntry pv = s->pivot;
   const int t = threadIdx.x;
   const unsigned base = blockIdx.x * (unsigned)kPartChunk + t * (unsigned)kPartItems;
@@ -565,12 +526,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const OrderEntry* __restri
 __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, size_t first,
                                                    const PartScalars* __restrict__ s,
                                                    const unsigned* __restrict__ pos_l,
-                                                   const unsigned* __restrict__ pos_r, PartDyn dyn) {
-  if (dyn.total_p) {
-    size_t lo = 0, hi = 0;
-    if (!part_dyn_range(dyn, &lo, &hi)) return;
-    first = lo + 1;
-  }
+                                                   const unsigned* __restrict__ pos_r) {
   const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= s->m) return;
   order_swap(a, first + pos_l[k], first + pos_r[k]);

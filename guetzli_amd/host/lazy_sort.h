@@ -45,9 +45,6 @@ class RangeDevice {
   // unguarded partition of [lo+1, hi) around it.
   virtual bool Partition(size_t lo, size_t hi, size_t* cut) = 0;
   virtual bool Fetch(size_t lo, size_t hi, void* dst) = 0;
-  // A device that has run ahead (gz_order_build_auto_begin: the first partition enqueued
-  // together with the construction of the order) knows the cut of that range already.
-  virtual bool KnownCut(size_t lo, size_t hi, size_t* cut) { return false; }
 };
 
 template <class T, class Less>
@@ -155,8 +152,7 @@ class LazySorted {
   void RefineDevice(const Range& r, std::vector<Range>* stack) {
     if (r.hi - r.lo > dev_threshold_ && r.depth > 0) {
       size_t cut = 0;
-      if ((dev_->KnownCut(r.lo, r.hi, &cut) || dev_->Partition(r.lo, r.hi, &cut)) && cut > r.lo &&
-          cut <= r.hi) {
+      if (dev_->Partition(r.lo, r.hi, &cut) && cut > r.lo && cut <= r.hi) {
         stack->push_back(Range{cut, r.hi, r.depth - 1, true});
         stack->push_back(Range{r.lo, cut, r.depth - 1, true});
         return;

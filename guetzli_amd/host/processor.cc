@@ -172,14 +172,7 @@ inline bool IsPrecious(const int16_t* orig_blk, int k) {
 
 // The device-resident global candidate order as LazySorted's back end.
 struct DeviceOrder : RangeDevice {
-  // first_cut != 0: gz_order_build_auto_begin has partitioned [0, total) on the device already
-  DeviceOrder(gz_ctx* c, size_t total, size_t first_cut) : ctx(c), total_(total), first_cut_(first_cut) {}
-  bool KnownCut(size_t lo, size_t hi, size_t* cut) override {
-    if (first_cut_ == 0 || lo != 0 || hi != total_) return false;
-    *cut = first_cut_;
-    first_cut_ = 0;
-    return true;
-  }
+  explicit DeviceOrder(gz_ctx* c) : ctx(c) {}
   bool Partition(size_t lo, size_t hi, size_t* cut) override {
     uint64_t c64 = 0;
     rc = gz_order_partition(ctx, lo, hi, &c64);
@@ -191,7 +184,6 @@ struct DeviceOrder : RangeDevice {
     return rc == GZ_OK;
   }
   gz_ctx* ctx;
-  size_t total_, first_cut_;
   int rc = GZ_OK;
 };
 
@@ -629,10 +621,9 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   std::vector<int> step_count(nb);
   bool first_up = true;
   // The order of the next iteration is constructed on the device right behind the evaluation
-  // of this iteration's candidate (gz_order_build_auto_begin), together with its first
-  // partition: `ahead` says that such a construction is in flight, for which direction.
+  // of this iteration's candidate (gz_order_build_auto_begin): `ahead` says that such a
+  // construction is in flight, and for which direction.
   int ahead = 0;
-  uint64_t last_total = 0;
 
   for (int direction = 1; direction >= -1; direction -= 2) {
     for (;;) {
@@ -646,15 +637,14 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       // arrays phase A left there, in the reference's sequence: blocks ascending; within a
       // block the remaining candidates ascending for "up", the applied ones descending for
       // "down".
-      uint64_t total = 0, below = 0, first_cut = 0;
+      uint64_t total = 0, below = 0;
       const float below_limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
       for (int radius = 1; radius <= 4; ++radius) {
         // block weights (ComputeBlockErrorAdjustmentWeights) and max_block_error stay on the
         // device; the host only supplies how far each block has advanced
         int32_t btc = 0;
-        first_cut = 0;
         if (radius == 1 && ahead == direction && !first_up) {
-          rc = gz_order_build_auto_end(ctx_, &total, &btc, &below, &first_cut);
+          rc = gz_order_build_auto_end(ctx_, &total, &btc, &below);
         } else {
           rc = gz_order_build_auto(ctx_, direction, radius, target_mul, first_up ? 0 : 1,
                                    next_cand.data(), first_up ? 1 : 0, below_limit, &total, &btc,
@@ -668,7 +658,6 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       t_pb_order_ += pw.lap();
       if (total == 0) break;
       n_order_ += (long)total;
-      last_total = total;
       if (order.size() < total) order.resize(total);
 
       // The reference std::sort-s `order` here (processor.cc:675-678) and then consumes a
@@ -682,7 +671,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           return a.second < b.second;
         }
       };
-      DeviceOrder dev_order(ctx_, (size_t)total, (size_t)first_cut);
+      DeviceOrder dev_order(ctx_);
       LazySorted<std::pair<int, float>, KeyLess> sorted(order.data(), (size_t)total, KeyLess(), -1,
                                                          1 << 17, &dev_order, device_threshold_);
       t_pb_sort_ += pw.lap();
@@ -842,9 +831,8 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         // the next iteration of this direction, radius 1, if it comes to that (processor.cc:
         // 622-663 behind :767): everything it reads is final -- next_cand, max_block_error
         // (gz_order_advance above), and the distance map the device is about to produce
-        const uint64_t upto = std::min<uint64_t>((uint64_t)cand_off[nb], std::max<uint64_t>(2 * last_total, 1 << 18));
         rc = gz_order_build_auto_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
-                                       below_limit, device_threshold_, upto);
+                                       below_limit);
         if (rc != GZ_OK) return Fail("gz_order_build_auto_begin", rc);
         ahead = direction;
       }

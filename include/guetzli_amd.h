@@ -301,17 +301,12 @@ int gz_order_build_auto(gz_ctx* ctx, int direction, int max_block_dist, double t
 /* gz_order_build_auto in two halves, so that the order of the NEXT iteration is constructed on
  * the device right behind the evaluation of the candidate it depends on (gz_compare_begin on
  * the same context: use_distmap is then allowed before gz_compare_end), with no host round
- * trip in between -- processor.cc:607-678 run back to back with :767.  _begin enqueues and
- * returns; next_cand is copied.  If the order turns out to have more than partition_above (and
- * at most partition_upto) entries, the first partition std::sort makes of it --
- * gz_order_partition(0, total) -- follows on the device at once.  _end waits and reports what
- * gz_order_build_auto reports, plus *first_cut = that partition's cut, 0 if it was not made.
+ * trip in between -- processor.cc:607-663 run back to back with :767.  _begin enqueues and
+ * returns (next_cand is copied); _end waits and reports what gz_order_build_auto reports.
  * Any other gz_order_build* call drops a pending _begin. */
 int gz_order_build_auto_begin(gz_ctx* ctx, int direction, int max_block_dist, double target_mul,
-                              int use_distmap, const int32_t* next_cand, int count_below, float limit,
-                              uint64_t partition_above, uint64_t partition_upto);
-int gz_order_build_auto_end(gz_ctx* ctx, uint64_t* total, int32_t* blocks_to_change, uint64_t* below,
-                            uint64_t* first_cut);
+                              int use_distmap, const int32_t* next_cand, int count_below, float limit);
+int gz_order_build_auto_end(gz_ctx* ctx, uint64_t* total, int32_t* blocks_to_change, uint64_t* below);
 int gz_order_advance(gz_ctx* ctx, float val_threshold, int direction);
 /* gz_apply_candidate_steps: the coefficient side of the global loop's steps
  * (processor.cc:704-736) for whole blocks: block blocks[i] advances by counts[i] steps in

@@ -224,23 +224,10 @@ def case_global_order(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
                     assert_bits_equal(got["block"], eb, "order blocks")
                     assert_bits_equal(got["val"], ev, "order vals")
                     assert below == int((ev < limit).sum())
-                # the two-halves form (construction enqueued ahead, first introsort partition with
-                # it when the order is large enough) = the one-call form + gz_order_partition
-                if total > 3:
-                    for above in (total - 1, total):     # partition made / not made
-                        ctx.order_build_auto(direction, radius, 1.0, use_dm, next_cand, limit=float(limit))
-                        cut = ctx.order_partition(0, total) if above < total else 0
-                        exp_arr = ctx.order_fetch(0, total)
-                        ctx.order_build_auto_begin(direction, radius, 1.0, use_dm, next_cand,
-                                                   limit=float(limit), partition_above=above,
-                                                   partition_upto=total + 5000)
-                        assert ctx.order_build_auto_end() == (total, btc, below, cut)
-                        assert_bits_equal(ctx.order_fetch(0, total), exp_arr, "order after _begin/_end")
-                    # more entries than the grids were sized for: no partition, the same order
-                    ctx.order_build_auto_begin(direction, radius, 1.0, use_dm, next_cand, limit=float(limit),
-                                               partition_above=0, partition_upto=total - 1)
-                    assert ctx.order_build_auto_end() == (total, btc, below, 0)
-                    assert_bits_equal(ctx.order_fetch(0, total), got, "order after _begin/_end, no partition")
+                # the two-halves form (construction enqueued ahead of the wait) = the one-call form
+                ctx.order_build_auto_begin(direction, radius, 1.0, use_dm, next_cand, limit=float(limit))
+                assert ctx.order_build_auto_end() == (total, btc, below)
+                assert_bits_equal(ctx.order_fetch(0, total), got, "order after _begin/_end")
                 # explicit-weights entry point gives the same order
                 t2, b2, _ = ctx.order_build(direction, next_cand, max_err, wgt)
                 assert (t2, b2) == (total, btc)

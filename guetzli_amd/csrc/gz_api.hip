@@ -333,7 +333,7 @@ struct gz_ctx {
   // second stream for the branch of Compare that does not depend on the Malta path (the
   // mask: DiffPrecompute + three blurs), forked and joined with events
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mask_pre = nullptr;
   // the entropy coder's kernels (gz_jpeg_scan) run on their own stream, beside a Compare that
   // gz_compare_begin has put on the main stream: both only read the candidate coefficients
   hipStream_t entropy_stream = nullptr;
@@ -718,11 +718,18 @@ int stage_separate(gz_ctx* c, Psycho* ps) {
   return GZ_OK;
 }
 
-// Mask first half: DiffPrecompute + three blurs -> mxb, myb1, myb2
-int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk) {
+// Mask first half: DiffPrecompute + three blurs -> mxb, myb1, myb2.  The three blurs only
+// share their input: with `other` given, the small one (radius 5) goes behind whatever is
+// queued there (the SameNoise blur, the shorter of the two side branches) instead of between
+// the two radius-20 blurs of this stream.
+int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullptr) {
   dim3 grid(gz_div_up(c->w, 1024), c->h, 2);
   GZ_LAUNCH(k_mask_pre, grid, dim3(256), c->stream, pk, c->w, c->h, c->pitch);
   KCHK(c);
+  if (other) {
+    HIPCHK(c, hipEventRecord(c->ev_mask_pre, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(other, c->ev_mask_pre, 0));
+  }
   {  // X: sigma r2 = 9.24 ; Y second: sigma r1 = 9.04 -- both radius 20, separate taps
     SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].p = c->diffx; t.p[0] = c->tmp[1]; ct.p[0] = c->tmp[1];
@@ -733,7 +740,11 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk) {
   {
     SrcPack<SrcPlain, 1> s; s.s[0].p = c->diffy;
     PostStore<1> post; post.out[0] = c->myb1;
-    TRY((blur2d<5, 1, SrcPlain, PostStore<1>>(c, s, post, c->blur[B_MASKY0])));
+    hipStream_t here = c->stream;
+    if (other) c->stream = other;
+    const int rc = blur2d<5, 1, SrcPlain, PostStore<1>>(c, s, post, c->blur[B_MASKY0]);
+    c->stream = here;
+    TRY(rc);
   }
   {
     SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
@@ -796,7 +807,8 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
     if (rc == GZ_OK) rc = blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN]);
   }
   c->stream = c->side_stream;
-  if (rc == GZ_OK) rc = stage_mask_blurs(c, mask_pack_psycho(c, p0, p1));
+  static const bool split = !(getenv("GZ_MASK_SPLIT") && atoi(getenv("GZ_MASK_SPLIT")) == 0);
+  if (rc == GZ_OK) rc = stage_mask_blurs(c, mask_pack_psycho(c, p0, p1), split ? c->side_stream2 : nullptr);
   c->stream = main_stream;
   TRY(rc);
   HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
@@ -1148,6 +1160,7 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   CHK0(pool_event_create(&c->ev_fork));
   CHK0(pool_event_create(&c->ev_join));
   CHK0(pool_event_create(&c->ev_join2));
+  CHK0(pool_event_create(&c->ev_mask_pre));
   const size_t ncoef = (size_t)3 * c->nb * 64;
   CHK0(pool_malloc((void**)&c->d_rgb, (size_t)3 * w * h));
   CHK0(pool_malloc((void**)&c->d_orig, ncoef * 2));
@@ -1253,6 +1266,7 @@ void gz_destroy(gz_ctx* c) {
   stage_free(&c->stage_entropy);
   if (c->h_res) (void)pool_host_free(c->h_res);
   pool_event_destroy(c->ev_join2);
+  pool_event_destroy(c->ev_mask_pre);
   pool_event_destroy(c->ev_fork);
   pool_event_destroy(c->ev_join);
   pool_stream_destroy(c->own_stream);   // synchronised at the top of gz_destroy

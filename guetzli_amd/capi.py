@@ -541,5 +541,6 @@ def load():
     """The product library (gfx950).  Raises if it is missing."""
     global _default
     if _default is None:
-        _default = Library(DEFAULT_LIB)
+        # GUETZLI_AMD_LIB: another build of the same library (kernel A/B runs of tools/)
+        _default = Library(os.environ.get("GUETZLI_AMD_LIB", DEFAULT_LIB))
     return _default

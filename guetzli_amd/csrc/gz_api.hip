@@ -139,7 +139,32 @@ MaltaNorm malta_norm(bool lf, double w_0gt1, double w_0lt1, double norm1) {
   n.norm2_0gt1 = w_pre0gt1 * norm1;
   n.norm2_0lt1 = w_pre0lt1 * norm1;
   n.norm1f = static_cast<float>(norm1);
+  auto mid = [](float x) { return x >= 0x1p-40f && x <= 0x1p40f; };
+  n.fast_div = mid(n.norm2_0gt1) && mid(n.norm2_0lt1) ? 1 : 0;
   return n;
+}
+
+// The six Malta passes of DiffmapPsychoImage (butteraugli.cc:835-874): [channel X/Y][band
+// UHF, HF, MF] -> normalisation and tap pattern.
+struct MaltaSpec {
+  MaltaNorm nm;
+  int lf;
+};
+void malta_specs(MaltaSpec out[2][3]) {
+  const float hf_asymmetry_ = 0.8f;
+  const double wUhfMalta = 5.1409625726, norm1Uhf = 58.5001247061;
+  const double wUhfMaltaX = 4.91743441556, norm1UhfX = 687196.39002;
+  const double wHfMalta = 153.671655716, norm1Hf = 83150785.9592;
+  const double wHfMaltaX = 668.358918152, norm1HfX = 0.882954368025;
+  const double wMfMalta = 6841.81248144, norm1Mf = 0.0135134962487;
+  const double wMfMaltaX = 813.901703816, norm1MfX = 16792.9322251;
+  const float sqrt_asym = sqrtf(hf_asymmetry_);   // float sqrt overload in the reference
+  out[1][0] = {malta_norm(false, wUhfMalta * hf_asymmetry_, wUhfMalta / hf_asymmetry_, norm1Uhf), 0};
+  out[1][1] = {malta_norm(true, wHfMalta * sqrt_asym, wHfMalta / sqrt_asym, norm1Hf), 1};
+  out[1][2] = {malta_norm(true, wMfMalta, wMfMalta, norm1Mf), 1};
+  out[0][0] = {malta_norm(false, wUhfMaltaX * hf_asymmetry_, wUhfMaltaX / hf_asymmetry_, norm1UhfX), 0};
+  out[0][1] = {malta_norm(true, wHfMaltaX * sqrt_asym, wHfMaltaX / sqrt_asym, norm1HfX), 1};
+  out[0][2] = {malta_norm(true, wMfMaltaX, wMfMaltaX, norm1MfX), 1};
 }
 
 struct Psycho {   // device planes of one image's PsychoImage (butteraugli.h:418-423)
@@ -487,14 +512,35 @@ void alloc_psycho(gz_ctx* c, Psycho* p) {
 }
 
 // ------------------------------------------------------------- blur dispatch helpers --
+// Row-pair / column-pair variants of the separate row and column passes (k_blur_h_pk,
+// k_blur_v_pk: twice the outputs per thread, packed arithmetic).  Packed f32 instructions
+// issue at the same lane rate as scalar ones on gfx950 (tools/ubench/pk.hip: 73 T lane-ops/s
+// either way), so what these variants gain is fewer LDS reads and address computations per
+// output, and what they lose is parallelism: measured per kernel (profiles/
+// r02_packed_blur_ab.log) they win from 4 MPix on for the radius-16 and radius-20 row passes
+// and the single-plane column passes, and lose below that and for the 3-plane column pass
+// and the SameNoise row pass.  GZ_BLUR_PK=0 / 1 forces the scalar / paired kernels everywhere
+// (read per call: the tests switch it).
+static bool packed_blur(const gz_ctx* c, bool favourable) {
+  const char* e = getenv("GZ_BLUR_PK");
+  if (e) return atoi(e) != 0;
+  return favourable && (size_t)c->w * c->h >= 4000000;
+}
+
 template <int R, class Src, int NC>
 int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
            const BlurCfg& cfg) {
   if (cfg.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
-  dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), NC);
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.bx;
   const int w = c->w, h = c->h, pitch = c->pitch;
+  if (packed_blur(c, R <= 20)) {
+    dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), NC);
+    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs);
+    KCHK(c);
+    return GZ_OK;
+  }
+  dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), NC);
   GZ_LAUNCH((k_blur_h<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs);
   KCHK(c);
   return GZ_OK;
@@ -536,6 +582,19 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
+  if (!BM && packed_blur(c, NC == 1)) {
+    if (small_tiles(c)) {
+      dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
+      GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
+                pitch, tp, bs);
+    } else {
+      dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
+      GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
+                pitch, tp, bs);
+    }
+    KCHK(c);
+    return GZ_OK;
+  }
   if (!BM && compact_code(c, "GZ_COMPACT_BLUR_V")) {
     if (small_tiles(c)) {
       dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
@@ -828,32 +887,16 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
   const float hf_asymmetry_ = 0.8f;
   // side stream: SameNoise blur + the mask branch; main stream: Malta
   TRY(fork_side_branch(c, p0, p1));
-  const double wUhfMalta = 5.1409625726, norm1Uhf = 58.5001247061;
-  const double wUhfMaltaX = 4.91743441556, norm1UhfX = 687196.39002;
-  const double wHfMalta = 153.671655716, norm1Hf = 83150785.9592;
-  const double wHfMaltaX = 668.358918152, norm1HfX = 0.882954368025;
-  const double wMfMalta = 6841.81248144, norm1Mf = 0.0135134962487;
-  const double wMfMaltaX = 813.901703816, norm1MfX = 16792.9322251;
-  const float sqrt_asym = sqrtf(hf_asymmetry_);   // float sqrt overload in the reference
+  MaltaSpec ms[2][3];
+  malta_specs(ms);
   dim3 mgrid(gz_div_up(c->w, MW), gz_div_up(c->h, MH), 2);
   MaltaArgs<3> ay, ax;
-  {  // Y channel
-    MaltaArgs<3>& a = ay;
-    a.pass[0] = {p0.uhf[1], p1.uhf[1],
-                 malta_norm(false, wUhfMalta * hf_asymmetry_, wUhfMalta / hf_asymmetry_, norm1Uhf), 0};
-    a.pass[1] = {p0.hf[1], p1.hf[1],
-                 malta_norm(true, wHfMalta * sqrt_asym, wHfMalta / sqrt_asym, norm1Hf), 1};
-    a.pass[2] = {p0.mf[1], p1.mf[1], malta_norm(true, wMfMalta, wMfMalta, norm1Mf), 1};
-    a.out = c->ac[1];
-  }
-  {  // X channel
-    MaltaArgs<3>& a = ax;
-    a.pass[0] = {p0.uhf[0], p1.uhf[0],
-                 malta_norm(false, wUhfMaltaX * hf_asymmetry_, wUhfMaltaX / hf_asymmetry_, norm1UhfX), 0};
-    a.pass[1] = {p0.hf[0], p1.hf[0],
-                 malta_norm(true, wHfMaltaX * sqrt_asym, wHfMaltaX / sqrt_asym, norm1HfX), 1};
-    a.pass[2] = {p0.mf[0], p1.mf[0], malta_norm(true, wMfMaltaX, wMfMaltaX, norm1MfX), 1};
-    a.out = c->ac[0];
+  for (int ch = 0; ch < 2; ++ch) {   // X, Y; passes in the reference's order: UHF, HF, MF
+    MaltaArgs<3>& a = ch ? ay : ax;
+    a.pass[0] = {p0.uhf[ch], p1.uhf[ch], ms[ch][0].nm, ms[ch][0].lf};
+    a.pass[1] = {p0.hf[ch], p1.hf[ch], ms[ch][1].nm, ms[ch][1].lf};
+    a.pass[2] = {p0.mf[ch], p1.mf[ch], ms[ch][2].nm, ms[ch][2].lf};
+    a.out = c->ac[ch];
   }
   GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);

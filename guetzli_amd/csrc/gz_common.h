@@ -61,6 +61,15 @@ static __device__ __forceinline__ void gz_stg4(float* p, size_t i, const gz_f4& 
 #define GZ_STG4(p, i, val) gz_stg4((p), (i), (val))
 #endif
 
+// Two floats that one packed instruction works on (v_pk_mul_f32 / v_pk_add_f32: two IEEE
+// f32 operations per lane and issue slot, each rounded like its scalar counterpart; the
+// build has contraction off, so a multiply and an add stay a multiply and an add).
+typedef float gz_f2 __attribute__((vector_size(8)));
+GZ_DEVFN gz_f2 gz_f2_splat(float x) {
+  gz_f2 r = {x, x};
+  return r;
+}
+
 #ifdef GZ_EMU
 #define GZ_STG(p, i, val) ((p)[i] = (val))
 #else

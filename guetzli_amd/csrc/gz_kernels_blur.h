@@ -165,6 +165,108 @@ __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<
   }
 }
 
+// Row pass with packed arithmetic: a workgroup takes HP = 8 rows as 4 row PAIRS; a thread
+// produces 4 consecutive outputs of both rows of a pair, every multiply and every add as one
+// packed instruction on (row 2p, row 2p + 1).  The pair's samples are staged interleaved,
+// tile[p][x][2], so that one 16-byte LDS read yields two (upper, lower) pairs ready for use.
+// Per output the operations and their order are those of k_blur_h: f32, ascending taps from
+// 0.0f.  Tiles that are not interior take k_blur_h's generic path (8 rows of it).
+constexpr int HP = 8;
+
+template <int R, class Src, int NC>
+__global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePack<NC> dst,
+                                                   int w, int h, int pitch, Taps<R> taps,
+                                                   BorderScale bs) {
+  constexpr int RA = (R + 3) & ~3;
+  constexpr int TP = HW + 2 * RA;
+  constexpr int OFF = RA - R;
+  __shared__ __attribute__((aligned(16))) float tile[HP * TP];
+  const GzTile bid = gz_xcd_tile();
+  const int c = bid.z;
+  Src s = src.s[0];
+  float* __restrict__ out = dst.p[0];
+#pragma unroll
+  for (int i = 1; i < NC; ++i)
+    if (c == i) {
+      s = src.s[i];
+      out = dst.p[i];
+    }
+  const int x0 = bid.x * HW, y0 = bid.y * HP;
+  const int tid = threadIdx.x;
+  if (x0 >= RA && x0 + HW + RA <= w && y0 + HP <= h && (pitch & 3) == 0) {
+    constexpr int NQ = TP / 4;          // 16-byte vectors per staged row
+    constexpr int NI = (HP / 2) * NQ;   // (pair, vector) items
+#pragma unroll
+    for (int k = 0; k < (NI + 255) / 256; ++k) {
+      const int i = 256 * k + tid;
+      if (256 * k + 255 < NI || i < NI) {
+        const int p = i / NQ, q = i - p * NQ;
+        const size_t g = (size_t)(y0 + 2 * p) * pitch + (x0 - RA + 4 * q);
+        const gz_f4 a = s.load4(g), b = s.load4(g + pitch);
+        gz_f4 lo, hi;
+        lo.v[0] = a.v[0]; lo.v[1] = b.v[0]; lo.v[2] = a.v[1]; lo.v[3] = b.v[1];
+        hi.v[0] = a.v[2]; hi.v[1] = b.v[2]; hi.v[2] = a.v[3]; hi.v[3] = b.v[3];
+        float* t = &tile[(p * TP + 4 * q) * 2];
+        *reinterpret_cast<gz_f4*>(t) = lo;
+        *reinterpret_cast<gz_f4*>(t + 4) = hi;
+      }
+    }
+    __syncthreads();
+    const int p = tid >> 6, xq = (tid & 63) * 4;
+    gz_f2 win[4 + 2 * RA];
+#pragma unroll
+    for (int i = 0; i < (4 + 2 * RA) / 2; ++i) {
+      const gz_f4 v = *reinterpret_cast<const gz_f4*>(&tile[(p * TP + xq + 2 * i) * 2]);
+      win[2 * i] = gz_f2{v.v[0], v.v[1]};
+      win[2 * i + 1] = gz_f2{v.v[2], v.v[3]};
+    }
+    gz_f4 oa, ob;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gz_f2 sum = gz_f2_splat(0.0f);
+#pragma unroll
+      for (int j = 0; j <= 2 * R; ++j) sum = sum + win[OFF + i + j] * gz_f2_splat(taps.ks[j]);
+      oa.v[i] = sum[0];
+      ob.v[i] = sum[1];
+    }
+    const size_t o = (size_t)(y0 + 2 * p) * pitch + x0 + xq;
+    GZ_STG4(out, o, oa);
+    GZ_STG4(out, o + pitch, ob);
+    return;
+  }
+  // generic tile: rows y0..y0+HP-1, columns x0-R .. x0+HW+R-1 (zero outside the image)
+  constexpr int GW = HW + 2 * R;
+  for (int i = tid; i < HP * GW; i += 256) {
+    const int ry = i / GW, rx = i - ry * GW;
+    const int x = x0 - R + rx, y = y0 + ry;
+    float v = 0.0f;
+    if (x >= 0 && x < w && y < h) v = s((size_t)y * pitch + x);
+    tile[ry * GW + rx] = v;
+  }
+  __syncthreads();
+  const int x = x0 + tid;
+  if (x >= w) return;
+  const bool border = x < R || x >= w - R;
+  float scale = 1.0f;
+  if (border) scale = x < R ? bs.lo[x] : bs.hi[w - 1 - x];
+#pragma unroll 1
+  for (int ry = 0; ry < HP; ++ry) {
+    const int y = y0 + ry;
+    if (y >= h) break;
+    const float* row = &tile[ry * GW + tid];
+    float sum = 0.0f;
+    if (!border) {
+#pragma unroll
+      for (int j = 0; j <= 2 * R; ++j) sum += row[j] * taps.ks[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j <= 2 * R; ++j) sum += row[j] * taps.k[j];
+      sum = sum * scale;
+    }
+    out[(size_t)y * pitch + x] = sum;
+  }
+}
+
 // --------------------------------------------------------------------- column pass --
 // grid = (ceil(w/VW), ceil(h/VH)); block = 256 = 64 columns x 4 row groups; each thread
 // produces VH/4 outputs of its column for every one of the NC planes, then hands the NC
@@ -397,6 +499,122 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
   if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
 }
 
+
+// Column pass with packed arithmetic: a thread takes two adjacent columns (an 8-byte LDS
+// read yields the pair) and TH/8 consecutive rows from a register window of row pairs; every
+// multiply and add is one packed instruction on (column x, column x + 1).  Tiles whose output
+// rows are all interior and whose columns are all inside the image take this path, the
+// others the per-output path with border handling (as a loop: it is rarely taken).
+template <int R, int NC, class Post, int TH>
+__global__ __launch_bounds__(256) void k_blur_v_pk(CPlanePack<NC> src, Post post, int w, int h,
+                                                   int pitch, Taps<R> taps, BorderScale bs) {
+  constexpr int RPT = TH / 8;    // rows per thread on the packed path
+  constexpr int VPTt = TH / 4;   // rows per thread on the generic path
+  __shared__ __attribute__((aligned(16))) float tile[TH + 2 * R][VW];
+  const int tid = threadIdx.x;
+  const int tx = tid & 63, tg = tid >> 6;
+  const GzTile bid = gz_xcd_tile();
+  const int x0 = bid.x * VW, y0 = bid.y * TH;
+  const bool vec = x0 + VW <= w && (pitch & 3) == 0;
+  const bool inner = vec && y0 >= R && y0 + TH + R <= h;
+  const int vq = (tid & 15) * 4, vr = tid >> 4;
+  if (inner) {
+    const int cp = tid & 31, rg = tid >> 5;
+    gz_f2 acc[NC][RPT];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float* __restrict__ in = src.p[c];
+      if (c > 0) __syncthreads();
+#pragma unroll
+      for (int k = 0; k < (TH + 2 * R + 15) / 16; ++k) {
+        const int ry = vr + 16 * k;
+        if ((k + 1) * 16 <= TH + 2 * R || ry < TH + 2 * R) {
+          const gz_f4 v = GZ_LDG4(in, (size_t)(y0 - R + ry) * pitch + x0 + vq);
+          *reinterpret_cast<gz_f4*>(&tile[ry][vq]) = v;
+        }
+      }
+      __syncthreads();
+      gz_f2 win[RPT + 2 * R];
+#pragma unroll
+      for (int i = 0; i < RPT + 2 * R; ++i)
+        win[i] = *reinterpret_cast<const gz_f2*>(&tile[rg * RPT + i][2 * cp]);
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        gz_f2 sum = gz_f2_splat(0.0f);
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j) sum = sum + win[i + j] * gz_f2_splat(taps.ks[j]);
+        acc[c][i] = sum;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const size_t idx = (size_t)(y0 + rg * RPT + i) * pitch + x0 + 2 * cp;
+      float v0[NC], v1[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        v0[c] = acc[c][i][0];
+        v1[c] = acc[c][i][1];
+      }
+      (void)post(idx, v0);
+      (void)post(idx + 1, v1);
+    }
+    return;
+  }
+  const int x = x0 + tx;
+  __shared__ float outv[NC > 1 ? NC : 1][NC > 1 ? TH : 1][VW];
+#pragma unroll 1
+  for (int c = 0; c < NC; ++c) {
+    const float* __restrict__ in = src.p[0];
+#pragma unroll
+    for (int k = 1; k < NC; ++k)
+      if (c == k) in = src.p[k];
+    if (c > 0) __syncthreads();
+    for (int ry = tg; ry < TH + 2 * R; ry += 4) {
+      const int y = y0 - R + ry;
+      float v = 0.0f;
+      if (x < w && y >= 0 && y < h) v = in[(size_t)y * pitch + x];
+      tile[ry][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < VPTt; ++i) {
+      const int ly = tg * VPTt + i;
+      const int y = y0 + ly;
+      float sum = 0.0f;
+      if (y < h) {
+        const bool border = y < R || y >= h - R;
+        const float* col = &tile[ly][tx];
+        if (!border) {
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) sum += col[j * VW] * taps.ks[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j <= 2 * R; ++j) sum += col[j * VW] * taps.k[j];
+          sum = sum * (y < R ? bs.lo[y] : bs.hi[h - 1 - y]);
+        }
+      }
+      if (NC > 1) {
+        outv[c][ly][tx] = sum;
+      } else {
+        float v1[1] = {sum};
+        if (x < w && y < h) (void)post((size_t)y * pitch + x, v1);
+      }
+    }
+  }
+  if (NC > 1) {
+#pragma unroll 1
+    for (int i = 0; i < VPTt; ++i) {
+      const int ly = tg * VPTt + i;
+      const int y = y0 + ly;
+      if (x < w && y < h) {
+        float v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = outv[c][ly][tx];   // (own writes)
+        (void)post((size_t)y * pitch + x, v);
+      }
+    }
+  }
+}
 
 // ------------------------------------------------------ fused row + column pass (2-D) --
 // Blur = Convolution along x, then along y (butteraugli.cc:229-233), for one 64x64 output

@@ -131,8 +131,12 @@ GZ_DEVFN void lf_to_vals(float x, float y, float b_arg, float* vx, float* vy, fl
 // ---- Malta per-pixel "diffs" value, butteraugli.cc:1473-1529 ---------------------
 struct MaltaNorm {
   float norm2_0gt1, norm2_0lt1, norm1f;
+  int fast_div;   // 1: norm2_* are in [2^-40, 2^40] (malta_diff may share one reciprocal)
 };
-GZ_DEVFN float malta_diff(float a, float b, const MaltaNorm nm) {
+// The reference's statement sequence, kept as the definition the fast form below is checked
+// against (tests/cpp/verify_malta_diff.cc on the host; tools/ubench/divcheck.hip for the
+// division on the device).
+GZ_DEVFN float malta_diff_plain(float a, float b, const MaltaNorm nm) {
   const float absval = (float)(0.5 * (double)fabsf(a) + 0.5 * (double)fabsf(b));
   const float diff = a - b;
   const float scaler = nm.norm2_0gt1 / (nm.norm1f + absval);
@@ -155,6 +159,93 @@ GZ_DEVFN float malta_diff(float a, float b, const MaltaNorm nm) {
   }
   if (hit) d = diff < 0 ? (float)((double)d - impact) : (float)((double)d + impact);
   return d;
+}
+
+#ifdef GZ_EMU
+inline int& gz_emu_rcp_ulps() {
+  static int v = 0;
+  return v;
+}
+#endif
+// n0 / d and n1 / d, both correctly rounded, from ONE reciprocal estimate: the refinement
+// steps of the compiler's own expansion of an IEEE f32 division (reciprocal, one Newton step
+// on it, quotient, two residual corrections -- all fused multiply-adds), without the operand
+// scaling and the special-case fix-up that surround it there.  Those two are the identity when
+// neither operand nor the quotient comes near the ends of the exponent range, which the caller
+// guarantees (2^-40 <= d, n <= 2^40).
+GZ_DEVFN void div2_shared(float n0, float n1, float d, float* q0, float* q1) {
+#ifdef GZ_EMU
+  // (v_rcp_f32 is accurate to 1 ulp: the host check runs the refinement from RN(1/d) and from
+  // its two neighbours, gz_emu_rcp_ulps() = -1, 0, +1)
+  float r0 = 1.0f / d;
+  if (gz_emu_rcp_ulps() > 0) r0 = __builtin_nextafterf(r0, __builtin_inff());
+  if (gz_emu_rcp_ulps() < 0) r0 = __builtin_nextafterf(r0, -__builtin_inff());
+#else
+  const float r0 = __builtin_amdgcn_rcpf(d);
+#endif
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  const float r = __builtin_fmaf(e0, r0, r0);
+  {
+    const float q = n0 * r;
+    const float e1 = __builtin_fmaf(-d, q, n0);
+    const float qq = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-d, qq, n0);
+    *q0 = __builtin_fmaf(e2, r, qq);
+  }
+  {
+    const float q = n1 * r;
+    const float e1 = __builtin_fmaf(-d, q, n1);
+    const float qq = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-d, qq, n1);
+    *q1 = __builtin_fmaf(e2, r, qq);
+  }
+}
+
+// Same value as malta_diff_plain, bit for bit, with a third of the instructions and no
+// divergent branches (a wave of malta_diff_plain costs ~375 cycles, most of it in the four
+// exec-masked regions of the if-ladder):
+//  * absval: for floats x, y >= 0, float(0.5*double(x) + 0.5*double(y)) == 0.5f * (x + y)
+//    whenever the float sum s = x + y is a normal number away from the range ends: the halves
+//    and -- for exponents at most 28 apart -- their sum are exact in double, so both sides
+//    round the exact (x + y) / 2 once to 24 bits; further apart, the smaller operand is below
+//    2^-5 ulp of the larger in both.  Sums outside [2^-100, 2^100] take the plain form
+//    (0 + 0 included: both give 0).
+//  * the two quotients share their reciprocal (div2_shared) when the denominator is in
+//    [2^-40, 2^40] (the numerators are per-pass constants, checked on the host:
+//    MaltaNorm::fast_div).
+//  * the ladder: with bb = (a < 0 ? -b : b) its four cases are  bb < too_small -> scaler2 *
+//    (too_small - bb),  else bb > too_big -> scaler2 * (bb - too_big)  -- negation is exact,
+//    x - (-y) == x + y == y + x -- and d -/+ impact is d + (-/+ impact).
+GZ_DEVFN float malta_diff(float a, float b, const MaltaNorm nm) {
+#ifdef GZ_MALTA_DIFF_PLAIN
+  return malta_diff_plain(a, b, nm);
+#endif
+  const float fa = fabsf(a), fb = fabsf(b);
+  const float s = fa + fb;
+  float absval = 0.5f * s;
+  if (!(s >= 0x1p-100f && s <= 0x1p100f)) absval = (float)(0.5 * (double)fa + 0.5 * (double)fb);
+  const float diff = a - b;
+  const float den = nm.norm1f + absval;
+  float scaler, scaler2;
+  if (nm.fast_div && den >= 0x1p-40f && den <= 0x1p40f) {
+    div2_shared(nm.norm2_0gt1, nm.norm2_0lt1, den, &scaler, &scaler2);
+  } else {
+    scaler = nm.norm2_0gt1 / den;
+    scaler2 = nm.norm2_0lt1 / den;
+  }
+  const float d = scaler * diff;
+  const double fabs0 = (double)fa;
+  const double too_small = 0.55 * fabs0;
+  const double too_big = 1.05 * fabs0;
+  const double bb = (double)(a < 0 ? -b : b);
+  const bool lo = bb < too_small;
+  const bool hit = lo || bb > too_big;
+  const double u = lo ? too_small : bb;
+  const double v = lo ? bb : too_big;
+  double impact = (double)scaler2 * (u - v);
+  if (diff < 0) impact = -impact;
+  const float r = (float)((double)d + impact);
+  return hit ? r : d;
 }
 
 // ---- L2Diff / L2DiffAsymmetric / SameNoiseLevels accumulations -------------------

@@ -121,6 +121,19 @@ def test_blur(L, wh):
     pc.case_blur(L, *wh)
 
 
+def test_paired_row_column_passes(L, monkeypatch):
+    """k_blur_h_pk / k_blur_v_pk (the default from 4 MPix on: test_large_odd_image_24_mpix runs
+    them at scale) forced at sizes the oracle handles quickly, 16- and 32-row tiles."""
+    monkeypatch.setenv("GZ_BLUR_PK", "1")
+    pc.case_blur(L, 1100, 300)
+    pc.case_stages(L, 440, 250, x0=0, y0=0)
+    monkeypatch.setenv("GZ_TILE_ROWS", "32")
+    pc.case_blur(L, 840, 200)
+    pc.case_compare(L, 444, 258, qscales=(6,))
+    monkeypatch.setenv("GZ_BLUR_PK", "0")
+    pc.case_blur(L, 840, 200)
+
+
 @pytest.mark.parametrize("wh", [(256, 192), (72, 48), (35, 41), (444, 258)])
 def test_stages(L, wh):
     pc.case_stages(L, *wh, x0=0, y0=0)

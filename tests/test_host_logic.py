@@ -65,3 +65,20 @@ def test_opsin_division_identities_hold_for_every_float(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count(" 0 mismatches") == 2, out.stdout
+
+
+def test_malta_diff_fast_form_equals_the_reference_sequence(tmp_path):
+    """gz_math.h evaluates Malta's per-pixel "diffs" value (MaltaDiffMapImpl, butteraugli.cc:
+    1473-1529) without the reference's if-ladder, with a float form of `absval` and with both
+    quotients from one reciprocal.  tests/cpp/verify_malta_diff.cc checks it bit for bit against
+    the reference's statement sequence on 10^8 random / threshold-hugging / denormal / huge
+    pairs for the six normalisations in use, and the shared-reciprocal division against the IEEE
+    quotient for every mantissa of the denominator with the reciprocal estimate off by -1, 0
+    and +1 ulp (the device's own v_rcp_f32 is covered by tools/ubench/divcheck.hip)."""
+    exe = str(tmp_path / "verify_md")
+    subprocess.run(["g++", "-O2", "-mfma", "-ffp-contract=off", "-pthread", "-DGZ_EMU",
+                    "-I" + os.path.join(ROOT, "guetzli_amd", "csrc"), "-I" + os.path.join(ROOT, "tests", "emu"),
+                    os.path.join(ROOT, "tests", "cpp", "verify_malta_diff.cc"), "-o", exe], check=True)
+    out = subprocess.run([exe, "100000000"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(" 0 mismatches") == 2, out.stdout

@@ -98,6 +98,18 @@ def test_stages_and_compare_with_compact_code_variants(L, monkeypatch):
     pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(5,))
 
 
+def test_blur_and_compare_with_paired_row_column_passes(L, monkeypatch):
+    """The row-pair / column-pair passes with packed arithmetic (k_blur_h_pk, k_blur_v_pk: what
+    images from 4 MPix on run) forced on images small enough for the emulation but wide and
+    tall enough to have interior tiles (x0 >= 256, 16-row tiles away from the border rows)."""
+    monkeypatch.setenv("GZ_BLUR_PK", "1")
+    pc.case_blur(L, 840, 72)
+    monkeypatch.setenv("GZ_TILE_ROWS", "32")
+    pc.case_blur(L, 600, 100, configs=pc.SIGMAS_BR[:4])
+    pc.case_stages(L, 72, 48)
+    pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(5,))
+
+
 # ------------------------------------------------------------------ YUV 4:2:0 (row f4) --
 needs_ref = pytest.mark.skipif(ref is None, reason="oracle/_ref/libgz_ref.so not built")
 

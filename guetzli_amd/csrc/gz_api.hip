@@ -552,18 +552,20 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
 constexpr int kTileRows = 32;
 constexpr int kSmallTileRows = 16;
 // Compact-code variants of the column pass (k_blur_v_compact) and of the multi-channel fused
-// blurs (k_blur2d<..., ROLL>): loops instead of 20-40 KB of straight-line code.  About one box
-// in eight has 2-3x the instruction-cache misses in these kernels (SQC_ICACHE_MISSES,
-// profiles/r01_sq_counters_*_box.csv) and runs a 1080p chain in 0.55 instead of 0.42 ms; the
-// compact variants bring that back to 0.49 there and cost nothing measurable on the other
-// boxes at 1080p, but 2-3 % at 4K, where the long kernels amortise their instruction fetch
-// (profiles/r01_slow_box_diagnostics_7_compact_ab.log).  Hence: used between 1.5 and 4 MPix;
-// GZ_COMPACT_BLUR_V / GZ_COMPACT_BLUR2D = 0 / 1 force either.
+// blurs (k_blur2d<..., ROLL>): loops instead of 20-40 KB of straight-line code.  A fraction of
+// the boxes (one in eight in round 1, more in round 2) shows 2-3x the instruction-cache misses
+// in the unrolled kernels (SQC_ICACHE_MISSES, profiles/r01_sq_counters_*_box.csv) and runs a
+// 1080p chain in 0.55 instead of 0.42 ms; every launch starts with cold instruction caches, so
+// the code size of a kernel that runs for 25-100 us is on its critical path.  The compact
+// variants are the default at every size: on the boxes that miss they win at 1080p (0.47 ->
+// 0.44 ms) and at 4K (1.295 -> 1.284 ms), on the others they cost nothing measurable (4K:
+// 1.162 vs 1.161-1.172 ms; profiles/r02_compact_variants_all_sizes_ab.log).
+// GZ_COMPACT_BLUR_V / GZ_COMPACT_BLUR2D = 0 select the unrolled kernels.
 static bool compact_code(const gz_ctx* c, const char* knob) {
+  (void)c;
   const char* e = getenv(knob);
   if (e) return atoi(e) != 0;
-  const size_t px = (size_t)c->w * c->h;
-  return px < 4000000;
+  return true;
 }
 // Images below ~1.5 MPix use 16-row tiles for the passes without block maxima: twice the
 // workgroups again (720p: 0.290 -> 0.257 ms per Compare; no gain at 1080p, a small loss at 4K).

@@ -134,6 +134,17 @@ def test_paired_row_column_passes(L, monkeypatch):
     pc.case_blur(L, 840, 200)
 
 
+def test_unrolled_code_variants(L, monkeypatch):
+    """The unrolled column pass / fused blurs (GZ_COMPACT_*=0; the compact variants are the default)."""
+    monkeypatch.setenv("GZ_COMPACT_BLUR_V", "0")
+    monkeypatch.setenv("GZ_COMPACT_BLUR2D", "0")
+    pc.case_blur(L, 444, 258)
+    pc.case_stages(L, 256, 192, x0=0, y0=0)
+    pc.case_compare(L, 444, 258, qscales=(6,))
+    monkeypatch.setenv("GZ_TILE_ROWS", "32")
+    pc.case_stages(L, 256, 192, x0=0, y0=0)
+
+
 @pytest.mark.parametrize("wh", [(256, 192), (72, 48), (35, 41), (444, 258)])
 def test_stages(L, wh):
     pc.case_stages(L, *wh, x0=0, y0=0)

@@ -87,11 +87,12 @@ def test_global_order(L):
     pc.case_global_order(L, 40, 32, x0=100, y0=60)
 
 
-def test_stages_and_compare_with_compact_code_variants(L, monkeypatch):
-    """The compact-code column pass and rolled-channel fused blurs (what 1.5-4 MPix images run,
-    e.g. 1080p) forced on a small image, so that they are checked in emulation as well."""
-    monkeypatch.setenv("GZ_COMPACT_BLUR_V", "1")
-    monkeypatch.setenv("GZ_COMPACT_BLUR2D", "1")
+def test_stages_and_compare_with_unrolled_code_variants(L, monkeypatch):
+    """The compact-code column pass and rolled-channel fused blurs are the default; the unrolled
+    kernels (GZ_COMPACT_BLUR_V=0 / GZ_COMPACT_BLUR2D=0) are forced here so that both are checked
+    in emulation."""
+    monkeypatch.setenv("GZ_COMPACT_BLUR_V", "0")
+    monkeypatch.setenv("GZ_COMPACT_BLUR2D", "0")
     pc.case_blur(L, 72, 48)
     pc.case_stages(L, 72, 48)
     pc.case_stages(L, 35, 41)

@@ -120,22 +120,37 @@ struct SearchArgs {
   float* out_err;               // [grid blocks][192]
 };
 
+// Candidates of one greedy step that are evaluated together: their wide stages (IDCT, colour,
+// opsin -- 64 busy lanes each) run one after the other, their narrow stages (in-order means,
+// FFTs, in-order CSF sums -- 3 to 24 busy lanes and long dependent FP64 chains per candidate)
+// run side by side on lanes that would otherwise idle.  3 = the default look-ahead.
+constexpr int kEvalBatch = 3;
+
 struct SearchLds {
   short coef[192];
-  int in[64], col[64];
   int ycc[3][64];       // pixel cache of the current (processed) block
-  int cpx[64];          // changed component of the candidate
-  float lin[3][64];
-  float tmp[3][64];
   float x0[3][64];      // original block's opsin image (per_block_pregamma_)
-  double d[3][64];
-  Cpx rowf[3][8][5];    // row FFT outputs F0..F4
-  double pw[3][40];     // |.|^2 * 0.000064 for flat indices 4..36
-  double red[4];
   float lut[256];
   unsigned char list[192];
   unsigned char oidx[192];
   float oerr[192];
+  union {
+    struct {            // scratch of one candidate's wide stages
+      int in[64], col[64];
+      int cpx[64];      // changed component of the candidate
+      float lin[3][64];
+      float tmp[3][64];
+    };
+    // |.|^2 * 0.000064 for flat indices 0..39 of a batch's candidates: written by the column
+    // stage, after the batch's last wide stage is done with the scratch
+    double pw[kEvalBatch][3][40];
+  };
+  // per candidate of the batch: opsin differences; after the row stage their row transforms in
+  // place, 8 doubles per row: F0.re, F4.re, F1, F2, F3 (F0, F4 of a real row are real)
+  double d[kEvalBatch][3][64];
+  double red[kEvalBatch][3];
+  float err[kEvalBatch];
+  int num;
   // 4:2:0 chroma search only: the 10x10 subsampled samples around the 16x16 block
   // (UpdatePixelsForBlock's `subsampled`, output_image.cc:150-183) per chroma component
   int s10[2][100];
@@ -225,11 +240,11 @@ struct SearchView {
   bool in_image;         // MODE 2: the sub-block is compared at all
 };
 
-// CompareBlock for this wavefront's 8x8 window with coefficient `ci` (= c*64+k) zeroed.
-// Uniform result (every lane returns the same value).
+// Wide stages of CompareBlock for this wavefront's 8x8 window with coefficient `ci`
+// (= c*64+k) zeroed: the opsin differences of the candidate go to s.d[slot].
 template <int MODE>
-GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, const SearchView& v, const int* ring,
-                              const SearchArgs& a) {
+GZ_DEVFN void eval_wide(SearchLds& s, int ci, int slot, int lane, const SearchView& v,
+                        const int* ring, const SearchArgs& a) {
   // ci == 64 * 3: nothing zeroed (the luma component is simply recomputed)
   const int cc = ci >= 192 ? 0 : ci >> 6, kk = ci >= 192 ? -1 : ci & 63;
   idct_component(s, cc, kk, lane, s.cpx);
@@ -259,61 +274,81 @@ GZ_DEVFN float eval_candidate(SearchLds& s, int ci, int lane, const SearchView& 
   __syncthreads();
   float x, y, z;
   opsin8x8(s, lane, a, &x, &y, &z);
-  s.d[0][lane] = (double)s.x0[0][lane] - (double)x;
-  s.d[1][lane] = (double)s.x0[1][lane] - (double)y;
-  s.d[2][lane] = (double)s.x0[2][lane] - (double)z;
+  s.d[slot][0][lane] = (double)s.x0[0][lane] - (double)x;
+  s.d[slot][1][lane] = (double)s.x0[1][lane] - (double)y;
+  s.d[slot][2][lane] = (double)s.x0[2][lane] - (double)z;
   __syncthreads();
-  // mean term (lanes 0..2, in index order) and row FFTs (lanes 8..31)
+}
+
+// Narrow stages (ButteraugliBlockDiff, butteraugli_comparator.cc:382-411, and CompareBlock's
+// masked sum) of the nc <= kEvalBatch candidates whose differences are in s.d[0..nc): every
+// candidate's arithmetic is what it would be alone -- lane assignments only -- and its error
+// lands in s.err[slot]; s.red[slot] keeps the three channel terms.
+GZ_DEVFN void eval_narrow(SearchLds& s, int nc, int lane, const SearchView& v) {
+  // mean term in index order: lane -> (slot, channel)
+  const int slot9 = lane / 3, ch9 = lane - 3 * slot9;
   double dc_term = 0.0;
-  if (lane < 3) {
+  if (lane < 3 * nc) {
+    const double* p = s.d[slot9][ch9];
     double sum = 0.0;
-    for (int i = 0; i < 64; ++i) sum += s.d[lane][i];
+    for (int i = 0; i < 64; ++i) sum += p[i];
     const double avg = sum / 64;
     dc_term = (4.0 * avg) * avg;
-  } else if (lane >= 8 && lane < 32) {
-    const int ch = (lane - 8) >> 3, row = (lane - 8) & 7;
-    const double* p = &s.d[ch][8 * row];
-    Cpx F[8];
-    real_fft8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], F);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) s.rowf[ch][row][k] = F[k];
   }
   __syncthreads();
-  // column stage: 15 lanes; lane -> (channel, transposed row k)
-  if (lane < 15) {
-    const int ch = lane / 5, k = lane - 5 * ch;
+  // row transforms, in place: task -> (slot, channel, row)
+  for (int t = lane; t < 24 * nc; t += 64) {
+    double* p = &s.d[t / 24][(t % 24) >> 3][8 * (t & 7)];
+    Cpx F[8];
+    real_fft8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], F);
+    p[0] = F[0].re; p[1] = F[4].re;
+    p[2] = F[1].re; p[3] = F[1].im;
+    p[4] = F[2].re; p[5] = F[2].im;
+    p[6] = F[3].re; p[7] = F[3].im;
+  }
+  __syncthreads();
+  // column stage: task -> (slot, channel, transposed row k)
+  if (lane < 15 * nc) {
+    const int sl = lane / 15, r = lane - 15 * sl;
+    const int ch = r / 5, k = r - 5 * ch;
+    const double* col = s.d[sl][ch];
     Cpx F[8];
     if (k == 0 || k == 4) {
-      real_fft8(s.rowf[ch][0][k].re, s.rowf[ch][1][k].re, s.rowf[ch][2][k].re,
-                s.rowf[ch][3][k].re, s.rowf[ch][4][k].re, s.rowf[ch][5][k].re,
-                s.rowf[ch][6][k].re, s.rowf[ch][7][k].re, F);
+      const int j = k == 0 ? 0 : 1;
+      real_fft8(col[j], col[8 + j], col[16 + j], col[24 + j], col[32 + j], col[40 + j],
+                col[48 + j], col[56 + j], F);
     } else {
       Cpx in[8];
 #pragma unroll
-      for (int x2 = 0; x2 < 8; ++x2) in[x2] = s.rowf[ch][x2][k];
+      for (int x2 = 0; x2 < 8; ++x2) {
+        in[x2].re = col[8 * x2 + 2 * k];
+        in[x2].im = col[8 * x2 + 2 * k + 1];
+      }
       fft8(in, F);
     }
 #pragma unroll
     for (int x2 = 0; x2 < 8; ++x2) {
       double pv = F[x2].re * F[x2].re + F[x2].im * F[x2].im;
       pv = pv * 0.000064;
-      s.pw[ch][8 * k + x2] = pv;
+      s.pw[sl][ch][8 * k + x2] = pv;
     }
   }
   __syncthreads();
-  if (lane < 3) {
+  if (lane < 3 * nc) {
+    const double* pw = s.pw[slot9][ch9];
     double acc = dc_term;   // diff_xyb[c] starts at 0.0: 0.0 + 4*avg*avg
-    for (int i = 4; i < 37; ++i) acc += kCsf8x8[i] * s.pw[lane][i];
-    s.red[lane] = acc;
+    for (int i = 4; i < 37; ++i) acc += kCsf8x8[i] * pw[i];
+    s.red[slot9][ch9] = acc;
   }
   __syncthreads();
-  double diff = 0.0;
-  diff += s.red[0] * (double)v.m0;
-  diff += s.red[1] * (double)v.m1;
-  diff += s.red[2] * (double)v.m2;
-  const float err = (float)sqrt(diff);
+  if (lane < nc) {
+    double diff = 0.0;
+    diff += s.red[lane][0] * (double)v.m0;
+    diff += s.red[lane][1] * (double)v.m1;
+    diff += s.red[lane][2] * (double)v.m2;
+    s.err[lane] = (float)sqrt(diff);
+  }
   __syncthreads();
-  return err;
 }
 
 // grid = one workgroup per block of the search grid; 64 threads (MODE 0, 1) or 256 (MODE 2).
@@ -322,7 +357,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
   constexpr int NW = MODE == 2 ? 4 : 1;
   __shared__ SearchLds sh[NW];
   __shared__ int s_ring[MODE == 2 ? 200 : 1];      // neighbours' samples around the block, fixed
-  __shared__ float s_err[4];
+  __shared__ float s_err[kEvalBatch][4];
   const int wave = MODE == 2 ? (int)(threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
   SearchLds& s = sh[wave];
   const int blk = blockIdx.x;
@@ -427,22 +462,28 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
     float best_err = 1e17f;
     int best_i = 0;
     const int tries = n < a.lookahead ? n : a.lookahead;
-    for (int i = 0; i < tries; ++i) {
-      float max_err = 0.0f;
+    for (int base = 0; base < tries; base += kEvalBatch) {
+      const int nc = tries - base < kEvalBatch ? tries - base : kEvalBatch;
+      for (int j = 0; j < nc; ++j) eval_wide<MODE>(s, (int)s.list[base + j], j, lane, v, s_ring, a);
+      eval_narrow(s, nc, lane, v);
       if (MODE == 2) {
-        const float e = eval_candidate<MODE>(s, (int)s.list[i], lane, v, s_ring, a);
-        if (lane == 0) s_err[wave] = v.in_image ? e : 0.0f;
+        if (lane < nc) s_err[lane][wave] = v.in_image ? s.err[lane] : 0.0f;
         __syncthreads();
-        for (int k = 0; k < 4; ++k) max_err = s_err[k] > max_err ? s_err[k] : max_err;   // std::max(max_err, err)
-        __syncthreads();
-      } else {
-        const float e = eval_candidate<MODE>(s, (int)s.list[i], lane, v, s_ring, a);
-        max_err = e > 0.0f ? e : 0.0f;   // std::max(0, err)
       }
-      if (max_err < best_err) {
-        best_err = max_err;
-        best_i = i;
+      for (int j = 0; j < nc; ++j) {
+        float max_err = 0.0f;
+        if (MODE == 2) {
+          for (int k = 0; k < 4; ++k) max_err = s_err[j][k] > max_err ? s_err[j][k] : max_err;   // std::max(max_err, err)
+        } else {
+          const float e = s.err[j];
+          max_err = e > 0.0f ? e : 0.0f;   // std::max(0, err)
+        }
+        if (max_err < best_err) {
+          best_err = max_err;
+          best_i = base + j;
+        }
       }
+      if (MODE == 2) __syncthreads();
     }
     const int ci = (int)s.list[best_i];
     __syncthreads();
@@ -484,11 +525,11 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
     }
     int num = 0;
     while (num < m && s.oerr[num] <= a.limit) ++num;
-    s.red[3] = (double)num;
+    s.num = num;
     if (wave == 0) a.out_cnt[blk] = num;
   }
   __syncthreads();
-  const int num = wave == 0 ? (int)s.red[3] : 0;
+  const int num = wave == 0 ? s.num : 0;
   for (int i = lane; i < num; i += 64) {
     a.out_idx[(size_t)blk * 192 + i] = s.oidx[i];
     a.out_err[(size_t)blk * 192 + i] = s.oerr[i];
@@ -535,12 +576,13 @@ __global__ __launch_bounds__(64) void k_compare_blocks(SearchArgs a, const int32
   v.m1 = a.block_mask[a.nb + mb];
   v.m2 = a.block_mask[2 * a.nb + mb];
   // candidate index 192: the luma component is recomputed with no coefficient zeroed
-  (void)eval_candidate<0>(s, 192, lane, v, nullptr, a);
+  eval_wide<0>(s, 192, 0, lane, v, nullptr, a);
+  eval_narrow(s, 1, lane, v);
   if (lane == 0) {
     double diff = 0.0;
-    diff += s.red[0] * (double)v.m0;
-    diff += s.red[1] * (double)v.m1;
-    diff += s.red[2] * (double)v.m2;
+    diff += s.red[0][0] * (double)v.m0;
+    diff += s.red[0][1] * (double)v.m1;
+    diff += s.red[0][2] * (double)v.m2;
     out[i] = sqrt(diff);
   }
 }

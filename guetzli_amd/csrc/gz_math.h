@@ -27,8 +27,9 @@ GZ_DEVFN void opsin_absorbance(float r, float g, float b, float* o0, float* o1,
 }
 
 // ---- GammaPolynomial, butteraugli.h:548-615 (Clenshaw, degree 5/5, all double) ----
-GZ_DEVFN double clenshaw6(double x, double c0, double c1, double c2, double c3, double c4,
-                          double c5) {
+// The reference's recursion, statement by statement (the form the host check compares with).
+GZ_DEVFN double clenshaw6_plain(double x, double c0, double c1, double c2, double c3, double c4,
+                                double c5) {
   double b1 = 0.0, b2 = 0.0, xb, t;
   xb = x * b1; t = ((xb + xb) - b2) + c5; b2 = b1; b1 = t;
   xb = x * b1; t = ((xb + xb) - b2) + c4; b2 = b1; b1 = t;
@@ -37,6 +38,25 @@ GZ_DEVFN double clenshaw6(double x, double c0, double c1, double c2, double c3, 
   xb = x * b1; t = ((xb + xb) - b2) + c1; b2 = b1; b1 = t;
   xb = x * b1;
   return (xb - b2) + c0;
+}
+// The same values with 14 operations instead of 23 (x finite, x2 = x + x):
+//  * the first step has b1 = b2 = 0: (x*0 + x*0) - 0 + c5 is c5;
+//  * the second has b2 = 0: y - 0 is y;
+//  * (x*b + x*b) is 2 * RN(x*b), and so is RN((x + x) * b): scaling by two commutes with
+//    rounding as long as the product is a normal number, and x*b is either exactly 0 or
+//    (x of order 1, b a sum of order-1 constants, at worst cancelled down to 2^-52) far from
+//    the denormal range.
+// tests/cpp/verify_opsin_divisions.cc compares gamma_poly_f built on this form with the plain
+// one for EVERY float argument.
+GZ_DEVFN double clenshaw6(double x, double x2, double c0, double c1, double c2, double c3,
+                          double c4, double c5) {
+  double b2 = c5;
+  double b1 = x2 * c5 + c4;
+  double t;
+  t = (x2 * b1 - b2) + c3; b2 = b1; b1 = t;
+  t = (x2 * b1 - b2) + c2; b2 = b1; b1 = t;
+  t = (x2 * b1 - b2) + c1; b2 = b1; b1 = t;
+  return (x * b1 - b2) + c0;
 }
 
 // float(yp / yq) of RationalPolynomial::operator() (butteraugli.h:581-591) -- what its
@@ -60,11 +80,19 @@ GZ_DEVFN float gamma_poly_f(double v) {
   const double r = __builtin_fma(-b, q, a);
   const double x01 = __builtin_fma(r, y, q);
   const double xc = 2.0 * x01 - 1.0;
-  const double yp = clenshaw6(xc, 98.7821300963361, 164.273222212631, 92.948112871376,
-                              33.8165311212688, 6.91626704983562, 0.556380877028234);
-  const double yq = clenshaw6(xc, 1, 1.64339473427892, 0.89392405219969,
-                              0.298947051776379, 0.0507146002577288,
-                              0.00226495093949756);
+  double yp, yq;
+  if (xc * 0.0 == 0.0) {   // finite (always, for the finite absorbances the chain produces)
+    const double x2 = xc + xc;
+    yp = clenshaw6(xc, x2, 98.7821300963361, 164.273222212631, 92.948112871376,
+                   33.8165311212688, 6.91626704983562, 0.556380877028234);
+    yq = clenshaw6(xc, x2, 1, 1.64339473427892, 0.89392405219969, 0.298947051776379,
+                   0.0507146002577288, 0.00226495093949756);
+  } else {
+    yp = clenshaw6_plain(xc, 98.7821300963361, 164.273222212631, 92.948112871376,
+                         33.8165311212688, 6.91626704983562, 0.556380877028234);
+    yq = clenshaw6_plain(xc, 1, 1.64339473427892, 0.89392405219969, 0.298947051776379,
+                         0.0507146002577288, 0.00226495093949756);
+  }
   if (yq == 0.0) return 0.0f;
   return (float)(yp / yq);
 }

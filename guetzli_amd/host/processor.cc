@@ -174,17 +174,25 @@ inline bool IsPrecious(const int16_t* orig_blk, int k) {
 struct DeviceOrder : RangeDevice {
   explicit DeviceOrder(gz_ctx* c) : ctx(c) {}
   bool Partition(size_t lo, size_t hi, size_t* cut) override {
+    Stopwatch w;
     uint64_t c64 = 0;
     rc = gz_order_partition(ctx, lo, hi, &c64);
     *cut = (size_t)c64;
+    t_partition += w.lap();
+    ++n_partition;
     return rc == GZ_OK;
   }
   bool Fetch(size_t lo, size_t hi, void* dst) override {
+    Stopwatch w;
     rc = gz_order_fetch(ctx, lo, hi, dst);
+    t_fetch += w.lap();
+    n_fetched += (long)(hi - lo);
     return rc == GZ_OK;
   }
   gz_ctx* ctx;
   int rc = GZ_OK;
+  double t_partition = 0, t_fetch = 0;   // seconds inside the device calls (round trips included)
+  long n_partition = 0, n_fetched = 0;
 };
 
 // ------------------------------------------------------------------- the encoder ------
@@ -292,7 +300,9 @@ class Encoder {
   double best_score_ = -1;
   double t_write_ = 0, t_compare_ = 0, t_quant_ = 0, t_blocksearch_ = 0, t_phaseb_ = 0,
          t_upload_ = 0;
-  double t_pb_ensure_ = 0, t_pb_fast_ = 0;
+  double t_pb_ensure_ = 0, t_pb_fast_ = 0, t_pb_dev_partition_ = 0, t_pb_dev_fetch_ = 0;
+  double t_fs_count_ = 0, t_fs_apply_ = 0, t_fs_mirror_ = 0, t_fs_delta_ = 0, t_fs_rest_ = 0;
+  long n_dev_partitions_ = 0, n_dev_fetched_ = 0;
   long n_fast_ = 0;
   double t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0, n_evaluations_ = 0;
@@ -613,6 +623,29 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   rc = gz_order_reset(ctx_);           // max_block_error := 0, kept on the device
   if (rc != GZ_OK) return Fail("gz_order_reset", rc);
   std::vector<int> next_cand(nb, 0);   // last_indexes
+  // The host mirror img_ follows the bulk ("fast") steps lazily: mirror_cand[b] says up to
+  // which candidate position block b's coefficients in img_ are current.  Only the blocks the
+  // slow steps touch (a hundred per iteration) need their mirror at once; the rest is brought
+  // up to date when the direction turns and at the end (on the worker pool).
+  std::vector<int> mirror_cand(nb, 0);
+  auto settle_block = [&](int b, int direction) {
+    while (mirror_cand[b] != next_cand[b]) {
+      const int idx = cand_idx[cand_off[b] + mirror_cand[b] + std::min(direction, 0)];
+      const int c = idx / 64, k = idx % 64;
+      const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
+      const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], quant_[c][k]);
+      if (!(newval == 0 && IsPrecious(orig_blk, k))) img_[Pos(c, b, k)] = (int16_t)newval;
+      mirror_cand[b] += direction;
+    }
+  };
+  auto settle_all = [&](int direction) {
+    WorkerPool& pool = WorkerPool::Get();
+    const int chunks = nb < 4096 ? 1 : 4 * pool.size();
+    const int per = (nb + chunks - 1) / chunks;
+    pool.Run(chunks, [&](int ch) {
+      for (int b = ch * per; b < std::min(nb, (ch + 1) * per); ++b) settle_block(b, direction);
+    });
+  };
   std::vector<int32_t> edit_pos;       // coefficient changes of one iteration
   std::vector<int16_t> edit_val;
   std::vector<std::pair<int, float> >& order = order_;   // host copy of the ranges that were fetched
@@ -701,6 +734,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       const size_t n_order = (size_t)total;
       auto apply_step = [&](size_t i) {
         const int b = sorted[i].first;
+        settle_block(b, direction);
         const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
         const int c = idx / 64, k = idx % 64;
         const int* q = quant_[c];
@@ -715,6 +749,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         }
         AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
         next_cand[b] += direction;
+        mirror_cand[b] = next_cand[b];
         if (!touched[b]) {
           touched[b] = 1;
           dirty.push_back(b);
@@ -745,6 +780,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
             dirty.push_back(b);
           }
         }
+        t_fs_count_ += fw.lap();
         if (fast_until > 0) {
           val_threshold = order[fast_until - 1].second;
           changed_coeffs += (int)fast_until;
@@ -753,30 +789,18 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           for (size_t di = 0; di < dirty.size(); ++di) counts[di] = step_count[dirty[di]];
           rc = gz_apply_candidate_steps(ctx_, direction, dirty.data(), counts.data(), (int)dirty.size());
           if (rc != GZ_OK) return Fail("gz_apply_candidate_steps", rc);
-          // ... while the host mirror is edited block by block on the worker pool
-          WorkerPool& pool = WorkerPool::Get();
-          const int chunks = dirty.size() < 2048 ? 1 : 4 * pool.size();
-          const size_t per = (dirty.size() + chunks - 1) / chunks;
-          pool.Run(chunks, [&](int ch) {
-            const size_t d0 = ch * per, d1 = std::min(dirty.size(), d0 + per);
-            for (size_t di = d0; di < d1; ++di) {
-              const int b = dirty[di];
-              for (int step = 0; step < step_count[b]; ++step) {
-                const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
-                const int c = idx / 64, k = idx % 64;
-                const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
-                const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], quant_[c][k]);
-                if (!(newval == 0 && IsPrecious(orig_blk, k)))
-                  img_[Pos(c, b, k)] = (int16_t)newval;
-                next_cand[b] += direction;
-              }
-            }
-          });
+          t_fs_apply_ += fw.lap();
+          // ... while the host only notes how far each block has advanced; its mirror of the
+          // coefficients follows when a slow step needs the block (settle_block)
+          for (size_t di = 0; di < dirty.size(); ++di) next_cand[dirty[di]] += direction * counts[di];
+          if (verify_) settle_all(direction);   // GZ_VERIFY_ENTROPY compares the whole mirror
           // the symbol statistics of the edited image come from the device: the change the
           // steps made to BuildACHistograms, counted over the touched blocks (the host's
           // ac_histo was exact before them: the slow steps below keep it so)
+          t_fs_mirror_ += fw.lap();
           std::vector<int32_t> delta(3 * 256);
           rc = gz_steps_histogram_delta(ctx_, delta.data());
+          t_fs_delta_ += fw.lap();
           if (rc != GZ_OK) return Fail("gz_steps_histogram_delta", rc);
           for (int c = 0; c < 3; ++c)
             for (int i = 0; i < 256; ++i)
@@ -791,7 +815,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
               }
           }
         }
-        t_pb_fast_ += fw.lap();
+        t_fs_rest_ += fw.lap();
         n_steps_ += (long)fast_until;
         n_fast_ += (long)fast_until;
         for (size_t i = fast_until; i < n_order; ++i) {
@@ -812,6 +836,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       t_pb_loop_ += pw.lap();
       const size_t order_size = (size_t)total;
       if (sorted.failed()) return Fail("gz_order_partition/fetch", dev_order.rc);
+      t_pb_dev_partition_ += dev_order.t_partition;
+      t_pb_dev_fetch_ += dev_order.t_fetch;
+      n_dev_partitions_ += dev_order.n_partition;
+      n_dev_fetched_ += dev_order.n_fetched;
       rc = gz_order_advance(ctx_, val_threshold, direction);   // max_block_error += weight * ...
       if (rc != GZ_OK) return Fail("gz_order_advance", rc);
 
@@ -847,6 +875,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       prev_size = est_size;
       sw.lap();
     }
+    settle_all(direction);   // img_ is exact again before the direction turns / the call returns
   }
   return true;
 }
@@ -953,6 +982,15 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->timers["pb_loop"] = t_pb_loop_;
   stats_->timers["pb_loop_codes"] = t_pb_codes_;
   stats_->timers["pb_loop_ensure_sorted"] = t_pb_ensure_;
+  stats_->timers["pb_fast_count"] = t_fs_count_;
+  stats_->timers["pb_fast_apply"] = t_fs_apply_;
+  stats_->timers["pb_fast_mirror"] = t_fs_mirror_;
+  stats_->timers["pb_fast_delta"] = t_fs_delta_;
+  stats_->timers["pb_device_partitions"] = t_pb_dev_partition_;
+  stats_->timers["pb_device_fetches"] = t_pb_dev_fetch_;
+  stats_->counters["phase B device partitions"] = (int)n_dev_partitions_;
+  stats_->counters["phase B entries fetched"] = (int)std::min<long>(n_dev_fetched_, 2147483647L);
+  t_pb_fast_ = t_fs_count_ + t_fs_apply_ + t_fs_mirror_ + t_fs_delta_ + t_fs_rest_;
   stats_->timers["pb_loop_fast_steps"] = t_pb_fast_;
   stats_->counters["block search evaluations"] = (int)std::min<long>(n_evaluations_, 2000000000L);
   stats_->counters["phase B fast steps"] = (int)n_fast_;

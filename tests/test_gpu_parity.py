@@ -242,6 +242,51 @@ def test_large_odd_image_24_mpix(L):
         assert head + ctx.jpeg_scan_bytes(cap=n + 16) + b"\xff\xd9" == exp
 
 
+def test_huge_image_256_mpix_periodicity(L):
+    """16384 x 16384 (268 MPix, a 44 GB plane arena, 4.2 M blocks): far beyond what the oracle
+    can check in a test, so size-independent properties.  The image is bees.png tiled from the
+    origin; with the 8x8 block grid its content repeats every (888, 1032) pixels, so the distance
+    map of a uniformly quantised candidate must repeat with that period away from the borders
+    (bit for bit: every sample sees identical inputs through identical operations), and must
+    equal the same window of the 3840x2160 image's map (a size whose kernels are pinned to the
+    oracle by the tests above).  An index that wrapped at 2^31 anywhere would break both.  Also:
+    distance == max(map), block maxima consistent, the device entropy coder's exact size
+    against the serial host writer."""
+    import guetzli_amd
+    w = h = 16384
+    target = 0.971769
+    q = np.full((3, 64), 5, np.int32)
+    px, py = 888, 1032   # lcm(444, 8), lcm(258, 8)
+    with L.context(images.tiled(3840, 2160), target) as small:
+        small.encode_rgb(download=False)
+        small.quantize(q, download=False)
+        _, ms, _ = small.compare(want_block_max=False)
+    win_small = ms[py:2 * py, px:2 * px].copy()   # >= 96 px from every border of the 4K image
+    del ms
+    rgb = images.tiled(w, h)
+    with L.context(rgb, target) as ctx:
+        ctx.encode_rgb(download=False)
+        cq = ctx.quantize(q)
+        d1, m1, b1 = ctx.compare()
+        assert d1 == m1.max()
+        ref_win = m1[py:2 * py, px:2 * px]
+        assert_bits_equal(ref_win, win_small, "16K window vs the same window of the 4K image")
+        for ky, kx in ((0, 1), (1, 0), (7, 9), (13, 16), (13, 1), (1, 16)):
+            y0, x0 = py * (1 + ky), px * (1 + kx)
+            assert y0 + py <= h - 96 and x0 + px <= w - 96
+            assert_bits_equal(m1[y0:y0 + py, x0:x0 + px], ref_win, f"period ({ky}, {kx})")
+        assert_bits_equal(b1, m1.reshape(ctx.bh, 8, ctx.bw, 8).max(axis=(1, 3)).reshape(-1), "block max")
+        del m1
+        host = guetzli_amd.load_host()
+        counts = ctx.jpeg_histograms(q)
+        head, depth, code = host.jpeg_head(counts, w, h, q)
+        n = ctx.jpeg_scan(3, depth, code)
+        exp = host.write_jpeg(cq, w, h, q)
+        assert len(head) + n + 2 == len(exp)
+        got = ctx.jpeg_scan_bytes(cap=n + 16)
+        assert head + got + b"\xff\xd9" == exp
+
+
 def test_block_search_small_ragged(L):
     pc.case_block_search(L, 45, 27)
     pc.case_block_search(L, 64, 40, x0=10, y0=10, qs=2)

@@ -19,8 +19,14 @@ HEADERS = ["gz_common.h", "gz_math.h", "gz_kernels_block.h", "gz_kernels_blur.h"
            "gz_kernels_diff.h", "gz_kernels_search.h", "gz_kernels_entropy.h", "gz_kernels_dctd.h", "gz_kernels_downsample.h",
            "gz_kernels_order.h", "gz_kernels_rank.h", "gz_host_weights.h", "tables_generated.h", "order_tables_generated.h"]
 ARCH = "gfx950"
+# -vectorize-slp=false: left to itself the compiler packs adjacent scalar f32 adds / multiplies
+# into v_pk_*_f32 pairs; those issue at the same lane rate as the scalar forms on gfx950
+# (tools/ubench/pk.hip) but need their operands in aligned register pairs (extra moves) and a
+# wait state before a dependent use: Malta 323 -> 304 us, the whole chain -3 % (4K) / -5 %
+# (1080p) with it off (profiles/r02_packed_blur_and_malta_diff_experiments.log, section 8).  The
+# kernels that want packed arithmetic ask for it explicitly (gz_f2).  Same results either way.
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-vectorize-slp=false"]
 
 
 def _newer_than_lib():

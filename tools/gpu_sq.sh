@@ -5,6 +5,7 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/${1:-sq}; mkdir -p $O
 shift
+ENVS=("$@")
 R=$GRAFT_REPO_ROOT
 ( cd /tmp && rocprofv3 -L > $R/$O/counters_avail.txt 2>&1 )
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
@@ -13,7 +14,7 @@ C="SQ_WAVES SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE
 for sz in "3840 2160 4k" "1920 1080 1080"; do set -- $sz
   for p in A B C; do
     eval ctrs=\$$p
-    ( cd /tmp && env GZ_SINGLE_STREAM=1 "${@:4}" timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $R/$O/sq_$3_$p -- python $R/tools/run_compare.py $1 $2 3 ) > $O/sq_$3_$p.log 2>&1
+    ( cd /tmp && env GZ_SINGLE_STREAM=1 "${ENVS[@]}" timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $R/$O/sq_$3_$p -- python $R/tools/run_compare.py $1 $2 3 ) > $O/sq_$3_$p.log 2>&1
   done
   python tools/pmc_summary.py $O/sq_$3_A $O/sq_$3_B $O/sq_$3_C > $O/chain_sq_$3.csv 2>$O/summary_$3.err
 done

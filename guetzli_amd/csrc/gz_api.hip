@@ -1180,6 +1180,9 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   if (!err) err = &dummy;
   *err = GZ_OK;
   if (!rgb || w < 8 || h < 8 || w >= (1 << 16) || h >= (1 << 16)) { *err = GZ_E_ARG; return nullptr; }
+  // coefficient positions (3 x blocks x 64) and candidate offsets (blocks x 189) are 32-bit
+  // on both sides of the ABI: 11.18 M blocks = 715 MPix is the largest image (tested: 268 MPix)
+  if ((uint64_t)((w + 7) / 8) * (uint64_t)((h + 7) / 8) * 192u > 0x7fffffffull) { *err = GZ_E_ARG; return nullptr; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev ||
       hipSetDevice(device) != hipSuccess) {

@@ -65,7 +65,9 @@ const char* gz_last_error(const gz_ctx* ctx);
  * linear RGB (LinearRgb, :33-47) and precomputes the original's PsychoImage pi0_
  * (butteraugli.cc:784-791).  `target` is Params::butteraugli_target
  * (processor.h:30).  Requires w,h >= 8 (butteraugli) -- Process() itself only builds a
- * comparator when w,h >= 32 (processor.cc:940).  Returns NULL on failure, *err set.
+ * comparator when w,h >= 32 (processor.cc:940) -- and w,h < 65536 (JPEG) with at most
+ * 11.18 M 8x8 blocks (715 MPix: coefficient positions are 32-bit), else GZ_E_ARG.  Returns
+ * NULL on failure, *err set.
  * Every entry point that takes a context runs on the context's device and leaves the calling
  * thread's current HIP device as it found it (a thread may own contexts on several GPUs). */
 gz_ctx* gz_create(int device, int w, int h, const uint8_t* rgb, float target, int* err);

@@ -5,8 +5,8 @@ set -e
 LIB=$(dirname $0)/../guetzli_amd/libguetzli_amd.so
 BIN=/opt/rocm/lib/llvm/bin
 T=$(mktemp -d)
-$BIN/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=<(objcopy -O binary --only-section=.hip_fatbin $LIB /dev/stdout) --output=$T/co.o --unbundle 2>/dev/null || \
-  { objcopy -O binary --only-section=.hip_fatbin $LIB $T/fat.bin; $BIN/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/fat.bin --output=$T/co.o --unbundle; }
+$BIN/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950:xnack- --input=<(objcopy -O binary --only-section=.hip_fatbin $LIB /dev/stdout) --output=$T/co.o --unbundle 2>/dev/null || \
+  { objcopy -O binary --only-section=.hip_fatbin $LIB $T/fat.bin; $BIN/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950:xnack- --input=$T/fat.bin --output=$T/co.o --unbundle; }
 echo "kernel,code_bytes,vgpr,agpr,sgpr,lds_bytes,scratch_bytes"
 $BIN/llvm-readelf --notes $T/co.o > $T/notes.txt
 $BIN/llvm-readelf -sW $T/co.o | awk '$4=="FUNC"{print $3","$8}' | sort -t, -k2 > $T/sizes.txt

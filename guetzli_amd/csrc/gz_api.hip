@@ -536,12 +536,12 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
   const int w = c->w, h = c->h, pitch = c->pitch;
   if (packed_blur(c, R <= 20)) {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), NC);
-    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs);
+    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs);
     KCHK(c);
     return GZ_OK;
   }
   dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), NC);
-  GZ_LAUNCH((k_blur_h<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs);
+  GZ_LAUNCH((k_blur_h<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs);
   KCHK(c);
   return GZ_OK;
 }
@@ -588,11 +588,11 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
     if (small_tiles(c)) {
       dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
       GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs);
+                pitch, tp, bs, tp, bs);
     } else {
       dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
       GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs);
+                pitch, tp, bs, tp, bs);
     }
     KCHK(c);
     return GZ_OK;
@@ -601,11 +601,11 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
     if (small_tiles(c)) {
       dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
       GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs, bm);
+                pitch, tp, bs, bm, tp, bs);
     } else {
       dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
       GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs, bm);
+                pitch, tp, bs, bm, tp, bs);
     }
     KCHK(c);
     return GZ_OK;
@@ -620,6 +620,48 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
   GZ_LAUNCH((k_blur_v<R, NC, Post, BM, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
             pitch, tp, bs, bm);
+  KCHK(c);
+  return GZ_OK;
+}
+
+// Two blurs of equal radius and different sigma on two independent planes as ONE launch per
+// pass (grid z = plane): the mask's radius-20 pair (butteraugli.cc:1780-1790).
+template <int R, class Src>
+int blur_h_pair(gz_ctx* c, const SrcPack<Src, 2>& src, const PlanePack<2>& dst, const BlurCfg& cfg0,
+                const BlurCfg& cfg1) {
+  if (cfg0.r != R || cfg1.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
+  const Taps<R> t0 = taps_of<R>(cfg0), t1 = taps_of<R>(cfg1);
+  const BorderScale b0 = cfg0.bx, b1 = cfg1.bx;
+  const int w = c->w, h = c->h, pitch = c->pitch;
+  if (packed_blur(c, R <= 20)) {
+    dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), 2);
+    GZ_LAUNCH((k_blur_h_pk<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1);
+  } else {
+    dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), 2);
+    GZ_LAUNCH((k_blur_h<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1);
+  }
+  KCHK(c);
+  return GZ_OK;
+}
+template <int R>
+int blur_v_pair(gz_ctx* c, const CPlanePack<2>& src, const PostStore<2>& post, const BlurCfg& cfg0,
+                const BlurCfg& cfg1) {
+  if (cfg0.r != R || cfg1.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
+  const Taps<R> t0 = taps_of<R>(cfg0), t1 = taps_of<R>(cfg1);
+  const BorderScale b0 = cfg0.by, b1 = cfg1.by;
+  const int w = c->w, h = c->h, pitch = c->pitch;
+  const BlockMaxOut bm{nullptr, nullptr, 0};
+  const bool small = small_tiles(c);
+  dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, small ? kSmallTileRows : kTileRows), 2);
+  if (packed_blur(c, true)) {
+    if (small) GZ_LAUNCH((k_blur_v_pk<R, 2, PostStore<2>, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
+    else GZ_LAUNCH((k_blur_v_pk<R, 2, PostStore<2>, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
+  } else if (compact_code(c, "GZ_COMPACT_BLUR_V")) {
+    if (small) GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, false, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, bm, t1, b1);
+    else GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, bm, t1, b1);
+  } else {
+    return GZ_E_STATE;   // (callers fall back to two single-plane blurs with the unrolled kernels)
+  }
   KCHK(c);
   return GZ_OK;
 }
@@ -791,7 +833,19 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
     HIPCHK(c, hipEventRecord(c->ev_mask_pre, c->stream));
     HIPCHK(c, hipStreamWaitEvent(other, c->ev_mask_pre, 0));
   }
-  {  // X: sigma r2 = 9.24 ; Y second: sigma r1 = 9.04 -- both radius 20, separate taps
+  // X: sigma r2 = 9.24 ; Y second: sigma r1 = 9.04 -- both radius 20, separate taps: one launch
+  // per pass for the two (GZ_MASK_PAIR=0, or the unrolled column kernels: one blur after the other)
+  static const bool pair_off = getenv("GZ_MASK_PAIR") && atoi(getenv("GZ_MASK_PAIR")) == 0;
+  const bool pair = !pair_off && (packed_blur(c, true) || compact_code(c, "GZ_COMPACT_BLUR_V"));
+  if (pair) {
+    SrcPack<SrcPlain, 2> s; PlanePack<2> t; CPlanePack<2> ct;
+    s.s[0].p = c->diffx; s.s[1].p = c->diffy;
+    t.p[0] = c->tmp[1]; t.p[1] = c->tmp[2];
+    ct.p[0] = c->tmp[1]; ct.p[1] = c->tmp[2];
+    TRY((blur_h_pair<20, SrcPlain>(c, s, t, c->blur[B_MASKX], c->blur[B_MASKY1])));
+    PostStore<2> post; post.out[0] = c->mxb; post.out[1] = c->myb2;
+    TRY((blur_v_pair<20>(c, ct, post, c->blur[B_MASKX], c->blur[B_MASKY1])));
+  } else {
     SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].p = c->diffx; t.p[0] = c->tmp[1]; ct.p[0] = c->tmp[1];
     TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKX])));
@@ -807,7 +861,7 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
     c->stream = here;
     TRY(rc);
   }
-  {
+  if (!pair) {
     SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].p = c->diffy; t.p[0] = c->tmp[2]; ct.p[0] = c->tmp[2];
     TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKY1])));

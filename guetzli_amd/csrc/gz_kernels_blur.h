@@ -78,10 +78,12 @@ struct CPlanePack {
 constexpr int HW = 256;
 constexpr int HH = 4;
 
-template <int R, class Src, int NC>
+// TWO = true (NC == 2): the second plane has its own taps and border scales (taps1, bs1) -- two
+// blurs of different sigma but equal radius in one launch (the mask's radius-20 pair).
+template <int R, class Src, int NC, bool TWO = false>
 __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<NC> dst,
-                                                int w, int h, int pitch, Taps<R> taps,
-                                                BorderScale bs) {
+                                                int w, int h, int pitch, Taps<R> taps0,
+                                                BorderScale bs0, Taps<R> taps1, BorderScale bs1) {
   constexpr int RA = (R + 3) & ~3;      // halo rounded up to whole 16-byte vectors
   constexpr int TP = HW + 2 * RA;       // staged columns (multiple of 4)
   constexpr int OFF = RA - R;
@@ -97,6 +99,8 @@ __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<
       s = src.s[i];
       out = dst.p[i];
     }
+  const Taps<R>& taps = (TWO && c == 1) ? taps1 : taps0;
+  const BorderScale& bs = (TWO && c == 1) ? bs1 : bs0;
   const int x0 = bid.x * HW, y0 = bid.y * HH;
   const int tid = threadIdx.x;
   // Interior tile (no border column, every staged sample inside the image, rows 16-byte
@@ -173,10 +177,10 @@ __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<
 // 0.0f.  Tiles that are not interior take k_blur_h's generic path (8 rows of it).
 constexpr int HP = 8;
 
-template <int R, class Src, int NC>
+template <int R, class Src, int NC, bool TWO = false>
 __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePack<NC> dst,
-                                                   int w, int h, int pitch, Taps<R> taps,
-                                                   BorderScale bs) {
+                                                   int w, int h, int pitch, Taps<R> taps0,
+                                                   BorderScale bs0, Taps<R> taps1, BorderScale bs1) {
   constexpr int RA = (R + 3) & ~3;
   constexpr int TP = HW + 2 * RA;
   constexpr int OFF = RA - R;
@@ -191,6 +195,8 @@ __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePa
       s = src.s[i];
       out = dst.p[i];
     }
+  const Taps<R>& taps = (TWO && c == 1) ? taps1 : taps0;
+  const BorderScale& bs = (TWO && c == 1) ? bs1 : bs0;
   const int x0 = bid.x * HW, y0 = bid.y * HP;
   const int tid = threadIdx.x;
   if (x0 >= RA && x0 + HW + RA <= w && y0 + HP <= h && (pitch & 3) == 0) {
@@ -404,15 +410,22 @@ __global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, i
   if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
 }
 
-template <int R, int NC, class Post, bool BM, int TH = 64>
+// ZCH = true (NC == 2, Post = PostStore<2>, not BM): the two planes are independent blurs with
+// their own taps (taps1 / bs1 for the second); the grid's z index picks the plane, each workgroup
+// does one.
+template <int R, int NC, class Post, bool BM, int TH = 64, bool ZCH = false>
 __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post post, int w, int h,
-                                                int pitch, Taps<R> taps, BorderScale bs,
-                                                BlockMaxOut bm) {
+                                                int pitch, Taps<R> taps0, BorderScale bs0,
+                                                BlockMaxOut bm, Taps<R> taps1, BorderScale bs1) {
   // TH = tile height (64, or 32 for small images: twice the workgroups to fill the chip)
   constexpr int VHt = TH, VPTt = TH / 4;
+  constexpr int NCL = ZCH ? 1 : NC;   // planes per workgroup
+  static_assert(!ZCH || (NC == 2 && !BM), "independent planes: two of them, no block maxima");
   __shared__ __attribute__((aligned(16))) float tile[VHt + 2 * R][VW];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const GzTile bid = gz_xcd_tile();
+  const Taps<R>& taps = (ZCH && bid.z == 1) ? taps1 : taps0;
+  const BorderScale& bs = (ZCH && bid.z == 1) ? bs1 : bs0;
   const int x0 = bid.x * VW, y0 = bid.y * VHt;
   const int x = x0 + tx;
   // staging with one aligned 16-byte load per lane when the tile's columns are all inside
@@ -426,14 +439,14 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
   // GZ_COMPACT_BLUR_V=1.
   // one channel: a row's result goes straight to the Post functor; several channels: the
   // per-channel results wait in LDS until the last channel is done
-  __shared__ float outv[NC > 1 ? NC : 1][NC > 1 ? VHt : 1][VW];
+  __shared__ float outv[NCL > 1 ? NCL : 1][NCL > 1 ? VHt : 1][VW];
   float res[VPTt];
 #pragma unroll 1
-  for (int c = 0; c < NC; ++c) {
+  for (int c = 0; c < NCL; ++c) {
     const float* __restrict__ in = src.p[0];
 #pragma unroll
     for (int k = 1; k < NC; ++k)
-      if (c == k) in = src.p[k];
+      if ((ZCH ? bid.z : c) == k) in = src.p[k];
     if (c > 0) __syncthreads();
     if (vec) {
 #pragma unroll 1
@@ -473,7 +486,10 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
           sum = sum * (y < R ? bs.lo[y] : bs.hi[h - 1 - y]);
         }
       }
-      if (NC > 1) {
+      if constexpr (ZCH) {
+        float* __restrict__ o = bid.z == 1 ? post.out[1] : post.out[0];
+        if (x < w && y < h) o[(size_t)y * pitch + x] = sum;
+      } else if (NC > 1) {
         outv[c][ly][tx] = sum;
       } else if (!BM) {
         float v1[1] = {sum};
@@ -489,11 +505,13 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
     const int ly = tg * VPTt + i;
     const int y = y0 + ly;
     res[i] = 0.0f;
-    if (NC > 1 && x < w && y < h) {
-      float v[NC];
+    if constexpr (!ZCH) {
+      if (NC > 1 && x < w && y < h) {
+        float v[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) v[c] = outv[c][ly][tx];
-      res[i] = post((size_t)y * pitch + x, v);
+        for (int c = 0; c < NC; ++c) v[c] = outv[c][ly][tx];
+        res[i] = post((size_t)y * pitch + x, v);
+      }
     }
   }
   if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
@@ -505,25 +523,31 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
 // multiply and add is one packed instruction on (column x, column x + 1).  Tiles whose output
 // rows are all interior and whose columns are all inside the image take this path, the
 // others the per-output path with border handling (as a loop: it is rarely taken).
-template <int R, int NC, class Post, int TH>
+template <int R, int NC, class Post, int TH, bool ZCH = false>
 __global__ __launch_bounds__(256) void k_blur_v_pk(CPlanePack<NC> src, Post post, int w, int h,
-                                                   int pitch, Taps<R> taps, BorderScale bs) {
+                                                   int pitch, Taps<R> taps0, BorderScale bs0,
+                                                   Taps<R> taps1, BorderScale bs1) {
   constexpr int RPT = TH / 8;    // rows per thread on the packed path
   constexpr int VPTt = TH / 4;   // rows per thread on the generic path
+  constexpr int NCL = ZCH ? 1 : NC;   // planes per workgroup (ZCH: see k_blur_v_compact)
+  static_assert(!ZCH || NC == 2, "independent planes: two of them");
   __shared__ __attribute__((aligned(16))) float tile[TH + 2 * R][VW];
   const int tid = threadIdx.x;
   const int tx = tid & 63, tg = tid >> 6;
   const GzTile bid = gz_xcd_tile();
+  const Taps<R>& taps = (ZCH && bid.z == 1) ? taps1 : taps0;
+  const BorderScale& bs = (ZCH && bid.z == 1) ? bs1 : bs0;
   const int x0 = bid.x * VW, y0 = bid.y * TH;
   const bool vec = x0 + VW <= w && (pitch & 3) == 0;
   const bool inner = vec && y0 >= R && y0 + TH + R <= h;
   const int vq = (tid & 15) * 4, vr = tid >> 4;
   if (inner) {
     const int cp = tid & 31, rg = tid >> 5;
-    gz_f2 acc[NC][RPT];
+    gz_f2 acc[NCL][RPT];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+    for (int c = 0; c < NCL; ++c) {
       const float* __restrict__ in = src.p[c];
+      if constexpr (ZCH) in = bid.z == 1 ? src.p[1] : src.p[0];
       if (c > 0) __syncthreads();
 #pragma unroll
       for (int k = 0; k < (TH + 2 * R + 15) / 16; ++k) {
@@ -549,25 +573,31 @@ __global__ __launch_bounds__(256) void k_blur_v_pk(CPlanePack<NC> src, Post post
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const size_t idx = (size_t)(y0 + rg * RPT + i) * pitch + x0 + 2 * cp;
-      float v0[NC], v1[NC];
+      if constexpr (ZCH) {
+        float* __restrict__ o = bid.z == 1 ? post.out[1] : post.out[0];
+        o[idx] = acc[0][i][0];
+        o[idx + 1] = acc[0][i][1];
+      } else {
+        float v0[NC], v1[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        v0[c] = acc[c][i][0];
-        v1[c] = acc[c][i][1];
+        for (int c = 0; c < NC; ++c) {
+          v0[c] = acc[c][i][0];
+          v1[c] = acc[c][i][1];
+        }
+        (void)post(idx, v0);
+        (void)post(idx + 1, v1);
       }
-      (void)post(idx, v0);
-      (void)post(idx + 1, v1);
     }
     return;
   }
   const int x = x0 + tx;
-  __shared__ float outv[NC > 1 ? NC : 1][NC > 1 ? TH : 1][VW];
+  __shared__ float outv[NCL > 1 ? NCL : 1][NCL > 1 ? TH : 1][VW];
 #pragma unroll 1
-  for (int c = 0; c < NC; ++c) {
+  for (int c = 0; c < NCL; ++c) {
     const float* __restrict__ in = src.p[0];
 #pragma unroll
     for (int k = 1; k < NC; ++k)
-      if (c == k) in = src.p[k];
+      if ((ZCH ? bid.z : c) == k) in = src.p[k];
     if (c > 0) __syncthreads();
     for (int ry = tg; ry < TH + 2 * R; ry += 4) {
       const int y = y0 - R + ry;
@@ -593,7 +623,10 @@ __global__ __launch_bounds__(256) void k_blur_v_pk(CPlanePack<NC> src, Post post
           sum = sum * (y < R ? bs.lo[y] : bs.hi[h - 1 - y]);
         }
       }
-      if (NC > 1) {
+      if constexpr (ZCH) {
+        float* __restrict__ o = bid.z == 1 ? post.out[1] : post.out[0];
+        if (x < w && y < h) o[(size_t)y * pitch + x] = sum;
+      } else if (NC > 1) {
         outv[c][ly][tx] = sum;
       } else {
         float v1[1] = {sum};
@@ -601,7 +634,7 @@ __global__ __launch_bounds__(256) void k_blur_v_pk(CPlanePack<NC> src, Post post
       }
     }
   }
-  if (NC > 1) {
+  if constexpr (NCL > 1) {
 #pragma unroll 1
     for (int i = 0; i < VPTt; ++i) {
       const int ly = tg * VPTt + i;

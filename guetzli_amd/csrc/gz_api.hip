@@ -494,6 +494,7 @@ void set_frame(gz_ctx* c, int factor) {
   c->coff[2] = c->nb + c->nbc;
   c->nblk = c->nb + 2 * c->nbc;
   c->have_search = false;
+  c->order_pending = false;   // a pending gz_order_build_auto_begin belonged to the old frame
 }
 size_t csamp_plane(const gz_ctx* c) {   // bytes of one chroma sample plane of a 4:2:0 frame
   return (size_t)((c->w + 15) / 16 * 8) * (size_t)((c->h + 15) / 16 * 8);
@@ -521,6 +522,13 @@ void alloc_psycho(gz_ctx* c, Psycho* p) {
 // and the single-plane column passes, and lose below that and for the 3-plane column pass
 // and the SameNoise row pass.  GZ_BLUR_PK=0 / 1 forces the scalar / paired kernels everywhere
 // (read per call: the tests switch it).
+// Code-path options of the blur kernels (gz_kernels_blur.h: kOptQuad, kOptRotate), read per
+// call so that the tests can run every path: GZ_BLUR_OPT=<bits> overrides the default.
+static int blur_opt() {
+  const char* e = getenv("GZ_BLUR_OPT");
+  if (e) return atoi(e);
+  return kOptQuad | kOptRotate;
+}
 static bool packed_blur(const gz_ctx* c, bool favourable) {
   const char* e = getenv("GZ_BLUR_PK");
   if (e) return atoi(e) != 0;
@@ -536,7 +544,7 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
   const int w = c->w, h = c->h, pitch = c->pitch;
   if (packed_blur(c, R <= 20)) {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), NC);
-    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs);
+    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs, blur_opt());
     KCHK(c);
     return GZ_OK;
   }
@@ -601,11 +609,11 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
     if (small_tiles(c)) {
       dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
       GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs, bm, tp, bs);
+                pitch, tp, bs, bm, tp, bs, blur_opt());
     } else {
       dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
       GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs, bm, tp, bs);
+                pitch, tp, bs, bm, tp, bs, blur_opt());
     }
     KCHK(c);
     return GZ_OK;
@@ -635,7 +643,7 @@ int blur_h_pair(gz_ctx* c, const SrcPack<Src, 2>& src, const PlanePack<2>& dst, 
   const int w = c->w, h = c->h, pitch = c->pitch;
   if (packed_blur(c, R <= 20)) {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), 2);
-    GZ_LAUNCH((k_blur_h_pk<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1);
+    GZ_LAUNCH((k_blur_h_pk<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1, blur_opt());
   } else {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), 2);
     GZ_LAUNCH((k_blur_h<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1);
@@ -657,8 +665,8 @@ int blur_v_pair(gz_ctx* c, const CPlanePack<2>& src, const PostStore<2>& post, c
     if (small) GZ_LAUNCH((k_blur_v_pk<R, 2, PostStore<2>, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
     else GZ_LAUNCH((k_blur_v_pk<R, 2, PostStore<2>, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
   } else if (compact_code(c, "GZ_COMPACT_BLUR_V")) {
-    if (small) GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, false, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, bm, t1, b1);
-    else GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, bm, t1, b1);
+    if (small) GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, false, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, bm, t1, b1, blur_opt());
+    else GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, bm, t1, b1, blur_opt());
   } else {
     return GZ_E_STATE;   // (callers fall back to two single-plane blurs with the unrolled kernels)
   }
@@ -677,11 +685,11 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
     if (small_tiles(c)) {
       dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
       GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w,
-                h, pitch, tp, bx, by, bm);
+                h, pitch, tp, bx, by, bm, blur_opt());
     } else {
       dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
       GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w,
-                h, pitch, tp, bx, by, bm);
+                h, pitch, tp, bx, by, bm, blur_opt());
     }
     KCHK(c);
     return GZ_OK;
@@ -689,13 +697,13 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   if (!BM && small_tiles(c)) {
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
     GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w,
-              h, pitch, tp, bx, by, bm);
+              h, pitch, tp, bx, by, bm, blur_opt());
     KCHK(c);
     return GZ_OK;
   }
   dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
   GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, kTileRows>), grid, dim3(256), c->stream, src, post, w,
-            h, pitch, tp, bx, by, bm);
+            h, pitch, tp, bx, by, bm, blur_opt());
   KCHK(c);
   return GZ_OK;
 }
@@ -1024,6 +1032,13 @@ int stage_chroma_samples(gz_ctx* c, const int16_t* d_coeffs) {
   return GZ_OK;
 }
 
+// The integer IDCT of k_reconstruct as packed 16-bit dot products (v_dot2c_i32_i16) -- the
+// default -- or as 24-bit multiply-adds (GZ_IDCT_DOT2=0; read per call: the tests run both).
+static bool idct_dot2() {
+  const char* e = getenv("GZ_IDCT_DOT2");
+  return !(e && atoi(e) == 0);
+}
+
 int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* srgb,
                       unsigned* clear_word = nullptr) {
   if (c->cfac == 2) {
@@ -1034,9 +1049,14 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
     KCHK(c);
     return GZ_OK;
   }
-  GZ_LAUNCH(k_reconstruct, dim3(c->bh * gz_div_up(c->bw, kReconBlocks)), dim3(256), c->stream,
-            d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
-            srgb, clear_word);
+  if (idct_dot2())
+    GZ_LAUNCH(k_reconstruct<true>, dim3(c->bh * gz_div_up(c->bw, kReconBlocks)), dim3(256), c->stream,
+              d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
+              srgb, clear_word);
+  else
+    GZ_LAUNCH(k_reconstruct<false>, dim3(c->bh * gz_div_up(c->bw, kReconBlocks)), dim3(256), c->stream,
+              d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
+              srgb, clear_word);
   KCHK(c);
   return GZ_OK;
 }
@@ -1730,6 +1750,7 @@ int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
       (direction != 1 && direction != -1) || (count_below && !below))
     return GZ_E_ARG;
   if (!c->have_search) { c->err = "gz_block_zeroing_orders must precede gz_order_build"; return GZ_E_STATE; }
+  c->order_pending = false;
   const int nb = c->sg_n;
   TRY(ensure_order_block_arrays(c));
   HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
@@ -1939,6 +1960,7 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
 int gz_order_upload(gz_ctx* c, const void* entries, uint64_t n) {
   DeviceScope ds_(c);
   if (!c || (n > 0 && !entries)) return GZ_E_ARG;
+  c->order_pending = false;
   TRY(ensure_order_capacity(c, (size_t)n));
   if (n > 0)
     HIPCHK(c, hipMemcpyAsync(c->d_order, entries, sizeof(OrderEntry) * n, hipMemcpyHostToDevice, c->stream));
@@ -2314,7 +2336,7 @@ int gz_probe_idct_blocks(int device, const int16_t* blocks, int n, uint8_t* out)
   if (hipMalloc((void**)&d_in, (size_t)n * 128) != hipSuccess) return GZ_E_HIP;
   if (hipMalloc((void**)&d_out, (size_t)n * 64) != hipSuccess) { (void)hipFree(d_in); return GZ_E_HIP; }
   if (hipMemcpy(d_in, blocks, (size_t)n * 128, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_in); (void)hipFree(d_out); return GZ_E_HIP; }
-  GZ_LAUNCH(k_idct_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0, d_in, n, d_out);
+  GZ_LAUNCH(k_idct_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0, d_in, n, d_out, idct_dot2() ? 1 : 0);
   int rc = hipGetLastError() == hipSuccess ? GZ_OK : GZ_E_HIP;
   if (hipMemcpy(out, d_out, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
   (void)hipFree(d_in); (void)hipFree(d_out);
@@ -2492,6 +2514,7 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
     else { c->err = "a 4:2:0 frame is searched with component mask 1 or 6"; return GZ_E_ARG; }
   }
   TRY(ensure_block_mask(c));
+  c->order_pending = false;   // a new search grid: a pending order of the old one is void
   const int nb = c->nb;   // capacity of the per-block arrays: the luma grid
   const int gn = mode == 2 ? c->nbc : c->nb;
   c->sg_w = mode == 2 ? c->cbw : c->bw;

@@ -70,6 +70,14 @@ GZ_DEVFN gz_f2 gz_f2_splat(float x) {
   return r;
 }
 
+// Two consecutive floats as one 8-byte store (the index is even).
+#ifdef GZ_EMU
+#define GZ_STG2(p, i, val) (*reinterpret_cast<gz_f2*>((p) + (i)) = (val))
+#else
+#define GZ_STG2(p, i, val) \
+  (*reinterpret_cast<__attribute__((address_space(1))) gz_f2*>((__attribute__((address_space(1))) float*)(p) + (i)) = (val))
+#endif
+
 #ifdef GZ_EMU
 #define GZ_STG(p, i, val) ((p)[i] = (val))
 #else
@@ -82,6 +90,17 @@ GZ_DEVFN gz_f2 gz_f2_splat(float x) {
 #define GZ_WAVE_UNIFORM(x) (x)
 #else
 #define GZ_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
+// A point where the lanes of a wavefront must have executed everything before it (loads
+// before a store to the same LDS row by a neighbouring lane).  On the GPU a wavefront has one
+// instruction stream, so there is nothing to do; the emulation's threads are fibers that run one
+// after the other and yield here (every thread of the workgroup must pass the same number of
+// these points).
+#ifdef GZ_EMU
+#define GZ_WAVE_LOCKSTEP() hipemu::yield()
+#else
+#define GZ_WAVE_LOCKSTEP() ((void)0)
 #endif
 
 // Release / acquire accesses at device scope for flags that workgroups of one launch pass to

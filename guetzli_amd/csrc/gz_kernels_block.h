@@ -32,6 +32,45 @@ GZ_CONST int kIdctM[64] = {
   8192, -11363,  10703,  -9633,   8192,  -6437,   4433,  -2260,
 };
 
+// The same matrix with two 16-bit entries per word, (kIdctM[8*r+2p] | kIdctM[8*r+2p+1] << 16):
+// operand of v_dot2c_i32_i16, which multiplies two pairs of 16-bit integers and adds both
+// products to a 32-bit accumulator in ONE instruction (the entries fit 15 bits, coefficients and
+// the column pass's results are int16 by definition, idct.cc:140,147).  Integer sums modulo
+// 2^32: the same value as eight separate multiply-adds in any order.
+#define GZ_PK16(a, b) ((uint32_t)((a) & 0xffff) | ((uint32_t)((b) & 0xffff) << 16))
+GZ_CONST uint32_t kIdctMP[32] = {
+  GZ_PK16(8192,  11363), GZ_PK16( 10703,   9633), GZ_PK16( 8192,   6437), GZ_PK16(  4433,   2260),
+  GZ_PK16(8192,   9633), GZ_PK16(  4433,  -2259), GZ_PK16(-8192, -11362), GZ_PK16(-10704,  -6436),
+  GZ_PK16(8192,   6437), GZ_PK16( -4433, -11362), GZ_PK16(-8192,   2261), GZ_PK16( 10704,   9633),
+  GZ_PK16(8192,   2260), GZ_PK16(-10703,  -6436), GZ_PK16( 8192,   9633), GZ_PK16( -4433, -11363),
+  GZ_PK16(8192,  -2260), GZ_PK16(-10703,   6436), GZ_PK16( 8192,  -9633), GZ_PK16( -4433,  11363),
+  GZ_PK16(8192,  -6437), GZ_PK16( -4433,  11362), GZ_PK16(-8192,  -2261), GZ_PK16( 10704,  -9633),
+  GZ_PK16(8192,  -9633), GZ_PK16(  4433,   2259), GZ_PK16(-8192,  11362), GZ_PK16(-10704,   6436),
+  GZ_PK16(8192, -11363), GZ_PK16( 10703,  -9633), GZ_PK16( 8192,  -6437), GZ_PK16(  4433,  -2260),
+};
+#ifdef GZ_EMU
+static inline int gz_sdot2(uint32_t a, uint32_t b, int c) {
+  const unsigned p0 = (unsigned)((int)(short)(a & 0xffff) * (int)(short)(b & 0xffff));
+  const unsigned p1 = (unsigned)((int)(short)(a >> 16) * (int)(short)(b >> 16));
+  return (int)((unsigned)c + p0 + p1);
+}
+#else
+typedef short gz_s2 __attribute__((ext_vector_type(2)));
+GZ_DEVFN int gz_sdot2(uint32_t a, uint32_t b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(gz_s2, a), __builtin_bit_cast(gz_s2, b), c, false);
+}
+#endif
+struct alignas(16) gz_u4 {
+  uint32_t v[4];
+};
+// sum_{u<8} M[row][u] * x[u] for 8 int16 values x packed in q (two per word)
+GZ_DEVFN int idct_dot8(const gz_u4& m, const gz_u4& q) {
+  int acc = gz_sdot2(m.v[0], q.v[0], 0);
+  acc = gz_sdot2(m.v[1], q.v[1], acc);
+  acc = gz_sdot2(m.v[2], q.v[2], acc);
+  return gz_sdot2(m.v[3], q.v[3], acc);
+}
+
 // fdct.cc:29-36, indexed by row class {0/4, 1/7, 2/6, 3/5}.
 GZ_CONST short kFdctRowTab[4][8] = {
   {22725, 21407, 19266, 16384, 12873,  8867, 4520, 0},
@@ -56,6 +95,14 @@ GZ_DEVFN int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 // TB/s; tools/ubench/bw.hip: 3.3 TB/s for dword accesses against 5.0 for 16-byte ones.)
 constexpr int kReconBlocks = 8;   // blocks per workgroup (grid = bh * ceil(bw / 8))
 
+// libjpeg YCbCr->RGB (color_transform.h; tables == these formulas, tools/gen_tables.py)
+GZ_DEVFN void ycc_to_rgb(int yy, int pcb, int pcr, int* r, int* g, int* b) {
+  const int cb = pcb - 128, cr = pcr - 128, half = 1 << 15;
+  *r = clamp255(yy + ((GZ_MUL24(91881, cr) + half) >> 16));
+  *g = clamp255(yy + ((GZ_MUL24(-46802, cr) + (GZ_MUL24(-22554, cb) + half)) >> 16));
+  *b = clamp255(yy + ((GZ_MUL24(116130, cb) + half) >> 16));
+}
+
 GZ_DEVFN void idct3_to_rgb(const int (*s_in)[64], int (*s_col)[64], int lane, int* r, int* g, int* b) {
   const int iy = lane >> 3, ix = lane & 7;
   int px[3];
@@ -68,21 +115,24 @@ GZ_DEVFN void idct3_to_rgb(const int (*s_in)[64], int (*s_col)[64], int lane, in
     px[c] = clamp255((acc + (257 << 17)) >> 18);
   }
   (void)s_in;
-  // libjpeg YCbCr->RGB (color_transform.h; tables == these formulas, tools/gen_tables.py)
-  const int yy = px[0], cb = px[1] - 128, cr = px[2] - 128, half = 1 << 15;
-  *r = clamp255(yy + ((GZ_MUL24(91881, cr) + half) >> 16));
-  *g = clamp255(yy + ((GZ_MUL24(-46802, cr) + (GZ_MUL24(-22554, cb) + half)) >> 16));
-  *b = clamp255(yy + ((GZ_MUL24(116130, cb) + half) >> 16));
+  ycc_to_rgb(px[0], px[1], px[2], r, g, b);
 }
 
+// DOT2: both passes as four v_dot2c_i32_i16 per output instead of eight multiply-adds, the
+// coefficients kept as int16 in LDS -- transposed by the staging store, so that the eight values
+// a lane needs (a column of the block, then a row of the column pass's results) are one
+// 16-byte read instead of eight dword reads.
+template <bool DOT2>
 __global__ __launch_bounds__(256) void k_reconstruct(
     const int16_t* __restrict__ coeffs, int w, int h, int bw, int nb, int pitch,
     size_t pstride, const float* __restrict__ srgb_lut, float* __restrict__ lin,
     uint8_t* __restrict__ srgb, unsigned* __restrict__ clear_word) {
   // first kernel of a Compare: also resets the distance accumulator of its last kernel
   if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
-  __shared__ int s_in[kReconBlocks][3][64];
-  __shared__ int s_col[kReconBlocks][3][64];
+  __shared__ __attribute__((aligned(16))) int s_in[DOT2 ? 1 : kReconBlocks][3][64];
+  __shared__ __attribute__((aligned(16))) int s_col[DOT2 ? 1 : kReconBlocks][3][64];
+  __shared__ __attribute__((aligned(16))) short s_in16[DOT2 ? kReconBlocks : 1][3][64];    // [ix][u]
+  __shared__ __attribute__((aligned(16))) short s_col16[DOT2 ? kReconBlocks : 1][3][64];   // [iy][u]
   __shared__ __attribute__((aligned(16))) float s_px[3][8][kReconBlocks * 8];   // [plane][row][x]
   __shared__ uint8_t s_u8[8][kReconBlocks * 8][3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -96,20 +146,33 @@ __global__ __launch_bounds__(256) void k_reconstruct(
     const bool live = bx < bw;
     const size_t blk = (size_t)by * bw + bx;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      s_in[j][c][lane] = live ? (int)coeffs[((size_t)c * nb + blk) * 64 + lane] : 0;
+    for (int c = 0; c < 3; ++c) {
+      const int16_t v = live ? coeffs[((size_t)c * nb + blk) * 64 + lane] : (int16_t)0;
+      if (DOT2) s_in16[j][c][8 * ix + iy] = v;   // lane = 8 * (row u) + column: transposed
+      else s_in[j][c][lane] = (int)v;
+    }
   }
   __syncthreads();
+  gz_u4 m_row, m_col;   // rows iy / ix of the matrix, packed
+  if (DOT2) {
+    m_row = *reinterpret_cast<const gz_u4*>(&kIdctMP[4 * iy]);
+    m_col = *reinterpret_cast<const gz_u4*>(&kIdctMP[4 * ix]);
+  }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int j = 2 * wave + k;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
-      int acc = 0;
+      if (DOT2) {
+        const gz_u4 q = *reinterpret_cast<const gz_u4*>(&s_in16[j][c][8 * ix]);
+        s_col16[j][c][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
+      } else {
+        int acc = 0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[j][c][8 * u + ix]);
-      s_col[j][c][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+        for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[j][c][8 * u + ix]);
+        s_col[j][c][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+      }
     }
   }
   __syncthreads();
@@ -117,7 +180,18 @@ __global__ __launch_bounds__(256) void k_reconstruct(
   for (int k = 0; k < 2; ++k) {
     const int j = 2 * wave + k;
     int r, g, b;
-    idct3_to_rgb(s_in[j], s_col[j], lane, &r, &g, &b);
+    if (DOT2) {
+      int px[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // row pass (idct.cc:150-160): out = clamp((sum + (257 << 17)) >> 18)
+        const gz_u4 q = *reinterpret_cast<const gz_u4*>(&s_col16[j][c][8 * iy]);
+        px[c] = clamp255((idct_dot8(m_col, q) + (257 << 17)) >> 18);
+      }
+      ycc_to_rgb(px[0], px[1], px[2], &r, &g, &b);
+    } else {
+      idct3_to_rgb(s_in[j], s_col[j], lane, &r, &g, &b);
+    }
     const int x = 8 * j + ix;
     if (lin) {
       s_px[0][iy][x] = srgb_lut[r];
@@ -162,15 +236,28 @@ __global__ __launch_bounds__(256) void k_reconstruct(
 
 // Bare-block IDCT probe (gz_probe_idct_blocks).
 __global__ __launch_bounds__(256) void k_idct_blocks(const int16_t* __restrict__ blocks,
-                                                     int n, uint8_t* __restrict__ out) {
+                                                     int n, uint8_t* __restrict__ out, int dot2) {
   __shared__ int s_in[kBlocksPerWG][64];
   __shared__ int s_col[kBlocksPerWG][64];
+  __shared__ __attribute__((aligned(16))) short s_in16[kBlocksPerWG][64];
+  __shared__ __attribute__((aligned(16))) short s_col16[kBlocksPerWG][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blk = blockIdx.x * kBlocksPerWG + wave;
   const bool live = blk < n;
   const int iy = lane >> 3, ix = lane & 7;
   s_in[wave][lane] = live ? (int)blocks[(size_t)blk * 64 + lane] : 0;
+  s_in16[wave][8 * ix + iy] = live ? blocks[(size_t)blk * 64 + lane] : (int16_t)0;
   __syncthreads();
+  if (dot2) {   // the arithmetic of k_reconstruct<true>
+    const gz_u4 m_row = *reinterpret_cast<const gz_u4*>(&kIdctMP[4 * iy]);
+    const gz_u4 m_col = *reinterpret_cast<const gz_u4*>(&kIdctMP[4 * ix]);
+    const gz_u4 q = *reinterpret_cast<const gz_u4*>(&s_in16[wave][8 * ix]);
+    s_col16[wave][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
+    __syncthreads();
+    const gz_u4 q2 = *reinterpret_cast<const gz_u4*>(&s_col16[wave][8 * iy]);
+    if (live) out[(size_t)blk * 64 + lane] = (uint8_t)clamp255((idct_dot8(m_col, q2) + (257 << 17)) >> 18);
+    return;
+  }
   int acc = 0;
   for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[wave][8 * u + ix]);
   s_col[wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);

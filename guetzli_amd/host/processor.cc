@@ -926,12 +926,14 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   const int try_420 = (input_is_420 || params_.force_420 || (params_.try_420 && !grey)) ? 1 : 0;
   const int force_420 = (input_is_420 || params_.force_420) ? 1 : 0;
   for (int downsample = force_420; downsample <= try_420; ++downsample) {
-    jpg_ncomp_ = 3;
+    // SaveToJpegData writes ONE component when both chroma components are all zero
+    // (output_image.cc:357) -- whatever the frame: an RGB / 4:4:4 input whose chroma is zero
+    // (Downsample does nothing, :305-308) and a 4:2:0 JPEG input with zero chroma alike.  The
+    // round then runs with ymul = 1.0, without the chroma search and with one AC histogram.
+    jpg_ncomp_ = (downsample && grey) ? 1 : 3;
     mirror_valid_ = false;   // img_ follows the device image from SetImageFromQuantization(best_q) on
     if (downsample && fac_ == 1) {   // DownsampleImage (:97-104) + SaveToJpegData
-      if (grey) {
-        jpg_ncomp_ = 1;   // Downsample does nothing (output_image.cc:305-308); one component is saved
-      } else {
+      if (!grey) {
         Stopwatch dw;
         if (params_.use_silver_screen) {
           // output_image.cc:309-318: ToSRGB() of the unquantised image -> RGBToYUV420 (host:

@@ -82,6 +82,15 @@ def test_device_ranking_is_std_sort(L, tmp_path):
     assert "device == std::sort" in out.stdout
 
 
+def test_idct_multiply_add_variant(L, monkeypatch):
+    """k_reconstruct / the IDCT probe run the packed 16-bit dot products (v_dot2c_i32_i16) by
+    default; GZ_IDCT_DOT2=0 selects the 24-bit multiply-add form: same integers, extreme
+    (+-32767) blocks included."""
+    monkeypatch.setenv("GZ_IDCT_DOT2", "0")
+    pc.case_block_kernels(L, n=4000)
+    pc.case_encode_quantize_reconstruct(L, 61, 43, x0=100, y0=50)
+
+
 def test_dct_double(L):
     pc.case_dct_double(L, n=20000)
 
@@ -143,6 +152,21 @@ def test_unrolled_code_variants(L, monkeypatch):
     pc.case_compare(L, 444, 258, qscales=(6,))
     monkeypatch.setenv("GZ_TILE_ROWS", "32")
     pc.case_stages(L, 256, 192, x0=0, y0=0)
+
+
+@pytest.mark.parametrize("opt", [0, 1, 2])
+def test_blur_code_path_options(L, monkeypatch, opt):
+    """GZ_BLUR_OPT: the epilogue by quads (bit 0) and the conflict-free lane mappings of the row
+    passes (bit 1) are both on by default; every other combination -- the round-2 code paths --
+    gives the same bits, scalar and paired passes, 16- and 32-row tiles."""
+    monkeypatch.setenv("GZ_BLUR_OPT", str(opt))
+    pc.case_blur(L, 444, 258)
+    pc.case_stages(L, 256, 192, x0=0, y0=0)
+    monkeypatch.setenv("GZ_TILE_ROWS", "32")
+    pc.case_compare(L, 444, 258, qscales=(6,))
+    monkeypatch.setenv("GZ_BLUR_PK", "1")
+    pc.case_blur(L, 1100, 300)
+    pc.case_stages(L, 440, 250, x0=0, y0=0)
 
 
 @pytest.mark.parametrize("wh", [(256, 192), (72, 48), (35, 41), (444, 258)])

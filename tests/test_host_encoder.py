@@ -206,13 +206,21 @@ def test_grey_image_matches_reference_in_emulation(host_emu, case):
     (41, 35, dict(quality=98, subsampling=2, progressive=True, comment=b"hi"), False, dict()),
     (24, 40, dict(quality=95, subsampling=2), True, dict()),          # too small for butteraugli
     (40, 32, dict(quality=97, subsampling=0), True, dict(try_420=True)),   # 4:4:4 input, both modes
+    # r = g = b content in a 3-component 4:2:0 file: chroma all zero -> SaveToJpegData writes one
+    # component although the frame stays 4:2:0 (ymul 1.0, no chroma search, one AC histogram)
+    (48, 40, dict(quality=97, subsampling=2, grey=True), True, dict()),
+    (41, 35, dict(quality=96, subsampling=2, grey=True), False, dict()),
 ])
 def test_jpeg_420_input_matches_reference_in_emulation(host_emu, case, monkeypatch):
     """YUV 4:2:0 JPEG input (processor.cc:811-815,847-849): decoded with the 2x2 pixel model,
     the original written from the input's own (padded) blocks, then the 4:2:0 search."""
     w, h, kw, clear, params = case
     monkeypatch.setenv("GZ_VERIFY_ENTROPY", "1")
-    data = _pil_jpeg(images.crop(w, h, 100, 60), **kw) + (b"" if clear else b"tail!")
+    kw = dict(kw)
+    rgb = images.crop(w, h, 100, 60)
+    if kw.pop("grey", False):
+        rgb = np.repeat(rgb[:, :, 1:2], 3, axis=2).copy()
+    data = _pil_jpeg(rgb, **kw) + (b"" if clear else b"tail!")
     target = ref._butteraugli_score_for_quality(95.0)
     exp_jpg, exp_trace = ref.process_params(data, target, clear_metadata=clear, want_trace=True, **params)
     assert exp_jpg is not None

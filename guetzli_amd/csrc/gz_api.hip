@@ -420,6 +420,10 @@ struct gz_ctx {
   struct OrderPending { unsigned long long total; unsigned counters[2]; };
   OrderPending* h_order_pending = nullptr;
   bool order_pending = false;
+  // quick-select descent decided on the device (gz_order_descend*): per-level ranges and pivots,
+  // the ranges' pinned copy for the host's replay
+  DescState* d_desc_st = nullptr; DescPivot* d_desc_pv = nullptr; DescState* h_desc = nullptr;
+  unsigned desc_epoch = 0; int desc_levels = 0; bool desc_pending = false;
   unsigned* d_order_nb = nullptr;                                 // [nb]
   unsigned long long* d_order_off = nullptr;                      // [nb+1]
   unsigned* d_order_counters = nullptr;                           // [2]
@@ -834,7 +838,7 @@ int stage_separate(gz_ctx* c, Psycho* ps) {
 // queued there (the SameNoise blur, the shorter of the two side branches) instead of between
 // the two radius-20 blurs of this stream.
 int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullptr) {
-  dim3 grid(gz_div_up(c->w, 1024), c->h, 2);
+  dim3 grid(gz_div_up(c->w, 1024), gz_div_up(c->h, kMaskRows), 2);
   GZ_LAUNCH(k_mask_pre, grid, dim3(256), c->stream, pk, c->w, c->h, c->pitch);
   KCHK(c);
   if (other) {
@@ -981,7 +985,7 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.w_0lt1 = (wmul1 / hf_asymmetry_) * 0.8;
     a.out = c->dsq;
     for (int i = 0; i < 3; ++i) a.mask_out[i] = a.mask_dc_out[i] = nullptr;
-    dim3 grid(gz_div_up(c->w, 256), c->h);
+    dim3 grid(gz_div_up(c->w, 1024), c->h);   // (4 pixels per thread)
     GZ_LAUNCH(k_combine, grid, dim3(256), c->stream, a, c->w, c->h, c->pitch);
     KCHK(c);
   }
@@ -1118,7 +1122,7 @@ int ensure_block_mask(gz_ctx* c) {
   ca.mask_x_blur = c->mxb; ca.mask_y_blur1 = c->myb1; ca.mask_y_blur2 = c->myb2;
   ca.luts = c->d_mask_luts;
   for (int i = 0; i < 3; ++i) { ca.mask_out[i] = c->mask_out[i]; ca.mask_dc_out[i] = nullptr; }
-  GZ_LAUNCH(k_combine, grid, dim3(256), c->stream, ca, c->w, c->h, c->pitch);
+  GZ_LAUNCH(k_combine, dim3(gz_div_up(c->w, 1024), c->h), dim3(256), c->stream, ca, c->w, c->h, c->pitch);   // (4 pixels per thread)
   KCHK(c);
   GZ_LAUNCH(k_gather_block_corners, dim3(gz_div_up(c->nb, 256)), dim3(256), c->stream,
             (const float*)c->mask_out[0], (const float*)c->mask_out[1],
@@ -1199,7 +1203,7 @@ void rank_all(const int16_t* coeffs, const int16_t* orig, int nb, int new_model,
 // ===================================================================== C surface ======
 extern "C" {
 
-int gz_abi_version(void) { return 2; }
+int gz_abi_version(void) { return 3; }
 
 int gz_trim_pool(void) {
   {
@@ -1377,6 +1381,8 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->d_order); (void)pool_free(c->d_pos_l); (void)pool_free(c->d_pos_r); (void)pool_free(c->d_chunk);
   (void)pool_free(c->d_part); (void)pool_free(c->d_order_nb); (void)pool_free(c->d_order_off);
   if (c->h_order_pending) (void)pool_host_free(c->h_order_pending);
+  if (c->h_desc) (void)pool_host_free(c->h_desc);
+  (void)pool_free(c->d_desc_st); (void)pool_free(c->d_desc_pv);
   (void)pool_free(c->d_order_counters); (void)pool_free(c->d_next_cand); (void)pool_free(c->d_weight);
   (void)pool_free(c->d_max_err); (void)pool_free(c->d_wflag); (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
   for (int b = 0; b < B_COUNT; ++b) (void)pool_free(c->blur[b].d_scale);
@@ -1677,9 +1683,11 @@ static int ensure_order_capacity(gz_ctx* c, size_t n) {
   c->order_cap = 0;
   const size_t cap = n + n / 8 + 4096;
   HIPCHK(c, pool_malloc((void**)&c->d_order, sizeof(OrderEntry) * cap));
-  HIPCHK(c, pool_malloc((void**)&c->d_pos_l, sizeof(unsigned) * (cap / 2 + 1)));
-  HIPCHK(c, pool_malloc((void**)&c->d_pos_r, sizeof(unsigned) * (cap / 2 + 1)));
   c->chunk_cap = cap / kPartChunk + 2;
+  // (gz_order_partition records at most cap / 2 swapped pairs per side; the descent's per-chunk
+  // stopper lists need a full chunk's worth per chunk)
+  HIPCHK(c, pool_malloc((void**)&c->d_pos_l, sizeof(unsigned) * c->chunk_cap * kPartChunk));
+  HIPCHK(c, pool_malloc((void**)&c->d_pos_r, sizeof(unsigned) * c->chunk_cap * kPartChunk));
   HIPCHK(c, pool_malloc((void**)&c->d_chunk, sizeof(unsigned) * 4 * c->chunk_cap));
   c->order_cap = cap;
   return GZ_OK;
@@ -1813,6 +1821,7 @@ int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double tar
       max_block_dist < 0 || (count_below && !below))
     return GZ_E_ARG;
   c->order_pending = false;
+  c->desc_pending = false;
   TRY(order_auto_enqueue(c, direction, max_block_dist, target_mul, use_distmap, next_cand));
   return order_build_device(c, direction, count_below, limit, total, blocks_to_change, below, true);
 }
@@ -1822,6 +1831,7 @@ int gz_order_build_auto_begin(gz_ctx* c, int direction, int max_block_dist, doub
   DeviceScope ds_(c);
   if (!c || !next_cand || (direction != 1 && direction != -1) || max_block_dist < 0) return GZ_E_ARG;
   c->order_pending = false;
+  c->desc_pending = false;
   TRY(order_auto_enqueue(c, direction, max_block_dist, target_mul, use_distmap, next_cand));
   TRY(order_build_enqueue(c, direction, count_below, limit, true));
   if (!c->h_order_pending) HIPCHK(c, pool_host_malloc((void**)&c->h_order_pending, sizeof(*c->h_order_pending)));
@@ -2030,6 +2040,98 @@ int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
   return GZ_OK;
 }
 
+
+// ---- quick-select descent decided on the device (gz_kernels_order.h: k_desc_count / k_desc_swap)
+static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, float per_block,
+                           uint64_t threshold, int max_levels, size_t n_bound) {
+  if (!c->d_desc_st) {
+    HIPCHK(c, pool_malloc((void**)&c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 1)));
+    HIPCHK(c, pool_malloc((void**)&c->d_desc_pv, sizeof(DescPivot) * kDescMaxLevels));
+    HIPCHK(c, pool_host_malloc((void**)&c->h_desc, sizeof(DescState) * (kDescMaxLevels + 1)));
+    HIPCHK(c, hipMemsetAsync(c->d_desc_st, 0, sizeof(DescState) * (kDescMaxLevels + 1), c->stream));
+    c->desc_epoch = 0;
+  }
+  if (++c->desc_epoch == 0) c->desc_epoch = 1;
+  int levels = std::max(0, std::min(max_levels, kDescMaxLevels));
+  const size_t nchunks = std::max<size_t>(1, (n_bound + kPartChunk - 1) / kPartChunk);
+  if (nchunks > (size_t)kDescMaxChunks || nchunks > c->chunk_cap) levels = 0;   // the host drives these
+  DescArgs A;
+  A.a = c->d_order;
+  A.st = c->d_desc_st;
+  A.pv = c->d_desc_pv;
+  A.cnt_l = c->d_chunk;
+  A.cnt_r = c->d_chunk + c->chunk_cap;
+  A.lpos = c->d_pos_l;
+  A.rpos = c->d_pos_r;
+  A.epoch = c->desc_epoch;
+  A.threshold = threshold < 16 ? 16 : threshold;
+  A.derive = derive;
+  A.n0 = n0;
+  A.last0 = last0;
+  A.total = c->d_order_off ? c->d_order_off + c->sg_n : nullptr;
+  A.counters = c->d_order_counters;
+  A.per_block = per_block;
+  const int swap_groups = (int)((n_bound + 1 + kPartChunk - 1) / kPartChunk);
+  for (int l = 0; l < levels; ++l) {
+    GZ_LAUNCH(k_desc_count, dim3((unsigned)nchunks), dim3(256), c->stream, A, l);
+    KCHK(c);
+    GZ_LAUNCH(k_desc_swap, dim3((unsigned)swap_groups), dim3(256), c->stream, A, l);
+    KCHK(c);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 1),
+                           hipMemcpyDeviceToHost, c->stream));
+  c->desc_levels = levels;
+  c->desc_pending = true;
+  return GZ_OK;
+}
+
+static int descend_collect(gz_ctx* c, uint64_t* log, int cap_levels, int* levels) {
+  int n = 0;
+  for (int l = 0; l < c->desc_levels && n < cap_levels; ++l) {
+    const DescState& before = c->h_desc[l];
+    const DescState& after = c->h_desc[l + 1];
+    if (after.epoch != c->desc_epoch || before.epoch != c->desc_epoch) break;
+    if (!(after.cut > before.lo && after.cut <= before.hi)) { c->err = "descent: cut outside its range"; return GZ_E_STATE; }
+    log[3 * n + 0] = before.lo;
+    log[3 * n + 1] = before.hi;
+    log[3 * n + 2] = after.cut;
+    ++n;
+  }
+  *levels = n;
+  return GZ_OK;
+}
+
+int gz_order_descend(gz_ctx* c, uint64_t last, uint64_t threshold, int max_levels, uint64_t* log,
+                     int* levels) {
+  DeviceScope ds_(c);
+  if (!c || !log || !levels || max_levels < 0) return GZ_E_ARG;
+  *levels = 0;
+  if (c->order_n == 0 || last >= c->order_n) return c->order_n == 0 ? GZ_OK : GZ_E_ARG;
+  TRY(descend_enqueue(c, 0, c->order_n, last, 0.0f, threshold, max_levels, c->order_n));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->desc_pending = false;
+  return descend_collect(c, log, max_levels, levels);
+}
+
+int gz_order_descend_begin(gz_ctx* c, float per_block, uint64_t threshold, int max_levels) {
+  DeviceScope ds_(c);
+  if (!c || max_levels < 0) return GZ_E_ARG;
+  if (!c->order_pending) { c->err = "gz_order_build_auto_begin must precede gz_order_descend_begin"; return GZ_E_STATE; }
+  return descend_enqueue(c, 1, 0, 0, per_block, threshold, max_levels, std::max<size_t>(c->search_total, 1));
+}
+
+int gz_order_descend_end(gz_ctx* c, uint64_t* log, int cap_levels, int* levels, uint64_t* last) {
+  DeviceScope ds_(c);
+  if (!c || !log || !levels || !last || cap_levels < 0) return GZ_E_ARG;
+  *levels = 0;
+  *last = 0;
+  if (!c->desc_pending) return GZ_OK;   // nothing was enqueued (or another build took its place)
+  if (c->order_pending) { c->err = "gz_order_build_auto_end must precede gz_order_descend_end"; return GZ_E_STATE; }
+  c->desc_pending = false;
+  TRY(descend_collect(c, log, cap_levels, levels));
+  if (*levels > 0) *last = c->h_desc[0].last;
+  return GZ_OK;
+}
 
 // ------------------------------------------------------------- device entropy coder ----
 static int ensure_entropy_buffers(gz_ctx* c) {
@@ -2309,7 +2411,7 @@ int gz_probe_mask(gz_ctx* c, const float* xyb0, const float* xyb1, float* mask3,
   ca.luts = c->d_mask_luts;
   ca.out = nullptr;
   for (int i = 0; i < 3; ++i) { ca.mask_out[i] = c->mask_out[i]; ca.mask_dc_out[i] = c->mask_dc_out[i]; }
-  dim3 grid(gz_div_up(c->w, 256), c->h);
+  dim3 grid(gz_div_up(c->w, 1024), c->h);   // (4 pixels per thread)
   GZ_LAUNCH(k_combine, grid, dim3(256), c->stream, ca, c->w, c->h, c->pitch);
   KCHK(c);
   const size_t n = (size_t)c->w * c->h;

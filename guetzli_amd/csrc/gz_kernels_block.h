@@ -63,6 +63,16 @@ GZ_DEVFN int gz_sdot2(uint32_t a, uint32_t b, int c) {
 struct alignas(16) gz_u4 {
   uint32_t v[4];
 };
+// 16 bytes of packed int16 from LDS / constant memory (16-byte aligned)
+GZ_DEVFN gz_u4 gz_load_u4(const void* p) {
+#ifdef GZ_EMU
+  gz_u4 r;
+  __builtin_memcpy(&r, p, sizeof(r));
+  return r;
+#else
+  return *reinterpret_cast<const gz_u4*>(p);
+#endif
+}
 // sum_{u<8} M[row][u] * x[u] for 8 int16 values x packed in q (two per word)
 GZ_DEVFN int idct_dot8(const gz_u4& m, const gz_u4& q) {
   int acc = gz_sdot2(m.v[0], q.v[0], 0);
@@ -155,8 +165,8 @@ __global__ __launch_bounds__(256) void k_reconstruct(
   __syncthreads();
   gz_u4 m_row, m_col;   // rows iy / ix of the matrix, packed
   if (DOT2) {
-    m_row = *reinterpret_cast<const gz_u4*>(&kIdctMP[4 * iy]);
-    m_col = *reinterpret_cast<const gz_u4*>(&kIdctMP[4 * ix]);
+    m_row = gz_load_u4(&kIdctMP[4 * iy]);
+    m_col = gz_load_u4(&kIdctMP[4 * ix]);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(
     for (int c = 0; c < 3; ++c) {
       // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
       if (DOT2) {
-        const gz_u4 q = *reinterpret_cast<const gz_u4*>(&s_in16[j][c][8 * ix]);
+        const gz_u4 q = gz_load_u4(&s_in16[j][c][8 * ix]);
         s_col16[j][c][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
       } else {
         int acc = 0;
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         // row pass (idct.cc:150-160): out = clamp((sum + (257 << 17)) >> 18)
-        const gz_u4 q = *reinterpret_cast<const gz_u4*>(&s_col16[j][c][8 * iy]);
+        const gz_u4 q = gz_load_u4(&s_col16[j][c][8 * iy]);
         px[c] = clamp255((idct_dot8(m_col, q) + (257 << 17)) >> 18);
       }
       ycc_to_rgb(px[0], px[1], px[2], &r, &g, &b);
@@ -249,12 +259,12 @@ __global__ __launch_bounds__(256) void k_idct_blocks(const int16_t* __restrict__
   s_in16[wave][8 * ix + iy] = live ? blocks[(size_t)blk * 64 + lane] : (int16_t)0;
   __syncthreads();
   if (dot2) {   // the arithmetic of k_reconstruct<true>
-    const gz_u4 m_row = *reinterpret_cast<const gz_u4*>(&kIdctMP[4 * iy]);
-    const gz_u4 m_col = *reinterpret_cast<const gz_u4*>(&kIdctMP[4 * ix]);
-    const gz_u4 q = *reinterpret_cast<const gz_u4*>(&s_in16[wave][8 * ix]);
+    const gz_u4 m_row = gz_load_u4(&kIdctMP[4 * iy]);
+    const gz_u4 m_col = gz_load_u4(&kIdctMP[4 * ix]);
+    const gz_u4 q = gz_load_u4(&s_in16[wave][8 * ix]);
     s_col16[wave][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
     __syncthreads();
-    const gz_u4 q2 = *reinterpret_cast<const gz_u4*>(&s_col16[wave][8 * iy]);
+    const gz_u4 q2 = gz_load_u4(&s_col16[wave][8 * iy]);
     if (live) out[(size_t)blk * 64 + lane] = (uint8_t)clamp255((idct_dot8(m_col, q2) + (257 << 17)) >> 18);
     return;
   }

@@ -43,40 +43,75 @@ struct MaskPrePack {
   float* out[2];
 };
 
-// grid = (ceil(w/1024), h, 2): a thread takes 4 consecutive pixels of a row -- 16-byte
-// loads of the row and of the row below, one 16-byte store -- when the row pitch allows it.
+// grid = (ceil(w/1024), ceil(h/kMaskRows), 2): a thread takes 4 consecutive pixels of a row
+// (16-byte accesses when the row pitch allows it) and walks down kMaskRows rows, keeping the row
+// below -- which every output needs -- in registers as the next row's own samples: the inputs
+// are read 1 + 1/kMaskRows times instead of twice (round 2 took one row per workgroup; its 84 us
+// at 4K were 14 plane passes through the L2 for 8 of compulsory traffic).
+constexpr int kMaskRows = 8;
+
+struct MaskRow4 {   // 4 consecutive mixed samples of one image's row + the sample right of them
+  gz_f4 v;
+  float r;
+};
+GZ_DEVFN MaskRow4 mask_row4(const MaskIn& in, size_t row, int x, int xr) {
+  MaskRow4 o;
+  o.v = in.load4(row + x);
+  o.r = in(row + xr);
+  return o;
+}
+
 __global__ __launch_bounds__(256) void k_mask_pre(MaskPrePack pk, int w, int h, int pitch) {
-  // rows in XCD-aware order: row y + 1 (read by this row's workgroups and by the next row's)
-  // then comes from the same L2
+  // bands in XCD-aware order: the row below a band's last row (read by this band and by the
+  // next one) then comes from the same L2
   const GzTile bid = gz_xcd_tile();
-  const int x = (bid.x * (int)blockDim.x + (int)threadIdx.x) * 4, y = bid.y;
-  if (x >= w || y >= h) return;
+  const int x = (bid.x * (int)blockDim.x + (int)threadIdx.x) * 4, y0 = bid.y * kMaskRows;
+  if (x >= w || y0 >= h) return;
   const int c = bid.z;
   MaskIn a = pk.in0[0], b = pk.in1[0];
   float* out = pk.out[0];
   if (c == 1) { a = pk.in0[1]; b = pk.in1[1]; out = pk.out[1]; }
-  // mirrored neighbour at the last column / row (butteraugli.cc:1706-1725)
-  const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
   if ((pitch & 3) == 0 && x + 3 < w) {
-    const size_t i = (size_t)y * pitch + x, id = (size_t)y2 * pitch + x;
-    const gz_f4 a0 = a.load4(i), ad = a.load4(id), b0 = b.load4(i), bd = b.load4(id);
     // right neighbour of the 4th pixel: the next column, or mirrored at the last column
+    // (butteraugli.cc:1706-1725); the neighbour below: the next row, mirrored at the last row
     const int xr = x + 4 < w ? x + 4 : x + 2;
-    const float ar = a((size_t)y * pitch + xr), br = b((size_t)y * pitch + xr);
-    gz_f4 o;
+    MaskRow4 a0 = mask_row4(a, (size_t)y0 * pitch, x, xr), b0 = mask_row4(b, (size_t)y0 * pitch, x, xr);
+    MaskRow4 ap = a0, bp = b0;   // the row above (for the mirrored last row)
+#pragma unroll 1
+    for (int r = 0; r < kMaskRows; ++r) {
+      const int y = y0 + r;
+      if (y >= h) break;
+      MaskRow4 ad, bd;
+      if (y + 1 < h) {
+        ad = mask_row4(a, (size_t)(y + 1) * pitch, x, xr);
+        bd = mask_row4(b, (size_t)(y + 1) * pitch, x, xr);
+      } else if (y > 0) {
+        if (r > 0) { ad = ap; bd = bp; }
+        else { ad = mask_row4(a, (size_t)(y - 1) * pitch, x, xr); bd = mask_row4(b, (size_t)(y - 1) * pitch, x, xr); }
+      } else {
+        ad = a0; bd = b0;
+      }
+      gz_f4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      o.v[k] = diff_precompute_px(a0.v[k], k < 3 ? a0.v[k < 3 ? k + 1 : 3] : ar, ad.v[k], b0.v[k],
-                                  k < 3 ? b0.v[k < 3 ? k + 1 : 3] : br, bd.v[k]);
-    GZ_STG4(out, i, o);
+      for (int k = 0; k < 4; ++k)
+        o.v[k] = diff_precompute_px(a0.v.v[k], k < 3 ? a0.v.v[k < 3 ? k + 1 : 3] : a0.r, ad.v.v[k],
+                                    b0.v.v[k], k < 3 ? b0.v.v[k < 3 ? k + 1 : 3] : b0.r, bd.v.v[k]);
+      GZ_STG4(out, (size_t)y * pitch + x, o);
+      ap = a0; bp = b0;
+      a0 = ad; b0 = bd;
+    }
     return;
   }
-  for (int k = 0; k < 4 && x + k < w; ++k) {
-    const int xx = x + k;
-    const int x2 = xx + 1 < w ? xx + 1 : (xx > 0 ? xx - 1 : xx);
-    const size_t i = (size_t)y * pitch + xx, ir = (size_t)y * pitch + x2,
-                 id = (size_t)y2 * pitch + xx;
-    out[i] = diff_precompute_px(a(i), a(ir), a(id), b(i), b(ir), b(id));
+  for (int r = 0; r < kMaskRows && y0 + r < h; ++r) {
+    const int y = y0 + r;
+    const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
+    for (int k = 0; k < 4 && x + k < w; ++k) {
+      const int xx = x + k;
+      const int x2 = xx + 1 < w ? xx + 1 : (xx > 0 ? xx - 1 : xx);
+      const size_t i = (size_t)y * pitch + xx, ir = (size_t)y * pitch + x2,
+                   id = (size_t)y2 * pitch + xx;
+      out[i] = diff_precompute_px(a(i), a(ir), a(id), b(i), b(ir), b(id));
+    }
   }
 }
 
@@ -239,12 +274,14 @@ GZ_DEVFN void mask_p0p1(float bx, float by1, float by2, double* p0, double* p1) 
   *p0 = (mul0 * w00) * s0 + p1_to_p0 * (*p1);
 }
 
-__global__ __launch_bounds__(256) void k_combine(CombineArgs a, int w, int h, int pitch) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w || y >= h) return;
-  const size_t i = (size_t)y * pitch + x;
+// One pixel of the stage: the mask values from the three mask blurs, the LF and HF-Y terms,
+// CombineChannels and the square-root stage.  Writes the optional mask planes itself; returns
+// the value of the sqrt-stage diffmap.
+GZ_DEVFN float combine_px(const CombineArgs& a, size_t i, float mxb, float myb1, float myb2, float ac0,
+                          float ac1_in, float lf0x, float lf1x, float lf0b, float lf1b, float snb,
+                          float hf0y, float hf1y) {
   double p0, p1;
-  mask_p0p1(a.mask_x_blur[i], a.mask_y_blur1[i], a.mask_y_blur2[i], &p0, &p1);
+  mask_p0p1(mxb, myb1, myb2, &p0, &p1);
   const double w_ytob_hf = 0.086624184478, w_ytob_lf = 21.6804277046;
   const float m0 = (float)interp_lut512(a.luts, p0);
   const double my = interp_lut512(a.luts + 512, p1);
@@ -263,17 +300,17 @@ __global__ __launch_bounds__(256) void k_combine(CombineArgs a, int w, int h, in
     a.mask_dc_out[1][i] = mdc1;
     a.mask_dc_out[2][i] = mdc2;
   }
-  if (a.out == nullptr) return;
+  if (a.out == nullptr) return 0.0f;
   // block_diff_dc: only X (wmul[6]) and B (wmul[8]) are non-zero (butteraugli.cc:873-883)
-  const float dc0 = l2diff_acc(0.0f, a.lf0_x[i], a.lf1_x[i], 1.01370836411);
+  const float dc0 = l2diff_acc(0.0f, lf0x, lf1x, 1.01370836411);
   const float dc1 = 0.0f;
-  const float dc2 = l2diff_acc(0.0f, a.lf0_b[i], a.lf1_b[i], 1.74566011615);
-  const float ac0 = a.ac0[i], ac2 = 0.0f;
-  float ac1 = a.ac1[i];
+  const float dc2 = l2diff_acc(0.0f, lf0b, lf1b, 1.74566011615);
+  const float ac2 = 0.0f;
+  float ac1 = ac1_in;
   if (a.sn_blur) {
-    const double d = (double)a.sn_blur[i];
+    const double d = (double)snb;
     ac1 = (float)((double)ac1 + (a.w_sn * d) * d);
-    ac1 = l2diff_asym_acc(ac1, a.hf0_y[i], a.hf1_y[i], a.w_0gt1, a.w_0lt1);
+    ac1 = l2diff_asym_acc(ac1, hf0y, hf1y, a.w_0gt1, a.w_0lt1);
   }
   const float m2 = (float)(w_ytob_hf * my);
   // CombineChannels: DotProduct(diff_dc, dc_mask) + DotProduct(diff_ac, mask)
@@ -281,7 +318,40 @@ __global__ __launch_bounds__(256) void k_combine(CombineArgs a, int w, int h, in
   const float sac = (ac0 * m0 + ac1 * m1) + ac2 * m2;
   const float v = sdc + sac;
   const float kInitialSlope = 100.0f;
-  a.out[i] = v < (1.0f / (kInitialSlope * kInitialSlope)) ? kInitialSlope * v : sqrtf(v);
+  return v < (1.0f / (kInitialSlope * kInitialSlope)) ? kInitialSlope * v : sqrtf(v);
+}
+
+// grid = (ceil(w / (4 * 256)), h): a thread takes 4 consecutive pixels of a row -- the twelve
+// input planes and the output move as 16-byte accesses -- when the pitch allows it.
+__global__ __launch_bounds__(256) void k_combine(CombineArgs a, int w, int h, int pitch) {
+  const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const size_t i = (size_t)y * pitch + x;
+  if ((pitch & 3) == 0 && x + 3 < w && a.out != nullptr) {
+    const gz_f4 mxb = GZ_LDG4(a.mask_x_blur, i), myb1 = GZ_LDG4(a.mask_y_blur1, i), myb2 = GZ_LDG4(a.mask_y_blur2, i);
+    const gz_f4 ac0 = GZ_LDG4(a.ac0, i), ac1 = GZ_LDG4(a.ac1, i);
+    const gz_f4 lf0x = GZ_LDG4(a.lf0_x, i), lf1x = GZ_LDG4(a.lf1_x, i), lf0b = GZ_LDG4(a.lf0_b, i), lf1b = GZ_LDG4(a.lf1_b, i);
+    gz_f4 snb = ac0, hf0y = ac0, hf1y = ac0;
+    if (a.sn_blur) { snb = GZ_LDG4(a.sn_blur, i); hf0y = GZ_LDG4(a.hf0_y, i); hf1y = GZ_LDG4(a.hf1_y, i); }
+    gz_f4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o.v[k] = combine_px(a, i + k, mxb.v[k], myb1.v[k], myb2.v[k], ac0.v[k], ac1.v[k], lf0x.v[k], lf1x.v[k],
+                          lf0b.v[k], lf1b.v[k], snb.v[k], hf0y.v[k], hf1y.v[k]);
+    GZ_STG4(a.out, i, o);
+    return;
+  }
+  for (int k = 0; k < 4 && x + k < w; ++k) {
+    const size_t j = i + k;
+    const bool full = a.out != nullptr;   // (mask-only calls read the three blurs alone)
+    const float v = combine_px(a, j, a.mask_x_blur[j], a.mask_y_blur1[j], a.mask_y_blur2[j],
+                               full ? a.ac0[j] : 0.0f, full ? a.ac1[j] : 0.0f,
+                               full ? a.lf0_x[j] : 0.0f, full ? a.lf1_x[j] : 0.0f,
+                               full ? a.lf0_b[j] : 0.0f, full ? a.lf1_b[j] : 0.0f,
+                               full && a.sn_blur ? a.sn_blur[j] : 0.0f,
+                               full && a.sn_blur ? a.hf0_y[j] : 0.0f, full && a.sn_blur ? a.hf1_y[j] : 0.0f);
+    if (full) a.out[j] = v;
+  }
 }
 
 // Arithmetic self-check (gz_probe_arith).

@@ -532,4 +532,275 @@ __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, s
   order_swap(a, first + pos_l[k], first + pos_r[k]);
 }
 
+// ------------------------------------- quick-select descent decided on the device (round 3) --
+// What the search driver needs of the sorted order before its stopping rule can fire is the SET
+// of the first `last + 1` entries (guetzli_amd/host/lazy_sort.h: SelectPrefix): libstdc++'s
+// introsort partitions the whole range, then the part that holds position `last`, and so on
+// until that part is small enough to be finished on the host.  Driven from the host, every one
+// of those partitions was five dependent launches and a round trip (~75 us each, 2-6 per
+// iteration of phase B).  Here the whole descent is enqueued at once, right behind the
+// construction of the order: per level TWO launches and no host in between --
+//   k_desc_count  every workgroup finds the pivot for itself (median of three: four reads),
+//                 flags the left / right stoppers of its chunk against it and writes their
+//                 positions, in order, into the chunk's own segments of two lists;
+//   k_desc_swap   every workgroup sums the chunk counts for itself (a few thousand numbers:
+//                 no scan kernel, no look-back chain across the chip), thread k finds the k-th
+//                 left stopper and the k-th right stopper from the right through those sums and
+//                 swaps them if they have not crossed; the one thread that sees "pair k - 1
+//                 swapped, pair k not" knows the cut, decides which side holds `last` and
+//                 writes the next level's range.
+// libstdc++ first moves the median to the front of the range (std::__move_median_to_first);
+// both kernels read the range as if that swap had happened (position `med` holds the old front
+// element) and k_desc_swap's first thread makes it real.  The arrangement and the cuts are those
+// of gz_order_partition (and of std::sort): tests/cpp/test_device_order.cc.
+constexpr int kDescMaxChunks = 4096;   // chunk tables of a workgroup: ranges up to 8.4 M entries
+constexpr int kDescMaxLevels = 12;
+
+struct DescState {                 // the range before level l (level 0: derived, see desc_load)
+  unsigned long long lo, hi;       // the range that holds `last`
+  unsigned long long last;
+  unsigned long long cut;          // cut of the partition that led here
+  int depth;                       // introsort's depth budget
+  unsigned epoch;                  // valid iff equal to the descent's epoch
+};
+struct DescPivot {
+  OrderEntry pivot, a_lo;          // the median of three; the element it changes places with
+  unsigned long long med;          // where the median was found
+};
+struct DescArgs {
+  OrderEntry* a;
+  DescState* st;                   // [kDescMaxLevels + 1]
+  DescPivot* pv;                   // [kDescMaxLevels]
+  unsigned* cnt_l;                 // [chunks]
+  unsigned* cnt_r;
+  unsigned* lpos;                  // [chunks * kPartChunk]: positions relative to lo + 1
+  unsigned* rpos;
+  unsigned epoch;
+  unsigned long long threshold;    // ranges up to this size are left to the host
+  int derive;                      // 0: n0 / last0; 1: from the order construction's results
+  unsigned long long n0, last0;
+  const unsigned long long* total; // number of entries (the offsets scan's last element)
+  const unsigned* counters;        // [0] blocks_to_change
+  float per_block;                 // coefficients to change per block (processor.cc:685-687)
+};
+
+// The range level `level` works on; false = nothing to do at this level.
+GZ_DEVFN bool desc_load(const DescArgs& A, int level, DescState* s) {
+  if (level == 0) {
+    const unsigned long long n = A.derive ? *A.total : A.n0;
+    if (n == 0) return false;
+    s->lo = 0;
+    s->hi = n;
+    int lg = 0;
+    for (unsigned long long m = n; m > 1; m >>= 1) ++lg;
+    s->depth = 2 * lg;
+    if (A.derive) {
+      // min_coeffs_to_change = coeffs_to_change_per_block * blocks_to_change (float product,
+      // truncated: processor.cc:685-687); the stopping rule cannot fire before that many steps,
+      // the entropy codes are refreshed every 10th (:739-741)
+      int min_coeffs = (int)(A.per_block * (float)(int)A.counters[0]);
+      if (min_coeffs < 0) min_coeffs = 0;
+      unsigned long long last_needed = (unsigned long long)min_coeffs;
+      if (last_needed > n - 1) last_needed = n - 1;
+      const unsigned long long fast_until = last_needed / 10 * 10;
+      s->last = fast_until ? fast_until - 1 : 0;
+    } else {
+      s->last = A.last0;
+    }
+    s->cut = 0;
+    s->epoch = A.epoch;
+  } else {
+    *s = A.st[level];
+    if (s->epoch != A.epoch) return false;
+  }
+  const unsigned long long len = s->hi - s->lo;
+  return len > A.threshold && len > 16 && s->depth > 0 &&
+         len - 1 <= (unsigned long long)kDescMaxChunks * kPartChunk;
+}
+
+GZ_DEVFN OrderEntry desc_read(const OrderEntry* a, unsigned long long p, unsigned long long med,
+                              const OrderEntry& a_lo) {
+  return p == med ? a_lo : a[p];
+}
+
+__global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
+  __shared__ unsigned lds[256];
+  DescState s;
+  if (!desc_load(A, level, &s)) return;
+  const unsigned long long first = s.lo + 1;
+  const unsigned n = (unsigned)(s.hi - first);
+  const unsigned nchunks = (n + kPartChunk - 1) / kPartChunk;
+  if (blockIdx.x >= nchunks) return;
+  // std::__move_median_to_first(lo, lo + 1, mid, hi - 1)
+  const unsigned long long x = s.lo + 1, y = s.lo + (s.hi - s.lo) / 2, z = s.hi - 1;
+  const OrderEntry ex = A.a[x], ey = A.a[y], ez = A.a[z], e0 = A.a[s.lo];
+  unsigned long long med;
+  if (order_less(ex, ey)) {
+    if (order_less(ey, ez)) med = y;
+    else if (order_less(ex, ez)) med = z;
+    else med = x;
+  } else if (order_less(ex, ez)) {
+    med = x;
+  } else if (order_less(ey, ez)) {
+    med = z;
+  } else {
+    med = y;
+  }
+  const OrderEntry pv = med == x ? ex : (med == y ? ey : ez);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    DescPivot o;
+    o.pivot = pv;
+    o.a_lo = e0;
+    o.med = med;
+    A.pv[level] = o;
+  }
+  const int t = threadIdx.x;
+  const unsigned base = blockIdx.x * (unsigned)kPartChunk + t * (unsigned)kPartItems;
+  unsigned fl = 0, fr = 0, nl = 0, nr = 0;
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
+    const unsigned p = base + i;
+    if (p < n) {
+      const OrderEntry e = desc_read(A.a, first + p, med, e0);
+      if (!order_less(e, pv)) { fl |= 1u << i; ++nl; }
+      if (!order_less(pv, e)) { fr |= 1u << i; ++nr; }
+    }
+  }
+  const unsigned incl_l = wg_inclusive_scan(nl, lds);
+  const unsigned incl_r = wg_inclusive_scan(nr, lds);
+  unsigned ol = blockIdx.x * (unsigned)kPartChunk + (incl_l - nl);
+  unsigned orr = blockIdx.x * (unsigned)kPartChunk + (incl_r - nr);
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
+    if ((fl >> i) & 1u) A.lpos[ol++] = base + i;
+    if ((fr >> i) & 1u) A.rpos[orr++] = base + i;
+  }
+  if (t == 255) {
+    A.cnt_l[blockIdx.x] = incl_l;
+    A.cnt_r[blockIdx.x] = incl_r;
+  }
+}
+
+// First index in tab[0 .. n] whose value exceeds k, minus one (tab ascending, tab[0] <= k < tab[n]).
+GZ_DEVFN unsigned desc_chunk_of(const unsigned* tab, unsigned n, unsigned k) {
+  unsigned lo = 0, hi = n;   // tab[lo] <= k < tab[hi]
+  while (hi - lo > 1) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (tab[mid] <= k) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
+  __shared__ unsigned PL[kDescMaxChunks + 1];   // left stoppers in the chunks before c
+  __shared__ unsigned RR[kDescMaxChunks + 1];   // right stoppers in the chunks after nchunks-1-i
+  __shared__ unsigned lds[256];
+  DescState s;
+  if (!desc_load(A, level, &s)) return;
+  const unsigned long long first = s.lo + 1;
+  const unsigned n = (unsigned)(s.hi - first);
+  const unsigned nchunks = (n + kPartChunk - 1) / kPartChunk;
+  const int t = threadIdx.x;
+  {  // the two tables, by every workgroup for itself
+    const unsigned per = (nchunks + 255) / 256;
+    const unsigned c0 = t * per < nchunks ? t * per : nchunks;
+    const unsigned c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    unsigned sl = 0, sr = 0;
+    for (unsigned c = c0; c < c1; ++c) {
+      sl += A.cnt_l[c];
+      sr += A.cnt_r[nchunks - 1 - c];
+    }
+    unsigned run_l = wg_inclusive_scan(sl, lds) - sl;
+    unsigned run_r = wg_inclusive_scan(sr, lds) - sr;
+    for (unsigned c = c0; c < c1; ++c) {
+      PL[c] = run_l;
+      RR[c] = run_r;
+      run_l += A.cnt_l[c];
+      run_r += A.cnt_r[nchunks - 1 - c];
+    }
+    if (c1 == nchunks && c0 < nchunks) {
+      PL[nchunks] = run_l;
+      RR[nchunks] = run_r;
+    }
+    __syncthreads();
+  }
+  const unsigned total_l = PL[nchunks], total_r = RR[nchunks];
+  const unsigned K = total_l < total_r ? total_l : total_r;   // pairs 0 .. K-1 exist; "pair" K ends the scan
+  const unsigned k0 = (blockIdx.x * 256u + (unsigned)t) * (unsigned)kPartItems;
+  if (k0 > K) return;
+  const DescPivot pvt = A.pv[level];
+  // positions (relative to `first`) of the k-th left stopper / the k-th right stopper from the right
+  auto pos_l = [&](unsigned k) {
+    const unsigned c = desc_chunk_of(PL, nchunks, k);
+    return A.lpos[c * (unsigned)kPartChunk + (k - PL[c])];
+  };
+  auto pos_r = [&](unsigned k) {
+    const unsigned i = desc_chunk_of(RR, nchunks, k);
+    const unsigned c = nchunks - 1 - i, cnt = RR[i + 1] - RR[i];
+    return A.rpos[c * (unsigned)kPartChunk + (cnt - 1 - (k - RR[i]))];
+  };
+  bool prev_swapped = true;   // (k == 0: the scan starts)
+  unsigned prev_pr = 0;
+  if (k0 > 0) {
+    const unsigned pl = pos_l(k0 - 1);   // (k0 - 1 < K: both exist)
+    prev_pr = pos_r(k0 - 1);
+    prev_swapped = pl < prev_pr;
+  }
+  for (int i = 0; i < kPartItems && prev_swapped; ++i) {
+    const unsigned k = k0 + (unsigned)i;
+    if (k > K) break;
+    const bool has_l = k < total_l, has_r = k < total_r;
+    unsigned pl = 0, pr = 0;
+    if (has_l) pl = pos_l(k);
+    if (has_r) pr = pos_r(k);
+    const bool swapped = has_l && has_r && pl < pr;
+    if (swapped) {
+      const OrderEntry vl = desc_read(A.a, first + pl, pvt.med, pvt.a_lo);
+      const OrderEntry vr = desc_read(A.a, first + pr, pvt.med, pvt.a_lo);
+      A.a[first + pl] = vr;
+      A.a[first + pr] = vl;
+      prev_pr = pr;
+    } else {
+      // the serial scan stops here: at the next untouched left stopper or at the last swapped
+      // right one, whichever comes first (libstdc++ __unguarded_partition returns `first`)
+      unsigned long long cut = s.hi;
+      if (has_l && first + pl < cut) cut = first + pl;
+      if (k >= 1 && first + prev_pr < cut) cut = first + prev_pr;
+      DescState nx;
+      if (s.last < cut) { nx.lo = s.lo; nx.hi = cut; } else { nx.lo = cut; nx.hi = s.hi; }
+      nx.last = s.last;
+      nx.cut = cut;
+      nx.depth = s.depth - 1;
+      nx.epoch = A.epoch;
+      A.st[level + 1] = nx;
+      if (level == 0) A.st[0] = s;   // (the derived level-0 range, for the host's replay)
+    }
+    prev_swapped = swapped;
+  }
+  if (k0 == 0) {
+    // the median's move to the front, made real: the front gets the pivot; the place the pivot
+    // came from gets the old front element unless a pair above has already put a partner there
+    A.a[s.lo] = pvt.pivot;
+    const unsigned pm = (unsigned)(pvt.med - first);
+    const unsigned c = pm / (unsigned)kPartChunk, ci = nchunks - 1 - c;
+    bool moved = false;
+    if (!order_less(pvt.a_lo, pvt.pivot)) {   // a left stopper: its rank among them
+      const unsigned* seg = A.lpos + c * (unsigned)kPartChunk;
+      unsigned lo = 0, hi = PL[c + 1] - PL[c];
+      while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (seg[mid] < pm) lo = mid + 1; else hi = mid; }
+      const unsigned k = PL[c] + lo;
+      if (k < total_r && pm < pos_r(k)) moved = true;
+    }
+    if (!moved && !order_less(pvt.pivot, pvt.a_lo)) {   // a right stopper
+      const unsigned* seg = A.rpos + c * (unsigned)kPartChunk;
+      const unsigned cnt = RR[ci + 1] - RR[ci];
+      unsigned lo = 0, hi = cnt;
+      while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (seg[mid] < pm) lo = mid + 1; else hi = mid; }
+      const unsigned k = RR[ci] + (cnt - 1 - lo);
+      if (k < total_l && pos_l(k) < pm) moved = true;
+    }
+    if (!moved) A.a[pvt.med] = pvt.a_lo;
+  }
+}
+
 }  // namespace gz

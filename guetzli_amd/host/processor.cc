@@ -173,7 +173,22 @@ inline bool IsPrecious(const int16_t* orig_blk, int k) {
 // The device-resident global candidate order as LazySorted's back end.
 struct DeviceOrder : RangeDevice {
   explicit DeviceOrder(gz_ctx* c) : ctx(c) {}
+  // Partitions the device has already made on its own (gz_order_descend*: the quick-select
+  // descent towards the position phase B needs, enqueued behind the order's construction), in
+  // the order LazySorted is going to ask for them: (lo, hi, cut) triples.
+  uint64_t log[3 * 12];
+  int log_n = 0, log_next = 0;
   bool Partition(size_t lo, size_t hi, size_t* cut) override {
+    if (log_next < log_n && log[3 * log_next] == lo && log[3 * log_next + 1] == hi) {
+      *cut = (size_t)log[3 * log_next + 2];
+      ++log_next;
+      ++n_replayed;
+      return true;
+    }
+    if (log_next < log_n) {   // the device went another way than the host: its array is not what we think
+      rc = GZ_E_STATE;
+      return false;
+    }
     Stopwatch w;
     uint64_t c64 = 0;
     rc = gz_order_partition(ctx, lo, hi, &c64);
@@ -192,7 +207,7 @@ struct DeviceOrder : RangeDevice {
   gz_ctx* ctx;
   int rc = GZ_OK;
   double t_partition = 0, t_fetch = 0;   // seconds inside the device calls (round trips included)
-  long n_partition = 0, n_fetched = 0;
+  long n_partition = 0, n_fetched = 0, n_replayed = 0;
 };
 
 // ------------------------------------------------------------------- the encoder ------
@@ -302,7 +317,11 @@ class Encoder {
          t_upload_ = 0;
   double t_pb_ensure_ = 0, t_pb_fast_ = 0, t_pb_dev_partition_ = 0, t_pb_dev_fetch_ = 0;
   double t_fs_count_ = 0, t_fs_apply_ = 0, t_fs_mirror_ = 0, t_fs_delta_ = 0, t_fs_rest_ = 0;
-  long n_dev_partitions_ = 0, n_dev_fetched_ = 0;
+  long n_dev_partitions_ = 0, n_dev_fetched_ = 0, n_dev_replayed_ = 0;
+  double t_pb_descend_ = 0;
+  // GZ_ORDER_DESCEND=0: the host asks for every introsort partition itself (round 2's path)
+  bool descend_ = true;
+  int descend_levels_ = 6;      // levels to enqueue per descent (follows what the orders need)
   long n_fast_ = 0;
   double t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0, n_evaluations_ = 0;
@@ -657,6 +676,9 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   // of this iteration's candidate (gz_order_build_auto_begin): `ahead` says that such a
   // construction is in flight, and for which direction.
   int ahead = 0;
+  uint64_t ahead_log[3 * 12];   // the partitions the device made behind that construction
+  int ahead_levels = 0;
+  uint64_t ahead_last = 0;
 
   for (int direction = 1; direction >= -1; direction -= 2) {
     for (;;) {
@@ -665,6 +687,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         if (prev_size > 1.01 * (double)best_size_) break;
       }
       int blocks_to_change = 0;
+      bool have_ahead_log = false;
       Stopwatch pw;
       // `order` (global_order, processor.cc:622-663) is built on the device from the CSR
       // arrays phase A left there, in the reference's sequence: blocks ascending; within a
@@ -678,6 +701,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         int32_t btc = 0;
         if (radius == 1 && ahead == direction && !first_up) {
           rc = gz_order_build_auto_end(ctx_, &total, &btc, &below);
+          if (rc == GZ_OK && descend_) {
+            rc = gz_order_descend_end(ctx_, ahead_log, 12, &ahead_levels, &ahead_last);
+            have_ahead_log = rc == GZ_OK && ahead_levels > 0;
+          }
         } else {
           rc = gz_order_build_auto(ctx_, direction, radius, target_mul, first_up ? 0 : 1,
                                    next_cand.data(), first_up ? 1 : 0, below_limit, &total, &btc,
@@ -687,6 +714,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         if (rc != GZ_OK) return Fail("gz_order_build_auto", rc);
         blocks_to_change = btc;
         if (total != 0) break;
+        have_ahead_log = false;   // (an empty order: the next radius builds another one)
       }
       t_pb_order_ += pw.lap();
       if (total == 0) break;
@@ -766,6 +794,23 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         const size_t last_needed = std::min<size_t>((size_t)std::max(min_coeffs_to_change, 0), n_order - 1);
         const size_t fast_until = last_needed / 10 * 10;
         Stopwatch fw;
+        // The introsort partitions that lead to position fast_until - 1, made by the device
+        // without the host in between: behind the order's construction when that was enqueued
+        // ahead (the device derives the position as the lines above do), else now, in one call.
+        if (descend_ && n_order > device_threshold_) {
+          const uint64_t want = fast_until ? fast_until - 1 : 0;
+          if (have_ahead_log) {
+            if (ahead_last != want) return Fail("gz_order_descend: position", GZ_E_STATE);
+            memcpy(dev_order.log, ahead_log, sizeof(uint64_t) * 3 * ahead_levels);
+            dev_order.log_n = ahead_levels;
+          } else {
+            int levels = 0;
+            rc = gz_order_descend(ctx_, want, device_threshold_, descend_levels_, dev_order.log, &levels);
+            if (rc != GZ_OK) return Fail("gz_order_descend", rc);
+            dev_order.log_n = levels;
+          }
+          t_pb_descend_ += fw.lap();
+        }
         sorted.SelectPrefix(fast_until);   // the set [0, fast_until) and element fast_until - 1
         t_pb_ensure_ += fw.lap();
         // Steps [0, fast_until): only how many steps each block takes matters (the n-th step
@@ -836,6 +881,12 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       t_pb_loop_ += pw.lap();
       const size_t order_size = (size_t)total;
       if (sorted.failed()) return Fail("gz_order_partition/fetch", dev_order.rc);
+      if (dev_order.log_n > 0) {
+        // as many levels next time as this order needed, plus one in reserve (an unused level
+        // costs two empty launches, a missing one a round trip per partition)
+        descend_levels_ = std::min(12, std::max(2, dev_order.log_n + (dev_order.n_partition > 0 ? 2 : 1)));
+      }
+      n_dev_replayed_ += dev_order.n_replayed;
       t_pb_dev_partition_ += dev_order.t_partition;
       t_pb_dev_fetch_ += dev_order.t_fetch;
       n_dev_partitions_ += dev_order.n_partition;
@@ -862,6 +913,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         rc = gz_order_build_auto_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
                                        below_limit);
         if (rc != GZ_OK) return Fail("gz_order_build_auto_begin", rc);
+        if (descend_) {
+          rc = gz_order_descend_begin(ctx_, per_block, device_threshold_, descend_levels_);
+          if (rc != GZ_OK) return Fail("gz_order_descend_begin", rc);
+        }
         ahead = direction;
       }
       if (!Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;
@@ -887,6 +942,7 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   // the original as the fallback output (processor.cc:826-846)
   verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
   if (const char* e = getenv("GZ_ORDER_AHEAD")) build_ahead_ = atoi(e) != 0;
+  if (const char* e = getenv("GZ_ORDER_DESCEND")) descend_ = atoi(e) != 0;
   if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
   best_score_ = -1;
   QuantMatrix ones;
@@ -990,6 +1046,8 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->timers["pb_fast_delta"] = t_fs_delta_;
   stats_->timers["pb_device_partitions"] = t_pb_dev_partition_;
   stats_->timers["pb_device_fetches"] = t_pb_dev_fetch_;
+  stats_->timers["pb_device_descents"] = t_pb_descend_;
+  stats_->counters["phase B partitions made ahead"] = (int)n_dev_replayed_;
   stats_->counters["phase B device partitions"] = (int)n_dev_partitions_;
   stats_->counters["phase B entries fetched"] = (int)std::min<long>(n_dev_fetched_, 2147483647L);
   t_pb_fast_ = t_fs_count_ + t_fs_apply_ + t_fs_mirror_ + t_fs_delta_ + t_fs_rest_;

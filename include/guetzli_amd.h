@@ -49,7 +49,7 @@ extern "C" {
 typedef struct gz_ctx gz_ctx;
 
 /* Library / device ------------------------------------------------------------ */
-int gz_abi_version(void);                 /* currently 2 */
+int gz_abi_version(void);                 /* currently 3 */
 /* Device and pinned host memory of destroyed contexts is kept (per device, exact sizes, at
  * most GZ_POOL_MB megabytes of device memory, default 16384) for the next context of the same
  * image size: a batch of same-sized images allocates once.  gz_trim_pool releases everything
@@ -327,6 +327,26 @@ int gz_steps_histogram_delta(gz_ctx* ctx, int32_t* ac_delta);
 int gz_order_upload(gz_ctx* ctx, const void* entries, uint64_t n);
 int gz_order_partition(gz_ctx* ctx, uint64_t lo, uint64_t hi, uint64_t* cut);
 int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);
+/* The quick-select descent of that sort, decided on the device.  What the global loop needs
+ * before its stopping rule can fire (processor.cc:743-746: not before min_coeffs_to_change
+ * steps) is the SET of the leading entries of the sorted order; std::sort's introsort reaches
+ * it by partitioning the whole order, then the part that holds position `last`, and so on.
+ * gz_order_descend runs up to max_levels of exactly those gz_order_partition steps back to back
+ * -- on the range [0, n), then on whichever side of the cut holds `last`, while the range has
+ * more than `threshold` entries and introsort's depth budget (2 floor(lg n)) lasts -- without
+ * the host in between, and reports them: log[3*i] = lo, log[3*i+1] = hi, log[3*i+2] = cut of
+ * step i, *levels of them.  Same arrangement, same cuts as the same sequence of
+ * gz_order_partition calls.
+ * gz_order_descend_begin: the same enqueued behind gz_order_build_auto_begin, before the order's
+ *   size is known to the host: `last` is derived on the device as the search driver derives it,
+ *   min_coeffs = (int)(per_block * blocks_to_change) (:685-687), capped at n - 1, rounded down
+ *   to the entropy-code refresh interval of 10 (:739-741), minus one (0 if that is 0).
+ * gz_order_descend_end: its log, after gz_order_build_auto_end, and the `last` it was made
+ *   for (meaningful when *levels > 0): a caller that derives another position must not replay it. */
+int gz_order_descend(gz_ctx* ctx, uint64_t last, uint64_t threshold, int max_levels,
+                     uint64_t* log, int* levels);
+int gz_order_descend_begin(gz_ctx* ctx, float per_block, uint64_t threshold, int max_levels);
+int gz_order_descend_end(gz_ctx* ctx, uint64_t* log, int cap_levels, int* levels, uint64_t* last);
 
 /* Entropy coding of the candidate -----------------------------------------------------
  * The search needs the exact size of every candidate's JPEG (ScoreJPEG) and the bytes of the

@@ -30,11 +30,21 @@ static decltype(&gz_destroy) p_destroy;
 static decltype(&gz_order_upload) p_upload;
 static decltype(&gz_order_partition) p_partition;
 static decltype(&gz_order_fetch) p_fetch;
+static decltype(&gz_order_descend) p_descend;
 static gz_ctx* g_ctx;
-static long g_partitions = 0, g_fetched = 0;
+static long g_partitions = 0, g_fetched = 0, g_replayed = 0;
 
 struct Dev : guetzli_amd::RangeDevice {
+  // partitions the device has already made (gz_order_descend), in the order it made them
+  std::vector<uint64_t> log;
+  size_t next = 0;
   bool Partition(size_t lo, size_t hi, size_t* cut) override {
+    if (3 * next + 2 < log.size() && log[3 * next] == lo && log[3 * next + 1] == hi) {
+      *cut = (size_t)log[3 * next + 2];
+      ++next;
+      ++g_replayed;
+      return true;
+    }
     uint64_t c = 0;
     if (p_partition(g_ctx, lo, hi, &c) != GZ_OK) return false;
     *cut = (size_t)c;
@@ -57,9 +67,21 @@ static int check(const std::vector<E>& v, const char* what, size_t threshold, si
   guetzli_amd::LazySorted<E, Less> lazy(host.data(), host.size(), Less(), -1, 1 << 17, &dev, threshold);
   const size_t upto = prefix_only ? std::min(prefix_only, v.size()) : v.size();
   size_t from = 0;
-  if (ensure == 3) {   // SelectPrefix: the right set below f, exact from f-1 on
+  if (ensure == 3 || ensure == 4) {   // SelectPrefix: the right set below f, exact from f-1 on
     const size_t f = upto / 2;
+    if (ensure == 4 && f > 0) {
+      // the descent towards position f - 1 made on the device in one go; LazySorted then
+      // replays its log instead of asking for the partitions one by one
+      dev.log.assign(3 * 12, 0);
+      int levels = 0;
+      if (p_descend(g_ctx, f - 1, threshold, 12, dev.log.data(), &levels) != GZ_OK) { printf("FAIL descend\n"); return 1; }
+      dev.log.resize(3 * (size_t)levels);
+    }
     lazy.SelectPrefix(f);
+    if (ensure == 4 && dev.next != dev.log.size() / 3) {
+      printf("FAIL %s n=%zu thr=%zu: %zu of %zu logged partitions replayed\n", what, v.size(), threshold, dev.next, dev.log.size() / 3);
+      return 1;
+    }
     if (f > 0) {
       std::vector<std::pair<float, int> > a, b;
       for (size_t i = 0; i < f; ++i) {
@@ -95,7 +117,8 @@ int main(int argc, char** argv) {
   p_upload = (decltype(p_upload))dlsym(h, "gz_order_upload");
   p_partition = (decltype(p_partition))dlsym(h, "gz_order_partition");
   p_fetch = (decltype(p_fetch))dlsym(h, "gz_order_fetch");
-  if (!p_create || !p_destroy || !p_upload || !p_partition || !p_fetch) { printf("missing symbol\n"); return 2; }
+  p_descend = (decltype(p_descend))dlsym(h, "gz_order_descend");
+  if (!p_create || !p_destroy || !p_upload || !p_partition || !p_fetch || !p_descend) { printf("missing symbol\n"); return 2; }
   const size_t max_n = (size_t)atol(argv[2]);
   std::vector<size_t> thresholds;
   for (int i = 3; i < argc; ++i) thresholds.push_back((size_t)atol(argv[i]));
@@ -135,6 +158,8 @@ int main(int argc, char** argv) {
           fails += check(v, "ensure", thr, n / 20 + 3, 1);
           fails += check(v, "ensure-half", thr, n / 20 + 3, 2);
           fails += check(v, "select-prefix", thr, n / 10 + 3, 3);
+          fails += check(v, "descend", thr, n / 10 + 3, 4);
+          fails += check(v, "descend-far", thr, n - n / 7, 4);
         }
         if (fails > 5) goto done;
       }
@@ -156,7 +181,7 @@ int main(int argc, char** argv) {
   }
 done:
   p_destroy(g_ctx);
-  printf("device partitions %ld, entries fetched %ld\n", g_partitions, g_fetched);
+  printf("device partitions %ld (+ %ld replayed from descents), entries fetched %ld\n", g_partitions, g_replayed, g_fetched);
   printf(fails ? "device_order: %d FAILURES\n" : "device_order: ok\n", fails);
   return fails ? 1 : 0;
 }

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib_path):
 
 def test_argument_errors_and_no_silent_fallback(lib_path):
     L = capi.Library(lib_path)
-    assert L.lib.gz_abi_version() == 2
+    assert L.lib.gz_abi_version() == 3
     assert L.lib.gz_strerror(-2).decode() == "no usable HIP device"
     err = C.c_int(0)
     rgb = np.zeros((16, 16, 3), np.uint8)

@@ -966,7 +966,10 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[2] = {p0.mf[ch], p1.mf[ch], ms[ch][2].nm, ms[ch][2].lf};
     a.out = c->ac[ch];
   }
-  GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
+  // GZ_MALTA_DMA=0: every pass staged through registers (round 2's kernel path); read per call
+  const char* dma_env = getenv("GZ_MALTA_DMA");
+  const int malta_opt = (dma_env && atoi(dma_env) == 0) ? 0 : 1;
+  GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch, malta_opt);
   KCHK(c);
   TRY(join_mask_branch(c));
   {

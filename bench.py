@@ -4,11 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): one 1920x1080 sRGB image (tests/golden/bees.png tiled
-from the origin), --quality 95 (butteraugli target 0.971769).  One image per
-GPU per step ("weak" scaling: rank r encodes the image circularly shifted by (37r, 53r)
-pixels, as in config 5); images are independent, so there is no data-path collective --
-only the barrier and the max-over-ranks of the elapsed time.
+Workload of `value` (BASELINE.json configs[1]): one 1920x1080 sRGB image (tests/golden/bees.png
+tiled from the origin), --quality 95 (butteraugli target 0.971769).  One image
+per GPU per step ("weak" scaling: rank r encodes the image circularly shifted by (37r, 53r)
+pixels, as in config 5); images are independent, so there is no data-path collective -- only
+the barrier and the max-over-ranks of the elapsed time.
 
 A STEP is one whole encode: guetzli::Process(params, stats, rgb, w, h, &out) through the
 host search driver (guetzli_amd/host) with every per-pixel / per-block operation on the GPU
@@ -20,27 +20,41 @@ the boundary is inside the number.  Rank 0's output is checked against the refer
 JPEG (SHA-256 recorded from the unmodified reference) after the timed region.
 
 Also on the JSON line:
+  value_4k / ms_per_step_4k / config_4k -- BASELINE configs[2], north_star's target size: one
+                  3840x2160 image at --quality 95, timed EXACTLY like `value` (same --steps and
+                  --warmup, same barrier / synchronise bracket, max over ranks), output hash
+                  checked against the reference's.
   roofline     -- HBM roofline of the butteraugli evaluation (the second half of the
                   metric): SURVEY.md 8(d) algorithmic bytes of one Compare (494 B/px) /
                   average duration of one Compare chain measured with HIP events on the
                   stream the kernels run on (gz_time_compare), same process, same image.
                   `traffic` = HBM bytes of one chain from the rocprofv3 FETCH_SIZE /
                   WRITE_SIZE passes committed under profiles/ (the counters cannot be read
-                  from inside this process).  `roofline_4k` = the same measurement on
-                  BASELINE.json configs[2] (3840x2160), the size the chain fills the chip at.
+                  from inside this process; `traffic_head` = the commit they were taken at).
+                  `roofline_4k` = the same measurement on 3840x2160, the size the chain fills
+                  the chip at.
+  scale_value  -- BASELINE config 5's work split on the GPUs this run has (the `config5_slice`
+                  leg): 3840x2160 images, 8 per GPU (image k -> rank k mod N), 8 in flight per
+                  GPU, records all-gathered over the process group; every output whose
+                  reference hash is committed (tests/golden/config5/: images 0-15) is checked.
+                  The throughput curve of the real multi-GPU workload can be read from it at
+                  every N.  `--config5` runs only this leg and reports it as `value`.
+  first_encode_s -- the process's first encode (HIP start-up, code-object load, pool fill).
+  box          -- three-second calibration of the box the run landed on (tools/ubench/bw:
+                  streaming copy rates), so that a slow box is visible as such.
   cpu_baseline -- the unmodified reference guetzli::Process (oracle/_ref, 1 thread) on this
                   box's host CPU, rank 0, N=1 only, on bounded samples: the bench image's top-left
                   640x360, and BASELINE config 0 verbatim (tests/bees.png, --quality 95).
-  other_configs.config5_slice -- BASELINE config 5's work split on the GPUs this run has:
-                  3840x2160 images, 8 per GPU (image k -> rank k mod N), 8 in flight per GPU,
-                  records all-gathered over the process group; every output whose reference
-                  hash is committed (tests/golden/config5/) is checked.  `--config5` runs only
-                  this leg and reports it as `value`.
+
+`--emulate` (CPU dry run, used by tests/test_bench_main.py at world size 2): the same control
+flow -- process group, barriers, max-over-ranks, all-gathers, rank-0-only legs -- over gloo
+and the test-suite's CPU emulation of the kernels on tiny images.  It measures nothing.
 """
 import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -54,13 +68,14 @@ ALGO_BYTES_PER_PX = 494.0          # 123.5 float-plane passes pe
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
 QUALITY = 95.0
 TARGET_Q95 = 0.971769              # ButteraugliScoreForQuality(95), quality.cc:31-85
-W, H = 1920, 1080
 GOLDEN_SHA_1080P_Q95 = "9c0eb414b8e73f4372c0b089eafe2350e6ff2ae83926d1c0c5f35cb5f7919729"
 GOLDEN_SHA_4K = {95: "481507d21e4d37f296ae6a2a93a84d950c4a135df310b3408a64390b25d59c05",
                  84: "f3be1e4385a977853f7cd224e1722a728c1fa0bc68f1115c27e657c23a028ac0"}
 CHAIN = ("butteraugli Compare chain (15 launches per Compare on 3 streams: k_reconstruct, 5 fused "
          "k_blur2d (radius < 16), 3 k_blur_h + 3 k_blur_v (radius >= 16; the mask's radius-20 pair is one "
          "launch per pass), k_malta (both channels), k_mask_pre, k_combine)")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_compare_pmc_traffic.json")
+TRAFFIC_JSON_OLD = os.path.join(ROOT, "profiles", "r02_compare_pmc_traffic.json")
 
 
 def cpu_baseline():
@@ -103,22 +118,130 @@ def config5_goldens():
     return out
 
 
-def config5_leg(host, images, torch, dist, rank, world, local_rank, images_per_gpu, in_flight, size):
+def box_calibration():
+    """Streaming copy rates of this box (tools/ubench/bw, < 1 s): the Compare chain follows them."""
+    exe = os.path.join(ROOT, "tools", "ubench", "bw")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout
+    except Exception:
+        return None
+    import re
+    cal = {}
+    for line in out.splitlines():
+        m = re.match(r"^copy (.+?)\s+([\d.]+) us/plane\s+([\d.]+) TB/s", line)
+        if m:
+            cal["copy_" + m.group(1).strip().replace(" ", "_") + "_TBps"] = float(m.group(3))
+    return cal or None
+
+
+class Env:
+    """Device and process-group plumbing: MI355X + RCCL, or (--emulate) the CPU dry run."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.emulate = args.emulate
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert self.world == args.gpus, f"WORLD_SIZE {self.world} != --gpus {args.gpus}"
+        self.dist = None
+        if not self.emulate:
+            assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+            torch.cuda.set_device(self.local_rank)
+        self.tensor_device = "cpu" if self.emulate else "cuda"
+        self.device = 0 if self.emulate else self.local_rank   # device index of this rank's contexts
+        if self.world > 1:
+            self.bind_cpus()
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.emulate:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+
+    def bind_cpus(self):
+        """One process per GPU: every rank keeps to its own contiguous share of the host cores
+        (its image threads and the driver's worker pool then do not migrate across the other
+        ranks' cores / NUMA nodes).  BENCH_NO_AFFINITY=1 leaves the scheduler alone."""
+        if os.environ.get("BENCH_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+            return
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+            per = len(cpus) // self.world
+            if per >= 2:
+                os.sched_setaffinity(0, cpus[self.local_rank * per:(self.local_rank + 1) * per])
+        except OSError:
+            pass
+
+    def sync(self):
+        if not self.emulate:
+            self.torch.cuda.synchronize()
+
+    def fence(self):
+        self.sync()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.tensor_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def libraries(self):
+        """(host driver, C-ABI library): the gfx950 build, or the emulation build for the dry run."""
+        import guetzli_amd
+        if self.emulate:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+            import build_emu
+            from guetzli_amd.capi import Library
+            from guetzli_amd.encoder import HostLibrary
+            if self.rank == 0:
+                build_emu.build_host()
+            if self.dist is not None:
+                self.dist.barrier()
+            return HostLibrary(build_emu.HOST_LIB), Library(build_emu.LIB)
+        return guetzli_amd.load_host(), guetzli_amd.load()   # no fallback: fails without the library
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()   # rank 0 has the extra legs: leave together
+            self.dist.destroy_process_group()
+
+
+def timed_steps(env, step, steps, warmup):
+    """W untimed steps, then exactly K steps between barrier + synchronise on both sides; the
+    maximum over ranks.  Returns (seconds, last result)."""
+    for _ in range(warmup):
+        step()
+    env.fence()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(steps):
+        res = step()
+    env.fence()
+    return env.max_over_ranks(time.perf_counter() - t0), res
+
+
+def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality):
     """8 images per GPU of config 5's batch; returns the JSON object of the leg (rank 0)."""
     from guetzli_amd.batch import run_config5
     w5, h5 = size
     base = images.tiled(w5, h5)
     get = lambda k: images.shifted(base, k)
-    proc = lambda im: host.process(im, quality=QUALITY, device=local_rank)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-    run_config5(get, min(2, images_per_gpu), proc, rank, world, dist, in_flight, fence, "cuda")   # warm-up
-    recs, secs = run_config5(get, images_per_gpu, proc, rank, world, dist, in_flight, fence, "cuda")
-    gold = config5_goldens()
+    proc = lambda im: host.process(im, quality=quality, device=env.device)
+    run_config5(get, min(2, images_per_gpu), proc, env.rank, env.world, env.dist, in_flight, env.fence,
+                env.tensor_device)   # warm-up
+    recs, secs = run_config5(get, images_per_gpu, proc, env.rank, env.world, env.dist, in_flight,
+                             env.fence, env.tensor_device)
+    gold = {} if env.emulate else config5_goldens()
     checked = 0
     for r in recs:
         g = gold.get((r["index"], w5, h5))
@@ -127,12 +250,23 @@ def config5_leg(host, images, torch, dist, rank, world, local_rank, images_per_g
             checked += 1
     n = len(recs)
     return {"workload": f"{n} independent {w5}x{h5} images (the bench image circularly shifted by "
-                        f"(37k, 53k)), --quality 95, {images_per_gpu} per GPU (image k -> rank k mod {world}), "
-                        f"{in_flight} in flight per GPU; records all-gathered",
+                        f"(37k, 53k)), --quality {quality:g}, {images_per_gpu} per GPU (image k -> rank k mod "
+                        f"{env.world}), {in_flight} in flight per GPU; records all-gathered",
             "images": n, "images_per_gpu": images_per_gpu, "in_flight": in_flight,
             "seconds": round(secs, 3), "value": round(n * w5 * h5 / 1e6 / secs, 3), "unit": "MPix/s",
             "outputs_checked_against_reference_hashes": checked,
             "distinct_outputs": len({r["sha256"] for r in recs})}
+
+
+def roofline_of(L, rgb, device, iters, warm):
+    w, h = rgb.shape[1], rgb.shape[0]
+    with L.context(rgb, TARGET_Q95, device=device) as ctx:
+        ctx.encode_rgb(download=False)
+        ctx.quantize(np.full((3, 64), 3, np.int32), download=False)
+        ctx.time_compare(warm)
+        ms = ctx.time_compare(iters) / iters
+    achieved = ALGO_BYTES_PER_PX * w * h / (ms * 1e-3) / 1e9
+    return ms, achieved
 
 
 def main():
@@ -151,30 +285,27 @@ def main():
     ap.add_argument("--in-flight", type=int, default=8)
     ap.add_argument("--size", default="4k", choices=["4k", "1080p"])
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default run")
+    ap.add_argument("--emulate", action="store_true",
+                    help="CPU dry run of the control flow (gloo + the test-suite's emulation of the "
+                         "kernels, tiny images): measures nothing")
     args = ap.parse_args()
 
-    import torch
-    import guetzli_amd
+    env = Env(args)
     import images
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-
-    host = guetzli_amd.load_host()        # links the gfx950 C-ABI library; no fallback
-    size5 = (3840, 2160) if args.size == "4k" else (1920, 1080)
+    host, L = env.libraries()
+    rank, world, local_rank = env.rank, env.world, env.device
+    emu = env.emulate
+    W, H = (48, 40) if emu else (1920, 1080)
+    W4, H4 = (56, 48) if emu else (3840, 2160)
+    quality = 84.0 if emu else QUALITY   # (the dry run: the shortest search)
+    size5 = (W4, H4) if args.size == "4k" else (W, H)
+    if emu:
+        args.images_per_gpu = min(args.images_per_gpu, 2)
+        args.in_flight = 1            # the emulation of the kernels is single-threaded
+        args.batch_images = min(args.batch_images, 2)
+        args.batch_workers = 1
     if args.config5:
-        leg = config5_leg(host, images, torch, dist, rank, world, local_rank, args.images_per_gpu,
-                          args.in_flight, size5)
+        leg = config5_leg(env, host, images, args.images_per_gpu, args.in_flight, size5, quality)
         if rank == 0:
             print(json.dumps({
                 "metric": "MPix/s encoded at --quality 95", "value": leg["value"], "unit": "MPix/s",
@@ -183,100 +314,91 @@ def main():
                 "dtype": "f32+f64 (butteraugli), int32/int16 (DCT/quantize/entropy coding)",
                 "data": "synthetic (tests/golden/bees.png tiled, circularly shifted per image, SURVEY 8d)",
                 "config": leg}), flush=True)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        env.finish()
         return
     rgb = images.shifted(images.tiled(W, H), rank)
+    rgb4k = images.shifted(images.tiled(W4, H4), rank)
 
     def step():
-        return host.process(rgb, quality=QUALITY, device=local_rank)
+        return host.process(rgb, quality=quality, device=local_rank)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step4k():
+        return host.process(rgb4k, quality=quality, device=local_rank)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    # the process's first encode, on its own: HIP start-up, code-object load, first allocations
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        jpg, info = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    step()
+    env.sync()
+    first_encode_s = time.perf_counter() - t0
 
-    # roofline leg: HIP events on the context's stream around whole Compare chains
-    L = guetzli_amd.load()
-    with L.context(rgb, TARGET_Q95, device=local_rank) as ctx:
-        ctx.encode_rgb(download=False)
-        ctx.quantize(np.full((3, 64), 3, np.int32), download=False)
-        ctx.time_compare(5)
-        iters = 50
-        ms = ctx.time_compare(iters) / iters
-    achieved = ALGO_BYTES_PER_PX * W * H / (ms * 1e-3) / 1e9
-    ms_4k = None
+    dt, (jpg, info) = timed_steps(env, step, args.steps, args.warmup)
+    dt4k = jpg4k = info4k = None
+    if not args.no_4k:
+        dt4k, (jpg4k, info4k) = timed_steps(env, step4k, args.steps, args.warmup)
+
+    # roofline legs: HIP events on the context's stream around whole Compare chains
+    ms, achieved = roofline_of(L, rgb, local_rank, 2 if emu else 50, 1 if emu else 5)
+    ms_4k = achieved_4k = None
     if rank == 0:
-        with L.context(images.tiled(3840, 2160), TARGET_Q95, device=local_rank) as ctx:
-            ctx.encode_rgb(download=False)
-            ctx.quantize(np.full((3, 64), 3, np.int32), download=False)
-            ctx.time_compare(3)
-            ms_4k = ctx.time_compare(20) / 20
+        ms_4k, achieved_4k = roofline_of(L, images.tiled(W4, H4), local_rank, 1 if emu else 20, 1 if emu else 3)
     # batch leg (BASELINE config 5 in miniature, rank 0): independent images in flight on one
     # GPU at the same time, one host thread each; reported beside `value`, never instead of it
     batch = None
     if rank == 0 and world == 1 and args.batch_images > 0:
         from guetzli_amd.batch import encode_concurrent
         imgs = [images.shifted(images.tiled(W, H), k) for k in range(args.batch_images)]
-        proc = lambda im: host.process(im, quality=QUALITY, device=local_rank)
+        proc = lambda im: host.process(im, quality=quality, device=local_rank)
         encode_concurrent(imgs[:args.batch_workers], proc, args.batch_workers)   # warm-up
-        torch.cuda.synchronize()
+        env.sync()
         tb = time.perf_counter()
         outs = encode_concurrent(imgs, proc, args.batch_workers)
-        torch.cuda.synchronize()
+        env.sync()
         tb = time.perf_counter() - tb
-        assert hashlib.sha256(outs[0][0]).hexdigest() == GOLDEN_SHA_1080P_Q95
+        assert emu or hashlib.sha256(outs[0][0]).hexdigest() == GOLDEN_SHA_1080P_Q95
         batch = {"images": args.batch_images, "in_flight": args.batch_workers,
                  "value": round(args.batch_images * W * H / 1e6 / tb, 4), "unit": "MPix/s",
                  "seconds": round(tb, 3),
-                 "note": "independent 1920x1080 images, several in flight on ONE GPU (one host "
+                 "note": f"independent {W}x{H} images, several in flight on ONE GPU (one host "
                          "thread + one device context each); output 0 checked against the "
                          "reference JPEG"}
-    # BASELINE configs[2] and [3] (one 3840x2160 image at quality 95 / 84), steady state:
-    # one untimed and one timed encode each, beside -- never instead of -- `value`
+    # BASELINE configs[3] (one 3840x2160 image at quality 84), steady state: one untimed and one
+    # timed encode, beside -- never instead of -- `value`
     other = None
-    if rank == 0 and world == 1 and not args.no_4k:
+    if rank == 0 and world == 1 and not args.no_4k and not emu:
         other = {}
-        img4k = images.tiled(3840, 2160)
-        for q, golden in ((95, GOLDEN_SHA_4K[95]), (84, GOLDEN_SHA_4K[84])):
-            host.process(img4k, quality=q, device=local_rank)
-            torch.cuda.synchronize()
-            t4 = time.perf_counter()
-            j4, i4 = host.process(img4k, quality=q, device=local_rank)
-            t4 = time.perf_counter() - t4
-            assert hashlib.sha256(j4).hexdigest() == golden
-            other[f"3840x2160_q{q}"] = {"seconds": round(t4, 3),
-                                        "value": round(3840 * 2160 / 1e6 / t4, 3), "unit": "MPix/s",
-                                        "iterations": i4["counters"].get("number of iterations"),
-                                        "output_sha256_matches_reference": True}
+        img4k = images.tiled(W4, H4)
+        host.process(img4k, quality=84, device=local_rank)
+        env.sync()
+        t4 = time.perf_counter()
+        j4, i4 = host.process(img4k, quality=84, device=local_rank)
+        t4 = time.perf_counter() - t4
+        assert hashlib.sha256(j4).hexdigest() == GOLDEN_SHA_4K[84]
+        other["3840x2160_q84"] = {"seconds": round(t4, 3), "value": round(W4 * H4 / 1e6 / t4, 3),
+                                  "unit": "MPix/s",
+                                  "iterations": i4["counters"].get("number of iterations"),
+                                  "output_sha256_matches_reference": True}
     c5 = None
     if not args.no_4k and not args.no_config5:   # every rank takes part
-        c5 = config5_leg(host, images, torch, dist, rank, world, local_rank, args.images_per_gpu,
-                         args.in_flight, size5)
+        c5 = config5_leg(env, host, images, args.images_per_gpu, args.in_flight, size5, quality)
     traffic = {}
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_compare_pmc_traffic.json")))
-    except Exception:
-        pass
+    for path in (TRAFFIC_JSON, TRAFFIC_JSON_OLD):
+        try:
+            traffic = json.load(open(path))
+            traffic.setdefault("source", os.path.relpath(path, ROOT))
+            break
+        except Exception:
+            pass
 
     if rank == 0:
-        sha = hashlib.sha256(jpg).hexdigest()
-        assert sha == GOLDEN_SHA_1080P_Q95, f"output JPEG differs from the reference: {sha}"
+        if not emu:
+            sha = hashlib.sha256(jpg).hexdigest()
+            assert sha == GOLDEN_SHA_1080P_Q95, f"output JPEG differs from the reference: {sha}"
+            if jpg4k is not None:
+                sha = hashlib.sha256(jpg4k).hexdigest()
+                assert sha == GOLDEN_SHA_4K[95], f"3840x2160 output JPEG differs from the reference: {sha}"
+        timer_keys = ("total", "phase_b_host", "compare", "block_search", "jpeg_write", "create+encode",
+                      "select_quant_matrix", "pb_device_partitions", "pb_device_descents",
+                      "pb_device_fetches", "pb_loop_codes")
         out = {
             "metric": "MPix/s encoded at --quality 95",
             "value": round(world * args.steps * W * H / 1e6 / dt, 4),
@@ -285,27 +407,30 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+f64 (butteraugli), int32/int16 (DCT/quantize/entropy coding)",
-            "data": "synthetic (tests/golden/bees.png tiled to 1920x1080, SURVEY 8d)",
-            "config": {"workload": "single 1920x1080 sRGB image, --quality 95, whole "
+            "data": f"synthetic (tests/golden/bees.png tiled to {W}x{H}, SURVEY 8d)",
+            "config": {"workload": f"single {W}x{H} sRGB image, --quality {quality:g}, whole "
                                    "guetzli::Process per step (host RGB in, JPEG bytes out), "
                                    "1 image per GPU per step",
                        "butteraugli_target": TARGET_Q95, "images_per_gpu": 1,
-                       "output_bytes": len(jpg), "output_sha256_matches_reference": True,
+                       "output_bytes": len(jpg), "output_sha256_matches_reference": not emu,
                        "iterations": info["counters"].get("number of iterations")},
+            "first_encode_s": round(first_encode_s, 3),
             "roofline": {"bound": "hbm",
                          "kernel": CHAIN,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic.get("1080p", {}).get("traffic_bytes"),
+                         "traffic_head": traffic.get("head"), "traffic_source": traffic.get("source"),
                          "ms_per_compare": round(ms, 4),
                          "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W * H},
-            "roofline_4k": {"bound": "hbm", "kernel": CHAIN, "workload": "3840x2160 (configs[2])",
-                            "achieved": round(ALGO_BYTES_PER_PX * 3840 * 2160 / (ms_4k * 1e-3) / 1e9, 1),
+            "roofline_4k": {"bound": "hbm", "kernel": CHAIN, "workload": f"{W4}x{H4} (configs[2])",
+                            "achieved": round(achieved_4k, 1),
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": round(ALGO_BYTES_PER_PX * 3840 * 2160 / (ms_4k * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "frac": round(achieved_4k / HBM_PEAK_GBPS, 4),
                             "traffic": traffic.get("4k", {}).get("traffic_bytes"),
+                            "traffic_head": traffic.get("head"),
                             "ms_per_compare": round(ms_4k, 4),
-                            "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * 3840 * 2160},
+                            "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W4 * H4},
             # phase A (not HBM-bound -- reported in evaluations, not bytes)
             "block_search": {"evaluations": info["counters"].get("block search evaluations"),
                              "seconds": round(info["timers"].get("block_search", 0.0), 4),
@@ -314,23 +439,38 @@ def main():
                              "note": "CompareBlock evaluations (one 8x8 IDCT + colour + opsin + FFT "
                                      "distance each) of gz_block_zeroing_orders; VALU utilisation of "
                                      "k_block_search: profiles/r02_block_search_pmc.csv"},
-            "host_timers_s": {k: round(v, 3) for k, v in info["timers"].items()
-                              if k in ("total", "phase_b_host", "compare", "block_search",
-                                       "jpeg_write", "create+encode", "select_quant_matrix")},
+            "host_timers_s": {k: round(v, 3) for k, v in info["timers"].items() if k in timer_keys},
         }
+        if dt4k is not None:
+            out["value_4k"] = round(world * args.steps * W4 * H4 / 1e6 / dt4k, 4)
+            out["ms_per_step_4k"] = round(dt4k / args.steps * 1e3, 2)
+            out["config_4k"] = {"workload": f"single {W4}x{H4} sRGB image, --quality {quality:g} (BASELINE "
+                                            "configs[2]), whole guetzli::Process per step, 1 image per GPU "
+                                            f"per step; {args.steps} timed steps after {args.warmup} warm-up, "
+                                            "bracketed like `value`",
+                                "steps": args.steps, "warmup": args.warmup, "output_bytes": len(jpg4k),
+                                "output_sha256_matches_reference": not emu,
+                                "iterations": info4k["counters"].get("number of iterations"),
+                                "host_timers_s": {k: round(v, 3) for k, v in info4k["timers"].items()
+                                                  if k in timer_keys}}
         if c5 is not None:
             other = dict(other or {})
             other["config5_slice"] = c5
+            out["scale_value"] = c5["value"]
+            out["scale_metric"] = ("MPix/s over BASELINE config 5's batch slice: 8 independent 3840x2160 "
+                                   "images per GPU, 8 in flight per GPU")
         if other is not None:
             out["other_configs"] = other
         if batch is not None:
             out["batch_one_gpu"] = batch
-        if world == 1 and not args.no_cpu_baseline:
+        if not emu:
+            cal = box_calibration()
+            if cal:
+                out["box"] = cal
+        if world == 1 and not args.no_cpu_baseline and not emu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()   # rank 0 has the extra legs: leave together
-        dist.destroy_process_group()
+    env.finish()
 
 
 if __name__ == "__main__":

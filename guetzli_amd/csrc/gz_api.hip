@@ -838,7 +838,7 @@ int stage_separate(gz_ctx* c, Psycho* ps) {
 // queued there (the SameNoise blur, the shorter of the two side branches) instead of between
 // the two radius-20 blurs of this stream.
 int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullptr) {
-  dim3 grid(gz_div_up(c->w, 1024), gz_div_up(c->h, kMaskRows), 2);
+  dim3 grid(gz_div_up(c->w, 1024), c->h, 2);
   GZ_LAUNCH(k_mask_pre, grid, dim3(256), c->stream, pk, c->w, c->h, c->pitch);
   KCHK(c);
   if (other) {
@@ -966,10 +966,7 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[2] = {p0.mf[ch], p1.mf[ch], ms[ch][2].nm, ms[ch][2].lf};
     a.out = c->ac[ch];
   }
-  // GZ_MALTA_DMA=0: every pass staged through registers (round 2's kernel path); read per call
-  const char* dma_env = getenv("GZ_MALTA_DMA");
-  const int malta_opt = (dma_env && atoi(dma_env) == 0) ? 0 : 1;
-  GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch, malta_opt);
+  GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);
   TRY(join_mask_branch(c));
   {

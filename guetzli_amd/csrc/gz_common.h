@@ -92,22 +92,6 @@ GZ_DEVFN gz_f2 gz_f2_splat(float x) {
 #define GZ_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
-// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4: no register in
-// between, the wave goes on while the data is in flight): lane l's bytes land at
-// lds_wave_base + 16 * l -- the destination is ONE address for the wavefront plus the lane
-// number, only the source is per lane.  GZ_GLDS_WAIT(): everything so requested has arrived
-// (to be followed by a barrier before other waves read it).
-#ifdef GZ_EMU
-#define GZ_GLDS16(gsrc, lds_wave_base) \
-  __builtin_memcpy((float*)(lds_wave_base) + 4 * ((int)threadIdx.x & 63), (gsrc), 16)
-#define GZ_GLDS_WAIT() ((void)0)
-#else
-#define GZ_GLDS16(gsrc, lds_wave_base)                                                             \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),         \
-                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
-#define GZ_GLDS_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
-
 // A point where the lanes of a wavefront must have executed everything before it (loads
 // before a store to the same LDS row by a neighbouring lane).  On the GPU a wavefront has one
 // instruction stream, so there is nothing to do; the emulation's threads are fibers that run one

@@ -43,75 +43,40 @@ struct MaskPrePack {
   float* out[2];
 };
 
-// grid = (ceil(w/1024), ceil(h/kMaskRows), 2): a thread takes 4 consecutive pixels of a row
-// (16-byte accesses when the row pitch allows it) and walks down kMaskRows rows, keeping the row
-// below -- which every output needs -- in registers as the next row's own samples: the inputs
-// are read 1 + 1/kMaskRows times instead of twice (round 2 took one row per workgroup; its 84 us
-// at 4K were 14 plane passes through the L2 for 8 of compulsory traffic).
-constexpr int kMaskRows = 8;
-
-struct MaskRow4 {   // 4 consecutive mixed samples of one image's row + the sample right of them
-  gz_f4 v;
-  float r;
-};
-GZ_DEVFN MaskRow4 mask_row4(const MaskIn& in, size_t row, int x, int xr) {
-  MaskRow4 o;
-  o.v = in.load4(row + x);
-  o.r = in(row + xr);
-  return o;
-}
-
+// grid = (ceil(w/1024), h, 2): a thread takes 4 consecutive pixels of a row -- 16-byte
+// loads of the row and of the row below, one 16-byte store -- when the row pitch allows it.
 __global__ __launch_bounds__(256) void k_mask_pre(MaskPrePack pk, int w, int h, int pitch) {
-  // bands in XCD-aware order: the row below a band's last row (read by this band and by the
-  // next one) then comes from the same L2
+  // rows in XCD-aware order: row y + 1 (read by this row's workgroups and by the next row's)
+  // then comes from the same L2
   const GzTile bid = gz_xcd_tile();
-  const int x = (bid.x * (int)blockDim.x + (int)threadIdx.x) * 4, y0 = bid.y * kMaskRows;
-  if (x >= w || y0 >= h) return;
+  const int x = (bid.x * (int)blockDim.x + (int)threadIdx.x) * 4, y = bid.y;
+  if (x >= w || y >= h) return;
   const int c = bid.z;
   MaskIn a = pk.in0[0], b = pk.in1[0];
   float* out = pk.out[0];
   if (c == 1) { a = pk.in0[1]; b = pk.in1[1]; out = pk.out[1]; }
+  // mirrored neighbour at the last column / row (butteraugli.cc:1706-1725)
+  const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
   if ((pitch & 3) == 0 && x + 3 < w) {
+    const size_t i = (size_t)y * pitch + x, id = (size_t)y2 * pitch + x;
+    const gz_f4 a0 = a.load4(i), ad = a.load4(id), b0 = b.load4(i), bd = b.load4(id);
     // right neighbour of the 4th pixel: the next column, or mirrored at the last column
-    // (butteraugli.cc:1706-1725); the neighbour below: the next row, mirrored at the last row
     const int xr = x + 4 < w ? x + 4 : x + 2;
-    MaskRow4 a0 = mask_row4(a, (size_t)y0 * pitch, x, xr), b0 = mask_row4(b, (size_t)y0 * pitch, x, xr);
-    MaskRow4 ap = a0, bp = b0;   // the row above (for the mirrored last row)
-#pragma unroll 1
-    for (int r = 0; r < kMaskRows; ++r) {
-      const int y = y0 + r;
-      if (y >= h) break;
-      MaskRow4 ad, bd;
-      if (y + 1 < h) {
-        ad = mask_row4(a, (size_t)(y + 1) * pitch, x, xr);
-        bd = mask_row4(b, (size_t)(y + 1) * pitch, x, xr);
-      } else if (y > 0) {
-        if (r > 0) { ad = ap; bd = bp; }
-        else { ad = mask_row4(a, (size_t)(y - 1) * pitch, x, xr); bd = mask_row4(b, (size_t)(y - 1) * pitch, x, xr); }
-      } else {
-        ad = a0; bd = b0;
-      }
-      gz_f4 o;
+    const float ar = a((size_t)y * pitch + xr), br = b((size_t)y * pitch + xr);
+    gz_f4 o;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        o.v[k] = diff_precompute_px(a0.v.v[k], k < 3 ? a0.v.v[k < 3 ? k + 1 : 3] : a0.r, ad.v.v[k],
-                                    b0.v.v[k], k < 3 ? b0.v.v[k < 3 ? k + 1 : 3] : b0.r, bd.v.v[k]);
-      GZ_STG4(out, (size_t)y * pitch + x, o);
-      ap = a0; bp = b0;
-      a0 = ad; b0 = bd;
-    }
+    for (int k = 0; k < 4; ++k)
+      o.v[k] = diff_precompute_px(a0.v[k], k < 3 ? a0.v[k < 3 ? k + 1 : 3] : ar, ad.v[k], b0.v[k],
+                                  k < 3 ? b0.v[k < 3 ? k + 1 : 3] : br, bd.v[k]);
+    GZ_STG4(out, i, o);
     return;
   }
-  for (int r = 0; r < kMaskRows && y0 + r < h; ++r) {
-    const int y = y0 + r;
-    const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
-    for (int k = 0; k < 4 && x + k < w; ++k) {
-      const int xx = x + k;
-      const int x2 = xx + 1 < w ? xx + 1 : (xx > 0 ? xx - 1 : xx);
-      const size_t i = (size_t)y * pitch + xx, ir = (size_t)y * pitch + x2,
-                   id = (size_t)y2 * pitch + xx;
-      out[i] = diff_precompute_px(a(i), a(ir), a(id), b(i), b(ir), b(id));
-    }
+  for (int k = 0; k < 4 && x + k < w; ++k) {
+    const int xx = x + k;
+    const int x2 = xx + 1 < w ? xx + 1 : (xx > 0 ? xx - 1 : xx);
+    const size_t i = (size_t)y * pitch + xx, ir = (size_t)y * pitch + x2,
+                 id = (size_t)y2 * pitch + xx;
+    out[i] = diff_precompute_px(a(i), a(ir), a(id), b(i), b(ir), b(id));
   }
 }
 
@@ -166,49 +131,14 @@ struct MaltaArgs {
   float* out;
 };
 
-// The haloed tile of one plane as 16-byte vectors, lane-linear: vector i = row i / 18, columns
-// 4 (i % 18) ... of the tile, which is also where it sits in the [MH + 8][MW + 8] array.
-constexpr int kMaltaVecs = (MH + 8) * ((MW + 8) / 4);   // 720
-constexpr int kMaltaTile = (MH + 8) * (MW + 8);         // floats
-
-// Requests the raw samples of one plane's haloed tile (all inside the image) into `raw` (LDS).
-GZ_DEVFN void malta_request(const float* __restrict__ plane, float* raw, int x0, int y0, int pitch) {
-  const int tid = (int)threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < (kMaltaVecs + 255) / 256; ++k) {
-    const int i = 256 * k + tid;
-    // (one destination per wavefront: its first lane's vector)
-    float* dst = raw + 4 * GZ_WAVE_UNIFORM(256 * k + (tid & ~63));
-    if (i < kMaltaVecs) {
-      const int ry = i / ((MW + 8) / 4), q = i - ry * ((MW + 8) / 4);
-      GZ_GLDS16(plane + ((size_t)(y0 - 4 + ry) * pitch + (x0 - 4 + 4 * q)), dst);
-    }
-  }
-}
-
 // grid = (ceil(w/MW), ceil(h/MH), 2): blockIdx.z = channel (a0: Y, a1: X) -- the two
-// channels are independent, one launch fills the chip better than two.
-//
-// opt & 1 (tiles whose haloed tile lies inside the image): the two planes of a pass travel from
-// global memory into LDS without passing through registers (global_load_lds_dwordx4), and the
-// request for the NEXT pass is issued before this pass's line sums: a pass's ~190 us of staging
-// at 4K was two thirds memory time (12 planes + 41 % halo) that nothing overlapped -- prefetching
-// through registers cost more in occupancy than it gained (profiles/
-// r02_malta_register_window_experiment.log), this costs LDS (2 x 11.5 KB) instead.  The
-// per-sample term is then computed LDS -> LDS.
-// (__launch_bounds__(256, 4): four waves per SIMD, i.e. at most 128 VGPRs -- the 34.5 KB of LDS
-// allow four workgroups per CU, and the kernel needs every one of them to hide its latencies)
+// channels are independent, one launch fills the chip better than two
 template <int NPASS>
-__global__ __launch_bounds__(256, 4) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs<NPASS> a1, int w,
-                                               int h, int pitch, int opt) {
+__global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs<NPASS> a1, int w,
+                                               int h, int pitch) {
   const GzTile bid = gz_xcd_tile();
   const MaltaArgs<NPASS>& a = bid.z ? a1 : a0;
-  // (one LDS object: with a second one the compiler drains the requests in flight before every
-  // LDS read, cdna_hip_programming.md)
-  __shared__ __attribute__((aligned(16))) float lds[3 * kMaltaTile];
-  float (*tile)[MW + 8] = reinterpret_cast<float (*)[MW + 8]>(lds);
-  float* raw0 = lds + kMaltaTile;
-  float* raw1 = lds + 2 * kMaltaTile;
+  __shared__ __attribute__((aligned(16))) float tile[MH + 8][MW + 8];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const int x0 = bid.x * MW, y0 = bid.y * MH;
   float acc[MPT];
@@ -217,67 +147,41 @@ __global__ __launch_bounds__(256, 4) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs
   // the haloed tile starts at x0 - 4: rows can be staged with aligned 16-byte loads when the
   // tile lies inside the image horizontally and the pitch allows it
   const bool vec = x0 >= 4 && x0 + MW + 4 <= w && (pitch & 3) == 0;
-  const bool direct = (opt & 1) && vec && y0 >= 4 && y0 + MH + 4 <= h;
-  if (direct) {
-    malta_request(a.pass[0].p0, raw0, x0, y0, pitch);
-    malta_request(a.pass[0].p1, raw1, x0, y0, pitch);
-  }
   for (int ps = 0; ps < NPASS; ++ps) {
     const MaltaPass P = a.pass[ps];
-    if (direct) {
-      GZ_GLDS_WAIT();
-      __syncthreads();   // this pass's samples are in; everybody is done with the previous tile
+    if (ps > 0) __syncthreads();
+    if (vec) {
+      constexpr int NV = (MH + 8) * ((MW + 8) / 4);   // 16-byte vectors in the tile
 #pragma unroll 1
-      for (int k = 0; k < (kMaltaVecs + 255) / 256; ++k) {
+      for (int k = 0; k < (NV + 255) / 256; ++k) {
         const int i = 256 * k + (int)threadIdx.x;
-        if (i < kMaltaVecs) {
-          const gz_f4 u0 = *reinterpret_cast<const gz_f4*>(raw0 + 4 * i);
-          const gz_f4 u1 = *reinterpret_cast<const gz_f4*>(raw1 + 4 * i);
+        if (i < NV) {
+          const int ry = i / ((MW + 8) / 4), q = i - ry * ((MW + 8) / 4);
+          const int y = y0 - 4 + ry;
           gz_f4 v;
+          v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
+          if (y >= 0 && y < h) {
+            const size_t idx = (size_t)y * pitch + (x0 - 4 + 4 * q);
+            const gz_f4 u0 = GZ_LDG4(P.p0, idx), u1 = GZ_LDG4(P.p1, idx);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], P.nm);
-          *reinterpret_cast<gz_f4*>(lds + 4 * i) = v;
+            for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], P.nm);
+          }
+          *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = v;
         }
-      }
-      __syncthreads();
-      if (ps + 1 < NPASS) {
-        malta_request(a.pass[ps + 1].p0, raw0, x0, y0, pitch);
-        malta_request(a.pass[ps + 1].p1, raw1, x0, y0, pitch);
       }
     } else {
-      if (ps > 0) __syncthreads();
-      if (vec) {
-#pragma unroll 1
-        for (int k = 0; k < (kMaltaVecs + 255) / 256; ++k) {
-          const int i = 256 * k + (int)threadIdx.x;
-          if (i < kMaltaVecs) {
-            const int ry = i / ((MW + 8) / 4), q = i - ry * ((MW + 8) / 4);
-            const int y = y0 - 4 + ry;
-            gz_f4 v;
-            v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
-            if (y >= 0 && y < h) {
-              const size_t idx = (size_t)y * pitch + (x0 - 4 + 4 * q);
-              const gz_f4 u0 = GZ_LDG4(P.p0, idx), u1 = GZ_LDG4(P.p1, idx);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], P.nm);
-            }
-            *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = v;
-          }
+      for (int i = threadIdx.x; i < (MH + 8) * (MW + 8); i += 256) {
+        const int ry = i / (MW + 8), rx = i - ry * (MW + 8);
+        const int x = x0 - 4 + rx, y = y0 - 4 + ry;
+        float v = 0.0f;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+          const size_t idx = (size_t)y * pitch + x;
+          v = malta_diff(GZ_LDG(P.p0, idx), GZ_LDG(P.p1, idx), P.nm);
         }
-      } else {
-        for (int i = threadIdx.x; i < (MH + 8) * (MW + 8); i += 256) {
-          const int ry = i / (MW + 8), rx = i - ry * (MW + 8);
-          const int x = x0 - 4 + rx, y = y0 - 4 + ry;
-          float v = 0.0f;
-          if (x >= 0 && x < w && y >= 0 && y < h) {
-            const size_t idx = (size_t)y * pitch + x;
-            v = malta_diff(GZ_LDG(P.p0, idx), GZ_LDG(P.p1, idx), P.nm);
-          }
-          tile[ry][rx] = v;
-        }
+        tile[ry][rx] = v;
       }
-      __syncthreads();
     }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < MPT; ++i) {
       const int ly = tg * MPT + i;

@@ -197,7 +197,19 @@ struct DeviceOrder : RangeDevice {
     ++n_partition;
     return rc == GZ_OK;
   }
+  // After a descent everything below the end of the range that holds the wanted position is
+  // going to be fetched, range by range; one copy brings it all (to where Fetch would put it).
+  bool Prefetch(size_t hi, void* base) {
+    Stopwatch w;
+    rc = gz_order_fetch(ctx, 0, hi, base);
+    t_fetch += w.lap();
+    n_fetched += (long)hi;
+    if (rc == GZ_OK) have_hi = hi;
+    return rc == GZ_OK;
+  }
+  size_t have_hi = 0;   // entries [0, have_hi) are on the host already
   bool Fetch(size_t lo, size_t hi, void* dst) override {
+    if (hi <= have_hi) return true;
     Stopwatch w;
     rc = gz_order_fetch(ctx, lo, hi, dst);
     t_fetch += w.lap();
@@ -808,6 +820,19 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
             rc = gz_order_descend(ctx_, want, device_threshold_, descend_levels_, dev_order.log, &levels);
             if (rc != GZ_OK) return Fail("gz_order_descend", rc);
             dev_order.log_n = levels;
+          }
+          if (dev_order.log_n > 0) {
+            // the range the descent ended in, and with it everything SelectPrefix will fetch
+            uint64_t flo = 0, fhi = n_order;
+            for (int l = 0; l < dev_order.log_n; ++l) {
+              const uint64_t cut = dev_order.log[3 * l + 2];
+              if (want < cut) fhi = cut; else flo = cut;
+            }
+            // (only when the descent got there: a range that is still large will be partitioned
+            // further on the device, and a copy taken now would be stale)
+            if (fhi - flo <= device_threshold_ && fhi <= ((size_t)1 << 19) &&
+                !dev_order.Prefetch((size_t)fhi, order.data()))
+              return Fail("gz_order_fetch", dev_order.rc);
           }
           t_pb_descend_ += fw.lap();
         }

@@ -1,0 +1,55 @@
+"""bench.py's own control flow at world size 2 on CPU: `bench.py --emulate` runs main() -- the
+process group, the timed bracket (barrier + max over ranks), the rank-0-only legs, the
+config-5 leg with its all-gather, the final barrier -- over gloo with the test-suite's CPU
+emulation of the kernels on tiny images, launched exactly as the driver launches the GPU run
+(python -m torch.distributed.run --nproc-per-node 2).  It checks the JSON contract of the one
+line rank 0 prints; it measures nothing."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _run(world, extra=()):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build_host()   # (built once here, not by two ranks at the same time)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    args = [os.path.join(ROOT, "bench.py"), "--emulate", "--gpus", str(world), "--steps", "1",
+            "--warmup", "0", "--no-cpu-baseline"] + list(extra)
+    if world == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", "29541"] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_main_two_ranks_gloo():
+    r = _run(2)
+    for k in CONTRACT:
+        assert k in r, k
+    assert r["n_gpus"] == 2 and r["steps"] == 1 and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["value"] > 0 and r["ms_per_step"] > 0 and r["higher_is_better"] is True
+    assert r["value_4k"] > 0 and r["ms_per_step_4k"] > 0 and r["config_4k"]["steps"] == 1
+    for key in ("roofline", "roofline_4k"):
+        assert r[key]["bound"] == "hbm" and r[key]["peak"] == 8000.0
+        assert abs(r[key]["frac"] - r[key]["achieved"] / r[key]["peak"]) < 1e-3
+    c5 = r["other_configs"]["config5_slice"]
+    assert c5["images"] == 2 * c5["images_per_gpu"] and c5["distinct_outputs"] == c5["images"]
+    assert r["scale_value"] == c5["value"]
+    assert "cpu_baseline" not in r and "batch_one_gpu" not in r   # N = 1 only
+
+
+def test_bench_config5_only_two_ranks_gloo():
+    r = _run(2, ["--config5", "--images-per-gpu", "1"])
+    assert r["n_gpus"] == 2 and r["config"]["images"] == 2 and r["value"] == r["config"]["value"]

@@ -91,15 +91,6 @@ def test_idct_multiply_add_variant(L, monkeypatch):
     pc.case_encode_quantize_reconstruct(L, 61, 43, x0=100, y0=50)
 
 
-def test_malta_staging_variants(L, monkeypatch):
-    """k_malta stages interior tiles through LDS-DMA (global_load_lds, the next pass requested
-    before this pass's line sums) by default; GZ_MALTA_DMA=0 takes every tile through registers.
-    An image with interior Malta tiles (haloed 72 x 40 tile inside the image), both ways."""
-    pc.case_compare(L, 444, 258, qscales=(6,))
-    monkeypatch.setenv("GZ_MALTA_DMA", "0")
-    pc.case_compare(L, 444, 258, qscales=(6,))
-
-
 def test_dct_double(L):
     pc.case_dct_double(L, n=20000)
 

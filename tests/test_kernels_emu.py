@@ -34,15 +34,6 @@ def test_idct_multiply_add_variant(L, monkeypatch):
     pc.case_encode_quantize_reconstruct(L, 61, 43, x0=100, y0=50)
 
 
-def test_malta_staging_variants(L, monkeypatch):
-    """k_malta stages interior tiles through LDS-DMA (global_load_lds, the next pass requested
-    before this pass's line sums) by default; GZ_MALTA_DMA=0 takes every tile through registers.
-    An image with interior Malta tiles (haloed 72 x 40 tile inside the image), both ways."""
-    pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
-    monkeypatch.setenv("GZ_MALTA_DMA", "0")
-    pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
-
-
 def test_dct_double(L):
     pc.case_dct_double(L, n=200)
 

@@ -55,6 +55,8 @@ SIGNATURES = {
     "gz_block_zeroing_orders": (_I, [_P, _I, _I, _P, _P, _P, _I]),
     "gz_block_zeroing_orders_masked": (_I, [_P, _I, _I, _I, _P, _P, _P, _I]),
     "gz_compare_blocks": (_I, [_P, _I, _P, _P, _P]),
+    "gz_compare_block_pixels": (_I, [_P, _I, _P, _P, _P]),
+    "gz_set_frame": (_I, [_P, _I]),
     "gz_search_evaluations": (_I, [_P, _P]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
     "gz_probe_rank_sort": (_I, [_I, _P, _P, _I, _P]),
@@ -224,8 +226,8 @@ class Context:
     def _chk(self, rc):
         self.L.check(rc, self.handle)
 
-    def _coeff_buf(self):
-        if self.cfac == 2:
+    def _coeff_buf(self, cfac=None):
+        if (cfac or self.cfac) == 2:
             return np.zeros((self.nb + 2 * self.nbc, 64), np.int16)
         return np.zeros((3, self.nb, 64), np.int16)
 
@@ -264,29 +266,29 @@ class Context:
     def set_orig_coeffs(self, coeffs):
         co = np.ascontiguousarray(coeffs, np.int16)
         assert co.size == 3 * self.nb * 64
-        self.cfac = 1
         self._chk(self.L.lib.gz_set_orig_coeffs(self.handle, _ptr(co)))
+        self.cfac = 1   # (only once the library has switched its frame)
 
     def set_orig_coeffs_420(self, coeffs):
         co = np.ascontiguousarray(coeffs, np.int16)
         assert co.size == (self.nb + 2 * self.nbc) * 64
-        self.cfac = 2
         self._chk(self.L.lib.gz_set_orig_coeffs_420(self.handle, _ptr(co)))
+        self.cfac = 2
 
     def downsample(self, download=True):
         """OutputImage::Downsample on the original: the frame becomes 4:2:0."""
-        self.cfac = 2
-        out = self._coeff_buf() if download else None
+        out = self._coeff_buf(2) if download else None
         self._chk(self.L.lib.gz_downsample(self.handle, _ptr(out)))
+        self.cfac = 2   # (a failed call leaves the 4:4:4 layout in place on both sides)
         return out
 
     def downsample_planes(self, y, u, v, download=True):
         """The silver-screen branch of OutputImage::Downsample, given RGBToYUV420's planes."""
         pl = [np.ascontiguousarray(p, np.float32) for p in (y, u, v)]
         assert all(p.size == self.w * self.h for p in pl)
-        self.cfac = 2
-        out = self._coeff_buf() if download else None
+        out = self._coeff_buf(2) if download else None
         self._chk(self.L.lib.gz_downsample_planes(self.handle, _ptr(pl[0]), _ptr(pl[1]), _ptr(pl[2]), _ptr(out)))
+        self.cfac = 2
         return out
 
     def quantize(self, q=None, download=True):
@@ -388,6 +390,19 @@ class Context:
         out = np.zeros(len(xy), np.float64)
         self._chk(self.L.lib.gz_compare_blocks(self.handle, len(xy), _ptr(xy), _ptr(co), _ptr(out)))
         return out
+
+    def compare_block_pixels(self, block_xy, ycc):
+        """SwitchBlock + CompareBlock for n 8x8 windows given by their YCbCr pixels (n x 3 x 64 u8)."""
+        xy = np.ascontiguousarray(block_xy, np.int32).reshape(-1, 2)
+        px = np.ascontiguousarray(ycc, np.uint8).reshape(-1, 3, 64)
+        assert len(xy) == len(px)
+        out = np.zeros(len(xy), np.float64)
+        self._chk(self.L.lib.gz_compare_block_pixels(self.handle, len(xy), _ptr(xy), _ptr(px), _ptr(out)))
+        return out
+
+    def set_frame(self, chroma_factor):
+        self._chk(self.L.lib.gz_set_frame(self.handle, int(chroma_factor)))
+        self.cfac = int(chroma_factor)
 
     # ---- global candidate order of phase B ----
     ORDER_DTYPE = np.dtype([("block", np.int32), ("val", np.float32)])

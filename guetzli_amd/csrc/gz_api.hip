@@ -442,6 +442,7 @@ struct gz_ctx {
   // pinned landing area for the small results every call waits for (a copy into pageable
   // memory costs 27 us per round trip on this system, into pinned memory 15)
   void* h_res = nullptr; size_t h_res_cap = 0;
+  void* d_cmp_stage = nullptr; size_t cmp_stage_cap = 0;   // gz_compare_blocks / _block_pixels staging
   size_t search_total = 0;   // candidates phase A produced (bounds every global order)
   unsigned long long search_evaluations = 0;   // CompareBlock evaluations of the last block search
   float last_distance = 0.0f;
@@ -1382,6 +1383,7 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->d_part); (void)pool_free(c->d_order_nb); (void)pool_free(c->d_order_off);
   if (c->h_order_pending) (void)pool_host_free(c->h_order_pending);
   if (c->h_desc) (void)pool_host_free(c->h_desc);
+  (void)pool_free(c->d_cmp_stage);
   (void)pool_free(c->d_desc_st); (void)pool_free(c->d_desc_pv);
   (void)pool_free(c->d_order_counters); (void)pool_free(c->d_next_cand); (void)pool_free(c->d_weight);
   (void)pool_free(c->d_max_err); (void)pool_free(c->d_wflag); (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
@@ -1457,6 +1459,7 @@ int gz_set_orig_coeffs_420(gz_ctx* c, const int16_t* coeffs) {
 }
 
 int gz_frame_layout(gz_ctx* c, int* chroma_factor, int* luma_blocks, int* chroma_blocks) {
+  DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   if (chroma_factor) *chroma_factor = c->cfac;
   if (luma_blocks) *luma_blocks = c->nb;
@@ -2740,32 +2743,80 @@ int gz_compare_blocks(gz_ctx* c, int n, const int32_t* block_xy, const int16_t* 
   for (int i = 0; i < n; ++i)
     if (block_xy[2 * i] < 0 || block_xy[2 * i] >= c->bw || block_xy[2 * i + 1] < 0 || block_xy[2 * i + 1] >= c->bh)
       return GZ_E_ARG;
+  if (c->cfac != 1) { c->err = "gz_compare_blocks takes coefficient blocks of a 4:4:4 frame (gz_compare_block_pixels serves any frame)"; return GZ_E_STATE; }
   TRY(ensure_block_mask(c));
-  // staging: positions, coefficients and results share one device block
+  // staging: positions, coefficients and results share one device block kept by the context
   const size_t need = (size_t)n * (8 + 384 + 8);
-  void* dev = nullptr;
-  HIPCHK(c, pool_malloc(&dev, need));
-  int32_t* d_xy = (int32_t*)dev;
-  double* d_out = (double*)((char*)dev + (size_t)n * 8);
-  int16_t* d_blk = (int16_t*)((char*)dev + (size_t)n * 16);
-  int rc = GZ_OK;
-  if (hipMemcpyAsync(d_xy, block_xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipMemcpyAsync(d_blk, coeffs, (size_t)n * 384, hipMemcpyHostToDevice, c->stream) != hipSuccess)
-    rc = GZ_E_HIP;
-  if (rc == GZ_OK) {
-    SearchArgs a;
-    search_args_common(c, &a);
-    GZ_LAUNCH(k_compare_blocks, dim3(n), dim3(64), c->stream, a, (const int32_t*)d_xy, (const int16_t*)d_blk, n, d_out);
-    if (hipGetLastError() != hipSuccess) rc = GZ_E_HIP;
+  if (need > c->cmp_stage_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)pool_free(c->d_cmp_stage);
+    c->d_cmp_stage = nullptr;
+    c->cmp_stage_cap = 0;
+    const size_t cap = std::max<size_t>(need, 4096);
+    HIPCHK(c, pool_malloc(&c->d_cmp_stage, cap));
+    c->cmp_stage_cap = cap;
   }
-  if (rc == GZ_OK && hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = GZ_E_HIP;
-  if (hipStreamSynchronize(c->stream) != hipSuccess) rc = GZ_E_HIP;
-  pool_free(dev);
-  if (rc != GZ_OK) c->err = "gz_compare_blocks: HIP call failed";
-  return rc;
+  int32_t* d_xy = (int32_t*)c->d_cmp_stage;
+  double* d_out = (double*)((char*)c->d_cmp_stage + (size_t)n * 8);
+  int16_t* d_blk = (int16_t*)((char*)c->d_cmp_stage + (size_t)n * 16);
+  HIPCHK(c, hipMemcpyAsync(d_xy, block_xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_blk, coeffs, (size_t)n * 384, hipMemcpyHostToDevice, c->stream));
+  SearchArgs a;
+  search_args_common(c, &a);
+  GZ_LAUNCH(k_compare_blocks, dim3(n), dim3(64), c->stream, a, (const int32_t*)d_xy, (const int16_t*)d_blk, n, d_out);
+  KCHK(c);
+  HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_compare_block_pixels(gz_ctx* c, int n, const int32_t* block_xy, const uint8_t* ycc, double* out) {
+  DeviceScope ds_(c);
+  if (!c || n < 0 || (n > 0 && (!block_xy || !ycc || !out))) return GZ_E_ARG;
+  if (n == 0) return GZ_OK;
+  for (int i = 0; i < n; ++i)
+    if (block_xy[2 * i] < 0 || block_xy[2 * i] >= c->bw || block_xy[2 * i + 1] < 0 || block_xy[2 * i + 1] >= c->bh)
+      return GZ_E_ARG;
+  TRY(ensure_block_mask(c));
+  // staging: positions, pixels and results share one device block kept by the context
+  const size_t need = (size_t)n * (8 + 8 + 192);
+  if (need > c->cmp_stage_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)pool_free(c->d_cmp_stage);
+    c->d_cmp_stage = nullptr;
+    c->cmp_stage_cap = 0;
+    const size_t cap = std::max<size_t>(need, 4096);
+    HIPCHK(c, pool_malloc(&c->d_cmp_stage, cap));
+    c->cmp_stage_cap = cap;
+  }
+  int32_t* d_xy = (int32_t*)c->d_cmp_stage;
+  double* d_out = (double*)((char*)c->d_cmp_stage + (size_t)n * 8);
+  uint8_t* d_px = (uint8_t*)c->d_cmp_stage + (size_t)n * 16;
+  HIPCHK(c, hipMemcpyAsync(d_xy, block_xy, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_px, ycc, (size_t)n * 192, hipMemcpyHostToDevice, c->stream));
+  SearchArgs a;
+  search_args_common(c, &a);
+  GZ_LAUNCH(k_compare_block_pixels, dim3(n), dim3(64), c->stream, a, (const int32_t*)d_xy,
+            (const uint8_t*)d_px, n, d_out);
+  KCHK(c);
+  HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GZ_OK;
+}
+
+int gz_set_frame(gz_ctx* c, int chroma_factor) {
+  DeviceScope ds_(c);
+  if (!c || (chroma_factor != 1 && chroma_factor != 2)) return GZ_E_ARG;
+  if (c->cfac == chroma_factor) return GZ_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  set_frame(c, chroma_factor);
+  c->have_cand = false;
+  c->have_orig = false;   // the original coefficients on the device belonged to the other frame
+  return GZ_OK;
 }
 
 int gz_search_evaluations(gz_ctx* c, uint64_t* evaluations) {
+  DeviceScope ds_(c);
   if (!c || !evaluations) return GZ_E_ARG;
   *evaluations = c->search_evaluations;
   return GZ_OK;

@@ -587,6 +587,68 @@ __global__ __launch_bounds__(64) void k_compare_blocks(SearchArgs a, const int32
   }
 }
 
+// The same for windows given by their YCbCr PIXELS (what CompareBlock reads of the image:
+// OutputImage::ToLinearRGB(xmin, ymin, 8, 8) <- OutputImageComponent::ToPixels, output_image.cc:
+// 69-96, edge replication included) -- the form of the seam that serves every frame: the pixels
+// of a subsampled component depend on its neighbours' blocks, which only the caller's
+// OutputImage holds.  ycc: n x 3 x 64 bytes (Y, Cb, Cr of a window one after the other).
+__global__ __launch_bounds__(64) void k_compare_block_pixels(SearchArgs a, const int32_t* __restrict__ block_xy,
+                                                             const uint8_t* __restrict__ ycc, int n,
+                                                             double* __restrict__ out) {
+  __shared__ SearchLds s;
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int bx = block_xy[2 * i], by = block_xy[2 * i + 1];
+  const int xmin = 8 * bx, ymin = 8 * by;
+  const int iy = lane >> 3, ix = lane & 7;
+  for (int k = lane; k < 256; k += 64) s.lut[k] = a.srgb_lut[k];
+  __syncthreads();
+  {
+    const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
+    const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
+    const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
+    s.lin[0][lane] = s.lut[p[0]];
+    s.lin[1][lane] = s.lut[p[1]];
+    s.lin[2][lane] = s.lut[p[2]];
+    __syncthreads();
+    float x0, y0, z0;
+    opsin8x8(s, lane, a, &x0, &y0, &z0);
+    s.x0[0][lane] = x0;
+    s.x0[1][lane] = y0;
+    s.x0[2][lane] = z0;
+  }
+  {
+    const uint8_t* p = ycc + (size_t)i * 192;
+    int r, g, b;
+    ycc_to_rgb((int)p[lane], (int)p[64 + lane], (int)p[128 + lane], &r, &g, &b);
+    s.lin[0][lane] = s.lut[r];
+    s.lin[1][lane] = s.lut[g];
+    s.lin[2][lane] = s.lut[b];
+    __syncthreads();
+    float x, y, z;
+    opsin8x8(s, lane, a, &x, &y, &z);
+    s.d[0][0][lane] = (double)s.x0[0][lane] - (double)x;
+    s.d[0][1][lane] = (double)s.x0[1][lane] - (double)y;
+    s.d[0][2][lane] = (double)s.x0[2][lane] - (double)z;
+    __syncthreads();
+  }
+  SearchView v;
+  v.off_x = v.off_y = 0;
+  v.in_image = true;
+  v.vw = v.vh = 8;
+  const int mb = by * a.bw + bx;
+  v.m0 = a.block_mask[mb];
+  v.m1 = a.block_mask[a.nb + mb];
+  v.m2 = a.block_mask[2 * a.nb + mb];
+  eval_narrow(s, 1, lane, v);
+  if (lane == 0) {
+    double diff = 0.0;
+    diff += s.red[0][0] * (double)v.m0;
+    diff += s.red[0][1] * (double)v.m1;
+    diff += s.red[0][2] * (double)v.m2;
+    out[i] = sqrt(diff);
+  }
+}
+
 // Picks mask planes at block corners: out[c][blk] = mask[c](8*by, 8*bx).
 __global__ __launch_bounds__(256) void k_gather_block_corners(const float* m0, const float* m1,
                                                               const float* m2, int pitch, int bw,

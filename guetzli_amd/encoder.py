@@ -11,6 +11,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_HOST_LIB = os.path.join(HERE, "libguetzli_amd_host.so")
 
 
+def _jpeg_dimensions(data):
+    """(width, height) of the first SOFn segment of a JPEG stream, (0, 0) if there is none."""
+    i, n = 2, len(data)
+    while i + 9 < n:
+        if data[i] != 0xFF:
+            i += 1
+            continue
+        m = data[i + 1]
+        if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7 or m == 0xFF:
+            i += 2 if m != 0xFF else 1
+            continue
+        seg = (data[i + 2] << 8) | data[i + 3]
+        if 0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
+            return (data[i + 7] << 8) | data[i + 8], (data[i + 5] << 8) | data[i + 6]
+        i += 2 + seg
+    return 0, 0
+
+
 class HostLibrary:
     def __init__(self, path=DEFAULT_HOST_LIB):
         if not os.path.exists(path):
@@ -49,7 +67,13 @@ class HostLibrary:
         """gzh_process_params with a buffer that grows to what the library asks for."""
         is_jpeg = isinstance(data, (bytes, bytearray))
         buf = np.frombuffer(data, np.uint8) if is_jpeg else data
-        cap = max(4 * len(data), 1 << 20) if is_jpeg else 3 * w * h + (1 << 16)
+        if is_jpeg:
+            # from the frame header's dimensions (a heavily compressed input re-encoded at a high
+            # quality can be many times its own size; a second call would repeat the whole search)
+            jw, jh = _jpeg_dimensions(data)
+            cap = max(3 * jw * jh + (1 << 16), 4 * len(data), 1 << 20)
+        else:
+            cap = 3 * w * h + (1 << 16)
         ip = (C.c_int * 7)(device, int(clear_metadata), int(try_420), int(force_420),
                            int(use_silver_screen), int(lookahead), int(new_model))
         tr = C.create_string_buffer(1 << 24) if want_trace else None

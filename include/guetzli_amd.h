@@ -254,6 +254,19 @@ int gz_search_evaluations(gz_ctx* ctx, uint64_t* evaluations);
  * searches with gz_block_zeroing_orders instead -- one call per block costs a round trip. */
 int gz_compare_blocks(gz_ctx* ctx, int n, const int32_t* block_xy, const int16_t* coeffs,
                       double* out);
+/* The same for 8x8 windows given by their YCbCr PIXELS -- what CompareBlock reads of the image:
+ * OutputImage::ToLinearRGB(xmin, ymin, 8, 8) (butteraugli_comparator.cc:467), i.e.
+ * OutputImageComponent::ToPixels (output_image.cc:69-96, edge replication included) of the three
+ * components.  This form serves every frame (comparator.h:50-52: SwitchBlock carries
+ * factor_x, factor_y): the pixels of a 2x2-subsampled component depend on its neighbours' blocks,
+ * which the caller's OutputImage holds.  block_xy: the window's position on the 8x8 luma grid
+ * (block_x * factor_x + off_x, block_y * factor_y + off_y); ycc: n x 3 x 64 bytes. */
+int gz_compare_block_pixels(gz_ctx* ctx, int n, const int32_t* block_xy, const uint8_t* ycc, double* out);
+/* OutputImageComponent::Reset(factor, factor) of the two chroma components (output_image.cc:
+ * 32-57) without touching their content: the layout gz_set_coeffs / gz_get_coeffs /
+ * gz_set_orig_coeffs* use from now on (1: 4:4:4, 2: 4:2:0).  A change drops the candidate, the
+ * original coefficients and the search results; the original PIXELS (gz_create) stay. */
+int gz_set_frame(gz_ctx* ctx, int chroma_factor);
 /* Host-only helper, exported for tests: the ranked input_order of
  * ComputeBlockZeroingOrder (processor.cc:381-400) for every block, as CSR, by std::sort
  * itself.  gz_block_zeroing_orders ranks on the device. */

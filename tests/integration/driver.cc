@@ -15,11 +15,13 @@
 #include "guetzli/stats.h"
 #include "hip_comparator.h"
 
-extern "C" long gzi_process(const uint8_t* rgb, int w, int h, float butteraugli_target, int device,
-                            uint8_t* out, long cap, char* trace, long trace_cap, long* calls) {
+static long run(const uint8_t* rgb, int w, int h, float butteraugli_target, int device, int force_420,
+                int try_420, uint8_t* out, long cap, char* trace, long trace_cap, long* calls) {
   std::vector<uint8_t> v(rgb, rgb + (size_t)3 * w * h);
   guetzli::Params params;
   params.butteraugli_target = butteraugli_target;
+  params.force_420 = force_420 != 0;
+  params.try_420 = try_420 != 0;
   guetzli::ProcessStats stats;
   std::string dbg;
   if (trace) stats.debug_output = &dbg;
@@ -36,6 +38,7 @@ extern "C" long gzi_process(const uint8_t* rgb, int w, int h, float butteraugli_
   if (calls && comparator) {
     calls[0] = comparator->compare_calls();
     calls[1] = comparator->compare_block_calls();
+    calls[2] = comparator->batched_search_calls();
   }
   const std::string& s = result.jpeg_data;
   if ((long)s.size() <= cap) memcpy(out, s.data(), s.size());
@@ -45,4 +48,16 @@ extern "C" long gzi_process(const uint8_t* rgb, int w, int h, float butteraugli_
     trace[n] = 0;
   }
   return (long)s.size();
+}
+
+// calls: [Compare, CompareBlock, batched phase-A] call counts of the comparator
+extern "C" long gzi_process(const uint8_t* rgb, int w, int h, float butteraugli_target, int device,
+                            uint8_t* out, long cap, char* trace, long trace_cap, long* calls) {
+  return run(rgb, w, h, butteraugli_target, device, 0, 0, out, cap, trace, trace_cap, calls);
+}
+// the same with Params::force_420 / try_420 (processor.h:36-37)
+extern "C" long gzi_process_params(const uint8_t* rgb, int w, int h, float butteraugli_target, int device,
+                                   int force_420, int try_420, uint8_t* out, long cap, char* trace,
+                                   long trace_cap, long* calls) {
+  return run(rgb, w, h, butteraugli_target, device, force_420, try_420, out, cap, trace, trace_cap, calls);
 }

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "guetzli/comparator.h"
+#include "guetzli/jpeg_data.h"
 #include "guetzli/output_image.h"
 #include "guetzli/stats.h"
 #include "guetzli_amd.h"
@@ -44,10 +45,21 @@ class HipButteraugliComparator : public Comparator {
                                           int factor_x, int factor_y,
                                           const std::vector<float>& distmap,
                                           std::vector<float>* block_weight) override;
+#ifdef GUETZLI_BATCHED_BLOCK_SEARCH
+  // The batched hook of INTEGRATION.md section 2 (declared in comparator.h by
+  // tests/integration/patch_reference.py, called once per SelectFrequencyMasking instead of its
+  // per-block loop, processor.cc:554-590): phase A for every block of the grid in one device call.
+  bool ComputeAllBlockZeroingOrders(const JPEGData& jpg, const OutputImage& img, uint8_t comp_mask,
+                                    int lookahead, bool new_zeroing_model,
+                                    std::vector<int>* candidate_coeff_offsets,
+                                    std::vector<uint8_t>* candidate_coeffs,
+                                    std::vector<float>* candidate_coeff_errors) override;
+#endif
 
   // counters for the test: how the seam was used
   long compare_calls() const { return compare_calls_; }
   long compare_block_calls() const { return compare_block_calls_; }
+  long batched_search_calls() const { return batched_search_calls_; }
 
  private:
   void Die(const char* what, int rc) const;
@@ -57,8 +69,11 @@ class HipButteraugliComparator : public Comparator {
   ProcessStats* stats_;
   float distance_ = 0.0f;
   std::vector<float> distmap_;
-  int block_x_ = 0, block_y_ = 0;
-  long compare_calls_ = 0;
+  int block_x_ = 0, block_y_ = 0, factor_x_ = 1, factor_y_ = 1;
+  // the image's coefficient arrays in the C ABI's layout, and the frame they have
+  int FrameOf(const OutputImage& img) const;
+  void GatherCoeffs(const OutputImage& img, std::vector<int16_t>* out) const;
+  long compare_calls_ = 0, batched_search_calls_ = 0;
   mutable long compare_block_calls_ = 0;
 };
 

@@ -590,4 +590,13 @@ def case_compare_blocks(L, w, h, x0=0, y0=0, qs=3, n=24):
             exp.append(oc.compare_block(cand, b % bw, b // bw))
         got = ctx.compare_blocks(np.array(xy), np.stack(blocks))
         assert_bits_equal(got, np.array(exp, np.float64), "CompareBlock")
+        # the pixel form of the seam (gz_compare_block_pixels): the windows' YCbCr pixels are the
+        # integer IDCT of their blocks, edge-replicated as OutputImageComponent::ToPixels does
+        px = L.idct_blocks(np.stack(blocks).reshape(-1, 64)).reshape(-1, 3, 8, 8)
+        for i, (bx, by) in enumerate(xy):
+            vw, vh = min(8, w - 8 * bx), min(8, h - 8 * by)
+            px[i, :, :, vw:] = px[i, :, :, vw - 1:vw]
+            px[i, :, vh:, :] = px[i, :, vh - 1:vh, :]
+        got_px = ctx.compare_block_pixels(np.array(xy), px.reshape(-1, 3, 64))
+        assert_bits_equal(got_px, np.array(exp, np.float64), "CompareBlock (pixels)")
     oc.close()

@@ -967,7 +967,12 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[2] = {p0.mf[ch], p1.mf[ch], ms[ch][2].nm, ms[ch][2].lf};
     a.out = c->ac[ch];
   }
-  GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
+  // GZ_MALTA_WIN=0: the line sums tap by tap from LDS (round 2's kernel); read per call
+  const char* mw_env = getenv("GZ_MALTA_WIN");
+  if (mw_env && atoi(mw_env) == 0)
+    GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
+  else
+    GZ_LAUNCH((k_malta_win<3>), mgrid, dim3(512), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);
   TRY(join_mask_branch(c));
   {

@@ -9,9 +9,9 @@
 //
 // What stays on the host is the serial decision logic of the reference (quant-matrix
 // bisection, global coefficient ordering, entropy-size model) and the JPEG writer; it is
-// written from scratch around flat coefficient arrays.  Scope: RGB input (the BASELINE
-// configurations) and YUV 4:4:4 JPEG input; try_420 / force_420 and 4:2:0 input are refused
-// with an error.
+// written from scratch around flat coefficient arrays.  Scope: everything guetzli::Process
+// accepts -- RGB input (the BASELINE configurations), YUV 4:4:4 and 4:2:0 JPEG input, every
+// field of Params (try_420 / force_420 / use_silver_screen included).
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -58,7 +58,8 @@ bool Process(const Params& params, ProcessStats* stats, const std::vector<uint8_
 // processor.h:39-41): the input is parsed on the host (jpeg_reader.h), its coefficients become
 // the original, its decoded pixels the comparator's reference image, its quantisation the
 // first candidate; Params::clear_metadata decides whether APPn / COM / trailing bytes are
-// carried over.  YUV 4:4:4 input only this round (4:2:0 is refused).
+// carried over.  YUV 4:4:4 and 4:2:0 input (other sampling factors are refused, as the reference
+// refuses them, processor.cc:811-823).
 bool Process(const Params& params, ProcessStats* stats, const std::string& jpeg_data,
              std::string* out);
 

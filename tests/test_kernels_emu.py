@@ -34,6 +34,15 @@ def test_idct_multiply_add_variant(L, monkeypatch):
     pc.case_encode_quantize_reconstruct(L, 61, 43, x0=100, y0=50)
 
 
+def test_malta_line_sum_variants(L, monkeypatch):
+    """k_malta_win (the default: every thread's neighbourhood loaded into registers once, the 16
+    oriented sums formed from registers) and k_malta (GZ_MALTA_WIN=0: every tap read from LDS)
+    give the same bits; an image with interior and border Malta tiles."""
+    pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
+    monkeypatch.setenv("GZ_MALTA_WIN", "0")
+    pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
+
+
 def test_dct_double(L):
     pc.case_dct_double(L, n=200)
 

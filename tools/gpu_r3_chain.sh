@@ -6,7 +6,7 @@
 set -u
 export TMPDIR=/tmp
 TAG=${1:-c1}; O=gpurun_out/$TAG; mkdir -p $O
-git -C . rev-parse HEAD > $O/head.txt 2>/dev/null || true
+cp .gpurun_head $O/head.txt 2>/dev/null || true
 tools/ubench/bw 2>/dev/null | head -3 | tee $O/bw.log
 if [ "${2:-}" != "skip" ]; then
   ( timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log ); tail -4 $O/pytest.log

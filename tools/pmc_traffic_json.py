@@ -26,6 +26,23 @@ def chain_totals(path, compares):
     return fetch, write
 
 
+def repo_head():
+    """The commit the measured code was built from: `git rev-parse HEAD`, or -- on the GPU box, whose
+    snapshot has no .git -- the file tools/gpurun_head.sh wrote before the run."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        h = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True)
+        if h.returncode == 0 and h.stdout.strip():
+            return h.stdout.strip()
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(root, ".gpurun_head")).read().strip()
+    except Exception:
+        return None
+
+
 def main():
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_pmc.sh) of one "
                    "butteraugli Compare chain (the chain's kernels: per-kernel average x launches per chain); "
@@ -45,6 +62,7 @@ def main():
         if "dwordx4" in r["kernel"] or "copy" in r["kernel"].lower():
             cal.setdefault(r["kernel"], {})[r["counter"]] = float(r["avg_value"])
     out["calibration"] = cal
+    out["head"] = repo_head()
     print(json.dumps(out, indent=1))
 
 

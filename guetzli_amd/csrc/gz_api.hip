@@ -269,32 +269,49 @@ inline void pool_host_free(void* ptr) { pool_release(host_pool(), true, ptr); }
 // synchronises its streams before it returns them).
 struct HandlePool {
   std::mutex mu;
-  std::multimap<int, hipStream_t> streams;   // device -> stream
+  std::multimap<int, hipStream_t> streams;   // device * 4 + priority class -> stream
   std::multimap<int, hipEvent_t> events;
 };
 HandlePool& handle_pool() { static HandlePool p; return p; }
-hipError_t pool_stream_create(hipStream_t* out) {
+// prio: 0 = default, +1 = the device's highest priority, -1 = its lowest.  The entropy coder's
+// stream runs beside the Compare chain of the same candidate and nobody waits for it before the
+// chain's result: it takes the lowest priority, the chain's main stream the highest, so that the
+// dispatcher fills the chip with the chain's workgroups first (GZ_STREAM_PRIO=0: all default).
+static bool stream_priorities() {
+  static const bool on = !(getenv("GZ_STREAM_PRIO") && atoi(getenv("GZ_STREAM_PRIO")) == 0);
+  return on;
+}
+hipError_t pool_stream_create(hipStream_t* out, int prio = 0) {
 #ifndef GZ_EMU
+  if (!stream_priorities()) prio = 0;
   int device = 0;
   (void)hipGetDevice(&device);
+  const int key = device * 4 + (prio + 1);
   {
     HandlePool& p = handle_pool();
     std::lock_guard<std::mutex> lk(p.mu);
-    auto it = p.streams.find(device);
+    auto it = p.streams.find(key);
     if (it != p.streams.end()) { *out = it->second; p.streams.erase(it); return hipSuccess; }
+  }
+  if (prio != 0) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      return hipStreamCreateWithPriority(out, hipStreamDefault, prio > 0 ? greatest : least);
   }
 #endif
   return hipStreamCreate(out);
 }
-void pool_stream_destroy(hipStream_t s_) {
+void pool_stream_destroy(hipStream_t s_, int prio = 0) {
   if (!s_) return;
 #ifndef GZ_EMU
+  if (!stream_priorities()) prio = 0;
   if (pool_limit_bytes() != 0) {
     int device = 0;
     (void)hipGetDevice(&device);
+    const int key = device * 4 + (prio + 1);
     HandlePool& p = handle_pool();
     std::lock_guard<std::mutex> lk(p.mu);
-    if (p.streams.count(device) < 64) { p.streams.insert(std::make_pair(device, s_)); return; }
+    if (p.streams.count(key) < 64) { p.streams.insert(std::make_pair(key, s_)); return; }
   }
 #endif
   (void)hipStreamDestroy(s_);
@@ -359,6 +376,7 @@ struct gz_ctx {
   // mask: DiffPrecompute + three blurs), forked and joined with events
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mask_pre = nullptr;
+  hipEvent_t ev_next_cand = nullptr;   // next_cand uploaded beside a Compare chain in flight
   // the entropy coder's kernels (gz_jpeg_scan) run on their own stream, beside a Compare that
   // gz_compare_begin has put on the main stream: both only read the candidate coefficients
   hipStream_t entropy_stream = nullptr;
@@ -967,12 +985,14 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[2] = {p0.mf[ch], p1.mf[ch], ms[ch][2].nm, ms[ch][2].lf};
     a.out = c->ac[ch];
   }
-  // GZ_MALTA_WIN=0: the line sums tap by tap from LDS (round 2's kernel); read per call
+  // GZ_MALTA_WIN=1: the line sums from a per-thread register window (k_malta_win: faster alone,
+  // 4K 294 -> 282 us, 1080p 85 -> 75 us, not beside the side streams' kernels: the chain gains
+  // nothing, profiles/r03_chain_kernel_experiments.log); read per call
   const char* mw_env = getenv("GZ_MALTA_WIN");
-  if (mw_env && atoi(mw_env) == 0)
-    GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
-  else
+  if (mw_env && atoi(mw_env) != 0)
     GZ_LAUNCH((k_malta_win<3>), mgrid, dim3(512), c->stream, ay, ax, c->w, c->h, c->pitch);
+  else
+    GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);
   TRY(join_mask_branch(c));
   {
@@ -1283,16 +1303,17 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   set_frame(c, 1);
   auto fail = [&](int code) { *err = code; gz_destroy(c); return (gz_ctx*)nullptr; };
 #define CHK0(call) do { if ((call) != hipSuccess) { return fail(GZ_E_HIP); } } while (0)
-  CHK0(pool_stream_create(&c->own_stream));
+  CHK0(pool_stream_create(&c->own_stream, 1));
   c->stream = c->own_stream;
   CHK0(pool_stream_create(&c->side_stream));
   CHK0(pool_stream_create(&c->side_stream2));
-  CHK0(pool_stream_create(&c->entropy_stream));
+  CHK0(pool_stream_create(&c->entropy_stream, -1));
   CHK0(pool_event_create(&c->ev_candidate));
   CHK0(pool_event_create(&c->ev_fork));
   CHK0(pool_event_create(&c->ev_join));
   CHK0(pool_event_create(&c->ev_join2));
   CHK0(pool_event_create(&c->ev_mask_pre));
+  CHK0(pool_event_create(&c->ev_next_cand));
   const size_t ncoef = (size_t)3 * c->nb * 64;
   CHK0(pool_malloc((void**)&c->d_rgb, (size_t)3 * w * h));
   CHK0(pool_malloc((void**)&c->d_orig, ncoef * 2));
@@ -1395,16 +1416,17 @@ void gz_destroy(gz_ctx* c) {
   for (int b = 0; b < B_COUNT; ++b) (void)pool_free(c->blur[b].d_scale);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); pool_stream_destroy(c->side_stream); }
   if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); pool_stream_destroy(c->side_stream2); }
-  if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); pool_stream_destroy(c->entropy_stream); }
+  if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); pool_stream_destroy(c->entropy_stream, -1); }
   pool_event_destroy(c->ev_candidate);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
   if (c->h_res) (void)pool_host_free(c->h_res);
   pool_event_destroy(c->ev_join2);
   pool_event_destroy(c->ev_mask_pre);
+  pool_event_destroy(c->ev_next_cand);
   pool_event_destroy(c->ev_fork);
   pool_event_destroy(c->ev_join);
-  pool_stream_destroy(c->own_stream);   // synchronised at the top of gz_destroy
+  pool_stream_destroy(c->own_stream, 1);   // synchronised at the top of gz_destroy
   delete c;
 }
 
@@ -1794,11 +1816,23 @@ static int order_auto_enqueue(gz_ctx* c, int direction, int max_block_dist, doub
   TRY(ensure_order_block_arrays(c));
   TRY(ensure_order_capacity(c, std::max<size_t>(c->search_total, 1)));   // also: the counters
   {
+    // With a Compare chain in flight on the main stream (gz_order_build_auto_begin) the upload
+    // takes the entropy stream, idle at this point, and the main stream waits for its event: the
+    // copy then runs beside the chain's first kernels instead of between its last kernel and the
+    // order's first (15-20 us of the critical path of every phase-B iteration).  Nothing on the
+    // main stream reads d_next_cand before the order's kernels.
+    hipStream_t up = c->compare_pending ? c->entropy_stream : c->stream;
     void* h = nullptr;
     TRY(stage_reserve(c, &c->stage_main, sizeof(int) * nb, &h));
     memcpy(h, next_cand, sizeof(int) * nb);
-    HIPCHK(c, hipMemcpyAsync(c->d_next_cand, h, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
-    TRY(stage_sent(c, &c->stage_main, c->stream));
+    // (behind everything the main stream did before the chain -- the bulk steps read the old values)
+    if (up != c->stream) HIPCHK(c, hipStreamWaitEvent(up, c->ev_candidate, 0));
+    HIPCHK(c, hipMemcpyAsync(c->d_next_cand, h, sizeof(int) * nb, hipMemcpyHostToDevice, up));
+    TRY(stage_sent(c, &c->stage_main, up));
+    if (up != c->stream) {
+      HIPCHK(c, hipEventRecord(c->ev_next_cand, up));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_next_cand, 0));
+    }
   }
   const int bw = c->sg_w, bh = c->sg_h;
   const float target = c->target;

@@ -212,31 +212,36 @@ __global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs<NP
 // reference's order.  A 64 x 32 tile is a workgroup of 512 threads (8 wavefronts).
 constexpr int WPX = 4;
 
+// The 16 oriented sums of the WPX pixels, orientation by orientation with the pixels' sums side
+// by side: WPX independent chains of additions in flight instead of one (a wavefront issues in
+// order, and a sum is a chain of dependent additions).  Per pixel the operations and their order
+// are malta_unit's.
 template <bool LF>
-GZ_DEVFN float malta_unit_win(const float (&win)[WPX + 8][9], int i) {
-  // centre of pixel i: win[i + 4][4]
-  float ret = 0.0f;
+GZ_DEVFN void malta_units_win(const float (&win)[WPX + 8][9], float* acc) {
+  float ret[WPX];
+#pragma unroll
+  for (int i = 0; i < WPX; ++i) ret[i] = 0.0f;
 #pragma unroll
   for (int o = 0; o < 16; ++o) {
-    float sum = 0.0f;
-    if (LF) {
+    float sum[WPX];
+    constexpr int kMaxTaps = LF ? 5 : 9;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const float v = win[i + 4 + kMaltaLF[o][k][0]][4 + kMaltaLF[o][k][1]];
-        sum = k == 0 ? v : sum + v;
-      }
-    } else {
+    for (int k = 0; k < kMaxTaps; ++k) {
+      if (LF || k < kMaltaHFCount[o]) {
+        const int dy = LF ? kMaltaLF[o][k][0] : kMaltaHF[o][k][0];
+        const int dx = LF ? kMaltaLF[o][k][1] : kMaltaHF[o][k][1];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        if (k < kMaltaHFCount[o]) {
-          const float v = win[i + 4 + kMaltaHF[o][k][0]][4 + kMaltaHF[o][k][1]];
-          sum = k == 0 ? v : sum + v;
+        for (int i = 0; i < WPX; ++i) {
+          const float v = win[i + 4 + dy][4 + dx];
+          sum[i] = k == 0 ? v : sum[i] + v;
         }
       }
     }
-    ret += sum * sum;
+#pragma unroll
+    for (int i = 0; i < WPX; ++i) ret[i] += sum[i] * sum[i];
   }
-  return ret;
+#pragma unroll
+  for (int i = 0; i < WPX; ++i) acc[i] += ret[i];
 }
 
 template <int NPASS>
@@ -293,13 +298,8 @@ __global__ __launch_bounds__(512) void k_malta_win(MaltaArgs<NPASS> a0, MaltaArg
     for (int r = 0; r < WPX + 8; ++r)
 #pragma unroll
       for (int cx = 0; cx < 9; ++cx) win[r][cx] = tile[tg * WPX + r][tx + cx];
-    if (P.lf) {
-#pragma unroll
-      for (int i = 0; i < WPX; ++i) acc[i] += malta_unit_win<true>(win, i);
-    } else {
-#pragma unroll
-      for (int i = 0; i < WPX; ++i) acc[i] += malta_unit_win<false>(win, i);
-    }
+    if (P.lf) malta_units_win<true>(win, acc);
+    else malta_units_win<false>(win, acc);
   }
   const int x = x0 + tx;
   if (x >= w) return;

@@ -393,6 +393,24 @@ GZ_DEVFN unsigned wg_inclusive_scan(unsigned v, unsigned* lds) {
   return r;
 }
 
+// The same with wavefront shuffles: a scan inside every wavefront, then the (at most four)
+// wavefront totals through LDS -- two barriers instead of sixteen.
+GZ_DEVFN unsigned wg_inclusive_scan_fast(unsigned v, unsigned* lds4) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = (unsigned)__shfl_up((int)x, (unsigned)d);
+    if (lane >= d) x += o;
+  }
+  if (lane == 63) lds4[wave] = x;
+  __syncthreads();
+  unsigned base = 0;
+  for (int wv = 0; wv < wave; ++wv) base += lds4[wv];
+  __syncthreads();
+  return x + base;
+}
+
 // Pass 1: per chunk, the number of left stoppers (!(e < pivot)) and right stoppers
 // (!(pivot < e)) among a[first .. first+n).
 __global__ __launch_bounds__(256) void k_part_count(const OrderEntry* __restrict__ a,
@@ -666,8 +684,8 @@ __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
       if (!order_less(pv, e)) { fr |= 1u << i; ++nr; }
     }
   }
-  const unsigned incl_l = wg_inclusive_scan(nl, lds);
-  const unsigned incl_r = wg_inclusive_scan(nr, lds);
+  const unsigned incl_l = wg_inclusive_scan_fast(nl, lds);
+  const unsigned incl_r = wg_inclusive_scan_fast(nr, lds);
   unsigned ol = blockIdx.x * (unsigned)kPartChunk + (incl_l - nl);
   unsigned orr = blockIdx.x * (unsigned)kPartChunk + (incl_r - nr);
 #pragma unroll
@@ -710,8 +728,8 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
       sl += A.cnt_l[c];
       sr += A.cnt_r[nchunks - 1 - c];
     }
-    unsigned run_l = wg_inclusive_scan(sl, lds) - sl;
-    unsigned run_r = wg_inclusive_scan(sr, lds) - sr;
+    unsigned run_l = wg_inclusive_scan_fast(sl, lds) - sl;
+    unsigned run_r = wg_inclusive_scan_fast(sr, lds) - sr;
     for (unsigned c = c0; c < c1; ++c) {
       PL[c] = run_l;
       RR[c] = run_r;
@@ -739,33 +757,51 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
     const unsigned c = nchunks - 1 - i, cnt = RR[i + 1] - RR[i];
     return A.rpos[c * (unsigned)kPartChunk + (cnt - 1 - (k - RR[i]))];
   };
+  // The thread's kPartItems pairs in three rounds -- positions, values, stores -- each round's
+  // memory accesses independent of one another (one pair after the other, every pair costs three
+  // dependent trips to memory).
+  unsigned pl[kPartItems], pr[kPartItems];
+  bool sw[kPartItems];
   bool prev_swapped = true;   // (k == 0: the scan starts)
   unsigned prev_pr = 0;
   if (k0 > 0) {
-    const unsigned pl = pos_l(k0 - 1);   // (k0 - 1 < K: both exist)
+    const unsigned ql = pos_l(k0 - 1);   // (k0 - 1 < K: both exist)
     prev_pr = pos_r(k0 - 1);
-    prev_swapped = pl < prev_pr;
+    prev_swapped = ql < prev_pr;
   }
-  for (int i = 0; i < kPartItems && prev_swapped; ++i) {
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
     const unsigned k = k0 + (unsigned)i;
-    if (k > K) break;
-    const bool has_l = k < total_l, has_r = k < total_r;
-    unsigned pl = 0, pr = 0;
-    if (has_l) pl = pos_l(k);
-    if (has_r) pr = pos_r(k);
-    const bool swapped = has_l && has_r && pl < pr;
-    if (swapped) {
-      const OrderEntry vl = desc_read(A.a, first + pl, pvt.med, pvt.a_lo);
-      const OrderEntry vr = desc_read(A.a, first + pr, pvt.med, pvt.a_lo);
-      A.a[first + pl] = vr;
-      A.a[first + pr] = vl;
-      prev_pr = pr;
-    } else {
-      // the serial scan stops here: at the next untouched left stopper or at the last swapped
-      // right one, whichever comes first (libstdc++ __unguarded_partition returns `first`)
+    const bool has_l = k <= K && k < total_l, has_r = k <= K && k < total_r;
+    pl[i] = has_l ? pos_l(k) : 0xffffffffu;
+    pr[i] = has_r ? pos_r(k) : 0u;
+    sw[i] = has_l && has_r && pl[i] < pr[i];
+  }
+  OrderEntry vl[kPartItems], vr[kPartItems];
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i)
+    if (sw[i]) {
+      vl[i] = desc_read(A.a, first + pl[i], pvt.med, pvt.a_lo);
+      vr[i] = desc_read(A.a, first + pr[i], pvt.med, pvt.a_lo);
+    }
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i)
+    if (sw[i]) {
+      A.a[first + pl[i]] = vr[i];
+      A.a[first + pr[i]] = vl[i];
+    }
+  // the one pair that is not swapped while its predecessor was: where the serial scan stops -- at
+  // the next untouched left stopper or at the last swapped right one, whichever comes first
+  // (libstdc++ __unguarded_partition returns `first`)
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
+    const unsigned k = k0 + (unsigned)i;
+    const bool before = i == 0 ? prev_swapped : sw[i - 1];
+    if (k <= K && before && !sw[i]) {
+      const unsigned last_pr = i == 0 ? prev_pr : pr[i - 1];
       unsigned long long cut = s.hi;
-      if (has_l && first + pl < cut) cut = first + pl;
-      if (k >= 1 && first + prev_pr < cut) cut = first + prev_pr;
+      if (pl[i] != 0xffffffffu && first + pl[i] < cut) cut = first + pl[i];
+      if (k >= 1 && first + last_pr < cut) cut = first + last_pr;
       DescState nx;
       if (s.last < cut) { nx.lo = s.lo; nx.hi = cut; } else { nx.lo = cut; nx.hi = s.hi; }
       nx.last = s.last;
@@ -775,7 +811,6 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
       A.st[level + 1] = nx;
       if (level == 0) A.st[0] = s;   // (the derived level-0 range, for the host's replay)
     }
-    prev_swapped = swapped;
   }
   if (k0 == 0) {
     // the median's move to the front, made real: the front gets the pivot; the place the pivot

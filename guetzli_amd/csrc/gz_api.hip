@@ -377,6 +377,7 @@ struct gz_ctx {
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mask_pre = nullptr;
   hipEvent_t ev_next_cand = nullptr;   // next_cand uploaded beside a Compare chain in flight
+  hipEvent_t ev_xyb = nullptr, ev_lfy = nullptr;   // B plane's LF blur on side stream 2 (stage_separate)
   // the entropy coder's kernels (gz_jpeg_scan) run on their own stream, beside a Compare that
   // gz_compare_begin has put on the main stream: both only read the candidate coefficients
   hipStream_t entropy_stream = nullptr;
@@ -808,8 +809,44 @@ int stage_opsin(gz_ctx* c) {
 }
 
 // SeparateFrequencies: xyb[3] -> Psycho planes
-int stage_separate(gz_ctx* c, Psycho* ps) {
-  {  // LF (radius 16: separate row and column passes -- the fused kernel's extra row-pass
+// split_b (the candidate's chain, unless single-stream): the LF blur of the B plane -- which only
+// k_combine reads -- runs on side stream 2 beside the X / Y bands instead of in front of them; the
+// caller joins that stream before k_combine (join_mask_branch).  Its row-pass result goes through
+// the distance-map plane, which nothing else touches before the chain's last kernel.
+int stage_separate(gz_ctx* c, Psycho* ps, bool split_b = false) {
+  static const bool split_off = getenv("GZ_LF_SPLIT") && atoi(getenv("GZ_LF_SPLIT")) == 0;
+  if (split_b && !split_off) {
+    HIPCHK(c, hipEventRecord(c->ev_xyb, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_xyb, 0));
+    hipStream_t main_stream = c->stream;
+    int rc = GZ_OK;
+    {
+      c->stream = c->side_stream2;
+      SrcPack<SrcPlain, 1> s; PlanePack<1> t;
+      s.s[0].p = c->xyb[2]; t.p[0] = c->distmap;
+      rc = blur_h<16, SrcPlain, 1>(c, s, t, c->blur[B_LF]);
+      c->stream = main_stream;
+      TRY(rc);
+    }
+    {
+      SrcPack<SrcPlain, 2> s; PlanePack<2> t; CPlanePack<2> ct;
+      for (int i = 0; i < 2; ++i) { s.s[i].p = c->xyb[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
+      TRY((blur_h<16, SrcPlain, 2>(c, s, t, c->blur[B_LF])));
+      PostLFxy post;
+      for (int i = 0; i < 2; ++i) { post.lf_raw[i] = c->lf_raw[i]; post.lf_vals[i] = ps->lfv[i]; }
+      TRY((blur_v<16, 2, PostLFxy>(c, ct, post, c->blur[B_LF])));
+    }
+    HIPCHK(c, hipEventRecord(c->ev_lfy, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_lfy, 0));
+    {
+      c->stream = c->side_stream2;
+      CPlanePack<1> ct; ct.p[0] = c->distmap;
+      PostLFb post; post.lf_raw_y = c->lf_raw[1]; post.lf_vals_b = ps->lfv[2];
+      rc = blur_v<16, 1, PostLFb>(c, ct, post, c->blur[B_LF]);
+      c->stream = main_stream;
+      TRY(rc);
+    }
+  } else {  // LF (radius 16: separate row and column passes -- the fused kernel's extra row-pass
      // arithmetic costs more than the intermediate plane at this radius)
     SrcPack<SrcPlain, 3> s;
     PlanePack<3> t;
@@ -1095,7 +1132,7 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
 int enqueue_compare(gz_ctx* c, bool want_block_max) {
   TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
   TRY(stage_opsin(c));
-  TRY(stage_separate(c, &c->pi1));
+  TRY(stage_separate(c, &c->pi1, !single_stream()));
   TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, true));
   return GZ_OK;
 }
@@ -1314,6 +1351,8 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   CHK0(pool_event_create(&c->ev_join2));
   CHK0(pool_event_create(&c->ev_mask_pre));
   CHK0(pool_event_create(&c->ev_next_cand));
+  CHK0(pool_event_create(&c->ev_xyb));
+  CHK0(pool_event_create(&c->ev_lfy));
   const size_t ncoef = (size_t)3 * c->nb * 64;
   CHK0(pool_malloc((void**)&c->d_rgb, (size_t)3 * w * h));
   CHK0(pool_malloc((void**)&c->d_orig, ncoef * 2));
@@ -1424,6 +1463,8 @@ void gz_destroy(gz_ctx* c) {
   pool_event_destroy(c->ev_join2);
   pool_event_destroy(c->ev_mask_pre);
   pool_event_destroy(c->ev_next_cand);
+  pool_event_destroy(c->ev_xyb);
+  pool_event_destroy(c->ev_lfy);
   pool_event_destroy(c->ev_fork);
   pool_event_destroy(c->ev_join);
   pool_stream_destroy(c->own_stream, 1);   // synchronised at the top of gz_destroy

@@ -1016,6 +1016,64 @@ struct PostLF {
   }
 };
 
+// The same in two parts, for the X / Y planes and for the B plane (XybLowFreqToVals mixes the
+// blurred Y into B, butteraugli.cc:386-389: the B part reads the raw LF of Y the first part
+// wrote): the B plane is needed by k_combine only, so its blur runs on a side stream beside the
+// MF / HF bands instead of in front of them.
+struct PostLFxy {
+  float* lf_raw[2];
+  float* lf_vals[2];
+  GZ_DEVFN float operator()(size_t idx, const float* v) const {
+    lf_raw[0][idx] = v[0];
+    lf_raw[1][idx] = v[1];
+    float vx, vy, vb;
+    lf_to_vals(v[0], v[1], 0.0f, &vx, &vy, &vb);
+    lf_vals[0][idx] = vx;
+    lf_vals[1][idx] = vy;
+    return vy;
+  }
+  GZ_DEVFN void pair(size_t idx, const float* v0, const float* v1) const {
+    (void)(*this)(idx, v0);
+    (void)(*this)(idx + 1, v1);
+  }
+  GZ_DEVFN void quad(size_t idx, const gz_f4* v) const {
+    GZ_STG4(lf_raw[0], idx, v[0]);
+    GZ_STG4(lf_raw[1], idx, v[1]);
+    gz_f4 vx, vy;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float vb;
+      lf_to_vals(v[0].v[i], v[1].v[i], 0.0f, &vx.v[i], &vy.v[i], &vb);
+    }
+    GZ_STG4(lf_vals[0], idx, vx);
+    GZ_STG4(lf_vals[1], idx, vy);
+  }
+};
+struct PostLFb {
+  const float* lf_raw_y;
+  float* lf_vals_b;
+  GZ_DEVFN float operator()(size_t idx, const float* v) const {
+    float vx, vy, vb;
+    lf_to_vals(0.0f, lf_raw_y[idx], v[0], &vx, &vy, &vb);
+    lf_vals_b[idx] = vb;
+    return vb;
+  }
+  GZ_DEVFN void pair(size_t idx, const float* v0, const float* v1) const {
+    (void)(*this)(idx, v0);
+    (void)(*this)(idx + 1, v1);
+  }
+  GZ_DEVFN void quad(size_t idx, const gz_f4* v) const {
+    const gz_f4 y = GZ_LDG4(lf_raw_y, idx);
+    gz_f4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float vx, vy;
+      lf_to_vals(0.0f, y.v[i], v[0].v[i], &vx, &vy, &o.v[i]);
+    }
+    GZ_STG4(lf_vals_b, idx, o);
+  }
+};
+
 // MF band of X and Y (butteraugli.cc:511-550) + SuppressXByY (:552-554):
 // v = blur(xyb - lf, sigma_hf) for c = 0,1.  (The B channel's MF is never consumed:
 // wmul[5] == 0, butteraugli.cc:873-883, and Malta runs on X and Y only.)

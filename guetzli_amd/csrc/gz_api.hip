@@ -273,13 +273,20 @@ struct HandlePool {
   std::multimap<int, hipEvent_t> events;
 };
 HandlePool& handle_pool() { static HandlePool p; return p; }
-// prio: 0 = default, +1 = the device's highest priority, -1 = its lowest.  The entropy coder's
-// stream runs beside the Compare chain of the same candidate and nobody waits for it before the
-// chain's result: it takes the lowest priority, the chain's main stream the highest, so that the
-// dispatcher fills the chip with the chain's workgroups first (GZ_STREAM_PRIO=0: all default).
+// prio: 0 = default, +1 = the device's highest priority, -1 = its lowest (GZ_STREAM_PRIO=0: all
+// default).  Who takes which: create_context.
 static bool stream_priorities() {
   static const bool on = !(getenv("GZ_STREAM_PRIO") && atoi(getenv("GZ_STREAM_PRIO")) == 0);
   return on;
+}
+// Contexts alive per device: adds `delta`, returns the count before.
+static int live_contexts(int device, int delta) {
+  static std::mutex mu;
+  static std::map<int, int> live;
+  std::lock_guard<std::mutex> lk(mu);
+  const int before = live[device];
+  live[device] = before + delta;
+  return before;
 }
 hipError_t pool_stream_create(hipStream_t* out, int prio = 0) {
 #ifndef GZ_EMU
@@ -375,6 +382,7 @@ struct gz_ctx {
   // second stream for the branch of Compare that does not depend on the Malta path (the
   // mask: DiffPrecompute + three blurs), forked and joined with events
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+  bool prio_streams = false, counted_live = false;   // (see create_context)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mask_pre = nullptr;
   hipEvent_t ev_next_cand = nullptr;   // next_cand uploaded beside a Compare chain in flight
   hipEvent_t ev_xyb = nullptr, ev_lfy = nullptr;   // B plane's LF blur on side stream 2 (stage_separate)
@@ -1340,11 +1348,20 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   set_frame(c, 1);
   auto fail = [&](int code) { *err = code; gz_destroy(c); return (gz_ctx*)nullptr; };
 #define CHK0(call) do { if ((call) != hipSuccess) { return fail(GZ_E_HIP); } } while (0)
-  CHK0(pool_stream_create(&c->own_stream, 1));
+  // The chain's main stream takes the device's highest priority, so that the dispatcher serves
+  // its workgroups before those of the entropy coder that runs beside it (1080p encode 0.144 ->
+  // 0.140 s) -- but only for a context that has the device to itself when it is created, and no
+  // stream ever goes BELOW the default: with several images in flight priorities invert (an
+  // image's low-priority entropy coder starves behind the other images' chains while its host
+  // thread waits for it: 16 x 1080p, 8 in flight, 21.8 -> 7.5-13.5 MPix/s with main = highest and
+  // entropy = lowest on every context; profiles/r03_stream_priorities.log).
+  c->prio_streams = live_contexts(device, +1) == 0;
+  c->counted_live = true;
+  CHK0(pool_stream_create(&c->own_stream, c->prio_streams ? 1 : 0));
   c->stream = c->own_stream;
   CHK0(pool_stream_create(&c->side_stream));
   CHK0(pool_stream_create(&c->side_stream2));
-  CHK0(pool_stream_create(&c->entropy_stream, -1));
+  CHK0(pool_stream_create(&c->entropy_stream, 0));   // (never below default: see above)
   CHK0(pool_event_create(&c->ev_candidate));
   CHK0(pool_event_create(&c->ev_fork));
   CHK0(pool_event_create(&c->ev_join));
@@ -1455,7 +1472,7 @@ void gz_destroy(gz_ctx* c) {
   for (int b = 0; b < B_COUNT; ++b) (void)pool_free(c->blur[b].d_scale);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); pool_stream_destroy(c->side_stream); }
   if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); pool_stream_destroy(c->side_stream2); }
-  if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); pool_stream_destroy(c->entropy_stream, -1); }
+  if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); pool_stream_destroy(c->entropy_stream, 0); }
   pool_event_destroy(c->ev_candidate);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
@@ -1467,7 +1484,8 @@ void gz_destroy(gz_ctx* c) {
   pool_event_destroy(c->ev_lfy);
   pool_event_destroy(c->ev_fork);
   pool_event_destroy(c->ev_join);
-  pool_stream_destroy(c->own_stream, 1);   // synchronised at the top of gz_destroy
+  pool_stream_destroy(c->own_stream, c->prio_streams ? 1 : 0);   // synchronised at the top of gz_destroy
+  if (c->counted_live) (void)live_contexts(c->device, -1);
   delete c;
 }
 

@@ -17,7 +17,7 @@ def chain_totals(path, compares):
     for r in csv.DictReader(open(path)):
         if not any(k in r["kernel"] for k in CHAIN):
             continue
-        per_chain = max(1, round(int(r["calls"]) / compares))
+        per_chain = round(int(r["calls"]) / compares)   # (0: a kernel of the context set-up only)
         total = float(r["avg_value"]) * per_chain
         if r["counter"] == "FETCH_SIZE":
             fetch += total

@@ -118,6 +118,27 @@ def config5_goldens():
     return out
 
 
+def block_search_counters():
+    """SQ counters of k_block_search from the committed rocprofv3 --pmc pass (tools/gpu_pmc.sh; the
+    counters cannot be read from inside this process): the share of its wave cycles in which a
+    wavefront issues a VALU instruction, and VALU instructions per wavefront."""
+    import csv
+    for name in ("r03_block_search_pmc.csv", "r02_block_search_pmc.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        c = {}
+        for r in csv.DictReader(open(path)):
+            if "k_block_search<0>" in r["kernel"]:
+                c[r["counter"]] = float(r["avg_value"])
+        if "SQ_WAVE_CYCLES" in c and "SQ_ACTIVE_INST_VALU" in c:
+            return {"source": "profiles/" + name,
+                    "valu_active_per_wave_cycle": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4),
+                    "wait_any_per_wave_cycle": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4),
+                    "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU")}
+    return None
+
+
 def box_calibration():
     """Streaming copy rates of this box (tools/ubench/bw, < 1 s): the Compare chain follows them."""
     exe = os.path.join(ROOT, "tools", "ubench", "bw")
@@ -436,9 +457,11 @@ def main():
                              "seconds": round(info["timers"].get("block_search", 0.0), 4),
                              "evaluations_per_s": round(info["counters"].get("block search evaluations", 0) /
                                                         max(info["timers"].get("block_search", 0.0), 1e-9)),
+                             "valu": block_search_counters(),
                              "note": "CompareBlock evaluations (one 8x8 IDCT + colour + opsin + FFT "
-                                     "distance each) of gz_block_zeroing_orders; VALU utilisation of "
-                                     "k_block_search: profiles/r02_block_search_pmc.csv"},
+                                     "distance each) of gz_block_zeroing_orders; `valu`: SQ counters of "
+                                     "k_block_search<0> on the same 1080p image (3 resident waves per SIMD: "
+                                     "valu_active_per_wave_cycle x 3 = share of SIMD cycles issuing VALU)"},
             "host_timers_s": {k: round(v, 3) for k, v in info["timers"].items() if k in timer_keys},
         }
         if dt4k is not None:

@@ -2328,8 +2328,14 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   JpegCodes codes{c->d_code_depth, c->d_code_bits};
   const FrameGeom geom = frame_geom(c, ncomp);
   const int nmcu = geom.mcu_cols * geom.mcu_rows;
-  GZ_LAUNCH(k_jpeg_block_bits, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
-            (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
+  // GZ_MCU_WAVES=1: one MCU per workgroup (round 2's launch shape), for comparison
+  static const bool one_wave = getenv("GZ_MCU_WAVES") && atoi(getenv("GZ_MCU_WAVES")) == 1;
+  if (one_wave)
+    GZ_LAUNCH(k_jpeg_block_bits<1>, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
+              (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
+  else
+    GZ_LAUNCH(k_jpeg_block_bits<kMcuWaves>, dim3(gz_div_up(nmcu, kMcuWaves)), dim3(64 * kMcuWaves), es,
+              (const int16_t*)c->d_cand, (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
   KCHK(c);
   TRY(enqueue_scan_offsets(c, 1, es, (const unsigned*)c->d_mcu_bits, nmcu, c->d_mcu_off));
   const unsigned long long* d_total = c->d_mcu_off + nmcu;
@@ -2337,9 +2343,14 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   GZ_LAUNCH(k_jpeg_clear_words, dim3(cgrid), dim3(256), es, c->d_words, d_total,
             (unsigned long long)c->words_cap, c->d_ff_count);
   KCHK(c);
-  GZ_LAUNCH(k_jpeg_emit, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
-            (const int*)c->d_jq, geom, codes, (const unsigned long long*)c->d_mcu_off,
-            c->d_words, (unsigned long long)c->words_cap);
+  if (one_wave)
+    GZ_LAUNCH(k_jpeg_emit<1>, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
+              (const int*)c->d_jq, geom, codes, (const unsigned long long*)c->d_mcu_off,
+              c->d_words, (unsigned long long)c->words_cap);
+  else
+    GZ_LAUNCH(k_jpeg_emit<kMcuWaves>, dim3(gz_div_up(nmcu, kMcuWaves)), dim3(64 * kMcuWaves), es,
+              (const int16_t*)c->d_cand, (const int*)c->d_jq, geom, codes,
+              (const unsigned long long*)c->d_mcu_off, c->d_words, (unsigned long long)c->words_cap);
   KCHK(c);
   GZ_LAUNCH(k_jpeg_count_ff, dim3(cgrid), dim3(256), es, (const unsigned*)c->d_words, d_total,
             c->d_ff_count);

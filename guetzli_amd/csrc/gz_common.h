@@ -103,6 +103,19 @@ GZ_DEVFN gz_f2 gz_f2_splat(float x) {
 #define GZ_WAVE_LOCKSTEP() ((void)0)
 #endif
 
+// Lanes of ONE wavefront exchanging data through LDS (a wavefront's LDS operations execute in
+// program order): nothing to wait for, but the compiler must keep the accesses on their sides of
+// this point.  (The emulation yields, as for GZ_WAVE_LOCKSTEP.)
+#ifdef GZ_EMU
+#define GZ_WAVE_SYNC() hipemu::yield()
+#else
+#define GZ_WAVE_SYNC()                                      \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                        \
+  } while (0)
+#endif
+
 // Release / acquire accesses at device scope for flags that workgroups of one launch pass to
 // each other through global memory (the decoupled look-back of k_scan_offsets).
 #ifdef GZ_EMU

@@ -195,12 +195,19 @@ GZ_DEVFN int wave_inclusive_sum(int v, int lane) {
   return v;
 }
 
-// bits[m] = number of scan bits of MCU m.
-__global__ __launch_bounds__(64) void k_jpeg_block_bits(const int16_t* __restrict__ coeffs,
+// bits[m] = number of scan bits of MCU m.  One wavefront per MCU, kMcuWaves of them per
+// workgroup: with a workgroup per MCU the 129 600 single-wavefront workgroups of a 4K frame were
+// bound by the rate at which workgroups can be dispatched (49 us = one per clock), not by what
+// they compute.
+constexpr int kMcuWaves = 4;
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_jpeg_block_bits(const int16_t* __restrict__ coeffs,
                                                         const int* __restrict__ q, FrameGeom g,
                                                         JpegCodes codes,
                                                         unsigned* __restrict__ bits) {
-  const int lane = threadIdx.x, m = blockIdx.x;
+  const int lane = threadIdx.x & 63, m = blockIdx.x * W + (int)(threadIdx.x >> 6);
+  if (m >= g.mcu_cols * g.mcu_rows) return;   // (a whole wavefront)
   const int mx = m % g.mcu_cols, my = m / g.mcu_cols, upm = geom_units_per_mcu(g);
   int total = 0;
   for (int u = 0; u < upm; ++u) {
@@ -344,15 +351,20 @@ GZ_DEVFN void or_bits(unsigned* words, bool lds, unsigned long long pos, unsigne
   if (lo) atomicOr(&words[w + 1], lo);
 }
 
-__global__ __launch_bounds__(64) void k_jpeg_emit(const int16_t* __restrict__ coeffs,
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_jpeg_emit(const int16_t* __restrict__ coeffs,
                                                   const int* __restrict__ q, FrameGeom g,
                                                   JpegCodes codes,
                                                   const unsigned long long* __restrict__ off,
                                                   unsigned* __restrict__ words,
                                                   unsigned long long cap_words) {
-  __shared__ unsigned stage[kStageWords + 2];
-  const int lane = threadIdx.x, m = blockIdx.x;
+  // one wavefront per MCU, each with its own staging area (no workgroup barrier: the wavefronts
+  // of a workgroup have nothing to do with each other)
+  __shared__ unsigned stage_all[W][kStageWords + 2];
+  unsigned* stage = stage_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63, m = blockIdx.x * W + (int)(threadIdx.x >> 6);
   const int nmcu = g.mcu_cols * g.mcu_rows, upm = geom_units_per_mcu(g);
+  if (m >= nmcu) return;   // (a whole wavefront)
   const int mx = m % g.mcu_cols, my = m / g.mcu_cols;
   const unsigned long long start = off[m], end = off[m + 1];
   // the last MCU also writes the 1-padding up to the byte boundary (BitWriter::JumpToByteBoundary)
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(64) void k_jpeg_emit(const int16_t* __restrict__ co
   const bool staged = span <= (unsigned long long)kStageWords * 32;
   if (staged) {
     for (int i = lane; i < kStageWords + 2; i += 64) stage[i] = 0;
-    __syncthreads();
+    GZ_WAVE_SYNC();
   }
   unsigned* dst = staged ? stage : words;
   unsigned long long base = staged ? start - (word0 << 5) : start;
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(64) void k_jpeg_emit(const int16_t* __restrict__ co
   }
   if (pad && lane == 0) or_bits(dst, staged, base, (1u << pad) - 1u, pad);
   if (staged) {
-    __syncthreads();
+    GZ_WAVE_SYNC();
     const int nwords = (int)((span + 31) >> 5);
     for (int i = lane; i < nwords; i += 64)
       if (stage[i]) atomicOr(&words[word0 + i], stage[i]);

@@ -128,7 +128,7 @@ def block_search_counters():
         if not os.path.exists(path):
             continue
         c = {}
-        for r in csv.DictReader(open(path)):
+        for r in csv.DictReader(l for l in open(path) if not l.startswith("#")):   # (first line: the commit stamp)
             if "k_block_search<0>" in r["kernel"]:
                 c[r["counter"]] = float(r["avg_value"])
         if "SQ_WAVE_CYCLES" in c and "SQ_ACTIVE_INST_VALU" in c:

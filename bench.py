@@ -251,13 +251,32 @@ def timed_steps(env, step, steps, warmup):
     return env.max_over_ranks(time.perf_counter() - t0), res
 
 
-def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality):
-    """8 images per GPU of config 5's batch; returns the JSON object of the leg (rank 0)."""
+def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, from_png=False):
+    """8 images per GPU of config 5's batch; returns the JSON object of the leg (rank 0).
+    from_png: the batch as configs[4] words it -- PNG files: every image arrives as PNG bytes
+    (encoded once, outside the timed region) and is decoded inside it by the product's reader
+    (guetzli_amd::ReadPng = the reference front end's ReadPNG, guetzli.cc:47-152) on the image's
+    own host thread, beside the other images' device work."""
     from guetzli_amd.batch import run_config5
     w5, h5 = size
     base = images.tiled(w5, h5)
-    get = lambda k: images.shifted(base, k)
-    proc = lambda im: host.process(im, quality=quality, device=env.device)
+    if from_png:
+        import io
+        from PIL import Image
+        pngs = {}
+
+        def get(k):
+            if k not in pngs:
+                b = io.BytesIO()
+                Image.fromarray(images.shifted(base, k)).save(b, "PNG", compress_level=1)
+                pngs[k] = b.getvalue()
+            return pngs[k]
+        for k in range(env.rank, images_per_gpu * env.world, env.world):
+            get(k)   # (encoded before anything is timed)
+        proc = lambda data: host.process(host.read_png(data), quality=quality, device=env.device)
+    else:
+        get = lambda k: images.shifted(base, k)
+        proc = lambda im: host.process(im, quality=quality, device=env.device)
     run_config5(get, min(2, images_per_gpu), proc, env.rank, env.world, env.dist, in_flight, env.fence,
                 env.tensor_device)   # warm-up
     recs, secs = run_config5(get, images_per_gpu, proc, env.rank, env.world, env.dist, in_flight,
@@ -271,7 +290,8 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality):
             checked += 1
     n = len(recs)
     return {"workload": f"{n} independent {w5}x{h5} images (the bench image circularly shifted by "
-                        f"(37k, 53k)), --quality {quality:g}, {images_per_gpu} per GPU (image k -> rank k mod "
+                        f"(37k, 53k)){' as PNG bytes, decoded inside the timed region' if from_png else ''}, "
+                        f"--quality {quality:g}, {images_per_gpu} per GPU (image k -> rank k mod "
                         f"{env.world}), {in_flight} in flight per GPU; records all-gathered",
             "images": n, "images_per_gpu": images_per_gpu, "in_flight": in_flight,
             "seconds": round(secs, 3), "value": round(n * w5 * h5 / 1e6 / secs, 3), "unit": "MPix/s",
@@ -305,7 +325,8 @@ def main():
     ap.add_argument("--images-per-gpu", type=int, default=8)
     ap.add_argument("--in-flight", type=int, default=8)
     ap.add_argument("--size", default="4k", choices=["4k", "1080p"])
-    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg of the default run")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 legs of the default run")
+    ap.add_argument("--png", action="store_true", help="with --config5: the images arrive as PNG bytes")
     ap.add_argument("--emulate", action="store_true",
                     help="CPU dry run of the control flow (gloo + the test-suite's emulation of the "
                          "kernels, tiny images): measures nothing")
@@ -326,7 +347,8 @@ def main():
         args.batch_images = min(args.batch_images, 2)
         args.batch_workers = 1
     if args.config5:
-        leg = config5_leg(env, host, images, args.images_per_gpu, args.in_flight, size5, quality)
+        leg = config5_leg(env, host, images, args.images_per_gpu, args.in_flight, size5, quality,
+                          from_png=args.png)
         if rank == 0:
             print(json.dumps({
                 "metric": "MPix/s encoded at --quality 95", "value": leg["value"], "unit": "MPix/s",
@@ -398,9 +420,11 @@ def main():
                                   "unit": "MPix/s",
                                   "iterations": i4["counters"].get("number of iterations"),
                                   "output_sha256_matches_reference": True}
-    c5 = None
+    c5 = c5png = None
     if not args.no_4k and not args.no_config5:   # every rank takes part
         c5 = config5_leg(env, host, images, args.images_per_gpu, args.in_flight, size5, quality)
+        c5png = config5_leg(env, host, images, 1 if emu else args.images_per_gpu, args.in_flight, size5, quality,
+                            from_png=True)
     traffic = {}
     for path in (TRAFFIC_JSON, TRAFFIC_JSON_OLD):
         try:
@@ -479,6 +503,7 @@ def main():
         if c5 is not None:
             other = dict(other or {})
             other["config5_slice"] = c5
+            other["config5_slice_from_png"] = c5png
             out["scale_value"] = c5["value"]
             out["scale_metric"] = ("MPix/s over BASELINE config 5's batch slice: 8 independent 3840x2160 "
                                    "images per GPU, 8 in flight per GPU")

@@ -277,8 +277,9 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
     else:
         get = lambda k: images.shifted(base, k)
         proc = lambda im: host.process(im, quality=quality, device=env.device)
-    run_config5(get, min(2, images_per_gpu), proc, env.rank, env.world, env.dist, in_flight, env.fence,
-                env.tensor_device)   # warm-up
+    if not env.emulate:
+        run_config5(get, min(2, images_per_gpu), proc, env.rank, env.world, env.dist, in_flight, env.fence,
+                    env.tensor_device)   # warm-up
     recs, secs = run_config5(get, images_per_gpu, proc, env.rank, env.world, env.dist, in_flight,
                              env.fence, env.tensor_device)
     gold = {} if env.emulate else config5_goldens()
@@ -337,8 +338,8 @@ def main():
     host, L = env.libraries()
     rank, world, local_rank = env.rank, env.world, env.device
     emu = env.emulate
-    W, H = (48, 40) if emu else (1920, 1080)
-    W4, H4 = (56, 48) if emu else (3840, 2160)
+    W, H = (40, 32) if emu else (1920, 1080)
+    W4, H4 = (48, 40) if emu else (3840, 2160)
     quality = 84.0 if emu else QUALITY   # (the dry run: the shortest search)
     size5 = (W4, H4) if args.size == "4k" else (W, H)
     if emu:

@@ -78,6 +78,8 @@ SIGNATURES = {
     "gz_jpeg_histograms": (_I, [_P, _P, _P]),
     "gz_jpeg_histograms_ncomp": (_I, [_P, _P, _I, _P]),
     "gz_jpeg_scan": (_I, [_P, _I, _P, _P, _P]),
+    "gz_jpeg_scan_begin": (_I, [_P, _I, _P, _P]),
+    "gz_jpeg_scan_end": (_I, [_P, _P]),
     "gz_jpeg_scan_keep": (_I, [_P]),
     "gz_jpeg_scan_bytes": (_I, [_P, _I, _P, C.c_size_t, _P]),
     "gz_probe_blur": (_I, [_P, _P, C.c_float, C.c_float, _P]),
@@ -501,6 +503,19 @@ class Context:
         assert d.shape == (2, 3, 256) and cd.shape == (2, 3, 256)
         n = np.zeros(1, np.uint64)
         self._chk(self.L.lib.gz_jpeg_scan(self.handle, ncomp, _ptr(d), _ptr(cd), _ptr(n)))
+        return int(n[0])
+
+    def jpeg_scan_begin(self, ncomp, depth, code):
+        """jpeg_scan in two halves: enqueue (entropy stream) ..."""
+        d = np.ascontiguousarray(depth, np.uint8)
+        cd = np.ascontiguousarray(code, np.uint16)
+        assert d.shape == (2, 3, 256) and cd.shape == (2, 3, 256)
+        self._chk(self.L.lib.gz_jpeg_scan_begin(self.handle, ncomp, _ptr(d), _ptr(cd)))
+
+    def jpeg_scan_end(self):
+        """... and collect: the scan's exact (stuffed) size in bytes."""
+        n = np.zeros(1, np.uint64)
+        self._chk(self.L.lib.gz_jpeg_scan_end(self.handle, _ptr(n)))
         return int(n[0])
 
     def jpeg_scan_keep(self):

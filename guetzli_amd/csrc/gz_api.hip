@@ -436,6 +436,8 @@ struct gz_ctx {
   unsigned* d_words_kept = nullptr; size_t words_kept_cap = 0;
   unsigned long long scan_bits = 0, scan_ff = 0, kept_bits = 0, kept_ff = 0;
   bool have_jq = false, have_scan = false, have_kept = false;
+  bool scan_pending = false;           // between gz_jpeg_scan_begin and _end
+  void* h_scan_result = nullptr;       // pinned: total bits, 0xFF count of the scan in flight
 
   // global candidate order of phase B (gz_kernels_order.h)
   OrderEntry* d_order = nullptr; size_t order_cap = 0; size_t order_n = 0;
@@ -1465,6 +1467,7 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->d_part); (void)pool_free(c->d_order_nb); (void)pool_free(c->d_order_off);
   if (c->h_order_pending) (void)pool_host_free(c->h_order_pending);
   if (c->h_desc) (void)pool_host_free(c->h_desc);
+  if (c->h_scan_result) (void)pool_host_free(c->h_scan_result);
   (void)pool_free(c->d_cmp_stage);
   (void)pool_free(c->d_desc_st); (void)pool_free(c->d_desc_pv);
   (void)pool_free(c->d_order_counters); (void)pool_free(c->d_next_cand); (void)pool_free(c->d_weight);
@@ -2294,10 +2297,10 @@ int gz_jpeg_histograms_ncomp(gz_ctx* c, const int* q, int ncomp, uint32_t* count
   return GZ_OK;
 }
 
-int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* code,
-                 uint64_t* scan_bytes) {
+int gz_jpeg_scan_begin(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* code) {
   DeviceScope ds_(c);
-  if (!c || !depth || !code || !scan_bytes || (ncomp != 1 && ncomp != 3)) return GZ_E_ARG;
+  if (!c || !depth || !code || (ncomp != 1 && ncomp != 3)) return GZ_E_ARG;
+  c->scan_pending = false;
   if (!c->have_cand || !c->have_jq) { c->err = "gz_jpeg_histograms must precede gz_jpeg_scan"; return GZ_E_STATE; }
   // Upper bound of a scan: per coefficient a code of at most 16 bits and at most 16 extra
   // bits (int16 magnitudes), plus an end-of-block per block, plus the final padding.  Sized
@@ -2328,14 +2331,17 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   JpegCodes codes{c->d_code_depth, c->d_code_bits};
   const FrameGeom geom = frame_geom(c, ncomp);
   const int nmcu = geom.mcu_cols * geom.mcu_rows;
-  // GZ_MCU_WAVES=1: one MCU per workgroup (round 2's launch shape), for comparison
-  static const bool one_wave = getenv("GZ_MCU_WAVES") && atoi(getenv("GZ_MCU_WAVES")) == 1;
-  if (one_wave)
-    GZ_LAUNCH(k_jpeg_block_bits<1>, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
+  const int upm = ncomp == 1 ? 1 : (c->cfac == 2 ? 6 : 3);   // blocks per MCU
+  const dim3 egrid(gz_div_up(nmcu, kMcuWaves * kMcuPerWave)), eblock(64 * kMcuWaves);
+  if (upm == 3)
+    GZ_LAUNCH((k_jpeg_block_bits<3, kMcuWaves>), egrid, eblock, es, (const int16_t*)c->d_cand,
+              (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
+  else if (upm == 6)
+    GZ_LAUNCH((k_jpeg_block_bits<6, kMcuWaves>), egrid, eblock, es, (const int16_t*)c->d_cand,
               (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
   else
-    GZ_LAUNCH(k_jpeg_block_bits<kMcuWaves>, dim3(gz_div_up(nmcu, kMcuWaves)), dim3(64 * kMcuWaves), es,
-              (const int16_t*)c->d_cand, (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
+    GZ_LAUNCH((k_jpeg_block_bits<1, kMcuWaves>), egrid, eblock, es, (const int16_t*)c->d_cand,
+              (const int*)c->d_jq, geom, codes, c->d_mcu_bits);
   KCHK(c);
   TRY(enqueue_scan_offsets(c, 1, es, (const unsigned*)c->d_mcu_bits, nmcu, c->d_mcu_off));
   const unsigned long long* d_total = c->d_mcu_off + nmcu;
@@ -2343,26 +2349,37 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   GZ_LAUNCH(k_jpeg_clear_words, dim3(cgrid), dim3(256), es, c->d_words, d_total,
             (unsigned long long)c->words_cap, c->d_ff_count);
   KCHK(c);
-  if (one_wave)
-    GZ_LAUNCH(k_jpeg_emit<1>, dim3(nmcu), dim3(64), es, (const int16_t*)c->d_cand,
-              (const int*)c->d_jq, geom, codes, (const unsigned long long*)c->d_mcu_off,
-              c->d_words, (unsigned long long)c->words_cap);
+  if (upm == 3)
+    GZ_LAUNCH((k_jpeg_emit<3, kMcuWaves>), egrid, eblock, es, (const int16_t*)c->d_cand, (const int*)c->d_jq,
+              geom, codes, (const unsigned long long*)c->d_mcu_off, c->d_words, (unsigned long long)c->words_cap);
+  else if (upm == 6)
+    GZ_LAUNCH((k_jpeg_emit<6, kMcuWaves>), egrid, eblock, es, (const int16_t*)c->d_cand, (const int*)c->d_jq,
+              geom, codes, (const unsigned long long*)c->d_mcu_off, c->d_words, (unsigned long long)c->words_cap);
   else
-    GZ_LAUNCH(k_jpeg_emit<kMcuWaves>, dim3(gz_div_up(nmcu, kMcuWaves)), dim3(64 * kMcuWaves), es,
-              (const int16_t*)c->d_cand, (const int*)c->d_jq, geom, codes,
-              (const unsigned long long*)c->d_mcu_off, c->d_words, (unsigned long long)c->words_cap);
+    GZ_LAUNCH((k_jpeg_emit<1, kMcuWaves>), egrid, eblock, es, (const int16_t*)c->d_cand, (const int*)c->d_jq,
+              geom, codes, (const unsigned long long*)c->d_mcu_off, c->d_words, (unsigned long long)c->words_cap);
   KCHK(c);
   GZ_LAUNCH(k_jpeg_count_ff, dim3(cgrid), dim3(256), es, (const unsigned*)c->d_words, d_total,
             c->d_ff_count);
   KCHK(c);
+  // (a buffer of its own: the calls allowed between the two halves use result_buffer)
+  if (!c->h_scan_result) HIPCHK(c, pool_host_malloc(&c->h_scan_result, 16));
+  HIPCHK(c, hipMemcpyAsync(c->h_scan_result, d_total, 8, hipMemcpyDeviceToHost, es));
+  HIPCHK(c, hipMemcpyAsync((char*)c->h_scan_result + 8, c->d_ff_count, 8, hipMemcpyDeviceToHost, es));
+  c->have_scan = false;
+  c->scan_pending = true;
+  return GZ_OK;
+}
+
+int gz_jpeg_scan_end(gz_ctx* c, uint64_t* scan_bytes) {
+  DeviceScope ds_(c);
+  if (!c || !scan_bytes) return GZ_E_ARG;
+  if (!c->scan_pending) { c->err = "gz_jpeg_scan_begin must precede gz_jpeg_scan_end"; return GZ_E_STATE; }
+  c->scan_pending = false;
   unsigned long long total_bits = 0, ff = 0;
-  void* res = nullptr;
-  TRY(result_buffer(c, 16, &res));
-  HIPCHK(c, hipMemcpyAsync(res, d_total, 8, hipMemcpyDeviceToHost, es));
-  HIPCHK(c, hipMemcpyAsync((char*)res + 8, c->d_ff_count, 8, hipMemcpyDeviceToHost, es));
-  HIPCHK(c, hipStreamSynchronize(es));
-  memcpy(&total_bits, res, 8);
-  memcpy(&ff, (char*)res + 8, 8);
+  HIPCHK(c, hipStreamSynchronize(c->entropy_stream));
+  memcpy(&total_bits, c->h_scan_result, 8);
+  memcpy(&ff, (char*)c->h_scan_result + 8, 8);
   const unsigned long long nbytes = (total_bits + 7) / 8;
   if (nbytes / 4 + 4 > c->words_cap) { c->err = "scan larger than its bound (code lengths above 16?)"; return GZ_E_ARG; }
   c->scan_bits = total_bits;
@@ -2370,6 +2387,13 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   c->have_scan = true;
   *scan_bytes = nbytes + ff;
   return GZ_OK;
+}
+
+int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* code,
+                 uint64_t* scan_bytes) {
+  if (!scan_bytes) return GZ_E_ARG;
+  TRY(gz_jpeg_scan_begin(c, ncomp, depth, code));
+  return gz_jpeg_scan_end(c, scan_bytes);
 }
 
 int gz_jpeg_scan_keep(gz_ctx* c) {

@@ -11,7 +11,7 @@
 //   k_jpeg_block_bits   bits per MCU under those codes       -> exclusive scan = bit offsets
 //   k_jpeg_emit         every MCU writes its bits at its offset (MSB-first)
 //   k_jpeg_count_ff     bytes equal to 0xFF (each costs one stuffed 0x00)
-// One 64-lane wavefront per MCU; lane = zig-zag position; runs of zeros come
+// One 64-lane wavefront per MCU at a time; lane = zig-zag position; runs of zeros come
 // from a ballot over "coefficient != 0", bit positions inside the MCU from a wavefront
 // prefix sum.  Integer work only; byte-exact by contract.
 #pragma once
@@ -174,17 +174,6 @@ struct JpegCodes {          // device pointers; [2][3][256]: (DC, AC) x componen
   const unsigned short* code;
 };
 
-GZ_DEVFN int lane_bits(const LaneSyms& s, const unsigned char* depth_dc,
-                       const unsigned char* depth_ac) {
-  int len = 0;
-  if (s.sym >= 0) {
-    const unsigned char* d = s.is_dc ? depth_dc : depth_ac;
-    len = s.zrl * depth_ac[0xf0] + d[s.sym] + s.nbits;
-  }
-  if (s.eob) len += depth_ac[0];
-  return len;
-}
-
 // Inclusive prefix sum over the 64 lanes.
 GZ_DEVFN int wave_inclusive_sum(int v, int lane) {
 #pragma unroll
@@ -195,29 +184,168 @@ GZ_DEVFN int wave_inclusive_sum(int v, int lane) {
   return v;
 }
 
-// bits[m] = number of scan bits of MCU m.  One wavefront per MCU, kMcuWaves of them per
-// workgroup: with a workgroup per MCU the 129 600 single-wavefront workgroups of a 4K frame were
-// bound by the rate at which workgroups can be dispatched (49 us = one per clock), not by what
-// they compute.
+// The two kernels that walk the coefficients (bits per MCU here, k_jpeg_emit below) are bound by
+// the instructions a wavefront issues, and the entropy coder runs beside the Compare chain: every
+// issue slot it takes is one the chain waits for.  Round 2's versions spent some 300 instructions
+// per 8x8 block (an integer division per coefficient, two more for the DC prediction on lane 0,
+// 64-bit index arithmetic, a six-step shuffle scan per block, the frame's geometry interpreted at
+// run time); these do the same work with
+//   * the MCU's shape as a template constant (UPM = blocks per MCU: 1 luma alone, 3 4:4:4,
+//     6 4:2:0): the loop over the blocks is unrolled, their loads are issued together;
+//   * coefficient / q as one float multiply and an exact integer correction (quant_div);
+//   * everything uniform across a wavefront (the DC quantisers, the ZRL and EOB code lengths, the
+//     lane's zig-zag position and quantisers) loaded once per wavefront, which then serves
+//     kMcuPerWave consecutive MCUs;
+//   * ONE reduction per MCU in the counting kernel (the blocks' lengths are summed per lane first);
+//   * a symbol's code and its extra bits written as one value (at most 32 bits).
+// 4K, 4:4:4: counting 133 -> 72 us, emitting 208 -> 149 us (profiles/r03_chain_kernel_experiments.log).
+constexpr int kMcuPerWave = 4;
+
+// trunc(a / q) for |a| <= 32768, q >= 1, rq = 1.0f / q: the float product is within 2^-8 of the
+// quotient, so its truncation is off by at most one; the remainder says which way.
+GZ_DEVFN int quant_div(int a, int q, float rq) {
+  const int m = a < 0 ? -a : a;
+  int k = (int)((float)m * rq);
+  const int r = m - k * q;
+  k += r >= q ? 1 : 0;
+  k -= r < 0 ? 1 : 0;
+  return a < 0 ? -k : k;
+}
+
+template <int UPM> struct McuShape {
+  static constexpr int kComps = UPM == 1 ? 1 : 3;
+  GZ_DEVFN static constexpr int comp(int u) { return UPM == 6 ? (u < 4 ? 0 : u - 3) : u; }
+  GZ_DEVFN static constexpr int ix(int u) { return UPM == 6 && u < 4 ? (u & 1) : 0; }
+  GZ_DEVFN static constexpr int iy(int u) { return UPM == 6 && u < 4 ? (u >> 1) : 0; }
+  GZ_DEVFN static constexpr int samp(int c) { return UPM == 6 && c == 0 ? 2 : 1; }
+};
+
+// What a wavefront keeps for all its MCUs.
+template <int UPM> struct WaveTables {
+  int nat;               // this lane's natural index
+  int q[3];              // this lane's quantisers, per component
+  float rq[3];
+  int q0[3];             // the DC quantisers (uniform)
+  float rq0[3];
+  int zrl_len[3], eob_len[3];
+  unsigned long long lt; // lanes below this one
+};
+
+template <int UPM>
+GZ_DEVFN void wave_tables_load(const int* __restrict__ q, const unsigned char* __restrict__ depth,
+                               int lane, WaveTables<UPM>* t) {
+  t->nat = kNaturalOrderDev[lane];
+  t->lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int c = 0; c < McuShape<UPM>::kComps; ++c) {
+    t->q[c] = q[c * 64 + t->nat];
+    t->rq[c] = 1.0f / (float)t->q[c];
+    t->q0[c] = q[c * 64];
+    t->rq0[c] = 1.0f / (float)t->q0[c];
+    t->zrl_len[c] = depth[(3 + c) * 256 + 0xf0];
+    t->eob_len[c] = depth[(3 + c) * 256];
+  }
+}
+
+// The raw (dequantised) values one block needs: this lane's coefficient, the block's DC as the
+// writer sees it (padding blocks repeat the DC before them, geom_dc) and the DC it is predicted
+// from (0: the component's first block).
+struct UnitRaw {
+  int v, dc, prev;
+};
+
+template <int UPM>
+GZ_DEVFN UnitRaw unit_load(const int16_t* __restrict__ coeffs, const FrameGeom& g, int u, int mx,
+                           int my, int nat) {
+  typedef McuShape<UPM> S;
+  const int c = S::comp(u), sp = S::samp(c), ix = S::ix(u), iy = S::iy(u);
+  const int bw = g.bw[c], bh = g.bh[c];
+  const int16_t* base = coeffs + (size_t)g.coff[c] * 64;
+  const int bx = mx * sp + ix, by = my * sp + iy;
+  auto dc_of = [&](int x, int y) {   // geom_dc's clamping, without the division
+    int rx = x < bw ? x : bw - 1, ry = y;
+    if (y >= bh) { rx = bw - 1; ry = bh - 1; }
+    return (int)base[(unsigned)(ry * bw + rx) * 64u];
+  };
+  UnitRaw r;
+  const bool real = bx < bw && by < bh;
+  r.v = real ? (int)base[(unsigned)(by * bw + bx) * 64u + (unsigned)nat] : 0;
+  r.dc = dc_of(bx, by);
+  // the component's previous block in scan order (EncodeScan, jpeg_data_writer.cc:499-536)
+  int px = 0, py = 0;
+  bool has = true;
+  if (ix > 0) { px = bx - 1; py = by; }
+  else if (iy > 0) { px = mx * sp + sp - 1; py = by - 1; }
+  else if (mx > 0) { px = mx * sp - 1; py = my * sp + sp - 1; }
+  else if (my > 0) { px = g.mcu_cols * sp - 1; py = my * sp - 1; }
+  else has = false;
+  r.prev = has ? dc_of(px, py) : 0;
+  return r;
+}
+
+// The block's symbols from the raw values (lane_symbols above, on what unit_load fetched).
+template <int UPM>
+GZ_DEVFN LaneSyms unit_symbols(const UnitRaw& r, const WaveTables<UPM>& t, int c, int lane) {
+  const int v = quant_div(r.v, t.q[c], t.rq[c]);
+  const bool nz = lane >= 1 && v != 0;
+  const unsigned long long mask = __ballot(nz);
+  LaneSyms s;
+  s.zrl = 0; s.sym = -1; s.nbits = 0; s.extra = 0; s.eob = 0; s.is_dc = lane == 0;
+  if (nz) {
+    const unsigned long long below = mask & t.lt;
+    const int prev = below ? 63 - __clzll((long long)below) : 0;
+    const int run = lane - prev - 1;
+    const int mag = v < 0 ? -v : v;
+    const int bits_v = v < 0 ? ~mag : mag;
+    s.zrl = run >> 4;
+    s.nbits = bit_length((unsigned)mag);
+    const int sym = ((run & 15) << 4) + s.nbits;
+    s.sym = sym > 255 ? 255 : sym;   // unreachable for 8-bit image data (|coeff| < 2^15)
+    s.extra = (unsigned)bits_v & ((1u << s.nbits) - 1u);
+  }
+  if (lane == 63) s.eob = mask ? (63 - __clzll((long long)mask)) < 63 : 1;
+  if (lane == 0)
+    lane_set_dc(&s, quant_div(r.dc, t.q0[c], t.rq0[c]), quant_div(r.prev, t.q0[c], t.rq0[c]));
+  return s;
+}
+
+// kMcuWaves wavefronts per workgroup: with a workgroup per MCU the 129 600 single-wavefront
+// workgroups of a 4K frame were bound by the rate at which workgroups can be dispatched (49 us =
+// one per clock), not by what they compute.
 constexpr int kMcuWaves = 4;
 
-template <int W>
+// bits[m] = number of scan bits of MCU m.
+template <int UPM, int W>
 __global__ __launch_bounds__(64 * W) void k_jpeg_block_bits(const int16_t* __restrict__ coeffs,
                                                         const int* __restrict__ q, FrameGeom g,
-                                                        JpegCodes codes,
-                                                        unsigned* __restrict__ bits) {
-  const int lane = threadIdx.x & 63, m = blockIdx.x * W + (int)(threadIdx.x >> 6);
-  if (m >= g.mcu_cols * g.mcu_rows) return;   // (a whole wavefront)
-  const int mx = m % g.mcu_cols, my = m / g.mcu_cols, upm = geom_units_per_mcu(g);
-  int total = 0;
-  for (int u = 0; u < upm; ++u) {
-    int c, ix, iy;
-    geom_unit(g, u, &c, &ix, &iy);
-    const LaneSyms s = lane_symbols(coeffs, q, g, c, ix, iy, mx, my, lane);
-    const int len = lane_bits(s, codes.depth + c * 256, codes.depth + (3 + c) * 256);
-    total += __shfl(wave_inclusive_sum(len, lane), 63);
+                                                        JpegCodes codes, unsigned* __restrict__ bits) {
+  typedef McuShape<UPM> S;
+  const int lane = threadIdx.x & 63;
+  const int nmcu = g.mcu_cols * g.mcu_rows;
+  const int m0 = (blockIdx.x * W + (int)(threadIdx.x >> 6)) * kMcuPerWave;
+  if (m0 >= nmcu) return;   // (a whole wavefront)
+  WaveTables<UPM> t;
+  wave_tables_load<UPM>(q, codes.depth, lane, &t);
+  int mx = m0 % g.mcu_cols, my = m0 / g.mcu_cols;
+  for (int m = m0; m < m0 + kMcuPerWave && m < nmcu; ++m) {
+    UnitRaw raw[UPM];
+#pragma unroll
+    for (int u = 0; u < UPM; ++u) raw[u] = unit_load<UPM>(coeffs, g, u, mx, my, t.nat);
+    int len = 0;
+#pragma unroll
+    for (int u = 0; u < UPM; ++u) {
+      const int c = S::comp(u);
+      const LaneSyms s = unit_symbols<UPM>(raw[u], t, c, lane);
+      if (s.sym >= 0) {
+        const unsigned char* d = codes.depth + (s.is_dc ? c : 3 + c) * 256;
+        len += s.zrl * t.zrl_len[c] + d[s.sym] + s.nbits;
+      }
+      if (s.eob) len += t.eob_len[c];
+    }
+    const int total = __shfl(wave_inclusive_sum(len, lane), 63);
+    if (lane == 0) bits[m] = (unsigned)total;
+    if (++mx == g.mcu_cols) { mx = 0; ++my; }
   }
-  if (lane == 0) bits[m] = (unsigned)total;
 }
 
 // off[0..n] = exclusive prefix sums of bits[0..n) (64-bit), in one pass over the array by
@@ -340,79 +468,114 @@ __global__ __launch_bounds__(256) void k_scan_offsets(const unsigned* __restrict
 // the staging buffer OR their pieces straight into global memory.
 constexpr int kStageWords = 256;
 
-GZ_DEVFN void or_bits(unsigned* words, bool lds, unsigned long long pos, unsigned value, int len) {
+GZ_DEVFN void or_bits(unsigned* words, unsigned long long pos, unsigned value, int len) {
   if (len == 0) return;
   const unsigned long long w = pos >> 5;
   const int sh = (int)(pos & 31);
   const unsigned long long x = (unsigned long long)value << (64 - len - sh);
   const unsigned hi = (unsigned)(x >> 32), lo = (unsigned)x;
-  (void)lds;
   if (hi) atomicOr(&words[w], hi);
   if (lo) atomicOr(&words[w + 1], lo);
 }
 
-template <int W>
+// `value`'s low `len` (1..32) bits at stream position pos: at most two words.
+GZ_DEVFN void or_bits32(unsigned* words, unsigned long long pos, unsigned value, int len) {
+  const unsigned long long w = pos >> 5;
+  const int sh = (int)(pos & 31);
+  const unsigned long long x = (unsigned long long)value << (64 - len - sh);
+  const unsigned hi = (unsigned)(x >> 32), lo = (unsigned)x;
+  if (hi) atomicOr(&words[w], hi);
+  if (lo) atomicOr(&words[w + 1], lo);
+}
+
+template <int UPM, int W>
 __global__ __launch_bounds__(64 * W) void k_jpeg_emit(const int16_t* __restrict__ coeffs,
                                                   const int* __restrict__ q, FrameGeom g,
                                                   JpegCodes codes,
                                                   const unsigned long long* __restrict__ off,
                                                   unsigned* __restrict__ words,
                                                   unsigned long long cap_words) {
-  // one wavefront per MCU, each with its own staging area (no workgroup barrier: the wavefronts
-  // of a workgroup have nothing to do with each other)
+  typedef McuShape<UPM> S;
+  // every wavefront has its own staging area (no workgroup barrier: the wavefronts of a
+  // workgroup have nothing to do with each other)
   __shared__ unsigned stage_all[W][kStageWords + 2];
   unsigned* stage = stage_all[threadIdx.x >> 6];
-  const int lane = threadIdx.x & 63, m = blockIdx.x * W + (int)(threadIdx.x >> 6);
-  const int nmcu = g.mcu_cols * g.mcu_rows, upm = geom_units_per_mcu(g);
-  if (m >= nmcu) return;   // (a whole wavefront)
-  const int mx = m % g.mcu_cols, my = m / g.mcu_cols;
-  const unsigned long long start = off[m], end = off[m + 1];
-  // the last MCU also writes the 1-padding up to the byte boundary (BitWriter::JumpToByteBoundary)
-  const int pad = m == nmcu - 1 ? (int)((8 - (end & 7)) & 7) : 0;
-  // `words` is sized for valid code lengths (<= 16 bits); with anything else the scan can be
-  // longer, the host reports that afterwards, and nothing is written past the buffer here
-  if (((end + pad + 63) >> 5) + 1 > cap_words) return;
-  const unsigned long long word0 = start >> 5;
-  const unsigned long long span = (end + pad) - (word0 << 5);   // bits from word0's first bit
-  const bool staged = span <= (unsigned long long)kStageWords * 32;
-  if (staged) {
-    for (int i = lane; i < kStageWords + 2; i += 64) stage[i] = 0;
-    GZ_WAVE_SYNC();
-  }
-  unsigned* dst = staged ? stage : words;
-  unsigned long long base = staged ? start - (word0 << 5) : start;
-  for (int u = 0; u < upm; ++u) {
-    int c, ix, iy;
-    geom_unit(g, u, &c, &ix, &iy);
-    const LaneSyms s = lane_symbols(coeffs, q, g, c, ix, iy, mx, my, lane);
-    const unsigned char* ddc = codes.depth + c * 256;
-    const unsigned char* dac = codes.depth + (3 + c) * 256;
-    const unsigned short* cdc = codes.code + c * 256;
-    const unsigned short* cac = codes.code + (3 + c) * 256;
-    const int len = lane_bits(s, ddc, dac);
-    const int incl = wave_inclusive_sum(len, lane);
-    const int total = __shfl(incl, 63);
-    unsigned long long pos = base + (unsigned long long)(incl - len);
-    if (s.sym >= 0) {
-      for (int z = 0; z < s.zrl; ++z) {
-        or_bits(dst, staged, pos, cac[0xf0], dac[0xf0]);
-        pos += dac[0xf0];
-      }
-      const int dl = s.is_dc ? ddc[s.sym] : dac[s.sym];
-      or_bits(dst, staged, pos, s.is_dc ? cdc[s.sym] : cac[s.sym], dl);
-      pos += dl;
-      or_bits(dst, staged, pos, s.extra, s.nbits);
-      pos += s.nbits;
-    }
-    if (s.eob) or_bits(dst, staged, pos, cac[0], dac[0]);
-    base += (unsigned long long)total;
-  }
-  if (pad && lane == 0) or_bits(dst, staged, base, (1u << pad) - 1u, pad);
-  if (staged) {
-    GZ_WAVE_SYNC();
+  const int lane = threadIdx.x & 63;
+  const int nmcu = g.mcu_cols * g.mcu_rows;
+  const int m0 = (blockIdx.x * W + (int)(threadIdx.x >> 6)) * kMcuPerWave;
+  if (m0 >= nmcu) return;   // (a whole wavefront)
+  WaveTables<UPM> t;
+  wave_tables_load<UPM>(q, codes.depth, lane, &t);
+  int mx = m0 % g.mcu_cols, my = m0 / g.mcu_cols;
+  for (int m = m0; m < m0 + kMcuPerWave && m < nmcu; ++m) {
+    const unsigned long long start = off[m], end = off[m + 1];
+    // the last MCU also writes the 1-padding up to the byte boundary (BitWriter::JumpToByteBoundary)
+    const int pad = m == nmcu - 1 ? (int)((8 - (end & 7)) & 7) : 0;
+    // `words` is sized for valid code lengths (<= 16 bits); with anything else the scan can be
+    // longer, the host reports that afterwards, and nothing is written past the buffer here
+    if (((end + pad + 63) >> 5) + 1 > cap_words) return;
+    UnitRaw raw[UPM];
+#pragma unroll
+    for (int u = 0; u < UPM; ++u) raw[u] = unit_load<UPM>(coeffs, g, u, mx, my, t.nat);
+    const unsigned long long word0 = start >> 5;
+    const unsigned long long span = (end + pad) - (word0 << 5);   // bits from word0's first bit
+    const bool staged = span <= (unsigned long long)kStageWords * 32;
     const int nwords = (int)((span + 31) >> 5);
-    for (int i = lane; i < nwords; i += 64)
-      if (stage[i]) atomicOr(&words[word0 + i], stage[i]);
+    if (staged) {
+      for (int i = lane; i < nwords + 1; i += 64) stage[i] = 0;
+      GZ_WAVE_SYNC();
+    }
+    unsigned* dst = staged ? stage : words;
+    unsigned long long base = staged ? start - (word0 << 5) : start;
+#pragma unroll
+    for (int u = 0; u < UPM; ++u) {
+      const int c = S::comp(u);
+      const LaneSyms s = unit_symbols<UPM>(raw[u], t, c, lane);
+      const int tab = (s.is_dc ? c : 3 + c) * 256;
+      int dl = 0;
+      unsigned cd = 0;
+      if (s.sym >= 0) {
+        dl = codes.depth[tab + s.sym];
+        cd = codes.code[tab + s.sym];
+      }
+      int len = s.sym >= 0 ? s.zrl * t.zrl_len[c] + dl + s.nbits : 0;
+      if (s.eob) len += t.eob_len[c];
+      const int incl = wave_inclusive_sum(len, lane);
+      const int total = __shfl(incl, 63);
+      unsigned long long pos = base + (unsigned long long)(incl - len);
+      if (s.sym >= 0) {
+        if (s.zrl) {
+          const unsigned zc = codes.code[(3 + c) * 256 + 0xf0];
+          for (int z = 0; z < s.zrl; ++z) {
+            or_bits(dst, pos, zc, t.zrl_len[c]);
+            pos += t.zrl_len[c];
+          }
+        }
+        // the code and the extra bits that follow it as one value
+        if (dl + s.nbits <= 32) {
+          if (dl + s.nbits > 0) or_bits32(dst, pos, (cd << s.nbits) | s.extra, dl + s.nbits);
+        } else {   // (code lengths no JPEG has: the host refuses the result)
+          or_bits(dst, pos, cd, dl);
+          or_bits(dst, pos + dl, s.extra, s.nbits);
+        }
+        pos += dl + s.nbits;
+      }
+      if (s.eob) or_bits(dst, pos, codes.code[(3 + c) * 256], t.eob_len[c]);
+      base += (unsigned long long)total;
+    }
+    if (pad && lane == 0) or_bits(dst, base, (1u << pad) - 1u, pad);
+    if (staged) {
+      GZ_WAVE_SYNC();
+      // whole words of the MCU's own are stored; the first and the last are shared with the
+      // neighbours (the buffer is zero before the launch)
+      for (int i = lane; i < nwords; i += 64) {
+        const unsigned x = stage[i];
+        if (i == 0 || i == nwords - 1) { if (x) atomicOr(&words[word0 + i], x); }
+        else words[word0 + i] = x;
+      }
+      GZ_WAVE_SYNC();   // (the staging area is cleared for the next MCU)
+    }
+    if (++mx == g.mcu_cols) { mx = 0; ++my; }
   }
 }
 

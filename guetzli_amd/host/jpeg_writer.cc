@@ -189,11 +189,7 @@ size_t HistogramHeaderBits(const SymbolHistogram& h) {
 }
 
 size_t HistogramEntropyBits(const SymbolHistogram& h, const uint8_t* depth) {
-  size_t bits = 0;
-  for (int i = 0; i + 1 < kHistoSize; ++i)
-    bits += (size_t)(h.counts[i] / 2) * (depth[i] + (i & 0xf));
-  bits += (bits * 3 + 512) >> 10;   // estimated 0xff escapes
-  return bits;
+  return EntropyBitsFromRaw(HistogramRawBits(h, depth));
 }
 
 size_t ClusterHistograms(SymbolHistogram* histo, size_t* num, int* histo_indexes,
@@ -227,8 +223,14 @@ size_t ClusterHistograms(SymbolHistogram* histo, size_t* num, int* histo_indexes
   return (total + 7) / 8;
 }
 
-void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHistogram* h) {
+void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHistogram* h,
+                       const uint8_t* depth, int64_t* raw_bits) {
   int run = 0;
+  int64_t bits = 0;   // what the symbols cost under `depth`: HistogramEntropyBits' sum, term by term
+  auto add = [&](int symbol) {
+    h->Add(symbol, weight);
+    if (depth) bits += depth[symbol] + (symbol & 0xf);
+  };
   for (int k = 1; k < 64; ++k) {
     const int nat = kNaturalOrder[k];
     const int v = block[nat];
@@ -237,14 +239,27 @@ void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHis
       continue;
     }
     while (run > 15) {
-      h->Add(0xf0, weight);
+      add(0xf0);
       run -= 16;
     }
     const int mag = std::abs(q ? v / q[nat] : v);
-    h->Add((run << 4) + FloorLog2((uint32_t)mag) + 1, weight);
+    add((run << 4) + FloorLog2((uint32_t)mag) + 1);
     run = 0;
   }
-  if (run > 0) h->Add(0, weight);
+  if (run > 0) add(0);
+  if (raw_bits) *raw_bits += weight * bits;
+}
+
+int64_t HistogramRawBits(const SymbolHistogram& h, const uint8_t* depth) {
+  int64_t bits = 0;
+  for (int i = 0; i + 1 < kHistoSize; ++i) bits += (int64_t)(h.counts[i] / 2) * (depth[i] + (i & 0xf));
+  return bits;
+}
+
+size_t EntropyBitsFromRaw(int64_t raw) {
+  size_t bits = (size_t)raw;
+  bits += (bits * 3 + 512) >> 10;   // estimated 0xff escapes
+  return bits;
 }
 
 // ------------------------------------------------------------------------- frames ----

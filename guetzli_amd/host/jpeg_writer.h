@@ -47,7 +47,13 @@ size_t ClusterHistograms(SymbolHistogram* histo, size_t* num, int* histo_indexes
 // One AC block's symbols (UpdateACHistogramForDCTBlock :197-216 / processor.cc:471-495):
 // coefficients are DEQUANTISED values, q the component's quant matrix (null = already
 // quantised).
-void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHistogram* h);
+// With depth / raw_bits: *raw_bits follows HistogramRawBits(h, depth) through the update (the
+// search's size estimate after every coefficient step without a pass over the histograms).
+void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHistogram* h,
+                       const uint8_t* depth = nullptr, int64_t* raw_bits = nullptr);
+// HistogramEntropyBits == EntropyBitsFromRaw(HistogramRawBits(h, depth)).
+int64_t HistogramRawBits(const SymbolHistogram& h, const uint8_t* depth);
+size_t EntropyBitsFromRaw(int64_t raw);
 
 // A frame ready to be written: quantised coefficient planes + tables.
 struct QuantTable {

@@ -275,6 +275,8 @@ class Encoder {
   size_t Pos(int c, int block, int k) const { return ((size_t)coff_[c] + block) * 64 + k; }
   bool Serialize(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac,
                  size_t* size);
+  bool SerializeBegin(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac);
+  bool SerializeEnd(const int (*q)[64], size_t* size);
   bool CompareBegin();
   bool CompareCurrent();
   bool MaybeOutput(size_t size);
@@ -337,6 +339,8 @@ class Encoder {
   long n_fast_ = 0;
   double t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0, n_evaluations_ = 0;
+  // where the host's time goes at the end of an iteration (stats_->timers)
+  double t_head_ = 0, t_cmp_begin_ = 0, t_cmp_end_ = 0, t_scan_begin_ = 0, t_scan_end_ = 0, t_ahead_begin_ = 0;
   bool build_ahead_ = true;     // GZ_ORDER_AHEAD=0: build each order when the loop asks for it
   size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device (32-64 K measured best at 1080p and 4K)
 };
@@ -423,6 +427,14 @@ bool Encoder::DeviceHistograms(const QuantMatrix q, SymbolHistogram* dc, SymbolH
 
 bool Encoder::Serialize(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac,
                         size_t* size) {
+  return SerializeBegin(q, dc, ac) && SerializeEnd(q, size);
+}
+
+// Serialize in two halves.  _Begin: the marker segments and Huffman codes on the host, then the
+// scan enqueued on the context's entropy stream (gz_jpeg_scan_begin) -- the caller goes on
+// enqueueing (the next order's construction) while the entropy coder runs beside the
+// evaluation.  _End collects the scan's length.
+bool Encoder::SerializeBegin(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac) {
   Stopwatch sw;
   Frame f;
   // a single component is written when both chroma planes are entirely zero
@@ -439,13 +451,20 @@ bool Encoder::Serialize(const int (*q)[64], const SymbolHistogram* dc, const Sym
     ac = ac1;
   }
   if (!BuildJpegHead(f, dc, ac, &head_)) return Fail("BuildJpegHead", GZ_E_STATE);
+  { const double d = sw.lap(); t_write_ += d; t_head_ += d; }
+  const int rc = gz_jpeg_scan_begin(ctx_, head_.ncomp, &head_.depth[0][0][0], &head_.code[0][0][0]);
+  { const double d = sw.lap(); t_write_ += d; t_scan_begin_ += d; }
+  if (rc != GZ_OK) return Fail("gz_jpeg_scan", rc);
+  return true;
+}
+bool Encoder::SerializeEnd(const int (*q)[64], size_t* size) {
+  Stopwatch sw;
   uint64_t scan_bytes = 0;
-  const int rc = gz_jpeg_scan(ctx_, head_.ncomp, &head_.depth[0][0][0], &head_.code[0][0][0],
-                              &scan_bytes);
+  const int rc = gz_jpeg_scan_end(ctx_, &scan_bytes);
   if (rc != GZ_OK) return Fail("gz_jpeg_scan", rc);
   *size = head_.bytes.size() + (size_t)scan_bytes + 2;   // + EOI
   if (jpeg_input_ && !meta_.strip) *size += meta_.tail_data.size();
-  t_write_ += sw.lap();
+  { const double d = sw.lap(); t_write_ += d; t_scan_end_ += d; }
   if (verify_ && !VerifyAgainstHostWriter(q, *size)) return false;
   return true;
 }
@@ -503,14 +522,14 @@ bool Encoder::VerifyAgainstHostWriter(const int (*q)[64], size_t size) {
 bool Encoder::CompareBegin() {
   Stopwatch sw;
   const int rc = gz_compare_begin(ctx_);
-  t_compare_ += sw.lap();
+  { const double d = sw.lap(); t_compare_ += d; t_cmp_begin_ += d; }
   if (rc != GZ_OK) return Fail("gz_compare_begin", rc);
   return true;
 }
 bool Encoder::CompareCurrent() {
   Stopwatch sw;
   const int rc = gz_compare_end(ctx_, &distance_);
-  t_compare_ += sw.lap();
+  { const double d = sw.lap(); t_compare_ += d; t_cmp_end_ += d; }
   if (rc != GZ_OK) return Fail("gz_compare_end", rc);
   Log(" BA[100.00%%] D[%6.4f]", distance_);
   return true;
@@ -646,6 +665,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
     if (f.ncomp == 1) { ac_histo[1].Clear(); ac_histo[2].Clear(); }
   }
   std::vector<uint8_t> ac_depths(3 * kHistoSize);
+  int64_t ac_raw_bits[3] = {0, 0, 0};
+  auto recount_raw_bits = [&] {
+    for (int c = 0; c < ncomp; ++c) ac_raw_bits[c] = HistogramRawBits(ac_histo[c], &ac_depths[c * kHistoSize]);
+  };
   int ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
   const int base_size = header_size + dc_size + ac_header +
                         (int)EntropyDataSize(ac_histo, ncomp, ac_depths.data());
@@ -781,13 +804,14 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
         int16_t* blk = &img_[Pos(c, b, 0)];
         const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
-        AddBlockACSymbols(blk, q, -1, &ac_histo[c]);
+        const uint8_t* depth = &ac_depths[c * kHistoSize];
+        AddBlockACSymbols(blk, q, -1, &ac_histo[c], depth, &ac_raw_bits[c]);
         if (!(newval == 0 && IsPrecious(orig_blk, k))) {
           blk[k] = (int16_t)newval;
           edit_pos.push_back((int32_t)Pos(c, b, k));
           edit_val.push_back((int16_t)newval);
         }
-        AddBlockACSymbols(blk, q, 1, &ac_histo[c]);
+        AddBlockACSymbols(blk, q, 1, &ac_histo[c], depth, &ac_raw_bits[c]);
         next_cand[b] += direction;
         mirror_cand[b] = next_cand[b];
         if (!touched[b]) {
@@ -888,16 +912,26 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         t_fs_rest_ += fw.lap();
         n_steps_ += (long)fast_until;
         n_fast_ += (long)fast_until;
+        // EntropyDataSize(ac_histo, ncomp, ac_depths) after every step, without its pass over the
+        // histograms: ac_raw_bits[c] follows HistogramRawBits(ac_histo[c], depths of c) through
+        // apply_step and is recounted when the depths change
+        recount_raw_bits();
         for (size_t i = fast_until; i < n_order; ++i) {
           apply_step(i);
           if (i % 10 == 0) {
             Stopwatch cw;
             ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
+            recount_raw_bits();
             t_pb_codes_ += cw.lap();
           }
           ++n_steps_;
-          est_size = header_size + dc_size + ac_header +
-                     (int)EntropyDataSize(ac_histo, ncomp, ac_depths.data());
+          size_t data_bits = 0;
+          for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ac_raw_bits[c]);
+          est_size = header_size + dc_size + ac_header + (int)((data_bits + 7) / 8);
+          if (verify_ && (data_bits + 7) / 8 != EntropyDataSize(ac_histo, ncomp, ac_depths.data())) {
+            fprintf(stderr, "guetzli_amd: incremental size estimate differs from a recount\n");
+            return false;
+          }
           if (changed_coeffs > min_coeffs_to_change &&
               std::abs(est_size - prev_size) > min_size_delta)
             break;
@@ -931,6 +965,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
 
       size_t jpg_size = 0;
       if (!CompareBegin()) return false;
+      // the entropy coder goes to its own stream before anything else is enqueued: it runs beside
+      // the evaluation, not behind the host work below
+      if (!SerializeBegin(quant_, dc_histo, ac_histo)) return false;
+      Stopwatch aw;
       if (build_ahead_) {
         // the next iteration of this direction, radius 1, if it comes to that (processor.cc:
         // 622-663 behind :767): everything it reads is final -- next_cand, max_block_error
@@ -944,7 +982,8 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         }
         ahead = direction;
       }
-      if (!Serialize(quant_, dc_histo, ac_histo, &jpg_size)) return false;
+      t_ahead_begin_ += aw.lap();
+      if (!SerializeEnd(quant_, &jpg_size)) return false;
       Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
           "EstErr[%.2f%%]",
           stats_->counters[kNumItersCnt], FrameStr(), comp_mask, direction > 0 ? "up" : "down",
@@ -1060,6 +1099,12 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->timers["block_search"] = t_blocksearch_;
   stats_->timers["phase_b_host"] = t_phaseb_;
   stats_->timers["block_upload"] = t_upload_;
+  stats_->timers["jpeg_head"] = t_head_;
+  stats_->timers["compare_begin"] = t_cmp_begin_;
+  stats_->timers["compare_end"] = t_cmp_end_;
+  stats_->timers["jpeg_scan_begin"] = t_scan_begin_;
+  stats_->timers["jpeg_scan_end"] = t_scan_end_;
+  stats_->timers["pb_order_ahead_begin"] = t_ahead_begin_;
   stats_->timers["pb_order"] = t_pb_order_;
   stats_->timers["pb_sort"] = t_pb_sort_;
   stats_->timers["pb_loop"] = t_pb_loop_;

@@ -380,6 +380,12 @@ int gz_order_descend_end(gz_ctx* ctx, uint64_t* log, int cap_levels, int* levels
  * kernels run on the context's entropy stream, ordered behind whatever put the candidate in
  * place; the call returns after its single synchronisation of that stream.
  *
+ * gz_jpeg_scan_begin / _end are the same call in two halves: _begin enqueues the scan on the
+ * entropy stream and returns, _end waits for it and returns the length.  Between them the
+ * caller may enqueue what gz_compare_begin's contract allows (the evaluation itself, the next
+ * order's construction: gz_order_build_auto_begin / gz_order_descend_begin) -- the entropy
+ * coder then runs beside the evaluation instead of behind the host code that enqueues it.
+ *
  * gz_jpeg_scan_keep snapshots the last scan on the device (the caller's "best so far",
  * processor.cc:139-148); gz_jpeg_scan_bytes downloads the last (kept = 0) or the kept
  * (kept = 1) scan as stuffed bytes. */
@@ -390,6 +396,8 @@ int gz_jpeg_histograms(gz_ctx* ctx, const int* q, uint32_t* counts);
 int gz_jpeg_histograms_ncomp(gz_ctx* ctx, const int* q, int ncomp, uint32_t* counts);
 int gz_jpeg_scan(gz_ctx* ctx, int ncomp, const uint8_t* depth, const uint16_t* code,
                  uint64_t* scan_bytes);
+int gz_jpeg_scan_begin(gz_ctx* ctx, int ncomp, const uint8_t* depth, const uint16_t* code);
+int gz_jpeg_scan_end(gz_ctx* ctx, uint64_t* scan_bytes);
 int gz_jpeg_scan_keep(gz_ctx* ctx);
 int gz_jpeg_scan_bytes(gz_ctx* ctx, int kept, uint8_t* out, size_t cap, size_t* n);
 

@@ -565,8 +565,17 @@ def test_global_order420(L):
 def _params_cases():
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "params_hashes.json")
-    return sorted(json.load(open(path)).items()) if os.path.exists(path) else []
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "golden", "params_hashes.json")
+    cases = dict(json.load(open(path))) if os.path.exists(path) else {}
+    # round 3: the 4:2:0 path, another quality, an odd size and 4:2:0 JPEG input at BASELINE sizes
+    # (tools/gen_golden_hashes_r3.py, one file per case)
+    r3 = os.path.join(here, "golden", "params_r3")
+    if os.path.isdir(r3):
+        for f in sorted(os.listdir(r3)):
+            if f.endswith(".json"):
+                cases[f[:-5]] = json.load(open(os.path.join(r3, f)))
+    return sorted(cases.items())
 
 
 @pytest.mark.parametrize("name,exp", _params_cases())

@@ -31,6 +31,8 @@ static decltype(&gz_order_upload) p_upload;
 static decltype(&gz_order_partition) p_partition;
 static decltype(&gz_order_fetch) p_fetch;
 static decltype(&gz_order_descend) p_descend;
+static decltype(&gz_last_error) p_last_error;
+static int g_pattern = -1;
 static gz_ctx* g_ctx;
 static long g_partitions = 0, g_fetched = 0, g_replayed = 0;
 
@@ -74,7 +76,11 @@ static int check(const std::vector<E>& v, const char* what, size_t threshold, si
       // replays its log instead of asking for the partitions one by one
       dev.log.assign(3 * 12, 0);
       int levels = 0;
-      if (p_descend(g_ctx, f - 1, threshold, 12, dev.log.data(), &levels) != GZ_OK) { printf("FAIL descend\n"); return 1; }
+      if (p_descend(g_ctx, f - 1, threshold, 12, dev.log.data(), &levels) != GZ_OK) {
+        printf("FAIL descend %s pattern %d n=%zu last=%zu threshold=%zu: %s\n", what, g_pattern, v.size(), f - 1, threshold,
+               p_last_error ? p_last_error(g_ctx) : "");
+        return 1;
+      }
       dev.log.resize(3 * (size_t)levels);
     }
     lazy.SelectPrefix(f);
@@ -118,6 +124,7 @@ int main(int argc, char** argv) {
   p_partition = (decltype(p_partition))dlsym(h, "gz_order_partition");
   p_fetch = (decltype(p_fetch))dlsym(h, "gz_order_fetch");
   p_descend = (decltype(p_descend))dlsym(h, "gz_order_descend");
+  p_last_error = (decltype(p_last_error))dlsym(h, "gz_last_error");
   if (!p_create || !p_destroy || !p_upload || !p_partition || !p_fetch || !p_descend) { printf("missing symbol\n"); return 2; }
   const size_t max_n = (size_t)atol(argv[2]);
   std::vector<size_t> thresholds;
@@ -152,6 +159,10 @@ int main(int argc, char** argv) {
         }
         // make ids distinguishable among equal keys
         for (size_t i = 0; i < n; ++i) v[i].first = (int)i;
+        // (GZ_TEST_ONLY_N=<n>: the checks of that size only; the data of the others is still drawn)
+        static const size_t only_n = getenv("GZ_TEST_ONLY_N") ? (size_t)atol(getenv("GZ_TEST_ONLY_N")) : 0;
+        if (only_n && n != only_n) continue;
+        g_pattern = pattern;
         fails += check(v, "full", thr, 0, 0);
         if (n > 1000) {
           fails += check(v, "prefix", thr, n / 50 + 3, 0);

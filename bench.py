@@ -32,7 +32,10 @@ Also on the JSON line:
                   WRITE_SIZE passes committed under profiles/ (the counters cannot be read
                   from inside this process; `traffic_head` = the commit they were taken at).
                   `roofline_4k` = the same measurement on 3840x2160, the size the chain fills
-                  the chip at.
+                  the chip at.  `valu` inside both: the chain's VALU floor (SQ_INSTS_VALU of its
+                  kernels from the committed --pmc pass / the chip's VALU issue rate) -- with
+                  contraction off the chain holds more VALU time than HBM time, and its
+                  largest kernel (Malta) runs at 0.9 of its own VALU floor.
   scale_value  -- BASELINE config 5's work split on the GPUs this run has (the `config5_slice`
                   leg): 3840x2160 images, 8 per GPU (image k -> rank k mod N), 8 in flight per
                   GPU, records all-gathered over the process group; every output whose
@@ -51,6 +54,7 @@ flow -- process group, barriers, max-over-ranks, all-gathers, rank-0-only legs -
 and the test-suite's CPU emulation of the kernels on tiny images.  It measures nothing.
 """
 import argparse
+import csv
 import hashlib
 import json
 import os
@@ -300,6 +304,35 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
             "distinct_outputs": len({r["sha256"] for r in recs})}
 
 
+SQ_COUNTERS = {"1080p": os.path.join(ROOT, "profiles", "r03_compare_1080p_sq_counters.csv"),
+               "4k": os.path.join(ROOT, "profiles", "r03_compare_4k_sq_counters.csv")}
+VALU_WAVE_INSTR_PER_S = 256 * 4 * 0.25 * 2.4e9   # 1024 SIMDs, a wave64 VALU instruction per 4 clocks, 2.4 GHz
+NOT_IN_CHAIN = ("k_encode_rgb", "k_linear_from_rgb8", "k_quantize", "__amd_rocclr")
+
+
+def valu_floor(size, ms_measured):
+    """The chain's VALU floor: SQ_INSTS_VALU of its kernels (rocprofv3 --pmc, committed under
+    profiles/ -- the counters cannot be read from inside this process) per Compare / the chip's
+    VALU issue rate.  With FMA contraction off (the reference is SSE2) every multiply and add is
+    an instruction of its own: the chain has more VALU time than HBM time in it."""
+    try:
+        rows = [r for r in csv.reader(l for l in open(SQ_COUNTERS[size]) if not l.startswith("#"))][1:]
+        valu = {r[0]: (int(r[2]), float(r[3])) for r in rows if r[1] == "SQ_INSTS_VALU"}
+        compares = valu["gz::k_combine"][0]          # one k_combine per Compare
+        per_kernel = {k: n * v / compares for k, (n, v) in valu.items() if not any(x in k for x in NOT_IN_CHAIN)}
+        total = sum(per_kernel.values())
+        floor_ms = total / VALU_WAVE_INSTR_PER_S * 1e3
+        top = max(per_kernel, key=per_kernel.get)
+        return {"wave_instructions_per_compare": round(total), "floor_ms": round(floor_ms, 4),
+                "frac_of_measured": round(floor_ms / ms_measured, 4),
+                "largest": {"kernel": top.replace("gz::", ""), "share": round(per_kernel[top] / total, 3)},
+                "source": os.path.relpath(SQ_COUNTERS[size], ROOT),
+                "note": "sum of SQ_INSTS_VALU over the chain's kernels per Compare / (1024 SIMDs x 1 wave64 "
+                        "instruction per 4 clocks x 2.4 GHz); frac_of_measured = this floor / ms_per_compare"}
+    except Exception as e:   # (profiles not present: the line stays valid)
+        return {"error": str(e)}
+
+
 def roofline_of(L, rgb, device, iters, warm):
     w, h = rgb.shape[1], rgb.shape[0]
     with L.context(rgb, TARGET_Q95, device=device) as ctx:
@@ -468,7 +501,8 @@ def main():
                          "traffic": traffic.get("1080p", {}).get("traffic_bytes"),
                          "traffic_head": traffic.get("head"), "traffic_source": traffic.get("source"),
                          "ms_per_compare": round(ms, 4),
-                         "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W * H},
+                         "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W * H,
+                         "valu": None if emu else valu_floor("1080p", ms)},
             "roofline_4k": {"bound": "hbm", "kernel": CHAIN, "workload": f"{W4}x{H4} (configs[2])",
                             "achieved": round(achieved_4k, 1),
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -476,7 +510,8 @@ def main():
                             "traffic": traffic.get("4k", {}).get("traffic_bytes"),
                             "traffic_head": traffic.get("head"),
                             "ms_per_compare": round(ms_4k, 4),
-                            "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W4 * H4},
+                            "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W4 * H4,
+                            "valu": None if emu or ms_4k is None else valu_floor("4k", ms_4k)},
             # phase A (not HBM-bound -- reported in evaluations, not bytes)
             "block_search": {"evaluations": info["counters"].get("block search evaluations"),
                              "seconds": round(info["timers"].get("block_search", 0.0), 4),

@@ -64,6 +64,7 @@ SIGNATURES = {
     "gz_order_reset": (_I, [_P]),
     "gz_order_build_auto": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float, _P, _P, _P]),
     "gz_order_build_auto_begin": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float]),
+    "gz_order_build_auto_descend_begin": (_I, [_P, _I, _I, C.c_double, _I, _P, _I, C.c_float, C.c_float, C.c_uint64, _I]),
     "gz_order_build_auto_end": (_I, [_P, _P, _P, _P]),
     "gz_order_advance": (_I, [_P, C.c_float, _I]),
     "gz_apply_coeff_edits": (_I, [_P, _P, _P, _I]),

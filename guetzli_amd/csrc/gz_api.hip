@@ -453,6 +453,10 @@ struct gz_ctx {
   // the ranges' pinned copy for the host's replay
   DescState* d_desc_st = nullptr; DescPivot* d_desc_pv = nullptr; DescState* h_desc = nullptr;
   unsigned desc_epoch = 0; int desc_levels = 0; bool desc_pending = false;
+  // gz_order_build_auto_descend_begin: the order's counters (and the distance of the Compare in
+  // flight) arrive with the descent's state, in h_desc[kDescMaxLevels + 1]
+  bool results_in_desc = false, distance_in_desc = false;
+  unsigned results_epoch = 0;          // the descent (desc_epoch) that published them
   unsigned* d_order_nb = nullptr;                                 // [nb]
   unsigned long long* d_order_off = nullptr;                      // [nb+1]
   unsigned* d_order_counters = nullptr;                           // [2]
@@ -529,6 +533,7 @@ void set_frame(gz_ctx* c, int factor) {
   c->nblk = c->nb + 2 * c->nbc;
   c->have_search = false;
   c->order_pending = false;   // a pending gz_order_build_auto_begin belonged to the old frame
+  c->results_in_desc = false;
 }
 size_t csamp_plane(const gz_ctx* c) {   // bytes of one chroma sample plane of a 4:2:0 frame
   return (size_t)((c->w + 15) / 16 * 8) * (size_t)((c->h + 15) / 16 * 8);
@@ -1669,6 +1674,7 @@ int gz_compare_begin(gz_ctx* c) {
   TRY(enqueue_compare(c, true));
   c->h_block_max_valid = false;
   c->compare_pending = true;
+  c->distance_in_desc = false;
   return GZ_OK;
 }
 
@@ -1676,11 +1682,21 @@ int gz_compare_end(gz_ctx* c, float* distance) {
   DeviceScope ds_(c);
   if (!c || !distance) return GZ_E_ARG;
   if (!c->compare_pending) { c->err = "gz_compare_begin must precede gz_compare_end"; return GZ_E_STATE; }
-  void* res = nullptr;
-  TRY(result_buffer(c, 4, &res));
-  HIPCHK(c, hipMemcpyAsync(res, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  memcpy(&c->last_distance, res, 4);
+  if (c->distance_in_desc) {
+    // gz_order_build_auto_descend_begin behind this evaluation: the distance comes with its results
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const DescState& p = c->h_desc[kDescMaxLevels + 1];
+    if (p.epoch != c->results_epoch || p.depth != 1) { c->err = "the distance did not arrive with the descent"; return GZ_E_STATE; }
+    const unsigned bits = (unsigned)p.cut;
+    memcpy(&c->last_distance, &bits, 4);
+    c->distance_in_desc = false;
+  } else {
+    void* res = nullptr;
+    TRY(result_buffer(c, 4, &res));
+    HIPCHK(c, hipMemcpyAsync(res, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(&c->last_distance, res, 4);
+  }
   *distance = c->last_distance;
   c->have_distmap = true;
   c->compare_pending = false;
@@ -1851,6 +1867,7 @@ int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
     return GZ_E_ARG;
   if (!c->have_search) { c->err = "gz_block_zeroing_orders must precede gz_order_build"; return GZ_E_STATE; }
   c->order_pending = false;
+  c->results_in_desc = false;
   const int nb = c->sg_n;
   TRY(ensure_order_block_arrays(c));
   HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
@@ -1925,6 +1942,7 @@ int gz_order_build_auto(gz_ctx* c, int direction, int max_block_dist, double tar
       max_block_dist < 0 || (count_below && !below))
     return GZ_E_ARG;
   c->order_pending = false;
+  c->results_in_desc = false;
   c->desc_pending = false;
   TRY(order_auto_enqueue(c, direction, max_block_dist, target_mul, use_distmap, next_cand));
   return order_build_device(c, direction, count_below, limit, total, blocks_to_change, below, true);
@@ -1935,6 +1953,7 @@ int gz_order_build_auto_begin(gz_ctx* c, int direction, int max_block_dist, doub
   DeviceScope ds_(c);
   if (!c || !next_cand || (direction != 1 && direction != -1) || max_block_dist < 0) return GZ_E_ARG;
   c->order_pending = false;
+  c->results_in_desc = false;
   c->desc_pending = false;
   TRY(order_auto_enqueue(c, direction, max_block_dist, target_mul, use_distmap, next_cand));
   TRY(order_build_enqueue(c, direction, count_below, limit, true));
@@ -1951,12 +1970,49 @@ int gz_order_build_auto_end(gz_ctx* c, uint64_t* total, int32_t* blocks_to_chang
   if (!c->order_pending) { c->err = "gz_order_build_auto_begin must precede gz_order_build_auto_end"; return GZ_E_STATE; }
   c->order_pending = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const gz_ctx::OrderPending& r = *c->h_order_pending;
+  gz_ctx::OrderPending r;
+  if (c->results_in_desc) {   // (gz_order_build_auto_descend_begin: with the descent's state)
+    const DescState& p = c->h_desc[kDescMaxLevels + 1];
+    if (p.epoch != c->results_epoch || p.depth != 1) { c->err = "the order's results did not arrive with the descent"; return GZ_E_STATE; }
+    r.total = p.lo;
+    r.counters[0] = (unsigned)p.hi;
+    r.counters[1] = (unsigned)p.last;
+    c->results_in_desc = false;
+  } else {
+    r = *c->h_order_pending;
+  }
   if (r.total > c->order_cap) { c->err = "order larger than the candidate count"; return GZ_E_STATE; }
   c->order_n = (size_t)r.total;
   *total = r.total;
   *blocks_to_change = (int32_t)r.counters[0];
   *below = r.counters[1];
+  return GZ_OK;
+}
+
+static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, float per_block,
+                           uint64_t threshold, int max_levels, size_t n_bound, bool publish);
+
+// gz_order_build_auto_begin + gz_order_descend_begin in one call, with ONE transfer of results.
+int gz_order_build_auto_descend_begin(gz_ctx* c, int direction, int max_block_dist, double target_mul,
+                                      int use_distmap, const int32_t* next_cand, int count_below,
+                                      float limit, float per_block, uint64_t threshold, int max_levels) {
+  DeviceScope ds_(c);
+  if (!c || !next_cand || (direction != 1 && direction != -1) || max_block_dist < 0 || max_levels < 0)
+    return GZ_E_ARG;
+  c->order_pending = false;
+  c->results_in_desc = false;
+  c->desc_pending = false;
+  c->results_in_desc = false;
+  c->distance_in_desc = false;
+  TRY(order_auto_enqueue(c, direction, max_block_dist, target_mul, use_distmap, next_cand));
+  TRY(order_build_enqueue(c, direction, count_below, limit, true));
+  TRY(descend_enqueue(c, 1, 0, 0, per_block, threshold, max_levels, std::max<size_t>(c->search_total, 1), true));
+  if (!c->results_in_desc) {   // (no level was launched: the order is too large for the descent's tables)
+    if (!c->h_order_pending) HIPCHK(c, pool_host_malloc((void**)&c->h_order_pending, sizeof(*c->h_order_pending)));
+    HIPCHK(c, hipMemcpyAsync(&c->h_order_pending->total, c->d_order_off + c->sg_n, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_order_pending->counters, c->d_order_counters, 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  c->order_pending = true;
   return GZ_OK;
 }
 
@@ -2075,6 +2131,7 @@ int gz_order_upload(gz_ctx* c, const void* entries, uint64_t n) {
   DeviceScope ds_(c);
   if (!c || (n > 0 && !entries)) return GZ_E_ARG;
   c->order_pending = false;
+  c->results_in_desc = false;
   TRY(ensure_order_capacity(c, (size_t)n));
   if (n > 0)
     HIPCHK(c, hipMemcpyAsync(c->d_order, entries, sizeof(OrderEntry) * n, hipMemcpyHostToDevice, c->stream));
@@ -2147,12 +2204,12 @@ int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
 
 // ---- quick-select descent decided on the device (gz_kernels_order.h: k_desc_count / k_desc_swap)
 static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, float per_block,
-                           uint64_t threshold, int max_levels, size_t n_bound) {
+                           uint64_t threshold, int max_levels, size_t n_bound, bool publish = false) {
   if (!c->d_desc_st) {
-    HIPCHK(c, pool_malloc((void**)&c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 1)));
+    HIPCHK(c, pool_malloc((void**)&c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 2)));
     HIPCHK(c, pool_malloc((void**)&c->d_desc_pv, sizeof(DescPivot) * kDescMaxLevels));
-    HIPCHK(c, pool_host_malloc((void**)&c->h_desc, sizeof(DescState) * (kDescMaxLevels + 1)));
-    HIPCHK(c, hipMemsetAsync(c->d_desc_st, 0, sizeof(DescState) * (kDescMaxLevels + 1), c->stream));
+    HIPCHK(c, pool_host_malloc((void**)&c->h_desc, sizeof(DescState) * (kDescMaxLevels + 2)));
+    HIPCHK(c, hipMemsetAsync(c->d_desc_st, 0, sizeof(DescState) * (kDescMaxLevels + 2), c->stream));
     c->desc_epoch = 0;
   }
   if (++c->desc_epoch == 0) c->desc_epoch = 1;
@@ -2175,6 +2232,8 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
   A.total = c->d_order_off ? c->d_order_off + c->sg_n : nullptr;
   A.counters = c->d_order_counters;
   A.per_block = per_block;
+  A.publish = publish && levels > 0 ? 1 : 0;
+  A.max_bits = c->d_max_bits;
   const int swap_groups = (int)((n_bound + 1 + kPartChunk - 1) / kPartChunk);
   for (int l = 0; l < levels; ++l) {
     GZ_LAUNCH(k_desc_count, dim3((unsigned)nchunks), dim3(256), c->stream, A, l);
@@ -2182,10 +2241,15 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
     GZ_LAUNCH(k_desc_swap, dim3((unsigned)swap_groups), dim3(256), c->stream, A, l);
     KCHK(c);
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 1),
+  HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 2),
                            hipMemcpyDeviceToHost, c->stream));
   c->desc_levels = levels;
   c->desc_pending = true;
+  if (A.publish) {
+    c->results_in_desc = true;
+    c->distance_in_desc = c->compare_pending;
+    c->results_epoch = c->desc_epoch;
+  }
   return GZ_OK;
 }
 
@@ -2753,6 +2817,7 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
   }
   TRY(ensure_block_mask(c));
   c->order_pending = false;   // a new search grid: a pending order of the old one is void
+  c->results_in_desc = false;
   const int nb = c->nb;   // capacity of the per-block arrays: the luma grid
   const int gn = mode == 2 ? c->nbc : c->nb;
   c->sg_w = mode == 2 ? c->cbw : c->bw;

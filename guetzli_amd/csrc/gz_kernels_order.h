@@ -587,7 +587,7 @@ struct DescPivot {
 };
 struct DescArgs {
   OrderEntry* a;
-  DescState* st;                   // [kDescMaxLevels + 1]
+  DescState* st;                   // [kDescMaxLevels + 2]: the ranges, then the results slot (publish)
   DescPivot* pv;                   // [kDescMaxLevels]
   unsigned* cnt_l;                 // [chunks]
   unsigned* cnt_r;
@@ -600,6 +600,12 @@ struct DescArgs {
   const unsigned long long* total; // number of entries (the offsets scan's last element)
   const unsigned* counters;        // [0] blocks_to_change
   float per_block;                 // coefficients to change per block (processor.cc:685-687)
+  // publish: the first level also copies what the host waits for at this point of an iteration
+  // into st[kDescMaxLevels + 1] -- lo = the order's size, hi = blocks_to_change, last = entries
+  // below the limit, cut = the bits of the last Compare's distance, depth = 1 -- so that ONE
+  // transfer of st brings everything (three small device-to-host copies less on the stream).
+  int publish;
+  const unsigned* max_bits;
 };
 
 // The range level `level` works on; false = nothing to do at this level.
@@ -643,6 +649,16 @@ GZ_DEVFN OrderEntry desc_read(const OrderEntry* a, unsigned long long p, unsigne
 
 __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
   __shared__ unsigned lds[256];
+  if (level == 0 && A.publish && blockIdx.x == 0 && threadIdx.x == 0) {
+    DescState r;
+    r.lo = *A.total;
+    r.hi = A.counters[0];
+    r.last = A.counters[1];
+    r.cut = A.max_bits ? *A.max_bits : 0u;
+    r.depth = 1;
+    r.epoch = A.epoch;
+    A.st[kDescMaxLevels + 1] = r;
+  }
   DescState s;
   if (!desc_load(A, level, &s)) return;
   const unsigned long long first = s.lo + 1;

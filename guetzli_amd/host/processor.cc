@@ -973,12 +973,21 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         // the next iteration of this direction, radius 1, if it comes to that (processor.cc:
         // 622-663 behind :767): everything it reads is final -- next_cand, max_block_error
         // (gz_order_advance above), and the distance map the device is about to produce
-        rc = gz_order_build_auto_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
-                                       below_limit);
-        if (rc != GZ_OK) return Fail("gz_order_build_auto_begin", rc);
-        if (descend_) {
-          rc = gz_order_descend_begin(ctx_, per_block, device_threshold_, descend_levels_);
-          if (rc != GZ_OK) return Fail("gz_order_descend_begin", rc);
+        static const bool one_transfer = !(getenv("GZ_ORDER_ONE_TRANSFER") && atoi(getenv("GZ_ORDER_ONE_TRANSFER")) == 0);
+        if (descend_ && one_transfer) {
+          // ... with the descent behind it, and everything the host waits for at this point (the
+          // order's size and counters, the descent's cuts, the candidate's distance) in one transfer
+          rc = gz_order_build_auto_descend_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
+                                                 below_limit, per_block, device_threshold_, descend_levels_);
+          if (rc != GZ_OK) return Fail("gz_order_build_auto_descend_begin", rc);
+        } else {
+          rc = gz_order_build_auto_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
+                                         below_limit);
+          if (rc != GZ_OK) return Fail("gz_order_build_auto_begin", rc);
+          if (descend_) {   // (GZ_ORDER_ONE_TRANSFER=0: the two calls, four transfers)
+            rc = gz_order_descend_begin(ctx_, per_block, device_threshold_, descend_levels_);
+            if (rc != GZ_OK) return Fail("gz_order_descend_begin", rc);
+          }
         }
         ahead = direction;
       }

@@ -359,6 +359,15 @@ int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);
 int gz_order_descend(gz_ctx* ctx, uint64_t last, uint64_t threshold, int max_levels,
                      uint64_t* log, int* levels);
 int gz_order_descend_begin(gz_ctx* ctx, float per_block, uint64_t threshold, int max_levels);
+/* gz_order_build_auto_begin followed by gz_order_descend_begin as ONE call: the same kernels, and
+ * one device-to-host transfer for everything the caller waits for afterwards -- the order's size
+ * and counters (gz_order_build_auto_end), the descent's log (gz_order_descend_end) and, when the
+ * call is made between gz_compare_begin and gz_compare_end, that evaluation's distance
+ * (gz_compare_end then only waits): three small copies less on the stream, each a dispatch of its
+ * own between the evaluation and the host. */
+int gz_order_build_auto_descend_begin(gz_ctx* ctx, int direction, int max_block_dist, double target_mul,
+                                      int use_distmap, const int32_t* next_cand, int count_below,
+                                      float limit, float per_block, uint64_t threshold, int max_levels);
 int gz_order_descend_end(gz_ctx* ctx, uint64_t* log, int cap_levels, int* levels, uint64_t* last);
 
 /* Entropy coding of the candidate -----------------------------------------------------

@@ -83,3 +83,30 @@ def test_malta_diff_fast_form_equals_the_reference_sequence(tmp_path):
     out = subprocess.run([exe, "100000000"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count(" 0 mismatches") == 2, out.stdout
+
+
+def test_entropy_coder_quantised_values_equal_integer_division(tmp_path):
+    """The entropy kernels get `coefficient / q` from one float multiply by 1.0f / q and an integer
+    correction (quant_div, gz_kernels_entropy.h).  tests/cpp/verify_quant_div.cc compares it with
+    C++'s int division for every dividend an int16 coefficient can be and every 16-bit quantiser."""
+    exe = str(tmp_path / "verify_qd")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-pthread", "-DGZ_EMU",
+                    "-I" + os.path.join(ROOT, "guetzli_amd", "csrc"), "-I" + os.path.join(ROOT, "tests", "emu"),
+                    os.path.join(ROOT, "tests", "cpp", "verify_quant_div.cc"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert " 0 mismatches" in out.stdout, out.stdout
+
+
+def test_bench_reads_the_chain_valu_floor_from_the_committed_counters():
+    """bench.py's roofline.valu: SQ_INSTS_VALU of the chain's kernels per Compare from
+    profiles/r03_compare_*_sq_counters.csv over the chip's VALU issue rate."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for size, ms in (("4k", 1.1), ("1080p", 0.36)):
+        v = bench.valu_floor(size, ms)
+        assert "error" not in v, v
+        assert 0.1 < v["floor_ms"] < ms and v["largest"]["kernel"].startswith("k_malta")
+        assert abs(v["frac_of_measured"] - v["floor_ms"] / ms) < 1e-3

@@ -455,6 +455,8 @@ struct gz_ctx {
   unsigned desc_epoch = 0; int desc_levels = 0; bool desc_pending = false;
   // gz_order_build_auto_descend_begin: the order's counters (and the distance of the Compare in
   // flight) arrive with the descent's state, in h_desc[kDescMaxLevels + 1]
+  void* h_order_mirror = nullptr;      // gz_order_host_mirror: pinned, order entries land in it directly
+  size_t order_mirror_cap = 0;         // entries
   bool results_in_desc = false, distance_in_desc = false;
   unsigned results_epoch = 0;          // the descent (desc_epoch) that published them
   unsigned* d_order_nb = nullptr;                                 // [nb]
@@ -1471,6 +1473,7 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->d_order); (void)pool_free(c->d_pos_l); (void)pool_free(c->d_pos_r); (void)pool_free(c->d_chunk);
   (void)pool_free(c->d_part); (void)pool_free(c->d_order_nb); (void)pool_free(c->d_order_off);
   if (c->h_order_pending) (void)pool_host_free(c->h_order_pending);
+  if (c->h_order_mirror) (void)pool_host_free(c->h_order_mirror);
   if (c->h_desc) (void)pool_host_free(c->h_desc);
   if (c->h_scan_result) (void)pool_host_free(c->h_scan_result);
   (void)pool_free(c->d_cmp_stage);
@@ -2183,10 +2186,34 @@ int gz_order_partition(gz_ctx* c, uint64_t lo, uint64_t hi, uint64_t* cut) {
   return GZ_OK;
 }
 
+int gz_order_host_mirror(gz_ctx* c, uint64_t entries, void** out) {
+  DeviceScope ds_(c);
+  if (!c || !out) return GZ_E_ARG;
+  if (entries > c->order_mirror_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (no transfer into the old one is in flight)
+    if (c->h_order_mirror) (void)pool_host_free(c->h_order_mirror);
+    c->h_order_mirror = nullptr;
+    c->order_mirror_cap = 0;
+    const size_t cap = (size_t)entries + (size_t)entries / 8 + 4096;
+    HIPCHK(c, pool_host_malloc(&c->h_order_mirror, sizeof(OrderEntry) * cap));
+    c->order_mirror_cap = cap;
+  }
+  *out = c->h_order_mirror;
+  return GZ_OK;
+}
+
 int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
   DeviceScope ds_(c);
   if (!c || !out || lo > hi || hi > c->order_n) return GZ_E_ARG;
   const size_t bytes = sizeof(OrderEntry) * (size_t)(hi - lo);
+  const char* mirror = (const char*)c->h_order_mirror;
+  if (bytes > 0 && mirror && (const char*)out >= mirror &&
+      (const char*)out + bytes <= mirror + sizeof(OrderEntry) * c->order_mirror_cap) {
+    // into the context's pinned mirror: no landing area, no second copy
+    HIPCHK(c, hipMemcpyAsync(out, c->d_order + lo, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GZ_OK;
+  }
   if (bytes > 0 && bytes <= ((size_t)4 << 20)) {   // the usual case: through the pinned landing area
     void* res = nullptr;
     TRY(result_buffer(c, bytes, &res));

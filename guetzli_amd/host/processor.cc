@@ -702,7 +702,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   };
   std::vector<int32_t> edit_pos;       // coefficient changes of one iteration
   std::vector<int16_t> edit_val;
-  std::vector<std::pair<int, float> >& order = order_;   // host copy of the ranges that were fetched
+  // host copy of the ranges that were fetched: in the context's page-locked mirror (the fetches
+  // are then single DMA transfers), or, GZ_ORDER_PINNED=0, in an ordinary array
+  static const bool pinned_order = !(getenv("GZ_ORDER_PINNED") && atoi(getenv("GZ_ORDER_PINNED")) == 0);
+  std::pair<int, float>* order = nullptr;
   std::vector<char> touched(nb);
   std::vector<int32_t> dirty;
   std::vector<int> step_count(nb);
@@ -754,7 +757,15 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       t_pb_order_ += pw.lap();
       if (total == 0) break;
       n_order_ += (long)total;
-      if (order.size() < total) order.resize(total);
+      if (pinned_order) {
+        void* mirror = nullptr;
+        rc = gz_order_host_mirror(ctx_, total, &mirror);
+        if (rc != GZ_OK) return Fail("gz_order_host_mirror", rc);
+        order = static_cast<std::pair<int, float>*>(mirror);
+      } else {
+        if (order_.size() < total) order_.resize(total);
+        order = order_.data();
+      }
 
       // The reference std::sort-s `order` here (processor.cc:675-678) and then consumes a
       // prefix.  Equal keys occur across different blocks and std::sort is not stable, so
@@ -768,7 +779,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         }
       };
       DeviceOrder dev_order(ctx_);
-      LazySorted<std::pair<int, float>, KeyLess> sorted(order.data(), (size_t)total, KeyLess(), -1,
+      LazySorted<std::pair<int, float>, KeyLess> sorted(order, (size_t)total, KeyLess(), -1,
                                                          1 << 17, &dev_order, device_threshold_);
       t_pb_sort_ += pw.lap();
 
@@ -855,7 +866,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
             // (only when the descent got there: a range that is still large will be partitioned
             // further on the device, and a copy taken now would be stale)
             if (fhi - flo <= device_threshold_ && fhi <= ((size_t)1 << 19) &&
-                !dev_order.Prefetch((size_t)fhi, order.data()))
+                !dev_order.Prefetch((size_t)fhi, order))
               return Fail("gz_order_fetch", dev_order.rc);
           }
           t_pb_descend_ += fw.lap();

@@ -340,6 +340,11 @@ int gz_steps_histogram_delta(gz_ctx* ctx, int32_t* ac_delta);
 int gz_order_upload(gz_ctx* ctx, const void* entries, uint64_t n);
 int gz_order_partition(gz_ctx* ctx, uint64_t lo, uint64_t hi, uint64_t* cut);
 int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);
+/* A host array of at least `entries` order entries (8 bytes each), page-locked and owned by the
+ * context: gz_order_fetch into it (at any offset) is one DMA transfer without the landing copy a
+ * pageable destination needs.  The search driver keeps its host copy of the order there.  A call
+ * that has to grow the array invalidates the pointer of the call before; gz_destroy frees it. */
+int gz_order_host_mirror(gz_ctx* ctx, uint64_t entries, void** out);
 /* The quick-select descent of that sort, decided on the device.  What the global loop needs
  * before its stopping rule can fire (processor.cc:743-746: not before min_coeffs_to_change
  * steps) is the SET of the leading entries of the sorted order; std::sort's introsort reaches

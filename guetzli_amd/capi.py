@@ -74,6 +74,7 @@ SIGNATURES = {
     "gz_order_partition": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
     "gz_order_fetch": (_I, [_P, C.c_uint64, C.c_uint64, _P]),
     "gz_order_host_mirror": (_I, [_P, C.c_uint64, _P]),
+    "gz_order_exported": (_I, [_P, _P]),
     "gz_order_descend": (_I, [_P, C.c_uint64, C.c_uint64, _I, _P, _P]),
     "gz_order_descend_begin": (_I, [_P, C.c_float, C.c_uint64, _I]),
     "gz_order_descend_end": (_I, [_P, _P, _I, _P, _P]),

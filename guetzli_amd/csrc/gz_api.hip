@@ -459,6 +459,7 @@ struct gz_ctx {
   size_t order_mirror_cap = 0;         // entries
   bool results_in_desc = false, distance_in_desc = false;
   unsigned results_epoch = 0;          // the descent (desc_epoch) that published them
+  unsigned export_epoch = 0;           // the descent whose k_desc_export wrote into the host mirror (0: none)
   unsigned* d_order_nb = nullptr;                                 // [nb]
   unsigned long long* d_order_off = nullptr;                      // [nb+1]
   unsigned* d_order_counters = nullptr;                           // [2]
@@ -2194,6 +2195,7 @@ int gz_order_host_mirror(gz_ctx* c, uint64_t entries, void** out) {
     if (c->h_order_mirror) (void)pool_host_free(c->h_order_mirror);
     c->h_order_mirror = nullptr;
     c->order_mirror_cap = 0;
+    c->export_epoch = 0;   // (what k_desc_export wrote went with the old array)
     const size_t cap = (size_t)entries + (size_t)entries / 8 + 4096;
     HIPCHK(c, pool_host_malloc(&c->h_order_mirror, sizeof(OrderEntry) * cap));
     c->order_mirror_cap = cap;
@@ -2233,10 +2235,10 @@ int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
 static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, float per_block,
                            uint64_t threshold, int max_levels, size_t n_bound, bool publish = false) {
   if (!c->d_desc_st) {
-    HIPCHK(c, pool_malloc((void**)&c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 2)));
+    HIPCHK(c, pool_malloc((void**)&c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 3)));
     HIPCHK(c, pool_malloc((void**)&c->d_desc_pv, sizeof(DescPivot) * kDescMaxLevels));
-    HIPCHK(c, pool_host_malloc((void**)&c->h_desc, sizeof(DescState) * (kDescMaxLevels + 2)));
-    HIPCHK(c, hipMemsetAsync(c->d_desc_st, 0, sizeof(DescState) * (kDescMaxLevels + 2), c->stream));
+    HIPCHK(c, pool_host_malloc((void**)&c->h_desc, sizeof(DescState) * (kDescMaxLevels + 3)));
+    HIPCHK(c, hipMemsetAsync(c->d_desc_st, 0, sizeof(DescState) * (kDescMaxLevels + 3), c->stream));
     c->desc_epoch = 0;
   }
   if (++c->desc_epoch == 0) c->desc_epoch = 1;
@@ -2268,7 +2270,17 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
     GZ_LAUNCH(k_desc_swap, dim3((unsigned)swap_groups), dim3(256), c->stream, A, l);
     KCHK(c);
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 2),
+  // gz_order_build_auto_descend_begin: the prefix the driver fetches next goes to its host mirror
+  // behind the last level (the driver's own bound on such a fetch: 2^19 entries)
+  c->export_epoch = 0;
+  static const bool do_export = !(getenv("GZ_ORDER_EXPORT") && atoi(getenv("GZ_ORDER_EXPORT")) == 0);
+  if (publish && levels > 0 && do_export && c->h_order_mirror) {
+    const unsigned long long max_entries = std::min<unsigned long long>(c->order_mirror_cap, 1ull << 19);
+    GZ_LAUNCH(k_desc_export, dim3(128), dim3(256), c->stream, A, levels, (OrderEntry*)c->h_order_mirror, max_entries);
+    KCHK(c);
+    c->export_epoch = c->desc_epoch;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 3),
                            hipMemcpyDeviceToHost, c->stream));
   c->desc_levels = levels;
   c->desc_pending = true;
@@ -2313,6 +2325,16 @@ int gz_order_descend_begin(gz_ctx* c, float per_block, uint64_t threshold, int m
   if (!c || max_levels < 0) return GZ_E_ARG;
   if (!c->order_pending) { c->err = "gz_order_build_auto_begin must precede gz_order_descend_begin"; return GZ_E_STATE; }
   return descend_enqueue(c, 1, 0, 0, per_block, threshold, max_levels, std::max<size_t>(c->search_total, 1));
+}
+
+int gz_order_exported(gz_ctx* c, uint64_t* entries) {
+  if (!c || !entries) return GZ_E_ARG;
+  *entries = 0;
+  if (c->desc_pending || c->order_pending) { c->err = "gz_order_descend_end must precede gz_order_exported"; return GZ_E_STATE; }
+  if (c->export_epoch == 0 || c->export_epoch != c->desc_epoch || !c->h_desc) return GZ_OK;
+  const DescState& p = c->h_desc[kDescMaxLevels + 2];
+  if (p.epoch == c->export_epoch && p.depth == 2 && p.lo <= c->order_n) *entries = p.lo;
+  return GZ_OK;
 }
 
 int gz_order_descend_end(gz_ctx* c, uint64_t* log, int cap_levels, int* levels, uint64_t* last) {

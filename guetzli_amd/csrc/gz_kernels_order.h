@@ -587,7 +587,7 @@ struct DescPivot {
 };
 struct DescArgs {
   OrderEntry* a;
-  DescState* st;                   // [kDescMaxLevels + 2]: the ranges, then the results slot (publish)
+  DescState* st;                   // [kDescMaxLevels + 3]: the ranges, the results slot (publish), k_desc_export's
   DescPivot* pv;                   // [kDescMaxLevels]
   unsigned* cnt_l;                 // [chunks]
   unsigned* cnt_r;
@@ -852,6 +852,46 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
     }
     if (!moved) A.a[pvt.med] = pvt.a_lo;
   }
+}
+
+// Behind the last level of a descent: the leading entries of the order up to the end of the range
+// the descent ended in -- what the search driver fetches next (guetzli_amd/host/processor.cc:
+// DeviceOrder::Prefetch) -- written straight into the context's page-locked host mirror, when the
+// descent got as far as the driver's own condition asks (range <= threshold) and the prefix fits
+// max_entries.  st[kDescMaxLevels + 2] tells the host: lo = entries exported (0: none), depth = 2.
+// One dispatch on the stream instead of a host round trip after it.
+__global__ __launch_bounds__(256) void k_desc_export(DescArgs A, int levels, OrderEntry* __restrict__ dst,
+                                                     unsigned long long max_entries) {
+  __shared__ unsigned long long s_hi;
+  if (threadIdx.x == 0) {
+    unsigned long long lo = 0, hi = 0;
+    bool any = false;
+    for (int l = 1; l <= levels; ++l) {
+      const DescState st = A.st[l];
+      if (st.epoch != A.epoch) break;
+      lo = st.lo;
+      hi = st.hi;
+      any = true;
+    }
+    const bool ok = any && hi - lo <= A.threshold && hi <= max_entries;
+    s_hi = ok ? hi : 0ull;
+    if (blockIdx.x == 0) {
+      DescState r;
+      r.lo = s_hi; r.hi = 0; r.last = 0; r.cut = 0; r.depth = 2; r.epoch = A.epoch;
+      A.st[kDescMaxLevels + 2] = r;
+    }
+  }
+  __syncthreads();
+  const unsigned long long n = s_hi;
+  // 16 bytes (two entries) per thread and step
+  const unsigned long long pairs = n >> 1;
+  struct alignas(16) Two { OrderEntry a, b; };
+  const Two* src2 = reinterpret_cast<const Two*>(A.a);
+  Two* dst2 = reinterpret_cast<Two*>(dst);
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs;
+       i += (unsigned long long)gridDim.x * blockDim.x)
+    dst2[i] = src2[i];
+  if ((n & 1ull) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = A.a[n - 1];
 }
 
 }  // namespace gz

@@ -333,6 +333,7 @@ class Encoder {
   double t_fs_count_ = 0, t_fs_apply_ = 0, t_fs_mirror_ = 0, t_fs_delta_ = 0, t_fs_rest_ = 0;
   long n_dev_partitions_ = 0, n_dev_fetched_ = 0, n_dev_replayed_ = 0;
   double t_pb_descend_ = 0;
+  long n_dev_exported_ = 0;
   // GZ_ORDER_DESCEND=0: the host asks for every introsort partition itself (round 2's path)
   bool descend_ = true;
   int descend_levels_ = 6;      // levels to enqueue per descent (follows what the orders need)
@@ -865,9 +866,21 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
             }
             // (only when the descent got there: a range that is still large will be partitioned
             // further on the device, and a copy taken now would be stale)
-            if (fhi - flo <= device_threshold_ && fhi <= ((size_t)1 << 19) &&
-                !dev_order.Prefetch((size_t)fhi, order))
-              return Fail("gz_order_fetch", dev_order.rc);
+            if (fhi - flo <= device_threshold_ && fhi <= ((size_t)1 << 19)) {
+              // ... unless the device has put exactly that prefix into the mirror already, behind
+              // the descent it made ahead (k_desc_export)
+              uint64_t exported = 0;
+              if (have_ahead_log && pinned_order) {
+                rc = gz_order_exported(ctx_, &exported);
+                if (rc != GZ_OK) return Fail("gz_order_exported", rc);
+              }
+              if (exported == fhi) {
+                dev_order.have_hi = (size_t)fhi;
+                ++n_dev_exported_;
+              } else if (!dev_order.Prefetch((size_t)fhi, order)) {
+                return Fail("gz_order_fetch", dev_order.rc);
+              }
+            }
           }
           t_pb_descend_ += fw.lap();
         }
@@ -1137,6 +1150,7 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->timers["pb_device_partitions"] = t_pb_dev_partition_;
   stats_->timers["pb_device_fetches"] = t_pb_dev_fetch_;
   stats_->timers["pb_device_descents"] = t_pb_descend_;
+  stats_->counters["phase B prefixes exported by the device"] = (int)n_dev_exported_;
   stats_->counters["phase B partitions made ahead"] = (int)n_dev_replayed_;
   stats_->counters["phase B device partitions"] = (int)n_dev_partitions_;
   stats_->counters["phase B entries fetched"] = (int)std::min<long>(n_dev_fetched_, 2147483647L);

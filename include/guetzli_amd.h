@@ -345,6 +345,12 @@ int gz_order_fetch(gz_ctx* ctx, uint64_t lo, uint64_t hi, void* out);
  * pageable destination needs.  The search driver keeps its host copy of the order there.  A call
  * that has to grow the array invalidates the pointer of the call before; gz_destroy frees it. */
 int gz_order_host_mirror(gz_ctx* ctx, uint64_t entries, void** out);
+/* After gz_order_build_auto_descend_begin ... gz_order_descend_end: the number of leading entries
+ * of the order that the device has already written into the host mirror behind the descent (the
+ * prefix up to the end of the range the descent ended in, when that range is within `threshold`
+ * and the prefix within 2^19 entries; else 0).  They are what gz_order_fetch(ctx, 0, n, mirror)
+ * would deliver at that moment: the driver skips that fetch. */
+int gz_order_exported(gz_ctx* ctx, uint64_t* entries);
 /* The quick-select descent of that sort, decided on the device.  What the global loop needs
  * before its stopping rule can fire (processor.cc:743-746: not before min_coeffs_to_change
  * steps) is the SET of the leading entries of the sorted order; std::sort's introsort reaches

@@ -306,29 +306,42 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
 
 SQ_COUNTERS = {"1080p": os.path.join(ROOT, "profiles", "r03_compare_1080p_sq_counters.csv"),
                "4k": os.path.join(ROOT, "profiles", "r03_compare_4k_sq_counters.csv")}
-VALU_WAVE_INSTR_PER_S = 256 * 4 * 0.25 * 2.4e9   # 1024 SIMDs, a wave64 VALU instruction per 4 clocks, 2.4 GHz
+# wave64 VALU instructions the chip issues per second: f32 multiplies / adds go at one per 2 clocks
+# and SIMD once a SIMD holds two or more waves (tools/ubench/pk.hip: 73 T lane-ops/s measured),
+# FP64 and -- as far as this repo has measured anything -- the rest at one per 4 clocks
+VALU_WAVE_INSTR_PER_S_F32 = 256 * 4 * 0.5 * 2.4e9
+VALU_WAVE_INSTR_PER_S_4CLK = 256 * 4 * 0.25 * 2.4e9
 NOT_IN_CHAIN = ("k_encode_rgb", "k_linear_from_rgb8", "k_quantize", "__amd_rocclr")
 
 
 def valu_floor(size, ms_measured):
-    """The chain's VALU floor: SQ_INSTS_VALU of its kernels (rocprofv3 --pmc, committed under
+    """The chain's VALU issue time: SQ_INSTS_VALU of its kernels (rocprofv3 --pmc, committed under
     profiles/ -- the counters cannot be read from inside this process) per Compare / the chip's
-    VALU issue rate.  With FMA contraction off (the reference is SSE2) every multiply and add is
-    an instruction of its own: the chain has more VALU time than HBM time in it."""
+    VALU issue rate, at both rates an instruction can have (the counters do not split the
+    instructions by class, so the chain's real floor lies between the two).  With FMA contraction
+    off (the reference is SSE2) every multiply and add is an instruction of its own.  A kernel's
+    count is its average per launch x its launches per Compare: the profiled run also launches the
+    opsin / LF / MF / HF kernels once for the ORIGINAL image when the context is created, and that
+    launch is not part of a Compare (until round 3's last session it was counted as a third of one)."""
     try:
         rows = [r for r in csv.reader(l for l in open(SQ_COUNTERS[size]) if not l.startswith("#"))][1:]
         valu = {r[0]: (int(r[2]), float(r[3])) for r in rows if r[1] == "SQ_INSTS_VALU"}
         compares = valu["gz::k_combine"][0]          # one k_combine per Compare
-        per_kernel = {k: n * v / compares for k, (n, v) in valu.items() if not any(x in k for x in NOT_IN_CHAIN)}
+        per_kernel = {k: max(1, n // compares) * v for k, (n, v) in valu.items()
+                      if not any(x in k for x in NOT_IN_CHAIN)}
         total = sum(per_kernel.values())
-        floor_ms = total / VALU_WAVE_INSTR_PER_S * 1e3
+        lo_ms = total / VALU_WAVE_INSTR_PER_S_F32 * 1e3
+        hi_ms = total / VALU_WAVE_INSTR_PER_S_4CLK * 1e3
         top = max(per_kernel, key=per_kernel.get)
-        return {"wave_instructions_per_compare": round(total), "floor_ms": round(floor_ms, 4),
-                "frac_of_measured": round(floor_ms / ms_measured, 4),
+        return {"wave_instructions_per_compare": round(total),
+                "floor_ms_f32_rate": round(lo_ms, 4), "floor_ms_4clk_rate": round(hi_ms, 4),
+                "frac_of_measured_f32_rate": round(lo_ms / ms_measured, 4),
+                "frac_of_measured_4clk_rate": round(hi_ms / ms_measured, 4),
                 "largest": {"kernel": top.replace("gz::", ""), "share": round(per_kernel[top] / total, 3)},
                 "source": os.path.relpath(SQ_COUNTERS[size], ROOT),
-                "note": "sum of SQ_INSTS_VALU over the chain's kernels per Compare / (1024 SIMDs x 1 wave64 "
-                        "instruction per 4 clocks x 2.4 GHz); frac_of_measured = this floor / ms_per_compare"}
+                "note": "sum over the chain's kernels of SQ_INSTS_VALU per launch x launches per Compare, / "
+                        "(1024 SIMDs x 2.4 GHz / 2 clocks [f32 mul/add rate, tools/ubench/pk.hip] or / 4 clocks "
+                        "[FP64 and the rest]); the chain's VALU floor lies between the two"}
     except Exception as e:   # (profiles not present: the line stays valid)
         return {"error": str(e)}
 

@@ -223,6 +223,25 @@ size_t ClusterHistograms(SymbolHistogram* histo, size_t* num, int* histo_indexes
   return (total + 7) / 8;
 }
 
+// Entropy-size model of the AC coefficients (processor.cc:497-525).
+size_t EntropyCodes(const SymbolHistogram* histo, int n, uint8_t* depths /*3*257*/) {
+  SymbolHistogram clustered[3] = {histo[0], histo[1], histo[2]};
+  size_t num = (size_t)n;
+  int indexes[3];
+  uint8_t cdepths[3 * kHistoSize];
+  ClusterHistograms(clustered, &num, indexes, cdepths);
+  for (int i = 0; i < n; ++i)
+    memcpy(&depths[i * kHistoSize], &cdepths[indexes[i] * kHistoSize], kHistoSize);
+  size_t header = 0;
+  for (size_t i = 0; i < num; ++i) header += HistogramHeaderBits(clustered[i]) / 8;
+  return header;
+}
+size_t EntropyDataSize(const SymbolHistogram* histo, int n, const uint8_t* depths) {
+  size_t bits = 0;
+  for (int i = 0; i < n; ++i) bits += HistogramEntropyBits(histo[i], &depths[i * kHistoSize]);
+  return (bits + 7) / 8;
+}
+
 void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHistogram* h,
                        const uint8_t* depth, int64_t* raw_bits) {
   int run = 0;

@@ -44,6 +44,12 @@ size_t HistogramEntropyBits(const SymbolHistogram& h, const uint8_t* depth);  //
 size_t ClusterHistograms(SymbolHistogram* histo, size_t* num, int* histo_indexes,
                          uint8_t* depth);
 
+// Entropy-size model of the AC coefficients (processor.cc:497-525): the histograms clustered,
+// depths[i * kHistoSize ..] = the code lengths histogram i is coded with; returns the header
+// bytes of the clustered codes.  EntropyDataSize: the data bytes under those code lengths.
+size_t EntropyCodes(const SymbolHistogram* histo, int n, uint8_t* depths /* n * kHistoSize */);
+size_t EntropyDataSize(const SymbolHistogram* histo, int n, const uint8_t* depths);
+
 // One AC block's symbols (UpdateACHistogramForDCTBlock :197-216 / processor.cc:471-495):
 // coefficients are DEQUANTISED values, q the component's quant matrix (null = already
 // quantised).

@@ -504,3 +504,123 @@ int gz_jpeg_scan_bytes(gz_ctx* c, int kept, uint8_t* out, size_t cap, size_t* n)
 }
 
 }  // extern "C"
+
+// ---- entry points added to the C ABI after the first version of this shim ------------------
+// Record mode forwards them (dlsym by name); replay mode answers from the logged data the way
+// the older entry points do.  The quick-select descents the device makes ahead are a pure
+// function of the order: replay reports "no levels made", and the driver asks for the
+// partitions one by one (gz_order_partition above) -- another path to the same order.
+namespace {
+template <class F>
+F real_sym(const char* name) {
+  real();
+  F f = (F)dlsym(real()->h, name);
+  if (!f) { fprintf(stderr, "gz_replay: %s missing in the real library\n", name); abort(); }
+  return f;
+}
+struct Pending {
+  bool order = false, scan = false;
+  int direction = 0, max_block_dist = 0, use_distmap = 0, count_below = 0;
+  double target_mul = 0;
+  float limit = 0;
+  std::vector<int32_t> next_cand;
+  int ncomp = 0;
+  std::vector<uint8_t> depth;
+  std::vector<uint16_t> code;
+  std::vector<std::pair<int, float> > mirror;
+};
+Pending& pending_of(gz_ctx* c) {
+  static thread_local Pending p;   // (one encode per thread in this test infrastructure)
+  (void)c;
+  return p;
+}
+}  // namespace
+
+extern "C" {
+
+int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int new_model,
+                                   int32_t* offsets, uint8_t* idx, float* err, int cap) {
+  if (comp_mask != 7) return not_logged("gz_block_zeroing_orders_masked (comp_mask != 7)");
+  return gz_block_zeroing_orders(c, lookahead, new_model, offsets, idx, err, cap);
+}
+int gz_search_evaluations(gz_ctx* c, uint64_t* evaluations) {
+  if (c->inner) return real_sym<decltype(&gz_search_evaluations)>("gz_search_evaluations")(c->inner, evaluations);
+  *evaluations = 0;
+  return GZ_OK;
+}
+int gz_jpeg_histograms_ncomp(gz_ctx* c, const int* q, int ncomp, uint32_t* counts) {
+  if (ncomp != 3) return not_logged("gz_jpeg_histograms_ncomp (ncomp != 3)");
+  return gz_jpeg_histograms(c, q, counts);
+}
+int gz_jpeg_scan_begin(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* code) {
+  Pending& p = pending_of(c);
+  p.scan = true;
+  p.ncomp = ncomp;
+  p.depth.assign(depth, depth + 2 * 3 * 256);   // (the tables are not read in replay mode; record
+  p.code.assign(code, code + 2 * 3 * 256);      //  mode hands them to the real scan at _end)
+  return GZ_OK;
+}
+int gz_jpeg_scan_end(gz_ctx* c, uint64_t* scan_bytes) {
+  Pending& p = pending_of(c);
+  if (!p.scan) return GZ_E_STATE;
+  p.scan = false;
+  return gz_jpeg_scan(c, p.ncomp, p.depth.data(), p.code.data(), scan_bytes);
+}
+int gz_order_build_auto_begin(gz_ctx* c, int direction, int max_block_dist, double target_mul,
+                              int use_distmap, const int32_t* next_cand, int count_below, float limit) {
+  Pending& p = pending_of(c);
+  p.order = true;
+  p.direction = direction; p.max_block_dist = max_block_dist; p.target_mul = target_mul;
+  p.use_distmap = use_distmap; p.count_below = count_below; p.limit = limit;
+  p.next_cand.assign(next_cand, next_cand + c->nb);
+  return GZ_OK;
+}
+int gz_order_build_auto_end(gz_ctx* c, uint64_t* total, int32_t* blocks_to_change, uint64_t* below) {
+  Pending& p = pending_of(c);
+  if (!p.order) return GZ_E_STATE;
+  p.order = false;
+  // (the evaluation that was in flight at _begin has been fetched by gz_compare_end since)
+  return gz_order_build_auto(c, p.direction, p.max_block_dist, p.target_mul, p.use_distmap,
+                             p.next_cand.data(), p.count_below, p.limit, total, blocks_to_change, below);
+}
+int gz_order_descend(gz_ctx* c, uint64_t last, uint64_t threshold, int max_levels, uint64_t* log, int* levels) {
+  (void)c; (void)last; (void)threshold; (void)max_levels; (void)log;
+  *levels = 0;
+  return GZ_OK;
+}
+int gz_order_descend_begin(gz_ctx* c, float per_block, uint64_t threshold, int max_levels) {
+  (void)c; (void)per_block; (void)threshold; (void)max_levels;
+  return GZ_OK;
+}
+int gz_order_build_auto_descend_begin(gz_ctx* c, int direction, int max_block_dist, double target_mul,
+                                      int use_distmap, const int32_t* next_cand, int count_below,
+                                      float limit, float per_block, uint64_t threshold, int max_levels) {
+  (void)per_block; (void)threshold; (void)max_levels;
+  return gz_order_build_auto_begin(c, direction, max_block_dist, target_mul, use_distmap, next_cand,
+                                   count_below, limit);
+}
+int gz_order_descend_end(gz_ctx* c, uint64_t* log, int cap_levels, int* levels, uint64_t* last) {
+  (void)c; (void)log; (void)cap_levels;
+  *levels = 0;
+  *last = 0;
+  return GZ_OK;
+}
+int gz_order_host_mirror(gz_ctx* c, uint64_t entries, void** out) {
+  Pending& p = pending_of(c);
+  if (p.mirror.size() < entries) p.mirror.resize(entries);
+  *out = p.mirror.data();
+  return GZ_OK;
+}
+int gz_order_exported(gz_ctx* c, uint64_t* entries) {
+  (void)c;
+  *entries = 0;
+  return GZ_OK;
+}
+int gz_set_orig_coeffs_420(gz_ctx* c, const int16_t* coeffs) { (void)c; (void)coeffs; return not_logged("gz_set_orig_coeffs_420"); }
+int gz_downsample(gz_ctx* c, int16_t* coeffs_out) { (void)c; (void)coeffs_out; return not_logged("gz_downsample"); }
+int gz_downsample_planes(gz_ctx* c, const float* y, const float* u, const float* v, int16_t* coeffs_out) {
+  (void)c; (void)y; (void)u; (void)v; (void)coeffs_out;
+  return not_logged("gz_downsample_planes");
+}
+
+}  // extern "C"

@@ -15,7 +15,6 @@
 #include "png_reader.h"
 #include "silver_screen.h"
 #include "jpeg_writer.h"
-#include "codes_ahead.h"
 #include "lazy_sort.h"
 #include "parallel.h"
 
@@ -344,10 +343,6 @@ class Encoder {
   // where the host's time goes at the end of an iteration (stats_->timers)
   double t_head_ = 0, t_cmp_begin_ = 0, t_cmp_end_ = 0, t_scan_begin_ = 0, t_scan_end_ = 0, t_ahead_begin_ = 0;
   bool build_ahead_ = true;     // GZ_ORDER_AHEAD=0: build each order when the loop asks for it
-  // GZ_CODES_AHEAD=0: every refresh of the size model's Huffman codes on the driver thread
-  bool codes_ahead_on_ = true;
-  CodesAhead codes_ahead_;
-  long n_codes_ahead_ = 0;
   size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device (32-64 K measured best at 1080p and 4K)
 };
 
@@ -828,13 +823,6 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         const size_t last_needed = std::min<size_t>((size_t)std::max(min_coeffs_to_change, 0), n_order - 1);
         const size_t fast_until = last_needed / 10 * 10;
         Stopwatch fw;
-        // the helper of the slow steps' size model wakes up now (its first job comes after the
-        // bulk steps) and goes back to sleep on every way out of this block
-        struct RestGuard {
-          CodesAhead* ca;
-          ~RestGuard() { if (ca) ca->Rest(); }
-        } rest_guard{codes_ahead_on_ ? &codes_ahead_ : nullptr};
-        if (codes_ahead_on_) codes_ahead_.Arm();
         // The introsort partitions that lead to position fast_until - 1, made by the device
         // without the host in between: behind the order's construction when that was enqueued
         // ahead (the device derives the position as the lines above do), else now, in one call.
@@ -933,82 +921,12 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         // histograms: ac_raw_bits[c] follows HistogramRawBits(ac_histo[c], depths of c) through
         // apply_step and is recounted when the depths change
         recount_raw_bits();
-        // The codes of the refresh at step i + 10 are computed beside steps i + 1 .. i + 10
-        // (codes_ahead.h): `ahead_for` is the step the helper's job in flight belongs to.
-        size_t ahead_for = (size_t)-1;
-        auto post_codes_ahead = [&](size_t i) {   // the state after step i is current
-          const size_t target = i + CodesAhead::kMaxSteps;
-          if (!codes_ahead_on_ || target >= n_order) return;
-          CodesAhead::Job& job = codes_ahead_.job();
-          job.codes = &EntropyCodes;
-          job.ncomp = ncomp;
-          for (int c = 0; c < 3; ++c) {
-            job.histo[c] = ac_histo[c];
-            job.q[c] = quant_[c];
-          }
-          job.nsteps = 0;
-          job.nblocks = 0;
-          int blk_b[CodesAhead::kMaxSteps], blk_c[CodesAhead::kMaxSteps], step_b[CodesAhead::kMaxSteps];
-          for (size_t j = i + 1; j <= target; ++j) {
-            const int b = sorted[j].first;
-            if (sorted.failed()) return;
-            settle_block(b, direction);
-            int taken = 0;   // steps of this block earlier in the window
-            for (int s = 0; s < job.nsteps; ++s) taken += step_b[s] == b;
-            const int idx = cand_idx[cand_off[b] + next_cand[b] + direction * taken + std::min(direction, 0)];
-            const int c = idx / 64, k = idx % 64;
-            const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
-            const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], quant_[c][k]);
-            int slot = -1;
-            for (int t = 0; t < job.nblocks; ++t)
-              if (blk_b[t] == b && blk_c[t] == c) slot = t;
-            if (slot < 0) {
-              slot = job.nblocks++;
-              blk_b[slot] = b;
-              blk_c[slot] = c;
-              memcpy(job.blocks[slot], &img_[Pos(c, b, 0)], sizeof(job.blocks[slot]));
-            }
-            CodesAhead::Step& st = job.steps[job.nsteps];
-            step_b[job.nsteps++] = b;
-            st.slot = slot;
-            st.c = c;
-            st.k = k;
-            st.newval = (int16_t)newval;
-            st.keep = newval == 0 && IsPrecious(orig_blk, k);
-          }
-          codes_ahead_.Post();
-          ahead_for = target;
-        };
         for (size_t i = fast_until; i < n_order; ++i) {
           apply_step(i);
           if (i % 10 == 0) {
             Stopwatch cw;
-            if (ahead_for == i) {
-              codes_ahead_.Wait();
-              const CodesAhead::Job& job = codes_ahead_.job();
-              if (verify_) {
-                for (int c = 0; c < ncomp; ++c)
-                  if (memcmp(job.histo[c].counts, ac_histo[c].counts, sizeof(ac_histo[c].counts)) != 0) {
-                    fprintf(stderr, "guetzli_amd: the statistics replayed ahead differ from the driver's\n");
-                    return false;
-                  }
-                std::vector<uint8_t> chk(3 * kHistoSize);
-                const int hdr = (int)EntropyCodes(ac_histo, ncomp, chk.data());
-                if (hdr != job.header || memcmp(chk.data(), job.depths, (size_t)ncomp * kHistoSize) != 0) {
-                  fprintf(stderr, "guetzli_amd: the codes computed ahead differ from the driver's\n");
-                  return false;
-                }
-              }
-              ac_header = job.header;
-              memcpy(ac_depths.data(), job.depths, (size_t)ncomp * kHistoSize);
-              for (int c = 0; c < ncomp; ++c) ac_raw_bits[c] = job.raw_bits[c];
-              ++n_codes_ahead_;
-            } else {
-              ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
-              recount_raw_bits();
-            }
-            ahead_for = (size_t)-1;
-            post_codes_ahead(i);
+            ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
+            recount_raw_bits();
             t_pb_codes_ += cw.lap();
           }
           ++n_steps_;
@@ -1103,7 +1021,6 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
   if (const char* e = getenv("GZ_ORDER_AHEAD")) build_ahead_ = atoi(e) != 0;
   if (const char* e = getenv("GZ_ORDER_DESCEND")) descend_ = atoi(e) != 0;
-  if (const char* e = getenv("GZ_CODES_AHEAD")) codes_ahead_on_ = atoi(e) != 0;
   if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
   best_score_ = -1;
   QuantMatrix ones;
@@ -1222,7 +1139,6 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->timers["pb_loop_fast_steps"] = t_pb_fast_;
   stats_->counters["block search evaluations"] = (int)std::min<long>(n_evaluations_, 2000000000L);
   stats_->counters["phase B fast steps"] = (int)n_fast_;
-  stats_->counters["phase B code refreshes made ahead"] = (int)n_codes_ahead_;
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
   if (best_on_host_) {

@@ -134,7 +134,14 @@ void put_tag(gz_ctx* c, int32_t t) { put(c, &t, 4); }
 void expect_tag(gz_ctx* c, int32_t t) {
   int32_t g = 0;
   get(c, &g, 4);
-  if (g != t) { fprintf(stderr, "gz_replay: log out of sync (want %d got %d)\n", t, g); abort(); }
+  static thread_local long seen[16] = {0};
+  if (g != t) {
+    fprintf(stderr, "gz_replay: log out of sync (want %d got %d) after", t, g);
+    for (int i = 1; i < 9; ++i) fprintf(stderr, " tag%d x %ld", i, seen[i]);
+    fprintf(stderr, "\n");
+    abort();
+  }
+  if (g > 0 && g < 16) ++seen[g];
 }
 
 }  // namespace
@@ -245,13 +252,14 @@ int gz_compare_end(gz_ctx* c, float* distance) {
   if (c->inner) {
     int rc = real()->compare_end(c->inner, distance);
     if (rc != GZ_OK) return rc;
-    // block maxima for the log: what gz_block_weights would fetch (all-ones weights query)
-    std::vector<float> w(c->nb);
+    // the block maxima for the log (replay builds the global order from them): the evaluation
+    // once more in its one-call form, which hands them over -- same candidate, same map
+    float again = 0;
+    rc = real()->compare(c->inner, &again, nullptr, c->bmax.data());
+    if (rc != GZ_OK) return rc;
+    if (again != *distance) { fprintf(stderr, "gz_replay: the repeated evaluation differs\n"); abort(); }
     put_tag(c, T_COMPARE);
     put(c, distance, 4);
-    // the maxima are not needed by the driver any more (weights are computed on the device);
-    // zeros keep the log format
-    std::fill(c->bmax.begin(), c->bmax.end(), 0.0f);
     put(c, c->bmax.data(), sizeof(float) * c->nb);
   } else {
     expect_tag(c, T_COMPARE);

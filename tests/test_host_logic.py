@@ -117,15 +117,3 @@ def test_bench_reads_the_chain_valu_floor_from_the_committed_counters():
         # the per-Compare count is below calls x average / Compares for the profiled run
         assert v["wave_instructions_per_compare"] < (470e6 if size == "4k" else 135e6)
 
-
-def test_codes_ahead_helper_matches_sequential_steps(tmp_path):
-    """guetzli_amd/host/codes_ahead.h: the helper thread that replays the next ten coefficient
-    steps of phase B on private copies and has the Huffman code lengths of the next refresh ready
-    -- thousands of random jobs (repeated blocks, kept "precious" coefficients, dropped jobs,
-    arm / rest cycles) against the same steps applied in sequence.  tests/cpp/test_codes_ahead.cc."""
-    exe = str(tmp_path / "test_codes_ahead")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_codes_ahead.cc"),
-                    os.path.join(ROOT, "guetzli_amd", "host", "jpeg_writer.cc"), "-o", exe, "-lz"], check=True)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert " 0 mismatches" in out.stdout, out.stdout

@@ -14,4 +14,11 @@ host = HostLibrary(build_replay.build_host())
 rgb = images.bees() if (w, h) == (444, 258) else images.tiled(w, h)
 t0 = time.perf_counter()
 jpg, info = host.process(rgb, quality=q)
-print(f"{w}x{h} q{q:g}: {len(jpg)} bytes sha256 {hashlib.sha256(jpg).hexdigest()} in {time.perf_counter()-t0:.2f}s log {os.path.getsize(out)} bytes")
+import json
+sha = hashlib.sha256(jpg).hexdigest()
+print(f"{w}x{h} q{q:g}: {len(jpg)} bytes sha256 {sha} in {time.perf_counter()-t0:.2f}s log {os.path.getsize(out)} bytes")
+# sidecar for the CPU test that replays the log (tests/test_host_logic.py)
+json.dump({"width": w, "height": h, "quality": q, "jpeg_bytes": len(jpg), "jpeg_sha256": sha,
+           "iterations": info["counters"].get("number of iterations"),
+           "head": open(os.path.join(ROOT, ".gpurun_head")).read().strip() if os.path.exists(os.path.join(ROOT, ".gpurun_head")) else None},
+          open(out + ".json", "w"), indent=1)

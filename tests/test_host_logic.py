@@ -2,6 +2,7 @@
 exactly (CPU only)."""
 import os
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -117,3 +118,32 @@ def test_bench_reads_the_chain_valu_floor_from_the_committed_counters():
         # the per-Compare count is below calls x average / Compares for the profiled run
         assert v["wave_instructions_per_compare"] < (470e6 if size == "4k" else 135e6)
 
+
+def test_host_driver_replays_a_960x540_encode_recorded_on_the_gpu(tmp_path, monkeypatch):
+    """The host search driver at a real image size without a GPU: tests/replay's shim stands in for
+    the device with the results an MI355X logged for this encode (tools/record_replay.py: original
+    coefficients, phase A's candidate lists, the distance and the per-block maxima of every
+    evaluation, the symbol statistics and scan sizes; 147 iterations) and the driver -- quant-matrix
+    bisection, global order with libstdc++'s tie order through the device-partition path, bulk and
+    slow steps, the size model -- must arrive at the JPEG the unmodified reference produces for this
+    image (jpeg_sha256_reference: oracle/_ref's Process() on the same pixels, 70 s of CPU,
+    generated once by tools/record_replay.py's sidecar step)."""
+    import hashlib
+    import json
+    import lzma
+    sys.path.insert(0, os.path.join(ROOT, "tests", "replay"))
+    import build_replay
+    import images
+    from guetzli_amd.encoder import HostLibrary
+    gold = os.path.join(ROOT, "tests", "golden", "replay")
+    meta = json.load(open(os.path.join(gold, "encode_960x540_q95.json")))
+    log = str(tmp_path / "encode.log")
+    with lzma.open(os.path.join(gold, "encode_960x540_q95.log.xz")) as f, open(log, "wb") as o:
+        o.write(f.read())
+    monkeypatch.setenv("GZ_REPLAY_MODE", "replay")
+    monkeypatch.setenv("GZ_REPLAY_FILE", log)
+    host = HostLibrary(build_replay.build_host())
+    jpg, info = host.process(images.tiled(meta["width"], meta["height"]), quality=meta["quality"])
+    assert len(jpg) == meta["jpeg_bytes"]
+    assert hashlib.sha256(jpg).hexdigest() == meta["jpeg_sha256"] == meta["jpeg_sha256_reference"]
+    assert info["counters"]["number of iterations"] == meta["iterations"]

@@ -37,7 +37,7 @@ Also on the JSON line:
                   contraction off the chain holds more VALU time than HBM time, and its
                   largest kernel (Malta) runs at 0.9 of its own VALU floor.
   scale_value  -- BASELINE config 5's work split on the GPUs this run has (the `config5_slice`
-                  leg): 3840x2160 images, 8 per GPU (image k -> rank k mod N), 8 in flight per
+                  leg): 3840x2160 images, 8 per GPU (image k -> rank k mod N), 4 in flight per
                   GPU, records all-gathered over the process group; every output whose
                   reference hash is committed (tests/golden/config5/: images 0-15) is checked.
                   The throughput curve of the real multi-GPU workload can be read from it at
@@ -366,11 +366,13 @@ def main():
     ap.add_argument("--no-4k", action="store_true", help="skip the 3840x2160 legs (configs[2], [3])")
     ap.add_argument("--batch-images", type=int, default=16,
                     help="images of the extra concurrent-batch leg (0 = skip)")
-    ap.add_argument("--batch-workers", type=int, default=8)
+    ap.add_argument("--batch-workers", type=int, default=4)
     ap.add_argument("--config5", action="store_true",
                     help="run only BASELINE config 5's slice (8 x 4K per GPU) and report it as value")
     ap.add_argument("--images-per-gpu", type=int, default=8)
-    ap.add_argument("--in-flight", type=int, default=8)
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="images in flight per GPU in the config-5 legs (4 keeps the GPU as busy as 8 or 12 "
+                         "do and varies less: profiles/r03_chain_kernel_experiments.log)")
     ap.add_argument("--size", default="4k", choices=["4k", "1080p"])
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 legs of the default run")
     ap.add_argument("--png", action="store_true", help="with --config5: the images arrive as PNG bytes")
@@ -555,7 +557,7 @@ def main():
             other["config5_slice_from_png"] = c5png
             out["scale_value"] = c5["value"]
             out["scale_metric"] = ("MPix/s over BASELINE config 5's batch slice: 8 independent 3840x2160 "
-                                   "images per GPU, 8 in flight per GPU")
+                                   f"images per GPU, {args.in_flight} in flight per GPU")
         if other is not None:
             out["other_configs"] = other
         if batch is not None:

@@ -62,7 +62,7 @@ def encode_shard_concurrent(get_image, indices, process, workers, rank=0):
         return list(ex.map(one, indices))
 
 
-def run_config5(get_image, images_per_gpu, process, rank=0, world=1, dist=None, workers=8,
+def run_config5(get_image, images_per_gpu, process, rank=0, world=1, dist=None, workers=4,
                 fence=None, device=None):
     """BASELINE config 5 ("a batch of independent images sharded 8-per-GPU across the GPUs of
     one node"): image k -> rank k mod world (k < images_per_gpu * world), every rank keeps

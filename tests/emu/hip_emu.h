@@ -9,11 +9,16 @@
 // references this file, and the emulated library has a different name and lives under
 // tests/.
 //
-// Model: one OS thread; each workgroup's threads are ucontext fibers scheduled
-// round-robin between __syncthreads() barriers; __shared__ is function-static storage
-// (one workgroup runs at a time); atomics are plain operations.
+// Model: one OS thread; each workgroup's threads are fibers scheduled round-robin between
+// __syncthreads() barriers; __shared__ is function-static storage (one workgroup runs at a
+// time); atomics are plain operations.  The fiber switch is a dozen instructions of our own on
+// x86-64 (glibc's swapcontext makes two rt_sigprocmask system calls per switch, and a workgroup
+// of 256 threads switches thousands of times per launch: the whole CPU suite ran three times as
+// long with it); other hosts keep ucontext.
 #pragma once
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -31,10 +36,33 @@ struct dim3 {
 };
 
 namespace hipemu {
+#if defined(__x86_64__)
+// gz_emu_switch(&save, load): pushes the callee-saved registers, stores the stack pointer in
+// *save, continues on the stack `load` (whose top holds six register values and a return address).
+extern "C" void gz_emu_switch(void** save_sp, void* load_sp);
+__asm__(
+    ".text\n"
+    ".p2align 4\n"
+    ".weak gz_emu_switch\n"
+    ".hidden gz_emu_switch\n"
+    ".type gz_emu_switch,@function\n"
+    "gz_emu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size gz_emu_switch,.-gz_emu_switch\n");
+struct Fiber {
+  void* sp = nullptr;
+};
+#else
+typedef ucontext_t Fiber;
+#endif
 struct State {
   dim3 threadIdx, blockIdx, blockDim, gridDim;
-  ucontext_t sched;
-  std::vector<ucontext_t> fibers;
+  Fiber sched;
+  std::vector<Fiber> fibers;
   std::vector<char*> stacks;
   std::vector<char> done;
   const std::function<void()>* body = nullptr;
@@ -45,11 +73,48 @@ inline State& st() {
   static State s;
   return s;
 }
+// the running fiber <-> the scheduler
+inline void to_sched() {
+  State& s = st();
+#if defined(__x86_64__)
+  gz_emu_switch(&s.fibers[s.current].sp, s.sched.sp);
+#else
+  swapcontext(&s.fibers[s.current], &s.sched);
+#endif
+}
+inline void to_fiber(int t) {
+  State& s = st();
+#if defined(__x86_64__)
+  gz_emu_switch(&s.sched.sp, s.fibers[t].sp);
+#else
+  swapcontext(&s.sched, &s.fibers[t]);
+#endif
+}
 inline void fiber_entry() {
   State& s = st();
   (*s.body)();
   s.done[s.current] = 1;
-  swapcontext(&s.fibers[s.current], &s.sched);
+  to_sched();
+  abort();   // (a finished fiber is never resumed)
+}
+inline void fiber_init(int t) {
+  State& s = st();
+#if defined(__x86_64__)
+  // top of the stack, 16-byte aligned: six zeroed registers, the entry as return address, and
+  // a slot that leaves the stack pointer where a call would have left it at fiber_entry
+  uintptr_t top = ((uintptr_t)s.stacks[t] + State::kStack) & ~(uintptr_t)15;
+  void** sp = (void**)(top - 64);
+  for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+  sp[6] = (void*)&fiber_entry;
+  sp[7] = nullptr;
+  s.fibers[t].sp = sp;
+#else
+  getcontext(&s.fibers[t]);
+  s.fibers[t].uc_stack.ss_sp = s.stacks[t];
+  s.fibers[t].uc_stack.ss_size = State::kStack;
+  s.fibers[t].uc_link = nullptr;
+  makecontext(&s.fibers[t], (void (*)())fiber_entry, 0);
+#endif
 }
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   State& s = st();
@@ -67,11 +132,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       for (unsigned bx = 0; bx < grid.x; ++bx) {
         s.blockIdx = dim3(bx, by, bz);
         for (int t = 0; t < nt; ++t) {
-          getcontext(&s.fibers[t]);
-          s.fibers[t].uc_stack.ss_sp = s.stacks[t];
-          s.fibers[t].uc_stack.ss_size = State::kStack;
-          s.fibers[t].uc_link = nullptr;
-          makecontext(&s.fibers[t], (void (*)())fiber_entry, 0);
+          fiber_init(t);
           s.done[t] = 0;
         }
         int alive = nt;
@@ -81,7 +142,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             if (s.done[t]) continue;
             s.current = t;
             s.threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-            swapcontext(&s.sched, &s.fibers[t]);
+            to_fiber(t);
             if (!s.done[t]) ++alive;
           }
         }
@@ -103,10 +164,7 @@ inline int num_threads() {
 #define blockDim (hipemu::st().blockDim)
 #define gridDim (hipemu::st().gridDim)
 
-inline void __syncthreads() {
-  hipemu::State& s = hipemu::st();
-  swapcontext(&s.fibers[s.current], &s.sched);
-}
+inline void __syncthreads() { hipemu::to_sched(); }
 
 #define __global__
 #define __device__
@@ -168,10 +226,7 @@ inline long long* wave_slots() {
   static long long slots[1024];
   return slots;
 }
-inline void yield() {
-  State& s = st();
-  swapcontext(&s.fibers[s.current], &s.sched);
-}
+inline void yield() { to_sched(); }
 }  // namespace hipemu
 inline unsigned long long __ballot(int pred) {
   const int tid = hipemu::linear_tid();

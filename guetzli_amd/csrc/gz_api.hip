@@ -1040,14 +1040,19 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[2] = {p0.mf[ch], p1.mf[ch], ms[ch][2].nm, ms[ch][2].lf};
     a.out = c->ac[ch];
   }
-  // GZ_MALTA_WIN=1: the line sums from a per-thread register window (k_malta_win: faster alone,
-  // 4K 294 -> 282 us, 1080p 85 -> 75 us, not beside the side streams' kernels: the chain gains
-  // nothing, profiles/r03_chain_kernel_experiments.log); read per call
+  // k_malta_rolled (the default): the loop over a thread's 8 pixels stays a loop, 59 VGPRs and 8
+  // wavefronts per SIMD instead of 120 / 4 (4K 313 -> 272 us, 1080p 89 -> 76 us, profiles/
+  // r03_chain_kernel_experiments.log).  GZ_MALTA_ROLLED=0: k_malta, the unrolled kernel;
+  // GZ_MALTA_WIN=1: the line sums from a per-thread register window (k_malta_win: faster than
+  // k_malta alone, not beside the side streams' kernels).  Read per call.
   const char* mw_env = getenv("GZ_MALTA_WIN");
+  const char* mr_env = getenv("GZ_MALTA_ROLLED");
   if (mw_env && atoi(mw_env) != 0)
     GZ_LAUNCH((k_malta_win<3>), mgrid, dim3(512), c->stream, ay, ax, c->w, c->h, c->pitch);
-  else
+  else if (mr_env && atoi(mr_env) == 0)
     GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
+  else
+    GZ_LAUNCH((k_malta_rolled<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);
   TRY(join_mask_branch(c));
   {

@@ -202,6 +202,80 @@ __global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs<NP
   }
 }
 
+// k_malta with the loop over a thread's 8 pixels left a loop and the pixels' accumulators in LDS:
+// one pixel's 16 line sums need a third of the registers all eight need side by side, and the
+// kernel's three phases per pass are bound by how many wavefronts a SIMD holds, not by a unit
+// (profiles/r03_chain_kernel_experiments.log) -- 8 wavefronts per SIMD instead of 4.  Same
+// operations per pixel in the same order.
+template <int NPASS>
+__global__ __launch_bounds__(256, 8) void k_malta_rolled(MaltaArgs<NPASS> a0, MaltaArgs<NPASS> a1, int w,
+                                               int h, int pitch) {
+  const GzTile bid = gz_xcd_tile();
+  const MaltaArgs<NPASS>& a = bid.z ? a1 : a0;
+  __shared__ __attribute__((aligned(16))) float tile[MH + 8][MW + 8];
+  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int x0 = bid.x * MW, y0 = bid.y * MH;
+  __shared__ float accs[MPT][256];
+#pragma unroll
+  for (int i = 0; i < MPT; ++i) accs[i][threadIdx.x] = 0.0f;   // (own slots: no barrier needed)
+  // the haloed tile starts at x0 - 4: rows can be staged with aligned 16-byte loads when the
+  // tile lies inside the image horizontally and the pitch allows it
+  const bool vec = x0 >= 4 && x0 + MW + 4 <= w && (pitch & 3) == 0;
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const MaltaPass P = a.pass[ps];
+    if (ps > 0) __syncthreads();
+    if (vec) {
+      constexpr int NV = (MH + 8) * ((MW + 8) / 4);   // 16-byte vectors in the tile
+#pragma unroll 1
+      for (int k = 0; k < (NV + 255) / 256; ++k) {
+        const int i = 256 * k + (int)threadIdx.x;
+        if (i < NV) {
+          const int ry = i / ((MW + 8) / 4), q = i - ry * ((MW + 8) / 4);
+          const int y = y0 - 4 + ry;
+          gz_f4 v;
+          v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
+          if (y >= 0 && y < h) {
+            const size_t idx = (size_t)y * pitch + (x0 - 4 + 4 * q);
+            const gz_f4 u0 = GZ_LDG4(P.p0, idx), u1 = GZ_LDG4(P.p1, idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], P.nm);
+          }
+          *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = v;
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < (MH + 8) * (MW + 8); i += 256) {
+        const int ry = i / (MW + 8), rx = i - ry * (MW + 8);
+        const int x = x0 - 4 + rx, y = y0 - 4 + ry;
+        float v = 0.0f;
+        if (x >= 0 && x < w && y >= 0 && y < h) {
+          const size_t idx = (size_t)y * pitch + x;
+          v = malta_diff(GZ_LDG(P.p0, idx), GZ_LDG(P.p1, idx), P.nm);
+        }
+        tile[ry][rx] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < MPT; ++i) {
+      const int ly = tg * MPT + i;
+      const float r = P.lf ? malta_unit<true>(tile, ly + 4, tx + 4)
+                           : malta_unit<false>(tile, ly + 4, tx + 4);
+      accs[i][threadIdx.x] += r;
+    }
+  }
+  const int x = x0 + tx;
+  if (x >= w) return;
+#pragma unroll
+  for (int i = 0; i < MPT; ++i) {
+    const int y = y0 + tg * MPT + i;
+    if (y >= h) break;
+    const size_t idx = (size_t)y * pitch + x;
+    const float v = accs[i][threadIdx.x];
+    GZ_STG(a.out, idx, v);
+  }
+}
+
 // ---- Malta from a register window -----------------------------------------------------
 // k_malta's line sums read every tap from LDS (ds_read2_b32: 128 bytes per clock and CU): 128
 // (HF) / 80 (LF) dwords per pixel and pass -- at 4K that is 54 / 34 us per pass of nothing but

@@ -35,11 +35,15 @@ def test_idct_multiply_add_variant(L, monkeypatch):
 
 
 def test_malta_line_sum_variants(L, monkeypatch):
-    """k_malta (the default: every tap read from LDS) and k_malta_win (GZ_MALTA_WIN=1: every
+    """k_malta_rolled (the default: every tap read from LDS, a thread's pixels one after the other,
+    accumulators in LDS), k_malta (GZ_MALTA_ROLLED=0: the same unrolled) and k_malta_win (GZ_MALTA_WIN=1: every
     thread's neighbourhood loaded into registers once, the 16 oriented sums formed from registers)
     give the same bits; an image with interior and border Malta tiles."""
     pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
     monkeypatch.setenv("GZ_MALTA_WIN", "1")
+    pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
+    monkeypatch.delenv("GZ_MALTA_WIN")
+    monkeypatch.setenv("GZ_MALTA_ROLLED", "0")   # k_malta: the loop over a thread's pixels unrolled
     pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
 
 

@@ -561,9 +561,13 @@ void alloc_psycho(gz_ctx* c, Psycho* p) {
 // either way), so what these variants gain is fewer LDS reads and address computations per
 // output, and what they lose is parallelism: measured per kernel (profiles/
 // r02_packed_blur_ab.log) they win from 4 MPix on for the radius-16 and radius-20 row passes
-// and the single-plane column passes, and lose below that and for the 3-plane column pass
-// and the SameNoise row pass.  GZ_BLUR_PK=0 / 1 forces the scalar / paired kernels everywhere
-// (read per call: the tests switch it).
+// and the single-plane column passes, and lose below that; the multi-plane column passes and
+// the radius-23 (SameNoise) row pass lose by a few microseconds kernel by kernel but win
+// inside the three-stream chain since Malta holds 8 wavefronts per SIMD (4K 1.066 -> 1.037 ms
+// with every pass paired, 1.049-1.056 / 1.044-1.053 with either of the two alone: profiles/
+// r03_chain_kernel_experiments.log) -- from 4 MPix on every separate pass is the paired one.
+// GZ_BLUR_PK=0 / 1 forces the scalar / paired kernels everywhere (read per call: the tests
+// switch it).
 // Code-path options of the blur kernels (gz_kernels_blur.h: kOptQuad, kOptRotate), read per
 // call so that the tests can run every path: GZ_BLUR_OPT=<bits> overrides the default.
 static int blur_opt() {
@@ -571,10 +575,10 @@ static int blur_opt() {
   if (e) return atoi(e);
   return kOptQuad | kOptRotate;
 }
-static bool packed_blur(const gz_ctx* c, bool favourable) {
+static bool packed_blur(const gz_ctx* c) {
   const char* e = getenv("GZ_BLUR_PK");
   if (e) return atoi(e) != 0;
-  return favourable && (size_t)c->w * c->h >= 4000000;
+  return (size_t)c->w * c->h >= 4000000;
 }
 
 template <int R, class Src, int NC>
@@ -584,7 +588,7 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.bx;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (packed_blur(c, R <= 20)) {
+  if (packed_blur(c)) {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), NC);
     GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs, blur_opt());
     KCHK(c);
@@ -634,7 +638,7 @@ int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (!BM && packed_blur(c, NC == 1)) {
+  if (!BM && packed_blur(c)) {
     if (small_tiles(c)) {
       dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
       GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
@@ -683,7 +687,7 @@ int blur_h_pair(gz_ctx* c, const SrcPack<Src, 2>& src, const PlanePack<2>& dst, 
   const Taps<R> t0 = taps_of<R>(cfg0), t1 = taps_of<R>(cfg1);
   const BorderScale b0 = cfg0.bx, b1 = cfg1.bx;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (packed_blur(c, R <= 20)) {
+  if (packed_blur(c)) {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), 2);
     GZ_LAUNCH((k_blur_h_pk<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1, blur_opt());
   } else {
@@ -703,7 +707,7 @@ int blur_v_pair(gz_ctx* c, const CPlanePack<2>& src, const PostStore<2>& post, c
   const BlockMaxOut bm{nullptr, nullptr, 0};
   const bool small = small_tiles(c);
   dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, small ? kSmallTileRows : kTileRows), 2);
-  if (packed_blur(c, true)) {
+  if (packed_blur(c)) {
     if (small) GZ_LAUNCH((k_blur_v_pk<R, 2, PostStore<2>, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
     else GZ_LAUNCH((k_blur_v_pk<R, 2, PostStore<2>, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
   } else if (compact_code(c, "GZ_COMPACT_BLUR_V")) {
@@ -922,7 +926,7 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
   // X: sigma r2 = 9.24 ; Y second: sigma r1 = 9.04 -- both radius 20, separate taps: one launch
   // per pass for the two (GZ_MASK_PAIR=0, or the unrolled column kernels: one blur after the other)
   static const bool pair_off = getenv("GZ_MASK_PAIR") && atoi(getenv("GZ_MASK_PAIR")) == 0;
-  const bool pair = !pair_off && (packed_blur(c, true) || compact_code(c, "GZ_COMPACT_BLUR_V"));
+  const bool pair = !pair_off && (packed_blur(c) || compact_code(c, "GZ_COMPACT_BLUR_V"));
   if (pair) {
     SrcPack<SrcPlain, 2> s; PlanePack<2> t; CPlanePack<2> ct;
     s.s[0].p = c->diffx; s.s[1].p = c->diffy;

@@ -39,7 +39,7 @@ Also on the JSON line:
   scale_value  -- BASELINE config 5's work split on the GPUs this run has (the `config5_slice`
                   leg): 3840x2160 images, 8 per GPU (image k -> rank k mod N), 4 in flight per
                   GPU, records all-gathered over the process group; every output whose
-                  reference hash is committed (tests/golden/config5/: images 0-31) is checked.
+                  reference hash is committed (tests/golden/config5/: all 64 images) is checked.
                   The throughput curve of the real multi-GPU workload can be read from it at
                   every N.  `--config5` runs only this leg and reports it as `value`.
   first_encode_s -- the process's first encode (HIP start-up, code-object load, pool fill).

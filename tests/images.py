@@ -54,3 +54,30 @@ def synthetic(w, h):
     v = 255.0 * (((x.astype(np.int64) // 2) + (y.astype(np.int64) // 2)) % 2)
     r[ck], g[ck], b[ck] = v[ck], v[ck], 255.0 - v[ck]
     return np.ascontiguousarray(np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8))
+
+
+# ---- degenerate content (round 4): what the reference handles at the edges of its search ----
+def flat(w, h, rgb):
+    """One colour everywhere: all AC coefficients zero, nothing for the zeroing search to rank."""
+    return np.ascontiguousarray(np.broadcast_to(np.array(rgb, np.uint8), (h, w, 3)))
+
+
+def stripes(w, h, period=37):
+    """Vertical stripes of the eight saturated corner colours of the RGB cube, `period` pixels
+    wide (not a multiple of 8: every stripe edge falls inside a block)."""
+    cols = np.array([(255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 0), (0, 255, 255),
+                     (255, 0, 255), (0, 0, 0), (255, 255, 255)], np.uint8)
+    idx = (np.arange(w) // period) % 8
+    return np.ascontiguousarray(np.broadcast_to(cols[idx][None, :, :], (h, w, 3)))
+
+
+def noise(w, h, seed=1):
+    """Uniform noise without an RNG library: a 32-bit integer hash of the sample index
+    (multiply / xorshift rounds), its top byte.  Every block has 63 non-zero AC coefficients per
+    component -> the 189-candidate lists of ComputeBlockZeroingOrder."""
+    i = (np.arange(w * h * 3, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    for mul in (0x7FEB352D, 0x846CA68B):
+        i ^= i >> np.uint64(16)
+        i = (i * np.uint64(mul)) & np.uint64(0xFFFFFFFF)
+    i ^= i >> np.uint64(16)
+    return np.ascontiguousarray((i >> np.uint64(24)).astype(np.uint8).reshape(h, w, 3))

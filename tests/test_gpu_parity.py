@@ -619,6 +619,97 @@ def test_whole_encode_params_golden_hashes(name, exp, monkeypatch):
     assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]
 
 
+def _degenerate_cases():
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "degenerate")
+    if not os.path.isdir(d):
+        return []
+    return [(f[:-5], json.load(open(os.path.join(d, f)))) for f in sorted(os.listdir(d)) if f.endswith(".json")]
+
+
+def degenerate_input(exp):
+    """(rgb as the reference's front end hands it to Process, params) of a tests/golden/degenerate case."""
+    import hashlib
+    import os
+    import guetzli_amd
+    if "png" in exp:
+        here = os.path.dirname(os.path.abspath(__file__))
+        data = open(os.path.join(here, "golden", "degenerate", exp["png"]), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == exp["png_sha256"]
+        rgb = guetzli_amd.read_png(data)          # the product's ReadPNG (host/png_reader.cc)
+    else:
+        spec = exp["image"]
+        kind, w, h = spec[:3]
+        rgb = {"flat": lambda: images.flat(w, h, spec[3]), "stripes": lambda: images.stripes(w, h),
+               "noise": lambda: images.noise(w, h), "tiled": lambda: images.tiled(w, h)}[kind]()
+    assert hashlib.sha256(rgb.tobytes()).hexdigest() == exp["rgb_sha256"]
+    return rgb, dict(exp["params"])
+
+
+@pytest.mark.parametrize("name,exp", _degenerate_cases())
+def test_degenerate_content_golden_hashes(name, exp):
+    """Content at the edges of the search, against hashes the UNMODIFIED reference produced
+    (tools/gen_goldens.py degenerate): flat black / white / grey / red (all AC zero; the v < 1e-4
+    branch of CalculateDiffmap, butteraugli.cc:722-732; try_420 / force_420 on flat chroma),
+    saturated-primary stripes, uniform noise (189-candidate zeroing lists), 33- and 32-pixel
+    slivers, and RGBA / 16-bit / interlaced grey+alpha / palette+tRNS PNG files through the
+    product's ReadPNG and the full encode."""
+    import hashlib
+    import guetzli_amd
+    rgb, params = degenerate_input(exp)
+    jpg, _ = guetzli_amd.load_host().process(rgb, quality=exp["quality"], **params)
+    assert len(jpg) == exp["bytes"]
+    assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]
+
+
+def test_config5_all_64_reference_hashes():
+    """BASELINE configs[4], the whole batch of an 8-GPU run on this one GPU: the 64 3840x2160
+    images (the bench image circularly shifted by (37k, 53k)) through guetzli_amd.batch.run_config5,
+    4 in flight, every output against the hash the UNMODIFIED reference produced for it
+    (tests/golden/config5/k0..k63.json, ~20 CPU-minutes of reference time each;
+    /root/reference/tests/golden_test.sh:24-26 is the reference's form of the same check)."""
+    import json
+    import os
+    import guetzli_amd
+    from guetzli_amd.batch import run_config5
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = {}
+    for k in range(64):
+        r = json.load(open(os.path.join(here, "golden", "config5", f"k{k}.json")))
+        assert (r["k"], r["w"], r["h"], r["quality"]) == (k, 3840, 2160, 95.0)
+        gold[k] = r
+    base = images.tiled(3840, 2160)
+    host = guetzli_amd.load_host()
+    recs, seconds = run_config5(lambda k: images.shifted(base, k), 64,
+                                lambda rgb: host.process(rgb, quality=95), workers=4)
+    assert [r["index"] for r in recs] == list(range(64))
+    bad = [r["index"] for r in recs
+           if (r["bytes"], r["sha256"]) != (gold[r["index"]]["bytes"], gold[r["index"]]["jpeg_sha256"])]
+    assert not bad, f"config-5 images with bytes unlike the reference's: {bad}"
+    print(f"config 5: 64 of 64 outputs equal to the reference's, {seconds:.1f} s = "
+          f"{64 * 3840 * 2160 / 1e6 / seconds:.1f} MPix/s on one GPU")
+
+
+def test_config5_members_from_png_bytes():
+    """The same batch handed over as PNG files (what `guetzli in.png out.jpg` reads): two members
+    through process_png give the reference's bytes."""
+    import hashlib
+    import io
+    import json
+    import os
+    from PIL import Image
+    import guetzli_amd
+    here = os.path.dirname(os.path.abspath(__file__))
+    base = images.tiled(3840, 2160)
+    for k in (5, 41):
+        b = io.BytesIO()
+        Image.fromarray(images.shifted(base, k)).save(b, "PNG", compress_level=1)
+        jpg, _ = guetzli_amd.process_png(b.getvalue(), quality=95)
+        r = json.load(open(os.path.join(here, "golden", "config5", f"k{k}.json")))
+        assert (len(jpg), hashlib.sha256(jpg).hexdigest()) == (r["bytes"], r["jpeg_sha256"])
+
+
 def test_contexts_on_a_foreign_current_device_are_safe(L):
     """Every entry point runs on its context's device and restores the caller's:
     with one GPU this checks at least that nothing changes the current device."""

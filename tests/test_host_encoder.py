@@ -86,6 +86,27 @@ def test_whole_encode_matches_reference_in_emulation(host_emu, case, monkeypatch
 
 
 @needs_ref
+@pytest.mark.parametrize("case", [
+    ("flat", (0, 0, 0), 40, 32, 95, {}), ("flat", (255, 255, 255), 33, 35, 95, {"try_420": True}),
+    ("flat", (255, 0, 0), 48, 32, 84, {"force_420": True}), ("stripes", 5, 48, 40, 95, {}),
+    ("stripes", 7, 41, 37, 90, {"force_420": True}), ("noise", 1, 40, 32, 95, {}),
+    ("noise", 2, 34, 33, 84, {"try_420": True}),
+])
+def test_degenerate_content_matches_reference_in_emulation(host_emu, case):
+    """Content at the edges of the search: flat images (all AC zero, empty zeroing
+    orders, the v < 1e-4 branch of CalculateDiffmap, butteraugli.cc:722-732), saturated stripes,
+    uniform noise (every coefficient a candidate) -- bytes and --verbose trace of the reference."""
+    kind, arg, w, h, quality, params = case
+    rgb = {"flat": lambda: images.flat(w, h, arg), "stripes": lambda: images.stripes(w, h, period=arg),
+           "noise": lambda: images.noise(w, h, seed=arg)}[kind]()
+    target = ref._butteraugli_score_for_quality(float(quality))
+    exp_jpg, exp_trace = ref.process_params(rgb, target, want_trace=True, **params)
+    got_jpg, info = host_emu.process(rgb, quality=quality, want_trace=True, **params)
+    assert info["trace"].splitlines() == exp_trace.splitlines()
+    assert got_jpg == exp_jpg
+
+
+@needs_ref
 @pytest.mark.parametrize("wh", [(24, 40), (31, 64), (8, 8), (1, 1), (5, 3)])
 def test_small_images_emit_the_unquantised_jpeg(host_emu, wh):
     """w or h < 32: no butteraugli; Process() returns the q = 1 JPEG of EncodeRGBToJpeg

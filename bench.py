@@ -4,11 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload of `value` (BASELINE.json configs[1]): one 1920x1080 sRGB image (tests/golden/bees.png
-tiled from the origin), --quality 95 (butteraugli target 0.971769).  One image
-per GPU per step ("weak" scaling: rank r encodes the image circularly shifted by (37r, 53r)
-pixels, as in config 5); images are independent, so there is no data-path collective -- only
-the barrier and the max-over-ranks of the elapsed time.
+Workload of `value` (BASELINE.json configs[2], north_star's target size and the rocprof config): one
+3840x2160 sRGB image (tests/golden/bees.png tiled from the origin), --quality 95
+(butteraugli target 0.971769).  One image per GPU per step ("weak" scaling: rank r encodes the
+image circularly shifted by (37r, 53r) pixels, as in config 5); images are independent, so there
+is no data-path collective -- only the barrier and the max-over-ranks of the elapsed time.
 
 A STEP is one whole encode: guetzli::Process(params, stats, rgb, w, h, &out) through the
 host search driver (guetzli_amd/host) with every per-pixel / per-block operation on the GPU
@@ -20,22 +20,22 @@ the boundary is inside the number.  Rank 0's output is checked against the refer
 JPEG (SHA-256 recorded from the unmodified reference) after the timed region.
 
 Also on the JSON line:
-  value_4k / ms_per_step_4k / config_4k -- BASELINE configs[2], north_star's target size: one
-                  3840x2160 image at --quality 95, timed EXACTLY like `value` (same --steps and
+  value_1080p / ms_per_step_1080p / config_1080p / roofline_1080p -- BASELINE configs[1], one
+                  1920x1080 image at --quality 95, timed EXACTLY like `value` (same --steps and
                   --warmup, same barrier / synchronise bracket, max over ranks), output hash
-                  checked against the reference's.
+                  checked against the reference's.  (Until round 3 this size was `value` and the
+                  3840x2160 leg was `value_4k`; --no-4k makes it the headline again.)
   roofline     -- HBM roofline of the butteraugli evaluation (the second half of the
-                  metric): SURVEY.md 8(d) algorithmic bytes of one Compare (494 B/px) /
-                  average duration of one Compare chain measured with HIP events on the
-                  stream the kernels run on (gz_time_compare), same process, same image.
+                  metric) on the headline image: SURVEY.md 8(d) algorithmic bytes of one Compare
+                  (494 B/px) / average duration of one Compare chain measured with HIP events on
+                  the stream the kernels run on (gz_time_compare), same process, same image.
                   `traffic` = HBM bytes of one chain from the rocprofv3 FETCH_SIZE /
                   WRITE_SIZE passes committed under profiles/ (the counters cannot be read
-                  from inside this process; `traffic_head` = the commit they were taken at).
-                  `roofline_4k` = the same measurement on 3840x2160, the size the chain fills
-                  the chip at.  `valu` inside both: the chain's VALU floor (SQ_INSTS_VALU of its
-                  kernels from the committed --pmc pass / the chip's VALU issue rate) -- with
-                  contraction off the chain holds more VALU time than HBM time, and its
-                  largest kernel (Malta) runs at 0.9 of its own VALU floor.
+                  from inside this process; `traffic_head` = the commit they were taken at);
+                  null with `traffic_stale` when the committed figure was measured on other kernel
+                  sources than this tree's (tools/gpu_pmc.sh regenerates it).  `valu` inside: the
+                  chain's VALU issue time at the two rates an instruction can have (SQ_INSTS_VALU
+                  of its kernels from the committed --pmc pass).
   scale_value  -- BASELINE config 5's work split on the GPUs this run has (the `config5_slice`
                   leg): 3840x2160 images, 8 per GPU (image k -> rank k mod N), 4 in flight per
                   GPU, records all-gathered over the process group; every output whose
@@ -78,8 +78,24 @@ GOLDEN_SHA_4K = {95: "481507d21e4d37f296ae6a2a93a84d950c4a135df310b3408a64390b25
 CHAIN = ("butteraugli Compare chain (15 launches per Compare on 3 streams: k_reconstruct, 5 fused "
          "k_blur2d (radius < 16), 3 k_blur_h + 3 k_blur_v (radius >= 16; the mask's radius-20 pair is one "
          "launch per pass), k_malta (both channels), k_mask_pre, k_combine)")
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_compare_pmc_traffic.json")
-TRAFFIC_JSON_OLD = os.path.join(ROOT, "profiles", "r02_compare_pmc_traffic.json")
+TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in
+                 ("r04_compare_pmc_traffic.json", "r03_compare_pmc_traffic.json")]
+
+
+def load_traffic():
+    """The committed PMC traffic figures, or {"stale": True, ...} when they were measured on other
+    kernel sources than this tree's (guetzli_amd.build.csrc_digest; tools/gpu_pmc.sh regenerates
+    them): a figure that no longer describes the code must not sit beside a live measurement."""
+    from guetzli_amd.build import csrc_digest
+    for path in TRAFFIC_JSONS:
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        t.setdefault("source", os.path.relpath(path, ROOT))
+        t["stale"] = t.get("csrc_sha256") != csrc_digest()
+        return t
+    return {"stale": True}
 
 
 def cpu_baseline():
@@ -173,6 +189,7 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         assert self.world == args.gpus, f"WORLD_SIZE {self.world} != --gpus {args.gpus}"
         self.dist = None
+        self.cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
         if not self.emulate:
             assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
             torch.cuda.set_device(self.local_rank)
@@ -198,10 +215,15 @@ class Env:
         try:
             cpus = sorted(os.sched_getaffinity(0))
             per = len(cpus) // self.world
-            if per >= 2:
+            if per >= 1:
                 os.sched_setaffinity(0, cpus[self.local_rank * per:(self.local_rank + 1) * per])
-        except OSError:
-            pass
+            else:   # fewer cores than ranks: nothing to partition, say so
+                print(f"bench.py: rank {self.rank}: {len(cpus)} host cores for {self.world} ranks -- "
+                      "not binding (ranks share the cores)", file=sys.stderr, flush=True)
+        except OSError as e:
+            print(f"bench.py: rank {self.rank}: sched_setaffinity failed ({e}) -- not binding",
+                  file=sys.stderr, flush=True)
+        self.cores = len(os.sched_getaffinity(0))
 
     def sync(self):
         if not self.emulate:
@@ -255,6 +277,15 @@ def timed_steps(env, step, steps, warmup):
     return env.max_over_ranks(time.perf_counter() - t0), res
 
 
+def ranks_seen(env):
+    """Sum over the process group of 1 per rank (RCCL all-reduce on the GPUs; gloo in the dry run)."""
+    if env.dist is None:
+        return 1
+    t = env.torch.ones(1, dtype=env.torch.int32, device=env.tensor_device)
+    env.dist.all_reduce(t, op=env.dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, from_png=False):
     """8 images per GPU of config 5's batch; returns the JSON object of the leg (rank 0).
     from_png: the batch as configs[4] words it -- PNG files: every image arrives as PNG bytes
@@ -301,7 +332,16 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
             "images": n, "images_per_gpu": images_per_gpu, "in_flight": in_flight,
             "seconds": round(secs, 3), "value": round(n * w5 * h5 / 1e6 / secs, 3), "unit": "MPix/s",
             "outputs_checked_against_reference_hashes": checked,
-            "distinct_outputs": len({r["sha256"] for r in recs})}
+            "distinct_outputs": len({r["sha256"] for r in recs}),
+            # what the process group saw: an all-reduced count of the ranks, and from the gathered
+            # records the ranks that delivered images with each rank's busiest image thread
+            "n_ranks_seen": ranks_seen(env),
+            "ranks_in_records": sorted({r["rank"] for r in recs}),
+            "images_per_rank": {str(k): sum(1 for r in recs if r["rank"] == k)
+                                for k in sorted({r["rank"] for r in recs})},
+            "encode_seconds_per_rank": {str(k): round(sum(r["seconds"] for r in recs if r["rank"] == k), 3)
+                                        for k in sorted({r["rank"] for r in recs})},
+            "host_cores_per_rank": env.cores}
 
 
 SQ_COUNTERS = {"1080p": os.path.join(ROOT, "profiles", "r03_compare_1080p_sq_counters.csv"),
@@ -474,14 +514,7 @@ def main():
         c5 = config5_leg(env, host, images, args.images_per_gpu, args.in_flight, size5, quality)
         c5png = config5_leg(env, host, images, 1 if emu else args.images_per_gpu, args.in_flight, size5, quality,
                             from_png=True)
-    traffic = {}
-    for path in (TRAFFIC_JSON, TRAFFIC_JSON_OLD):
-        try:
-            traffic = json.load(open(path))
-            traffic.setdefault("source", os.path.relpath(path, ROOT))
-            break
-        except Exception:
-            pass
+    traffic = load_traffic()
 
     if rank == 0:
         if not emu:
@@ -493,64 +526,69 @@ def main():
         timer_keys = ("total", "phase_b_host", "compare", "block_search", "jpeg_write", "create+encode",
                       "select_quant_matrix", "pb_device_partitions", "pb_device_descents",
                       "pb_device_fetches", "pb_loop_codes")
+
+        def leg(w, h, seconds, jpeg, inf, which):
+            """value / ms_per_step / config of one timed size (both sizes are timed identically)."""
+            return (round(world * args.steps * w * h / 1e6 / seconds, 4), round(seconds / args.steps * 1e3, 2),
+                    {"workload": f"single {w}x{h} sRGB image, --quality {quality:g} (BASELINE {which}), whole "
+                                 "guetzli::Process per step (host RGB in, JPEG bytes out), 1 image per GPU "
+                                 f"per step; {args.steps} timed steps after {args.warmup} warm-up between "
+                                 "barrier + synchronise, max over ranks",
+                     "butteraugli_target": TARGET_Q95, "images_per_gpu": 1, "steps": args.steps,
+                     "warmup": args.warmup, "output_bytes": len(jpeg),
+                     "output_sha256_matches_reference": not emu,
+                     "iterations": inf["counters"].get("number of iterations"),
+                     "host_timers_s": {k: round(v, 3) for k, v in inf["timers"].items() if k in timer_keys}})
+
+        def roof(w, h, ms_c, ach, key):
+            t = traffic.get(key, {})
+            return {"bound": "hbm", "kernel": CHAIN, "workload": f"{w}x{h}",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBPS, 4),
+                    "traffic": None if traffic.get("stale") else t.get("traffic_bytes"),
+                    "traffic_stale": bool(traffic.get("stale")), "traffic_head": traffic.get("head"),
+                    "traffic_source": traffic.get("source"), "ms_per_compare": round(ms_c, 4),
+                    "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * w * h,
+                    "valu": None if emu else valu_floor(key, ms_c)}
+
+        v_small, ms_small, cfg_small = leg(W, H, dt, jpg, info, "configs[1]")
+        roof_small = roof(W, H, ms, achieved, "1080p")
+        if dt4k is not None:
+            # the headline: BASELINE configs[2], north_star's target size and the rocprof config
+            v_big, ms_big, cfg_big = leg(W4, H4, dt4k, jpg4k, info4k, "configs[2]")
+            head, inf_head = (v_big, ms_big, cfg_big, roof(W4, H4, ms_4k, achieved_4k, "4k"), (W4, H4)), info4k
+        else:
+            head, inf_head = (v_small, ms_small, cfg_small, roof_small, (W, H)), info
         out = {
             "metric": "MPix/s encoded at --quality 95",
-            "value": round(world * args.steps * W * H / 1e6 / dt, 4),
+            "value": head[0],
             "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "ms_per_step": head[1],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32+f64 (butteraugli), int32/int16 (DCT/quantize/entropy coding)",
-            "data": f"synthetic (tests/golden/bees.png tiled to {W}x{H}, SURVEY 8d)",
-            "config": {"workload": f"single {W}x{H} sRGB image, --quality {quality:g}, whole "
-                                   "guetzli::Process per step (host RGB in, JPEG bytes out), "
-                                   "1 image per GPU per step",
-                       "butteraugli_target": TARGET_Q95, "images_per_gpu": 1,
-                       "output_bytes": len(jpg), "output_sha256_matches_reference": not emu,
-                       "iterations": info["counters"].get("number of iterations")},
+            "data": f"synthetic (tests/golden/bees.png tiled to {head[4][0]}x{head[4][1]}, SURVEY 8d)",
+            "config": head[2],
             "first_encode_s": round(first_encode_s, 3),
-            "roofline": {"bound": "hbm",
-                         "kernel": CHAIN,
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic.get("1080p", {}).get("traffic_bytes"),
-                         "traffic_head": traffic.get("head"), "traffic_source": traffic.get("source"),
-                         "ms_per_compare": round(ms, 4),
-                         "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W * H,
-                         "valu": None if emu else valu_floor("1080p", ms)},
-            "roofline_4k": {"bound": "hbm", "kernel": CHAIN, "workload": f"{W4}x{H4} (configs[2])",
-                            "achieved": round(achieved_4k, 1),
-                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": round(achieved_4k / HBM_PEAK_GBPS, 4),
-                            "traffic": traffic.get("4k", {}).get("traffic_bytes"),
-                            "traffic_head": traffic.get("head"),
-                            "ms_per_compare": round(ms_4k, 4),
-                            "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * W4 * H4,
-                            "valu": None if emu or ms_4k is None else valu_floor("4k", ms_4k)},
+            "roofline": head[3],
             # phase A (SURVEY 8d: not HBM-bound -- reported in evaluations, not bytes)
-            "block_search": {"evaluations": info["counters"].get("block search evaluations"),
-                             "seconds": round(info["timers"].get("block_search", 0.0), 4),
-                             "evaluations_per_s": round(info["counters"].get("block search evaluations", 0) /
-                                                        max(info["timers"].get("block_search", 0.0), 1e-9)),
+            "block_search": {"evaluations": inf_head["counters"].get("block search evaluations"),
+                             "seconds": round(inf_head["timers"].get("block_search", 0.0), 4),
+                             "evaluations_per_s": round(inf_head["counters"].get("block search evaluations", 0) /
+                                                        max(inf_head["timers"].get("block_search", 0.0), 1e-9)),
                              "valu": block_search_counters(),
                              "note": "CompareBlock evaluations (one 8x8 IDCT + colour + opsin + FFT "
-                                     "distance each) of gz_block_zeroing_orders; `valu`: SQ counters of "
-                                     "k_block_search<0> on the same 1080p image (3 resident waves per SIMD: "
-                                     "valu_active_per_wave_cycle x 3 = share of SIMD cycles issuing VALU)"},
-            "host_timers_s": {k: round(v, 3) for k, v in info["timers"].items() if k in timer_keys},
+                                     "distance each) of gz_block_zeroing_orders on the headline image; "
+                                     "`valu`: SQ counters of k_block_search<0> on the 1080p image from the "
+                                     "committed --pmc pass (valu_active_per_wave_cycle x resident waves per "
+                                     "SIMD = share of SIMD cycles issuing VALU)"},
+            "host_timers_s": head[2]["host_timers_s"],
         }
         if dt4k is not None:
-            out["value_4k"] = round(world * args.steps * W4 * H4 / 1e6 / dt4k, 4)
-            out["ms_per_step_4k"] = round(dt4k / args.steps * 1e3, 2)
-            out["config_4k"] = {"workload": f"single {W4}x{H4} sRGB image, --quality {quality:g} (BASELINE "
-                                            "configs[2]), whole guetzli::Process per step, 1 image per GPU "
-                                            f"per step; {args.steps} timed steps after {args.warmup} warm-up, "
-                                            "bracketed like `value`",
-                                "steps": args.steps, "warmup": args.warmup, "output_bytes": len(jpg4k),
-                                "output_sha256_matches_reference": not emu,
-                                "iterations": info4k["counters"].get("number of iterations"),
-                                "host_timers_s": {k: round(v, 3) for k, v in info4k["timers"].items()
-                                                  if k in timer_keys}}
+            out["value_1080p"] = v_small
+            out["ms_per_step_1080p"] = ms_small
+            out["config_1080p"] = cfg_small
+            out["roofline_1080p"] = roof_small
         if c5 is not None:
             other = dict(other or {})
             other["config5_slice"] = c5

@@ -38,6 +38,18 @@ def _newer_than_lib():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def csrc_digest():
+    """SHA-256 over the kernel sources (csrc/ files in name order): what a profile under
+    profiles/ was measured on.  bench.py refuses a committed traffic figure whose digest is not
+    the tree's (the GPU box's snapshot has no .git to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(f.encode() + b"\0")
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 def hipcc_path():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

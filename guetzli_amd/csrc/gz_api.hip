@@ -535,8 +535,17 @@ void set_frame(gz_ctx* c, int factor) {
   c->coff[2] = c->nb + c->nbc;
   c->nblk = c->nb + 2 * c->nbc;
   c->have_search = false;
-  c->order_pending = false;   // a pending gz_order_build_auto_begin belonged to the old frame
+  // whatever was pending or kept belonged to the old frame: a stale gz_order_build_auto_end /
+  // gz_order_descend_end / gz_compare_end / gz_jpeg_scan_end must fail, not return its data
+  c->order_pending = false;
   c->results_in_desc = false;
+  c->desc_pending = false;
+  c->distance_in_desc = false;
+  c->compare_pending = false;
+  c->scan_pending = false;
+  c->have_distmap = false;
+  c->have_scan = false;
+  c->export_epoch = 0;
 }
 size_t csamp_plane(const gz_ctx* c) {   // bytes of one chroma sample plane of a 4:2:0 frame
   return (size_t)((c->w + 15) / 16 * 8) * (size_t)((c->h + 15) / 16 * 8);
@@ -1909,11 +1918,14 @@ static int order_auto_enqueue(gz_ctx* c, int direction, int max_block_dist, doub
   TRY(ensure_order_capacity(c, std::max<size_t>(c->search_total, 1)));   // also: the counters
   {
     // With a Compare chain in flight on the main stream (gz_order_build_auto_begin) the upload
-    // takes the entropy stream, idle at this point, and the main stream waits for its event: the
-    // copy then runs beside the chain's first kernels instead of between its last kernel and the
-    // order's first (15-20 us of the critical path of every phase-B iteration).  Nothing on the
-    // main stream reads d_next_cand before the order's kernels.
-    hipStream_t up = c->compare_pending ? c->entropy_stream : c->stream;
+    // takes side stream 1 -- behind the chain's short SameNoise / radius-5 branch there, long before
+    // Malta ends on the main stream -- and the main stream waits for its event: the copy then runs
+    // beside the chain instead of between its last kernel and the order's first (15-20 us of the
+    // critical path of every phase-B iteration).  NOT the entropy stream: the driver queues the
+    // candidate's whole scan there (gz_jpeg_scan_begin) before it asks for the order, and the
+    // order, the descent and the distance that arrives with them would wait for the coder
+    // (ADVICE r3).  Nothing on the main stream reads d_next_cand before the order's kernels.
+    hipStream_t up = c->compare_pending ? c->side_stream : c->stream;
     void* h = nullptr;
     TRY(stage_reserve(c, &c->stage_main, sizeof(int) * nb, &h));
     memcpy(h, next_cand, sizeof(int) * nb);
@@ -2356,6 +2368,11 @@ int gz_order_descend_end(gz_ctx* c, uint64_t* log, int cap_levels, int* levels, 
   c->desc_pending = false;
   TRY(descend_collect(c, log, cap_levels, levels));
   if (*levels > 0) *last = c->h_desc[0].last;
+#ifdef GZ_EMU
+  // test hook of the emulation build only (tests/test_host_encoder.py): a device that derived
+  // another position than the host -- the driver's guard must refuse the rearranged order
+  if (*levels > 0 && getenv("GZ_EMU_SKEW_DESCENT")) *last += 10;
+#endif
   return GZ_OK;
 }
 

@@ -94,13 +94,20 @@ GZ_DEVFN gz_f2 gz_f2_splat(float x) {
 
 // A point where the lanes of a wavefront must have executed everything before it (loads
 // before a store to the same LDS row by a neighbouring lane).  On the GPU a wavefront has one
-// instruction stream, so there is nothing to do; the emulation's threads are fibers that run one
-// after the other and yield here (every thread of the workgroup must pass the same number of
-// these points).
+// instruction stream, so no instruction is needed -- but the COMPILER must keep every LDS access
+// on its side of the point (a load it can prove not to alias an earlier store of the same thread
+// may otherwise sink below it, and a neighbouring lane would read the overwritten value: ADVICE
+// r3): a wavefront-scope fence + wave barrier, which emit nothing.  The emulation's threads are
+// fibers that run one after the other and yield here (every thread of the workgroup must pass the
+// same number of these points).
 #ifdef GZ_EMU
 #define GZ_WAVE_LOCKSTEP() hipemu::yield()
 #else
-#define GZ_WAVE_LOCKSTEP() ((void)0)
+#define GZ_WAVE_LOCKSTEP()                                  \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                        \
+  } while (0)
 #endif
 
 // Lanes of ONE wavefront exchanging data through LDS (a wavefront's LDS operations execute in

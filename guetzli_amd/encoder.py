@@ -71,6 +71,8 @@ class HostLibrary:
             # from the frame header's dimensions (a heavily compressed input re-encoded at a high
             # quality can be many times its own size; a second call would repeat the whole search)
             jw, jh = _jpeg_dimensions(data)
+            if jw * jh > (1 << 28):   # a header nobody has validated yet (65535 x 65535 = 12.9 GB):
+                jw = jh = 0           # start small, the grow-and-retry path covers a real giant
             cap = max(3 * jw * jh + (1 << 16), 4 * len(data), 1 << 20)
         else:
             cap = 3 * w * h + (1 << 16)

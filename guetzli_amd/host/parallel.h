@@ -1,8 +1,12 @@
 // A small persistent worker pool for the host search driver's O(candidates) passes (building
 // and partitioning the global candidate order of phase B).  The reference is single-threaded;
 // every pass parallelised here produces exactly the sequence its serial form produces.
-// GZ_HOST_THREADS overrides the worker count (default: min(16, hardware threads)).
+// GZ_HOST_THREADS overrides the worker count (default: min(16, the cores this PROCESS may run on:
+// sched_getaffinity, not hardware_concurrency -- one process per GPU keeps to its share of the
+// host cores, bench.py's Env.bind_cpus, and a pool sized for the whole machine would put 8 x 16
+// workers on a node with few cores per GPU).
 #pragma once
+#include <sched.h>
 #include <condition_variable>
 #include <cstdlib>
 #include <functional>
@@ -49,9 +53,20 @@ class WorkerPool {
     fn_ = nullptr;
   }
 
+  // Cores the calling process may be scheduled on (its affinity mask at the pool's creation).
+  static int AllowedCpus() {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+      int n = CPU_COUNT(&set);
+      if (n > 0) return n;
+    }
+    return (int)std::thread::hardware_concurrency();
+  }
+
  private:
   WorkerPool() {
-    int n = (int)std::thread::hardware_concurrency();
+    int n = AllowedCpus();
     if (n <= 0) n = 1;
     if (n > 16) n = 16;
     if (const char* e = getenv("GZ_HOST_THREADS")) n = atoi(e) > 0 ? atoi(e) : n;

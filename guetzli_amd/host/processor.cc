@@ -1474,6 +1474,10 @@ double gzh_butteraugli_score_for_quality(double q) {
   return guetzli_amd::ButteraugliScoreForQuality(q);
 }
 
+// Threads of the driver's worker pool (the calling thread included): min(16, cores the process may
+// run on), GZ_HOST_THREADS overrides.  Test hook for the per-rank core share of a multi-GPU run.
+int gzh_worker_pool_size() { return guetzli_amd::WorkerPool::Get().size(); }
+
 // ReadJpeg as a canonical dump (test hook; oracle/ref_harness.cc writes the same format from
 // the reference's JPEGData): int32 w, h, ncomp; per component id, h_samp, v_samp, quant_idx,
 // width_in_blocks, height_in_blocks; int32 nquant; per table index, precision, 64 values;

@@ -40,16 +40,53 @@ def test_bench_main_two_ranks_gloo():
         assert k in r, k
     assert r["n_gpus"] == 2 and r["steps"] == 1 and r["scaling"] == "weak" and r["vs_baseline"] is None
     assert r["value"] > 0 and r["ms_per_step"] > 0 and r["higher_is_better"] is True
-    assert r["value_4k"] > 0 and r["ms_per_step_4k"] > 0 and r["config_4k"]["steps"] == 1
-    for key in ("roofline", "roofline_4k"):
+    assert r["value_1080p"] > 0 and r["ms_per_step_1080p"] > 0 and r["config_1080p"]["steps"] == 1
+    assert "configs[2]" in r["config"]["workload"] and "configs[1]" in r["config_1080p"]["workload"]
+    for key in ("roofline", "roofline_1080p"):
         assert r[key]["bound"] == "hbm" and r[key]["peak"] == 8000.0
         assert abs(r[key]["frac"] - r[key]["achieved"] / r[key]["peak"]) < 1e-3
     c5 = r["other_configs"]["config5_slice"]
     assert c5["images"] == 2 * c5["images_per_gpu"] and c5["distinct_outputs"] == c5["images"]
     assert r["scale_value"] == c5["value"]
+    assert c5["n_ranks_seen"] == 2 and c5["ranks_in_records"] == [0, 1]
+    assert c5["images_per_rank"] == {"0": c5["images_per_gpu"], "1": c5["images_per_gpu"]}
     assert "cpu_baseline" not in r and "batch_one_gpu" not in r   # N = 1 only
 
 
 def test_bench_config5_only_two_ranks_gloo():
     r = _run(2, ["--config5", "--images-per-gpu", "1"])
     assert r["n_gpus"] == 2 and r["config"]["images"] == 2 and r["value"] == r["config"]["value"]
+
+
+def test_worker_pool_is_sized_from_the_affinity_mask():
+    """A rank bound to two cores gets a two-thread pool, whatever the machine has (VERDICT r3:
+    std::thread::hardware_concurrency ignores the mask Env.bind_cpus sets)."""
+    from guetzli_amd import build as gzbuild
+    lib = gzbuild.build_host()
+    code = f"import ctypes; print(ctypes.CDLL({lib!r}).gzh_worker_pool_size())"
+    env = {k: v for k, v in os.environ.items() if k != "GZ_HOST_THREADS"}
+    two = subprocess.run(["taskset", "-c", "0-1", sys.executable, "-c", code], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert two.returncode == 0, two.stderr
+    assert int(two.stdout) == 2
+    one = subprocess.run(["taskset", "-c", "0", sys.executable, "-c", code], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert int(one.stdout) == 1
+
+
+def test_bench_two_ranks_on_two_cores_finishes():
+    """The multi-GPU launch on a box with ONE host core per rank ("one core per GPU
+    on this box"): `taskset -c 0-1` around the world-2 dry run of config 5 -- every rank binds to
+    its single core, sizes its pool from it, and the run completes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build_host()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    cmd = ["taskset", "-c", "0-1", sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29543",
+           os.path.join(ROOT, "bench.py"), "--emulate", "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--config5", "--images-per-gpu", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["config"]["n_ranks_seen"] == 2 and r["config"]["host_cores_per_rank"] == 1

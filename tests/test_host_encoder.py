@@ -85,6 +85,21 @@ def test_whole_encode_matches_reference_in_emulation(host_emu, case, monkeypatch
     assert info["counters"]["number of iterations"] >= 3
 
 
+def test_descent_position_mismatch_aborts_the_encode(host_emu, monkeypatch, capfd):
+    """The device rearranges the order along ITS derivation of the descent position; the host
+    replays the logged partitions along its own.  If the two ever disagreed the array would no
+    longer be what LazySorted believes -- the driver must fail, not emit other bytes.
+    GZ_EMU_SKEW_DESCENT (emulation build only) makes gz_order_descend_end report another position."""
+    monkeypatch.setenv("GZ_ORDER_DEVICE_THRESHOLD", "128")
+    rgb = images.crop(40, 32, 100, 60)
+    _, info = host_emu.process(rgb, quality=95)
+    assert info["counters"]["phase B partitions made ahead"] > 0      # the guard is on this path
+    monkeypatch.setenv("GZ_EMU_SKEW_DESCENT", "1")
+    with pytest.raises(RuntimeError):
+        host_emu.process(rgb, quality=95)
+    assert "gz_order_descend: position" in capfd.readouterr().err
+
+
 @needs_ref
 @pytest.mark.parametrize("case", [
     ("flat", (0, 0, 0), 40, 32, 95, {}), ("flat", (255, 255, 255), 33, 35, 95, {"try_420": True}),

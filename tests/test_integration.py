@@ -152,3 +152,80 @@ def test_patched_reference_processor_with_the_batched_hook_bees(kw, golden):
     assert calls[1] == 0 and calls[2] >= 1
     print(f"patched reference Processor + batched hook, bees {kw}: {dt:.2f} s")
     assert dt < 3.0, dt
+
+
+# ---- the whole-Process seam: the UNMODIFIED front end guetzli/guetzli.cc over this repository ----
+def _make_cli(host_lib, out):
+    if os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-s", "-C", os.path.join(HERE, "integration"), "cli",
+                        f"HOST_LIB={host_lib}", f"CLI={out}"], check=True)
+    return os.path.exists(out)
+
+
+def _png(rgb):
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(rgb).save(b, "PNG")
+    return b.getvalue()
+
+
+def _cli(exe, args, data, tmp_path, suffix=".png"):
+    """`guetzli [flags] in out` -> (return code, output bytes or None, stderr text)."""
+    src, dst = tmp_path / ("in" + suffix), tmp_path / "out.jpg"
+    src.write_bytes(data)
+    if dst.exists():
+        dst.unlink()
+    r = subprocess.run([exe] + list(args) + [str(src), str(dst)], capture_output=True, timeout=1200)
+    return r.returncode, (dst.read_bytes() if dst.exists() else None), r.stderr.decode()
+
+
+@pytest.mark.skipif(ref is None, reason="oracle/_ref/libgz_ref.so not built")
+def test_unmodified_front_end_over_the_drop_in_process_in_emulation(tmp_path):
+    """guetzli/guetzli.cc compiled UNCHANGED, guetzli::Process (both overloads, processor.h:39-41,
+    54-56) supplied by tests/integration/process_adapter.cc -> guetzli_amd::Process: PNG and JPEG
+    input, --quality, --verbose (the reference's trace on stderr), the front end's own refusals."""
+    import build_emu
+    exe = os.path.join(BUILD, "guetzli_emu")
+    if not _make_cli(build_emu.build_host(), exe):
+        pytest.skip("tests/integration/_build not built (needs /root/reference)")
+    rgb = images.crop(40, 32, 100, 60)
+    for q in (95, 84):
+        exp_jpg, exp_trace = ref.process(rgb, ref._butteraugli_score_for_quality(float(q)), want_trace=True)
+        rc, got, err = _cli(exe, ["--verbose", "--quality", str(q)], _png(rgb), tmp_path)
+        assert rc == 0, err
+        assert got == exp_jpg
+        assert err == exp_trace
+    # JPEG input goes through the other overload
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(images.crop(48, 40, 30, 20)).save(b, "JPEG", quality=97, subsampling=0)
+    exp_jpg, _ = ref.process_jpeg(b.getvalue(), ref._butteraugli_score_for_quality(95.0))
+    rc, got, err = _cli(exe, [], b.getvalue(), tmp_path, ".jpg")
+    assert rc == 0 and got == exp_jpg, err
+    # the front end's own checks still guard the call (guetzli.cc:286-292)
+    rc, got, err = _cli(exe, ["--memlimit", "1"], _png(rgb), tmp_path)
+    assert rc == 1 and got is None and "Memory limit would be exceeded" in err
+    rc, got, err = _cli(exe, [], b"\x89PNG\r\n\x1a\nnot a png", tmp_path)
+    assert rc == 1 and got is None and "Error reading PNG data" in err
+
+
+@pytest.mark.gpu
+def test_unmodified_front_end_over_the_drop_in_process_bees(tmp_path):
+    """`guetzli_hip tests/bees.png out.jpg` (BASELINE configs[0] as the reference's golden test
+    runs it, tests/golden_test.sh): the golden JPEG; --quality 84; --verbose = the reference's
+    trace, byte for byte, on stderr."""
+    from guetzli_amd import build as gzbuild
+    exe = os.path.join(BUILD, "guetzli_hip")
+    if not _make_cli(gzbuild.HOST_LIB, exe):
+        pytest.skip("tests/integration/_build not built (needs /root/reference)")
+    data = open(images.BEES, "rb").read()
+    rc, jpg, err = _cli(exe, [], data, tmp_path)
+    assert rc == 0, err
+    assert hashlib.sha256(jpg).hexdigest() == "f2673f12a4856e020627fa151493a80b1cb2ee4dc81e28afc62dc089baf50242"
+    rc, jpg, err = _cli(exe, ["--quality", "84"], data, tmp_path)
+    assert rc == 0 and hashlib.sha256(jpg).hexdigest() == "95f509f457ce8ddd85087c804664539e0ef7b1f3a6c6ca1cbedcd9ba29a89379"
+    rc, jpg, err = _cli(exe, ["--verbose"], data, tmp_path)
+    assert rc == 0 and hashlib.sha256(jpg).hexdigest() == "f2673f12a4856e020627fa151493a80b1cb2ee4dc81e28afc62dc089baf50242"
+    assert hashlib.sha256(err.encode()).hexdigest() == "954ec7623366bc3c345fc5b0748017f9a5e0128aba0917a249cca390a615f787"

@@ -63,6 +63,10 @@ def main():
             cal.setdefault(r["kernel"], {})[r["counter"]] = float(r["avg_value"])
     out["calibration"] = cal
     out["head"] = repo_head()
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from guetzli_amd.build import csrc_digest
+    out["csrc_sha256"] = csrc_digest()      # bench.py: a figure measured on other kernel sources is stale
     print(json.dumps(out, indent=1))
 
 

@@ -120,6 +120,11 @@ struct gz_ctx {
   std::vector<std::pair<int, float> > order;
   std::vector<float> max_err, weight;
   std::string err;
+  // GZ_REPLAY_DIRTY_LOG: blocks whose coefficients changed since the last evaluation (analysis of
+  // an incremental Compare, tools/dirty_tiles.py)
+  std::vector<unsigned char> dirty;
+  bool all_dirty = true;
+  int evals = 0;
 };
 
 namespace {
@@ -211,6 +216,7 @@ int gz_encode_rgb(gz_ctx* c, int16_t* coeffs_out) {
 }
 
 int gz_quantize(gz_ctx* c, const int* q, int16_t* coeffs_out) {
+  c->all_dirty = true;
   if (c->inner) return real()->quantize(c->inner, q, coeffs_out);
   if (!coeffs_out) return GZ_OK;
   const size_t per = (size_t)c->nb * 64;
@@ -225,7 +231,45 @@ int gz_quantize(gz_ctx* c, const int* q, int16_t* coeffs_out) {
   return GZ_OK;
 }
 
+
+// ---- dirty-tile statistics (GZ_REPLAY_DIRTY_LOG=path): what fraction of the image a Compare that
+// recomputed only what a changed block can reach would have to touch.  A block reaches the pixels
+// within HALO of it: opsin blur 2 + LF 16 + MF 8 + HF 4 + mask pre 1 + mask blur 20 (SameNoise: 23)
+// + final blur 3 = 54..56 (butteraugli.cc:184-233,489-622,1699-1817).
+static void dirty_mark(gz_ctx* c, int block) {
+  if (c->dirty.empty()) c->dirty.assign(c->nb, 0);
+  if (block >= 0 && block < c->nb) c->dirty[block] = 1;
+}
+static void dirty_report(gz_ctx* c) {
+  const char* path = getenv("GZ_REPLAY_DIRTY_LOG");
+  if (!path) return;
+  if (c->dirty.empty()) c->dirty.assign(c->nb, 0);
+  const int HALO = 56, TW = 64, TH = 32;
+  const int tw = (c->w + TW - 1) / TW, th = (c->h + TH - 1) / TH;
+  std::vector<unsigned char> tile(tw * th, 0);
+  long nd = 0;
+  for (int by = 0; by < c->bh; ++by)
+    for (int bx = 0; bx < c->bw; ++bx) {
+      if (!c->all_dirty && !c->dirty[by * c->bw + bx]) continue;
+      ++nd;
+      const int x0 = std::max(0, bx * 8 - HALO) / TW, x1 = std::min(c->w - 1, bx * 8 + 7 + HALO) / TW;
+      const int y0 = std::max(0, by * 8 - HALO) / TH, y1 = std::min(c->h - 1, by * 8 + 7 + HALO) / TH;
+      for (int ty = y0; ty <= y1; ++ty) memset(&tile[ty * tw + x0], 1, x1 - x0 + 1);
+    }
+  long nt = 0;
+  for (unsigned char t : tile) nt += t;
+  FILE* f = fopen(path, "a");
+  if (f) {
+    fprintf(f, "%d %ld %d %ld %d\n", c->evals, nd, c->nb, nt, tw * th);
+    fclose(f);
+  }
+  ++c->evals;
+  c->all_dirty = false;
+  std::fill(c->dirty.begin(), c->dirty.end(), 0);
+}
+
 int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
+  dirty_report(c);
   if (distmap) { fprintf(stderr, "gz_replay: distmap download is not logged\n"); abort(); }
   c->bmax.resize(c->nb);
   if (c->inner) {
@@ -246,7 +290,10 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
 
 // The split form: in record mode the evaluation really runs between the two calls; the log
 // entry (distance + block maxima, as for gz_compare) is written / read at _end.
-int gz_compare_begin(gz_ctx* c) { return c->inner ? real()->compare_begin(c->inner) : GZ_OK; }
+int gz_compare_begin(gz_ctx* c) {
+  dirty_report(c);
+  return c->inner ? real()->compare_begin(c->inner) : GZ_OK;
+}
 int gz_compare_end(gz_ctx* c, float* distance) {
   c->bmax.resize(c->nb);
   if (c->inner) {
@@ -367,6 +414,7 @@ int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
 }
 
 int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int n) {
+  for (int i = 0; i < n; ++i) dirty_mark(c, (pos[i] / 64) % c->nb);
   if (c->inner) return real()->apply_coeff_edits(c->inner, pos, val, n);
   for (int i = 0; i < n; ++i)
     if (pos[i] < 0 || pos[i] >= 3 * c->nb * 64) return GZ_E_ARG;
@@ -395,6 +443,7 @@ int gz_encode_rgb_only(int device, const uint8_t* rgb, int w, int h, int16_t* co
 
 int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
                              const int32_t* counts, int n) {
+  for (int i = 0; i < n; ++i) if (counts[i] > 0) dirty_mark(c, blocks[i]);
   if (c->inner) return real()->apply_candidate_steps(c->inner, direction, blocks, counts, n);
   return GZ_OK;   // the host driver keeps its own mirror of the image; nothing to replay
 }
@@ -451,6 +500,7 @@ int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
 }
 
 int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int16_t* blocks) {
+  for (int i = 0; i < n; ++i) dirty_mark(c, block_index[i]);
   if (c->inner) return real()->set_coeff_blocks(c->inner, block_index, n, blocks);
   for (int i = 0; i < n; ++i)
     if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Merged timeline (HIP API calls on the host, kernels and copies on the device) of phase-B
-# iterations of one 1080p encode.  Usage: gpu_trace_full.sh TAG
+# iterations of one encode.  Usage: gpu_trace_full.sh TAG [W H]   (default 1920 1080)
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/${1:-trf}; mkdir -p $O
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python $GRAFT_REPO_ROOT/tools/encode_time.py 1920 1080 95 x 2 ) > $O/trace.log 2>&1
+W=${2:-1920}; H=${3:-1080}
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python $GRAFT_REPO_ROOT/tools/encode_time.py $W $H 95 x 2 ) > $O/trace.log 2>&1
 tail -2 $O/trace.log
 python3 - $O/trace <<'PY' | tee $O/timeline_full.txt
 import csv, sys, glob, os

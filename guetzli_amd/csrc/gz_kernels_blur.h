@@ -999,9 +999,9 @@ __global__ __launch_bounds__(256) void k_blur_stream(SrcPack<Src, NC> src, Post 
     for (int k = 1; k < NC; ++k)
       if ((ZCH ? bid.z : c) == k) s[c] = src.s[k];
   }
-  gz_f4 pre[NCL][NVT];
+  gz_f4 preA[NCL][NVT], preB[NCL][NVT];
   // loads of input block t (rows ys - R + t SG ...), fast path: into registers
-  auto prefetch = [&](int t) {
+  auto prefetch = [&](int t, gz_f4 (&pre)[NCL][NVT]) {
     const int yin = ys - R + t * SG;
 #pragma unroll
     for (int c = 0; c < NCL; ++c) {
@@ -1019,12 +1019,17 @@ __global__ __launch_bounds__(256) void k_blur_stream(SrcPack<Src, NC> src, Post 
       }
     }
   };
-  if (xin) prefetch(0);
+  // two blocks ahead: block t + 2 is requested when block t's samples have left their registers, so
+  // that a block's loads have two steps of arithmetic to arrive in (one step is less than the
+  // memory latency of a chip whose workgroups all march in step)
+  if (xin) {
+    prefetch(0, preA);
+    if (steps > 1) prefetch(1, preB);
+  }
   const int hr = tid >> 4, hq = (tid & 15) * 4;            // row pass: row of the block, first column
   const int tx = tid & 63;                                // column pass: lane = column
   const int tg = GZ_WAVE_UNIFORM(tid >> 6);               // ... wave = group of 4 rows
-#pragma unroll 1
-  for (int t = 0; t < steps; ++t) {
+  auto step = [&](int t, gz_f4 (&pre)[NCL][NVT]) {
     const int yin = ys - R + t * SG;
     // ---- 1. the block's samples into LDS
     if (xin) {
@@ -1052,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(SrcPack<Src, NC> src, Post 
       }
     }
     __syncthreads();
-    if (xin && t + 1 < steps) prefetch(t + 1);   // in flight during the passes below
+    if (xin && t + 2 < steps) prefetch(t + 2, pre);   // in flight during this step and the next
     // ---- 2. row pass of the block into its ring block
     const int rb = (t % (RING / SG)) * SG;       // ring row of the block's first row
 #pragma unroll
@@ -1169,6 +1174,11 @@ __global__ __launch_bounds__(256) void k_blur_stream(SrcPack<Src, NC> src, Post 
       }
     }
     __syncthreads();   // the next step overwrites the stage and the oldest ring block
+  };
+#pragma unroll 1
+  for (int t = 0; t < steps; t += 2) {
+    step(t, preA);
+    if (t + 1 < steps) step(t + 1, preB);
   }
 }
 

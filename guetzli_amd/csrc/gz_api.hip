@@ -390,11 +390,6 @@ struct gz_ctx {
   // gz_compare_begin has put on the main stream: both only read the candidate coefficients
   hipStream_t entropy_stream = nullptr;
   hipEvent_t ev_candidate = nullptr;   // main stream: the candidate is in place
-  // main stream, inside a Compare chain: Malta has been passed / the chain's last kernel has.
-  // The candidate's entropy coding waits for one of them (gz_jpeg_scan_begin): beside the band
-  // splitting and Malta its kernels take the issue slots the chain is short of, beside the order's
-  // construction and descent -- small dependent launches -- they are free.
-  hipEvent_t ev_malta_done = nullptr, ev_chain_done = nullptr;
   std::string err;
 
   uint8_t* d_rgb = nullptr;
@@ -734,51 +729,6 @@ int blur_v_pair(gz_ctx* c, const CPlanePack<2>& src, const PostStore<2>& post, c
   return GZ_OK;
 }
 
-// Streaming row + column pass for the radii >= 16 (k_blur_stream): one launch per blur, no
-// intermediate plane.  Segment height: enough workgroups to fill the chip (256 CUs x 4-6 resident
-// workgroups) against the 2R warm-up rows every segment repeats.  GZ_BLUR_STREAM=0 selects the
-// separate passes (read per call: the tests run both), GZ_STREAM_SEG=<rows> forces a height.
-static bool stream_blur(const gz_ctx* c) {
-  (void)c;
-  const char* e = getenv("GZ_BLUR_STREAM");
-  return !e || atoi(e) != 0;
-}
-static int stream_seg_rows(const gz_ctx* c, int planes_z) {
-  if (const char* e = getenv("GZ_STREAM_SEG")) {
-    const int v = atoi(e);
-    if (v >= SG) return (v + SG - 1) / SG * SG;
-  }
-  const int strips = gz_div_up(c->w, SSW) * planes_z;
-  int segs = gz_div_up(1024, strips);
-  const int max_segs = std::max(1, c->h / 96);      // at least 96 rows per segment
-  segs = std::max(1, std::min(segs, max_segs));
-  return (gz_div_up(c->h, segs) + SG - 1) / SG * SG;
-}
-template <int R, int NC, class Src, class Post>
-int blur_stream(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurCfg& cfg) {
-  if (cfg.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
-  const Taps<R> tp = taps_of<R>(cfg);
-  const int seg = stream_seg_rows(c, 1);
-  dim3 grid(gz_div_up(c->w, SSW), gz_div_up(c->h, seg));
-  GZ_LAUNCH((k_blur_stream<R, NC, Src, Post>), grid, dim3(256), c->stream, src, post, c->w, c->h, c->pitch, seg,
-            tp, cfg.bx, cfg.by, tp, cfg.bx, cfg.by);
-  KCHK(c);
-  return GZ_OK;
-}
-// ... two independent planes with their own taps in one launch (grid z = plane)
-template <int R, class Src>
-int blur_stream_pair(gz_ctx* c, const SrcPack<Src, 2>& src, const PostStore<2>& post, const BlurCfg& cfg0,
-                     const BlurCfg& cfg1) {
-  if (cfg0.r != R || cfg1.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
-  const Taps<R> t0 = taps_of<R>(cfg0), t1 = taps_of<R>(cfg1);
-  const int seg = stream_seg_rows(c, 2);
-  dim3 grid(gz_div_up(c->w, SSW), gz_div_up(c->h, seg), 2);
-  GZ_LAUNCH((k_blur_stream<R, 2, Src, PostStore<2>, true>), grid, dim3(256), c->stream, src, post, c->w, c->h,
-            c->pitch, seg, t0, cfg0.bx, cfg0.by, t1, cfg1.bx, cfg1.by);
-  KCHK(c);
-  return GZ_OK;
-}
-
 template <int R, int NC, class Src, class Post, bool BM = false>
 int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurCfg& cfg,
            BlockMaxOut bm = BlockMaxOut{nullptr, nullptr, 0}) {
@@ -896,30 +846,7 @@ int stage_opsin(gz_ctx* c) {
 // the distance-map plane, which nothing else touches before the chain's last kernel.
 int stage_separate(gz_ctx* c, Psycho* ps, bool split_b = false) {
   static const bool split_off = getenv("GZ_LF_SPLIT") && atoi(getenv("GZ_LF_SPLIT")) == 0;
-  if (stream_blur(c)) {
-    // LF by the streaming kernel: X / Y on this stream, B (read by k_combine only; its Post
-    // functor reads the raw LF of Y the first launch wrote) behind it -- on side stream 2 when the
-    // caller joins that stream before k_combine, else here
-    {
-      SrcPack<SrcPlain, 2> s;
-      for (int i = 0; i < 2; ++i) s.s[i].p = c->xyb[i];
-      PostLFxy post;
-      for (int i = 0; i < 2; ++i) { post.lf_raw[i] = c->lf_raw[i]; post.lf_vals[i] = ps->lfv[i]; }
-      TRY((blur_stream<16, 2, SrcPlain, PostLFxy>(c, s, post, c->blur[B_LF])));
-    }
-    const bool side = split_b && !split_off;
-    hipStream_t main_stream = c->stream;
-    if (side) {
-      HIPCHK(c, hipEventRecord(c->ev_lfy, c->stream));
-      HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_lfy, 0));
-      c->stream = c->side_stream2;
-    }
-    SrcPack<SrcPlain, 1> s; s.s[0].p = c->xyb[2];
-    PostLFb post; post.lf_raw_y = c->lf_raw[1]; post.lf_vals_b = ps->lfv[2];
-    const int rc = blur_stream<16, 1, SrcPlain, PostLFb>(c, s, post, c->blur[B_LF]);
-    c->stream = main_stream;
-    TRY(rc);
-  } else if (split_b && !split_off) {
+  if (split_b && !split_off) {
     HIPCHK(c, hipEventRecord(c->ev_xyb, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_xyb, 0));
     hipStream_t main_stream = c->stream;
@@ -1009,12 +936,7 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
   // per pass for the two (GZ_MASK_PAIR=0, or the unrolled column kernels: one blur after the other)
   static const bool pair_off = getenv("GZ_MASK_PAIR") && atoi(getenv("GZ_MASK_PAIR")) == 0;
   const bool pair = !pair_off && (packed_blur(c) || compact_code(c, "GZ_COMPACT_BLUR_V"));
-  if (stream_blur(c)) {
-    SrcPack<SrcPlain, 2> s;
-    s.s[0].p = c->diffx; s.s[1].p = c->diffy;
-    PostStore<2> post; post.out[0] = c->mxb; post.out[1] = c->myb2;
-    TRY((blur_stream_pair<20, SrcPlain>(c, s, post, c->blur[B_MASKX], c->blur[B_MASKY1])));
-  } else if (pair) {
+  if (pair) {
     SrcPack<SrcPlain, 2> s; PlanePack<2> t; CPlanePack<2> ct;
     s.s[0].p = c->diffx; s.s[1].p = c->diffy;
     t.p[0] = c->tmp[1]; t.p[1] = c->tmp[2];
@@ -1038,7 +960,7 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
     c->stream = here;
     TRY(rc);
   }
-  if (!pair && !stream_blur(c)) {
+  if (!pair) {
     SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].p = c->diffy; t.p[0] = c->tmp[2]; ct.p[0] = c->tmp[2];
     TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKY1])));
@@ -1079,13 +1001,9 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
     SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].a = p0.hf[1]; s.s[0].b = p1.hf[1];
     t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    TRY((blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN])));
     PostStore<1> post; post.out[0] = c->snb;
-    if (stream_blur(c)) {
-      TRY((blur_stream<23, 1, SrcSameNoise, PostStore<1>>(c, s, post, c->blur[B_SN])));
-    } else {
-      TRY((blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN])));
-      TRY((blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN])));
-    }
+    TRY((blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN])));
     return stage_mask_blurs(c, mask_pack_psycho(c, p0, p1));
   }
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -1098,13 +1016,9 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
     SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].a = p0.hf[1]; s.s[0].b = p1.hf[1];
     t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
+    rc = blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN]);
     PostStore<1> post; post.out[0] = c->snb;
-    if (stream_blur(c)) {
-      rc = blur_stream<23, 1, SrcSameNoise, PostStore<1>>(c, s, post, c->blur[B_SN]);
-    } else {
-      rc = blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN]);
-      if (rc == GZ_OK) rc = blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN]);
-    }
+    if (rc == GZ_OK) rc = blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN]);
   }
   c->stream = c->side_stream;
   static const bool split = !(getenv("GZ_MASK_SPLIT") && atoi(getenv("GZ_MASK_SPLIT")) == 0);
@@ -1153,7 +1067,6 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
   else
     GZ_LAUNCH((k_malta_rolled<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);
-  HIPCHK(c, hipEventRecord(c->ev_malta_done, c->stream));
   TRY(join_mask_branch(c));
   {
     CombineArgs a;
@@ -1182,7 +1095,6 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     BlockMaxOut bm{want_block_max ? c->d_block_max : nullptr, c->d_max_bits, c->bw};
     TRY((blur2d<3, 1, SrcPlain, PostDiffmapMix, true>(c, s, post, c->blur[B_FINAL], bm)));
   }
-  HIPCHK(c, hipEventRecord(c->ev_chain_done, c->stream));
   return GZ_OK;
 }
 
@@ -1479,8 +1391,6 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   CHK0(pool_stream_create(&c->side_stream2));
   CHK0(pool_stream_create(&c->entropy_stream, 0));   // (never below default: see above)
   CHK0(pool_event_create(&c->ev_candidate));
-  CHK0(pool_event_create(&c->ev_malta_done));
-  CHK0(pool_event_create(&c->ev_chain_done));
   CHK0(pool_event_create(&c->ev_fork));
   CHK0(pool_event_create(&c->ev_join));
   CHK0(pool_event_create(&c->ev_join2));
@@ -1594,8 +1504,6 @@ void gz_destroy(gz_ctx* c) {
   if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); pool_stream_destroy(c->side_stream2); }
   if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); pool_stream_destroy(c->entropy_stream, 0); }
   pool_event_destroy(c->ev_candidate);
-  pool_event_destroy(c->ev_malta_done);
-  pool_event_destroy(c->ev_chain_done);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
   if (c->h_res) (void)pool_host_free(c->h_res);
@@ -2550,17 +2458,6 @@ int gz_jpeg_scan_begin(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_
   hipStream_t es = c->entropy_stream;
   if (!c->compare_pending) HIPCHK(c, hipEventRecord(c->ev_candidate, c->stream));
   HIPCHK(c, hipStreamWaitEvent(es, c->ev_candidate, 0));
-  if (c->compare_pending) {
-    // ... and, with an evaluation in flight (gz_compare_begin), behind its heavy part: the coder
-    // then runs beside the chain's tail and the next order's construction and descent instead of
-    // beside the band splitting and Malta, whose time it stretched by a quarter (4K: the MF blur
-    // 96 -> 363 us with k_jpeg_block_bits / k_jpeg_emit next to it, profiles/r04_*timeline*).
-    // GZ_SCAN_AFTER = 0: behind the candidate only (until round 3), 1: behind Malta (default),
-    // 2: behind the chain's last kernel.
-    static const int after = getenv("GZ_SCAN_AFTER") ? atoi(getenv("GZ_SCAN_AFTER")) : 1;
-    if (after == 1) HIPCHK(c, hipStreamWaitEvent(es, c->ev_malta_done, 0));
-    else if (after == 2) HIPCHK(c, hipStreamWaitEvent(es, c->ev_chain_done, 0));
-  }
   {
     void* h = nullptr;
     TRY(stage_reserve(c, &c->stage_entropy, 1536 + sizeof(unsigned short) * 1536, &h));
@@ -2703,10 +2600,6 @@ int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, f
     break;
 #define GZ_BLUR_CASE2(R)                                                    \
   case R:                                                                   \
-    if (stream_blur(c)) {                                                   \
-      rc = blur_stream<R, 1, SrcPlain, PostStore<1>>(c, s, post, cfg);      \
-      break;                                                                \
-    }                                                                       \
     rc = blur_h<R, SrcPlain, 1>(c, s, t, cfg);                              \
     if (rc == GZ_OK) rc = blur_v<R, 1, PostStore<1>>(c, ct, post, cfg);     \
     break;

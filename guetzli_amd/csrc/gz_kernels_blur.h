@@ -932,256 +932,6 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
   if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
 }
 
-// ------------------------------------------------- streaming row + column pass (radius >= 16) --
-// Blur = Convolution along x, then along y (butteraugli.cc:229-233) for the large radii, without
-// the intermediate plane and without vertical halo re-reads: a workgroup owns a strip of SSW = 64
-// output columns and a segment of `seg_rows` output rows and WALKS DOWN the image in steps of
-// SG = 16 rows.  Per step it
-//   1. stores the 16 input rows x (64 + 2 RA) columns it loaded during the step before into LDS
-//      (source functor applied; zero outside the image) and issues the loads of the next step,
-//      which stay in flight during everything below;
-//   2. row pass: a thread takes 4 consecutive outputs of one row from a register window of the
-//      staged samples (one 16-byte LDS read per 4 samples) and writes them into a RING of the last
-//      RING >= 2R + 16 row-pass results (RING a multiple of 16: a step fills one ring block);
-//   3. column pass from the ring: lane = column, 4 consecutive rows per thread from a window of
-//      4 + 2R ring rows -- the 16 output rows whose last input row has just arrived;
-//   4. hands the NC blurred values of every pixel to the Post functor (by quads through LDS with
-//      16-byte global accesses where the strip allows it).
-// Each output is computed with exactly the operations of the separate passes: f32, taps in
-// ascending order from 0.0f; interior samples use the pre-scaled taps, border samples the raw taps
-// and one multiply by the host-computed scale; samples outside the image are staged as +0.0f.
-// Compared with k_blur_h + k_blur_v: no intermediate plane (NC plane writes + NC x 2.0 plane reads
-// with 32-row tiles less), one launch instead of two, and a steady-state pipeline instead of
-// stage / barrier / compute / barrier / store per tile.  The price is the warm-up of a segment
-// (2R rows of row pass and loads per segment) and (64 + 2RA)/64 x the loads, which neighbouring
-// strips -- on the same XCD, gz_xcd_tile -- find in L2.
-// ZCH = true (NC == 2, Post = PostStore<2>): two independent planes with their own taps, the
-// grid's z index picks the plane (the mask's radius-20 pair).
-constexpr int SSW = 64;      // strip width
-constexpr int SG = 16;       // rows per step
-constexpr int SPITCH = 128;  // staged row pitch in floats: a multiple of 64, so that the lanes of a
-                             // ds_read_b128 group ({0-3, 12-15} of one row, {20-27} of the next) hit
-                             // 16 distinct 16-byte slots (MI355X_MICROARCH.md, LDS)
-
-template <int R, int NC, class Src, class Post, bool ZCH = false>
-__global__ __launch_bounds__(256) void k_blur_stream(SrcPack<Src, NC> src, Post post, int w, int h,
-                                                     int pitch, int seg_rows, Taps<R> taps0,
-                                                     BorderScale bsx0, BorderScale bsy0, Taps<R> taps1,
-                                                     BorderScale bsx1, BorderScale bsy1) {
-  constexpr int RA = (R + 3) & ~3;
-  constexpr int IW = SSW + 2 * RA;                       // staged columns (multiple of 4, <= SPITCH)
-  constexpr int OFF = RA - R;
-  constexpr int RING = (2 * R + SG + SG - 1) / SG * SG;  // ring rows
-  constexpr int NCL = ZCH ? 1 : NC;                      // planes per workgroup
-  constexpr int NV = SG * (IW / 4);                      // 16-byte vectors per staged plane and step
-  constexpr int NVT = (NV + 255) / 256;                  // ... per thread
-  static_assert(IW <= SPITCH, "staged row too wide");
-  static_assert(!ZCH || NC == 2, "independent planes: two of them");
-  __shared__ __attribute__((aligned(16))) float stage[NCL][SG][SPITCH];   // (the epilogue's results too)
-  __shared__ __attribute__((aligned(16))) float ring[NCL][RING][SSW];
-  const int tid = threadIdx.x;
-  const GzTile bid = gz_xcd_tile();
-  const Taps<R>& taps = (ZCH && bid.z == 1) ? taps1 : taps0;
-  const BorderScale& bsx = (ZCH && bid.z == 1) ? bsx1 : bsx0;
-  const BorderScale& bsy = (ZCH && bid.z == 1) ? bsy1 : bsy0;
-  const int x0 = bid.x * SSW;
-  const int ys = bid.y * seg_rows;                       // output rows [ys, ye)
-  const int ye = ys + seg_rows < h ? ys + seg_rows : h;
-  const int steps = (ye - ys + 2 * R + SG - 1) / SG;     // input rows [ys - R, ye + R) in blocks of SG
-  // the fast path: all staged columns inside the image and no border column among the outputs
-  const bool xin = x0 >= RA && x0 + SSW + RA <= w && (pitch & 3) == 0;
-  const bool quads = x0 + SSW <= w && (pitch & 3) == 0;   // epilogue by quads
-  Src s[NCL];
-#pragma unroll
-  for (int c = 0; c < NCL; ++c) {
-    s[c] = src.s[0];   // constant indices into the kernel arguments
-#pragma unroll
-    for (int k = 1; k < NC; ++k)
-      if ((ZCH ? bid.z : c) == k) s[c] = src.s[k];
-  }
-  gz_f4 preA[NCL][NVT], preB[NCL][NVT];
-  // loads of input block t (rows ys - R + t SG ...), fast path: into registers
-  auto prefetch = [&](int t, gz_f4 (&pre)[NCL][NVT]) {
-    const int yin = ys - R + t * SG;
-#pragma unroll
-    for (int c = 0; c < NCL; ++c) {
-#pragma unroll
-      for (int k = 0; k < NVT; ++k) {
-        const int i = 256 * k + tid;
-        gz_f4 v;
-        v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
-        if (256 * k + 255 < NV || i < NV) {
-          const int ry = i / (IW / 4), q = i - ry * (IW / 4);
-          const int y = yin + ry;
-          if (y >= 0 && y < h) v = s[c].load4((size_t)y * pitch + (x0 - RA + 4 * q));
-        }
-        pre[c][k] = v;
-      }
-    }
-  };
-  // two blocks ahead: block t + 2 is requested when block t's samples have left their registers, so
-  // that a block's loads have two steps of arithmetic to arrive in (one step is less than the
-  // memory latency of a chip whose workgroups all march in step)
-  if (xin) {
-    prefetch(0, preA);
-    if (steps > 1) prefetch(1, preB);
-  }
-  const int hr = tid >> 4, hq = (tid & 15) * 4;            // row pass: row of the block, first column
-  const int tx = tid & 63;                                // column pass: lane = column
-  const int tg = GZ_WAVE_UNIFORM(tid >> 6);               // ... wave = group of 4 rows
-  auto step = [&](int t, gz_f4 (&pre)[NCL][NVT]) {
-    const int yin = ys - R + t * SG;
-    // ---- 1. the block's samples into LDS
-    if (xin) {
-#pragma unroll
-      for (int c = 0; c < NCL; ++c) {
-#pragma unroll
-        for (int k = 0; k < NVT; ++k) {
-          const int i = 256 * k + tid;
-          if (256 * k + 255 < NV || i < NV) {
-            const int ry = i / (IW / 4), q = i - ry * (IW / 4);
-            *reinterpret_cast<gz_f4*>(&stage[c][ry][4 * q]) = pre[c][k];
-          }
-        }
-      }
-    } else {
-#pragma unroll 1
-      for (int c = 0; c < NCL; ++c) {
-        for (int i = tid; i < SG * IW; i += 256) {
-          const int ry = i / IW, rx = i - ry * IW;
-          const int x = x0 - RA + rx, y = yin + ry;
-          float v = 0.0f;
-          if (x >= 0 && x < w && y >= 0 && y < h) v = s[c]((size_t)y * pitch + x);
-          stage[c][ry][rx] = v;
-        }
-      }
-    }
-    __syncthreads();
-    if (xin && t + 2 < steps) prefetch(t + 2, pre);   // in flight during this step and the next
-    // ---- 2. row pass of the block into its ring block
-    const int rb = (t % (RING / SG)) * SG;       // ring row of the block's first row
-#pragma unroll
-    for (int c = 0; c < NCL; ++c) {
-      float win[4 + 2 * RA];
-#pragma unroll
-      for (int i = 0; i < (4 + 2 * RA) / 4; ++i) {
-        const gz_f4 v = *reinterpret_cast<const gz_f4*>(&stage[c][hr][hq + 4 * i]);
-        win[4 * i] = v.v[0]; win[4 * i + 1] = v.v[1]; win[4 * i + 2] = v.v[2]; win[4 * i + 3] = v.v[3];
-      }
-      gz_f4 o;
-      if (xin) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float sum = 0.0f;
-#pragma unroll
-          for (int j = 0; j <= 2 * R; ++j) sum += win[OFF + i + j] * taps.ks[j];
-          o.v[i] = sum;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {   // (unrolled: a run-time index would put the window in scratch)
-          const int x = x0 + hq + i;
-          float sum = 0.0f;
-          if (x < w) {
-            if (x >= R && x < w - R) {
-#pragma unroll
-              for (int j = 0; j <= 2 * R; ++j) sum += win[OFF + i + j] * taps.ks[j];
-            } else {
-#pragma unroll
-              for (int j = 0; j <= 2 * R; ++j) sum += win[OFF + i + j] * taps.k[j];
-              sum = sum * (x < R ? bsx.lo[x] : bsx.hi[w - 1 - x]);
-            }
-          }
-          o.v[i] = sum;
-        }
-      }
-      *reinterpret_cast<gz_f4*>(&ring[c][rb + hr][hq]) = o;
-    }
-    __syncthreads();
-    // ---- 3. column pass: output rows yo .. yo + SG - 1 (those inside [ys, ye))
-    const int yo = yin + SG - 1 - R - (SG - 1);   // = ys - 2R + t SG
-    const bool any = yo + SG > ys && yo < ye;     // (uniform over the workgroup)
-    float acc[NCL][4];
-    if (any) {
-      // ring row of the window's first row: input row yo + 4 tg - R  ->  (yo + 4 tg - R) - (ys - R)
-      int start = (t * SG - 2 * R + 4 * tg) % RING;
-      if (start < 0) start += RING;
-#pragma unroll
-      for (int c = 0; c < NCL; ++c) {
-        float win[4 + 2 * R];
-#pragma unroll
-        for (int k = 0; k < 4 + 2 * R; ++k) {
-          int row = start + k;
-          row = row >= RING ? row - RING : row;
-          win[k] = ring[c][row][tx];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int y = yo + 4 * tg + i;
-          float sum = 0.0f;
-          if (y >= R && y < h - R) {
-#pragma unroll
-            for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.ks[j];
-          } else if (y >= 0 && y < h) {
-#pragma unroll
-            for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.k[j];
-            sum = sum * (y < R ? bsy.lo[y] : bsy.hi[h - 1 - y]);
-          }
-          acc[c][i] = sum;
-        }
-      }
-    }
-    // ---- 4. the results to the Post functor
-    if (any && quads) {
-      // (the staged samples are dead since the barrier behind the row pass)
-      float(*outv)[SG][SSW] = reinterpret_cast<float(*)[SG][SSW]>(&stage[0][0][0]);
-#pragma unroll
-      for (int c = 0; c < NCL; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) outv[c][4 * tg + i][tx] = acc[c][i];
-      __syncthreads();
-      const int row = tid >> 4, c4 = (tid & 15) * 4;
-      const int y = yo + row;
-      if (y >= ys && y < ye) {
-        const size_t idx = (size_t)y * pitch + x0 + c4;
-        gz_f4 v[NCL];
-#pragma unroll
-        for (int c = 0; c < NCL; ++c) v[c] = *reinterpret_cast<const gz_f4*>(&outv[c][row][c4]);
-        if constexpr (ZCH) {
-          float* __restrict__ o = bid.z == 1 ? post.out[1] : post.out[0];
-          GZ_STG4(o, idx, v[0]);
-        } else {
-          post.quad(idx, v);
-        }
-      }
-    } else if (any) {
-      const int x = x0 + tx;
-#pragma unroll 1
-      for (int i = 0; i < 4; ++i) {
-        const int y = yo + 4 * tg + i;
-        if (x < w && y >= ys && y < ye) {
-          const size_t idx = (size_t)y * pitch + x;
-          if constexpr (ZCH) {
-            float* __restrict__ o = bid.z == 1 ? post.out[1] : post.out[0];
-            o[idx] = acc[0][i];
-          } else {
-            float v[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) v[c] = acc[c][i];
-            (void)post(idx, v);
-          }
-        }
-      }
-    }
-    __syncthreads();   // the next step overwrites the stage and the oldest ring block
-  };
-#pragma unroll 1
-  for (int t = 0; t < steps; t += 2) {
-    step(t, preA);
-    if (t + 1 < steps) step(t + 1, preB);
-  }
-}
-
 // ------------------------------------------------------------------- post functors --
 template <int NC>
 struct PostStore {

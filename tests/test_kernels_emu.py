@@ -186,25 +186,3 @@ def test_jpeg_entropy420(L, host_emu, wh):
 
 def test_global_order420(L):
     pc.case_global_order420(L, 48, 40, oracle, x0=100, y0=60)
-
-
-@pytest.mark.parametrize("seg", [16, 48])
-def test_blur_streaming_kernel_segments(L, monkeypatch, seg):
-    """k_blur_stream (radius >= 16: one launch per blur, a ring of row-pass results walked down a
-    column strip): segment heights that give several segments on images small enough for the
-    emulation -- interior strips (vector loads, register window) and border / unaligned strips,
-    segments that end inside a 16-row step, the two-plane and paired forms through the stages."""
-    monkeypatch.setenv("GZ_STREAM_SEG", str(seg))
-    big = [c for c in pc.SIGMAS_BR if c[0] > 5.0]      # the radii the streaming kernel serves
-    for wh in ((256, 200), (258, 67), (600, 70), (33, 130)):
-        pc.case_blur(L, *wh, configs=big)
-    pc.case_stages(L, 200, 160)
-    pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(5,))
-
-
-def test_blur_separate_passes_still_agree(L, monkeypatch):
-    """GZ_BLUR_STREAM=0: the separate row and column passes (the form before round 4)."""
-    monkeypatch.setenv("GZ_BLUR_STREAM", "0")
-    pc.case_blur(L, 256, 200)
-    pc.case_stages(L, 72, 48)
-    pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(5,))

@@ -72,6 +72,22 @@ def build(force=False, verbose=False):
     # XNACK-off boxes (profiles/r02_packed_blur_and_malta_diff_experiments.log, section 9).
     cmd = [hipcc] + [f"--offload-arch={ARCH}:xnack{m}" for m in ("-", "+")] + FLAGS + \
         [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    return _run(cmd, verbose)
+
+
+def build_variant(name, defines):
+    """A/B builds for tools/gpu_variants.sh: guetzli_amd/variants/<name>.so = the library compiled
+    with extra -D definitions (build-time experiments of the kernels; git-ignored, travels to the GPU
+    box, where the script copies one variant after the other over libguetzli_amd.so)."""
+    out = os.path.join(HERE, "variants", name + ".so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [hipcc_path()] + [f"--offload-arch={ARCH}:xnack-"] + FLAGS + ["-D" + d for d in defines] + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    _run(cmd, True)
+    return out
+
+
+def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -110,5 +126,8 @@ def build_host(force=False, verbose=False, device_lib=None, out=None):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":   # build.py --variant NAME [DEFINE ...]
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))

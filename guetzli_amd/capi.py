@@ -84,6 +84,7 @@ SIGNATURES = {
     "gz_jpeg_scan_begin": (_I, [_P, _I, _P, _P]),
     "gz_jpeg_scan_end": (_I, [_P, _P]),
     "gz_jpeg_scan_keep": (_I, [_P]),
+    "gz_jpeg_scan_bits": (_I, [_P, _P, _P]),
     "gz_jpeg_scan_bytes": (_I, [_P, _I, _P, C.c_size_t, _P]),
     "gz_probe_blur": (_I, [_P, _P, C.c_float, C.c_float, _P]),
     "gz_probe_opsin": (_I, [_P, _P, _P]),
@@ -520,6 +521,12 @@ class Context:
         n = np.zeros(1, np.uint64)
         self._chk(self.L.lib.gz_jpeg_scan_end(self.handle, _ptr(n)))
         return int(n[0])
+
+    def jpeg_scan_bits(self):
+        """(bits, stuffed bytes) of the last scan: scan bytes = ceil(bits / 8) + stuffed."""
+        b = np.zeros(2, np.uint64)
+        self._chk(self.L.lib.gz_jpeg_scan_bits(self.handle, _ptr(b[:1]), _ptr(b[1:])))
+        return int(b[0]), int(b[1])
 
     def jpeg_scan_keep(self):
         self._chk(self.L.lib.gz_jpeg_scan_keep(self.handle))

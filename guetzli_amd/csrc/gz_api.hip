@@ -273,12 +273,9 @@ struct HandlePool {
   std::multimap<int, hipEvent_t> events;
 };
 HandlePool& handle_pool() { static HandlePool p; return p; }
-// prio: 0 = default, +1 = the device's highest priority, -1 = its lowest (GZ_STREAM_PRIO=0: all
-// default).  Who takes which: create_context.
-static bool stream_priorities() {
-  static const bool on = !(getenv("GZ_STREAM_PRIO") && atoi(getenv("GZ_STREAM_PRIO")) == 0);
-  return on;
-}
+// prio: 0 = default, +1 = the device's highest priority, -1 = its lowest.  Who takes which:
+// create_context.
+static bool stream_priorities() { return true; }
 // Contexts alive per device: adds `delta`, returns the count before.
 static int live_contexts(int device, int delta) {
   static std::mutex mu;
@@ -564,30 +561,30 @@ void alloc_psycho(gz_ctx* c, Psycho* p) {
 }
 
 // ------------------------------------------------------------- blur dispatch helpers --
-// Row-pair / column-pair variants of the separate row and column passes (k_blur_h_pk,
-// k_blur_v_pk: twice the outputs per thread, packed arithmetic).  Packed f32 instructions
-// issue at the same lane rate as scalar ones on gfx950 (tools/ubench/pk.hip: 73 T lane-ops/s
-// either way), so what these variants gain is fewer LDS reads and address computations per
-// output, and what they lose is parallelism: measured per kernel (profiles/
-// r02_packed_blur_ab.log) they win from 4 MPix on for the radius-16 and radius-20 row passes
-// and the single-plane column passes, and lose below that; the multi-plane column passes and
-// the radius-23 (SameNoise) row pass lose by a few microseconds kernel by kernel but win
-// inside the three-stream chain since Malta holds 8 wavefronts per SIMD (4K 1.066 -> 1.037 ms
-// with every pass paired, 1.049-1.056 / 1.044-1.053 with either of the two alone: profiles/
-// r03_chain_kernel_experiments.log) -- from 4 MPix on every separate pass is the paired one.
-// GZ_BLUR_PK=0 / 1 forces the scalar / paired kernels everywhere (read per call: the tests
-// switch it).
-// Code-path options of the blur kernels (gz_kernels_blur.h: kOptQuad, kOptRotate), read per
-// call so that the tests can run every path: GZ_BLUR_OPT=<bits> overrides the default.
-static int blur_opt() {
-  const char* e = getenv("GZ_BLUR_OPT");
-  if (e) return atoi(e);
-  return kOptQuad | kOptRotate;
-}
+// Radius < 16: one fused launch per blur (k_blur2d); radius >= 16: a row pass and a column pass.
+// Two measured crossovers pick the instantiation (both knobs are read per call, so that the tests
+// run every one of them on images small enough for the emulation):
+//  * GZ_BLUR_PK -- row-pair / column-pair passes with packed arithmetic (k_blur_h_pk, k_blur_v_pk:
+//    twice the outputs per thread, half the LDS reads and address computations per output, half
+//    the workgroups) from 4 MPix on, the one-output-row kernels (k_blur_h, k_blur_v_compact) below
+//    (profiles/r02_packed_blur_ab.log, r03_chain_kernel_experiments.log);
+//  * GZ_TILE_ROWS -- 64 x 32 tiles from 1.5 MPix on, 64 x 16 below: twice the workgroups for
+//    256 CUs (720p: 0.290 -> 0.257 ms per Compare; no gain at 1080p, a small loss at 4K).
+// What round 4 removed after it had lost every A/B of rounds 2 and 3: the unrolled (non-compact)
+// column pass and fused kernels, 64-row tiles, the epilogue without 16-byte accesses and the row
+// pass with LDS bank conflicts (GZ_BLUR_OPT), the three-plane LF passes, the unpaired mask blurs.
 static bool packed_blur(const gz_ctx* c) {
   const char* e = getenv("GZ_BLUR_PK");
   if (e) return atoi(e) != 0;
   return (size_t)c->w * c->h >= 4000000;
+}
+constexpr int kTileRows = 32;
+constexpr int kSmallTileRows = 16;
+static bool small_tiles(const gz_ctx* c) {
+  const char* e = getenv("GZ_TILE_ROWS");
+  if (e && atoi(e) == 16) return true;
+  if (e && atoi(e) == 32) return false;
+  return (size_t)c->w * c->h < 1500000;
 }
 
 template <int R, class Src, int NC>
@@ -599,90 +596,30 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
   const int w = c->w, h = c->h, pitch = c->pitch;
   if (packed_blur(c)) {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), NC);
-    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs, blur_opt());
-    KCHK(c);
-    return GZ_OK;
+    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs);
+  } else {
+    dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), NC);
+    GZ_LAUNCH((k_blur_h<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs);
   }
-  dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), NC);
-  GZ_LAUNCH((k_blur_h<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs);
   KCHK(c);
   return GZ_OK;
 }
-// Column-pass tiles are 64 columns x 32 rows: measured faster than 64x64 at 1080p (0.47 vs
-// 0.54 ms per Compare: twice the workgroups for 256 CUs) and at 4K (1.37 vs 1.40 ms), and
-// much less sensitive to boxes whose memory is mapped with small pages (a 64-row tile of the
-// radius-20 pass touches 104 rows 15 KB apart).
-constexpr int kTileRows = 32;
-constexpr int kSmallTileRows = 16;
-// Compact-code variants of the column pass (k_blur_v_compact) and of the multi-channel fused
-// blurs (k_blur2d<..., ROLL>): loops instead of 20-40 KB of straight-line code.  A fraction of
-// the boxes (one in eight in round 1, more in round 2) shows 2-3x the instruction-cache misses
-// in the unrolled kernels (SQC_ICACHE_MISSES, profiles/r01_sq_counters_*_box.csv) and runs a
-// 1080p chain in 0.55 instead of 0.42 ms; every launch starts with cold instruction caches, so
-// the code size of a kernel that runs for 25-100 us is on its critical path.  The compact
-// variants are the default at every size: on the boxes that miss they win at 1080p (0.47 ->
-// 0.44 ms) and at 4K (1.295 -> 1.284 ms), on the others they cost nothing measurable (4K:
-// 1.162 vs 1.161-1.172 ms; profiles/r02_compact_variants_all_sizes_ab.log).
-// GZ_COMPACT_BLUR_V / GZ_COMPACT_BLUR2D = 0 select the unrolled kernels.
-static bool compact_code(const gz_ctx* c, const char* knob) {
-  (void)c;
-  const char* e = getenv(knob);
-  if (e) return atoi(e) != 0;
-  return true;
-}
-// Images below ~1.5 MPix use 16-row tiles for the passes without block maxima: twice the
-// workgroups again (720p: 0.290 -> 0.257 ms per Compare; no gain at 1080p, a small loss at 4K).
-// GZ_TILE_ROWS=16 / 32 forces either.
-static bool small_tiles(const gz_ctx* c) {
-  const char* e = getenv("GZ_TILE_ROWS");   // read per call: the tests switch it
-  if (e && atoi(e) == 16) return true;
-  if (e && atoi(e) == 32) return false;
-  return (size_t)c->w * c->h < 1500000;
-}
 
-template <int R, int NC, class Post, bool BM = false>
-int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg& cfg,
-           BlockMaxOut bm = BlockMaxOut{nullptr, nullptr, 0}) {
+template <int R, int NC, class Post>
+int blur_v(gz_ctx* c, const CPlanePack<NC>& src, const Post& post, const BlurCfg& cfg) {
   if (cfg.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bs = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (!BM && packed_blur(c)) {
-    if (small_tiles(c)) {
-      dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
-      GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs, tp, bs);
-    } else {
-      dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
-      GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs, tp, bs);
-    }
-    KCHK(c);
-    return GZ_OK;
+  const bool small = small_tiles(c);
+  dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, small ? kSmallTileRows : kTileRows));
+  if (packed_blur(c)) {
+    if (small) GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h, pitch, tp, bs, tp, bs);
+    else GZ_LAUNCH((k_blur_v_pk<R, NC, Post, kTileRows>), grid, dim3(256), c->stream, src, post, w, h, pitch, tp, bs, tp, bs);
+  } else {
+    if (small) GZ_LAUNCH((k_blur_v_compact<R, NC, Post, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h, pitch, tp, bs, tp, bs);
+    else GZ_LAUNCH((k_blur_v_compact<R, NC, Post, kTileRows>), grid, dim3(256), c->stream, src, post, w, h, pitch, tp, bs, tp, bs);
   }
-  if (!BM && compact_code(c, "GZ_COMPACT_BLUR_V")) {
-    if (small_tiles(c)) {
-      dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
-      GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs, bm, tp, bs, blur_opt());
-    } else {
-      dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
-      GZ_LAUNCH((k_blur_v_compact<R, NC, Post, false, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-                pitch, tp, bs, bm, tp, bs, blur_opt());
-    }
-    KCHK(c);
-    return GZ_OK;
-  }
-  if (!BM && small_tiles(c)) {
-    dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kSmallTileRows));
-    GZ_LAUNCH((k_blur_v<R, NC, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-              pitch, tp, bs, bm);
-    KCHK(c);
-    return GZ_OK;
-  }
-  dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, kTileRows));
-  GZ_LAUNCH((k_blur_v<R, NC, Post, BM, kTileRows>), grid, dim3(256), c->stream, src, post, w, h,
-            pitch, tp, bs, bm);
   KCHK(c);
   return GZ_OK;
 }
@@ -698,7 +635,7 @@ int blur_h_pair(gz_ctx* c, const SrcPack<Src, 2>& src, const PlanePack<2>& dst, 
   const int w = c->w, h = c->h, pitch = c->pitch;
   if (packed_blur(c)) {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), 2);
-    GZ_LAUNCH((k_blur_h_pk<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1, blur_opt());
+    GZ_LAUNCH((k_blur_h_pk<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1);
   } else {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), 2);
     GZ_LAUNCH((k_blur_h<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1);
@@ -713,22 +650,21 @@ int blur_v_pair(gz_ctx* c, const CPlanePack<2>& src, const PostStore<2>& post, c
   const Taps<R> t0 = taps_of<R>(cfg0), t1 = taps_of<R>(cfg1);
   const BorderScale b0 = cfg0.by, b1 = cfg1.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  const BlockMaxOut bm{nullptr, nullptr, 0};
   const bool small = small_tiles(c);
   dim3 grid(gz_div_up(c->w, VW), gz_div_up(c->h, small ? kSmallTileRows : kTileRows), 2);
   if (packed_blur(c)) {
     if (small) GZ_LAUNCH((k_blur_v_pk<R, 2, PostStore<2>, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
     else GZ_LAUNCH((k_blur_v_pk<R, 2, PostStore<2>, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
-  } else if (compact_code(c, "GZ_COMPACT_BLUR_V")) {
-    if (small) GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, false, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, bm, t1, b1, blur_opt());
-    else GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, bm, t1, b1, blur_opt());
   } else {
-    return GZ_E_STATE;   // (callers fall back to two single-plane blurs with the unrolled kernels)
+    if (small) GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
+    else GZ_LAUNCH((k_blur_v_compact<R, 2, PostStore<2>, kTileRows, true>), grid, dim3(256), c->stream, src, post, w, h, pitch, t0, b0, t1, b1);
   }
   KCHK(c);
   return GZ_OK;
 }
 
+// BM = true (the chain's last blur): the Post functor's results are also reduced to the per-block
+// maxima and the image maximum; that kernel keeps its results in registers (always 32-row tiles).
 template <int R, int NC, class Src, class Post, bool BM = false>
 int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurCfg& cfg,
            BlockMaxOut bm = BlockMaxOut{nullptr, nullptr, 0}) {
@@ -736,29 +672,15 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bx = cfg.bx, by = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (!BM && compact_code(c, "GZ_COMPACT_BLUR2D")) {   // rolled channel / post / border-path loops
-    if (small_tiles(c)) {
-      dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
-      GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kSmallTileRows, true>), grid, dim3(256), c->stream, src, post, w,
-                h, pitch, tp, bx, by, bm, blur_opt());
-    } else {
-      dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
-      GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kTileRows, true>), grid, dim3(256), c->stream, src, post, w,
-                h, pitch, tp, bx, by, bm, blur_opt());
-    }
-    KCHK(c);
-    return GZ_OK;
-  }
   if (!BM && small_tiles(c)) {
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
     GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w,
-              h, pitch, tp, bx, by, bm, blur_opt());
-    KCHK(c);
-    return GZ_OK;
+              h, pitch, tp, bx, by, bm);
+  } else {
+    dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
+    GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, kTileRows>), grid, dim3(256), c->stream, src, post, w,
+              h, pitch, tp, bx, by, bm);
   }
-  dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
-  GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, kTileRows>), grid, dim3(256), c->stream, src, post, w,
-            h, pitch, tp, bx, by, bm, blur_opt());
   KCHK(c);
   return GZ_OK;
 }
@@ -840,55 +762,47 @@ int stage_opsin(gz_ctx* c) {
 }
 
 // SeparateFrequencies: xyb[3] -> Psycho planes
-// split_b (the candidate's chain, unless single-stream): the LF blur of the B plane -- which only
-// k_combine reads -- runs on side stream 2 beside the X / Y bands instead of in front of them; the
-// caller joins that stream before k_combine (join_mask_branch).  Its row-pass result goes through
-// the distance-map plane, which nothing else touches before the chain's last kernel.
-int stage_separate(gz_ctx* c, Psycho* ps, bool split_b = false) {
-  static const bool split_off = getenv("GZ_LF_SPLIT") && atoi(getenv("GZ_LF_SPLIT")) == 0;
-  if (split_b && !split_off) {
+// The LF blur (radius 16) runs as X / Y (two planes, PostLFxy) and B (one plane, PostLFb: its
+// XybLowFreqToVals mixes in the raw LF of Y the first wrote, butteraugli.cc:386-389).  side_b (the
+// candidate's chain, unless single-stream): B -- which only k_combine reads -- goes to side stream
+// 2, beside the MF / HF bands instead of in front of them; the caller joins that stream before
+// k_combine (join_mask_branch).  Its row-pass result goes through the distance-map plane, which
+// nothing else touches before the chain's last kernel.
+int stage_separate(gz_ctx* c, Psycho* ps, bool side_b = false) {
+  hipStream_t main_stream = c->stream;
+  hipStream_t b_stream = side_b ? c->side_stream2 : c->stream;
+  int rc = GZ_OK;
+  if (side_b) {
     HIPCHK(c, hipEventRecord(c->ev_xyb, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_xyb, 0));
-    hipStream_t main_stream = c->stream;
-    int rc = GZ_OK;
-    {
-      c->stream = c->side_stream2;
-      SrcPack<SrcPlain, 1> s; PlanePack<1> t;
-      s.s[0].p = c->xyb[2]; t.p[0] = c->distmap;
-      rc = blur_h<16, SrcPlain, 1>(c, s, t, c->blur[B_LF]);
-      c->stream = main_stream;
-      TRY(rc);
-    }
-    {
-      SrcPack<SrcPlain, 2> s; PlanePack<2> t; CPlanePack<2> ct;
-      for (int i = 0; i < 2; ++i) { s.s[i].p = c->xyb[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
-      TRY((blur_h<16, SrcPlain, 2>(c, s, t, c->blur[B_LF])));
-      PostLFxy post;
-      for (int i = 0; i < 2; ++i) { post.lf_raw[i] = c->lf_raw[i]; post.lf_vals[i] = ps->lfv[i]; }
-      TRY((blur_v<16, 2, PostLFxy>(c, ct, post, c->blur[B_LF])));
-    }
+    HIPCHK(c, hipStreamWaitEvent(b_stream, c->ev_xyb, 0));
+  }
+  {
+    c->stream = b_stream;
+    SrcPack<SrcPlain, 1> s; PlanePack<1> t;
+    s.s[0].p = c->xyb[2]; t.p[0] = c->distmap;
+    rc = blur_h<16, SrcPlain, 1>(c, s, t, c->blur[B_LF]);
+    c->stream = main_stream;
+    TRY(rc);
+  }
+  {
+    SrcPack<SrcPlain, 2> s; PlanePack<2> t; CPlanePack<2> ct;
+    for (int i = 0; i < 2; ++i) { s.s[i].p = c->xyb[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
+    TRY((blur_h<16, SrcPlain, 2>(c, s, t, c->blur[B_LF])));
+    PostLFxy post;
+    for (int i = 0; i < 2; ++i) { post.lf_raw[i] = c->lf_raw[i]; post.lf_vals[i] = ps->lfv[i]; }
+    TRY((blur_v<16, 2, PostLFxy>(c, ct, post, c->blur[B_LF])));
+  }
+  if (side_b) {
     HIPCHK(c, hipEventRecord(c->ev_lfy, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->side_stream2, c->ev_lfy, 0));
-    {
-      c->stream = c->side_stream2;
-      CPlanePack<1> ct; ct.p[0] = c->distmap;
-      PostLFb post; post.lf_raw_y = c->lf_raw[1]; post.lf_vals_b = ps->lfv[2];
-      rc = blur_v<16, 1, PostLFb>(c, ct, post, c->blur[B_LF]);
-      c->stream = main_stream;
-      TRY(rc);
-    }
-  } else {  // LF (radius 16: separate row and column passes -- the fused kernel's extra row-pass
-     // arithmetic costs more than the intermediate plane at this radius)
-    SrcPack<SrcPlain, 3> s;
-    PlanePack<3> t;
-    CPlanePack<3> ct;
-    for (int i = 0; i < 3; ++i) { s.s[i].p = c->xyb[i]; t.p[i] = c->tmp[i]; ct.p[i] = c->tmp[i]; }
-    TRY((blur_h<16, SrcPlain, 3>(c, s, t, c->blur[B_LF])));
-    PostLF post;
-    post.lf_raw[0] = c->lf_raw[0];
-    post.lf_raw[1] = c->lf_raw[1];
-    for (int i = 0; i < 3; ++i) post.lf_vals[i] = ps->lfv[i];
-    TRY((blur_v<16, 3, PostLF>(c, ct, post, c->blur[B_LF])));
+    HIPCHK(c, hipStreamWaitEvent(b_stream, c->ev_lfy, 0));
+  }
+  {
+    c->stream = b_stream;
+    CPlanePack<1> ct; ct.p[0] = c->distmap;
+    PostLFb post; post.lf_raw_y = c->lf_raw[1]; post.lf_vals_b = ps->lfv[2];
+    rc = blur_v<16, 1, PostLFb>(c, ct, post, c->blur[B_LF]);
+    c->stream = main_stream;
+    TRY(rc);
   }
   {  // MF (X, Y)
     SrcPack<SrcDiff, 2> s;
@@ -920,10 +834,10 @@ int stage_separate(gz_ctx* c, Psycho* ps, bool split_b = false) {
   return GZ_OK;
 }
 
-// Mask first half: DiffPrecompute + three blurs -> mxb, myb1, myb2.  The three blurs only
-// share their input: with `other` given, the small one (radius 5) goes behind whatever is
-// queued there (the SameNoise blur, the shorter of the two side branches) instead of between
-// the two radius-20 blurs of this stream.
+// Mask first half: DiffPrecompute + three blurs -> mxb, myb1, myb2.  The three blurs only share
+// their input: the two of radius 20 (X: sigma r2 = 9.24; Y second: sigma r1 = 9.04 -- separate
+// taps) are one launch per pass (grid z = plane); with `other` given, the small one (radius 5)
+// goes behind whatever is queued there (the SameNoise blur, the shorter of the two side branches).
 int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullptr) {
   dim3 grid(gz_div_up(c->w, 1024), c->h, 2);
   GZ_LAUNCH(k_mask_pre, grid, dim3(256), c->stream, pk, c->w, c->h, c->pitch);
@@ -932,11 +846,7 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
     HIPCHK(c, hipEventRecord(c->ev_mask_pre, c->stream));
     HIPCHK(c, hipStreamWaitEvent(other, c->ev_mask_pre, 0));
   }
-  // X: sigma r2 = 9.24 ; Y second: sigma r1 = 9.04 -- both radius 20, separate taps: one launch
-  // per pass for the two (GZ_MASK_PAIR=0, or the unrolled column kernels: one blur after the other)
-  static const bool pair_off = getenv("GZ_MASK_PAIR") && atoi(getenv("GZ_MASK_PAIR")) == 0;
-  const bool pair = !pair_off && (packed_blur(c) || compact_code(c, "GZ_COMPACT_BLUR_V"));
-  if (pair) {
+  {
     SrcPack<SrcPlain, 2> s; PlanePack<2> t; CPlanePack<2> ct;
     s.s[0].p = c->diffx; s.s[1].p = c->diffy;
     t.p[0] = c->tmp[1]; t.p[1] = c->tmp[2];
@@ -944,12 +854,6 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
     TRY((blur_h_pair<20, SrcPlain>(c, s, t, c->blur[B_MASKX], c->blur[B_MASKY1])));
     PostStore<2> post; post.out[0] = c->mxb; post.out[1] = c->myb2;
     TRY((blur_v_pair<20>(c, ct, post, c->blur[B_MASKX], c->blur[B_MASKY1])));
-  } else {
-    SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
-    s.s[0].p = c->diffx; t.p[0] = c->tmp[1]; ct.p[0] = c->tmp[1];
-    TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKX])));
-    PostStore<1> post; post.out[0] = c->mxb;
-    TRY((blur_v<20, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKX])));
   }
   {
     SrcPack<SrcPlain, 1> s; s.s[0].p = c->diffy;
@@ -959,13 +863,6 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
     const int rc = blur2d<5, 1, SrcPlain, PostStore<1>>(c, s, post, c->blur[B_MASKY0]);
     c->stream = here;
     TRY(rc);
-  }
-  if (!pair) {
-    SrcPack<SrcPlain, 1> s; PlanePack<1> t; CPlanePack<1> ct;
-    s.s[0].p = c->diffy; t.p[0] = c->tmp[2]; ct.p[0] = c->tmp[2];
-    TRY((blur_h<20, SrcPlain, 1>(c, s, t, c->blur[B_MASKY1])));
-    PostStore<1> post; post.out[0] = c->myb2;
-    TRY((blur_v<20, 1, PostStore<1>>(c, ct, post, c->blur[B_MASKY1])));
   }
   return GZ_OK;
 }
@@ -1021,8 +918,7 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
     if (rc == GZ_OK) rc = blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN]);
   }
   c->stream = c->side_stream;
-  static const bool split = !(getenv("GZ_MASK_SPLIT") && atoi(getenv("GZ_MASK_SPLIT")) == 0);
-  if (rc == GZ_OK) rc = stage_mask_blurs(c, mask_pack_psycho(c, p0, p1), split ? c->side_stream2 : nullptr);
+  if (rc == GZ_OK) rc = stage_mask_blurs(c, mask_pack_psycho(c, p0, p1), c->side_stream2);
   c->stream = main_stream;
   TRY(rc);
   HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
@@ -1053,19 +949,7 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[2] = {p0.mf[ch], p1.mf[ch], ms[ch][2].nm, ms[ch][2].lf};
     a.out = c->ac[ch];
   }
-  // k_malta_rolled (the default): the loop over a thread's 8 pixels stays a loop, 59 VGPRs and 8
-  // wavefronts per SIMD instead of 120 / 4 (4K 313 -> 272 us, 1080p 89 -> 76 us, profiles/
-  // r03_chain_kernel_experiments.log).  GZ_MALTA_ROLLED=0: k_malta, the unrolled kernel;
-  // GZ_MALTA_WIN=1: the line sums from a per-thread register window (k_malta_win: faster than
-  // k_malta alone, not beside the side streams' kernels).  Read per call.
-  const char* mw_env = getenv("GZ_MALTA_WIN");
-  const char* mr_env = getenv("GZ_MALTA_ROLLED");
-  if (mw_env && atoi(mw_env) != 0)
-    GZ_LAUNCH((k_malta_win<3>), mgrid, dim3(512), c->stream, ay, ax, c->w, c->h, c->pitch);
-  else if (mr_env && atoi(mr_env) == 0)
-    GZ_LAUNCH((k_malta<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
-  else
-    GZ_LAUNCH((k_malta_rolled<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
+  GZ_LAUNCH((k_malta_rolled<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);
   TRY(join_mask_branch(c));
   {
@@ -1135,13 +1019,6 @@ int stage_chroma_samples(gz_ctx* c, const int16_t* d_coeffs) {
   return GZ_OK;
 }
 
-// The integer IDCT of k_reconstruct as packed 16-bit dot products (v_dot2c_i32_i16) -- the
-// default -- or as 24-bit multiply-adds (GZ_IDCT_DOT2=0; read per call: the tests run both).
-static bool idct_dot2() {
-  const char* e = getenv("GZ_IDCT_DOT2");
-  return !(e && atoi(e) == 0);
-}
-
 int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* srgb,
                       unsigned* clear_word = nullptr) {
   if (c->cfac == 2) {
@@ -1152,14 +1029,9 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
     KCHK(c);
     return GZ_OK;
   }
-  if (idct_dot2())
-    GZ_LAUNCH(k_reconstruct<true>, dim3(c->bh * gz_div_up(c->bw, kReconBlocks)), dim3(256), c->stream,
-              d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
-              srgb, clear_word);
-  else
-    GZ_LAUNCH(k_reconstruct<false>, dim3(c->bh * gz_div_up(c->bw, kReconBlocks)), dim3(256), c->stream,
-              d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
-              srgb, clear_word);
+  GZ_LAUNCH(k_reconstruct, dim3(c->bh * gz_div_up(c->bw, kReconBlocks)), dim3(256), c->stream,
+            d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
+            srgb, clear_word);
   KCHK(c);
   return GZ_OK;
 }
@@ -2294,8 +2166,7 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
   // gz_order_build_auto_descend_begin: the prefix the driver fetches next goes to its host mirror
   // behind the last level (the driver's own bound on such a fetch: 2^19 entries)
   c->export_epoch = 0;
-  static const bool do_export = !(getenv("GZ_ORDER_EXPORT") && atoi(getenv("GZ_ORDER_EXPORT")) == 0);
-  if (publish && levels > 0 && do_export && c->h_order_mirror) {
+  if (publish && levels > 0 && c->h_order_mirror) {
     const unsigned long long max_entries = std::min<unsigned long long>(c->order_mirror_cap, 1ull << 19);
     GZ_LAUNCH(k_desc_export, dim3(128), dim3(256), c->stream, A, levels, (OrderEntry*)c->h_order_mirror, max_entries);
     KCHK(c);
@@ -2421,9 +2292,8 @@ int gz_jpeg_histograms_ncomp(gz_ctx* c, const int* q, int ncomp, uint32_t* count
     HIPCHK(c, hipMemcpyAsync(c->d_jq, c->h_jq, sizeof(int) * 192, hipMemcpyHostToDevice, c->stream));
   }
   HIPCHK(c, hipMemsetAsync(c->d_hist, 0, sizeof(unsigned) * 1536, c->stream));
-  static const char* hg = getenv("GZ_HIST_GRID");
   const FrameGeom geom = frame_geom(c, ncomp);
-  const int grid = std::min(gz_div_up(geom.mcu_cols * geom.mcu_rows, kHistWaves), hg ? atoi(hg) : 1024);
+  const int grid = std::min(gz_div_up(geom.mcu_cols * geom.mcu_rows, kHistWaves), 1024);
   GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
             (const int*)c->d_jq, geom, c->d_hist);
   KCHK(c);
@@ -2533,6 +2403,15 @@ int gz_jpeg_scan(gz_ctx* c, int ncomp, const uint8_t* depth, const uint16_t* cod
   if (!scan_bytes) return GZ_E_ARG;
   TRY(gz_jpeg_scan_begin(c, ncomp, depth, code));
   return gz_jpeg_scan_end(c, scan_bytes);
+}
+
+int gz_jpeg_scan_bits(gz_ctx* c, uint64_t* bits, uint64_t* stuffed) {
+  DeviceScope ds_(c);
+  if (!c || !bits || !stuffed) return GZ_E_ARG;
+  if (!c->have_scan) { c->err = "no scan yet"; return GZ_E_STATE; }
+  *bits = c->scan_bits;
+  *stuffed = c->scan_ff;
+  return GZ_OK;
 }
 
 int gz_jpeg_scan_keep(gz_ctx* c) {
@@ -2713,7 +2592,7 @@ int gz_probe_idct_blocks(int device, const int16_t* blocks, int n, uint8_t* out)
   if (hipMalloc((void**)&d_in, (size_t)n * 128) != hipSuccess) return GZ_E_HIP;
   if (hipMalloc((void**)&d_out, (size_t)n * 64) != hipSuccess) { (void)hipFree(d_in); return GZ_E_HIP; }
   if (hipMemcpy(d_in, blocks, (size_t)n * 128, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_in); (void)hipFree(d_out); return GZ_E_HIP; }
-  GZ_LAUNCH(k_idct_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0, d_in, n, d_out, idct_dot2() ? 1 : 0);
+  GZ_LAUNCH(k_idct_blocks, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), (hipStream_t)0, d_in, n, d_out);
   int rc = hipGetLastError() == hipSuccess ? GZ_OK : GZ_E_HIP;
   if (hipMemcpy(out, d_out, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) rc = GZ_E_HIP;
   (void)hipFree(d_in); (void)hipFree(d_out);

@@ -128,21 +128,20 @@ GZ_DEVFN void idct3_to_rgb(const int (*s_in)[64], int (*s_col)[64], int lane, in
   ycc_to_rgb(px[0], px[1], px[2], r, g, b);
 }
 
-// DOT2: both passes as four v_dot2c_i32_i16 per output instead of eight multiply-adds, the
+// Both IDCT passes as four v_dot2c_i32_i16 per output instead of eight multiply-adds, the
 // coefficients kept as int16 in LDS -- transposed by the staging store, so that the eight values
 // a lane needs (a column of the block, then a row of the column pass's results) are one
-// 16-byte read instead of eight dword reads.
-template <bool DOT2>
+// 16-byte read instead of eight dword reads.  (Round 3's 24-bit multiply-add form of this kernel,
+// 72 instead of 59 us at 4K, was removed in round 4; idct3_to_rgb keeps that arithmetic for the
+// 4:2:0 and block-search kernels.)
 __global__ __launch_bounds__(256) void k_reconstruct(
     const int16_t* __restrict__ coeffs, int w, int h, int bw, int nb, int pitch,
     size_t pstride, const float* __restrict__ srgb_lut, float* __restrict__ lin,
     uint8_t* __restrict__ srgb, unsigned* __restrict__ clear_word) {
   // first kernel of a Compare: also resets the distance accumulator of its last kernel
   if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
-  __shared__ __attribute__((aligned(16))) int s_in[DOT2 ? 1 : kReconBlocks][3][64];
-  __shared__ __attribute__((aligned(16))) int s_col[DOT2 ? 1 : kReconBlocks][3][64];
-  __shared__ __attribute__((aligned(16))) short s_in16[DOT2 ? kReconBlocks : 1][3][64];    // [ix][u]
-  __shared__ __attribute__((aligned(16))) short s_col16[DOT2 ? kReconBlocks : 1][3][64];   // [iy][u]
+  __shared__ __attribute__((aligned(16))) short s_in16[kReconBlocks][3][64];    // [ix][u]
+  __shared__ __attribute__((aligned(16))) short s_col16[kReconBlocks][3][64];   // [iy][u]
   __shared__ __attribute__((aligned(16))) float s_px[3][8][kReconBlocks * 8];   // [plane][row][x]
   __shared__ uint8_t s_u8[8][kReconBlocks * 8][3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -158,31 +157,20 @@ __global__ __launch_bounds__(256) void k_reconstruct(
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int16_t v = live ? coeffs[((size_t)c * nb + blk) * 64 + lane] : (int16_t)0;
-      if (DOT2) s_in16[j][c][8 * ix + iy] = v;   // lane = 8 * (row u) + column: transposed
-      else s_in[j][c][lane] = (int)v;
+      s_in16[j][c][8 * ix + iy] = v;   // lane = 8 * (row u) + column: transposed
     }
   }
   __syncthreads();
-  gz_u4 m_row, m_col;   // rows iy / ix of the matrix, packed
-  if (DOT2) {
-    m_row = gz_load_u4(&kIdctMP[4 * iy]);
-    m_col = gz_load_u4(&kIdctMP[4 * ix]);
-  }
+  // rows iy / ix of the matrix, packed
+  const gz_u4 m_row = gz_load_u4(&kIdctMP[4 * iy]), m_col = gz_load_u4(&kIdctMP[4 * ix]);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int j = 2 * wave + k;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
-      if (DOT2) {
-        const gz_u4 q = gz_load_u4(&s_in16[j][c][8 * ix]);
-        s_col16[j][c][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
-      } else {
-        int acc = 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[j][c][8 * u + ix]);
-        s_col[j][c][lane] = (int)(short)((acc + (1 << 10)) >> 11);
-      }
+      const gz_u4 q = gz_load_u4(&s_in16[j][c][8 * ix]);
+      s_col16[j][c][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
     }
   }
   __syncthreads();
@@ -190,18 +178,14 @@ __global__ __launch_bounds__(256) void k_reconstruct(
   for (int k = 0; k < 2; ++k) {
     const int j = 2 * wave + k;
     int r, g, b;
-    if (DOT2) {
-      int px[3];
+    int px[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        // row pass (idct.cc:150-160): out = clamp((sum + (257 << 17)) >> 18)
-        const gz_u4 q = gz_load_u4(&s_col16[j][c][8 * iy]);
-        px[c] = clamp255((idct_dot8(m_col, q) + (257 << 17)) >> 18);
-      }
-      ycc_to_rgb(px[0], px[1], px[2], &r, &g, &b);
-    } else {
-      idct3_to_rgb(s_in[j], s_col[j], lane, &r, &g, &b);
+    for (int c = 0; c < 3; ++c) {
+      // row pass (idct.cc:150-160): out = clamp((sum + (257 << 17)) >> 18)
+      const gz_u4 q = gz_load_u4(&s_col16[j][c][8 * iy]);
+      px[c] = clamp255((idct_dot8(m_col, q) + (257 << 17)) >> 18);
     }
+    ycc_to_rgb(px[0], px[1], px[2], &r, &g, &b);
     const int x = 8 * j + ix;
     if (lin) {
       s_px[0][iy][x] = srgb_lut[r];
@@ -244,37 +228,24 @@ __global__ __launch_bounds__(256) void k_reconstruct(
   }
 }
 
-// Bare-block IDCT probe (gz_probe_idct_blocks).
+// Bare-block IDCT probe (gz_probe_idct_blocks): the arithmetic of k_reconstruct.
 __global__ __launch_bounds__(256) void k_idct_blocks(const int16_t* __restrict__ blocks,
-                                                     int n, uint8_t* __restrict__ out, int dot2) {
-  __shared__ int s_in[kBlocksPerWG][64];
-  __shared__ int s_col[kBlocksPerWG][64];
+                                                     int n, uint8_t* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) short s_in16[kBlocksPerWG][64];
   __shared__ __attribute__((aligned(16))) short s_col16[kBlocksPerWG][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int blk = blockIdx.x * kBlocksPerWG + wave;
   const bool live = blk < n;
   const int iy = lane >> 3, ix = lane & 7;
-  s_in[wave][lane] = live ? (int)blocks[(size_t)blk * 64 + lane] : 0;
   s_in16[wave][8 * ix + iy] = live ? blocks[(size_t)blk * 64 + lane] : (int16_t)0;
   __syncthreads();
-  if (dot2) {   // the arithmetic of k_reconstruct<true>
-    const gz_u4 m_row = gz_load_u4(&kIdctMP[4 * iy]);
-    const gz_u4 m_col = gz_load_u4(&kIdctMP[4 * ix]);
-    const gz_u4 q = gz_load_u4(&s_in16[wave][8 * ix]);
-    s_col16[wave][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
-    __syncthreads();
-    const gz_u4 q2 = gz_load_u4(&s_col16[wave][8 * iy]);
-    if (live) out[(size_t)blk * 64 + lane] = (uint8_t)clamp255((idct_dot8(m_col, q2) + (257 << 17)) >> 18);
-    return;
-  }
-  int acc = 0;
-  for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s_in[wave][8 * u + ix]);
-  s_col[wave][lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  const gz_u4 m_row = gz_load_u4(&kIdctMP[4 * iy]);
+  const gz_u4 m_col = gz_load_u4(&kIdctMP[4 * ix]);
+  const gz_u4 q = gz_load_u4(&s_in16[wave][8 * ix]);
+  s_col16[wave][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
   __syncthreads();
-  acc = 0;
-  for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s_col[wave][8 * iy + u]);
-  if (live) out[(size_t)blk * 64 + lane] = (uint8_t)clamp255((acc + (257 << 17)) >> 18);
+  const gz_u4 q2 = gz_load_u4(&s_col16[wave][8 * iy]);
+  if (live) out[(size_t)blk * 64 + lane] = (uint8_t)clamp255((idct_dot8(m_col, q2) + (257 << 17)) >> 18);
 }
 
 // ---------------------------------------------------------------- 4:2:0 reconstruct --

@@ -29,12 +29,6 @@ struct BorderScale {
   const float* hi;
 };
 
-// Code-path options of the blur kernels (kernel argument `opt`; every combination gives the
-// same results): kOptQuad = epilogue by quads with 16-byte accesses, kOptRotate = conflict-free
-// lane-to-quad mapping of the fused kernel's row pass.
-constexpr int kOptQuad = 1;
-constexpr int kOptRotate = 2;
-
 // ----------------------------------------------------------------- source functors --
 // A source yields the input sample at flat index `idx` (= y*pitch + x).
 struct SrcPlain {
@@ -186,21 +180,19 @@ constexpr int HP = 8;
 template <int R, class Src, int NC, bool TWO = false>
 __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePack<NC> dst,
                                                    int w, int h, int pitch, Taps<R> taps0,
-                                                   BorderScale bs0, Taps<R> taps1, BorderScale bs1,
-                                                   int opt) {
+                                                   BorderScale bs0, Taps<R> taps1, BorderScale bs1) {
   constexpr int RA = (R + 3) & ~3;
   constexpr int TP = HW + 2 * RA;
   constexpr int OFF = RA - R;
-  // kOptRotate: conflict-free window reads.  A thread's 16-byte reads walk its window in steps
-  // of one slot, but neighbouring threads start 2 slots apart (4 outputs x 2 rows), so of the 16
-  // lanes of a ds_read_b128 group ({0-3, 12-15, 20-27}, ...) only 8 distinct slots (mod 16) are
-  // touched: every read takes twice its cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
-  // 0.32-0.63 in profiles/r02_compare_4k_sq_counters.csv).  With the option a wavefront takes TWO
-  // row pairs x 128 columns instead of one x 256 -- lanes with bit 3 clear the first pair, set
-  // the second -- and consecutive pairs are staged an odd number of slots apart (4 floats of
-  // padding): each group then reads 8 even and 8 odd slots.  Same outputs per thread.
-  const bool rot = (opt & kOptRotate) != 0;
-  const int PS = TP * 2 + (rot ? 4 : 0);   // floats per staged row pair
+  // Conflict-free window reads.  A thread's 16-byte reads walk its window in steps of one slot,
+  // but neighbouring threads start 2 slots apart (4 outputs x 2 rows), so with one row pair x 256
+  // columns per wavefront only 8 distinct slots (mod 16) are touched by the 16 lanes of a
+  // ds_read_b128 group ({0-3, 12-15, 20-27}, ...) and every read takes twice its cycles
+  // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.32-0.63 in profiles/r02_compare_4k_sq_counters.csv).
+  // A wavefront therefore takes TWO row pairs x 128 columns -- lanes with bit 3 clear the first
+  // pair, set the second -- and consecutive pairs are staged an odd number of slots apart (4
+  // floats of padding): each group then reads 8 even and 8 odd slots.  Same outputs per thread.
+  constexpr int PS = TP * 2 + 4;   // floats per staged row pair
   __shared__ __attribute__((aligned(16))) float tile[(HP / 2) * (TP * 2 + 4)];
   const GzTile bid = gz_xcd_tile();
   const int c = bid.z;
@@ -235,12 +227,9 @@ __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePa
       }
     }
     __syncthreads();
-    int p = tid >> 6, xq = (tid & 63) * 4;
-    if (rot) {
-      const int wv = tid >> 6, l = tid & 63;
-      p = 2 * (wv >> 1) + ((l >> 3) & 1);
-      xq = ((wv & 1) * 32 + (((l >> 4) << 3) | (l & 7))) * 4;
-    }
+    const int wv = tid >> 6, l = tid & 63;
+    const int p = 2 * (wv >> 1) + ((l >> 3) & 1);
+    const int xq = ((wv & 1) * 32 + (((l >> 4) << 3) | (l & 7))) * 4;
     gz_f2 win[4 + 2 * RA];
 #pragma unroll
     for (int i = 0; i < (4 + 2 * RA) / 2; ++i) {
@@ -357,92 +346,16 @@ GZ_DEVFN void block_max_from_registers(const float* res, int tx, int row0, int x
   }
 }
 
-template <int R, int NC, class Post, bool BM, int TH = 64>
-__global__ __launch_bounds__(256) void k_blur_v(CPlanePack<NC> src, Post post, int w, int h,
-                                                int pitch, Taps<R> taps, BorderScale bs,
-                                                BlockMaxOut bm) {
-  // TH = tile height (64, or 32 for small images: twice the workgroups to fill the chip)
-  constexpr int VHt = TH, VPTt = TH / 4;
-  __shared__ __attribute__((aligned(16))) float tile[VHt + 2 * R][VW];
-  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const GzTile bid = gz_xcd_tile();
-  const int x0 = bid.x * VW, y0 = bid.y * VHt;
-  const int x = x0 + tx;
-  // staging with one aligned 16-byte load per lane when the tile's columns are all inside
-  // the image and rows are 16-byte aligned (rows outside the image are zero)
-  const bool vec = x0 + VW <= w && (pitch & 3) == 0;
-  const int vq = (threadIdx.x & 15) * 4, vr = threadIdx.x >> 4;
-  float acc[NC][VPTt];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const float* __restrict__ in = src.p[c];
-    if (c > 0) __syncthreads();
-    if (vec) {
-#pragma unroll
-      for (int k = 0; k < (VHt + 2 * R + 15) / 16; ++k) {
-        const int ry = vr + 16 * k;
-        if ((k + 1) * 16 <= VHt + 2 * R || ry < VHt + 2 * R) {
-          const int y = y0 - R + ry;
-          gz_f4 v;
-          v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
-          if (y >= 0 && y < h) v = GZ_LDG4(in, (size_t)y * pitch + x0 + vq);
-          *reinterpret_cast<gz_f4*>(&tile[ry][vq]) = v;
-        }
-      }
-    } else {
-      for (int ry = tg; ry < VHt + 2 * R; ry += 4) {
-        const int y = y0 - R + ry;
-        float v = 0.0f;
-        if (x < w && y >= 0 && y < h) v = in[(size_t)y * pitch + x];
-        tile[ry][tx] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < VPTt; ++i) {
-      const int ly = tg * VPTt + i;   // local output row
-      const int y = y0 + ly;
-      float sum = 0.0f;
-      if (y < h) {
-        const bool border = y < R || y >= h - R;
-        if (!border) {
-#pragma unroll
-          for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.ks[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j <= 2 * R; ++j) sum += tile[ly + j][tx] * taps.k[j];
-          sum = sum * (y < R ? bs.lo[y] : bs.hi[h - 1 - y]);
-        }
-      }
-      acc[c][i] = sum;
-    }
-  }
-  float res[VPTt];
-#pragma unroll
-  for (int i = 0; i < VPTt; ++i) {
-    const int y = y0 + tg * VPTt + i;
-    res[i] = 0.0f;
-    if (x < w && y < h) {
-      float v[NC];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) v[c] = acc[c][i];
-      res[i] = post((size_t)y * pitch + x, v);
-    }
-  }
-  if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
-}
-
-// ZCH = true (NC == 2, Post = PostStore<2>, not BM): the two planes are independent blurs with
-// their own taps (taps1 / bs1 for the second); the grid's z index picks the plane, each workgroup
-// does one.
-template <int R, int NC, class Post, bool BM, int TH = 64, bool ZCH = false>
+// ZCH = true (NC == 2, Post = PostStore<2>): the two planes are independent blurs with their own
+// taps (taps1 / bs1 for the second); the grid's z index picks the plane, each workgroup does one.
+template <int R, int NC, class Post, int TH, bool ZCH = false>
 __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post post, int w, int h,
                                                 int pitch, Taps<R> taps0, BorderScale bs0,
-                                                BlockMaxOut bm, Taps<R> taps1, BorderScale bs1, int opt) {
-  // TH = tile height (64, or 32 for small images: twice the workgroups to fill the chip)
+                                                Taps<R> taps1, BorderScale bs1) {
+  // TH = tile height (32, or 16 for small images: twice the workgroups to fill the chip)
   constexpr int VHt = TH, VPTt = TH / 4;
   constexpr int NCL = ZCH ? 1 : NC;   // planes per workgroup
-  static_assert(!ZCH || (NC == 2 && !BM), "independent planes: two of them, no block maxima");
+  static_assert(!ZCH || NC == 2, "independent planes: two of them");
   __shared__ __attribute__((aligned(16))) float tile[VHt + 2 * R][VW];
   const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const GzTile bid = gz_xcd_tile();
@@ -454,18 +367,15 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
   // the image and rows are 16-byte aligned (rows outside the image are zero)
   const bool vec = x0 + VW <= w && (pitch & 3) == 0;
   const int vq = (threadIdx.x & 15) * 4, vr = threadIdx.x >> 4;
-  // Compact code on purpose: the channel and row loops stay loops (only the taps are
-  // unrolled) and the per-channel results wait in LDS instead of registers: 5 KB of
-  // instructions instead of 34 KB for <16, 3>.  Experiment for the boxes whose
-  // SQC_ICACHE_MISSES are 3x higher (profiles/r01_sq_counters_*_box.csv); selected with
-  // GZ_COMPACT_BLUR_V=1.
-  // one channel: a row's result goes straight to the Post functor; several channels: the
-  // per-channel results wait in LDS until the last channel is done.  With kOptQuad (tiles whose
-  // columns are all inside the image) the results of every kernel wait in LDS and leave by
-  // quads: 4 consecutive pixels of a row per thread, 16-byte accesses in the Post functor.
-  const bool quads = (opt & kOptQuad) && vec && !BM;
+  // Compact code on purpose: the channel and row loops stay loops (only the taps are unrolled):
+  // 5 KB of instructions instead of the 34 KB of the unrolled form for <16, 3> -- every launch
+  // starts with cold instruction caches, and some boxes miss three times as often
+  // (profiles/r01_sq_counters_*_box.csv).  Tiles whose columns are all inside the image keep their
+  // results in LDS and hand them to the Post functor by quads: 4 consecutive pixels of a row per
+  // thread, 16-byte accesses (a dword per lane streams at two thirds of that rate); the other
+  // tiles go pixel by pixel (one plane: straight from the row loop; several: through LDS).
+  const bool quads = vec;
   __shared__ __attribute__((aligned(16))) float outv[NCL][VHt][VW];
-  float res[VPTt];
 #pragma unroll 1
   for (int c = 0; c < NCL; ++c) {
     const float* __restrict__ in = src.p[0];
@@ -518,11 +428,9 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
         if (x < w && y < h) o[(size_t)y * pitch + x] = sum;
       } else if (NC > 1) {
         outv[c][ly][tx] = sum;
-      } else if (!BM) {
+      } else {
         float v1[1] = {sum};
         if (x < w && y < h) post((size_t)y * pitch + x, v1);
-      } else {
-        outv[0][0][tx] = 0.0f;   // (BM kernels are never compact)
       }
     }
   }
@@ -548,21 +456,19 @@ __global__ __launch_bounds__(256) void k_blur_v_compact(CPlanePack<NC> src, Post
     return;
   }
   // (each lane reads back what it wrote itself: no barrier needed)
-#pragma unroll
-  for (int i = 0; i < VPTt; ++i) {
-    const int ly = tg * VPTt + i;
-    const int y = y0 + ly;
-    res[i] = 0.0f;
-    if constexpr (!ZCH) {
-      if (NC > 1 && x < w && y < h) {
+  if constexpr (!ZCH && NC > 1) {
+#pragma unroll 1
+    for (int i = 0; i < VPTt; ++i) {
+      const int ly = tg * VPTt + i;
+      const int y = y0 + ly;
+      if (x < w && y < h) {
         float v[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) v[c] = outv[c][ly][tx];
-        res[i] = post((size_t)y * pitch + x, v);
+        (void)post((size_t)y * pitch + x, v);
       }
     }
   }
-  if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
 }
 
 
@@ -715,13 +621,19 @@ __global__ __launch_bounds__(256) void k_blur_v_pk(CPlanePack<NC> src, Post post
 // pass arithmetic.
 constexpr int T2 = 64;   // tile edge
 
-// ROLL = true: the channel loop stays a loop and the per-channel results wait in LDS instead
-// of registers -- the kernel's code shrinks by about NC x (experiment for the boxes with the
-// high instruction-cache miss counts, GZ_COMPACT_BLUR2D=1).
-template <int R, int NC, class Src, class Post, bool BM, int TH = 64, bool ROLL = false>
-__global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post, int w, int h,
+// Without block maxima (BM = false: every blur but the chain's last) the channel loop stays a loop
+// and the per-channel results wait in LDS instead of registers (ROLL): the code shrinks by about
+// NC x (opsin blur 40 -> 6 KB, MF 32 -> 10, HF 23 -> 6), and the results leave by quads.
+#ifdef GZ_BLUR2D_WPS   // (build-time experiment: wavefronts per SIMD the register allocation aims for)
+#define GZ_BLUR2D_BOUNDS __launch_bounds__(256, GZ_BLUR2D_WPS)
+#else
+#define GZ_BLUR2D_BOUNDS __launch_bounds__(256)
+#endif
+template <int R, int NC, class Src, class Post, bool BM, int TH>
+__global__ GZ_BLUR2D_BOUNDS void k_blur2d(SrcPack<Src, NC> src, Post post, int w, int h,
                                                 int pitch, Taps<R> taps, BorderScale bsx,
-                                                BorderScale bsy, BlockMaxOut bm, int opt) {
+                                                BorderScale bsy, BlockMaxOut bm) {
+  constexpr bool ROLL = !BM;
   constexpr int RA = (R + 3) & ~3;
   constexpr int IW = T2 + 2 * RA;   // staged columns, multiple of 4
   constexpr int IH = TH + 2 * R;    // staged rows (TH = tile height: 64, or 32 for small images)
@@ -744,7 +656,7 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
   // which quad of a row changes nothing in the results.
   constexpr int kRowSlotShift = (IW / 4) & 15;
   const int hr = tid >> 4;                  // rows hr + 16k
-  const int hq = (opt & kOptRotate) ? (((tid & 15) - (hr & 1) * kRowSlotShift) & 15) * 4 : (tid & 15) * 4;
+  const int hq = (((tid & 15) - (hr & 1) * kRowSlotShift) & 15) * 4;
   float acc[ROLL ? 1 : NC][VPTt];
   __shared__ __attribute__((aligned(16))) float outv[ROLL ? NC : 1][ROLL ? TH : 1][T2];
   constexpr int kChannelUnroll = ROLL ? 1 : NC;
@@ -886,7 +798,7 @@ __global__ __launch_bounds__(256) void k_blur2d(SrcPack<Src, NC> src, Post post,
   }
   const int x = x0 + tx;
   if (ROLL && !BM) {
-    if ((opt & kOptQuad) && x0 + T2 <= w && (pitch & 3) == 0) {
+    if (x0 + T2 <= w && (pitch & 3) == 0) {
       // Epilogue by quads: a thread takes 4 consecutive pixels of a row from the results in
       // LDS, so that everything the Post functor reads and writes moves as 16-byte accesses
       // (a dword per lane streams at two thirds of that rate, tools/ubench/bw.hip).
@@ -984,39 +896,9 @@ struct PostOpsin {
   }
 };
 
-// LF band (butteraugli.cc:510, :606-621): v = blur(xyb, sigma_lf).  Keeps the raw LF of
-// X and Y (needed by the MF band and by the bright-area suppression) and writes the
-// "vals" conversion of all three.
-struct PostLF {
-  float* lf_raw[2];
-  float* lf_vals[3];
-  GZ_DEVFN float operator()(size_t idx, const float* v) const {
-    lf_raw[0][idx] = v[0];
-    lf_raw[1][idx] = v[1];
-    float vx, vy, vb;
-    lf_to_vals(v[0], v[1], v[2], &vx, &vy, &vb);
-    lf_vals[0][idx] = vx;
-    lf_vals[1][idx] = vy;
-    lf_vals[2][idx] = vb;
-    return vy;
-  }
-  GZ_DEVFN void pair(size_t idx, const float* v0, const float* v1) const {
-    (void)(*this)(idx, v0);
-    (void)(*this)(idx + 1, v1);
-  }
-  GZ_DEVFN void quad(size_t idx, const gz_f4* v) const {
-    GZ_STG4(lf_raw[0], idx, v[0]);
-    GZ_STG4(lf_raw[1], idx, v[1]);
-    gz_f4 vx, vy, vb;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lf_to_vals(v[0].v[i], v[1].v[i], v[2].v[i], &vx.v[i], &vy.v[i], &vb.v[i]);
-    GZ_STG4(lf_vals[0], idx, vx);
-    GZ_STG4(lf_vals[1], idx, vy);
-    GZ_STG4(lf_vals[2], idx, vb);
-  }
-};
-
-// The same in two parts, for the X / Y planes and for the B plane (XybLowFreqToVals mixes the
+// LF band (butteraugli.cc:510, :606-621): v = blur(xyb, sigma_lf).  Keeps the raw LF of X and Y
+// (needed by the MF band and by the bright-area suppression) and writes the "vals" conversion of
+// all three -- in two parts, for the X / Y planes and for the B plane (XybLowFreqToVals mixes the
 // blurred Y into B, butteraugli.cc:386-389: the B part reads the raw LF of Y the first part
 // wrote): the B plane is needed by k_combine only, so its blur runs on a side stream beside the
 // MF / HF bands instead of in front of them.

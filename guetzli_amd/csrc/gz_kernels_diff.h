@@ -131,82 +131,13 @@ struct MaltaArgs {
   float* out;
 };
 
-// grid = (ceil(w/MW), ceil(h/MH), 2): blockIdx.z = channel (a0: Y, a1: X) -- the two
-// channels are independent, one launch fills the chip better than two
-template <int NPASS>
-__global__ __launch_bounds__(256) void k_malta(MaltaArgs<NPASS> a0, MaltaArgs<NPASS> a1, int w,
-                                               int h, int pitch) {
-  const GzTile bid = gz_xcd_tile();
-  const MaltaArgs<NPASS>& a = bid.z ? a1 : a0;
-  __shared__ __attribute__((aligned(16))) float tile[MH + 8][MW + 8];
-  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int x0 = bid.x * MW, y0 = bid.y * MH;
-  float acc[MPT];
-#pragma unroll
-  for (int i = 0; i < MPT; ++i) acc[i] = 0.0f;
-  // the haloed tile starts at x0 - 4: rows can be staged with aligned 16-byte loads when the
-  // tile lies inside the image horizontally and the pitch allows it
-  const bool vec = x0 >= 4 && x0 + MW + 4 <= w && (pitch & 3) == 0;
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const MaltaPass P = a.pass[ps];
-    if (ps > 0) __syncthreads();
-    if (vec) {
-      constexpr int NV = (MH + 8) * ((MW + 8) / 4);   // 16-byte vectors in the tile
-#pragma unroll 1
-      for (int k = 0; k < (NV + 255) / 256; ++k) {
-        const int i = 256 * k + (int)threadIdx.x;
-        if (i < NV) {
-          const int ry = i / ((MW + 8) / 4), q = i - ry * ((MW + 8) / 4);
-          const int y = y0 - 4 + ry;
-          gz_f4 v;
-          v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
-          if (y >= 0 && y < h) {
-            const size_t idx = (size_t)y * pitch + (x0 - 4 + 4 * q);
-            const gz_f4 u0 = GZ_LDG4(P.p0, idx), u1 = GZ_LDG4(P.p1, idx);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], P.nm);
-          }
-          *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = v;
-        }
-      }
-    } else {
-      for (int i = threadIdx.x; i < (MH + 8) * (MW + 8); i += 256) {
-        const int ry = i / (MW + 8), rx = i - ry * (MW + 8);
-        const int x = x0 - 4 + rx, y = y0 - 4 + ry;
-        float v = 0.0f;
-        if (x >= 0 && x < w && y >= 0 && y < h) {
-          const size_t idx = (size_t)y * pitch + x;
-          v = malta_diff(GZ_LDG(P.p0, idx), GZ_LDG(P.p1, idx), P.nm);
-        }
-        tile[ry][rx] = v;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < MPT; ++i) {
-      const int ly = tg * MPT + i;
-      const float r = P.lf ? malta_unit<true>(tile, ly + 4, tx + 4)
-                           : malta_unit<false>(tile, ly + 4, tx + 4);
-      acc[i] += r;
-    }
-  }
-  const int x = x0 + tx;
-  if (x >= w) return;
-#pragma unroll
-  for (int i = 0; i < MPT; ++i) {
-    const int y = y0 + tg * MPT + i;
-    if (y >= h) break;
-    const size_t idx = (size_t)y * pitch + x;
-    const float v = acc[i];
-    GZ_STG(a.out, idx, v);
-  }
-}
-
-// k_malta with the loop over a thread's 8 pixels left a loop and the pixels' accumulators in LDS:
-// one pixel's 16 line sums need a third of the registers all eight need side by side, and the
-// kernel's three phases per pass are bound by how many wavefronts a SIMD holds, not by a unit
-// (profiles/r03_chain_kernel_experiments.log) -- 8 wavefronts per SIMD instead of 4.  Same
-// operations per pixel in the same order.
+// grid = (ceil(w/MW), ceil(h/MH), 2): blockIdx.z = channel (a0: Y, a1: X) -- the two channels are
+// independent, one launch fills the chip better than two.  The loop over a thread's 8 pixels stays a
+// loop and the pixels' accumulators live in LDS: one pixel's 16 line sums need a third of the
+// registers all eight need side by side (59 VGPRs: 8 wavefronts per SIMD), and the kernel's three
+// phases per pass are bound by how many wavefronts a SIMD holds, not by a unit.  (Round 3 measured
+// the unrolled form, 120 VGPRs, and the line sums from a per-thread register window, 125 VGPRs and
+// 512 threads, against it: profiles/r03_chain_kernel_experiments.log; both were removed in round 4.)
 template <int NPASS>
 __global__ __launch_bounds__(256, 8) void k_malta_rolled(MaltaArgs<NPASS> a0, MaltaArgs<NPASS> a1, int w,
                                                int h, int pitch) {
@@ -273,115 +204,6 @@ __global__ __launch_bounds__(256, 8) void k_malta_rolled(MaltaArgs<NPASS> a0, Ma
     const size_t idx = (size_t)y * pitch + x;
     const float v = accs[i][threadIdx.x];
     GZ_STG(a.out, idx, v);
-  }
-}
-
-// ---- Malta from a register window -----------------------------------------------------
-// k_malta's line sums read every tap from LDS (ds_read2_b32: 128 bytes per clock and CU): 128
-// (HF) / 80 (LF) dwords per pixel and pass -- at 4K that is 54 / 34 us per pass of nothing but
-// LDS reads, 2 x (54 + 34 + 34) = 244 us of the kernel's 290, against ~80 us for the additions
-// themselves.  Here a thread takes WPX = 4 vertically consecutive pixels and first loads their
-// whole (WPX + 8) x 9 neighbourhood into registers -- 108 values for 4 pixels instead of 512 /
-// 320 tap reads -- then forms the 16 oriented sums of each pixel from registers, taps in the
-// reference's order.  A 64 x 32 tile is a workgroup of 512 threads (8 wavefronts).
-constexpr int WPX = 4;
-
-// The 16 oriented sums of the WPX pixels, orientation by orientation with the pixels' sums side
-// by side: WPX independent chains of additions in flight instead of one (a wavefront issues in
-// order, and a sum is a chain of dependent additions).  Per pixel the operations and their order
-// are malta_unit's.
-template <bool LF>
-GZ_DEVFN void malta_units_win(const float (&win)[WPX + 8][9], float* acc) {
-  float ret[WPX];
-#pragma unroll
-  for (int i = 0; i < WPX; ++i) ret[i] = 0.0f;
-#pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    float sum[WPX];
-    constexpr int kMaxTaps = LF ? 5 : 9;
-#pragma unroll
-    for (int k = 0; k < kMaxTaps; ++k) {
-      if (LF || k < kMaltaHFCount[o]) {
-        const int dy = LF ? kMaltaLF[o][k][0] : kMaltaHF[o][k][0];
-        const int dx = LF ? kMaltaLF[o][k][1] : kMaltaHF[o][k][1];
-#pragma unroll
-        for (int i = 0; i < WPX; ++i) {
-          const float v = win[i + 4 + dy][4 + dx];
-          sum[i] = k == 0 ? v : sum[i] + v;
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < WPX; ++i) ret[i] += sum[i] * sum[i];
-  }
-#pragma unroll
-  for (int i = 0; i < WPX; ++i) acc[i] += ret[i];
-}
-
-template <int NPASS>
-__global__ __launch_bounds__(512) void k_malta_win(MaltaArgs<NPASS> a0, MaltaArgs<NPASS> a1, int w,
-                                                   int h, int pitch) {
-  const GzTile bid = gz_xcd_tile();
-  const MaltaArgs<NPASS>& a = bid.z ? a1 : a0;
-  __shared__ __attribute__((aligned(16))) float tile[MH + 8][MW + 8];
-  const int tx = threadIdx.x & 63, tg = threadIdx.x >> 6;   // 8 row groups of WPX rows
-  const int x0 = bid.x * MW, y0 = bid.y * MH;
-  float acc[WPX];
-#pragma unroll
-  for (int i = 0; i < WPX; ++i) acc[i] = 0.0f;
-  const bool vec = x0 >= 4 && x0 + MW + 4 <= w && (pitch & 3) == 0;
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const MaltaPass P = a.pass[ps];
-    if (ps > 0) __syncthreads();
-    if (vec) {
-      constexpr int NV = (MH + 8) * ((MW + 8) / 4);   // 16-byte vectors in the tile
-#pragma unroll 1
-      for (int k = 0; k < (NV + 511) / 512; ++k) {
-        const int i = 512 * k + (int)threadIdx.x;
-        if (i < NV) {
-          const int ry = i / ((MW + 8) / 4), q = i - ry * ((MW + 8) / 4);
-          const int y = y0 - 4 + ry;
-          gz_f4 v;
-          v.v[0] = v.v[1] = v.v[2] = v.v[3] = 0.0f;
-          if (y >= 0 && y < h) {
-            const size_t idx = (size_t)y * pitch + (x0 - 4 + 4 * q);
-            const gz_f4 u0 = GZ_LDG4(P.p0, idx), u1 = GZ_LDG4(P.p1, idx);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], P.nm);
-          }
-          *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = v;
-        }
-      }
-    } else {
-      for (int i = threadIdx.x; i < (MH + 8) * (MW + 8); i += 512) {
-        const int ry = i / (MW + 8), rx = i - ry * (MW + 8);
-        const int x = x0 - 4 + rx, y = y0 - 4 + ry;
-        float v = 0.0f;
-        if (x >= 0 && x < w && y >= 0 && y < h) {
-          const size_t idx = (size_t)y * pitch + x;
-          v = malta_diff(GZ_LDG(P.p0, idx), GZ_LDG(P.p1, idx), P.nm);
-        }
-        tile[ry][rx] = v;
-      }
-    }
-    __syncthreads();
-    // the neighbourhood of this thread's WPX pixels: rows tg * WPX .. + WPX + 7 of the haloed
-    // tile, columns tx .. tx + 8
-    float win[WPX + 8][9];
-#pragma unroll
-    for (int r = 0; r < WPX + 8; ++r)
-#pragma unroll
-      for (int cx = 0; cx < 9; ++cx) win[r][cx] = tile[tg * WPX + r][tx + cx];
-    if (P.lf) malta_units_win<true>(win, acc);
-    else malta_units_win<false>(win, acc);
-  }
-  const int x = x0 + tx;
-  if (x >= w) return;
-#pragma unroll
-  for (int i = 0; i < WPX; ++i) {
-    const int y = y0 + tg * WPX + i;
-    if (y >= h) break;
-    GZ_STG(a.out, (size_t)y * pitch + x, acc[i]);
   }
 }
 

@@ -128,9 +128,8 @@ constexpr int kEvalBatch = 3;
 
 struct SearchLds {
   short coef[192];
-  int ycc[3][64];       // pixel cache of the current (processed) block
+  unsigned char ycc[3][64];   // pixel cache of the current (processed) block (values 0..255)
   float x0[3][64];      // original block's opsin image (per_block_pregamma_)
-  float lut[256];
   unsigned char list[192];
   unsigned char oidx[192];
   float oerr[192];
@@ -151,15 +150,25 @@ struct SearchLds {
   double red[kEvalBatch][3];
   float err[kEvalBatch];
   int num;
-  // 4:2:0 chroma search only: the 10x10 subsampled samples around the 16x16 block
-  // (UpdatePixelsForBlock's `subsampled`, output_image.cc:150-183) per chroma component
-  int s10[2][100];
-  short cellsrc[100];   // >= 0: the cell is sample cellsrc of the block itself; -1: a neighbour's
+};
+// One wavefront's share of LDS decides how many of them a SIMD holds: 160 KB / 16 = 10 240 bytes
+// for four per SIMD.  Round 4 took the struct from 12 672 to 10 064 bytes: the sRGB table is read
+// from global memory (1 KB per wavefront for three L1-resident loads per evaluation), the pixel
+// cache holds bytes, and what only the 4:2:0 chroma search needs lives in a struct of its own.
+static_assert(sizeof(SearchLds) <= 10240 - 64, "k_block_search: four wavefronts per SIMD need <= 10 KB of LDS each");
+
+// 4:2:0 chroma search only (MODE 2): the 10x10 subsampled samples around the 16x16 block
+// (UpdatePixelsForBlock's `subsampled`, output_image.cc:150-183) per chroma component.
+template <bool ON>
+struct SearchLds420 {
+  int s10[2][ON ? 100 : 1];
+  short cellsrc[ON ? 100 : 2];   // >= 0: the cell is sample cellsrc of the block itself; -1: a neighbour's
 };
 
 // Integer IDCT of s.coef[c] with coefficient `zero_k` forced to 0 (or -1: none); result of
 // this lane's pixel returned, and left in `dst[lane]` after the trailing barrier.
-GZ_DEVFN void idct_component(SearchLds& s, int c, int zero_k, int lane, int* dst) {
+template <class T>
+GZ_DEVFN void idct_component(SearchLds& s, int c, int zero_k, int lane, T* dst) {
   const int iy = lane >> 3, ix = lane & 7;
   s.in[lane] = lane == zero_k ? 0 : (int)s.coef[64 * c + lane];
   __syncthreads();
@@ -171,7 +180,7 @@ GZ_DEVFN void idct_component(SearchLds& s, int c, int zero_k, int lane, int* dst
   acc = 0;
 #pragma unroll
   for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s.col[8 * iy + u]);
-  dst[lane] = clamp255((acc + (257 << 17)) >> 18);
+  dst[lane] = (T)clamp255((acc + (257 << 17)) >> 18);
   __syncthreads();
 }
 
@@ -210,10 +219,10 @@ GZ_DEVFN void opsin8x8(SearchLds& s, int lane, const SearchArgs& a, float* ox, f
 // own samples taken from `own` (an 8x8 IDCT result), and this lane's upsampled + rounded pixel
 // (UpdatePixelsForBlock's fancy upsampler :192-203, then ToPixels :82) of the 8x8 sub-block
 // (off_x, off_y) of the 16x16 area.
-GZ_DEVFN void fill_s10(SearchLds& s, int cc, const int* own, const int* ring, int lane) {
+GZ_DEVFN void fill_s10(SearchLds420<true>& q, int cc, const int* own, const int* ring, int lane) {
   for (int cell = lane; cell < 100; cell += 64) {
-    const int src = s.cellsrc[cell];
-    s.s10[cc - 1][cell] = src >= 0 ? own[src] : ring[cell];
+    const int src = q.cellsrc[cell];
+    q.s10[cc - 1][cell] = src >= 0 ? own[src] : ring[cell];
   }
   __syncthreads();
 }
@@ -243,8 +252,8 @@ struct SearchView {
 // Wide stages of CompareBlock for this wavefront's 8x8 window with coefficient `ci`
 // (= c*64+k) zeroed: the opsin differences of the candidate go to s.d[slot].
 template <int MODE>
-GZ_DEVFN void eval_wide(SearchLds& s, int ci, int slot, int lane, const SearchView& v,
-                        const int* ring, const SearchArgs& a) {
+GZ_DEVFN void eval_wide(SearchLds& s, SearchLds420<MODE == 2>& q, int ci, int slot, int lane,
+                        const SearchView& v, const int* ring, const SearchArgs& a) {
   // ci == 64 * 3: nothing zeroed (the luma component is simply recomputed)
   const int cc = ci >= 192 ? 0 : ci >> 6, kk = ci >= 192 ? -1 : ci & 63;
   idct_component(s, cc, kk, lane, s.cpx);
@@ -253,9 +262,9 @@ GZ_DEVFN void eval_wide(SearchLds& s, int ci, int slot, int lane, const SearchVi
   const int sx = ix < v.vw ? ix : v.vw - 1, sy = iy < v.vh ? iy : v.vh - 1;
   const int sp = 8 * sy + sx;
   int py, pcb, pcr;
-  if (MODE == 2) {
-    fill_s10(s, cc, s.cpx, ring + 100 * (cc - 1), lane);
-    const int px = upsampled_pixel(s.s10[cc - 1], 8 * v.off_x + sx, 8 * v.off_y + sy);
+  if constexpr (MODE == 2) {
+    fill_s10(q, cc, s.cpx, ring + 100 * (cc - 1), lane);
+    const int px = upsampled_pixel(q.s10[cc - 1], 8 * v.off_x + sx, 8 * v.off_y + sy);
     py = s.ycc[0][sp];
     pcb = (cc == 1 ? px : s.ycc[1][sp]) - 128;
     pcr = (cc == 2 ? px : s.ycc[2][sp]) - 128;
@@ -268,9 +277,9 @@ GZ_DEVFN void eval_wide(SearchLds& s, int ci, int slot, int lane, const SearchVi
   const int r = clamp255(py + ((GZ_MUL24(91881, pcr) + half) >> 16));
   const int g = clamp255(py + ((GZ_MUL24(-46802, pcr) + (GZ_MUL24(-22554, pcb) + half)) >> 16));
   const int b = clamp255(py + ((GZ_MUL24(116130, pcb) + half) >> 16));
-  s.lin[0][lane] = s.lut[r];
-  s.lin[1][lane] = s.lut[g];
-  s.lin[2][lane] = s.lut[b];
+  s.lin[0][lane] = GZ_LDG(a.srgb_lut, r);
+  s.lin[1][lane] = GZ_LDG(a.srgb_lut, g);
+  s.lin[2][lane] = GZ_LDG(a.srgb_lut, b);
   __syncthreads();
   float x, y, z;
   opsin8x8(s, lane, a, &x, &y, &z);
@@ -352,14 +361,19 @@ GZ_DEVFN void eval_narrow(SearchLds& s, int nc, int lane, const SearchView& v) {
 }
 
 // grid = one workgroup per block of the search grid; 64 threads (MODE 0, 1) or 256 (MODE 2).
+#ifndef GZ_SEARCH_WPS
+#define GZ_SEARCH_WPS 4   // wavefronts per SIMD the register allocation aims for (<= 128 VGPRs)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArgs a) {
+__global__ __launch_bounds__(MODE == 2 ? 256 : 64, MODE == 2 ? 3 : GZ_SEARCH_WPS) void k_block_search(SearchArgs a) {
   constexpr int NW = MODE == 2 ? 4 : 1;
   __shared__ SearchLds sh[NW];
+  __shared__ SearchLds420<MODE == 2> sq[NW];
   __shared__ int s_ring[MODE == 2 ? 200 : 1];      // neighbours' samples around the block, fixed
   __shared__ float s_err[kEvalBatch][4];
   const int wave = MODE == 2 ? (int)(threadIdx.x >> 6) : 0, lane = threadIdx.x & 63;
   SearchLds& s = sh[wave];
+  SearchLds420<MODE == 2>& q = sq[wave];
   const int blk = blockIdx.x;
   const int gw = MODE == 2 ? a.cbw : a.bw;      // width of the search grid
   const int gbx = blk % gw, gby = blk / gw;
@@ -374,7 +388,6 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
   if (v.vw < 1) v.vw = 1;                   // (sub-blocks outside the image: evaluated, ignored)
   if (v.vh < 1) v.vh = 1;
   const int iy = lane >> 3, ix = lane & 7;
-  for (int i = lane; i < 256; i += 64) s.lut[i] = a.srgb_lut[i];
   for (int c = 0; c < 3; ++c) {
     const bool mine = MODE == 0 || (MODE == 1 && c == 0) || (MODE == 2 && c > 0);
     s.coef[64 * c + lane] = mine ? a.coeffs[((size_t)a.coff[c] + blk) * 64 + lane] : (short)0;
@@ -388,9 +401,9 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
     const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
     const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
     const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
-    s.lin[0][lane] = s.lut[p[0]];
-    s.lin[1][lane] = s.lut[p[1]];
-    s.lin[2][lane] = s.lut[p[2]];
+    s.lin[0][lane] = GZ_LDG(a.srgb_lut, p[0]);
+    s.lin[1][lane] = GZ_LDG(a.srgb_lut, p[1]);
+    s.lin[2][lane] = GZ_LDG(a.srgb_lut, p[2]);
     __syncthreads();
     float x0, y0, z0;
     opsin8x8(s, lane, a, &x0, &y0, &z0);
@@ -399,16 +412,16 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
     s.x0[2][lane] = z0;
   }
   const int mxs = (a.w - 1) >> 1, mys = (a.h - 1) >> 1;
-  if (MODE == 0) {
+  if constexpr (MODE == 0) {
     for (int c = 0; c < 3; ++c) idct_component(s, c, -1, lane, s.ycc[c]);
-  } else if (MODE == 1) {
+  } else if constexpr (MODE == 1) {
     idct_component(s, 0, -1, lane, s.ycc[0]);
     const int sw = a.cbw * 8;
     const size_t pl = (size_t)sw * (size_t)(((a.h + 15) >> 4) * 8);
     const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
     const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
-    s.ycc[1][lane] = chroma420_pixel(a.samples, sw, mxs, mys, x, y);
-    s.ycc[2][lane] = chroma420_pixel(a.samples + pl, sw, mxs, mys, x, y);
+    s.ycc[1][lane] = (unsigned char)chroma420_pixel(a.samples, sw, mxs, mys, x, y);
+    s.ycc[2][lane] = (unsigned char)chroma420_pixel(a.samples + pl, sw, mxs, mys, x, y);
     __syncthreads();
   } else {
     // luma pixels of this wavefront's 8x8 sub-block (fixed during the chroma search)
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
       acc = 0;
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s.col[8 * iy + u]);
-      s.ycc[0][lane] = clamp255((acc + (257 << 17)) >> 18);
+      s.ycc[0][lane] = (unsigned char)clamp255((acc + (257 << 17)) >> 18);
       __syncthreads();
     }
     // the 10x10 neighbourhood: which cells are the block's own samples (after the replication
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
       gy = gy < 0 ? 0 : (gy > mys ? mys : gy);
       const int lx = gx - 8 * gbx, ly = gy - 8 * gby;
       const bool own = lx >= 0 && lx < 8 && ly >= 0 && ly < 8;
-      s.cellsrc[cell] = own ? (short)(8 * ly + lx) : (short)-1;
+      q.cellsrc[cell] = own ? (short)(8 * ly + lx) : (short)-1;
       if (wave == 0) {
         s_ring[cell] = (int)a.samples[(size_t)gy * sw + gx];
         s_ring[100 + cell] = (int)a.samples[pl + (size_t)gy * sw + gx];
@@ -446,8 +459,8 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
     __syncthreads();
     for (int c = 1; c < 3; ++c) {
       idct_component(s, c, -1, lane, s.cpx);
-      fill_s10(s, c, s.cpx, s_ring + 100 * (c - 1), lane);
-      s.ycc[c][lane] = upsampled_pixel(s.s10[c - 1], 8 * v.off_x + ix, 8 * v.off_y + iy);
+      fill_s10(q, c, s.cpx, s_ring + 100 * (c - 1), lane);
+      s.ycc[c][lane] = (unsigned char)upsampled_pixel(q.s10[c - 1], 8 * v.off_x + ix, 8 * v.off_y + iy);
       __syncthreads();
     }
   }
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
     const int tries = n < a.lookahead ? n : a.lookahead;
     for (int base = 0; base < tries; base += kEvalBatch) {
       const int nc = tries - base < kEvalBatch ? tries - base : kEvalBatch;
-      for (int j = 0; j < nc; ++j) eval_wide<MODE>(s, (int)s.list[base + j], j, lane, v, s_ring, a);
+      for (int j = 0; j < nc; ++j) eval_wide<MODE>(s, q, (int)s.list[base + j], j, lane, v, s_ring, a);
       eval_narrow(s, nc, lane, v);
       if (MODE == 2) {
         if (lane < nc) s_err[lane][wave] = v.in_image ? s.err[lane] : 0.0f;
@@ -504,11 +517,11 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64) void k_block_search(SearchArg
     }
     ++m;
     --n;
-    if (MODE == 2) {
+    if constexpr (MODE == 2) {
       const int c = ci >> 6;
       idct_component(s, c, -1, lane, s.cpx);
-      fill_s10(s, c, s.cpx, s_ring + 100 * (c - 1), lane);
-      s.ycc[c][lane] = upsampled_pixel(s.s10[c - 1], 8 * v.off_x + ix, 8 * v.off_y + iy);
+      fill_s10(q, c, s.cpx, s_ring + 100 * (c - 1), lane);
+      s.ycc[c][lane] = (unsigned char)upsampled_pixel(q.s10[c - 1], 8 * v.off_x + ix, 8 * v.off_y + iy);
       __syncthreads();
     } else {
       idct_component(s, ci >> 6, -1, lane, s.ycc[ci >> 6]);
@@ -548,16 +561,15 @@ __global__ __launch_bounds__(64) void k_compare_blocks(SearchArgs a, const int32
   const int bx = block_xy[2 * i], by = block_xy[2 * i + 1];
   const int xmin = 8 * bx, ymin = 8 * by;
   const int iy = lane >> 3, ix = lane & 7;
-  for (int k = lane; k < 256; k += 64) s.lut[k] = a.srgb_lut[k];
   for (int c = 0; c < 3; ++c) s.coef[64 * c + lane] = blocks[((size_t)i * 3 + c) * 64 + lane];
   __syncthreads();
   {
     const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
     const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
     const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
-    s.lin[0][lane] = s.lut[p[0]];
-    s.lin[1][lane] = s.lut[p[1]];
-    s.lin[2][lane] = s.lut[p[2]];
+    s.lin[0][lane] = GZ_LDG(a.srgb_lut, p[0]);
+    s.lin[1][lane] = GZ_LDG(a.srgb_lut, p[1]);
+    s.lin[2][lane] = GZ_LDG(a.srgb_lut, p[2]);
     __syncthreads();
     float x0, y0, z0;
     opsin8x8(s, lane, a, &x0, &y0, &z0);
@@ -576,7 +588,8 @@ __global__ __launch_bounds__(64) void k_compare_blocks(SearchArgs a, const int32
   v.m1 = a.block_mask[a.nb + mb];
   v.m2 = a.block_mask[2 * a.nb + mb];
   // candidate index 192: the luma component is recomputed with no coefficient zeroed
-  eval_wide<0>(s, 192, 0, lane, v, nullptr, a);
+  SearchLds420<false> q;   // (unused by this mode)
+  eval_wide<0>(s, q, 192, 0, lane, v, nullptr, a);
   eval_narrow(s, 1, lane, v);
   if (lane == 0) {
     double diff = 0.0;
@@ -600,15 +613,13 @@ __global__ __launch_bounds__(64) void k_compare_block_pixels(SearchArgs a, const
   const int bx = block_xy[2 * i], by = block_xy[2 * i + 1];
   const int xmin = 8 * bx, ymin = 8 * by;
   const int iy = lane >> 3, ix = lane & 7;
-  for (int k = lane; k < 256; k += 64) s.lut[k] = a.srgb_lut[k];
-  __syncthreads();
   {
     const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
     const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
     const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
-    s.lin[0][lane] = s.lut[p[0]];
-    s.lin[1][lane] = s.lut[p[1]];
-    s.lin[2][lane] = s.lut[p[2]];
+    s.lin[0][lane] = GZ_LDG(a.srgb_lut, p[0]);
+    s.lin[1][lane] = GZ_LDG(a.srgb_lut, p[1]);
+    s.lin[2][lane] = GZ_LDG(a.srgb_lut, p[2]);
     __syncthreads();
     float x0, y0, z0;
     opsin8x8(s, lane, a, &x0, &y0, &z0);
@@ -620,9 +631,9 @@ __global__ __launch_bounds__(64) void k_compare_block_pixels(SearchArgs a, const
     const uint8_t* p = ycc + (size_t)i * 192;
     int r, g, b;
     ycc_to_rgb((int)p[lane], (int)p[64 + lane], (int)p[128 + lane], &r, &g, &b);
-    s.lin[0][lane] = s.lut[r];
-    s.lin[1][lane] = s.lut[g];
-    s.lin[2][lane] = s.lut[b];
+    s.lin[0][lane] = GZ_LDG(a.srgb_lut, r);
+    s.lin[1][lane] = GZ_LDG(a.srgb_lut, g);
+    s.lin[2][lane] = GZ_LDG(a.srgb_lut, b);
     __syncthreads();
     float x, y, z;
     opsin8x8(s, lane, a, &x, &y, &z);

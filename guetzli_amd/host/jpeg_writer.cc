@@ -72,11 +72,6 @@ void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_
     HuffmanDepthsUncached(counts, length, tree_limit, depth);
     return;
   }
-  static const bool no_memo = getenv("GZ_NO_HUFF_MEMO") != nullptr;
-  if (no_memo) {
-    HuffmanDepthsUncached(counts, length, tree_limit, depth);
-    return;
-  }
   static thread_local HuffMemo memo = {};
   for (int s = 0; s < HuffMemo::kSlots; ++s)
     if (memo.valid[s] && memo.limit[s] == tree_limit &&

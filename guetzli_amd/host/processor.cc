@@ -277,6 +277,9 @@ class Encoder {
                  size_t* size);
   bool SerializeBegin(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac);
   bool SerializeEnd(const int (*q)[64], size_t* size);
+  bool PrepareHead(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac);
+  bool ScanBegin();
+  size_t SizeLowerBound() const;
   bool CompareBegin();
   bool CompareCurrent();
   bool MaybeOutput(size_t size);
@@ -334,15 +337,14 @@ class Encoder {
   long n_dev_partitions_ = 0, n_dev_fetched_ = 0, n_dev_replayed_ = 0;
   double t_pb_descend_ = 0;
   long n_dev_exported_ = 0;
-  // GZ_ORDER_DESCEND=0: the host asks for every introsort partition itself (round 2's path)
-  bool descend_ = true;
   int descend_levels_ = 6;      // levels to enqueue per descent (follows what the orders need)
   long n_fast_ = 0;
+  long n_scans_ = 0, n_scans_skipped_ = 0;   // candidates entropy-coded / known to lose without it
+  uint64_t head_bits_ = 0;                   // scan bits of the candidate head_ was built for
   double t_pb_order_ = 0, t_pb_sort_ = 0, t_pb_loop_ = 0, t_pb_codes_ = 0;
   long n_steps_ = 0, n_order_ = 0, n_evaluations_ = 0;
   // where the host's time goes at the end of an iteration (stats_->timers)
   double t_head_ = 0, t_cmp_begin_ = 0, t_cmp_end_ = 0, t_scan_begin_ = 0, t_scan_end_ = 0, t_ahead_begin_ = 0;
-  bool build_ahead_ = true;     // GZ_ORDER_AHEAD=0: build each order when the loop asks for it
   size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device (32-64 K measured best at 1080p and 4K)
 };
 
@@ -436,6 +438,14 @@ bool Encoder::Serialize(const int (*q)[64], const SymbolHistogram* dc, const Sym
 // enqueueing (the next order's construction) while the entropy coder runs beside the
 // evaluation.  _End collects the scan's length.
 bool Encoder::SerializeBegin(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac) {
+  return PrepareHead(q, dc, ac) && ScanBegin();
+}
+
+// The host's half of a candidate's JPEG: marker segments and Huffman codes (head_), and -- from the
+// same symbol statistics -- the exact number of bits of its scan: every symbol occurrence costs its
+// code length plus its extra bits (the low nibble of an AC symbol, the category of a DC symbol:
+// jpeg_data_writer.cc:446-497), so the scan is head_bits_ long before a single bit is written.
+bool Encoder::PrepareHead(const int (*q)[64], const SymbolHistogram* dc, const SymbolHistogram* ac) {
   Stopwatch sw;
   Frame f;
   // a single component is written when both chroma planes are entirely zero
@@ -452,11 +462,28 @@ bool Encoder::SerializeBegin(const int (*q)[64], const SymbolHistogram* dc, cons
     ac = ac1;
   }
   if (!BuildJpegHead(f, dc, ac, &head_)) return Fail("BuildJpegHead", GZ_E_STATE);
+  head_bits_ = 0;
+  for (int c = 0; c < head_.ncomp; ++c)
+    head_bits_ += (uint64_t)HistogramRawBits(dc[c], head_.depth[0][c]) +
+                  (uint64_t)HistogramRawBits(ac[c], head_.depth[1][c]);
   { const double d = sw.lap(); t_write_ += d; t_head_ += d; }
+  return true;
+}
+
+bool Encoder::ScanBegin() {
+  Stopwatch sw;
   const int rc = gz_jpeg_scan_begin(ctx_, head_.ncomp, &head_.depth[0][0][0], &head_.code[0][0][0]);
   { const double d = sw.lap(); t_write_ += d; t_scan_begin_ += d; }
   if (rc != GZ_OK) return Fail("gz_jpeg_scan", rc);
   return true;
+}
+
+// What the candidate's JPEG weighs at least: its head, its scan's bits as bytes -- the 0x00 stuffed
+// behind every 0xFF byte of the scan (jpeg_bit_writer.h:62-70) only adds to that -- and EOI.
+size_t Encoder::SizeLowerBound() const {
+  size_t size = head_.bytes.size() + (size_t)((head_bits_ + 7) / 8) + 2;
+  if (jpeg_input_ && !meta_.strip) size += meta_.tail_data.size();
+  return size;
 }
 bool Encoder::SerializeEnd(const int (*q)[64], size_t* size) {
   Stopwatch sw;
@@ -466,6 +493,17 @@ bool Encoder::SerializeEnd(const int (*q)[64], size_t* size) {
   *size = head_.bytes.size() + (size_t)scan_bytes + 2;   // + EOI
   if (jpeg_input_ && !meta_.strip) *size += meta_.tail_data.size();
   { const double d = sw.lap(); t_write_ += d; t_scan_end_ += d; }
+  ++n_scans_;
+  if (verify_) {   // GZ_VERIFY_ENTROPY: the bit count derived from the statistics is the coder's
+    uint64_t bits = 0, ff = 0;
+    const int rb = gz_jpeg_scan_bits(ctx_, &bits, &ff);
+    if (rb != GZ_OK) return Fail("gz_jpeg_scan_bits", rb);
+    if (bits != head_bits_ || (bits + 7) / 8 + ff != scan_bytes || SizeLowerBound() > *size) {
+      fprintf(stderr, "guetzli_amd: scan of %llu bits (+%llu stuffed bytes), the symbol statistics say %llu\n",
+              (unsigned long long)bits, (unsigned long long)ff, (unsigned long long)head_bits_);
+      return false;
+    }
+  }
   if (verify_ && !VerifyAgainstHostWriter(q, *size)) return false;
   return true;
 }
@@ -685,8 +723,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   std::vector<int32_t> edit_pos;       // coefficient changes of one iteration
   std::vector<int16_t> edit_val;
   // host copy of the ranges that were fetched: in the context's page-locked mirror (the fetches
-  // are then single DMA transfers), or, GZ_ORDER_PINNED=0, in an ordinary array
-  static const bool pinned_order = !(getenv("GZ_ORDER_PINNED") && atoi(getenv("GZ_ORDER_PINNED")) == 0);
+  // are then single DMA transfers)
   std::pair<int, float>* order = nullptr;
   std::vector<char> touched(nb);
   std::vector<int32_t> dirty;
@@ -721,7 +758,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         int32_t btc = 0;
         if (radius == 1 && ahead == direction && !first_up) {
           rc = gz_order_build_auto_end(ctx_, &total, &btc, &below);
-          if (rc == GZ_OK && descend_) {
+          if (rc == GZ_OK) {
             rc = gz_order_descend_end(ctx_, ahead_log, 12, &ahead_levels, &ahead_last);
             have_ahead_log = rc == GZ_OK && ahead_levels > 0;
           }
@@ -739,14 +776,11 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       t_pb_order_ += pw.lap();
       if (total == 0) break;
       n_order_ += (long)total;
-      if (pinned_order) {
+      {
         void* mirror = nullptr;
         rc = gz_order_host_mirror(ctx_, total, &mirror);
         if (rc != GZ_OK) return Fail("gz_order_host_mirror", rc);
         order = static_cast<std::pair<int, float>*>(mirror);
-      } else {
-        if (order_.size() < total) order_.resize(total);
-        order = order_.data();
       }
 
       // The reference std::sort-s `order` here (processor.cc:675-678) and then consumes a
@@ -826,7 +860,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         // The introsort partitions that lead to position fast_until - 1, made by the device
         // without the host in between: behind the order's construction when that was enqueued
         // ahead (the device derives the position as the lines above do), else now, in one call.
-        if (descend_ && n_order > device_threshold_) {
+        if (n_order > device_threshold_) {
           const uint64_t want = fast_until ? fast_until - 1 : 0;
           if (have_ahead_log) {
             if (ahead_last != want) return Fail("gz_order_descend: position", GZ_E_STATE);
@@ -851,7 +885,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
               // ... unless the device has put exactly that prefix into the mirror already, behind
               // the descent it made ahead (k_desc_export)
               uint64_t exported = 0;
-              if (have_ahead_log && pinned_order) {
+              if (have_ahead_log) {
                 rc = gz_order_exported(ctx_, &exported);
                 if (rc != GZ_OK) return Fail("gz_order_exported", rc);
               }
@@ -970,41 +1004,51 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
 
       size_t jpg_size = 0;
       if (!CompareBegin()) return false;
+      // The candidate's exact size is observable in two places only: the --verbose trace
+      // (Out[...], EstErr[...]) and MaybeOutput's comparison of scores (processor.cc:139-148,767).
+      // Its head and the exact length of its scan in bits follow from the symbol statistics the
+      // host holds anyway (PrepareHead); only the bytes stuffed behind 0xFF need the coder.  Without
+      // a trace the candidate is therefore entropy-coded only if it can win: ScoreJPEG grows with
+      // the size, so a candidate whose score at its size's LOWER bound does not beat the best so
+      // far loses whatever it weighs -- 140 of the 149 candidates of a 4K encode at quality 95,
+      // whose evaluation then has the device to itself (the coder's kernels took a sixth of the
+      // summed kernel time, profiles/r03_bench_kernel_stats.csv).
+      const bool every_size = stats_->debug_output || stats_->debug_output_file || verify_;
+      if (!PrepareHead(quant_, dc_histo, ac_histo)) return false;
       // the entropy coder goes to its own stream before anything else is enqueued: it runs beside
       // the evaluation, not behind the host work below
-      if (!SerializeBegin(quant_, dc_histo, ac_histo)) return false;
+      if (every_size && !ScanBegin()) return false;
       Stopwatch aw;
-      if (build_ahead_) {
+      {
         // the next iteration of this direction, radius 1, if it comes to that (processor.cc:
         // 622-663 behind :767): everything it reads is final -- next_cand, max_block_error
-        // (gz_order_advance above), and the distance map the device is about to produce
-        static const bool one_transfer = !(getenv("GZ_ORDER_ONE_TRANSFER") && atoi(getenv("GZ_ORDER_ONE_TRANSFER")) == 0);
-        if (descend_ && one_transfer) {
-          // ... with the descent behind it, and everything the host waits for at this point (the
-          // order's size and counters, the descent's cuts, the candidate's distance) in one transfer
-          rc = gz_order_build_auto_descend_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
-                                                 below_limit, per_block, device_threshold_, descend_levels_);
-          if (rc != GZ_OK) return Fail("gz_order_build_auto_descend_begin", rc);
-        } else {
-          rc = gz_order_build_auto_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
-                                         below_limit);
-          if (rc != GZ_OK) return Fail("gz_order_build_auto_begin", rc);
-          if (descend_) {   // (GZ_ORDER_ONE_TRANSFER=0: the two calls, four transfers)
-            rc = gz_order_descend_begin(ctx_, per_block, device_threshold_, descend_levels_);
-            if (rc != GZ_OK) return Fail("gz_order_descend_begin", rc);
-          }
-        }
+        // (gz_order_advance above), and the distance map the device is about to produce -- with the
+        // descent behind it, and everything the host waits for at this point (the order's size and
+        // counters, the descent's cuts, the candidate's distance) in one transfer
+        rc = gz_order_build_auto_descend_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
+                                               below_limit, per_block, device_threshold_, descend_levels_);
+        if (rc != GZ_OK) return Fail("gz_order_build_auto_descend_begin", rc);
         ahead = direction;
       }
       t_ahead_begin_ += aw.lap();
-      if (!SerializeEnd(quant_, &jpg_size)) return false;
-      Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
-          "EstErr[%.2f%%]",
-          stats_->counters[kNumItersCnt], FrameStr(), comp_mask, direction > 0 ? "up" : "down",
-          changed_coeffs, order_size, dirty.size(), blocks_to_change, nb, val_threshold,
-          jpg_size, 100.0 - (100.0 * est_size) / jpg_size);
-      if (!CompareCurrent()) return false;
-      if (!MaybeOutput(jpg_size)) return false;
+      if (every_size) {
+        if (!SerializeEnd(quant_, &jpg_size)) return false;
+        Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
+            "EstErr[%.2f%%]",
+            stats_->counters[kNumItersCnt], FrameStr(), comp_mask, direction > 0 ? "up" : "down",
+            changed_coeffs, order_size, dirty.size(), blocks_to_change, nb, val_threshold,
+            jpg_size, 100.0 - (100.0 * est_size) / jpg_size);
+        if (!CompareCurrent()) return false;
+        if (!MaybeOutput(jpg_size)) return false;
+      } else {
+        if (!CompareCurrent()) return false;
+        if (best_score_ < 0 ||
+            ScoreJPEG(distance_, (int)SizeLowerBound(), params_.butteraugli_target) < best_score_) {
+          if (!ScanBegin() || !SerializeEnd(quant_, &jpg_size) || !MaybeOutput(jpg_size)) return false;
+        } else {
+          ++n_scans_skipped_;
+        }
+      }
       prev_size = est_size;
       sw.lap();
     }
@@ -1019,8 +1063,6 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   const int w = w_, h = h_;
   // the original as the fallback output (processor.cc:826-846)
   verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
-  if (const char* e = getenv("GZ_ORDER_AHEAD")) build_ahead_ = atoi(e) != 0;
-  if (const char* e = getenv("GZ_ORDER_DESCEND")) descend_ = atoi(e) != 0;
   if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
   best_score_ = -1;
   QuantMatrix ones;
@@ -1139,6 +1181,8 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->timers["pb_loop_fast_steps"] = t_pb_fast_;
   stats_->counters["block search evaluations"] = (int)std::min<long>(n_evaluations_, 2000000000L);
   stats_->counters["phase B fast steps"] = (int)n_fast_;
+  stats_->counters["candidates entropy-coded"] = (int)n_scans_;
+  stats_->counters["candidates rejected on their size bound"] = (int)n_scans_skipped_;
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
   if (best_on_host_) {

@@ -419,6 +419,12 @@ int gz_jpeg_scan(gz_ctx* ctx, int ncomp, const uint8_t* depth, const uint16_t* c
 int gz_jpeg_scan_begin(gz_ctx* ctx, int ncomp, const uint8_t* depth, const uint16_t* code);
 int gz_jpeg_scan_end(gz_ctx* ctx, uint64_t* scan_bytes);
 int gz_jpeg_scan_keep(gz_ctx* ctx);
+/* Of the last scan: its length in bits (before byte stuffing and padding) and the number of 0xFF
+ * bytes it holds, i.e. of 0x00 bytes stuffed: scan_bytes = ceil(bits / 8) + stuffed.  The bit
+ * count is a function of the symbol statistics and the code lengths alone (every occurrence costs
+ * its code plus its extra bits, jpeg_data_writer.cc:446-497); the host driver derives it that way
+ * to bound a candidate's size without coding it, and checks itself against this. */
+int gz_jpeg_scan_bits(gz_ctx* ctx, uint64_t* bits, uint64_t* stuffed);
 int gz_jpeg_scan_bytes(gz_ctx* ctx, int kept, uint8_t* out, size_t cap, size_t* n);
 
 /* Stage probes (parity tests) -----------------------------------------------------

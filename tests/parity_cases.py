@@ -362,6 +362,14 @@ def case_jpeg_entropy(L, host, w, h, x0=0, y0=0, check_histograms=True):
             n = ctx.jpeg_scan(ncomp, depth, code)
             scan = ctx.jpeg_scan_bytes()
             assert len(scan) == n
+            # the scan's length in bits is a function of the symbol statistics and the code lengths
+            # alone (what the search driver bounds a candidate's size with, without coding it);
+            # the stuffed bytes are the 0xFF bytes of the stream
+            bits, stuffed = ctx.jpeg_scan_bits()
+            cnt = np.asarray(counts, np.int64)[:, :ncomp]
+            extra = np.arange(256) & 15
+            assert bits == int((cnt * (depth[:, :ncomp].astype(np.int64) + extra)).sum())
+            assert n == (bits + 7) // 8 + stuffed and stuffed == scan.count(b"\xff\x00")
             got = head + scan + b"\xff\xd9"
             exp = host.write_jpeg(cq, w, h, q)           # pinned to the reference in
             assert got == exp, (len(got), len(exp))      # test_host_encoder.test_write_jpeg_bytes
@@ -484,6 +492,14 @@ def case_jpeg_entropy420(L, H, w, h, chk, x0=0, y0=0):
             n = ctx.jpeg_scan(ncomp, depth, code)
             scan = ctx.jpeg_scan_bytes()
             assert len(scan) == n
+            # the scan's length in bits is a function of the symbol statistics and the code lengths
+            # alone (what the search driver bounds a candidate's size with, without coding it);
+            # the stuffed bytes are the 0xFF bytes of the stream
+            bits, stuffed = ctx.jpeg_scan_bits()
+            cnt = np.asarray(counts, np.int64)[:, :ncomp]
+            extra = np.arange(256) & 15
+            assert bits == int((cnt * (depth[:, :ncomp].astype(np.int64) + extra)).sum())
+            assert n == (bits + 7) // 8 + stuffed and stuffed == scan.count(b"\xff\x00")
             got = head + scan + b"\xff\xd9"
             assert got == exp, (len(got), len(exp), ncomp)
 

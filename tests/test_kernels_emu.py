@@ -25,25 +25,8 @@ def test_block_kernels(L):
     pc.case_block_kernels(L, n=300)
 
 
-def test_idct_multiply_add_variant(L, monkeypatch):
-    """k_reconstruct / the IDCT probe run the packed 16-bit dot products (v_dot2c_i32_i16) by
-    default; GZ_IDCT_DOT2=0 selects the 24-bit multiply-add form: same integers, extreme
-    (+-32767) blocks included."""
-    monkeypatch.setenv("GZ_IDCT_DOT2", "0")
-    pc.case_block_kernels(L, n=300)
-    pc.case_encode_quantize_reconstruct(L, 61, 43, x0=100, y0=50)
-
-
-def test_malta_line_sum_variants(L, monkeypatch):
-    """k_malta_rolled (the default: every tap read from LDS, a thread's pixels one after the other,
-    accumulators in LDS), k_malta (GZ_MALTA_ROLLED=0: the same unrolled) and k_malta_win (GZ_MALTA_WIN=1: every
-    thread's neighbourhood loaded into registers once, the 16 oriented sums formed from registers)
-    give the same bits; an image with interior and border Malta tiles."""
-    pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
-    monkeypatch.setenv("GZ_MALTA_WIN", "1")
-    pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
-    monkeypatch.delenv("GZ_MALTA_WIN")
-    monkeypatch.setenv("GZ_MALTA_ROLLED", "0")   # k_malta: the loop over a thread's pixels unrolled
+def test_malta_interior_and_border_tiles(L):
+    """k_malta_rolled on an image with interior and border Malta tiles, against the oracle."""
     pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))
 
 
@@ -107,31 +90,6 @@ def test_jpeg_entropy(L, host_emu, wh):
 
 def test_global_order(L):
     pc.case_global_order(L, 40, 32, x0=100, y0=60)
-
-
-def test_stages_and_compare_with_unrolled_code_variants(L, monkeypatch):
-    """The compact-code column pass and rolled-channel fused blurs are the default; the unrolled
-    kernels (GZ_COMPACT_BLUR_V=0 / GZ_COMPACT_BLUR2D=0) are forced here so that both are checked
-    in emulation."""
-    monkeypatch.setenv("GZ_COMPACT_BLUR_V", "0")
-    monkeypatch.setenv("GZ_COMPACT_BLUR2D", "0")
-    pc.case_blur(L, 72, 48)
-    pc.case_stages(L, 72, 48)
-    pc.case_stages(L, 35, 41)
-    pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(5,))
-
-
-@pytest.mark.parametrize("opt", [0, 1, 2])
-def test_blur_code_path_options(L, monkeypatch, opt):
-    """GZ_BLUR_OPT: epilogue by quads (bit 0) and conflict-free row-pass lane mappings (bit 1) are
-    on by default; the other combinations are checked here, scalar and paired passes."""
-    monkeypatch.setenv("GZ_BLUR_OPT", str(opt))
-    pc.case_blur(L, 256, 200, configs=pc.SIGMAS_BR[:5])
-    pc.case_stages(L, 200, 160)
-    monkeypatch.setenv("GZ_BLUR_PK", "1")
-    monkeypatch.setenv("GZ_TILE_ROWS", "32")
-    pc.case_blur(L, 600, 100, configs=pc.SIGMAS_BR[:4])
-    pc.case_stages(L, 72, 48)
 
 
 def test_blur_and_compare_with_paired_row_column_passes(L, monkeypatch):

@@ -624,13 +624,11 @@ constexpr int T2 = 64;   // tile edge
 // Without block maxima (BM = false: every blur but the chain's last) the channel loop stays a loop
 // and the per-channel results wait in LDS instead of registers (ROLL): the code shrinks by about
 // NC x (opsin blur 40 -> 6 KB, MF 32 -> 10, HF 23 -> 6), and the results leave by quads.
-#ifdef GZ_BLUR2D_WPS   // (build-time experiment: wavefronts per SIMD the register allocation aims for)
-#define GZ_BLUR2D_BOUNDS __launch_bounds__(256, GZ_BLUR2D_WPS)
-#else
-#define GZ_BLUR2D_BOUNDS __launch_bounds__(256)
-#endif
+// (256, 4): registers for four wavefronts per SIMD -- the MF instance (PostMF's quad epilogue) took
+// 143 VGPRs = three per SIMD without the bound; 1080p chain 0.358-0.362 -> 0.350 ms, 4K -0.4 %
+// (profiles/r04_occupancy_experiments.log; five per SIMD: no further gain).
 template <int R, int NC, class Src, class Post, bool BM, int TH>
-__global__ GZ_BLUR2D_BOUNDS void k_blur2d(SrcPack<Src, NC> src, Post post, int w, int h,
+__global__ __launch_bounds__(256, 4) void k_blur2d(SrcPack<Src, NC> src, Post post, int w, int h,
                                                 int pitch, Taps<R> taps, BorderScale bsx,
                                                 BorderScale bsy, BlockMaxOut bm) {
   constexpr bool ROLL = !BM;

@@ -151,11 +151,11 @@ struct SearchLds {
   float err[kEvalBatch];
   int num;
 };
-// One wavefront's share of LDS decides how many of them a SIMD holds: 160 KB / 16 = 10 240 bytes
-// for four per SIMD.  Round 4 took the struct from 12 672 to 10 064 bytes: the sRGB table is read
-// from global memory (1 KB per wavefront for three L1-resident loads per evaluation), the pixel
-// cache holds bytes, and what only the 4:2:0 chroma search needs lives in a struct of its own.
-static_assert(sizeof(SearchLds) <= 10240 - 64, "k_block_search: four wavefronts per SIMD need <= 10 KB of LDS each");
+// Round 4 took the struct from 12 672 to 10 064 bytes (160 KB / 16 wavefronts = 10 240): the sRGB
+// table is read from global memory (three L1-resident loads per evaluation instead of three LDS
+// reads at random banks), the pixel cache holds bytes, and what only the 4:2:0 chroma search needs
+// lives in a struct of its own.  k_block_search<0>: 10.0 -> 8.9 ms at 1080p, 34 -> 30.9 ms at 4K.
+static_assert(sizeof(SearchLds) <= 10240 - 64, "k_block_search: keep a wavefront's LDS below 10 KB");
 
 // 4:2:0 chroma search only (MODE 2): the 10x10 subsampled samples around the 16x16 block
 // (UpdatePixelsForBlock's `subsampled`, output_image.cc:150-183) per chroma component.
@@ -361,11 +361,12 @@ GZ_DEVFN void eval_narrow(SearchLds& s, int nc, int lane, const SearchView& v) {
 }
 
 // grid = one workgroup per block of the search grid; 64 threads (MODE 0, 1) or 256 (MODE 2).
-#ifndef GZ_SEARCH_WPS
-#define GZ_SEARCH_WPS 4   // wavefronts per SIMD the register allocation aims for (<= 128 VGPRs)
-#endif
+// (Round 4: capped at 128 VGPRs -- four wavefronts per SIMD, which the 10 KB of LDS allow -- the
+// kernel is 5 % SLOWER than at its natural 137 / three per SIMD: 9.42 vs 8.89 ms at 1080p, 32.4 vs
+// 30.9 ms at 4K, profiles/r04_occupancy_experiments.log.  It is bound by the FP64 chains it issues,
+// not by the latency more wavefronts would hide -- hence the explicit 3.)
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 256 : 64, MODE == 2 ? 3 : GZ_SEARCH_WPS) void k_block_search(SearchArgs a) {
+__global__ __launch_bounds__(MODE == 2 ? 256 : 64, 3) void k_block_search(SearchArgs a) {
   constexpr int NW = MODE == 2 ? 4 : 1;
   __shared__ SearchLds sh[NW];
   __shared__ SearchLds420<MODE == 2> sq[NW];

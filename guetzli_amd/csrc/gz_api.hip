@@ -413,6 +413,8 @@ struct gz_ctx {
   // scratch
   float *lin[3], *tmp[3], *xyb[3], *lf_raw[2], *hfp[2];
   float *snb, *diffx, *diffy, *mxb, *myb1, *myb2, *ac[2], *dsq, *distmap;
+  float* sup0[2];   // the original's half of DiffPrecompute (k_mask_sup of pi0: X, Y), per image
+  float* sup_scratch[2] = {nullptr, nullptr};   // the same for Mask() on raw planes (block mask, probe)
   float *mask_out[3], *mask_dc_out[3];
   bool have_mask_out = false;
 
@@ -520,7 +522,7 @@ namespace {
     }                                                                                \
   } while (0)
 
-const int kNumPlanes = 9 + 9 + 3 + 3 + 3 + 2 + 2 + 10;   // pi0, pi1, lin, tmp, xyb, lf_raw, hfp, 10 singles
+const int kNumPlanes = 9 + 9 + 3 + 3 + 3 + 2 + 2 + 10 + 2;   // pi0, pi1, lin, tmp, xyb, lf_raw, hfp, 10 singles, sup0[2]
 
 void set_frame(gz_ctx* c, int factor) {
   c->cfac = factor;
@@ -867,22 +869,51 @@ int stage_mask_blurs(gz_ctx* c, const MaskPrePack& pk, hipStream_t other = nullp
   return GZ_OK;
 }
 
-MaskPrePack mask_pack_psycho(gz_ctx* c, const Psycho& a, const Psycho& b) {
-  // MaskPsychoImage muls (butteraugli.cc:759-764)
-  const double muls[4] = {0, 1.64178305129, 0.831081703362, 3.23680933546};
-  MaskPrePack pk;
+// MaskPsychoImage's inputs (butteraugli.cc:753-782): a * uhf + b * hf of a PsychoImage, X and Y.
+static void mask_in_psycho(const Psycho& p, MaskIn in[2]) {
+  const double muls[4] = {0, 1.64178305129, 0.831081703362, 3.23680933546};   // (:759-764)
   for (int i = 0; i < 2; ++i) {
-    pk.in0[i].a = pk.in1[i].a = muls[2 * i];
-    pk.in0[i].b = pk.in1[i].b = muls[2 * i + 1];
-    pk.in0[i].plain = pk.in1[i].plain = 0;
-    pk.in0[i].hf = a.hf[i];
-    pk.in1[i].hf = b.hf[i];
-    pk.in0[i].uhf = muls[2 * i] == 0 ? nullptr : a.uhf[i];
-    pk.in1[i].uhf = muls[2 * i] == 0 ? nullptr : b.uhf[i];
+    in[i].a = muls[2 * i];
+    in[i].b = muls[2 * i + 1];
+    in[i].plain = 0;
+    in[i].hf = p.hf[i];
+    in[i].uhf = muls[2 * i] == 0 ? nullptr : p.uhf[i];
   }
+}
+// The original's half, once per image (gz_set_rgb): c->sup0.
+int stage_mask_sup(gz_ctx* c, const MaskIn in[2], float* const out[2]) {
+  MaskSupPack pk;
+  for (int i = 0; i < 2; ++i) { pk.in[i] = in[i]; pk.out[i] = out[i]; }
+  dim3 grid(gz_div_up(c->w, 1024), c->h, 2);
+  GZ_LAUNCH(k_mask_sup, grid, dim3(256), c->stream, pk, c->w, c->h, c->pitch);
+  KCHK(c);
+  return GZ_OK;
+}
+MaskPrePack mask_pack_psycho(gz_ctx* c, const Psycho& b) {
+  MaskPrePack pk;
+  mask_in_psycho(b, pk.in1);
+  pk.sup0[0] = c->sup0[0];
+  pk.sup0[1] = c->sup0[1];
   pk.out[0] = c->diffx;
   pk.out[1] = c->diffy;
   return pk;
+}
+int ensure_pip(gz_ctx* c);
+// Mask(xyb0, xyb1) on raw planes (StartBlockComparisons' mask of the original with itself, the
+// stage probe): image 0's half goes through two scratch planes of the probe arena.
+int mask_pack_plain(gz_ctx* c, const float* const a[2], const float* const b[2], MaskPrePack* pk) {
+  MaskIn in0[2];
+  for (int i = 0; i < 2; ++i) {
+    in0[i] = {nullptr, a[i], 0.0, 1.0, 1};
+    pk->in1[i] = {nullptr, b[i], 0.0, 1.0, 1};
+  }
+  TRY(ensure_pip(c));   // (sup_scratch)
+  TRY(stage_mask_sup(c, in0, c->sup_scratch));
+  pk->sup0[0] = c->sup_scratch[0];
+  pk->sup0[1] = c->sup_scratch[1];
+  pk->out[0] = c->diffx;
+  pk->out[1] = c->diffy;
+  return GZ_OK;
 }
 
 // The SameNoise blur and the mask branch (DiffPrecompute + three blurs; scratch planes
@@ -901,7 +932,7 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
     TRY((blur_h<23, SrcSameNoise, 1>(c, s, t, c->blur[B_SN])));
     PostStore<1> post; post.out[0] = c->snb;
     TRY((blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN])));
-    return stage_mask_blurs(c, mask_pack_psycho(c, p0, p1));
+    return stage_mask_blurs(c, mask_pack_psycho(c, p1));
   }
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
@@ -918,7 +949,7 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
     if (rc == GZ_OK) rc = blur_v<23, 1, PostStore<1>>(c, ct, post, c->blur[B_SN]);
   }
   c->stream = c->side_stream;
-  if (rc == GZ_OK) rc = stage_mask_blurs(c, mask_pack_psycho(c, p0, p1), c->side_stream2);
+  if (rc == GZ_OK) rc = stage_mask_blurs(c, mask_pack_psycho(c, p1), c->side_stream2);
   c->stream = main_stream;
   TRY(rc);
   HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
@@ -1029,9 +1060,16 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
     KCHK(c);
     return GZ_OK;
   }
-  GZ_LAUNCH(k_reconstruct, dim3(c->bh * gz_div_up(c->bw, kReconBlocks)), dim3(256), c->stream,
+  // strips of 8 blocks per workgroup: as many (up to 4) as leave the chip ~2000 workgroups (8 per CU)
+  const int strips = gz_div_up(c->bw, kReconBlocks);
+  int per = 4;
+  while (per > 1 && (long)c->bh * gz_div_up(strips, per) < 2000) per >>= 1;
+#ifdef GZ_EMU
+  if (const char* e = getenv("GZ_EMU_RECON_STRIPS")) per = atoi(e);   // (the strip loop on images the emulation can afford)
+#endif
+  GZ_LAUNCH(k_reconstruct, dim3(c->bh * gz_div_up(strips, per)), dim3(256), c->stream,
             d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
-            srgb, clear_word);
+            srgb, clear_word, per);
   KCHK(c);
   return GZ_OK;
 }
@@ -1059,10 +1097,11 @@ int download_plane(gz_ctx* c, const float* dev, float* host) {
 
 int ensure_pip(gz_ctx* c) {
   if (c->have_pip) return GZ_OK;
-  HIPCHK(c, pool_malloc((void**)&c->extra_arena, sizeof(float) * c->plane * 15));
-  for (int i = 0; i < 15; ++i) c->free_planes.push_back(c->extra_arena + (size_t)i * c->plane);
+  HIPCHK(c, pool_malloc((void**)&c->extra_arena, sizeof(float) * c->plane * 17));
+  for (int i = 0; i < 17; ++i) c->free_planes.push_back(c->extra_arena + (size_t)i * c->plane);
   alloc_psycho(c, &c->pip);
   for (int i = 0; i < 3; ++i) { c->mask_out[i] = take_plane(c); c->mask_dc_out[i] = take_plane(c); }
+  for (int i = 0; i < 2; ++i) c->sup_scratch[i] = take_plane(c);
   c->have_pip = true;
   return GZ_OK;
 }
@@ -1081,12 +1120,10 @@ int ensure_block_mask(gz_ctx* c) {
   KCHK(c);
   TRY(stage_opsin(c));
   MaskPrePack pk;
-  for (int i = 0; i < 2; ++i) {
-    pk.in0[i] = {nullptr, c->xyb[i], 0.0, 1.0, 1};
-    pk.in1[i] = {nullptr, c->xyb[i], 0.0, 1.0, 1};
+  {
+    const float* const x2[2] = {c->xyb[0], c->xyb[1]};
+    TRY(mask_pack_plain(c, x2, x2, &pk));
   }
-  pk.out[0] = c->diffx;
-  pk.out[1] = c->diffy;
   TRY(stage_mask_blurs(c, pk));
   CombineArgs ca;
   memset(&ca, 0, sizeof(ca));
@@ -1292,6 +1329,7 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   c->mxb = take_plane(c); c->myb1 = take_plane(c); c->myb2 = take_plane(c);
   c->ac[0] = take_plane(c); c->ac[1] = take_plane(c);
   c->dsq = take_plane(c); c->distmap = take_plane(c);
+  c->sup0[0] = take_plane(c); c->sup0[1] = take_plane(c);
   // lin planes must be contiguous for k_reconstruct / k_linear_from_rgb8 (plane stride)
   if (c->lin[1] != c->lin[0] + c->plane || c->lin[2] != c->lin[0] + 2 * c->plane) return fail(GZ_E_STATE);
 
@@ -1333,6 +1371,11 @@ int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
   KCHK(c);
   TRY(stage_opsin(c));
   TRY(stage_separate(c, &c->pi0));
+  {  // the original's half of every Compare's DiffPrecompute
+    MaskIn in0[2];
+    mask_in_psycho(c->pi0, in0);
+    TRY(stage_mask_sup(c, in0, c->sup0));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_block_mask = false;   // StartBlockComparisons' mask belongs to the old original
   c->have_distmap = false;
@@ -2551,13 +2594,10 @@ int gz_probe_mask(gz_ctx* c, const float* xyb0, const float* xyb1, float* mask3,
   float* b[2] = {c->pi1.hf[0], c->pi1.hf[1]};
   TRY(upload_planes(c, xyb0, a, 2));
   TRY(upload_planes(c, xyb1, b, 2));
+  const float* const ca2[2] = {a[0], a[1]};
+  const float* const cb2[2] = {b[0], b[1]};
   MaskPrePack pk;
-  for (int i = 0; i < 2; ++i) {
-    pk.in0[i] = {nullptr, a[i], 0.0, 1.0, 1};
-    pk.in1[i] = {nullptr, b[i], 0.0, 1.0, 1};
-  }
-  pk.out[0] = c->diffx;
-  pk.out[1] = c->diffy;
+  TRY(mask_pack_plain(c, ca2, cb2, &pk));
   TRY(stage_mask_blurs(c, pk));
   CombineArgs ca;
   memset(&ca, 0, sizeof(ca));

@@ -134,10 +134,16 @@ GZ_DEVFN void idct3_to_rgb(const int (*s_in)[64], int (*s_col)[64], int lane, in
 // 16-byte read instead of eight dword reads.  (Round 3's 24-bit multiply-add form of this kernel,
 // 72 instead of 59 us at 4K, was removed in round 4; idct3_to_rgb keeps that arithmetic for the
 // 4:2:0 and block-search kernels.)
+// strips_per_wg: a workgroup takes that many consecutive strips of its block row, one after the
+// other, with the NEXT strip's coefficients already requested while it transforms the current one
+// (six 2-byte loads per lane, held in registers): twice the bytes in flight per wavefront.  Round 3's
+// one-strip workgroups waited for their loads 73 % of their cycles (SQ_WAIT_ANY) at 2.6 TB/s.
+// (strips_per_wg is the caller's: 4 where that still leaves several workgroups per CU.)
 __global__ __launch_bounds__(256) void k_reconstruct(
     const int16_t* __restrict__ coeffs, int w, int h, int bw, int nb, int pitch,
     size_t pstride, const float* __restrict__ srgb_lut, float* __restrict__ lin,
-    uint8_t* __restrict__ srgb, unsigned* __restrict__ clear_word) {
+    uint8_t* __restrict__ srgb, unsigned* __restrict__ clear_word, int strips_per_wg) {
+  const int kReconStrips = strips_per_wg;
   // first kernel of a Compare: also resets the distance accumulator of its last kernel
   if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
   __shared__ __attribute__((aligned(16))) short s_in16[kReconBlocks][3][64];    // [ix][u]
@@ -146,85 +152,106 @@ __global__ __launch_bounds__(256) void k_reconstruct(
   __shared__ uint8_t s_u8[8][kReconBlocks * 8][3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int strips = (bw + kReconBlocks - 1) / kReconBlocks;
-  const int by = blockIdx.x / strips, bx0 = (blockIdx.x % strips) * kReconBlocks;
+  const int groups = (strips + kReconStrips - 1) / kReconStrips;
+  const int by = blockIdx.x / groups, s0 = (blockIdx.x % groups) * kReconStrips;
+  const int ns = strips - s0 < kReconStrips ? strips - s0 : kReconStrips;
   const int iy = lane >> 3, ix = lane & 7;
-  // the three components of both blocks together: one memory latency, two barriers
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int j = 2 * wave + k, bx = bx0 + j;
-    const bool live = bx < bw;
-    const size_t blk = (size_t)by * bw + bx;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int16_t v = live ? coeffs[((size_t)c * nb + blk) * 64 + lane] : (int16_t)0;
-      s_in16[j][c][8 * ix + iy] = v;   // lane = 8 * (row u) + column: transposed
-    }
-  }
-  __syncthreads();
   // rows iy / ix of the matrix, packed
   const gz_u4 m_row = gz_load_u4(&kIdctMP[4 * iy]), m_col = gz_load_u4(&kIdctMP[4 * ix]);
+  // this lane's coefficient of the wavefront's two blocks x three components of strip `st`
+  auto fetch = [&](int st, int16_t (&v)[2][3]) {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int j = 2 * wave + k;
+    for (int k = 0; k < 2; ++k) {
+      const int bx = (s0 + st) * kReconBlocks + 2 * wave + k;
+      const bool live = bx < bw;
+      const size_t blk = (size_t)by * bw + bx;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
-      const gz_u4 q = gz_load_u4(&s_in16[j][c][8 * ix]);
-      s_col16[j][c][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
+      for (int c = 0; c < 3; ++c) v[k][c] = live ? coeffs[((size_t)c * nb + blk) * 64 + lane] : (int16_t)0;
     }
-  }
-  __syncthreads();
+  };
+  int16_t cur[2][3], nxt[2][3];
+  fetch(0, nxt);
+#pragma unroll 1
+  for (int st = 0; st < ns; ++st) {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int j = 2 * wave + k;
-    int r, g, b;
-    int px[3];
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      // row pass (idct.cc:150-160): out = clamp((sum + (257 << 17)) >> 18)
-      const gz_u4 q = gz_load_u4(&s_col16[j][c][8 * iy]);
-      px[c] = clamp255((idct_dot8(m_col, q) + (257 << 17)) >> 18);
+      for (int c = 0; c < 3; ++c) cur[k][c] = nxt[k][c];
+    if (st + 1 < ns) fetch(st + 1, nxt);   // in flight during this strip's arithmetic
+    const int bx0 = (s0 + st) * kReconBlocks;
+    // the three components of both blocks together: one memory latency, two barriers
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = 2 * wave + k;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s_in16[j][c][8 * ix + iy] = cur[k][c];   // lane = 8 * (row u) + column: transposed
     }
-    ycc_to_rgb(px[0], px[1], px[2], &r, &g, &b);
-    const int x = 8 * j + ix;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = 2 * wave + k;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
+        const gz_u4 q = gz_load_u4(&s_in16[j][c][8 * ix]);
+        s_col16[j][c][lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = 2 * wave + k;
+      int r, g, b;
+      int px[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // row pass (idct.cc:150-160): out = clamp((sum + (257 << 17)) >> 18)
+        const gz_u4 q = gz_load_u4(&s_col16[j][c][8 * iy]);
+        px[c] = clamp255((idct_dot8(m_col, q) + (257 << 17)) >> 18);
+      }
+      ycc_to_rgb(px[0], px[1], px[2], &r, &g, &b);
+      const int x = 8 * j + ix;
+      if (lin) {
+        s_px[0][iy][x] = srgb_lut[r];
+        s_px[1][iy][x] = srgb_lut[g];
+        s_px[2][iy][x] = srgb_lut[b];
+      }
+      if (srgb) {
+        s_u8[iy][x][0] = (uint8_t)r;
+        s_u8[iy][x][1] = (uint8_t)g;
+        s_u8[iy][x][2] = (uint8_t)b;
+      }
+    }
+    __syncthreads();
+    const int x0 = 8 * bx0, y0 = 8 * by;
     if (lin) {
-      s_px[0][iy][x] = srgb_lut[r];
-      s_px[1][iy][x] = srgb_lut[g];
-      s_px[2][iy][x] = srgb_lut[b];
+      // 3 planes x 8 rows x 16 four-pixel groups = 384 16-byte stores
+      for (int i = threadIdx.x; i < 3 * 8 * (kReconBlocks * 2); i += 256) {
+        const int q = i % (kReconBlocks * 2), row = (i / (kReconBlocks * 2)) % 8, pl = i / (kReconBlocks * 16);
+        const int x = x0 + 4 * q, y = y0 + row;
+        if (y >= h || x >= w) continue;
+        const size_t o = (size_t)pl * pstride + (size_t)y * pitch + x;
+        if (x + 3 < w && (pitch & 3) == 0) {
+          GZ_STG4(lin, o, *reinterpret_cast<const gz_f4*>(&s_px[pl][row][4 * q]));
+        } else {
+          for (int e = 0; e < 4 && x + e < w; ++e) lin[o + e] = s_px[pl][row][4 * q + e];
+        }
+      }
     }
     if (srgb) {
-      s_u8[iy][x][0] = (uint8_t)r;
-      s_u8[iy][x][1] = (uint8_t)g;
-      s_u8[iy][x][2] = (uint8_t)b;
-    }
-  }
-  __syncthreads();
-  const int x0 = 8 * bx0, y0 = 8 * by;
-  if (lin) {
-    // 3 planes x 8 rows x 16 four-pixel groups = 384 16-byte stores
-    for (int i = threadIdx.x; i < 3 * 8 * (kReconBlocks * 2); i += 256) {
-      const int q = i % (kReconBlocks * 2), row = (i / (kReconBlocks * 2)) % 8, pl = i / (kReconBlocks * 16);
-      const int x = x0 + 4 * q, y = y0 + row;
-      if (y >= h || x >= w) continue;
-      const size_t o = (size_t)pl * pstride + (size_t)y * pitch + x;
-      if (x + 3 < w && (pitch & 3) == 0) {
-        GZ_STG4(lin, o, *reinterpret_cast<const gz_f4*>(&s_px[pl][row][4 * q]));
-      } else {
-        for (int e = 0; e < 4 && x + e < w; ++e) lin[o + e] = s_px[pl][row][4 * q + e];
+      for (int i = threadIdx.x; i < 8 * kReconBlocks * 8; i += 256) {
+        const int xx = i % (kReconBlocks * 8), row = i / (kReconBlocks * 8);
+        const int x = x0 + xx, y = y0 + row;
+        if (x < w && y < h) {
+          uint8_t* p = srgb + ((size_t)y * w + x) * 3;
+          p[0] = s_u8[row][xx][0];
+          p[1] = s_u8[row][xx][1];
+          p[2] = s_u8[row][xx][2];
+        }
       }
     }
-  }
-  if (srgb) {
-    for (int i = threadIdx.x; i < 8 * kReconBlocks * 8; i += 256) {
-      const int xx = i % (kReconBlocks * 8), row = i / (kReconBlocks * 8);
-      const int x = x0 + xx, y = y0 + row;
-      if (x < w && y < h) {
-        uint8_t* p = srgb + ((size_t)y * w + x) * 3;
-        p[0] = s_u8[row][xx][0];
-        p[1] = s_u8[row][xx][1];
-        p[2] = s_u8[row][xx][2];
-      }
-    }
+    // (the next strip's first barrier stands between these reads of s_px / s_u8 and its writes
+    // to them, which come two barriers later)
   }
 }
 

@@ -37,46 +37,97 @@ struct MaskIn {
     return r;
   }
 };
+// The two halves of DiffPrecompute apart: the ORIGINAL's |c - right| + |c - down| is the same for
+// every candidate of an image, so gz_set_rgb computes it once (k_mask_sup: two planes) and a
+// Compare reads those two planes instead of the original's three band planes (k_mask_pre: 5 plane
+// reads + 2 writes instead of 6 + 2, a third fewer memory instructions: 84 -> ~60 us at 4K).
+struct MaskSupPack {
+  MaskIn in[2];     // [X, Y] of one image
+  float* out[2];
+};
 struct MaskPrePack {
-  MaskIn in0[2];   // [X, Y] of image 0
-  MaskIn in1[2];   // [X, Y] of image 1
+  const float* sup0[2];   // k_mask_sup of image 0
+  MaskIn in1[2];          // [X, Y] of image 1
   float* out[2];
 };
 
-// grid = (ceil(w/1024), h, 2): a thread takes 4 consecutive pixels of a row -- 16-byte
-// loads of the row and of the row below, one 16-byte store -- when the row pitch allows it.
-__global__ __launch_bounds__(256) void k_mask_pre(MaskPrePack pk, int w, int h, int pitch) {
-  // rows in XCD-aware order: row y + 1 (read by this row's workgroups and by the next row's)
-  // then comes from the same L2
+// This thread's four mixed samples of row y at columns x .. x + 3, of the row below (mirrored at
+// the last row) and the sample right of the fourth (the next lane's first, or -- last lane of a
+// wavefront, last quad of a row -- loaded; mirrored at the last column: butteraugli.cc:1706-1725).
+struct MaskQuad { gz_f4 c, d; float r; };
+GZ_DEVFN MaskQuad mask_quad(const MaskIn& a, int x, int y, int w, int h, int pitch) {
+  const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
+  MaskQuad q;
+  q.c = a.load4((size_t)y * pitch + x);
+  q.d = a.load4((size_t)y2 * pitch + x);
+  const int lane = (int)(threadIdx.x & 63);
+  // (called by the lanes whose whole quad lies inside the image: the next lane takes part iff its
+  // quad does too)
+  const float next = __uint_as_float((unsigned)__shfl((int)__float_as_uint(q.c.v[0]), lane + 1));
+  if (lane != 63 && x + 7 < w) {
+    q.r = next;
+  } else {
+    const int xr = x + 4 < w ? x + 4 : x + 2;
+    q.r = a((size_t)y * pitch + xr);
+  }
+  return q;
+}
+
+// grid = (ceil(w/1024), h, 2): a thread takes 4 consecutive pixels of a row -- 16-byte loads of
+// the row and of the row below, one 16-byte store -- when the row pitch allows it.  Rows in
+// XCD-aware order: row y + 1 (read by this row's workgroups and by the next row's) then comes
+// from the same L2.
+__global__ __launch_bounds__(256) void k_mask_sup(MaskSupPack pk, int w, int h, int pitch) {
   const GzTile bid = gz_xcd_tile();
   const int x = (bid.x * (int)blockDim.x + (int)threadIdx.x) * 4, y = bid.y;
   if (x >= w || y >= h) return;
   const int c = bid.z;
-  MaskIn a = pk.in0[0], b = pk.in1[0];
+  MaskIn a = pk.in[0];
   float* out = pk.out[0];
-  if (c == 1) { a = pk.in0[1]; b = pk.in1[1]; out = pk.out[1]; }
-  // mirrored neighbour at the last column / row (butteraugli.cc:1706-1725)
+  if (c == 1) { a = pk.in[1]; out = pk.out[1]; }
   const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
   if ((pitch & 3) == 0 && x + 3 < w) {
-    const size_t i = (size_t)y * pitch + x, id = (size_t)y2 * pitch + x;
-    const gz_f4 a0 = a.load4(i), ad = a.load4(id), b0 = b.load4(i), bd = b.load4(id);
-    // right neighbour of the 4th pixel: the next column, or mirrored at the last column
-    const int xr = x + 4 < w ? x + 4 : x + 2;
-    const float ar = a((size_t)y * pitch + xr), br = b((size_t)y * pitch + xr);
+    const MaskQuad q = mask_quad(a, x, y, w, h, pitch);
+    gz_f4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o.v[k] = diff_sup(q.c.v[k], k < 3 ? q.c.v[k < 3 ? k + 1 : 3] : q.r, q.d.v[k]);
+    GZ_STG4(out, (size_t)y * pitch + x, o);
+    return;
+  }
+  for (int k = 0; k < 4 && x + k < w; ++k) {
+    const int xx = x + k;
+    const int x2 = xx + 1 < w ? xx + 1 : (xx > 0 ? xx - 1 : xx);
+    const size_t i = (size_t)y * pitch + xx;
+    out[i] = diff_sup(a(i), a((size_t)y * pitch + x2), a((size_t)y2 * pitch + xx));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mask_pre(MaskPrePack pk, int w, int h, int pitch) {
+  const GzTile bid = gz_xcd_tile();
+  const int x = (bid.x * (int)blockDim.x + (int)threadIdx.x) * 4, y = bid.y;
+  if (x >= w || y >= h) return;
+  const int c = bid.z;
+  MaskIn b = pk.in1[0];
+  const float* sup0 = pk.sup0[0];
+  float* out = pk.out[0];
+  if (c == 1) { b = pk.in1[1]; sup0 = pk.sup0[1]; out = pk.out[1]; }
+  const int y2 = y + 1 < h ? y + 1 : (y > 0 ? y - 1 : y);
+  if ((pitch & 3) == 0 && x + 3 < w) {
+    const size_t i = (size_t)y * pitch + x;
+    const gz_f4 s0 = GZ_LDG4(sup0, i);
+    const MaskQuad q = mask_quad(b, x, y, w, h, pitch);
     gz_f4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      o.v[k] = diff_precompute_px(a0.v[k], k < 3 ? a0.v[k < 3 ? k + 1 : 3] : ar, ad.v[k], b0.v[k],
-                                  k < 3 ? b0.v[k < 3 ? k + 1 : 3] : br, bd.v[k]);
+      o.v[k] = diff_from_sups(s0.v[k], diff_sup(q.c.v[k], k < 3 ? q.c.v[k < 3 ? k + 1 : 3] : q.r, q.d.v[k]));
     GZ_STG4(out, i, o);
     return;
   }
   for (int k = 0; k < 4 && x + k < w; ++k) {
     const int xx = x + k;
     const int x2 = xx + 1 < w ? xx + 1 : (xx > 0 ? xx - 1 : xx);
-    const size_t i = (size_t)y * pitch + xx, ir = (size_t)y * pitch + x2,
-                 id = (size_t)y2 * pitch + xx;
-    out[i] = diff_precompute_px(a(i), a(ir), a(id), b(i), b(ir), b(id));
+    const size_t i = (size_t)y * pitch + xx;
+    out[i] = diff_from_sups(sup0[i], diff_sup(b(i), b((size_t)y * pitch + x2), b((size_t)y2 * pitch + xx)));
   }
 }
 

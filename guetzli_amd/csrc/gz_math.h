@@ -320,10 +320,11 @@ GZ_DEVFN float same_noise_pre(float a, float b) {
 }
 
 // ---- Mask: DiffPrecompute core (butteraugli.cc:1723-1733) and LUT interpolation ---
-GZ_DEVFN float diff_precompute_px(float c0, float r0, float d0, float c1, float r1,
-                                  float d1) {
-  const double sup0 = (double)(fabsf(c0 - r0) + fabsf(c0 - d0));
-  const double sup1 = (double)(fabsf(c1 - r1) + fabsf(c1 - d1));
+// One image's half: |c - right| + |c - down| in float (fabs(float) is the float overload,
+// butteraugli.cc:1726-1729), the other's likewise; then min, scale, clamp.
+GZ_DEVFN float diff_sup(float c, float r, float d) { return fabsf(c - r) + fabsf(c - d); }
+GZ_DEVFN float diff_from_sups(float sup0f, float sup1f) {
+  const double sup0 = (double)sup0f, sup1 = (double)sup1f;
   const double mul0 = 0.918416534734, cutoff = 55.0184555849;
   float v = (float)(mul0 * (sup0 < sup1 ? sup0 : sup1));   // std::min(sup0, sup1)
   if ((double)v >= cutoff) v = (float)cutoff;

@@ -25,6 +25,16 @@ def test_block_kernels(L):
     pc.case_block_kernels(L, n=300)
 
 
+@pytest.mark.parametrize("strips", [2, 4])
+def test_reconstruct_with_several_strips_per_workgroup(L, monkeypatch, strips):
+    """k_reconstruct's strip loop (large images: a workgroup takes 2 or 4 strips of 8 blocks with
+    the next strip's coefficients in flight), forced on images the emulation can afford; widths
+    that end inside a strip group and inside a strip."""
+    monkeypatch.setenv("GZ_EMU_RECON_STRIPS", str(strips))
+    pc.case_encode_quantize_reconstruct(L, 200, 43, x0=100, y0=50)
+    pc.case_encode_quantize_reconstruct(L, 333, 20, x0=0, y0=50)
+
+
 def test_malta_interior_and_border_tiles(L):
     """k_malta_rolled on an image with interior and border Malta tiles, against the oracle."""
     pc.case_compare(L, 200, 110, x0=100, y0=60, qscales=(5,))

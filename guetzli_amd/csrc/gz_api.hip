@@ -2003,9 +2003,10 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
   if (c->have_jq) {
     // with the symbol statistics' quantiser known, the steps also report what they do to the
     // AC histograms (gz_steps_histogram_delta)
-    if (!c->d_step_delta) HIPCHK(c, pool_malloc((void**)&c->d_step_delta, sizeof(unsigned) * 768));
-    HIPCHK(c, hipMemsetAsync(c->d_step_delta, 0, sizeof(unsigned) * 768, c->stream));
-    GZ_LAUNCH(k_apply_steps_hist, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
+    if (!c->d_step_delta) HIPCHK(c, pool_malloc((void**)&c->d_step_delta, sizeof(unsigned) * 768 * kStepDeltaCopies));
+    HIPCHK(c, hipMemsetAsync(c->d_step_delta, 0, sizeof(unsigned) * 768 * kStepDeltaCopies, c->stream));
+    // (persistent workgroups: four per CU's worth at most, each wavefront taking several blocks)
+    GZ_LAUNCH(k_apply_steps_hist, dim3(std::min(gz_div_up(n, 4), 1024)), dim3(256), c->stream, (const int*)d_blocks,
               (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
               (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
               (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta);
@@ -2029,10 +2030,16 @@ int gz_steps_histogram_delta(gz_ctx* c, int32_t* ac_delta) {
     return GZ_E_STATE;
   }
   void* res = nullptr;
-  TRY(result_buffer(c, sizeof(unsigned) * 768, &res));
-  HIPCHK(c, hipMemcpyAsync(res, c->d_step_delta, sizeof(unsigned) * 768, hipMemcpyDeviceToHost, c->stream));
+  TRY(result_buffer(c, sizeof(unsigned) * 768 * kStepDeltaCopies, &res));
+  HIPCHK(c, hipMemcpyAsync(res, c->d_step_delta, sizeof(unsigned) * 768 * kStepDeltaCopies, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  memcpy(ac_delta, res, sizeof(unsigned) * 768);
+  // the workgroups' changes went to kStepDeltaCopies copies of the counters (k_apply_steps_hist)
+  const unsigned* part = static_cast<const unsigned*>(res);
+  for (int k = 0; k < 768; ++k) {
+    unsigned sum = 0;
+    for (int r = 0; r < kStepDeltaCopies; ++r) sum += part[r * 768 + k];
+    ac_delta[k] = (int32_t)sum;
+  }
   return GZ_OK;
 }
 

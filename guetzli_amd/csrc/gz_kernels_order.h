@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_apply_steps(const int* __restrict__ blo
 // statistics (BuildACHistograms of the image before minus after, for the touched blocks only):
 // the block's coefficient blocks go through LDS, their symbols are counted out of the
 // histogram, the steps are applied, the symbols are counted back in.  delta: [3][256] counters
-// (wrapping unsigned arithmetic = signed differences), zeroed by the caller; jq = the quantiser
+// (wrapping unsigned arithmetic = signed differences) x kStepDeltaCopies, zeroed by the caller; jq = the quantiser
 // the symbols are defined under (gz_jpeg_histograms' matrix).  After ~6000 steps an iteration
 // the host's size model needs the statistics again; recounting the 32 400 blocks of a 1080p
 // image took 40-50 us, the touched blocks take a fraction of that.
@@ -275,6 +275,13 @@ GZ_DEVFN void steps_count_symbols(const short* blk3, const int* __restrict__ jq,
   }
 }
 
+// Grid-stride over the touched blocks (a wavefront takes blocks wv, wv + total wavefronts, ...):
+// a workgroup's LDS histogram collects the changes of all its blocks and goes to global memory
+// ONCE, into one of kStepDeltaCopies copies (the caller sums them).  With a workgroup per four
+// blocks, 26 000 touched blocks of a 4K iteration meant 6500 workgroups x ~100 atomics on the same
+// 768 words: the launch spent its 81 us queueing at a dozen L2 lines.  The wavefronts of a
+// workgroup share nothing but that histogram, so they synchronise only around it.
+constexpr int kStepDeltaCopies = 16;
 __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict__ blocks,
                                                           const int* __restrict__ counts, int n,
                                                           int direction, const int* __restrict__ next_cand,
@@ -287,34 +294,45 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
   __shared__ short s_blk[4][3 * 64];
   __shared__ unsigned s_delta[3 * 256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
-  const bool live = i < n;   // a wavefront past the end repeats the last block and drops the result
-  const int b = blocks[live ? i : n - 1], cnt = live ? counts[i] : 0, nx = next_cand[b];
   for (int k = threadIdx.x; k < 3 * 256; k += 256) s_delta[k] = 0u;
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-    if ((sg.comp_mask >> c) & 1) s_blk[wave][c * 64 + lane] = cand[((size_t)sg.coff[c] + b) * 64 + lane];
   __syncthreads();
-  steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 0xffffffffu, s_delta);
-  __syncthreads();
-  for (int j = lane; j < cnt; j += 64) {
-    const int p = direction > 0 ? nx + j : nx - 1 - j;
-    const int idx = cand_idx[(size_t)b * 192 + p];
-    const int c = idx >> 6, k = idx & 63;
-    const short* ob = orig + ((size_t)sg.coff[c] + b) * 64;
-    const int newval = step_new_value(direction, ob, k, q[c * 64 + k]);
-    if (!(newval == 0 && step_is_precious(ob, k))) s_blk[wave][c * 64 + k] = (short)newval;
-  }
-  __syncthreads();
-  steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 1u, s_delta);
-  if (live) {
+  const int stride = (int)gridDim.x * 4;
+  // (the same trip count for the four wavefronts -- the first one's, the largest: a wavefront past
+  // the end repeats the last block and drops the result, so that every thread of the workgroup
+  // passes the same sequence of synchronisation points, which the test emulation relies on)
+  const int first = (int)blockIdx.x * 4;
+  const int iters = first < n ? (n - first + stride - 1) / stride : 0;
+  for (int it = 0; it < iters; ++it) {
+    const int i = first + wave + it * stride;
+    const bool live = i < n;
+    const int b = blocks[live ? i : n - 1], cnt = live ? counts[i] : 0, nx = next_cand[b];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      if ((sg.comp_mask >> c) & 1) cand[((size_t)sg.coff[c] + b) * 64 + lane] = s_blk[wave][c * 64 + lane];
+      if ((sg.comp_mask >> c) & 1) s_blk[wave][c * 64 + lane] = cand[((size_t)sg.coff[c] + b) * 64 + lane];
+    GZ_WAVE_SYNC();
+    steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 0xffffffffu, s_delta);
+    GZ_WAVE_SYNC();
+    for (int j = lane; j < cnt; j += 64) {
+      const int p = direction > 0 ? nx + j : nx - 1 - j;
+      const int idx = cand_idx[(size_t)b * 192 + p];
+      const int c = idx >> 6, k = idx & 63;
+      const short* ob = orig + ((size_t)sg.coff[c] + b) * 64;
+      const int newval = step_new_value(direction, ob, k, q[c * 64 + k]);
+      if (!(newval == 0 && step_is_precious(ob, k))) s_blk[wave][c * 64 + k] = (short)newval;
+    }
+    GZ_WAVE_SYNC();
+    steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 1u, s_delta);
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if ((sg.comp_mask >> c) & 1) cand[((size_t)sg.coff[c] + b) * 64 + lane] = s_blk[wave][c * 64 + lane];
+    }
+    GZ_WAVE_SYNC();   // (the block's copy is overwritten by the wavefront's next block)
   }
   __syncthreads();
+  unsigned* out = delta + (blockIdx.x % kStepDeltaCopies) * 768;
   for (int k = threadIdx.x; k < 3 * 256; k += 256)
-    if (s_delta[k]) atomicAdd(&delta[k], s_delta[k]);
+    if (s_delta[k]) atomicAdd(&out[k], s_delta[k]);
 }
 
 // Per-block maxima of the distance map over fx x fy groups of 8x8 blocks: the first loop of

@@ -116,8 +116,22 @@ def cpu_baseline():
     jb, _ = ref.process(bees, TARGET_Q95)
     db = time.perf_counter() - t0
     assert hashlib.sha256(jb).hexdigest() == "f2673f12a4856e020627fa151493a80b1cb2ee4dc81e28afc62dc089baf50242"
+    # whole BASELINE images through the same reference build on this kind of box, once per round
+    # (tools/ref_cpu_time.py under gpurun: 9 and 2.3 minutes -- too long for this line)
+    full = {}
+    for key, name in (("3840x2160_q95", "r04_reference_cpu_4k.json"), ("1920x1080_q95", "r04_reference_cpu_1080p.json")):
+        try:
+            r = json.load(open(os.path.join(ROOT, "profiles", name)))
+            full[key] = {k: r[k] for k in ("seconds", "value", "unit", "host_cpu", "host_cores_present", "cores_used",
+                                           "output_sha256", "head")}
+            full[key]["source"] = "profiles/" + name
+        except Exception:
+            pass
     return {"value": round(w * h / 1e6 / dt, 6), "unit": "MPix/s", "cores": 1,
-            "kind": "reference",
+            "kind": "reference", "full_images_same_box_kind": full,
+            "note": "the 3840x2160 image of `value` through the unmodified reference on the bench box's host CPU "
+                    "(EPYC 9575F, 1 thread of 256): 543.4 s = 0.01526 MPix/s, output hash = the GPU's "
+                    "(profiles/r04_reference_cpu_4k.json); this line's own sample is the bounded one below",
             "sample": f"unmodified reference guetzli::Process on the top-left {w}x{h} of the "
                       f"bench image, --quality 95: {dt:.1f} s of CPU, single thread "
                       f"({os.cpu_count()} host cores present); output {len(jpg)} bytes",
@@ -143,7 +157,7 @@ def block_search_counters():
     counters cannot be read from inside this process): the share of its wave cycles in which a
     wavefront issues a VALU instruction, and VALU instructions per wavefront."""
     import csv
-    for name in ("r03_block_search_pmc.csv", "r02_block_search_pmc.csv"):
+    for name in ("r04_block_search_pmc.csv", "r03_block_search_pmc.csv", "r02_block_search_pmc.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -344,8 +358,17 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
             "host_cores_per_rank": env.cores}
 
 
-SQ_COUNTERS = {"1080p": os.path.join(ROOT, "profiles", "r03_compare_1080p_sq_counters.csv"),
-               "4k": os.path.join(ROOT, "profiles", "r03_compare_4k_sq_counters.csv")}
+def _latest_profile(name):
+    """profiles/<round>_<name> of the newest round that has it."""
+    for rn in ("r04", "r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rn}_{name}")
+        if os.path.exists(path):
+            return path
+    return os.path.join(ROOT, "profiles", "r04_" + name)
+
+
+SQ_COUNTERS = {"1080p": _latest_profile("compare_1080p_sq_counters.csv"),
+               "4k": _latest_profile("compare_4k_sq_counters.csv")}
 # wave64 VALU instructions the chip issues per second: f32 multiplies / adds go at one per 2 clocks
 # and SIMD once a SIMD holds two or more waves (tools/ubench/pk.hip: 73 T lane-ops/s measured),
 # FP64 and -- as far as this repo has measured anything -- the rest at one per 4 clocks

@@ -1,9 +1,9 @@
 #!/bin/bash
-# The round's profile set of the FINAL code in one session (copied to profiles/r03_* afterwards by
-# tools/collect_r3_profiles.sh): chain timings, per-kernel rocprofv3 statistics with the chain
+# The round's profile set of the FINAL code in one session (copied to profiles/rNN_* afterwards by
+# tools/collect_profiles.sh): chain timings, per-kernel rocprofv3 statistics with the chain
 # serialised, SQ counters incl. LDS bank conflicts, FETCH/WRITE traffic, the bench line, the
 # rocprofv3 kernel statistics of the bench command, whole-encode timers, one iteration's timeline.
-# Usage: tools/gpurun_head.sh --timeout 2400 -- 'bash tools/gpu_r3_profiles.sh [tag]'
+# Usage: tools/gpurun_head.sh --timeout 2400 -- 'bash tools/gpu_profiles.sh [tag]'
 set -u
 export TMPDIR=/tmp
 TAG=${1:-prof}; O=gpurun_out/$TAG; mkdir -p $O
@@ -25,3 +25,4 @@ python bench.py 2>$O/bench.err | tee $O/bench.json | cut -c1-300
 # bench's own is the one with the chain's kernels in it)
 f=$(grep -l "k_malta" $(find $O/benchprof -name "*kernel_stats.csv") | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats.csv; rm -rf $O/benchprof
 bash tools/gpu_trace_full.sh $TAG/timeline > $O/timeline.log 2>&1
+bash tools/gpu_trace_full.sh $TAG/timeline4k 3840 2160 > $O/timeline4k.log 2>&1

@@ -75,9 +75,9 @@ TARGET_Q95 = 0.971769              # ButteraugliScoreForQuality(95), quality.cc:
 GOLDEN_SHA_1080P_Q95 = "9c0eb414b8e73f4372c0b089eafe2350e6ff2ae83926d1c0c5f35cb5f7919729"
 GOLDEN_SHA_4K = {95: "481507d21e4d37f296ae6a2a93a84d950c4a135df310b3408a64390b25d59c05",
                  84: "f3be1e4385a977853f7cd224e1722a728c1fa0bc68f1115c27e657c23a028ac0"}
-CHAIN = ("butteraugli Compare chain (15 launches per Compare on 3 streams: k_reconstruct, 5 fused "
-         "k_blur2d (radius < 16), 3 k_blur_h + 3 k_blur_v (radius >= 16; the mask's radius-20 pair is one "
-         "launch per pass), k_malta (both channels), k_mask_pre, k_combine)")
+CHAIN = ("butteraugli Compare chain (17 launches per Compare on 3 streams: k_reconstruct, 5 fused "
+         "k_blur2d (radius < 16), 4 k_blur_h + 4 k_blur_v (radius >= 16: LF X/Y, LF B, SameNoise, the mask's "
+         "radius-20 pair as one launch per pass), k_malta_rolled (both channels), k_mask_pre, k_combine)")
 TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in
                  ("r04_compare_pmc_traffic.json", "r03_compare_pmc_traffic.json")]
 

@@ -904,6 +904,7 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
 #define GZ_POPCLL(x) __popcll(x)
 #endif
 constexpr int kFinishThreads = 1024;
+constexpr int kFinishBatch = 4;   // rows of 64 entries / pairs a thread has in flight per step
 __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int levels, unsigned max_range) {
   __shared__ DescState s_state;
   __shared__ int s_level;
@@ -955,20 +956,26 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
       med = y;
     }
     const OrderEntry pv = med == x ? ex : (med == y ? ey : ez);
-    // a wavefront takes a contiguous segment, its lanes consecutive entries: stopper counts ...
-    const unsigned seg = ((n + NWV - 1) / NWV + 63) & ~63u;
+    // a wavefront takes a contiguous segment, its lanes consecutive entries -- kFinishBatch rows of
+    // 64 per step, all of a step's loads in flight together (one row per step would make every
+    // step wait for a trip to L2: 64 dependent trips per pass on a 64 K range): stopper counts ...
+    const unsigned seg = ((n + NWV - 1) / NWV + (64 * kFinishBatch - 1)) / (64 * kFinishBatch) * (64 * kFinishBatch);
     const unsigned s0 = (unsigned)wv * seg;
     unsigned nl = 0, nr = 0;
-    for (unsigned base = 0; base < seg; base += 64) {
-      const unsigned p = s0 + base + (unsigned)lane;
-      bool fl = false, fr = false;
-      if (p < n) {
-        const OrderEntry e = desc_read(A.a, first + p, med, e0);
-        fl = !order_less(e, pv);
-        fr = !order_less(pv, e);
+    for (unsigned base = 0; base < seg; base += 64 * kFinishBatch) {
+      OrderEntry e[kFinishBatch];
+#pragma unroll
+      for (int u = 0; u < kFinishBatch; ++u) {
+        const unsigned p = s0 + base + 64u * u + (unsigned)lane;
+        e[u] = p < n ? desc_read(A.a, first + p, med, e0) : pv;
       }
-      nl += (unsigned)GZ_POPCLL(__ballot(fl));
-      nr += (unsigned)GZ_POPCLL(__ballot(fr));
+#pragma unroll
+      for (int u = 0; u < kFinishBatch; ++u) {
+        const unsigned p = s0 + base + 64u * u + (unsigned)lane;
+        const bool fl = p < n && !order_less(e[u], pv), fr = p < n && !order_less(pv, e[u]);
+        nl += (unsigned)GZ_POPCLL(__ballot(fl));
+        nr += (unsigned)GZ_POPCLL(__ballot(fr));
+      }
     }
     if (lane == 0) { s_wl[wv] = nl; s_wr[wv] = nr; }
     if (t == 0) s_m = 0u;
@@ -980,34 +987,56 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
       total_r += s_wr[w];
     }
     // ... then their positions, in order, into the two lists
-    for (unsigned base = 0; base < seg; base += 64) {
-      const unsigned p = s0 + base + (unsigned)lane;
-      bool fl = false, fr = false;
-      if (p < n) {
-        const OrderEntry e = desc_read(A.a, first + p, med, e0);
-        fl = !order_less(e, pv);
-        fr = !order_less(pv, e);
+    for (unsigned base = 0; base < seg; base += 64 * kFinishBatch) {
+      OrderEntry e[kFinishBatch];
+#pragma unroll
+      for (int u = 0; u < kFinishBatch; ++u) {
+        const unsigned p = s0 + base + 64u * u + (unsigned)lane;
+        e[u] = p < n ? desc_read(A.a, first + p, med, e0) : pv;
       }
-      const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
-      if (fl) A.lpos[ol + (unsigned)GZ_POPCLL(ml & lt)] = p;
-      if (fr) A.rpos[orr + (unsigned)GZ_POPCLL(mr & lt)] = p;
-      ol += (unsigned)GZ_POPCLL(ml);
-      orr += (unsigned)GZ_POPCLL(mr);
+#pragma unroll
+      for (int u = 0; u < kFinishBatch; ++u) {
+        const unsigned p = s0 + base + 64u * u + (unsigned)lane;
+        const bool fl = p < n && !order_less(e[u], pv), fr = p < n && !order_less(pv, e[u]);
+        const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
+        if (fl) A.lpos[ol + (unsigned)GZ_POPCLL(ml & lt)] = p;
+        if (fr) A.rpos[orr + (unsigned)GZ_POPCLL(mr & lt)] = p;
+        ol += (unsigned)GZ_POPCLL(ml);
+        orr += (unsigned)GZ_POPCLL(mr);
+      }
     }
     __syncthreads();
     // pair k = (k-th left stopper, k-th right stopper from the right) swaps while they have not
-    // crossed; crossing is monotone in k, so the number of swapped pairs is the crossing point
+    // crossed; crossing is monotone in k, so the number of swapped pairs is the crossing point.
+    // kFinishBatch pairs per thread and step in three rounds -- positions, values, stores -- each
+    // round's accesses independent of one another.
     const unsigned K = total_l < total_r ? total_l : total_r;
     unsigned mine = 0;
-    for (unsigned k = (unsigned)t; k < K; k += kFinishThreads) {
-      const unsigned pl = A.lpos[k], pr = A.rpos[total_r - 1 - k];
-      if (pl < pr) {
-        const OrderEntry vl = desc_read(A.a, first + pl, med, e0);
-        const OrderEntry vr = desc_read(A.a, first + pr, med, e0);
-        A.a[first + pl] = vr;
-        A.a[first + pr] = vl;
-        ++mine;
+    for (unsigned k0 = (unsigned)t; k0 < K; k0 += kFinishThreads * kFinishBatch) {
+      unsigned pl[kFinishBatch], pr[kFinishBatch];
+      bool sw[kFinishBatch];
+#pragma unroll
+      for (int u = 0; u < kFinishBatch; ++u) {
+        const unsigned k = k0 + (unsigned)u * kFinishThreads;
+        pl[u] = k < K ? A.lpos[k] : 0xffffffffu;
+        pr[u] = k < K ? A.rpos[total_r - 1 - k] : 0u;
       }
+      OrderEntry vl[kFinishBatch], vr[kFinishBatch];
+#pragma unroll
+      for (int u = 0; u < kFinishBatch; ++u) {
+        sw[u] = pl[u] < pr[u];
+        if (sw[u]) {
+          vl[u] = desc_read(A.a, first + pl[u], med, e0);
+          vr[u] = desc_read(A.a, first + pr[u], med, e0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kFinishBatch; ++u)
+        if (sw[u]) {
+          A.a[first + pl[u]] = vr[u];
+          A.a[first + pr[u]] = vl[u];
+          ++mine;
+        }
     }
     if (mine) atomicAdd(&s_m, mine);
     __syncthreads();

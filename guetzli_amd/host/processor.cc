@@ -864,7 +864,9 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         // The introsort partitions that lead to position fast_until - 1, made by the device
         // without the host in between: behind the order's construction when that was enqueued
         // ahead (the device derives the position as the lines above do), else now, in one call.
-        if (n_order > device_threshold_) {
+        // (A log made ahead must be replayed whatever the order's size: k_desc_finish has rearranged
+        // the device's array along it.)
+        if (have_ahead_log || n_order > device_threshold_) {
           const uint64_t want = fast_until ? fast_until - 1 : 0;
           if (have_ahead_log) {
             if (ahead_last != want) return Fail("gz_order_descend: position", GZ_E_STATE);

@@ -85,6 +85,29 @@ def test_whole_encode_matches_reference_in_emulation(host_emu, case, monkeypatch
     assert info["counters"]["number of iterations"] >= 3
 
 
+@needs_ref
+@pytest.mark.parametrize("threshold", [None, 128])
+def test_repeated_content_ties_in_the_global_order(host_emu, monkeypatch, threshold):
+    """An image of one 16x16 patch repeated: every block has eleven exact copies, so the keys of
+    phase B's global order tie in groups of twelve and which copy std::sort serves first decides the
+    bytes.  With the default threshold these small orders are taken all the way down by the
+    device's single-workgroup descent (k_desc_finish) behind their construction, and the driver must
+    replay that log whatever the order's size (a GPU-only failure of round 4: the emulation's other
+    images have no ties to get wrong); with a threshold of 128 the chip-wide levels run first."""
+    if threshold:
+        monkeypatch.setenv("GZ_ORDER_DEVICE_THRESHOLD", str(threshold))
+    rgb = np.ascontiguousarray(np.tile(images.crop(16, 16, 200, 100), (3, 4, 1)))
+    assert rgb.shape == (48, 64, 3)
+    target = ref._butteraugli_score_for_quality(95.0)
+    exp_jpg, exp_trace = ref.process(rgb, target, want_trace=True)
+    got_jpg, info = host_emu.process(rgb, quality=95, want_trace=True)
+    assert info["trace"].splitlines() == exp_trace.splitlines()
+    assert got_jpg == exp_jpg
+    got2, info2 = host_emu.process(rgb, quality=95)      # (without a trace: the size-bound path)
+    assert got2 == exp_jpg
+    assert info2["counters"]["phase B partitions made ahead"] > 0
+
+
 def test_descent_position_mismatch_aborts_the_encode(host_emu, monkeypatch, capfd):
     """The device rearranges the order along ITS derivation of the descent position; the host
     replays the logged partitions along its own.  If the two ever disagreed the array would no

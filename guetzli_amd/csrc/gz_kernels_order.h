@@ -905,11 +905,18 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
 #endif
 constexpr int kFinishThreads = 1024;
 constexpr int kFinishBatch = 4;   // rows of 64 entries / pairs a thread has in flight per step
+constexpr int kFinishLds = 8192;   // entries of a range that moves into LDS (64 KB + 2 x 32 KB of lists)
 __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int levels, unsigned max_range) {
   __shared__ DescState s_state;
   __shared__ int s_level;
   __shared__ unsigned s_wl[kFinishThreads / 64], s_wr[kFinishThreads / 64];
-  __shared__ unsigned s_m;
+  __shared__ unsigned s_m, s_moved;
+  // Once the range fits, it moves into LDS with its two stopper lists and every further level runs
+  // there: a level is half a dozen dependent trips to memory whatever its size (pivot, the two
+  // passes, the pairs' positions, their values, the cut), ~1 us each to L2 and ~0.1 to LDS, and
+  // nine of a 64 K range's twelve levels are below kFinishLds entries.
+  __shared__ __attribute__((aligned(16))) OrderEntry s_a[kFinishLds];
+  __shared__ unsigned s_lp[kFinishLds], s_rp[kFinishLds];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   constexpr int NWV = kFinishThreads / 64;
   if (t == 0) {
@@ -937,12 +944,27 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
   int depth = s_state.depth;
   if (hi - lo > (unsigned long long)max_range) return;
   const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;   // lanes below this one
+  OrderEntry* a = A.a;            // a[i] = entry at position i of the order (global memory, or the LDS copy)
+  unsigned* lp = A.lpos;
+  unsigned* rp = A.rpos;
+  bool in_lds = false;
+  unsigned long long lds_lo = 0, lds_hi = 0;
   while (hi - lo > 16 && depth > 0 && L < kDescMaxLevels) {
+    if (!in_lds && hi - lo <= (unsigned long long)kFinishLds) {
+      for (unsigned long long i = lo + (unsigned)t; i < hi; i += kFinishThreads) s_a[i - lo] = A.a[i];
+      __syncthreads();
+      a = s_a - lo;   // (indexed by absolute position like the global array)
+      lp = s_lp;
+      rp = s_rp;
+      in_lds = true;
+      lds_lo = lo;
+      lds_hi = hi;
+    }
     const unsigned long long first = lo + 1;
     const unsigned n = (unsigned)(hi - first);
     // std::__move_median_to_first(lo, lo + 1, mid, hi - 1), virtually (as k_desc_count)
     const unsigned long long x = lo + 1, y = lo + (hi - lo) / 2, z = hi - 1;
-    const OrderEntry ex = A.a[x], ey = A.a[y], ez = A.a[z], e0 = A.a[lo];
+    const OrderEntry ex = a[x], ey = a[y], ez = a[z], e0 = a[lo];
     unsigned long long med;
     if (order_less(ex, ey)) {
       if (order_less(ey, ez)) med = y;
@@ -967,7 +989,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
         const unsigned p = s0 + base + 64u * u + (unsigned)lane;
-        e[u] = p < n ? desc_read(A.a, first + p, med, e0) : pv;
+        e[u] = p < n ? desc_read(a, first + p, med, e0) : pv;
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
@@ -978,7 +1000,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
       }
     }
     if (lane == 0) { s_wl[wv] = nl; s_wr[wv] = nr; }
-    if (t == 0) s_m = 0u;
+    if (t == 0) { s_m = 0u; s_moved = 0u; }
     __syncthreads();
     unsigned ol = 0, orr = 0, total_l = 0, total_r = 0;
     for (int w = 0; w < NWV; ++w) {
@@ -992,15 +1014,15 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
         const unsigned p = s0 + base + 64u * u + (unsigned)lane;
-        e[u] = p < n ? desc_read(A.a, first + p, med, e0) : pv;
+        e[u] = p < n ? desc_read(a, first + p, med, e0) : pv;
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
         const unsigned p = s0 + base + 64u * u + (unsigned)lane;
         const bool fl = p < n && !order_less(e[u], pv), fr = p < n && !order_less(pv, e[u]);
         const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
-        if (fl) A.lpos[ol + (unsigned)GZ_POPCLL(ml & lt)] = p;
-        if (fr) A.rpos[orr + (unsigned)GZ_POPCLL(mr & lt)] = p;
+        if (fl) lp[ol + (unsigned)GZ_POPCLL(ml & lt)] = p;
+        if (fr) rp[orr + (unsigned)GZ_POPCLL(mr & lt)] = p;
         ol += (unsigned)GZ_POPCLL(ml);
         orr += (unsigned)GZ_POPCLL(mr);
       }
@@ -1011,6 +1033,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
     // kFinishBatch pairs per thread and step in three rounds -- positions, values, stores -- each
     // round's accesses independent of one another.
     const unsigned K = total_l < total_r ? total_l : total_r;
+    const unsigned pm = (unsigned)(med - first);
     unsigned mine = 0;
     for (unsigned k0 = (unsigned)t; k0 < K; k0 += kFinishThreads * kFinishBatch) {
       unsigned pl[kFinishBatch], pr[kFinishBatch];
@@ -1018,49 +1041,39 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
         const unsigned k = k0 + (unsigned)u * kFinishThreads;
-        pl[u] = k < K ? A.lpos[k] : 0xffffffffu;
-        pr[u] = k < K ? A.rpos[total_r - 1 - k] : 0u;
+        pl[u] = k < K ? lp[k] : 0xffffffffu;
+        pr[u] = k < K ? rp[total_r - 1 - k] : 0u;
       }
       OrderEntry vl[kFinishBatch], vr[kFinishBatch];
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
         sw[u] = pl[u] < pr[u];
         if (sw[u]) {
-          vl[u] = desc_read(A.a, first + pl[u], med, e0);
-          vr[u] = desc_read(A.a, first + pr[u], med, e0);
+          vl[u] = desc_read(a, first + pl[u], med, e0);
+          vr[u] = desc_read(a, first + pr[u], med, e0);
         }
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u)
         if (sw[u]) {
-          A.a[first + pl[u]] = vr[u];
-          A.a[first + pr[u]] = vl[u];
+          a[first + pl[u]] = vr[u];
+          a[first + pr[u]] = vl[u];
           ++mine;
+          if (pl[u] == pm || pr[u] == pm) s_moved = 1u;   // the place the pivot came from got a partner
         }
     }
     if (mine) atomicAdd(&s_m, mine);
     __syncthreads();
     const unsigned m = s_m;
     unsigned long long cut = hi;   // (libstdc++ __unguarded_partition returns `first`)
-    if (m < total_l) { const unsigned long long c2 = first + A.lpos[m]; cut = c2 < cut ? c2 : cut; }
-    if (m >= 1) { const unsigned long long c2 = first + A.rpos[total_r - m]; cut = c2 < cut ? c2 : cut; }
+    if (m < total_l) { const unsigned long long c2 = first + lp[m]; cut = c2 < cut ? c2 : cut; }
+    if (m >= 1) { const unsigned long long c2 = first + rp[total_r - m]; cut = c2 < cut ? c2 : cut; }
     if (t == 0) {
       // the median's move to the front, made real: the front gets the pivot; the place the pivot
       // came from gets the old front element unless a pair above has put a partner there
-      A.a[lo] = pv;
-      const unsigned pm = (unsigned)(med - first);
-      bool moved = false;
-      if (!order_less(e0, pv)) {   // a left stopper: its rank among them
-        unsigned a0 = 0, a1 = total_l;
-        while (a0 < a1) { const unsigned mid = (a0 + a1) >> 1; if (A.lpos[mid] < pm) a0 = mid + 1; else a1 = mid; }
-        if (a0 < m) moved = true;
-      }
-      if (!moved && !order_less(pv, e0)) {   // a right stopper: its rank from the right
-        unsigned a0 = 0, a1 = total_r;
-        while (a0 < a1) { const unsigned mid = (a0 + a1) >> 1; if (A.rpos[mid] < pm) a0 = mid + 1; else a1 = mid; }
-        if (total_r - 1 - a0 < m) moved = true;
-      }
-      if (!moved) A.a[med] = e0;
+      a[lo] = pv;
+      const bool moved = s_moved != 0u;
+      if (!moved) a[med] = e0;
       DescState nx;
       if (last < cut) { nx.lo = lo; nx.hi = cut; } else { nx.lo = cut; nx.hi = hi; }
       nx.last = last;
@@ -1081,14 +1094,18 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
   }
   if (hi - lo <= 16 && t == 0) {   // std::__insertion_sort of the final range
     for (unsigned long long i = lo + 1; i < hi; ++i) {
-      const OrderEntry val = A.a[i];
+      const OrderEntry val = a[i];
       unsigned long long j = i;
-      while (j > lo && order_less(val, A.a[j - 1])) {
-        A.a[j] = A.a[j - 1];
+      while (j > lo && order_less(val, a[j - 1])) {
+        a[j] = a[j - 1];
         --j;
       }
-      A.a[j] = val;
+      a[j] = val;
     }
+  }
+  if (in_lds) {   // the LDS copy back to where it came from (entries only moved inside that range)
+    __syncthreads();
+    for (unsigned long long i = lds_lo + (unsigned)t; i < lds_hi; i += kFinishThreads) A.a[i] = s_a[i - lds_lo];
   }
 }
 

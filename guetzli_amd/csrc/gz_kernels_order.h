@@ -944,16 +944,19 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
   int depth = s_state.depth;
   if (hi - lo > (unsigned long long)max_range) return;
   const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;   // lanes below this one
-  OrderEntry* a = A.a;            // a[i] = entry at position i of the order (global memory, or the LDS copy)
+  OrderEntry* a = A.a;            // position i of the order is a[i - off] (global memory, or the LDS copy)
+  unsigned long long off = 0;
   unsigned* lp = A.lpos;
   unsigned* rp = A.rpos;
   bool in_lds = false;
   unsigned long long lds_lo = 0, lds_hi = 0;
+#define FIN_READ(p) ((p) == med ? e0 : a[(p) - off])
   while (hi - lo > 16 && depth > 0 && L < kDescMaxLevels) {
     if (!in_lds && hi - lo <= (unsigned long long)kFinishLds) {
       for (unsigned long long i = lo + (unsigned)t; i < hi; i += kFinishThreads) s_a[i - lo] = A.a[i];
       __syncthreads();
-      a = s_a - lo;   // (indexed by absolute position like the global array)
+      a = s_a;
+      off = lo;   // (position i of the order is a[i - off])
       lp = s_lp;
       rp = s_rp;
       in_lds = true;
@@ -964,7 +967,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
     const unsigned n = (unsigned)(hi - first);
     // std::__move_median_to_first(lo, lo + 1, mid, hi - 1), virtually (as k_desc_count)
     const unsigned long long x = lo + 1, y = lo + (hi - lo) / 2, z = hi - 1;
-    const OrderEntry ex = a[x], ey = a[y], ez = a[z], e0 = a[lo];
+    const OrderEntry ex = a[(x) - off], ey = a[(y) - off], ez = a[(z) - off], e0 = a[(lo) - off];
     unsigned long long med;
     if (order_less(ex, ey)) {
       if (order_less(ey, ez)) med = y;
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
         const unsigned p = s0 + base + 64u * u + (unsigned)lane;
-        e[u] = p < n ? desc_read(a, first + p, med, e0) : pv;
+        e[u] = p < n ? FIN_READ(first + p) : pv;
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
         const unsigned p = s0 + base + 64u * u + (unsigned)lane;
-        e[u] = p < n ? desc_read(a, first + p, med, e0) : pv;
+        e[u] = p < n ? FIN_READ(first + p) : pv;
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u) {
@@ -1049,15 +1052,15 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
       for (int u = 0; u < kFinishBatch; ++u) {
         sw[u] = pl[u] < pr[u];
         if (sw[u]) {
-          vl[u] = desc_read(a, first + pl[u], med, e0);
-          vr[u] = desc_read(a, first + pr[u], med, e0);
+          vl[u] = FIN_READ(first + pl[u]);
+          vr[u] = FIN_READ(first + pr[u]);
         }
       }
 #pragma unroll
       for (int u = 0; u < kFinishBatch; ++u)
         if (sw[u]) {
-          a[first + pl[u]] = vr[u];
-          a[first + pr[u]] = vl[u];
+          a[first + pl[u] - off] = vr[u];
+          a[first + pr[u] - off] = vl[u];
           ++mine;
           if (pl[u] == pm || pr[u] == pm) s_moved = 1u;   // the place the pivot came from got a partner
         }
@@ -1071,9 +1074,9 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
     if (t == 0) {
       // the median's move to the front, made real: the front gets the pivot; the place the pivot
       // came from gets the old front element unless a pair above has put a partner there
-      a[lo] = pv;
+      a[(lo) - off] = pv;
       const bool moved = s_moved != 0u;
-      if (!moved) a[med] = e0;
+      if (!moved) a[(med) - off] = e0;
       DescState nx;
       if (last < cut) { nx.lo = lo; nx.hi = cut; } else { nx.lo = cut; nx.hi = hi; }
       nx.last = last;
@@ -1094,13 +1097,13 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
   }
   if (hi - lo <= 16 && t == 0) {   // std::__insertion_sort of the final range
     for (unsigned long long i = lo + 1; i < hi; ++i) {
-      const OrderEntry val = a[i];
+      const OrderEntry val = a[(i) - off];
       unsigned long long j = i;
-      while (j > lo && order_less(val, a[j - 1])) {
-        a[j] = a[j - 1];
+      while (j > lo && order_less(val, a[(j - 1) - off])) {
+        a[(j) - off] = a[(j - 1) - off];
         --j;
       }
-      a[j] = val;
+      a[(j) - off] = val;
     }
   }
   if (in_lds) {   // the LDS copy back to where it came from (entries only moved inside that range)
@@ -1108,6 +1111,7 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
     for (unsigned long long i = lds_lo + (unsigned)t; i < lds_hi; i += kFinishThreads) A.a[i] = s_a[i - lds_lo];
   }
 }
+#undef FIN_READ
 
 // Behind the last level of a descent: the leading entries of the order up to the end of the range
 // the descent ended in -- what the search driver fetches next (guetzli_amd/host/processor.cc:

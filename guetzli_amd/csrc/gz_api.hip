@@ -2175,7 +2175,6 @@ int gz_order_fetch(gz_ctx* c, uint64_t lo, uint64_t hi, void* out) {
 
 
 // ---- quick-select descent decided on the device (gz_kernels_order.h: k_desc_count / k_desc_swap)
-static_assert(kDescMaxLevels == GZ_ORDER_MAX_LEVELS, "the header's log size is the kernels'");
 static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, float per_block,
                            uint64_t threshold, int max_levels, size_t n_bound, bool publish = false) {
   if (!c->d_desc_st) {
@@ -2214,11 +2213,6 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
     GZ_LAUNCH(k_desc_swap, dim3((unsigned)swap_groups), dim3(256), c->stream, A, l);
     KCHK(c);
   }
-  // ... and the rest of the way, down to the 16 entries around the wanted position, in one workgroup
-  if (levels > 0) {
-    GZ_LAUNCH(k_desc_finish, dim3(1), dim3(kFinishThreads), c->stream, A, levels, 1u << 18);
-    KCHK(c);
-  }
   // gz_order_build_auto_descend_begin: the prefix the driver fetches next goes to its host mirror
   // behind the last level (the driver's own bound on such a fetch: 2^19 entries)
   c->export_epoch = 0;
@@ -2242,12 +2236,11 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
 
 static int descend_collect(gz_ctx* c, uint64_t* log, int cap_levels, int* levels) {
   int n = 0;
-  for (int l = 0; c->desc_levels > 0 && l < kDescMaxLevels; ++l) {
+  for (int l = 0; l < c->desc_levels && n < cap_levels; ++l) {
     const DescState& before = c->h_desc[l];
     const DescState& after = c->h_desc[l + 1];
     if (after.epoch != c->desc_epoch || before.epoch != c->desc_epoch) break;
     if (!(after.cut > before.lo && after.cut <= before.hi)) { c->err = "descent: cut outside its range"; return GZ_E_STATE; }
-    if (n >= cap_levels) { c->err = "descent: log too small for the levels made"; return GZ_E_ARG; }
     log[3 * n + 0] = before.lo;
     log[3 * n + 1] = before.hi;
     log[3 * n + 2] = after.cut;
@@ -2266,7 +2259,7 @@ int gz_order_descend(gz_ctx* c, uint64_t last, uint64_t threshold, int max_level
   TRY(descend_enqueue(c, 0, c->order_n, last, 0.0f, threshold, max_levels, c->order_n));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->desc_pending = false;
-  return descend_collect(c, log, kDescMaxLevels, levels);   // (the caller's log holds GZ_ORDER_MAX_LEVELS triples)
+  return descend_collect(c, log, max_levels, levels);
 }
 
 int gz_order_descend_begin(gz_ctx* c, float per_block, uint64_t threshold, int max_levels) {

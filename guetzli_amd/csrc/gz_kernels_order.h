@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, s
 // element) and k_desc_swap's first thread makes it real.  The arrangement and the cuts are those
 // of gz_order_partition (and of std::sort): tests/cpp/test_device_order.cc.
 constexpr int kDescMaxChunks = 4096;   // chunk tables of a workgroup: ranges up to 8.4 M entries
-constexpr int kDescMaxLevels = 48;   // 12 for the chip-wide levels + what k_desc_finish adds below them
+constexpr int kDescMaxLevels = 12;
 
 struct DescState {                 // the range before level l (level 0: derived, see desc_load)
   unsigned long long lo, hi;       // the range that holds `last`
@@ -627,21 +627,8 @@ struct DescArgs {
 };
 
 // The range level `level` works on; false = nothing to do at this level.
-// The whole order as the first range: its size, introsort's depth limit, the wanted position.
-GZ_DEVFN bool desc_initial(const DescArgs& A, DescState* s);
 GZ_DEVFN bool desc_load(const DescArgs& A, int level, DescState* s) {
   if (level == 0) {
-    if (!desc_initial(A, s)) return false;
-  } else {
-    *s = A.st[level];
-    if (s->epoch != A.epoch) return false;
-  }
-  const unsigned long long len = s->hi - s->lo;
-  return len > A.threshold && len > 16 && s->depth > 0 &&
-         len - 1 <= (unsigned long long)kDescMaxChunks * kPartChunk;
-}
-GZ_DEVFN bool desc_initial(const DescArgs& A, DescState* s) {
-  {
     const unsigned long long n = A.derive ? *A.total : A.n0;
     if (n == 0) return false;
     s->lo = 0;
@@ -664,8 +651,13 @@ GZ_DEVFN bool desc_initial(const DescArgs& A, DescState* s) {
     }
     s->cut = 0;
     s->epoch = A.epoch;
+  } else {
+    *s = A.st[level];
+    if (s->epoch != A.epoch) return false;
   }
-  return true;
+  const unsigned long long len = s->hi - s->lo;
+  return len > A.threshold && len > 16 && s->depth > 0 &&
+         len - 1 <= (unsigned long long)kDescMaxChunks * kPartChunk;
 }
 
 GZ_DEVFN OrderEntry desc_read(const OrderEntry* a, unsigned long long p, unsigned long long med,
@@ -884,235 +876,6 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
   }
 }
 
-// ---------------------------------------------------- the rest of the descent in ONE workgroup --
-// Below `threshold` entries the chip-wide levels stop (two launches per level cost more than the
-// range is worth) and, until round 4, the host took over: it fetched the range, went on
-// partitioning it on one core until the part holding `last` was down to introsort's 16, and
-// insertion-sorted that -- 107 us per iteration of a 4K encode with the device idle.  A range of
-// that size is one workgroup's work: k_desc_finish goes on from wherever the launches before it
-// got to -- the same steps (median of three moved to the front, unguarded Hoare partition as two
-// ordered stopper lists and pairwise swaps, keep the side that holds `last`), logged level by
-// level for the host's replay exactly as k_desc_swap logs them -- down to a range of <= 16 entries,
-// which it insertion-sorts (libstdc++'s final pass never moves an element across a range
-// boundary: guetzli_amd/host/lazy_sort.h).  Afterwards positions [0, last] of the array hold
-// exactly the entries std::sort would put there, position `last` itself final.  It stops early --
-// and the host finishes as before -- when the range is still larger than `max_range`, when
-// introsort's depth limit is reached (the heap-sort fallback) or when the log is full.
-#ifdef GZ_EMU
-#define GZ_POPCLL(x) __builtin_popcountll(x)
-#else
-#define GZ_POPCLL(x) __popcll(x)
-#endif
-constexpr int kFinishThreads = 1024;
-constexpr int kFinishBatch = 4;   // rows of 64 entries / pairs a thread has in flight per step
-constexpr int kFinishLds = 8192;   // entries of a range that moves into LDS (64 KB + 2 x 32 KB of lists)
-__global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int levels, unsigned max_range) {
-  __shared__ DescState s_state;
-  __shared__ int s_level;
-  __shared__ unsigned s_wl[kFinishThreads / 64], s_wr[kFinishThreads / 64];
-  __shared__ unsigned s_m, s_moved;
-  // Once the range fits, it moves into LDS with its two stopper lists and every further level runs
-  // there: a level is half a dozen dependent trips to memory whatever its size (pivot, the two
-  // passes, the pairs' positions, their values, the cut), ~1 us each to L2 and ~0.1 to LDS, and
-  // nine of a 64 K range's twelve levels are below kFinishLds entries.
-  __shared__ __attribute__((aligned(16))) OrderEntry s_a[kFinishLds];
-  __shared__ unsigned s_lp[kFinishLds], s_rp[kFinishLds];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  constexpr int NWV = kFinishThreads / 64;
-  if (t == 0) {
-    DescState s;
-    int L = -1;
-    if (A.st[0].epoch == A.epoch) {   // the chip-wide levels made at least one cut
-      s = A.st[0];
-      L = 0;
-      for (int l = 0; l < levels && l < kDescMaxLevels; ++l) {
-        if (A.st[l + 1].epoch != A.epoch) break;
-        s = A.st[l + 1];
-        L = l + 1;
-      }
-    } else if (desc_initial(A, &s)) {   // none: the whole order is this kernel's
-      L = 0;
-    }
-    s_state = s;
-    s_level = L;
-  }
-  __syncthreads();
-  int L = s_level;
-  if (L < 0) return;
-  unsigned long long lo = s_state.lo, hi = s_state.hi;
-  const unsigned long long last = s_state.last;
-  int depth = s_state.depth;
-  if (hi - lo > (unsigned long long)max_range) return;
-  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;   // lanes below this one
-  OrderEntry* a = A.a;            // position i of the order is a[i - off] (global memory, or the LDS copy)
-  unsigned long long off = 0;
-  unsigned* lp = A.lpos;
-  unsigned* rp = A.rpos;
-  bool in_lds = false;
-  unsigned long long lds_lo = 0, lds_hi = 0;
-#define FIN_READ(p) ((p) == med ? e0 : a[(p) - off])
-  while (hi - lo > 16 && depth > 0 && L < kDescMaxLevels) {
-    if (!in_lds && hi - lo <= (unsigned long long)kFinishLds) {
-      for (unsigned long long i = lo + (unsigned)t; i < hi; i += kFinishThreads) s_a[i - lo] = A.a[i];
-      __syncthreads();
-      a = s_a;
-      off = lo;   // (position i of the order is a[i - off])
-      lp = s_lp;
-      rp = s_rp;
-      in_lds = true;
-      lds_lo = lo;
-      lds_hi = hi;
-    }
-    const unsigned long long first = lo + 1;
-    const unsigned n = (unsigned)(hi - first);
-    // std::__move_median_to_first(lo, lo + 1, mid, hi - 1), virtually (as k_desc_count)
-    const unsigned long long x = lo + 1, y = lo + (hi - lo) / 2, z = hi - 1;
-    const OrderEntry ex = a[(x) - off], ey = a[(y) - off], ez = a[(z) - off], e0 = a[(lo) - off];
-    unsigned long long med;
-    if (order_less(ex, ey)) {
-      if (order_less(ey, ez)) med = y;
-      else if (order_less(ex, ez)) med = z;
-      else med = x;
-    } else if (order_less(ex, ez)) {
-      med = x;
-    } else if (order_less(ey, ez)) {
-      med = z;
-    } else {
-      med = y;
-    }
-    const OrderEntry pv = med == x ? ex : (med == y ? ey : ez);
-    // a wavefront takes a contiguous segment, its lanes consecutive entries -- kFinishBatch rows of
-    // 64 per step, all of a step's loads in flight together (one row per step would make every
-    // step wait for a trip to L2: 64 dependent trips per pass on a 64 K range): stopper counts ...
-    const unsigned seg = ((n + NWV - 1) / NWV + (64 * kFinishBatch - 1)) / (64 * kFinishBatch) * (64 * kFinishBatch);
-    const unsigned s0 = (unsigned)wv * seg;
-    unsigned nl = 0, nr = 0;
-    for (unsigned base = 0; base < seg; base += 64 * kFinishBatch) {
-      OrderEntry e[kFinishBatch];
-#pragma unroll
-      for (int u = 0; u < kFinishBatch; ++u) {
-        const unsigned p = s0 + base + 64u * u + (unsigned)lane;
-        e[u] = p < n ? FIN_READ(first + p) : pv;
-      }
-#pragma unroll
-      for (int u = 0; u < kFinishBatch; ++u) {
-        const unsigned p = s0 + base + 64u * u + (unsigned)lane;
-        const bool fl = p < n && !order_less(e[u], pv), fr = p < n && !order_less(pv, e[u]);
-        nl += (unsigned)GZ_POPCLL(__ballot(fl));
-        nr += (unsigned)GZ_POPCLL(__ballot(fr));
-      }
-    }
-    if (lane == 0) { s_wl[wv] = nl; s_wr[wv] = nr; }
-    if (t == 0) { s_m = 0u; s_moved = 0u; }
-    __syncthreads();
-    unsigned ol = 0, orr = 0, total_l = 0, total_r = 0;
-    for (int w = 0; w < NWV; ++w) {
-      if (w < wv) { ol += s_wl[w]; orr += s_wr[w]; }
-      total_l += s_wl[w];
-      total_r += s_wr[w];
-    }
-    // ... then their positions, in order, into the two lists
-    for (unsigned base = 0; base < seg; base += 64 * kFinishBatch) {
-      OrderEntry e[kFinishBatch];
-#pragma unroll
-      for (int u = 0; u < kFinishBatch; ++u) {
-        const unsigned p = s0 + base + 64u * u + (unsigned)lane;
-        e[u] = p < n ? FIN_READ(first + p) : pv;
-      }
-#pragma unroll
-      for (int u = 0; u < kFinishBatch; ++u) {
-        const unsigned p = s0 + base + 64u * u + (unsigned)lane;
-        const bool fl = p < n && !order_less(e[u], pv), fr = p < n && !order_less(pv, e[u]);
-        const unsigned long long ml = __ballot(fl), mr = __ballot(fr);
-        if (fl) lp[ol + (unsigned)GZ_POPCLL(ml & lt)] = p;
-        if (fr) rp[orr + (unsigned)GZ_POPCLL(mr & lt)] = p;
-        ol += (unsigned)GZ_POPCLL(ml);
-        orr += (unsigned)GZ_POPCLL(mr);
-      }
-    }
-    __syncthreads();
-    // pair k = (k-th left stopper, k-th right stopper from the right) swaps while they have not
-    // crossed; crossing is monotone in k, so the number of swapped pairs is the crossing point.
-    // kFinishBatch pairs per thread and step in three rounds -- positions, values, stores -- each
-    // round's accesses independent of one another.
-    const unsigned K = total_l < total_r ? total_l : total_r;
-    const unsigned pm = (unsigned)(med - first);
-    unsigned mine = 0;
-    for (unsigned k0 = (unsigned)t; k0 < K; k0 += kFinishThreads * kFinishBatch) {
-      unsigned pl[kFinishBatch], pr[kFinishBatch];
-      bool sw[kFinishBatch];
-#pragma unroll
-      for (int u = 0; u < kFinishBatch; ++u) {
-        const unsigned k = k0 + (unsigned)u * kFinishThreads;
-        pl[u] = k < K ? lp[k] : 0xffffffffu;
-        pr[u] = k < K ? rp[total_r - 1 - k] : 0u;
-      }
-      OrderEntry vl[kFinishBatch], vr[kFinishBatch];
-#pragma unroll
-      for (int u = 0; u < kFinishBatch; ++u) {
-        sw[u] = pl[u] < pr[u];
-        if (sw[u]) {
-          vl[u] = FIN_READ(first + pl[u]);
-          vr[u] = FIN_READ(first + pr[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kFinishBatch; ++u)
-        if (sw[u]) {
-          a[first + pl[u] - off] = vr[u];
-          a[first + pr[u] - off] = vl[u];
-          ++mine;
-          if (pl[u] == pm || pr[u] == pm) s_moved = 1u;   // the place the pivot came from got a partner
-        }
-    }
-    if (mine) atomicAdd(&s_m, mine);
-    __syncthreads();
-    const unsigned m = s_m;
-    unsigned long long cut = hi;   // (libstdc++ __unguarded_partition returns `first`)
-    if (m < total_l) { const unsigned long long c2 = first + lp[m]; cut = c2 < cut ? c2 : cut; }
-    if (m >= 1) { const unsigned long long c2 = first + rp[total_r - m]; cut = c2 < cut ? c2 : cut; }
-    if (t == 0) {
-      // the median's move to the front, made real: the front gets the pivot; the place the pivot
-      // came from gets the old front element unless a pair above has put a partner there
-      a[(lo) - off] = pv;
-      const bool moved = s_moved != 0u;
-      if (!moved) a[(med) - off] = e0;
-      DescState nx;
-      if (last < cut) { nx.lo = lo; nx.hi = cut; } else { nx.lo = cut; nx.hi = hi; }
-      nx.last = last;
-      nx.cut = cut;
-      nx.depth = depth - 1;
-      nx.epoch = A.epoch;
-      A.st[L + 1] = nx;
-      if (L == 0) {
-        DescState s0s;
-        s0s.lo = lo; s0s.hi = hi; s0s.last = last; s0s.cut = 0; s0s.depth = depth; s0s.epoch = A.epoch;
-        A.st[0] = s0s;
-      }
-    }
-    if (last < cut) hi = cut; else lo = cut;
-    --depth;
-    ++L;
-    __syncthreads();   // the swaps and the front element are in place before the next level reads
-  }
-  if (hi - lo <= 16 && t == 0) {   // std::__insertion_sort of the final range
-    for (unsigned long long i = lo + 1; i < hi; ++i) {
-      const OrderEntry val = a[(i) - off];
-      unsigned long long j = i;
-      while (j > lo && order_less(val, a[(j - 1) - off])) {
-        a[(j) - off] = a[(j - 1) - off];
-        --j;
-      }
-      a[(j) - off] = val;
-    }
-  }
-  if (in_lds) {   // the LDS copy back to where it came from (entries only moved inside that range)
-    __syncthreads();
-    for (unsigned long long i = lds_lo + (unsigned)t; i < lds_hi; i += kFinishThreads) A.a[i] = s_a[i - lds_lo];
-  }
-}
-#undef FIN_READ
-
 // Behind the last level of a descent: the leading entries of the order up to the end of the range
 // the descent ended in -- what the search driver fetches next (guetzli_amd/host/processor.cc:
 // DeviceOrder::Prefetch) -- written straight into the context's page-locked host mirror, when the
@@ -1122,20 +885,17 @@ __global__ __launch_bounds__(kFinishThreads) void k_desc_finish(DescArgs A, int 
 __global__ __launch_bounds__(256) void k_desc_export(DescArgs A, int levels, OrderEntry* __restrict__ dst,
                                                      unsigned long long max_entries) {
   __shared__ unsigned long long s_hi;
-  (void)levels;
   if (threadIdx.x == 0) {
-    // the first range of the descent that is small enough for the host: k_desc_finish has taken
-    // the part of it that holds `last` further, the host walks on into its other parts
     unsigned long long lo = 0, hi = 0;
-    bool found = false;
-    for (int l = 0; l <= kDescMaxLevels && !found; ++l) {
+    bool any = false;
+    for (int l = 1; l <= levels; ++l) {
       const DescState st = A.st[l];
       if (st.epoch != A.epoch) break;
       lo = st.lo;
       hi = st.hi;
-      found = hi - lo <= A.threshold;
+      any = true;
     }
-    const bool ok = found && hi <= max_entries;
+    const bool ok = any && hi - lo <= A.threshold && hi <= max_entries;
     s_hi = ok ? hi : 0ull;
     if (blockIdx.x == 0) {
       DescState r;

@@ -45,10 +45,6 @@ class RangeDevice {
   // unguarded partition of [lo+1, hi) around it.
   virtual bool Partition(size_t lo, size_t hi, size_t* cut) = 0;
   virtual bool Fetch(size_t lo, size_t hi, void* dst) = 0;
-  // A partition of [lo, hi) the device has ALREADY made on its own (gz_order_descend*: the
-  // descent towards the position the caller is after, k_desc_finish included -- ranges of any
-  // size, down to introsort's 16): its cut, or false if it made none of this range.
-  virtual bool Replayed(size_t lo, size_t hi, size_t* cut) { (void)lo; (void)hi; (void)cut; return false; }
 };
 
 template <class T, class Less>
@@ -154,14 +150,6 @@ class LazySorted {
   // One step on a device-resident range: partition it there while it is large, else bring
   // it to the host.  Pushes the result(s) on `stack`, leftmost on top.
   void RefineDevice(const Range& r, std::vector<Range>* stack) {
-    if (r.hi - r.lo > 16 && r.depth > 0) {   // (what the device did to the range comes first)
-      size_t cut = 0;
-      if (dev_->Replayed(r.lo, r.hi, &cut) && cut > r.lo && cut <= r.hi) {
-        stack->push_back(Range{cut, r.hi, r.depth - 1, true});
-        stack->push_back(Range{r.lo, cut, r.depth - 1, true});
-        return;
-      }
-    }
     if (r.hi - r.lo > dev_threshold_ && r.depth > 0) {
       size_t cut = 0;
       if (dev_->Partition(r.lo, r.hi, &cut) && cut > r.lo && cut <= r.hi) {

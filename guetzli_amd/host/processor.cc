@@ -176,18 +176,15 @@ struct DeviceOrder : RangeDevice {
   // Partitions the device has already made on its own (gz_order_descend*: the quick-select
   // descent towards the position phase B needs, enqueued behind the order's construction), in
   // the order LazySorted is going to ask for them: (lo, hi, cut) triples.
-  uint64_t log[3 * GZ_ORDER_MAX_LEVELS];
+  uint64_t log[3 * 12];
   int log_n = 0, log_next = 0;
-  bool Replayed(size_t lo, size_t hi, size_t* cut) override {
+  bool Partition(size_t lo, size_t hi, size_t* cut) override {
     if (log_next < log_n && log[3 * log_next] == lo && log[3 * log_next + 1] == hi) {
       *cut = (size_t)log[3 * log_next + 2];
       ++log_next;
       ++n_replayed;
       return true;
     }
-    return false;
-  }
-  bool Partition(size_t lo, size_t hi, size_t* cut) override {
     if (log_next < log_n) {   // the device went another way than the host: its array is not what we think
       rc = GZ_E_STATE;
       return false;
@@ -736,7 +733,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   // of this iteration's candidate (gz_order_build_auto_begin): `ahead` says that such a
   // construction is in flight, and for which direction.
   int ahead = 0;
-  uint64_t ahead_log[3 * GZ_ORDER_MAX_LEVELS];   // the partitions the device made behind that construction
+  uint64_t ahead_log[3 * 12];   // the partitions the device made behind that construction
   int ahead_levels = 0;
   uint64_t ahead_last = 0;
 
@@ -762,7 +759,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         if (radius == 1 && ahead == direction && !first_up) {
           rc = gz_order_build_auto_end(ctx_, &total, &btc, &below);
           if (rc == GZ_OK) {
-            rc = gz_order_descend_end(ctx_, ahead_log, GZ_ORDER_MAX_LEVELS, &ahead_levels, &ahead_last);
+            rc = gz_order_descend_end(ctx_, ahead_log, 12, &ahead_levels, &ahead_last);
             have_ahead_log = rc == GZ_OK && ahead_levels > 0;
           }
         } else {
@@ -798,7 +795,6 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         }
       };
       DeviceOrder dev_order(ctx_);
-      int wide_levels = 0;   // levels of the descent's log made by chip-wide launches
       LazySorted<std::pair<int, float>, KeyLess> sorted(order, (size_t)total, KeyLess(), -1,
                                                          1 << 17, &dev_order, device_threshold_);
       t_pb_sort_ += pw.lap();
@@ -864,9 +860,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         // The introsort partitions that lead to position fast_until - 1, made by the device
         // without the host in between: behind the order's construction when that was enqueued
         // ahead (the device derives the position as the lines above do), else now, in one call.
-        // (A log made ahead must be replayed whatever the order's size: k_desc_finish has rearranged
-        // the device's array along it.)
-        if (have_ahead_log || n_order > device_threshold_) {
+        if (n_order > device_threshold_) {
           const uint64_t want = fast_until ? fast_until - 1 : 0;
           if (have_ahead_log) {
             if (ahead_last != want) return Fail("gz_order_descend: position", GZ_E_STATE);
@@ -880,14 +874,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           }
           if (dev_order.log_n > 0) {
             // the range the descent ended in, and with it everything SelectPrefix will fetch
-            // (the first range of the descent that is small enough for the host: the levels below
-            // it are k_desc_finish's, inside that range)
             uint64_t flo = 0, fhi = n_order;
-            wide_levels = 0;
-            for (int l = 0; l < dev_order.log_n && fhi - flo > device_threshold_; ++l) {
+            for (int l = 0; l < dev_order.log_n; ++l) {
               const uint64_t cut = dev_order.log[3 * l + 2];
               if (want < cut) fhi = cut; else flo = cut;
-              ++wide_levels;
             }
             // (only when the descent got there: a range that is still large will be partitioned
             // further on the device, and a copy taken now would be stale)
@@ -990,11 +980,9 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       const size_t order_size = (size_t)total;
       if (sorted.failed()) return Fail("gz_order_partition/fetch", dev_order.rc);
       if (dev_order.log_n > 0) {
-        // as many chip-wide levels next time as this order needed, plus one in reserve (an unused
-        // level costs two empty launches, a missing one a round trip per partition)
-        descend_levels_ = std::min(12, std::max(2, wide_levels + (dev_order.n_partition > 0 ? 2 : 1)));
-        // every partition the device made must have been replayed: its array is arranged by them
-        if (dev_order.log_next != dev_order.log_n) return Fail("gz_order_descend: log not replayed", GZ_E_STATE);
+        // as many levels next time as this order needed, plus one in reserve (an unused level
+        // costs two empty launches, a missing one a round trip per partition)
+        descend_levels_ = std::min(12, std::max(2, dev_order.log_n + (dev_order.n_partition > 0 ? 2 : 1)));
       }
       n_dev_replayed_ += dev_order.n_replayed;
       t_pb_dev_partition_ += dev_order.t_partition;

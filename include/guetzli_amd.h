@@ -366,15 +366,7 @@ int gz_order_exported(gz_ctx* ctx, uint64_t* entries);
  *   min_coeffs = (int)(per_block * blocks_to_change) (:685-687), capped at n - 1, rounded down
  *   to the entropy-code refresh interval of 10 (:739-741), minus one (0 if that is 0).
  * gz_order_descend_end: its log, after gz_order_build_auto_end, and the `last` it was made
- *   for (meaningful when *levels > 0): a caller that derives another position must not replay it.
- * Round 4: behind the max_levels chip-wide levels ONE workgroup takes the descent the rest of the
- *   way (k_desc_finish): the same steps on the range that holds `last` until it has 16 entries or
- *   fewer, which it insertion-sorts -- positions [0, last] then hold exactly the entries std::sort
- *   puts there, position `last` final.  Its steps are logged like the others: a log has up to
- *   GZ_ORDER_MAX_LEVELS entries (gz_order_descend's `log` must have room for that many triples;
- *   gz_order_descend_end fails with GZ_E_ARG if cap_levels is too small for what was made), and the
- *   caller must replay ALL of them before it partitions anything itself. */
-#define GZ_ORDER_MAX_LEVELS 48
+ *   for (meaningful when *levels > 0): a caller that derives another position must not replay it. */
 int gz_order_descend(gz_ctx* ctx, uint64_t last, uint64_t threshold, int max_levels,
                      uint64_t* log, int* levels);
 int gz_order_descend_begin(gz_ctx* ctx, float per_block, uint64_t threshold, int max_levels);

@@ -40,16 +40,13 @@ struct Dev : guetzli_amd::RangeDevice {
   // partitions the device has already made (gz_order_descend), in the order it made them
   std::vector<uint64_t> log;
   size_t next = 0;
-  bool Replayed(size_t lo, size_t hi, size_t* cut) override {
+  bool Partition(size_t lo, size_t hi, size_t* cut) override {
     if (3 * next + 2 < log.size() && log[3 * next] == lo && log[3 * next + 1] == hi) {
       *cut = (size_t)log[3 * next + 2];
       ++next;
       ++g_replayed;
       return true;
     }
-    return false;
-  }
-  bool Partition(size_t lo, size_t hi, size_t* cut) override {
     uint64_t c = 0;
     if (p_partition(g_ctx, lo, hi, &c) != GZ_OK) return false;
     *cut = (size_t)c;
@@ -77,7 +74,7 @@ static int check(const std::vector<E>& v, const char* what, size_t threshold, si
     if (ensure == 4 && f > 0) {
       // the descent towards position f - 1 made on the device in one go; LazySorted then
       // replays its log instead of asking for the partitions one by one
-      dev.log.assign(3 * GZ_ORDER_MAX_LEVELS, 0);
+      dev.log.assign(3 * 12, 0);
       int levels = 0;
       if (p_descend(g_ctx, f - 1, threshold, 12, dev.log.data(), &levels) != GZ_OK) {
         printf("FAIL descend %s pattern %d n=%zu last=%zu threshold=%zu: %s\n", what, g_pattern, v.size(), f - 1, threshold,

@@ -90,10 +90,10 @@ def test_whole_encode_matches_reference_in_emulation(host_emu, case, monkeypatch
 def test_repeated_content_ties_in_the_global_order(host_emu, monkeypatch, threshold):
     """An image of one 16x16 patch repeated: every block has eleven exact copies, so the keys of
     phase B's global order tie in groups of twelve and which copy std::sort serves first decides the
-    bytes.  With the default threshold these small orders are taken all the way down by the
-    device's single-workgroup descent (k_desc_finish) behind their construction, and the driver must
-    replay that log whatever the order's size (a GPU-only failure of round 4: the emulation's other
-    images have no ties to get wrong); with a threshold of 128 the chip-wide levels run first."""
+    bytes -- the emulation's other images have no ties to get wrong (a round-4 experiment that
+    rearranged small orders on the device without the host replaying it passed every CPU test and
+    failed on the GPU's tiled images).  Default threshold: the host sorts these small orders itself;
+    128: the device's partitions and descents, replayed by the host."""
     if threshold:
         monkeypatch.setenv("GZ_ORDER_DEVICE_THRESHOLD", str(threshold))
     rgb = np.ascontiguousarray(np.tile(images.crop(16, 16, 200, 100), (3, 4, 1)))
@@ -105,7 +105,8 @@ def test_repeated_content_ties_in_the_global_order(host_emu, monkeypatch, thresh
     assert got_jpg == exp_jpg
     got2, info2 = host_emu.process(rgb, quality=95)      # (without a trace: the size-bound path)
     assert got2 == exp_jpg
-    assert info2["counters"]["phase B partitions made ahead"] > 0
+    if threshold:
+        assert info2["counters"]["phase B partitions made ahead"] > 0
 
 
 def test_descent_position_mismatch_aborts_the_encode(host_emu, monkeypatch, capfd):

@@ -2,8 +2,9 @@
 (oracle/_ref/libgz_ref.so): every stage of the hot path, bit for bit.
 
 CPU-only.  Skipped when the prebuilt reference library is absent (it can only be
-built where /root/reference exists); tests/test_golden.py covers that case from the
-committed fixtures."""
+built where /root/reference exists; the built file travels with the snapshot); the committed
+fixtures under tests/golden/ -- the reference's JPEG hashes, read by tests/test_gpu_parity.py --
+do not need it."""
 import numpy as np
 import pytest
 

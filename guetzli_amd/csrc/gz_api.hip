@@ -1765,7 +1765,7 @@ static int order_build_enqueue(gz_ctx* c, int direction, int count_below, float 
     KCHK(c);
   }
   TRY(enqueue_scan_offsets(c, 0, c->stream, (const unsigned*)c->d_order_nb, nb, c->d_order_off));
-  GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, 4)), dim3(256), c->stream,
+  GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, 256 / kFillLanes)), dim3(256), c->stream,
             (const float*)c->d_out_err, (const int*)c->d_next_cand, (const float*)c->d_weight,
             (const float*)c->d_max_err, (const unsigned long long*)c->d_order_off, direction, nb,
             count_below ? 1 : 0, limit, c->d_order, c->d_order_counters);

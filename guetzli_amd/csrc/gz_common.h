@@ -142,6 +142,14 @@ GZ_DEVFN gz_f2 gz_f2_splat(float x) {
 #define GZ_MUL24(a, b) __mul24((a), (b))
 #endif
 
+// Number of set bits of a wavefront mask (__ballot), and the mask of the lanes below this one.
+#ifdef GZ_EMU
+#define GZ_POPC64(x) __builtin_popcountll((unsigned long long)(x))
+#else
+#define GZ_POPC64(x) __popcll((unsigned long long)(x))
+#endif
+#define GZ_LANES_BELOW(lane) ((1ull << (lane)) - 1ull)
+
 static inline int gz_div_up(int a, int b) { return (a + b - 1) / b; }
 
 // ---- XCD-aware tile order ---------------------------------------------------------------

@@ -46,22 +46,26 @@ __global__ __launch_bounds__(256) void k_order_sizes(const int* __restrict__ cnt
                                                      unsigned* __restrict__ n_b,
                                                      unsigned* __restrict__ counters) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
   int n = 0;
-  if (!(weight[b] == 0)) {
-    const int at = next_cand[b];
-    n = direction > 0 ? cnt[b] - at : at;
-    if (n < 0) n = 0;
+  if (b < nb) {
+    if (!(weight[b] == 0)) {
+      const int at = next_cand[b];
+      n = direction > 0 ? cnt[b] - at : at;
+      if (n < 0) n = 0;
+    }
+    n_b[b] = (unsigned)n;
   }
-  n_b[b] = (unsigned)n;
-  if (n > 0) atomicAdd(&counters[0], 1u);
+  const unsigned long long m = __ballot(n > 0);   // (one atomic per wavefront)
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[0], (unsigned)GZ_POPC64(m));
 }
 
-// One wave per block: entry j of block b is (b, (err[at+j] - max_err) / weight) for "up",
-// (b, (max_err - err[at-1-j]) / weight) for "down" (float arithmetic, processor.cc:649-657).
-// err has a fixed stride of 192 per block (k_block_search's layout).  counters[1] += number
-// of vals < limit when count_below (the partition_point of processor.cc:690-696 counts
-// exactly these once the order is sorted).
+// Sixteen lanes per block (a block has a few dozen entries at most; a whole wavefront per block
+// left most of its lanes idle and was bound by the number of wavefronts): entry j of block b is
+// (b, (err[at+j] - max_err) / weight) for "up", (b, (max_err - err[at-1-j]) / weight) for "down"
+// (float arithmetic, processor.cc:649-657).  err has a fixed stride of 192 per block
+// (k_block_search's layout).  counters[1] += number of vals < limit when count_below (the
+// partition_point of processor.cc:690-696 counts exactly these once the order is sorted).
+constexpr int kFillLanes = 16;
 __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ err,
                                                     const int* __restrict__ next_cand,
                                                     const float* __restrict__ weight,
@@ -70,8 +74,8 @@ __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ er
                                                     int direction, int nb, int count_below,
                                                     float limit, OrderEntry* __restrict__ out,
                                                     unsigned* __restrict__ counters) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + wave;
+  const int group = threadIdx.x / kFillLanes, sub = threadIdx.x % kFillLanes;
+  const int b = blockIdx.x * (256 / kFillLanes) + group;
   if (b >= nb) return;
   const unsigned long long o = off[b];
   const int n = (int)(off[b + 1] - o);
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ er
   const float base = max_err[b], wb = weight[b];
   const float* e = err + (size_t)b * 192;
   unsigned below = 0;
-  for (int j = lane; j < n; j += 64) {
+  for (int j = sub; j < n; j += kFillLanes) {
     OrderEntry v;
     v.block = b;
     v.val = direction > 0 ? (e[at + j] - base) / wb : (base - e[at - 1 - j]) / wb;
@@ -131,18 +135,23 @@ __global__ __launch_bounds__(256) void k_weights_flag(const float* __restrict__ 
   flag[b] = f ? 1 : 0;
 }
 
-// The entry count of the block (k_order_sizes) comes out of the same pass when cnt is given.
-GZ_DEVFN void order_size_of(int b, float w, const int* __restrict__ cnt,
+// The entry count of the block (k_order_sizes) comes out of the same pass when cnt is given;
+// blocks_to_change (counters[0]) is counted per wavefront (an atomic per block on the one counter
+// was most of the kernel's time).  Every lane of the workgroup calls this (valid = a real block).
+GZ_DEVFN void order_size_of(bool valid, int b, float w, const int* __restrict__ cnt,
                             const int* __restrict__ next_cand, int direction,
                             unsigned* __restrict__ n_b, unsigned* __restrict__ counters) {
   int n = 0;
-  if (!(w == 0)) {
-    const int at = next_cand[b];
-    n = direction > 0 ? cnt[b] - at : at;
-    if (n < 0) n = 0;
+  if (valid) {
+    if (!(w == 0)) {
+      const int at = next_cand[b];
+      n = direction > 0 ? cnt[b] - at : at;
+      if (n < 0) n = 0;
+    }
+    n_b[b] = (unsigned)n;
   }
-  n_b[b] = (unsigned)n;
-  if (n > 0) atomicAdd(&counters[0], 1u);
+  const unsigned long long m = __ballot(n > 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[0], (unsigned)GZ_POPC64(m));
 }
 
 __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __restrict__ flag,
@@ -153,27 +162,28 @@ __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __r
                                                         unsigned* __restrict__ n_b,
                                                         unsigned* __restrict__ counters) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= bw * bh) return;
-  if (direction > 0) {
-    const float w = flag[b] ? 1.0f : 0.0f;
+  const bool valid = b < bw * bh;
+  float w = 0.0f;
+  if (valid) {
+    if (direction > 0) {
+      w = flag[b] ? 1.0f : 0.0f;
+    } else {
+      const int bx = b % bw, by = b / bw;
+      const int x0 = bx - r > 0 ? bx - r : 0, y0 = by - r > 0 ? by - r : 0;
+      const int x1 = bx + 1 + r < bw ? bx + 1 + r : bw, y1 = by + 1 + r < bh ? by + 1 + r : bh;
+      int dmin = r + 1;
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x)
+          if (flag[y * bw + x]) {
+            const int dy = y > by ? y - by : by - y, dx = x > bx ? x - bx : bx - x;
+            const int d = dy > dx ? dy : dx;
+            dmin = d < dmin ? d : dmin;
+          }
+      w = dmin <= r ? 1.0f / (dmin + 1.0f) : 0.0f;
+    }
     weight[b] = w;
-    if (cnt) order_size_of(b, w, cnt, next_cand, direction, n_b, counters);
-    return;
   }
-  const int bx = b % bw, by = b / bw;
-  const int x0 = bx - r > 0 ? bx - r : 0, y0 = by - r > 0 ? by - r : 0;
-  const int x1 = bx + 1 + r < bw ? bx + 1 + r : bw, y1 = by + 1 + r < bh ? by + 1 + r : bh;
-  int dmin = r + 1;
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x)
-      if (flag[y * bw + x]) {
-        const int dy = y > by ? y - by : by - y, dx = x > bx ? x - bx : bx - x;
-        const int d = dy > dx ? dy : dx;
-        dmin = d < dmin ? d : dmin;
-      }
-  const float w = dmin <= r ? 1.0f / (dmin + 1.0f) : 0.0f;
-  weight[b] = w;
-  if (cnt) order_size_of(b, w, cnt, next_cand, direction, n_b, counters);
+  if (cnt) order_size_of(valid, b, w, cnt, next_cand, direction, n_b, counters);
 }
 
 // max_block_error[i] += block_weight[i] * val_threshold * direction  (processor.cc:754-756)
@@ -666,7 +676,7 @@ GZ_DEVFN OrderEntry desc_read(const OrderEntry* a, unsigned long long p, unsigne
 }
 
 __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
-  __shared__ unsigned lds[256];
+  __shared__ unsigned wsum[8];
   if (level == 0 && A.publish && blockIdx.x == 0 && threadIdx.x == 0) {
     DescState r;
     r.lo = *A.total;
@@ -706,30 +716,48 @@ __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
     o.med = med;
     A.pv[level] = o;
   }
-  const int t = threadIdx.x;
-  const unsigned base = blockIdx.x * (unsigned)kPartChunk + t * (unsigned)kPartItems;
-  unsigned fl = 0, fr = 0, nl = 0, nr = 0;
+  // A wavefront takes kPartItems rows of 64 consecutive entries (512 bytes per load instruction);
+  // the rank of a stopper inside the chunk comes from the rows' lane masks.
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned wbase = blockIdx.x * (unsigned)kPartChunk + (unsigned)wave * (64u * kPartItems);
+  unsigned long long bl[kPartItems], br[kPartItems];
+  unsigned tl = 0, tr = 0;
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
-    const unsigned p = base + i;
+    const unsigned p = wbase + (unsigned)i * 64u + (unsigned)lane;
+    bool l = false, r = false;
     if (p < n) {
       const OrderEntry e = desc_read(A.a, first + p, med, e0);
-      if (!order_less(e, pv)) { fl |= 1u << i; ++nl; }
-      if (!order_less(pv, e)) { fr |= 1u << i; ++nr; }
+      l = !order_less(e, pv);
+      r = !order_less(pv, e);
     }
+    bl[i] = __ballot(l);
+    br[i] = __ballot(r);
+    tl += (unsigned)GZ_POPC64(bl[i]);
+    tr += (unsigned)GZ_POPC64(br[i]);
   }
-  const unsigned incl_l = wg_inclusive_scan_fast(nl, lds);
-  const unsigned incl_r = wg_inclusive_scan_fast(nr, lds);
-  unsigned ol = blockIdx.x * (unsigned)kPartChunk + (incl_l - nl);
-  unsigned orr = blockIdx.x * (unsigned)kPartChunk + (incl_r - nr);
+  if (lane == 0) {
+    wsum[wave] = tl;
+    wsum[4 + wave] = tr;
+  }
+  __syncthreads();
+  unsigned ol = blockIdx.x * (unsigned)kPartChunk, orr = ol;
+  for (int wv = 0; wv < wave; ++wv) {
+    ol += wsum[wv];
+    orr += wsum[4 + wv];
+  }
+  const unsigned long long below = GZ_LANES_BELOW(lane);
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
-    if ((fl >> i) & 1u) A.lpos[ol++] = base + i;
-    if ((fr >> i) & 1u) A.rpos[orr++] = base + i;
+    const unsigned p = wbase + (unsigned)i * 64u + (unsigned)lane;
+    if ((bl[i] >> lane) & 1ull) A.lpos[ol + (unsigned)GZ_POPC64(bl[i] & below)] = p;
+    if ((br[i] >> lane) & 1ull) A.rpos[orr + (unsigned)GZ_POPC64(br[i] & below)] = p;
+    ol += (unsigned)GZ_POPC64(bl[i]);
+    orr += (unsigned)GZ_POPC64(br[i]);
   }
-  if (t == 255) {
-    A.cnt_l[blockIdx.x] = incl_l;
-    A.cnt_r[blockIdx.x] = incl_r;
+  if (t == 0) {
+    A.cnt_l[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    A.cnt_r[blockIdx.x] = wsum[4] + wsum[5] + wsum[6] + wsum[7];
   }
 }
 
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
   const unsigned long long first = s.lo + 1;
   const unsigned n = (unsigned)(s.hi - first);
   const unsigned nchunks = (n + kPartChunk - 1) / kPartChunk;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   {  // the two tables, by every workgroup for itself
     const unsigned per = (nchunks + 255) / 256;
     const unsigned c0 = t * per < nchunks ? t * per : nchunks;
@@ -776,43 +804,60 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
     }
     __syncthreads();
   }
+  // (no workgroup barrier below this line: the wavefronts go their own ways)
   const unsigned total_l = PL[nchunks], total_r = RR[nchunks];
   const unsigned K = total_l < total_r ? total_l : total_r;   // pairs 0 .. K-1 exist; "pair" K ends the scan
-  const unsigned k0 = (blockIdx.x * 256u + (unsigned)t) * (unsigned)kPartItems;
-  if (k0 > K) return;
+  // the wavefront's pairs: kPartItems rows of 64 consecutive k (their positions sit next to each
+  // other in the chunks' lists, and the stoppers themselves nearly so)
+  const unsigned kw = blockIdx.x * (unsigned)kPartChunk + (unsigned)wave * (64u * kPartItems);
+  if (kw > K) return;
   const DescPivot pvt = A.pv[level];
   // positions (relative to `first`) of the k-th left stopper / the k-th right stopper from the right
-  auto pos_l = [&](unsigned k) {
+  auto find_l = [&](unsigned k) {
     const unsigned c = desc_chunk_of(PL, nchunks, k);
     return A.lpos[c * (unsigned)kPartChunk + (k - PL[c])];
   };
-  auto pos_r = [&](unsigned k) {
+  auto find_r = [&](unsigned k) {
     const unsigned i = desc_chunk_of(RR, nchunks, k);
     const unsigned c = nchunks - 1 - i, cnt = RR[i + 1] - RR[i];
     return A.rpos[c * (unsigned)kPartChunk + (cnt - 1 - (k - RR[i]))];
   };
-  // The thread's kPartItems pairs in three rounds -- positions, values, stores -- each round's
-  // memory accesses independent of one another (one pair after the other, every pair costs three
-  // dependent trips to memory).
-  unsigned pl[kPartItems], pr[kPartItems];
-  bool sw[kPartItems];
-  bool prev_swapped = true;   // (k == 0: the scan starts)
+  bool prev_swapped = true;   // (kw == 0: the scan starts)
   unsigned prev_pr = 0;
-  if (k0 > 0) {
-    const unsigned ql = pos_l(k0 - 1);   // (k0 - 1 < K: both exist)
-    prev_pr = pos_r(k0 - 1);
+  if (kw > 0) {
+    const unsigned ql = find_l(kw - 1);   // (kw - 1 < K: both exist)
+    prev_pr = find_r(kw - 1);
     prev_swapped = ql < prev_pr;
     // Left stoppers ascend and right stoppers descend with k: once a pair has crossed, every later
-    // one has.  A thread behind the crossing has nothing to swap and no cut to find -- about half
-    // of them (the pivot is a median of three), for one pair's look-up instead of five.
+    // one has.  A wavefront behind the crossing has nothing to swap and no cut to find -- about
+    // half of them (the pivot is a median of three).
     if (!prev_swapped) return;
   }
+  // every lane finds the chunks of its first pair once and walks on from there (the next row's k
+  // is 64 further: the same chunk or the one after)
+  unsigned cl = 0, ir = 0;
+  {
+    const unsigned k = kw + (unsigned)lane;
+    if (k < total_l) cl = desc_chunk_of(PL, nchunks, k);
+    if (k < total_r) ir = desc_chunk_of(RR, nchunks, k);
+  }
+  unsigned pl[kPartItems], pr[kPartItems];
+  bool sw[kPartItems];
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
-    const unsigned k = k0 + (unsigned)i;
+    const unsigned k = kw + (unsigned)i * 64u + (unsigned)lane;
     const bool has_l = k <= K && k < total_l, has_r = k <= K && k < total_r;
-    pl[i] = has_l ? pos_l(k) : 0xffffffffu;
-    pr[i] = has_r ? pos_r(k) : 0u;
+    pl[i] = 0xffffffffu;
+    pr[i] = 0u;
+    if (has_l) {
+      while (PL[cl + 1] <= k) ++cl;
+      pl[i] = A.lpos[cl * (unsigned)kPartChunk + (k - PL[cl])];
+    }
+    if (has_r) {
+      while (RR[ir + 1] <= k) ++ir;
+      const unsigned c = nchunks - 1 - ir, cnt = RR[ir + 1] - RR[ir];
+      pr[i] = A.rpos[c * (unsigned)kPartChunk + (cnt - 1 - (k - RR[ir]))];
+    }
     sw[i] = has_l && has_r && pl[i] < pr[i];
   }
   OrderEntry vl[kPartItems], vr[kPartItems];
@@ -830,27 +875,35 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
     }
   // the one pair that is not swapped while its predecessor was: where the serial scan stops -- at
   // the next untouched left stopper or at the last swapped right one, whichever comes first
-  // (libstdc++ __unguarded_partition returns `first`)
+  // (libstdc++ __unguarded_partition returns `first`).  The swapped pairs of a wavefront are a
+  // prefix of its rows and lanes: the first row whose mask is not full holds that pair.
+  bool all_before = true;
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
-    const unsigned k = k0 + (unsigned)i;
-    const bool before = i == 0 ? prev_swapped : sw[i - 1];
-    if (k <= K && before && !sw[i]) {
-      const unsigned last_pr = i == 0 ? prev_pr : pr[i - 1];
-      unsigned long long cut = s.hi;
-      if (pl[i] != 0xffffffffu && first + pl[i] < cut) cut = first + pl[i];
-      if (k >= 1 && first + last_pr < cut) cut = first + last_pr;
-      DescState nx;
-      if (s.last < cut) { nx.lo = s.lo; nx.hi = cut; } else { nx.lo = cut; nx.hi = s.hi; }
-      nx.last = s.last;
-      nx.cut = cut;
-      nx.depth = s.depth - 1;
-      nx.epoch = A.epoch;
-      A.st[level + 1] = nx;
-      if (level == 0) A.st[0] = s;   // (the derived level-0 range, for the host's replay)
+    const unsigned long long m = __ballot(sw[i]);
+    if (all_before && m != ~0ull) {   // (the same in every lane)
+      all_before = false;
+      const int j = GZ_POPC64(m);     // lanes 0 .. j-1 swapped: lane j holds the pair
+      unsigned last_pr = prev_pr;     // the right stopper of the pair before it
+      if (j > 0) last_pr = (unsigned)__shfl((int)pr[i], j - 1);
+      else if (i > 0) last_pr = (unsigned)__shfl((int)pr[i > 0 ? i - 1 : 0], 63);
+      const unsigned k = kw + (unsigned)i * 64u + (unsigned)lane;
+      if (lane == j && k <= K) {
+        unsigned long long cut = s.hi;
+        if (pl[i] != 0xffffffffu && first + pl[i] < cut) cut = first + pl[i];
+        if (k >= 1 && first + last_pr < cut) cut = first + last_pr;
+        DescState nx;
+        if (s.last < cut) { nx.lo = s.lo; nx.hi = cut; } else { nx.lo = cut; nx.hi = s.hi; }
+        nx.last = s.last;
+        nx.cut = cut;
+        nx.depth = s.depth - 1;
+        nx.epoch = A.epoch;
+        A.st[level + 1] = nx;
+        if (level == 0) A.st[0] = s;   // (the derived level-0 range, for the host's replay)
+      }
     }
   }
-  if (k0 == 0) {
+  if (blockIdx.x == 0 && t == 0) {
     // the median's move to the front, made real: the front gets the pivot; the place the pivot
     // came from gets the old front element unless a pair above has already put a partner there
     A.a[s.lo] = pvt.pivot;
@@ -862,7 +915,7 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
       unsigned lo = 0, hi = PL[c + 1] - PL[c];
       while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (seg[mid] < pm) lo = mid + 1; else hi = mid; }
       const unsigned k = PL[c] + lo;
-      if (k < total_r && pm < pos_r(k)) moved = true;
+      if (k < total_r && pm < find_r(k)) moved = true;
     }
     if (!moved && !order_less(pvt.pivot, pvt.a_lo)) {   // a right stopper
       const unsigned* seg = A.rpos + c * (unsigned)kPartChunk;
@@ -870,7 +923,7 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
       unsigned lo = 0, hi = cnt;
       while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if (seg[mid] < pm) lo = mid + 1; else hi = mid; }
       const unsigned k = RR[ci] + (cnt - 1 - lo);
-      if (k < total_l && pos_l(k) < pm) moved = true;
+      if (k < total_l && find_l(k) < pm) moved = true;
     }
     if (!moved) A.a[pvt.med] = pvt.a_lo;
   }

@@ -462,6 +462,7 @@ struct gz_ctx {
   unsigned* d_order_nb = nullptr;                                 // [nb]
   unsigned long long* d_order_off = nullptr;                      // [nb+1]
   unsigned* d_order_counters = nullptr;                           // [2]
+  unsigned* d_order_groups = nullptr;                             // [2 * ceil(nb / kOrderGroup)]: sum of n_b, blocks with n_b > 0
   int* d_next_cand = nullptr; float* d_weight = nullptr; float* d_max_err = nullptr;   // [nb]
   bool have_search = false;
   unsigned char* d_wflag = nullptr;                               // [nb]
@@ -1406,6 +1407,7 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->d_words); (void)pool_free(c->d_words_kept);
   (void)pool_free(c->d_order); (void)pool_free(c->d_pos_l); (void)pool_free(c->d_pos_r); (void)pool_free(c->d_chunk);
   (void)pool_free(c->d_part); (void)pool_free(c->d_order_nb); (void)pool_free(c->d_order_off);
+  (void)pool_free(c->d_order_groups);
   if (c->h_order_pending) (void)pool_host_free(c->h_order_pending);
   if (c->h_order_mirror) (void)pool_host_free(c->h_order_mirror);
   if (c->h_desc) (void)pool_host_free(c->h_desc);
@@ -1743,6 +1745,7 @@ static int ensure_order_block_arrays(gz_ctx* c) {
   const int nb = c->nb;
   HIPCHK(c, pool_malloc((void**)&c->d_order_nb, sizeof(unsigned) * nb));
   HIPCHK(c, pool_malloc((void**)&c->d_order_off, sizeof(unsigned long long) * (nb + 1)));
+  HIPCHK(c, pool_malloc((void**)&c->d_order_groups, sizeof(unsigned) * 2 * gz_div_up(nb, kOrderGroup)));
   HIPCHK(c, pool_malloc((void**)&c->d_next_cand, sizeof(int) * nb));
   HIPCHK(c, pool_malloc((void**)&c->d_weight, sizeof(float) * nb));
   HIPCHK(c, pool_malloc((void**)&c->d_max_err, sizeof(float) * nb));
@@ -1757,18 +1760,19 @@ static int order_build_enqueue(gz_ctx* c, int direction, int count_below, float 
   // An order never has more entries than phase A produced candidates: sized once, so that the
   // construction runs through without a host round trip between counting and filling.
   TRY(ensure_order_capacity(c, std::max<size_t>(c->search_total, 1)));
+  if ((unsigned long long)c->search_total >= (1ull << 31)) { c->err = "order beyond 2^31 entries"; return GZ_E_STATE; }
   if (!sizes_done) {   // (gz_order_build_auto's weight kernels have done both already)
     HIPCHK(c, hipMemsetAsync(c->d_order_counters, 0, sizeof(unsigned) * 2, c->stream));
-    GZ_LAUNCH(k_order_sizes, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
+    GZ_LAUNCH(k_order_sizes, dim3(gz_div_up(nb, kOrderGroup)), dim3(kOrderGroup), c->stream,
               (const int*)c->d_out_cnt, (const int*)c->d_next_cand, (const float*)c->d_weight,
-              direction, nb, c->d_order_nb, c->d_order_counters);
+              direction, nb, c->d_order_nb, c->d_order_groups);
     KCHK(c);
   }
-  TRY(enqueue_scan_offsets(c, 0, c->stream, (const unsigned*)c->d_order_nb, nb, c->d_order_off));
-  GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, 256 / kFillLanes)), dim3(256), c->stream,
+  // (no scan of the counts: k_order_fill's workgroups find their offsets from the group sums)
+  GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, kFillBlocks)), dim3(256), c->stream,
             (const float*)c->d_out_err, (const int*)c->d_next_cand, (const float*)c->d_weight,
-            (const float*)c->d_max_err, (const unsigned long long*)c->d_order_off, direction, nb,
-            count_below ? 1 : 0, limit, c->d_order, c->d_order_counters);
+            (const float*)c->d_max_err, (const unsigned*)c->d_order_nb, (const unsigned*)c->d_order_groups,
+            direction, nb, count_below ? 1 : 0, limit, c->d_order, c->d_order_off + nb, c->d_order_counters);
   KCHK(c);
   return GZ_OK;
 }
@@ -1867,9 +1871,9 @@ static int order_auto_enqueue(gz_ctx* c, int direction, int max_block_dist, doub
             d_bmax, use_distmap ? 1 : 0, bw, bh, target, target_mul,
             direction, max_block_dist, c->d_wflag, c->d_order_counters);
   KCHK(c);
-  GZ_LAUNCH(k_weights_gather, dim3(gz_div_up(nb, 256)), dim3(256), c->stream,
+  GZ_LAUNCH(k_weights_gather, dim3(gz_div_up(nb, kOrderGroup)), dim3(kOrderGroup), c->stream,
             (const unsigned char*)c->d_wflag, bw, bh, direction, max_block_dist, c->d_weight,
-            (const int*)c->d_out_cnt, (const int*)c->d_next_cand, c->d_order_nb, c->d_order_counters);
+            (const int*)c->d_out_cnt, (const int*)c->d_next_cand, c->d_order_nb, c->d_order_groups);
   KCHK(c);
   return GZ_OK;
 }

@@ -36,50 +36,121 @@ struct OrderEntry {
 GZ_DEVFN bool order_less(const OrderEntry& a, const OrderEntry& b) { return a.val < b.val; }
 
 // ----------------------------------------------------------------- building the order --
+// The order is built without a scan kernel and without atomics on the critical path: the kernel
+// that knows the blocks' entry counts n_b (k_weights_gather, or k_order_sizes when the weights come
+// from the host) also writes, per workgroup of kOrderGroup blocks, the group's sum of n_b and its
+// number of blocks with n_b > 0; k_order_fill's workgroups add up the groups before theirs for
+// themselves (a few hundred numbers) and find their blocks' offsets from there.  (Round 3: an
+// atomic per wavefront on the one counter -- 2 000 device-scope atomics on one address, 26 us --
+// and a decoupled look-back scan of 64 tiles, 15 us, both on phase B's critical path.)
+constexpr int kOrderGroup = 256;   // = the block size of the kernels that write the group sums
+
+// Sum over the workgroup (256 threads); every thread gets it.  lds4: 4 ints.
+GZ_DEVFN int wg_sum(int v, int* lds4) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, (unsigned)d);
+    if (lane >= d) v += o;
+  }
+  __syncthreads();   // (lds4 may still be read from a previous call)
+  if (lane == 63) lds4[wave] = v;
+  __syncthreads();
+  return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// The group's two sums; every thread of the workgroup calls this (n = 0 beyond the last block).
+GZ_DEVFN void order_group_sums(int n, unsigned* __restrict__ group_sums) {
+  __shared__ int lds4[4];
+  const int sum = wg_sum(n, lds4);
+  const int cnt = wg_sum(n > 0 ? 1 : 0, lds4);
+  if (threadIdx.x == 0) {
+    group_sums[2 * blockIdx.x] = (unsigned)sum;
+    group_sums[2 * blockIdx.x + 1] = (unsigned)cnt;
+  }
+}
+
 // n_b[b] = number of entries block b contributes (processor.cc:638-661): none if its weight
 // is 0; the candidates from next_cand[b] on for "up"; the next_cand[b] applied ones for
-// "down".  counters[0] += blocks with at least one entry (blocks_to_change).
-__global__ __launch_bounds__(256) void k_order_sizes(const int* __restrict__ cnt,
-                                                     const int* __restrict__ next_cand,
-                                                     const float* __restrict__ weight,
-                                                     int direction, int nb,
-                                                     unsigned* __restrict__ n_b,
-                                                     unsigned* __restrict__ counters) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// "down".
+GZ_DEVFN int order_size_of(bool valid, int b, float w, const int* __restrict__ cnt,
+                           const int* __restrict__ next_cand, int direction,
+                           unsigned* __restrict__ n_b) {
   int n = 0;
-  if (b < nb) {
-    if (!(weight[b] == 0)) {
+  if (valid) {
+    if (!(w == 0)) {
       const int at = next_cand[b];
       n = direction > 0 ? cnt[b] - at : at;
       if (n < 0) n = 0;
     }
     n_b[b] = (unsigned)n;
   }
-  const unsigned long long m = __ballot(n > 0);   // (one atomic per wavefront)
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[0], (unsigned)GZ_POPC64(m));
+  return n;
+}
+
+__global__ __launch_bounds__(256) void k_order_sizes(const int* __restrict__ cnt,
+                                                     const int* __restrict__ next_cand,
+                                                     const float* __restrict__ weight,
+                                                     int direction, int nb,
+                                                     unsigned* __restrict__ n_b,
+                                                     unsigned* __restrict__ group_sums) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = b < nb;
+  const int n = order_size_of(valid, b, valid ? weight[b] : 0.0f, cnt, next_cand, direction, n_b);
+  order_group_sums(n, group_sums);
 }
 
 // Sixteen lanes per block (a block has a few dozen entries at most; a whole wavefront per block
 // left most of its lanes idle and was bound by the number of wavefronts): entry j of block b is
 // (b, (err[at+j] - max_err) / weight) for "up", (b, (max_err - err[at-1-j]) / weight) for "down"
 // (float arithmetic, processor.cc:649-657).  err has a fixed stride of 192 per block
-// (k_block_search's layout).  counters[1] += number of vals < limit when count_below (the
-// partition_point of processor.cc:690-696 counts exactly these once the order is sorted).
+// (k_block_search's layout).  The workgroup's 16 blocks lie in one group: their offsets are the
+// sums of the groups before + the n_b of the group's blocks before them.  Workgroup 0 also writes
+// the order's size (*total) and blocks_to_change (counters[0]).  counters[1] += number of
+// vals < limit when count_below (the partition_point of processor.cc:690-696 counts exactly
+// these once the order is sorted).
 constexpr int kFillLanes = 16;
+constexpr int kFillBlocks = 256 / kFillLanes;
 __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ err,
                                                     const int* __restrict__ next_cand,
                                                     const float* __restrict__ weight,
                                                     const float* __restrict__ max_err,
-                                                    const unsigned long long* __restrict__ off,
+                                                    const unsigned* __restrict__ n_b,
+                                                    const unsigned* __restrict__ group_sums,
                                                     int direction, int nb, int count_below,
                                                     float limit, OrderEntry* __restrict__ out,
+                                                    unsigned long long* __restrict__ total,
                                                     unsigned* __restrict__ counters) {
-  const int group = threadIdx.x / kFillLanes, sub = threadIdx.x % kFillLanes;
-  const int b = blockIdx.x * (256 / kFillLanes) + group;
+  __shared__ int lds4[4];
+  __shared__ unsigned own[kFillBlocks];
+  const int t = threadIdx.x;
+  const int group = t / kFillLanes, sub = t % kFillLanes;
+  const int b0 = blockIdx.x * kFillBlocks, b = b0 + group;
+  const int g = b0 / kOrderGroup, ngroups = (nb + kOrderGroup - 1) / kOrderGroup;
+  if (blockIdx.x == 0) {   // (the whole workgroup)
+    int all = 0, changed = 0;
+    for (int i = t; i < ngroups; i += 256) {
+      all += (int)group_sums[2 * i];
+      changed += (int)group_sums[2 * i + 1];
+    }
+    all = wg_sum(all, lds4);
+    changed = wg_sum(changed, lds4);
+    if (t == 0) {
+      *total = (unsigned long long)(unsigned)all;
+      counters[0] = (unsigned)changed;
+    }
+  }
+  // entries before the workgroup's first block: whole groups, then the blocks of its own group
+  int part = 0;
+  for (int i = t; i < g; i += 256) part += (int)group_sums[2 * i];
+  if (g * kOrderGroup + t < b0) part += (int)n_b[g * kOrderGroup + t];
+  if (t < kFillBlocks) own[t] = b0 + t < nb ? n_b[b0 + t] : 0u;
+  const unsigned base_wg = (unsigned)wg_sum(part, lds4);   // (its barriers also publish own[])
   if (b >= nb) return;
-  const unsigned long long o = off[b];
-  const int n = (int)(off[b + 1] - o);
+  const int n = (int)own[group];
   if (n == 0) return;
+  unsigned long long o = base_wg;
+  for (int i = 0; i < group; ++i) o += own[i];
   const int at = next_cand[b];
   const float base = max_err[b], wb = weight[b];
   const float* e = err + (size_t)b * 192;
@@ -135,32 +206,15 @@ __global__ __launch_bounds__(256) void k_weights_flag(const float* __restrict__ 
   flag[b] = f ? 1 : 0;
 }
 
-// The entry count of the block (k_order_sizes) comes out of the same pass when cnt is given;
-// blocks_to_change (counters[0]) is counted per wavefront (an atomic per block on the one counter
-// was most of the kernel's time).  Every lane of the workgroup calls this (valid = a real block).
-GZ_DEVFN void order_size_of(bool valid, int b, float w, const int* __restrict__ cnt,
-                            const int* __restrict__ next_cand, int direction,
-                            unsigned* __restrict__ n_b, unsigned* __restrict__ counters) {
-  int n = 0;
-  if (valid) {
-    if (!(w == 0)) {
-      const int at = next_cand[b];
-      n = direction > 0 ? cnt[b] - at : at;
-      if (n < 0) n = 0;
-    }
-    n_b[b] = (unsigned)n;
-  }
-  const unsigned long long m = __ballot(n > 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[0], (unsigned)GZ_POPC64(m));
-}
-
+// The entry count of the block and the group sums (k_order_sizes) come out of the same pass when
+// cnt is given.
 __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __restrict__ flag,
                                                         int bw, int bh, int direction, int r,
                                                         float* __restrict__ weight,
                                                         const int* __restrict__ cnt,
                                                         const int* __restrict__ next_cand,
                                                         unsigned* __restrict__ n_b,
-                                                        unsigned* __restrict__ counters) {
+                                                        unsigned* __restrict__ group_sums) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < bw * bh;
   float w = 0.0f;
@@ -183,7 +237,7 @@ __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __r
     }
     weight[b] = w;
   }
-  if (cnt) order_size_of(valid, b, w, cnt, next_cand, direction, n_b, counters);
+  if (cnt) order_group_sums(order_size_of(valid, b, w, cnt, next_cand, direction, n_b), group_sums);
 }
 
 // max_block_error[i] += block_weight[i] * val_threshold * direction  (processor.cc:754-756)
@@ -780,6 +834,8 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
   const unsigned long long first = s.lo + 1;
   const unsigned n = (unsigned)(s.hi - first);
   const unsigned nchunks = (n + kPartChunk - 1) / kPartChunk;
+  // (the grid is sized for the largest order: there are at most n pairs)
+  if ((unsigned long long)blockIdx.x * (unsigned)kPartChunk > n) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   {  // the two tables, by every workgroup for itself
     const unsigned per = (nchunks + 255) / 256;

@@ -140,28 +140,43 @@ __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ er
       counters[0] = (unsigned)changed;
     }
   }
+  // Everything that does not depend on the offset is loaded before the workgroup's sum (whose
+  // barriers the compiler will not move loads across): the block's scalars and its first two
+  // rounds of entries -- the kernel is a chain of dependent trips to memory, not a stream.
+  const bool valid = b < nb;
+  int n = 0, at = 0;
+  float base = 0.0f, wb = 1.0f;
+  if (valid) {
+    n = (int)n_b[b];
+    at = next_cand[b];
+    base = max_err[b];
+    wb = weight[b];
+  }
+  const float* e = err + (size_t)(valid ? b : 0) * 192;
+  auto entry = [&](int j) { return direction > 0 ? e[at + j] : e[at - 1 - j]; };
+  float e0 = 0.0f, e1 = 0.0f;
+  if (sub < n) e0 = entry(sub);
+  if (sub + kFillLanes < n) e1 = entry(sub + kFillLanes);
   // entries before the workgroup's first block: whole groups, then the blocks of its own group
   int part = 0;
   for (int i = t; i < g; i += 256) part += (int)group_sums[2 * i];
   if (g * kOrderGroup + t < b0) part += (int)n_b[g * kOrderGroup + t];
   if (t < kFillBlocks) own[t] = b0 + t < nb ? n_b[b0 + t] : 0u;
   const unsigned base_wg = (unsigned)wg_sum(part, lds4);   // (its barriers also publish own[])
-  if (b >= nb) return;
-  const int n = (int)own[group];
   if (n == 0) return;
   unsigned long long o = base_wg;
   for (int i = 0; i < group; ++i) o += own[i];
-  const int at = next_cand[b];
-  const float base = max_err[b], wb = weight[b];
-  const float* e = err + (size_t)b * 192;
   unsigned below = 0;
-  for (int j = sub; j < n; j += kFillLanes) {
+  auto put = [&](int j, float ev) {
     OrderEntry v;
     v.block = b;
-    v.val = direction > 0 ? (e[at + j] - base) / wb : (base - e[at - 1 - j]) / wb;
+    v.val = direction > 0 ? (ev - base) / wb : (base - ev) / wb;
     out[o + j] = v;
     below += (count_below && v.val < limit) ? 1u : 0u;
-  }
+  };
+  if (sub < n) put(sub, e0);
+  if (sub + kFillLanes < n) put(sub + kFillLanes, e1);
+  for (int j = sub + 2 * kFillLanes; j < n; j += kFillLanes) put(j, entry(j));
   if (count_below && below) atomicAdd(&counters[1], below);
 }
 
@@ -836,6 +851,7 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
   const unsigned nchunks = (n + kPartChunk - 1) / kPartChunk;
   // (the grid is sized for the largest order: there are at most n pairs)
   if ((unsigned long long)blockIdx.x * (unsigned)kPartChunk > n) return;
+  const DescPivot pvt = A.pv[level];   // (asked for here: it arrives while the tables are built)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   {  // the two tables, by every workgroup for itself
     const unsigned per = (nchunks + 255) / 256;
@@ -867,7 +883,6 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
   // other in the chunks' lists, and the stoppers themselves nearly so)
   const unsigned kw = blockIdx.x * (unsigned)kPartChunk + (unsigned)wave * (64u * kPartItems);
   if (kw > K) return;
-  const DescPivot pvt = A.pv[level];
   // positions (relative to `first`) of the k-th left stopper / the k-th right stopper from the right
   auto find_l = [&](unsigned k) {
     const unsigned c = desc_chunk_of(PL, nchunks, k);
@@ -878,24 +893,35 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
     const unsigned c = nchunks - 1 - i, cnt = RR[i + 1] - RR[i];
     return A.rpos[c * (unsigned)kPartChunk + (cnt - 1 - (k - RR[i]))];
   };
-  bool prev_swapped = true;   // (kw == 0: the scan starts)
-  unsigned prev_pr = 0;
-  if (kw > 0) {
-    const unsigned ql = find_l(kw - 1);   // (kw - 1 < K: both exist)
-    prev_pr = find_r(kw - 1);
-    prev_swapped = ql < prev_pr;
-    // Left stoppers ascend and right stoppers descend with k: once a pair has crossed, every later
-    // one has.  A wavefront behind the crossing has nothing to swap and no cut to find -- about
-    // half of them (the pivot is a median of three).
-    if (!prev_swapped) return;
-  }
-  // every lane finds the chunks of its first pair once and walks on from there (the next row's k
-  // is 64 further: the same chunk or the one after)
+  // The chunks of the pair BEFORE the wavefront's first one, found by the wavefront together (64
+  // table entries per step instead of one): every lane walks on from there -- its k is at most
+  // 64 * kPartItems further.
+  const unsigned kp = kw > 0 ? kw - 1 : 0;
+  auto chunk_by_wave = [&](const unsigned* tab, unsigned k) {
+    // tab[0 .. nchunks] ascending, tab[0] <= k < tab[nchunks]: the last index with tab[i] <= k
+    unsigned lo = 0, len = nchunks;               // the answer lies in [lo, lo + len)
+    while (len > 1) {
+      const unsigned step = (len + 63) / 64;      // lane j looks at lo + j * step
+      const unsigned i = lo + (unsigned)lane * step;
+      const unsigned long long le = __ballot(i < lo + len && tab[i] <= k);
+      const unsigned j = (unsigned)GZ_POPC64(le) - 1u;   // (lane 0 always holds: tab[lo] <= k)
+      const unsigned nlo = lo + j * step;
+      len = nlo + step <= lo + len ? step : lo + len - nlo;
+      lo = nlo;
+    }
+    return lo;
+  };
   unsigned cl = 0, ir = 0;
-  {
-    const unsigned k = kw + (unsigned)lane;
-    if (k < total_l) cl = desc_chunk_of(PL, nchunks, k);
-    if (k < total_r) ir = desc_chunk_of(RR, nchunks, k);
+  if (kp < total_l) cl = chunk_by_wave(PL, kp);
+  if (kp < total_r) ir = chunk_by_wave(RR, kp);
+  // the predecessor pair and the kPartItems rows in ONE round of look-ups (they do not depend on
+  // one another): a wavefront behind the crossing finds out a little later than it could, the
+  // others save a trip to memory
+  unsigned prev_pl = 0, prev_pr = 0;
+  if (kw > 0) {   // (kp < K: both exist)
+    prev_pl = A.lpos[cl * (unsigned)kPartChunk + (kp - PL[cl])];
+    const unsigned c = nchunks - 1 - ir, cnt = RR[ir + 1] - RR[ir];
+    prev_pr = A.rpos[c * (unsigned)kPartChunk + (cnt - 1 - (kp - RR[ir]))];
   }
   unsigned pl[kPartItems], pr[kPartItems];
   bool sw[kPartItems];
@@ -916,6 +942,11 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
     }
     sw[i] = has_l && has_r && pl[i] < pr[i];
   }
+  // Left stoppers ascend and right stoppers descend with k: once a pair has crossed, every later
+  // one has.  A wavefront behind the crossing has nothing to swap and no cut to find -- about
+  // half of them (the pivot is a median of three).
+  const bool prev_swapped = kw == 0 || prev_pl < prev_pr;
+  if (!prev_swapped) return;
   OrderEntry vl[kPartItems], vr[kPartItems];
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i)

@@ -28,7 +28,7 @@ def test_device_partition_is_std_sort_in_emulation(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread",
                     os.path.join(ROOT, "tests", "cpp", "test_device_order.cc"), "-o", exe, "-ldl"],
                    check=True)
-    out = subprocess.run([exe, build_emu.build(), "4097", "512"], capture_output=True, text=True)
+    out = subprocess.run([exe, build_emu.build(), "32769", "512"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device_order: ok" in out.stdout
 

@@ -65,11 +65,11 @@ struct HuffMemo {
 }  // namespace
 
 static void HuffmanDepthsUncached(const uint32_t* counts, size_t length, int tree_limit,
-                                  uint8_t* depth);
+                                  uint8_t* depth, int stream);
 
-void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth) {
+void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth, int stream) {
   if (length != (size_t)kHistoSize) {
-    HuffmanDepthsUncached(counts, length, tree_limit, depth);
+    HuffmanDepthsUncached(counts, length, tree_limit, depth, -1);
     return;
   }
   static thread_local HuffMemo memo = {};
@@ -81,7 +81,7 @@ void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_
         if (counts[i]) depth[i] = memo.depth[s][i];
       return;
     }
-  HuffmanDepthsUncached(counts, length, tree_limit, depth);
+  HuffmanDepthsUncached(counts, length, tree_limit, depth, stream);
   const int s = memo.next;
   memo.next = (memo.next + 1) % HuffMemo::kSlots;
   memcpy(memo.counts[s], counts, sizeof(memo.counts[s]));
@@ -90,24 +90,34 @@ void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_
   memo.valid[s] = true;
 }
 
+namespace {
+// The order of the present symbols by (count, symbol descending) of the last construction on a
+// "stream" of histograms (phase B asks for the codes of the same component again after ten
+// coefficient steps: the counts have moved by a few units and the order hardly at all).
+struct HuffOrder {
+  int n;
+  int16_t sym_id[260];
+  int16_t order[260];
+};
+const int kHuffStreams = 8;
+}  // namespace
+
 static void HuffmanDepthsUncached(const uint32_t* counts, size_t length, int tree_limit,
-                                  uint8_t* depth) {
+                                  uint8_t* depth, int stream) {
   // Called ~10^4 times per image by phase B's size model, typically with ~8 repetitions each
-  // (AC counts span 1..10^6, so the unconstrained tree is ~22 deep): flat arrays, one sort,
-  // and no tree walk for the attempts that fail.
+  // (AC counts span 1..10^6, so the unconstrained tree is ~22 deep): flat arrays, one sort (or
+  // the last order of the stream, repaired), leaves that are a fill and a copy, and no tree walk
+  // for the attempts that fail.
   const size_t kMax = 2 * 260 + 2;
-  if (length > 260) {   // not a JPEG histogram: generic containers
-    std::vector<uint32_t> c(counts, counts + length);
-    std::vector<uint8_t> d(length, 0);
-    // split recursively is not needed in this code base; refuse loudly
+  if (length > 260) {   // not a JPEG histogram: refuse loudly
     fprintf(stderr, "guetzli_amd: HuffmanDepths on %zu symbols is not supported\n", length);
     abort();
   }
   uint32_t sym_count[260];
-  int sym_id[260];
+  int16_t sym_id[260];
   size_t n = 0;
   for (size_t i = length; i-- > 0;)   // present symbols, symbol descending
-    if (counts[i]) { sym_count[n] = counts[i]; sym_id[n] = (int)i; ++n; }
+    if (counts[i]) { sym_count[n] = counts[i]; sym_id[n] = (int16_t)i; ++n; }
   if (n == 0) return;
   if (n == 1) {
     depth[sym_id[0]] = 1;
@@ -115,30 +125,50 @@ static void HuffmanDepthsUncached(const uint32_t* counts, size_t length, int tre
   }
   // The leaves of one construction are ordered by (weight ascending, symbol descending) with
   // weight = max(count, floor).  All leaves at the floor therefore come first in symbol
-  // order, and the rest follow in (count, symbol) order whatever the floor is: one sort
-  // serves every repetition.
-  uint64_t by_count[260];   // (count, position in sym_*) ascending
-  for (size_t i = 0; i < n; ++i) by_count[i] = ((uint64_t)sym_count[i] << 32) | (uint64_t)i;
-  std::sort(by_count, by_count + n);
+  // order, and the rest follow in (count, symbol) order whatever the floor is: one order
+  // serves every repetition.  order[j] = position in sym_* of the j-th smallest (count, position).
+  int16_t order[260];
+  static thread_local HuffOrder last[kHuffStreams];
+  HuffOrder* memo = stream >= 0 && stream < kHuffStreams ? &last[stream] : nullptr;
+  if (memo && memo->n == (int)n && memcmp(memo->sym_id, sym_id, n * sizeof(int16_t)) == 0) {
+    // the same symbols as last time: their last order, repaired by insertion (a total order:
+    // whichever way it is reached, the result is the one a sort gives)
+    order[0] = memo->order[0];
+    for (size_t j = 1; j < n; ++j) {
+      const int16_t p = memo->order[j];
+      const uint32_t c = sym_count[p];
+      size_t k = j;
+      while (k > 0 && (sym_count[order[k - 1]] > c || (sym_count[order[k - 1]] == c && order[k - 1] > p))) {
+        order[k] = order[k - 1];
+        --k;
+      }
+      order[k] = p;
+    }
+  } else {
+    uint64_t by_count[260];   // (count, position in sym_*) ascending
+    for (size_t i = 0; i < n; ++i) by_count[i] = ((uint64_t)sym_count[i] << 32) | (uint64_t)i;
+    std::sort(by_count, by_count + n);
+    for (size_t j = 0; j < n; ++j) order[j] = (int16_t)(by_count[j] & 0xffffffffu);
+  }
+  if (memo) {
+    memo->n = (int)n;
+    memcpy(memo->sym_id, sym_id, n * sizeof(int16_t));
+    memcpy(memo->order, order, n * sizeof(int16_t));
+  }
+  uint32_t sorted_count[260];
+  for (size_t j = 0; j < n; ++j) sorted_count[j] = sym_count[order[j]];
   uint32_t weight[kMax];
   int16_t child[kMax][2];
   uint8_t height[kMax];   // of the subtree under a node, <= tree_limit while building
-  int leaf_sym[260];
-  size_t above = 0;   // first entry of by_count whose count exceeds the floor
+  size_t above = 0;   // first entry of the order whose count exceeds the floor
   for (uint32_t floor_count = 1;; floor_count *= 2) {
     // a floor below every count changes nothing: same (too deep) tree as the attempt before
-    if (floor_count > 1 && (uint32_t)(by_count[0] >> 32) >= floor_count) continue;
-    while (above < n && (uint32_t)(by_count[above] >> 32) <= floor_count) ++above;
-    size_t m = 0;
-    if (above > 0)
-      for (size_t i = 0; i < n; ++i)
-        if (sym_count[i] <= floor_count) { weight[m] = floor_count; leaf_sym[m] = sym_id[i]; ++m; }
-    for (size_t j = above; j < n; ++j) {
-      const size_t i = (size_t)(by_count[j] & 0xffffffffu);
-      weight[m] = sym_count[i];
-      leaf_sym[m] = sym_id[i];
-      ++m;
-    }
+    if (floor_count > 1 && sorted_count[0] >= floor_count) continue;
+    while (above < n && sorted_count[above] <= floor_count) ++above;
+    // the leaves' weights: `above` leaves at the floor, then the counts above it (which symbols
+    // they are matters only for the attempt that succeeds)
+    for (size_t j = 0; j < above; ++j) weight[j] = floor_count;
+    memcpy(weight + above, sorted_count + above, (n - above) * sizeof(uint32_t));
     // two queues: leaves [0, n) and inner nodes [n + 1, ...), each closed by a sentinel; on
     // equal weight the leaf is taken
     weight[n] = ~0u;
@@ -172,7 +202,12 @@ static void HuffmanDepthsUncached(const uint32_t* counts, size_t length, int tre
       level[child[at][0]] = l;
       level[child[at][1]] = l;
     }
-    for (size_t i = 0; i < n; ++i) depth[leaf_sym[i]] = level[i];
+    // leaf m: the floor's leaves in symbol order (descending), then the order's rest
+    size_t m = 0;
+    if (above > 0)
+      for (size_t i = 0; i < n; ++i)
+        if (sym_count[i] <= floor_count) depth[sym_id[i]] = level[m++];
+    for (size_t j = above; j < n; ++j) depth[sym_id[order[j]]] = level[m++];
     return;
   }
 }
@@ -193,7 +228,7 @@ size_t ClusterHistograms(SymbolHistogram* histo, size_t* num, int* histo_indexes
   size_t costs[4];
   for (size_t i = 0; i < *num; ++i) {
     histo_indexes[i] = (int)i;
-    HuffmanDepths(histo[i].counts, kHistoSize, 16, &depth[i * kHistoSize]);
+    HuffmanDepths(histo[i].counts, kHistoSize, 16, &depth[i * kHistoSize], (int)i);
     costs[i] = HistogramHeaderBits(histo[i]) + HistogramEntropyBits(histo[i], &depth[i * kHistoSize]);
   }
   const size_t orig_num = *num;
@@ -202,7 +237,7 @@ size_t ClusterHistograms(SymbolHistogram* histo, size_t* num, int* histo_indexes
     SymbolHistogram both(histo[last]);
     both.Merge(histo[prev]);
     uint8_t depth_both[kHistoSize] = {0};
-    HuffmanDepths(both.counts, kHistoSize, 16, depth_both);
+    HuffmanDepths(both.counts, kHistoSize, 16, depth_both, 3 + (int)(orig_num - *num));
     const size_t cost_both = HistogramHeaderBits(both) + HistogramEntropyBits(both, depth_both);
     if (cost_both >= costs[last] + costs[prev]) break;
     histo[prev] = both;

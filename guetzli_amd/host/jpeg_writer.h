@@ -35,7 +35,9 @@ struct SymbolHistogram {
 };
 
 // Length-limited Huffman depths (CreateHuffmanTree, entropy_encode.cc:73-145).
-void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth);
+// stream: which sequence of slowly changing histograms this one belongs to (0..7; the construction
+// starts from the last order of the stream's symbols), -1 for none.  The result does not depend on it.
+void HuffmanDepths(const uint32_t* counts, size_t length, int tree_limit, uint8_t* depth, int stream = -1);
 
 size_t HistogramHeaderBits(const SymbolHistogram& h);                       // :218-226
 size_t HistogramEntropyBits(const SymbolHistogram& h, const uint8_t* depth);  // :228-239

@@ -1518,6 +1518,12 @@ double gzh_butteraugli_score_for_quality(double q) {
   return guetzli_amd::ButteraugliScoreForQuality(q);
 }
 
+// Length-limited Huffman depths of a 257-entry histogram (CreateHuffmanTree, entropy_encode.cc:
+// 73-145), the way phase B's size model calls it (stream: see jpeg_writer.h).  Test hook.
+void gzh_huffman_depths(const uint32_t* counts, int tree_limit, uint8_t* depth, int stream) {
+  guetzli_amd::HuffmanDepths(counts, (size_t)guetzli_amd::kHistoSize, tree_limit, depth, stream);
+}
+
 // Threads of the driver's worker pool (the calling thread included): min(16, cores the process may
 // run on), GZ_HOST_THREADS overrides.  Test hook for the per-rank core share of a multi-GPU run.
 int gzh_worker_pool_size() { return guetzli_amd::WorkerPool::Get().size(); }

@@ -147,3 +147,78 @@ def test_host_driver_replays_a_960x540_encode_recorded_on_the_gpu(tmp_path, monk
     assert len(jpg) == meta["jpeg_bytes"]
     assert hashlib.sha256(jpg).hexdigest() == meta["jpeg_sha256"] == meta["jpeg_sha256_reference"]
     assert info["counters"]["number of iterations"] == meta["iterations"]
+
+
+def test_huffman_depths_are_the_reference_tree(tmp_path):
+    """The search driver's length-limited Huffman depths (guetzli_amd/host/jpeg_writer.cc: one sort
+    or the stream's last order repaired, floor leaves as a fill) against the reference's
+    CreateHuffmanTree itself (entropy_encode.cc:73-145, from oracle/_ref/libgz_ref.so): random,
+    sparse, tie-heavy and too-deep histograms, and streams of slowly drifting ones as phase B's size
+    model produces them -- with and without the stream hint."""
+    import ctypes as C
+    import numpy as np
+    import pytest
+    refso = os.path.join(ROOT, "oracle", "_ref", "libgz_ref.so")
+    if not os.path.exists(refso):
+        pytest.skip("oracle/_ref/libgz_ref.so not built")
+    from guetzli_amd import build as gzbuild
+    host = C.CDLL(gzbuild.build_host())
+    host.gzh_huffman_depths.restype = None
+    host.gzh_huffman_depths.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    ref = C.CDLL(refso)
+    create = getattr(ref, "_ZN7guetzli17CreateHuffmanTreeEPKjmiPNS_11HuffmanTreeEPh")
+    create.restype = None
+    create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    tree = np.zeros(8 * (2 * 257 + 1), np.uint8)
+
+    def check(counts, stream, what):
+        counts = np.ascontiguousarray(counts, np.uint32)
+        want = np.zeros(257, np.uint8)
+        got = np.zeros(257, np.uint8)
+        create(counts.ctypes.data, 257, 16, tree.ctypes.data, want.ctypes.data)
+        host.gzh_huffman_depths(counts.ctypes.data, 16, got.ctypes.data, stream)
+        assert np.array_equal(want, got), (what, np.nonzero(want != got)[0][:8])
+
+    rng = np.random.default_rng(20260924)
+
+    def ac_like(scale):
+        c = np.zeros(257, np.uint32)
+        for s in range(256):
+            run, size = s >> 4, s & 15
+            if size > 10 or (size == 0 and run not in (0, 15)):
+                continue
+            c[s] = 2 * int(scale * np.exp(-0.55 * run - 0.9 * abs(size - 2)) * rng.uniform(0.5, 1.5))
+        c[256] = 1
+        return c
+
+    for i in range(300):       # independent histograms, no hint and a (useless) hint
+        kind = i % 6
+        if kind == 0:
+            c = ac_like(10.0 ** rng.uniform(0, 6.5))
+        elif kind == 1:
+            c = np.where(rng.random(257) < 0.1, rng.integers(1, 50, 257), 0).astype(np.uint32)
+        elif kind == 2:
+            c = (2 ** rng.integers(0, 24, 257)).astype(np.uint32) * (rng.random(257) < 0.5)
+        elif kind == 3:
+            c = np.full(257, rng.integers(1, 5), np.uint32) * (rng.random(257) < 0.7)   # ties
+        elif kind == 4:
+            c = np.zeros(257, np.uint32)
+            c[rng.integers(0, 257, rng.integers(1, 4))] = rng.integers(1, 1000)         # 1-3 symbols
+        else:
+            fib = [1, 1]
+            while len(fib) < 40:
+                fib.append(fib[-1] + fib[-2])
+            c = np.zeros(257, np.uint32)
+            c[:40] = fib                                                                  # deepest tree
+        check(c, -1, ("single", kind))
+        check(c, i % 8, ("single hinted", kind))
+    for stream in range(5):    # drifting histograms on one stream: the cached order is repaired
+        c = ac_like(10.0 ** rng.uniform(2, 6)).astype(np.int64)
+        for step in range(400):
+            for _ in range(rng.integers(1, 12)):
+                s = int(rng.integers(0, 256))
+                if c[s] or rng.random() < 0.05:
+                    c[s] = max(0, c[s] + 2 * int(rng.integers(-3, 4)))   # symbols come and go
+            check(c.astype(np.uint32), stream, ("stream", stream, step))
+            if step % 50 == 0:   # another stream's histogram in between, under the same id
+                check(ac_like(1000.0), stream, ("interleaved", stream, step))

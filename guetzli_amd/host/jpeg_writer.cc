@@ -299,6 +299,50 @@ void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHis
   if (raw_bits) *raw_bits += weight * bits;
 }
 
+// The same update for ONE coefficient that changes (natural index k >= 1, blk still holds the old
+// value): the AC symbols of a block differ only between the non-zero coefficient before position
+// k of the scan and the one after it -- the coefficient's own symbol, its successor's zero run and
+// the end-of-block code.  Equal to AddBlockACSymbols(blk, q, -1) + the store + AddBlockACSymbols
+// (blk, q, +1), for a few coefficients' work instead of two passes over the block.
+void ReplaceCoeffACSymbols(const int16_t* blk, const int* q, int k, int newval, SymbolHistogram* h,
+                           const uint8_t* depth, int64_t* raw_bits) {
+  static int zigzag_of[64] = {-1};
+  if (zigzag_of[0] < 0) {   // (idempotent: every thread writes the same values)
+    for (int z = 63; z >= 0; --z) zigzag_of[kNaturalOrder[z]] = z;
+  }
+  const int oldval = blk[k];
+  if (oldval == newval) return;
+  const int z = zigzag_of[k];
+  int pz = z - 1, nz = z + 1;             // the non-zero neighbours in scan order: 0 / 64 if none
+  while (pz >= 1 && blk[kNaturalOrder[pz]] == 0) --pz;
+  while (nz <= 63 && blk[kNaturalOrder[nz]] == 0) ++nz;
+  int64_t bits = 0;
+  auto add = [&](int symbol, int weight) {
+    h->Add(symbol, weight);
+    if (depth) bits += weight * (depth[symbol] + (symbol & 0xf));
+  };
+  auto coeff = [&](int run, int v, int nat, int weight) {   // `run` zeros, then the value v at nat
+    while (run > 15) {
+      add(0xf0, weight);
+      run -= 16;
+    }
+    const int mag = std::abs(q ? v / q[nat] : v);
+    add((run << 4) + FloorLog2((uint32_t)mag) + 1, weight);
+  };
+  auto window = [&](int v, int weight) {   // the symbols between pz and nz with v at position z
+    int last = pz;                         // last non-zero position so far
+    if (v != 0) {
+      coeff(z - 1 - pz, v, k, weight);
+      last = z;
+    }
+    if (nz <= 63) coeff(nz - 1 - last, blk[kNaturalOrder[nz]], kNaturalOrder[nz], weight);
+    else if (last < 63) add(0, weight);    // trailing zeros: the end-of-block code
+  };
+  window(oldval, -1);
+  window(newval, 1);
+  if (raw_bits) *raw_bits += bits;
+}
+
 int64_t HistogramRawBits(const SymbolHistogram& h, const uint8_t* depth) {
   int64_t bits = 0;
   for (int i = 0; i + 1 < kHistoSize; ++i) bits += (int64_t)(h.counts[i] / 2) * (depth[i] + (i & 0xf));

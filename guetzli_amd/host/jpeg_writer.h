@@ -60,6 +60,10 @@ size_t EntropyDataSize(const SymbolHistogram* histo, int n, const uint8_t* depth
 void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHistogram* h,
                        const uint8_t* depth = nullptr, int64_t* raw_bits = nullptr);
 // HistogramEntropyBits == EntropyBitsFromRaw(HistogramRawBits(h, depth)).
+// AddBlockACSymbols(blk, q, -1) + blk[k] = newval + AddBlockACSymbols(blk, q, +1) without the two
+// passes (k >= 1; blk holds the old value and is not written).
+void ReplaceCoeffACSymbols(const int16_t* blk, const int* q, int k, int newval, SymbolHistogram* h,
+                           const uint8_t* depth, int64_t* raw_bits);
 int64_t HistogramRawBits(const SymbolHistogram& h, const uint8_t* depth);
 size_t EntropyBitsFromRaw(int64_t raw);
 

@@ -832,13 +832,20 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         int16_t* blk = &img_[Pos(c, b, 0)];
         const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
         const uint8_t* depth = &ac_depths[c * kHistoSize];
-        AddBlockACSymbols(blk, q, -1, &ac_histo[c], depth, &ac_raw_bits[c]);
         if (!(newval == 0 && IsPrecious(orig_blk, k))) {
-          blk[k] = (int16_t)newval;
+          // UpdateACHistogram before and after the change (processor.cc:715-722): only the symbols
+          // around the coefficient differ
+          if (k >= 1) {
+            ReplaceCoeffACSymbols(blk, q, k, newval, &ac_histo[c], depth, &ac_raw_bits[c]);
+            blk[k] = (int16_t)newval;
+          } else {
+            AddBlockACSymbols(blk, q, -1, &ac_histo[c], depth, &ac_raw_bits[c]);
+            blk[k] = (int16_t)newval;
+            AddBlockACSymbols(blk, q, 1, &ac_histo[c], depth, &ac_raw_bits[c]);
+          }
           edit_pos.push_back((int32_t)Pos(c, b, k));
           edit_val.push_back((int16_t)newval);
         }
-        AddBlockACSymbols(blk, q, 1, &ac_histo[c], depth, &ac_raw_bits[c]);
         next_cand[b] += direction;
         mirror_cand[b] = next_cand[b];
         if (!touched[b]) {

@@ -18,6 +18,18 @@ def test_lazy_sort_is_std_sort(tmp_path):
     assert "lazy_sort: ok" in out.stdout
 
 
+def test_local_ac_symbol_update_equals_two_block_passes(tmp_path):
+    """ReplaceCoeffACSymbols (the symbols around one changed coefficient, phase B's slow steps)
+    == AddBlockACSymbols(-1) + store + AddBlockACSymbols(+1) on 200 000 random blocks."""
+    exe = str(tmp_path / "test_ac_symbols")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall",
+                    os.path.join(ROOT, "tests", "cpp", "test_ac_symbols.cc"),
+                    os.path.join(ROOT, "guetzli_amd", "host", "jpeg_writer.cc"), "-o", exe, "-lz"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ac_symbols: ok" in out.stdout
+
+
 def test_device_partition_is_std_sort_in_emulation(tmp_path):
     """gz_order_partition (gz_kernels_order.h, here the CPU emulation build of the kernel
     sources) driven by LazySorted reproduces std::sort's permutation, ties included."""

@@ -2210,7 +2210,10 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
   A.per_block = per_block;
   A.publish = publish && levels > 0 ? 1 : 0;
   A.max_bits = c->d_max_bits;
-  const int swap_groups = (int)((n_bound + 1 + kPartChunk - 1) / kPartChunk);
+  int swap_groups = std::min<int>((int)((n_bound + 1 + kPartChunk - 1) / kPartChunk), kDescSwapGrid);
+#ifdef GZ_EMU
+  if (const char* e = getenv("GZ_EMU_DESC_SWAP_GRID")) swap_groups = std::max(1, atoi(e));   // (the loop over groups on orders the emulation can afford)
+#endif
   for (int l = 0; l < levels; ++l) {
     GZ_LAUNCH(k_desc_count, dim3((unsigned)nchunks), dim3(256), c->stream, A, l);
     KCHK(c);

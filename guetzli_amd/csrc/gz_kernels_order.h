@@ -670,6 +670,7 @@ __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, s
 // of gz_order_partition (and of std::sort): tests/cpp/test_device_order.cc.
 constexpr int kDescMaxChunks = 4096;   // chunk tables of a workgroup: ranges up to 8.4 M entries
 constexpr int kDescMaxLevels = 12;
+constexpr int kDescSwapGrid = 1024;    // workgroups of k_desc_swap (four fit on a CU: 33 KB of LDS)
 
 struct DescState {                 // the range before level l (level 0: derived, see desc_load)
   unsigned long long lo, hi;       // the range that holds `last`
@@ -881,8 +882,14 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
   const unsigned K = total_l < total_r ? total_l : total_r;   // pairs 0 .. K-1 exist; "pair" K ends the scan
   // the wavefront's pairs: kPartItems rows of 64 consecutive k (their positions sit next to each
   // other in the chunks' lists, and the stoppers themselves nearly so)
-  const unsigned kw = blockIdx.x * (unsigned)kPartChunk + (unsigned)wave * (64u * kPartItems);
-  if (kw > K) return;
+  // The grid has at most kDescSwapGrid workgroups, each with its tables built once: group g of
+  // kPartChunk pairs goes to workgroup g % gridDim.x.  (A workgroup per group of the LARGEST
+  // possible order -- 3 400 at 4K, 33 KB of LDS each, four to a CU -- made the groups that have
+  // nothing to do queue behind the ones that work: 47 us for the first level where the same
+  // kernel on a grid of the order's own size takes 21, profiles/r04_occupancy_experiments.log.)
+  for (unsigned g = blockIdx.x;; g += gridDim.x) {
+  const unsigned kw = g * (unsigned)kPartChunk + (unsigned)wave * (64u * kPartItems);
+  if (kw > K) return;   // (and so are the workgroup's later groups)
   // positions (relative to `first`) of the k-th left stopper / the k-th right stopper from the right
   auto find_l = [&](unsigned k) {
     const unsigned c = desc_chunk_of(PL, nchunks, k);
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
   // one has.  A wavefront behind the crossing has nothing to swap and no cut to find -- about
   // half of them (the pivot is a median of three).
   const bool prev_swapped = kw == 0 || prev_pl < prev_pr;
-  if (!prev_swapped) return;
+  if (!prev_swapped) return;   // (the later groups are behind the crossing too)
   OrderEntry vl[kPartItems], vr[kPartItems];
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i)
@@ -990,7 +997,7 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
       }
     }
   }
-  if (blockIdx.x == 0 && t == 0) {
+  if (g == 0 && t == 0) {
     // the median's move to the front, made real: the front gets the pivot; the place the pivot
     // came from gets the old front element unless a pair above has already put a partner there
     A.a[s.lo] = pvt.pivot;
@@ -1014,6 +1021,7 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
     }
     if (!moved) A.a[pvt.med] = pvt.a_lo;
   }
+  }   // for g
 }
 
 // Behind the last level of a descent: the leading entries of the order up to the end of the range

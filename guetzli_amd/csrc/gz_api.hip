@@ -460,7 +460,7 @@ struct gz_ctx {
   unsigned results_epoch = 0;          // the descent (desc_epoch) that published them
   unsigned export_epoch = 0;           // the descent whose k_desc_export wrote into the host mirror (0: none)
   unsigned* d_order_nb = nullptr;                                 // [nb]
-  unsigned long long* d_order_off = nullptr;                      // [nb+1]
+  unsigned long long* d_order_off = nullptr;                      // [nb+1]: [nb] = the order's size; the first 4 nb BYTES: every block's offset inside its group
   unsigned* d_order_counters = nullptr;                           // [2]
   unsigned* d_order_groups = nullptr;                             // [2 * ceil(nb / kOrderGroup)]: sum of n_b, blocks with n_b > 0
   int* d_next_cand = nullptr; float* d_weight = nullptr; float* d_max_err = nullptr;   // [nb]
@@ -1765,13 +1765,14 @@ static int order_build_enqueue(gz_ctx* c, int direction, int count_below, float 
     HIPCHK(c, hipMemsetAsync(c->d_order_counters, 0, sizeof(unsigned) * 2, c->stream));
     GZ_LAUNCH(k_order_sizes, dim3(gz_div_up(nb, kOrderGroup)), dim3(kOrderGroup), c->stream,
               (const int*)c->d_out_cnt, (const int*)c->d_next_cand, (const float*)c->d_weight,
-              direction, nb, c->d_order_nb, c->d_order_groups);
+              direction, nb, c->d_order_nb, c->d_order_groups, (unsigned*)c->d_order_off);
     KCHK(c);
   }
   // (no scan of the counts: k_order_fill's workgroups find their offsets from the group sums)
   GZ_LAUNCH(k_order_fill, dim3(gz_div_up(nb, kFillBlocks)), dim3(256), c->stream,
             (const float*)c->d_out_err, (const int*)c->d_next_cand, (const float*)c->d_weight,
             (const float*)c->d_max_err, (const unsigned*)c->d_order_nb, (const unsigned*)c->d_order_groups,
+            (const unsigned*)c->d_order_off /* the blocks' offsets inside their groups: the first 4 nb bytes */,
             direction, nb, count_below ? 1 : 0, limit, c->d_order, c->d_order_off + nb, c->d_order_counters);
   KCHK(c);
   return GZ_OK;
@@ -1873,7 +1874,8 @@ static int order_auto_enqueue(gz_ctx* c, int direction, int max_block_dist, doub
   KCHK(c);
   GZ_LAUNCH(k_weights_gather, dim3(gz_div_up(nb, kOrderGroup)), dim3(kOrderGroup), c->stream,
             (const unsigned char*)c->d_wflag, bw, bh, direction, max_block_dist, c->d_weight,
-            (const int*)c->d_out_cnt, (const int*)c->d_next_cand, c->d_order_nb, c->d_order_groups);
+            (const int*)c->d_out_cnt, (const int*)c->d_next_cand, c->d_order_nb, c->d_order_groups,
+            (unsigned*)c->d_order_off);
   KCHK(c);
   return GZ_OK;
 }
@@ -2211,11 +2213,15 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
   A.publish = publish && levels > 0 ? 1 : 0;
   A.max_bits = c->d_max_bits;
   int swap_groups = std::min<int>((int)((n_bound + 1 + kPartChunk - 1) / kPartChunk), kDescSwapGrid);
+  int count_groups = (int)std::min<size_t>(nchunks, (size_t)kDescCountGrid);
 #ifdef GZ_EMU
-  if (const char* e = getenv("GZ_EMU_DESC_SWAP_GRID")) swap_groups = std::max(1, atoi(e));   // (the loop over groups on orders the emulation can afford)
+  if (const char* e = getenv("GZ_EMU_DESC_SWAP_GRID")) {   // (the loops over groups on orders the emulation can afford)
+    swap_groups = std::max(1, atoi(e));
+    count_groups = std::max(1, atoi(e));
+  }
 #endif
   for (int l = 0; l < levels; ++l) {
-    GZ_LAUNCH(k_desc_count, dim3((unsigned)nchunks), dim3(256), c->stream, A, l);
+    GZ_LAUNCH(k_desc_count, dim3((unsigned)count_groups), dim3(256), c->stream, A, l);
     KCHK(c);
     GZ_LAUNCH(k_desc_swap, dim3((unsigned)swap_groups), dim3(256), c->stream, A, l);
     KCHK(c);

@@ -45,28 +45,37 @@ GZ_DEVFN bool order_less(const OrderEntry& a, const OrderEntry& b) { return a.va
 // and a decoupled look-back scan of 64 tiles, 15 us, both on phase B's critical path.)
 constexpr int kOrderGroup = 256;   // = the block size of the kernels that write the group sums
 
-// Sum over the workgroup (256 threads); every thread gets it.  lds4: 4 ints.
-GZ_DEVFN int wg_sum(int v, int* lds4) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+// Sum over the wavefront; every lane gets it.
+GZ_DEVFN int wave_sum(int v) {
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int o = __shfl_up(v, (unsigned)d);
     if (lane >= d) v += o;
   }
-  __syncthreads();   // (lds4 may still be read from a previous call)
-  if (lane == 63) lds4[wave] = v;
-  __syncthreads();
-  return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  return __shfl(v, 63);
 }
 
-// The group's two sums; every thread of the workgroup calls this (n = 0 beyond the last block).
-GZ_DEVFN void order_group_sums(int n, unsigned* __restrict__ group_sums) {
-  __shared__ int lds4[4];
-  const int sum = wg_sum(n, lds4);
-  const int cnt = wg_sum(n > 0 ? 1 : 0, lds4);
-  if (threadIdx.x == 0) {
-    group_sums[2 * blockIdx.x] = (unsigned)sum;
-    group_sums[2 * blockIdx.x + 1] = (unsigned)cnt;
+// The group's two sums and every block's offset inside its group (the entries of the group's
+// blocks before it); every thread of the workgroup calls this (n = 0 beyond the last block).
+GZ_DEVFN void order_group_sums(bool valid, int b, int n, unsigned* __restrict__ group_sums,
+                               unsigned* __restrict__ blk_off) {
+  __shared__ int lds8[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int incl = n, cnt = n > 0 ? 1 : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, (unsigned)d), oc = __shfl_up(cnt, (unsigned)d);
+    if (lane >= d) { incl += o; cnt += oc; }
+  }
+  if (lane == 63) { lds8[wave] = incl; lds8[4 + wave] = cnt; }
+  __syncthreads();
+  int before = 0;
+  for (int wv = 0; wv < wave; ++wv) before += lds8[wv];
+  if (valid) blk_off[b] = (unsigned)(before + incl - n);
+  if (t == 0) {
+    group_sums[2 * blockIdx.x] = (unsigned)(lds8[0] + lds8[1] + lds8[2] + lds8[3]);
+    group_sums[2 * blockIdx.x + 1] = (unsigned)(lds8[4] + lds8[5] + lds8[6] + lds8[7]);
   }
 }
 
@@ -93,22 +102,23 @@ __global__ __launch_bounds__(256) void k_order_sizes(const int* __restrict__ cnt
                                                      const float* __restrict__ weight,
                                                      int direction, int nb,
                                                      unsigned* __restrict__ n_b,
-                                                     unsigned* __restrict__ group_sums) {
+                                                     unsigned* __restrict__ group_sums,
+                                                     unsigned* __restrict__ blk_off) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < nb;
   const int n = order_size_of(valid, b, valid ? weight[b] : 0.0f, cnt, next_cand, direction, n_b);
-  order_group_sums(n, group_sums);
+  order_group_sums(valid, b, n, group_sums, blk_off);
 }
 
 // Sixteen lanes per block (a block has a few dozen entries at most; a whole wavefront per block
 // left most of its lanes idle and was bound by the number of wavefronts): entry j of block b is
 // (b, (err[at+j] - max_err) / weight) for "up", (b, (max_err - err[at-1-j]) / weight) for "down"
 // (float arithmetic, processor.cc:649-657).  err has a fixed stride of 192 per block
-// (k_block_search's layout).  The workgroup's 16 blocks lie in one group: their offsets are the
-// sums of the groups before + the n_b of the group's blocks before them.  Workgroup 0 also writes
-// the order's size (*total) and blocks_to_change (counters[0]).  counters[1] += number of
-// vals < limit when count_below (the partition_point of processor.cc:690-696 counts exactly
-// these once the order is sorted).
+// (k_block_search's layout).  A block's offset = the sums of the groups before its own (added up
+// by every wavefront for itself: a few hundred numbers, no barrier) + its offset inside the group.
+// The first wavefront of the grid also writes the order's size (*total) and blocks_to_change
+// (counters[0]).  counters[1] += number of vals < limit when count_below (the partition_point of
+// processor.cc:690-696 counts exactly these once the order is sorted).
 constexpr int kFillLanes = 16;
 constexpr int kFillBlocks = 256 / kFillLanes;
 __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ err,
@@ -117,55 +127,50 @@ __global__ __launch_bounds__(256) void k_order_fill(const float* __restrict__ er
                                                     const float* __restrict__ max_err,
                                                     const unsigned* __restrict__ n_b,
                                                     const unsigned* __restrict__ group_sums,
+                                                    const unsigned* __restrict__ blk_off,
                                                     int direction, int nb, int count_below,
                                                     float limit, OrderEntry* __restrict__ out,
                                                     unsigned long long* __restrict__ total,
                                                     unsigned* __restrict__ counters) {
-  __shared__ int lds4[4];
-  __shared__ unsigned own[kFillBlocks];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63;
   const int group = t / kFillLanes, sub = t % kFillLanes;
   const int b0 = blockIdx.x * kFillBlocks, b = b0 + group;
   const int g = b0 / kOrderGroup, ngroups = (nb + kOrderGroup - 1) / kOrderGroup;
-  if (blockIdx.x == 0) {   // (the whole workgroup)
+  if (blockIdx.x == 0 && t < 64) {   // (one wavefront)
     int all = 0, changed = 0;
-    for (int i = t; i < ngroups; i += 256) {
+    for (int i = lane; i < ngroups; i += 64) {
       all += (int)group_sums[2 * i];
       changed += (int)group_sums[2 * i + 1];
     }
-    all = wg_sum(all, lds4);
-    changed = wg_sum(changed, lds4);
-    if (t == 0) {
+    all = wave_sum(all);
+    changed = wave_sum(changed);
+    if (lane == 0) {
       *total = (unsigned long long)(unsigned)all;
       counters[0] = (unsigned)changed;
     }
   }
-  // Everything that does not depend on the offset is loaded before the workgroup's sum (whose
-  // barriers the compiler will not move loads across): the block's scalars and its first two
-  // rounds of entries -- the kernel is a chain of dependent trips to memory, not a stream.
+  // everything the block needs is asked for at once: its scalars, its offset, its first two
+  // rounds of entries, the sums of the groups before
   const bool valid = b < nb;
   int n = 0, at = 0;
+  unsigned inside = 0;
   float base = 0.0f, wb = 1.0f;
   if (valid) {
     n = (int)n_b[b];
     at = next_cand[b];
     base = max_err[b];
     wb = weight[b];
+    inside = blk_off[b];
   }
   const float* e = err + (size_t)(valid ? b : 0) * 192;
   auto entry = [&](int j) { return direction > 0 ? e[at + j] : e[at - 1 - j]; };
   float e0 = 0.0f, e1 = 0.0f;
   if (sub < n) e0 = entry(sub);
   if (sub + kFillLanes < n) e1 = entry(sub + kFillLanes);
-  // entries before the workgroup's first block: whole groups, then the blocks of its own group
   int part = 0;
-  for (int i = t; i < g; i += 256) part += (int)group_sums[2 * i];
-  if (g * kOrderGroup + t < b0) part += (int)n_b[g * kOrderGroup + t];
-  if (t < kFillBlocks) own[t] = b0 + t < nb ? n_b[b0 + t] : 0u;
-  const unsigned base_wg = (unsigned)wg_sum(part, lds4);   // (its barriers also publish own[])
+  for (int i = lane; i < g; i += 64) part += (int)group_sums[2 * i];
+  const unsigned long long o = (unsigned)wave_sum(part) + inside;
   if (n == 0) return;
-  unsigned long long o = base_wg;
-  for (int i = 0; i < group; ++i) o += own[i];
   unsigned below = 0;
   auto put = [&](int j, float ev) {
     OrderEntry v;
@@ -229,7 +234,8 @@ __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __r
                                                         const int* __restrict__ cnt,
                                                         const int* __restrict__ next_cand,
                                                         unsigned* __restrict__ n_b,
-                                                        unsigned* __restrict__ group_sums) {
+                                                        unsigned* __restrict__ group_sums,
+                                                        unsigned* __restrict__ blk_off) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < bw * bh;
   float w = 0.0f;
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __r
     }
     weight[b] = w;
   }
-  if (cnt) order_group_sums(order_size_of(valid, b, w, cnt, next_cand, direction, n_b), group_sums);
+  if (cnt) order_group_sums(valid, b, order_size_of(valid, b, w, cnt, next_cand, direction, n_b), group_sums, blk_off);
 }
 
 // max_block_error[i] += block_weight[i] * val_threshold * direction  (processor.cc:754-756)
@@ -670,6 +676,7 @@ __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, s
 // of gz_order_partition (and of std::sort): tests/cpp/test_device_order.cc.
 constexpr int kDescMaxChunks = 4096;   // chunk tables of a workgroup: ranges up to 8.4 M entries
 constexpr int kDescMaxLevels = 12;
+constexpr int kDescCountGrid = 2048;   // workgroups of k_desc_count (eight fit on a CU)
 constexpr int kDescSwapGrid = 1024;    // workgroups of k_desc_swap (four fit on a CU: 33 KB of LDS)
 
 struct DescState {                 // the range before level l (level 0: derived, see desc_load)
@@ -746,7 +753,7 @@ GZ_DEVFN OrderEntry desc_read(const OrderEntry* a, unsigned long long p, unsigne
 }
 
 __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
-  __shared__ unsigned wsum[8];
+  __shared__ unsigned wsum[2][8];
   if (level == 0 && A.publish && blockIdx.x == 0 && threadIdx.x == 0) {
     DescState r;
     r.lo = *A.total;
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
   const unsigned long long first = s.lo + 1;
   const unsigned n = (unsigned)(s.hi - first);
   const unsigned nchunks = (n + kPartChunk - 1) / kPartChunk;
-  if (blockIdx.x >= nchunks) return;
+  if (blockIdx.x >= nchunks) return;   // (the grid: at most kDescCountGrid workgroups, looping over the chunks)
   // std::__move_median_to_first(lo, lo + 1, mid, hi - 1)
   const unsigned long long x = s.lo + 1, y = s.lo + (s.hi - s.lo) / 2, z = s.hi - 1;
   const OrderEntry ex = A.a[x], ey = A.a[y], ez = A.a[z], e0 = A.a[s.lo];
@@ -789,7 +796,9 @@ __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
   // A wavefront takes kPartItems rows of 64 consecutive entries (512 bytes per load instruction);
   // the rank of a stopper inside the chunk comes from the rows' lane masks.
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const unsigned wbase = blockIdx.x * (unsigned)kPartChunk + (unsigned)wave * (64u * kPartItems);
+  int par = 0;   // (two sets of the wavefront sums: a chunk's are read while the next one's are written)
+  for (unsigned chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x, par ^= 1) {
+  const unsigned wbase = chunk * (unsigned)kPartChunk + (unsigned)wave * (64u * kPartItems);
   unsigned long long bl[kPartItems], br[kPartItems];
   unsigned tl = 0, tr = 0;
 #pragma unroll
@@ -807,14 +816,14 @@ __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
     tr += (unsigned)GZ_POPC64(br[i]);
   }
   if (lane == 0) {
-    wsum[wave] = tl;
-    wsum[4 + wave] = tr;
+    wsum[par][wave] = tl;
+    wsum[par][4 + wave] = tr;
   }
   __syncthreads();
-  unsigned ol = blockIdx.x * (unsigned)kPartChunk, orr = ol;
+  unsigned ol = chunk * (unsigned)kPartChunk, orr = ol;
   for (int wv = 0; wv < wave; ++wv) {
-    ol += wsum[wv];
-    orr += wsum[4 + wv];
+    ol += wsum[par][wv];
+    orr += wsum[par][4 + wv];
   }
   const unsigned long long below = GZ_LANES_BELOW(lane);
 #pragma unroll
@@ -826,9 +835,10 @@ __global__ __launch_bounds__(256) void k_desc_count(DescArgs A, int level) {
     orr += (unsigned)GZ_POPC64(br[i]);
   }
   if (t == 0) {
-    A.cnt_l[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    A.cnt_r[blockIdx.x] = wsum[4] + wsum[5] + wsum[6] + wsum[7];
+    A.cnt_l[chunk] = wsum[par][0] + wsum[par][1] + wsum[par][2] + wsum[par][3];
+    A.cnt_r[chunk] = wsum[par][4] + wsum[par][5] + wsum[par][6] + wsum[par][7];
   }
+  }   // for chunk
 }
 
 // First index in tab[0 .. n] whose value exceeds k, minus one (tab ascending, tab[0] <= k < tab[n]).

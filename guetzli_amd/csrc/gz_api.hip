@@ -2012,7 +2012,7 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     if (!c->d_step_delta) HIPCHK(c, pool_malloc((void**)&c->d_step_delta, sizeof(unsigned) * 768 * kStepDeltaCopies));
     HIPCHK(c, hipMemsetAsync(c->d_step_delta, 0, sizeof(unsigned) * 768 * kStepDeltaCopies, c->stream));
     // (persistent workgroups: four per CU's worth at most, each wavefront taking several blocks)
-    GZ_LAUNCH(k_apply_steps_hist, dim3(std::min(gz_div_up(n, 4), 1024)), dim3(256), c->stream, (const int*)d_blocks,
+    GZ_LAUNCH(k_apply_steps_hist, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)d_blocks,
               (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
               (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
               (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta);

@@ -366,7 +366,8 @@ GZ_DEVFN void steps_count_symbols(const short* blk3, const int* __restrict__ jq,
 // blocks, 26 000 touched blocks of a 4K iteration meant 6500 workgroups x ~100 atomics on the same
 // 768 words: the launch spent its 81 us queueing at a dozen L2 lines.  The wavefronts of a
 // workgroup share nothing but that histogram, so they synchronise only around it.
-constexpr int kStepDeltaCopies = 16;
+constexpr int kStepDeltaCopies = 32;
+constexpr int kStepHistGrid = 2048;   // workgroups at most (1024 / 16 copies: 7 ms of a 4K encode waiting for the kernel, 2048 / 32: 6, 4096 / 64: 9.5)
 __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict__ blocks,
                                                           const int* __restrict__ counts, int n,
                                                           int direction, const int* __restrict__ next_cand,

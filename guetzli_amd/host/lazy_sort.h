@@ -33,7 +33,80 @@
 
 #include "parallel.h"
 
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+#define GZ_LAZY_SORT_AVX2 1
+#endif
+
 namespace guetzli_amd {
+
+// A comparator that orders 8-byte {int32, float} entries by the float (phase B's order) says so
+// with a member constant `enum { float_second_key = 1 };`: the partitions' pass over the elements
+// then runs eight entries at a time where the CPU has AVX2 (same lists, same arrangement).
+template <class L, class = void>
+struct HasFloatSecondKey { static constexpr bool value = false; };
+template <class L>
+struct HasFloatSecondKey<L, decltype((void)L::float_second_key)> { static constexpr bool value = L::float_second_key != 0; };
+
+#ifdef GZ_LAZY_SORT_AVX2
+namespace detail {
+struct CompressTable {
+  alignas(32) uint32_t perm[256][8];
+  CompressTable() {
+    for (int m = 0; m < 256; ++m) {
+      int k = 0;
+      for (int j = 0; j < 8; ++j)
+        if (m & (1 << j)) perm[m][k++] = (uint32_t)j;
+      for (; k < 8; ++k) perm[m][k] = 0;
+    }
+  }
+};
+inline const CompressTable& compress_table() {
+  static const CompressTable t;
+  return t;
+}
+inline bool cpu_has_avx2() {
+  static const bool have = __builtin_cpu_supports("avx2");
+  return have;
+}
+// Positions i (0 .. n-1) of the entries e with !(e.key < pv) -> lb, with !(pv < e.key) -> rb, each
+// in ascending order; entries are 8 bytes {int32, float key}.  lb / rb have room for n + 8.
+__attribute__((target("avx2"))) inline void StopperListsAvx2(const void* entries, size_t n, float pv,
+                                                              uint32_t* lb, size_t* nl_out,
+                                                              uint32_t* rb, size_t* nr_out) {
+  const CompressTable& t = compress_table();
+  const float* f = static_cast<const float*>(entries);
+  const __m256 pvv = _mm256_set1_ps(pv);
+  __m256i idx = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+  const __m256i eight = _mm256_set1_epi32(8);
+  size_t nl = 0, nr = 0, i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const __m256 v0 = _mm256_loadu_ps(f + 2 * i);       // i0 k0 i1 k1 | i2 k2 i3 k3
+    const __m256 v1 = _mm256_loadu_ps(f + 2 * i + 8);   // i4 k4 i5 k5 | i6 k6 i7 k7
+    const __m256 sh = _mm256_shuffle_ps(v0, v1, _MM_SHUFFLE(3, 1, 3, 1));   // k0 k1 k4 k5 | k2 k3 k6 k7
+    const __m256 keys = _mm256_castpd_ps(_mm256_permute4x64_pd(_mm256_castps_pd(sh), 0xD8));   // k0 .. k7
+    const int ml = _mm256_movemask_ps(_mm256_cmp_ps(keys, pvv, _CMP_NLT_UQ));   // !(key < pv)
+    const int mr = _mm256_movemask_ps(_mm256_cmp_ps(pvv, keys, _CMP_NLT_UQ));   // !(pv < key)
+    const __m256i pl = _mm256_load_si256(reinterpret_cast<const __m256i*>(t.perm[ml]));
+    const __m256i pr = _mm256_load_si256(reinterpret_cast<const __m256i*>(t.perm[mr]));
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(lb + nl), _mm256_permutevar8x32_epi32(idx, pl));
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(rb + nr), _mm256_permutevar8x32_epi32(idx, pr));
+    nl += (size_t)__builtin_popcount((unsigned)ml);
+    nr += (size_t)__builtin_popcount((unsigned)mr);
+    idx = _mm256_add_epi32(idx, eight);
+  }
+  for (; i < n; ++i) {
+    const float k = f[2 * i + 1];
+    lb[nl] = (uint32_t)i;
+    nl += !(k < pv);
+    rb[nr] = (uint32_t)i;
+    nr += !(pv < k);
+  }
+  *nl_out = nl;
+  *nr_out = nr;
+}
+}  // namespace detail
+#endif
 
 // Optional back end for an array that starts out on the device (include/guetzli_amd.h,
 // gz_order_*): ranges are partitioned there -- same arrangement and cut as Partition()
@@ -287,19 +360,29 @@ class LazySorted {
     const size_t n = last - first;
     if (n >= 512 && n < (size_t)UINT32_MAX) {
       static thread_local std::vector<uint32_t> lb, rb;
-      if (lb.size() < n) {
-        lb.resize(n);
-        rb.resize(n);
+      if (lb.size() < n + 8) {
+        lb.resize(n + 8);
+        rb.resize(n + 8);
       }
       const T pv = a_[pivot];
       size_t nl = 0, nr = 0;
-      for (size_t i = 0; i < n; ++i) {
-        const T& e = a_[first + i];
-        lb[nl] = (uint32_t)i;
-        nl += !less_(e, pv);
-        rb[nr] = (uint32_t)i;
-        nr += !less_(pv, e);
+      bool listed = false;
+#ifdef GZ_LAZY_SORT_AVX2
+      if constexpr (HasFloatSecondKey<Less>::value && sizeof(T) == 8) {
+        if (detail::cpu_has_avx2()) {
+          detail::StopperListsAvx2(a_ + first, n, pv.second, lb.data(), &nl, rb.data(), &nr);
+          listed = true;
+        }
       }
+#endif
+      if (!listed)
+        for (size_t i = 0; i < n; ++i) {
+          const T& e = a_[first + i];
+          lb[nl] = (uint32_t)i;
+          nl += !less_(e, pv);
+          rb[nr] = (uint32_t)i;
+          nr += !less_(pv, e);
+        }
       size_t m = 0;   // pairs (m-th left stopper, m-th right stopper from the right) that swap
       while (m < nl && m < nr && lb[m] < rb[nr - 1 - m]) {
         std::swap(a_[first + lb[m]], a_[first + rb[nr - 1 - m]]);

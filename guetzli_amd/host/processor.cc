@@ -790,6 +790,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       // large ranges run on the device (gz_order_partition); ranges that have become small
       // are fetched and finished here.
       struct KeyLess {
+        enum { float_second_key = 1 };   // (lazy_sort.h: the AVX2 pass over the keys)
         bool operator()(const std::pair<int, float>& a, const std::pair<int, float>& b) const {
           return a.second < b.second;
         }

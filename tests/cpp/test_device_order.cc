@@ -22,6 +22,9 @@
 
 typedef std::pair<int, float> E;
 struct Less {
+#ifndef GZ_TEST_PLAIN_LESS
+  enum { float_second_key = 1 };   // lazy_sort.h's AVX2 pass over the keys (-DGZ_TEST_PLAIN_LESS: the generic one)
+#endif
   bool operator()(const E& a, const E& b) const { return a.second < b.second; }
 };
 

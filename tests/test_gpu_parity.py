@@ -680,3 +680,30 @@ def test_contexts_on_a_foreign_current_device_are_safe(L):
         ctx.quantize(None)
         ctx.compare()
         assert hip.hipGetDevice(ctypes.byref(dev)) == 0 and dev.value == 0
+
+
+def test_large_image_beyond_the_device_descent_reference_hash():
+    """7680x4320 (four times BASELINE's largest size): an iteration's order has 12.5 M entries, more
+    than the device's quick-select descent takes by itself (8.4 M: its workgroups' tables), so the
+    first partitions of every iteration are driven from the host (gz_order_partition) before the
+    descent takes over -- the output must still be the unmodified reference's
+    (tests/golden/large/: 75 CPU-minutes of reference time)."""
+    import glob
+    import hashlib
+    import json
+    import os
+    import guetzli_amd
+    here = os.path.dirname(os.path.abspath(__file__))
+    cases = sorted(glob.glob(os.path.join(here, "golden", "large", "*.json")))
+    if not cases:
+        pytest.skip("no fixture under tests/golden/large")
+    for path in cases:
+        exp = json.load(open(path))
+        kind, w, h = exp["image"][:3]
+        assert kind == "tiled" and not exp["params"]
+        rgb = images.tiled(w, h)
+        assert hashlib.sha256(rgb.tobytes()).hexdigest() == exp["rgb_sha256"]
+        jpg, info = guetzli_amd.process(rgb, quality=exp["quality"])
+        assert len(jpg) == exp["bytes"], (path, len(jpg), exp["bytes"])
+        assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"], path
+        assert info["counters"]["phase B device partitions"] > 0   # (the host-driven ones)

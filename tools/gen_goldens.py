@@ -9,6 +9,9 @@ script for every family of fixtures under tests/golden/ (it replaces the four pe
   gen_goldens.py params [--all]        -> params_hashes.json       (guetzli::Params fields, grey, 4:2:0 input)
   gen_goldens.py params_r3 NAME...     -> params_r3/NAME.json      (4:2:0 / q84 / odd size at BASELINE sizes)
   gen_goldens.py config5 K...          -> config5/kK.json          (BASELINE config 5's batch members)
+  gen_goldens.py large [NAME...]       -> large/NAME.json          (beyond BASELINE's sizes: 7680x4320,
+                                          where an iteration's order exceeds what the device descends
+                                          by itself; 75 minutes of one core)
   gen_goldens.py degenerate [NAME...]  -> degenerate/NAME.json (+ NAME.png for PNG input)
                                           (round 4: flat, saturated, noise, slivers, RGBA / 16-bit /
                                           palette PNG through ReadPNG + Process)
@@ -173,6 +176,19 @@ def fam_config5(args):
         print(rec, flush=True)
 
 
+LARGE = {
+    "tiled_7680x4320_q95": (("tiled", 7680, 4320), 95.0, dict(), None),
+}
+
+
+def fam_large(args):
+    os.makedirs(os.path.join(GOLD, "large"), exist_ok=True)
+    for name in (args or sorted(LARGE)):
+        entry = params_entry(*LARGE[name])
+        json.dump(entry, open(os.path.join(GOLD, "large", name + ".json"), "w"), indent=1)
+        print(name, entry, flush=True)
+
+
 # Round 4 (VERDICT r3 "content diversity"): content at the edges of what the search handles.
 DEGENERATE = {
     # name: (image spec, quality, Params fields)
@@ -246,7 +262,7 @@ def fam_degenerate(args):
 
 if __name__ == "__main__":
     fams = {"whole": fam_whole, "jpegin": fam_jpegin, "params": fam_params, "params_r3": fam_params_r3,
-            "config5": fam_config5, "degenerate": fam_degenerate}
+            "config5": fam_config5, "degenerate": fam_degenerate, "large": fam_large}
     if len(sys.argv) < 2 or sys.argv[1] not in fams:
         sys.exit(__doc__)
     fams[sys.argv[1]](sys.argv[2:])

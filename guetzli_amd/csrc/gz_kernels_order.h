@@ -671,10 +671,6 @@ __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, s
 //                 swaps them if they have not crossed; the one thread that sees "pair k - 1
 //                 swapped, pair k not" knows the cut, decides which side holds `last` and
 //                 writes the next level's range.
-// Round 4: a wavefront takes ROWS of 64 consecutive entries (k_desc_count) / pairs (k_desc_swap) --
-// loads of 512 contiguous bytes, a stopper's rank from the rows' lane masks -- and both kernels run
-// on a bounded grid that loops over the chunks / groups of pairs (a workgroup per group of the
-// largest possible order queued the idle ones behind the working ones: DESIGN.md 3.6).
 // libstdc++ first moves the median to the front of the range (std::__move_median_to_first);
 // both kernels read the range as if that swap had happened (position `med` holds the old front
 // element) and k_desc_swap's first thread makes it real.  The arrangement and the cuts are those

@@ -2057,7 +2057,11 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
   const int limit = c->nblk * 64;
   for (int i = 0; i < n; ++i)
     if (pos[i] < 0 || pos[i] >= limit) return GZ_E_ARG;
-  if ((size_t)n > c->edit_cap) {
+  // A few hundred edits per iteration, between the host's last step and the chain's first kernel:
+  // the kernel reads them straight from the page-locked staging buffer (two copies of a few KB on
+  // the stream cost more than the bytes' trip over the bus).  Bulk edits go through device memory.
+  const bool direct = n <= 4096;
+  if (!direct && (size_t)n > c->edit_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));   // the pool hands memory on without waiting
     (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
     c->d_edit_pos = nullptr; c->d_edit_val = nullptr;
@@ -2065,18 +2069,21 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
     HIPCHK(c, pool_malloc((void**)&c->d_edit_pos, sizeof(int) * c->edit_cap));
     HIPCHK(c, pool_malloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
   }
-  {
-    void* h = nullptr;
-    TRY(stage_reserve(c, &c->stage_main, (sizeof(int) + sizeof(short)) * n, &h));
-    memcpy(h, pos, sizeof(int) * n);
-    memcpy((int*)h + n, val, sizeof(short) * n);
+  void* h = nullptr;
+  TRY(stage_reserve(c, &c->stage_main, (sizeof(int) + sizeof(short)) * n, &h));
+  memcpy(h, pos, sizeof(int) * n);
+  memcpy((int*)h + n, val, sizeof(short) * n);
+  const int* k_pos = (const int*)h;
+  const short* k_val = (const short*)((int*)h + n);
+  if (!direct) {
     HIPCHK(c, hipMemcpyAsync(c->d_edit_pos, h, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_edit_val, (int*)h + n, sizeof(short) * n, hipMemcpyHostToDevice, c->stream));
-    TRY(stage_sent(c, &c->stage_main, c->stream));
+    k_pos = c->d_edit_pos;
+    k_val = c->d_edit_val;
   }
-  GZ_LAUNCH(k_apply_coeff_edits, dim3(gz_div_up(n, 256)), dim3(256), c->stream,
-            (const int*)c->d_edit_pos, (const short*)c->d_edit_val, n, c->d_cand);
+  GZ_LAUNCH(k_apply_coeff_edits, dim3(gz_div_up(n, 256)), dim3(256), c->stream, k_pos, k_val, n, c->d_cand);
   KCHK(c);
+  TRY(stage_sent(c, &c->stage_main, c->stream));   // (the staging buffer is free again behind the kernel)
   return GZ_OK;   // the caller's buffers were copied to the staging buffer: no wait
 }
 
@@ -2231,12 +2238,15 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
   c->export_epoch = 0;
   if (publish && levels > 0 && c->h_order_mirror) {
     const unsigned long long max_entries = std::min<unsigned long long>(c->order_mirror_cap, 1ull << 19);
-    GZ_LAUNCH(k_desc_export, dim3(128), dim3(256), c->stream, A, levels, (OrderEntry*)c->h_order_mirror, max_entries);
+    // (its first workgroup also writes the descent's state into c->h_desc: no copy on the stream)
+    GZ_LAUNCH(k_desc_export, dim3(128), dim3(256), c->stream, A, levels, (OrderEntry*)c->h_order_mirror, max_entries,
+              (DescState*)c->h_desc);
     KCHK(c);
     c->export_epoch = c->desc_epoch;
+  } else {
+    HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 3),
+                             hipMemcpyDeviceToHost, c->stream));
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc_st, sizeof(DescState) * (kDescMaxLevels + 3),
-                           hipMemcpyDeviceToHost, c->stream));
   c->desc_levels = levels;
   c->desc_pending = true;
   if (A.publish) {

@@ -671,6 +671,10 @@ __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, s
 //                 swaps them if they have not crossed; the one thread that sees "pair k - 1
 //                 swapped, pair k not" knows the cut, decides which side holds `last` and
 //                 writes the next level's range.
+// Round 4: a wavefront takes ROWS of 64 consecutive entries (k_desc_count) / pairs (k_desc_swap) --
+// loads of 512 contiguous bytes, a stopper's rank from the rows' lane masks -- and both kernels run
+// on a bounded grid that loops over the chunks / groups of pairs (a workgroup per group of the
+// largest possible order queued the idle ones behind the working ones: DESIGN.md 3.6).
 // libstdc++ first moves the median to the front of the range (std::__move_median_to_first);
 // both kernels read the range as if that swap had happened (position `med` holds the old front
 // element) and k_desc_swap's first thread makes it real.  The arrangement and the cuts are those
@@ -1042,8 +1046,10 @@ __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
 // max_entries.  st[kDescMaxLevels + 2] tells the host: lo = entries exported (0: none), depth = 2.
 // One dispatch on the stream instead of a host round trip after it.
 __global__ __launch_bounds__(256) void k_desc_export(DescArgs A, int levels, OrderEntry* __restrict__ dst,
-                                                     unsigned long long max_entries) {
+                                                     unsigned long long max_entries,
+                                                     DescState* __restrict__ host_state) {
   __shared__ unsigned long long s_hi;
+  __shared__ DescState s_own;
   if (threadIdx.x == 0) {
     unsigned long long lo = 0, hi = 0;
     bool any = false;
@@ -1060,9 +1066,14 @@ __global__ __launch_bounds__(256) void k_desc_export(DescArgs A, int levels, Ord
       DescState r;
       r.lo = s_hi; r.hi = 0; r.last = 0; r.cut = 0; r.depth = 2; r.epoch = A.epoch;
       A.st[kDescMaxLevels + 2] = r;
+      s_own = r;
     }
   }
   __syncthreads();
+  // the descent's state (ranges, results slot, this kernel's own slot) for the host, straight into
+  // its page-locked copy: thread 0 of the first workgroup has just written the last of it
+  if (blockIdx.x == 0 && host_state && threadIdx.x < kDescMaxLevels + 3)
+    host_state[threadIdx.x] = threadIdx.x == kDescMaxLevels + 2 ? s_own : A.st[threadIdx.x];
   const unsigned long long n = s_hi;
   // 16 bytes (two entries) per thread and step
   const unsigned long long pairs = n >> 1;

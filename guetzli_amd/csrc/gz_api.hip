@@ -2200,7 +2200,11 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
   if (++c->desc_epoch == 0) c->desc_epoch = 1;
   int levels = std::max(0, std::min(max_levels, kDescMaxLevels));
   const size_t nchunks = std::max<size_t>(1, (n_bound + kPartChunk - 1) / kPartChunk);
-  if (nchunks > (size_t)kDescMaxChunks || nchunks > c->chunk_cap) levels = 0;   // the host drives these
+  bool big = nchunks > (size_t)kDescMaxChunks;   // (orders beyond 8.4 M entries: the instantiation with the larger tables)
+#ifdef GZ_EMU
+  if (getenv("GZ_EMU_DESC_BIG")) big = true;
+#endif
+  if (nchunks > (size_t)kDescMaxChunksBig || nchunks > c->chunk_cap) levels = 0;   // the host drives these
   DescArgs A;
   A.a = c->d_order;
   A.st = c->d_desc_st;
@@ -2209,6 +2213,7 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
   A.cnt_r = c->d_chunk + c->chunk_cap;
   A.lpos = c->d_pos_l;
   A.rpos = c->d_pos_r;
+  A.max_chunks = big ? kDescMaxChunksBig : kDescMaxChunks;
   A.epoch = c->desc_epoch;
   A.threshold = threshold < 16 ? 16 : threshold;
   A.derive = derive;
@@ -2230,7 +2235,8 @@ static int descend_enqueue(gz_ctx* c, int derive, uint64_t n0, uint64_t last0, f
   for (int l = 0; l < levels; ++l) {
     GZ_LAUNCH(k_desc_count, dim3((unsigned)count_groups), dim3(256), c->stream, A, l);
     KCHK(c);
-    GZ_LAUNCH(k_desc_swap, dim3((unsigned)swap_groups), dim3(256), c->stream, A, l);
+    if (big) GZ_LAUNCH(k_desc_swap<kDescMaxChunksBig>, dim3((unsigned)std::min(swap_groups, 256)), dim3(256), c->stream, A, l);
+    else GZ_LAUNCH(k_desc_swap<kDescMaxChunks>, dim3((unsigned)swap_groups), dim3(256), c->stream, A, l);
     KCHK(c);
   }
   // gz_order_build_auto_descend_begin: the prefix the driver fetches next goes to its host mirror

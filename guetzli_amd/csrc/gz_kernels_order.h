@@ -679,7 +679,8 @@ __global__ __launch_bounds__(256) void k_part_swap(OrderEntry* __restrict__ a, s
 // both kernels read the range as if that swap had happened (position `med` holds the old front
 // element) and k_desc_swap's first thread makes it real.  The arrangement and the cuts are those
 // of gz_order_partition (and of std::sort): tests/cpp/test_device_order.cc.
-constexpr int kDescMaxChunks = 4096;   // chunk tables of a workgroup: ranges up to 8.4 M entries
+constexpr int kDescMaxChunks = 4096;      // chunk tables of a workgroup: ranges up to 8.4 M entries (33 KB of LDS)
+constexpr int kDescMaxChunksBig = 16384;  // the instantiation for larger orders: up to 33.5 M entries (131 KB: one workgroup per CU)
 constexpr int kDescMaxLevels = 12;
 constexpr int kDescCountGrid = 2048;   // workgroups of k_desc_count (eight fit on a CU)
 constexpr int kDescSwapGrid = 1024;    // workgroups of k_desc_swap (four fit on a CU: 33 KB of LDS)
@@ -703,6 +704,7 @@ struct DescArgs {
   unsigned* cnt_r;
   unsigned* lpos;                  // [chunks * kPartChunk]: positions relative to lo + 1
   unsigned* rpos;
+  unsigned max_chunks;             // of the k_desc_swap instantiation that is launched (its tables)
   unsigned epoch;
   unsigned long long threshold;    // ranges up to this size are left to the host
   int derive;                      // 0: n0 / last0; 1: from the order construction's results
@@ -749,7 +751,7 @@ GZ_DEVFN bool desc_load(const DescArgs& A, int level, DescState* s) {
   }
   const unsigned long long len = s->hi - s->lo;
   return len > A.threshold && len > 16 && s->depth > 0 &&
-         len - 1 <= (unsigned long long)kDescMaxChunks * kPartChunk;
+         len - 1 <= (unsigned long long)A.max_chunks * kPartChunk;
 }
 
 GZ_DEVFN OrderEntry desc_read(const OrderEntry* a, unsigned long long p, unsigned long long med,
@@ -856,9 +858,10 @@ GZ_DEVFN unsigned desc_chunk_of(const unsigned* tab, unsigned n, unsigned k) {
   return lo;
 }
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void k_desc_swap(DescArgs A, int level) {
-  __shared__ unsigned PL[kDescMaxChunks + 1];   // left stoppers in the chunks before c
-  __shared__ unsigned RR[kDescMaxChunks + 1];   // right stoppers in the chunks after nchunks-1-i
+  __shared__ unsigned PL[MAXC + 1];   // left stoppers in the chunks before c
+  __shared__ unsigned RR[MAXC + 1];   // right stoppers in the chunks after nchunks-1-i
   __shared__ unsigned lds[256];
   DescState s;
   if (!desc_load(A, level, &s)) return;

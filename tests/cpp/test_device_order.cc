@@ -142,7 +142,8 @@ int main(int argc, char** argv) {
   int fails = 0;
   const size_t sizes[] = {4, 5, 17, 18, 33, 100, 257, 1000, 2047, 2048, 2049, 4097, 20000,
                           32769 /* 16 chunks: the table's entry 16 is the next thread's */, 65536, 300001, 2000003,
-                          5000011, 8388609 /* 4096 chunks: the descent's tables are full */};
+                          5000011, 8388609 /* 4096 chunks: the descent's tables are full */,
+                          12000017 /* beyond them: k_desc_swap's instantiation with the larger tables */};
   for (size_t thr : thresholds) {
     for (size_t n : sizes) {
       if (n > max_n || n > 4000 * thr) continue;   // keep the number of device calls bounded

@@ -53,8 +53,8 @@ def test_global_order(L, wh):
 
 def test_device_partition_is_std_sort(L, tmp_path):
     """gz_order_partition on the GPU, driven by the product's LazySorted, against std::sort
-    itself: every size / tie pattern up to 8.4M entries (the largest range the device descends by
-    itself), two device thresholds."""
+    itself: every size / tie pattern up to 12M entries (8.4M: the tables of the descent's usual
+    kernel are full; 12M: its instantiation with the larger tables), two device thresholds."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,7 +62,7 @@ def test_device_partition_is_std_sort(L, tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread",
                     os.path.join(root, "tests", "cpp", "test_device_order.cc"), "-o", exe, "-ldl"],
                    check=True)
-    out = subprocess.run([exe, L.path, "8388609", "16", "65536"], capture_output=True, text=True)
+    out = subprocess.run([exe, L.path, "12000017", "16", "65536"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device_order: ok" in out.stdout
 

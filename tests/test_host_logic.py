@@ -50,6 +50,11 @@ def test_device_partition_is_std_sort_in_emulation(tmp_path):
     out = subprocess.run([exe, build_emu.build(), "32769", "512"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device_order: ok" in out.stdout
+    # k_desc_swap's instantiation with the larger tables (on the GPU: orders beyond 8.4 M entries)
+    out = subprocess.run([exe, build_emu.build(), "20000", "512"], capture_output=True, text=True,
+                         env=dict(os.environ, GZ_EMU_DESC_BIG="1", GZ_TEST_ONLY_N="20000"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "device_order: ok" in out.stdout
     # k_desc_swap's loop over groups of pairs (on the GPU: orders beyond 2 M entries): a grid of 3
     out = subprocess.run([exe, build_emu.build(), "20000", "512"], capture_output=True, text=True,
                          env=dict(os.environ, GZ_EMU_DESC_SWAP_GRID="3", GZ_TEST_ONLY_N="20000"))

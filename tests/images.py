@@ -81,3 +81,60 @@ def noise(w, h, seed=1):
         i = (i * np.uint64(mul)) & np.uint64(0xFFFFFFFF)
     i ^= i >> np.uint64(16)
     return np.ascontiguousarray((i >> np.uint64(24)).astype(np.uint8).reshape(h, w, 3))
+
+
+# ---- photographs (round 5): tests/golden/photos/, licences in LICENSES.md there ----------------
+PHOTOS = os.path.join(ROOT, "tests", "golden", "photos")
+PHOTO_FILES = {"china": "china.jpg", "flower": "flower.jpg", "astronaut": "astronaut.png",
+               "coffee": "coffee.png", "chelsea": "chelsea.png", "gravel": "gravel.png",
+               "rocket": "rocket.jpg", "hubble": "hubble_deep_field.jpg", "retina": "retina.jpg"}
+
+
+def photo_bytes(name):
+    return open(os.path.join(PHOTOS, PHOTO_FILES[name]), "rb").read()
+
+
+def photo(name):
+    """uint8 [h][w][3] of a committed photograph (a JPEG file decoded by Pillow's libjpeg: the
+    fixtures record the SHA-256 of these pixels, a test skips on another decoder's rounding)."""
+    from PIL import Image
+    return np.ascontiguousarray(np.array(Image.open(os.path.join(PHOTOS, PHOTO_FILES[name])).convert("RGB")))
+
+
+def mosaic(w, h):
+    """A w x h image without any period: the nine photographs laid out in strips, left to right
+    and top to bottom, each strip as high as its first photograph, the sequence continuing where
+    the strip before stopped and a photograph cut where it meets the right or lower edge; every
+    other strip starts with a horizontally mirrored copy shifted by a third of its width.  No RNG.
+    (tests/images.tiled repeats a 444x258 tile 8.6 x 8.4 times at 3840x2160: this is the image
+    that shows whether the 4K numbers hold off periodic content.)"""
+    names = ["astronaut", "chelsea", "china", "coffee", "hubble", "gravel", "flower", "retina", "rocket"]
+    pics = [photo(n) for n in names]
+    out = np.zeros((h, w, 3), np.uint8)
+    k, y, strip = 0, 0, 0
+    while y < h:
+        sh = min(pics[k % len(pics)].shape[0], h - y)
+        x = 0
+        first = True
+        while x < w:
+            p = pics[k % len(pics)]
+            if strip % 2 == 1:
+                p = p[:, ::-1]
+            if first and strip % 2 == 1:
+                p = p[:, p.shape[1] // 3:]
+            first = False
+            ph = min(p.shape[0], sh)
+            pw = min(p.shape[1], w - x)
+            out[y:y + ph, x:x + pw] = p[:ph, :pw]
+            if ph < sh:      # a shorter photograph: continue it with its own mirrored rows
+                rest = sh - ph
+                fill = p[::-1][:rest, :pw]
+                out[y + ph:y + ph + fill.shape[0], x:x + pw] = fill
+                if fill.shape[0] < rest:
+                    out[y + ph + fill.shape[0]:y + sh, x:x + pw] = p[:rest - fill.shape[0], :pw]
+            x += pw
+            k += 1
+        y += sh
+        strip += 1
+        k += 2               # the next strip starts two photographs further on
+    return np.ascontiguousarray(out)

@@ -621,6 +621,59 @@ def test_degenerate_content_golden_hashes(name, exp):
     assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]
 
 
+def _photo_cases():
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "photos")
+    if not os.path.isdir(d):
+        return []
+    return [(f[:-5], json.load(open(os.path.join(d, f)))) for f in sorted(os.listdir(d)) if f.endswith(".json")]
+
+
+def photo_input(exp):
+    """What a tests/golden/photos case hands to Process: (rgb, None) or (None, jpeg bytes)."""
+    import hashlib
+    if "jpeg_input" in exp:
+        data = images.photo_bytes(exp["jpeg_input"].split(".")[0].replace("hubble_deep_field", "hubble"))
+        assert hashlib.sha256(data).hexdigest() == exp["input_sha256"]
+        return None, data
+    spec = exp["image"]
+    kind, w, h = spec[:3]
+    rgb = {"photo": lambda: images.photo(spec[3]), "mosaic": lambda: images.mosaic(w, h),
+           "bees": images.bees}[kind]()
+    assert rgb.shape == (h, w, 3)
+    if hashlib.sha256(rgb.tobytes()).hexdigest() != exp["rgb_sha256"]:
+        pytest.skip("this machine's JPEG decoder gives other pixels for the committed photograph")
+    return rgb, None
+
+
+@pytest.mark.parametrize("name,exp", _photo_cases())
+def test_photo_golden_hashes(name, exp, capfd):
+    """Round 5: real photographs -- skin, sky gradients, wood grain, fur,
+    gravel, a star field, a fundus image; as RGB at q95 / q84 / a fractional quality, as the
+    camera's own JPEG stream (4:4:4 and 4:2:0, with and without metadata, with try_420) -- bees.png
+    at q100 / q99 / q97.5 / q85.5 / q110 and the refused q83 (processor.cc:800-806), and a
+    3840x2160 / 1920x1080 mosaic of the photographs without any period, against hashes the
+    UNMODIFIED reference produced (tools/gen_goldens.py photos; licences in
+    tests/golden/photos/LICENSES.md)."""
+    import hashlib
+    import guetzli_amd
+    rgb, data = photo_input(exp)
+    params = dict(exp["params"])
+    host = guetzli_amd.load_host()
+    if exp.get("refused"):
+        with pytest.raises(RuntimeError):
+            host.process(rgb, quality=exp["quality"], **params)
+        assert "quality >= 84" in capfd.readouterr().err
+        return
+    if data is not None:
+        jpg, _ = host.process_jpeg(data, quality=exp["quality"], **params)
+    else:
+        jpg, _ = host.process(rgb, quality=exp["quality"], **params)
+    assert len(jpg) == exp["bytes"]
+    assert hashlib.sha256(jpg).hexdigest() == exp["jpeg_sha256"]
+
+
 def test_config5_all_64_reference_hashes():
     """BASELINE configs[4], the whole batch of an 8-GPU run on this one GPU: the 64 3840x2160
     images (the bench image circularly shifted by (37k, 53k)) through guetzli_amd.batch.run_config5,

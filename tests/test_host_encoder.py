@@ -303,3 +303,63 @@ def test_c_wrappers_do_not_let_exceptions_through(host_emu):
         chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
     with pytest.raises(ValueError):
         host_emu.read_png(bomb)
+
+
+# ---- round 5: photographs and qualities off the table's tested rows, in emulation -------------------
+PHOTO_CROPS = [
+    # photo, x0, y0, w, h, quality, Params
+    ("astronaut", 200, 60, 48, 40, 95.0, {}),            # skin, hair, a hard collar edge
+    ("china", 300, 40, 40, 32, 100.0, {}),               # sky gradient against a roof line; the table's last row
+    ("coffee", 250, 150, 40, 32, 97.5, {}),              # porcelain highlight; interpolated quality
+    ("gravel", 100, 100, 40, 32, 85.5, {}),              # grey texture (all-zero chroma); interpolated quality
+    ("chelsea", 180, 90, 48, 40, 90.0, dict(try_420=True)),   # fur
+    ("hubble", 400, 300, 40, 32, 99.0, {}),              # points of light on black
+    ("flower", 280, 150, 40, 32, 110.0, dict(force_420=True)),   # quality clamped to the table's end (quality.cc:79-80)
+]
+
+
+@needs_ref
+@pytest.mark.parametrize("case", PHOTO_CROPS, ids=[f"{c[0]}_q{c[5]:g}" for c in PHOTO_CROPS])
+def test_photograph_crops_match_reference_in_emulation(host_emu, case):
+    """Crops of the committed photographs (tests/golden/photos) through the whole driver with the
+    kernels in emulation: bytes and --verbose trace of the unmodified reference, at q100 (tiny
+    target: the search ends in 'up' iterations, processor.cc:690-698), fractional qualities (the
+    interpolation of quality.cc:78-85) and q110 (clamped)."""
+    name, x0, y0, w, h, quality, params = case
+    rgb = np.ascontiguousarray(images.photo(name)[y0:y0 + h, x0:x0 + w])
+    assert rgb.shape == (h, w, 3)
+    target = ref._butteraugli_score_for_quality(quality)
+    assert host_emu.butteraugli_score_for_quality(quality) == target
+    exp_jpg, exp_trace = ref.process_params(rgb, target, want_trace=True, **params)
+    got_jpg, info = host_emu.process(rgb, quality=quality, want_trace=True, **params)
+    exp_lines, got_lines = exp_trace.splitlines(), info["trace"].splitlines()
+    for i, (a, b) in enumerate(zip(exp_lines, got_lines)):
+        assert a == b, f"trace line {i}:\n ref: {a}\n got: {b}"
+    assert len(exp_lines) == len(got_lines)
+    assert got_jpg == exp_jpg
+    got2, _ = host_emu.process(rgb, quality=quality, **params)      # (without a trace: the size-bound path)
+    assert got2 == exp_jpg
+
+
+@needs_ref
+@pytest.mark.parametrize("quality,refused", [(83.0, True), (83.1, True), (70.0, True), (83.2, False)])
+def test_qualities_below_84_are_refused_like_the_reference(host_emu, quality, refused, capfd):
+    """processor.cc:800-806: butteraugli_target > 2.0 -> Process returns false after the message;
+    nothing is written.  The rule is on the TARGET, not on the quality: 83.2 interpolates
+    (quality.cc:78-85) to 1.9966 and is encoded, by the reference and here."""
+    rgb = images.crop(40, 32, 100, 60)
+    target = ref._butteraugli_score_for_quality(quality)
+    assert (target > 2.0) == refused
+    exp = ref.process_params(rgb, target)[0]
+    assert (exp is None) == refused
+    capfd.readouterr()
+    if not refused:
+        assert host_emu.process(rgb, quality=quality)[0] == exp
+        return
+    with pytest.raises(RuntimeError):
+        host_emu.process(rgb, quality=quality)
+    assert "Guetzli should be called with quality >= 84" in capfd.readouterr().err
+    data = _pil_jpeg(rgb, quality=97, subsampling=0)
+    assert ref.process_params(data, target)[0] is None
+    with pytest.raises(RuntimeError):
+        host_emu.process_jpeg(data, quality=quality)

@@ -15,6 +15,12 @@ script for every family of fixtures under tests/golden/ (it replaces the four pe
   gen_goldens.py degenerate [NAME...]  -> degenerate/NAME.json (+ NAME.png for PNG input)
                                           (round 4: flat, saturated, noise, slivers, RGBA / 16-bit /
                                           palette PNG through ReadPNG + Process)
+  gen_goldens.py photos [NAME...]      -> photos/NAME.json  (round 5: real photographs as RGB and
+                                          as camera-written JPEG input, qualities 100 / 99 / 97.5 /
+                                          85.5 and the refused 83, a 3840x2160 mosaic without a
+                                          period; one file per case, the cases run in parallel
+                                          processes: `gen_goldens.py photos --list | xargs -P 6 -n 1
+                                          python tools/gen_goldens.py photos`)
 """
 import hashlib, io, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +48,10 @@ def image(spec):
         return images.noise(w, h)
     if kind == "crop":
         return images.crop(w, h, spec[3], spec[4])
+    if kind == "photo":
+        return images.photo(spec[3])
+    if kind == "mosaic":
+        return images.mosaic(w, h)
     return images.tiled(w, h) if kind == "tiled" else images.synthetic(w, h)
 
 
@@ -260,8 +270,75 @@ def fam_degenerate(args):
         print(name, entry, flush=True)
 
 
+# Round 5: photographs and qualities off the four tested so far.
+# name: (image spec, quality, Params fields, JPEG-input file or None)
+PHOTOS = {
+    "china_q95": (("photo", 640, 427, "china"), 95.0, dict(), None),
+    "china_q84": (("photo", 640, 427, "china"), 84.0, dict(), None),
+    "flower_q95": (("photo", 640, 427, "flower"), 95.0, dict(), None),
+    "flower_q84": (("photo", 640, 427, "flower"), 84.0, dict(), None),
+    "astronaut_q95": (("photo", 512, 512, "astronaut"), 95.0, dict(), None),
+    "astronaut_q84": (("photo", 512, 512, "astronaut"), 84.0, dict(), None),
+    "coffee_q95": (("photo", 600, 400, "coffee"), 95.0, dict(), None),
+    "coffee_q84": (("photo", 600, 400, "coffee"), 84.0, dict(), None),
+    "gravel_q95": (("photo", 512, 512, "gravel"), 95.0, dict(), None),
+    "gravel_q84": (("photo", 512, 512, "gravel"), 84.0, dict(), None),
+    "chelsea_try420_q90": (("photo", 451, 300, "chelsea"), 90.0, dict(try_420=True), None),
+    "rocket_force420_q95": (("photo", 640, 427, "rocket"), 95.0, dict(force_420=True), None),
+    "hubble_q92.25": (("photo", 1000, 872, "hubble"), 92.25, dict(), None),
+    # the camera's / the editor's own JPEG stream as Process(jpeg_data): its tables, sampling, markers
+    "china_jpegin_q95": (None, 95.0, dict(), "china"),
+    "flower_jpegin_q95": (None, 95.0, dict(), "flower"),
+    "flower_jpegin_keepmeta_q88": (None, 88.0, dict(clear_metadata=False), "flower"),
+    "rocket_jpegin_try420_q90": (None, 90.0, dict(try_420=True), "rocket"),
+    "retina_jpegin420_q95": (None, 95.0, dict(), "retina"),
+    # qualities: the table's end (quality.cc:31-76), the interpolation (:78-85), the refusal
+    # (processor.cc:800-806: butteraugli_target > 2.0 -> Process returns false, nothing written)
+    "bees_q100": (("bees", 444, 258), 100.0, dict(), None),
+    "bees_q99": (("bees", 444, 258), 99.0, dict(), None),
+    "bees_q97.5": (("bees", 444, 258), 97.5, dict(), None),
+    "bees_q85.5": (("bees", 444, 258), 85.5, dict(), None),
+    "bees_q110": (("bees", 444, 258), 110.0, dict(), None),
+    "bees_q83_refused": (("bees", 444, 258), 83.0, dict(), None),
+    "astronaut_q100": (("photo", 512, 512, "astronaut"), 100.0, dict(), None),
+    # BASELINE configs[2]'s size on content without a period
+    "mosaic_3840x2160_q95": (("mosaic", 3840, 2160), 95.0, dict(), None),
+    "mosaic_1920x1080_q95": (("mosaic", 1920, 1080), 95.0, dict(), None),
+}
+
+
+def fam_photos(args):
+    out_dir = os.path.join(GOLD, "photos")
+    if args == ["--list"]:
+        print("\n".join(PHOTOS))
+        return
+    for name in (args or list(PHOTOS)):
+        spec, q, params, jpeg_in = PHOTOS[name]
+        t0 = time.time()
+        target = ref._butteraugli_score_for_quality(q)
+        entry = {"quality": q, "params": params, "butteraugli_target": target}
+        if jpeg_in is None:
+            rgb = image(spec)
+            entry["image"] = list(spec)
+            entry["rgb_sha256"] = sha(rgb.tobytes())
+            jpg, _ = ref.process_params(rgb, target, **params)
+        else:
+            data = images.photo_bytes(jpeg_in)
+            entry["jpeg_input"] = images.PHOTO_FILES[jpeg_in]
+            entry["input_sha256"] = sha(data)
+            jpg, _ = ref.process_params(data, target, **params)
+        if jpg is None:
+            entry["refused"] = True          # guetzli::Process returned false
+        else:
+            entry["bytes"] = len(jpg)
+            entry["jpeg_sha256"] = sha(jpg)
+        entry["reference_cpu_seconds"] = round(time.time() - t0, 1)
+        json.dump(entry, open(os.path.join(out_dir, name + ".json"), "w"), indent=1)
+        print(name, entry, flush=True)
+
+
 if __name__ == "__main__":
-    fams = {"whole": fam_whole, "jpegin": fam_jpegin, "params": fam_params, "params_r3": fam_params_r3,
+    fams = {"photos": fam_photos, "whole": fam_whole, "jpegin": fam_jpegin, "params": fam_params, "params_r3": fam_params_r3,
             "config5": fam_config5, "degenerate": fam_degenerate, "large": fam_large}
     if len(sys.argv) < 2 or sys.argv[1] not in fams:
         sys.exit(__doc__)

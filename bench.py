@@ -20,6 +20,10 @@ the boundary is inside the number.  Rank 0's output is checked against the refer
 JPEG (SHA-256 recorded from the unmodified reference) after the timed region.
 
 Also on the JSON line:
+  value_workload -- "3840x2160" (or "1920x1080" with --no-4k): which size `value` is.  `value_4k`
+                  and `value_1080p` (+ ms_per_step_4k / _1080p) are ALWAYS emitted under those names,
+                  whatever the headline, so that rounds compare like with like (until round 3
+                  `value` was the 1080p leg, since round 4 it is the 4K leg: ADVICE r4).
   value_1080p / ms_per_step_1080p / config_1080p / roofline_1080p -- BASELINE configs[1], one
                   1920x1080 image at --quality 95, timed EXACTLY like `value` (same --steps and
                   --warmup, same barrier / synchronise bracket, max over ranks), output hash
@@ -36,6 +40,15 @@ Also on the JSON line:
                   sources than this tree's (tools/gpu_pmc.sh regenerates it).  `valu` inside: the
                   chain's VALU issue time at the two rates an instruction can have (SQ_INSTS_VALU
                   of its kernels from the committed --pmc pass).
+  roofline.kernels -- per kernel of the chain: launches per Compare, average duration with the
+                  chain serialised on one stream (rocprofv3 --kernel-trace --stats), counter bytes
+                  (2 x FETCH_SIZE + WRITE_SIZE), TB/s, VALU wave-instructions; `block_passes`: SURVEY
+                  8(d)'s block-pass rooflines (k_reconstruct 18 B/px, k_quantize 12, k_encode_rgb 9).
+                  Assembled by tools/kernel_roofline.py from the committed profile set, under the same
+                  source-digest guard as `traffic`.
+  other_configs.mosaic_3840x2160_q95 -- the same size on content WITHOUT a period (a mosaic of the
+                  nine committed photographs, tests/images.mosaic): seconds, MPix/s, iterations,
+                  output checked against the reference's hash.  Beside `value`, never instead.
   scale_value  -- BASELINE config 5's work split on the GPUs this run has (the `config5_slice`
                   leg): 3840x2160 images, 8 per GPU (image k -> rank k mod N), 4 in flight per
                   GPU, records all-gathered over the process group; every output whose
@@ -96,6 +109,30 @@ def load_traffic():
         t["stale"] = t.get("csrc_sha256") != csrc_digest()
         return t
     return {"stale": True}
+
+
+def load_kernel_roofline():
+    """profiles/r05_compare_kernels.json (tools/kernel_roofline.py on the GPU box, from the same
+    session's rocprofv3 CSVs): the chain's kernels one by one and the block passes.  None when it
+    was assembled from other kernel sources than this tree's."""
+    from guetzli_amd.build import csrc_digest
+    for name in ("r05_compare_kernels.json",):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if t.get("csrc_sha256") != csrc_digest():
+            return {"stale": True, "source": "profiles/" + name, "head": t.get("head")}
+        t["source"] = "profiles/" + name
+        return t
+    return None
+
+
+def mosaic_golden():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "photos", "mosaic_3840x2160_q95.json")))
+    except Exception:
+        return None
 
 
 def cpu_baseline():
@@ -492,10 +529,13 @@ def main():
         dt4k, (jpg4k, info4k) = timed_steps(env, step4k, args.steps, args.warmup)
 
     # roofline legs: HIP events on the context's stream around whole Compare chains
-    ms, achieved = roofline_of(L, rgb, local_rank, 2 if emu else 50, 1 if emu else 5)
+    # (warm-up: the clocks need ~20 ms of sustained chains to settle -- the first 20 chains after an
+    # idle moment run 7 % slower than the 200 behind them, tools/chain_in_process.py,
+    # profiles/r05_chain_in_process.log; an encode runs 150 of them back to back)
+    ms, achieved = roofline_of(L, rgb, local_rank, 2 if emu else 200, 1 if emu else 60)
     ms_4k = achieved_4k = None
     if rank == 0:
-        ms_4k, achieved_4k = roofline_of(L, images.tiled(W4, H4), local_rank, 1 if emu else 20, 1 if emu else 3)
+        ms_4k, achieved_4k = roofline_of(L, images.tiled(W4, H4), local_rank, 1 if emu else 100, 1 if emu else 20)
     # batch leg (BASELINE config 5 in miniature, rank 0): independent images in flight on one
     # GPU at the same time, one host thread each; reported beside `value`, never instead of it
     batch = None
@@ -532,6 +572,26 @@ def main():
                                   "unit": "MPix/s",
                                   "iterations": i4["counters"].get("number of iterations"),
                                   "output_sha256_matches_reference": True}
+        # the headline's size on content without a period: beside `value`
+        gold = mosaic_golden()
+        if gold is not None:
+            mos = images.mosaic(W4, H4)
+            if hashlib.sha256(mos.tobytes()).hexdigest() == gold["rgb_sha256"]:
+                host.process(mos, quality=QUALITY, device=local_rank)
+                env.sync()
+                tm = time.perf_counter()
+                jm, im = host.process(mos, quality=QUALITY, device=local_rank)
+                tm = time.perf_counter() - tm
+                assert hashlib.sha256(jm).hexdigest() == gold["jpeg_sha256"], "mosaic output differs from the reference"
+                other["mosaic_3840x2160_q95"] = {
+                    "workload": "3840x2160 mosaic of the nine committed photographs (tests/images.mosaic: no "
+                                "period, no RNG), --quality 95, one untimed and one timed encode",
+                    "seconds": round(tm, 3), "value": round(W4 * H4 / 1e6 / tm, 3), "unit": "MPix/s",
+                    "iterations": im["counters"].get("number of iterations"), "output_bytes": len(jm),
+                    "output_sha256_matches_reference": True,
+                    "reference_cpu_seconds": gold.get("reference_cpu_seconds"),
+                    "host_timers_s": {k: round(v, 3) for k, v in im["timers"].items()
+                                      if k in ("total", "phase_b_host", "compare", "block_search", "select_quant_matrix")}}
     c5 = c5png = None
     if not args.no_4k and not args.no_config5:   # every rank takes part
         c5 = config5_leg(env, host, images, args.images_per_gpu, args.in_flight, size5, quality)
@@ -572,8 +632,12 @@ def main():
                     "traffic_stale": bool(traffic.get("stale")), "traffic_head": traffic.get("head"),
                     "traffic_source": traffic.get("source"), "ms_per_compare": round(ms_c, 4),
                     "algorithmic_bytes_per_compare": ALGO_BYTES_PER_PX * w * h,
-                    "valu": None if emu else valu_floor(key, ms_c)}
+                    "valu": None if emu else valu_floor(key, ms_c),
+                    "kernels": None if emu else (kernels or {}).get(key),
+                    "kernels_source": None if emu or not kernels else
+                                      {k: kernels.get(k) for k in ("source", "head", "stale") if k in kernels}}
 
+        kernels = None if emu else load_kernel_roofline()
         v_small, ms_small, cfg_small = leg(W, H, dt, jpg, info, "configs[1]")
         roof_small = roof(W, H, ms, achieved, "1080p")
         if dt4k is not None:
@@ -585,6 +649,7 @@ def main():
         out = {
             "metric": "MPix/s encoded at --quality 95",
             "value": head[0],
+            "value_workload": f"{head[4][0]}x{head[4][1]}",
             "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head[1],
@@ -607,11 +672,16 @@ def main():
                                      "SIMD = share of SIMD cycles issuing VALU)"},
             "host_timers_s": head[2]["host_timers_s"],
         }
+        # the same two legs under names that do not depend on which of them is the headline
+        out["value_1080p"] = v_small
+        out["ms_per_step_1080p"] = ms_small
         if dt4k is not None:
-            out["value_1080p"] = v_small
-            out["ms_per_step_1080p"] = ms_small
+            out["value_4k"] = head[0]
+            out["ms_per_step_4k"] = head[1]
             out["config_1080p"] = cfg_small
             out["roofline_1080p"] = roof_small
+            if kernels and not kernels.get("stale"):
+                out["block_passes"] = kernels.get("block_passes")
         if c5 is not None:
             other = dict(other or {})
             other["config5_slice"] = c5

@@ -26,7 +26,11 @@ ARCH = "gfx950"
 # (1080p) with it off (profiles/r02_packed_blur_and_malta_diff_experiments.log, section 8).  The
 # kernels that want packed arithmetic ask for it explicitly (gz_f2).  Same results either way.
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-vectorize-slp=false"]
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-vectorize-slp=false",
+         # the fused blurs' taps in vector registers (gz_common.h GZ_IN_VGPR: a scalar-register operand
+         # makes v_mul_f32 a 4-cycle instruction, tools/ubench/issue.hip): chain -0.7 % at 4K beside
+         # Malta, nothing serialised (profiles/r05_variants.log)
+         "-DGZ_TAPS_VGPR"]
 
 
 def _newer_than_lib():

@@ -142,6 +142,20 @@ GZ_DEVFN gz_f2 gz_f2_splat(float x) {
 #define GZ_MUL24(a, b) __mul24((a), (b))
 #endif
 
+// A value kept in a vector register.  Kernel arguments live in scalar registers, and on gfx950 a
+// v_mul_f32 / v_add_f32 with a scalar-register operand issues in 4 cycles where the all-VGPR form
+// takes 2.5 (tools/ubench/issue.hip, profiles/r05_issue_cost.log): a blur's taps, multiplied into
+// every sample, are worth their 2R + 1 vector registers.  No instruction beyond the one-off copy.
+#ifdef GZ_EMU
+#define GZ_IN_VGPR(x) (x)
+#else
+static __device__ __forceinline__ float gz_in_vgpr(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+#define GZ_IN_VGPR(x) gz_in_vgpr(x)
+#endif
+
 // Number of set bits of a wavefront mask (__ballot), and the mask of the lanes below this one.
 #ifdef GZ_EMU
 #define GZ_POPC64(x) __builtin_popcountll((unsigned long long)(x))

@@ -666,6 +666,13 @@ __global__ __launch_bounds__(256, 4) void k_blur2d(SrcPack<Src, NC> src, Post po
       if (c == k) s = src.s[k];
     if (c > 0) __syncthreads();   // the column pass of the previous plane is done with the tile
     if (interior) {
+#ifdef GZ_TAPS_VGPR
+      float kv[2 * R + 1];
+#pragma unroll
+      for (int j = 0; j <= 2 * R; ++j) kv[j] = GZ_IN_VGPR(taps.ks[j]);
+#else
+      const float* kv = taps.ks;
+#endif
       // ---- stage: aligned 16-byte loads, all of a thread's loads in flight before the
       // first LDS store (compile-time trip counts: the loads are issued back to back)
       constexpr int NV = IH * (IW / 4);            // 16-byte vectors in the tile
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(256, 4) void k_blur2d(SrcPack<Src, NC> src, Post po
           for (int i = 0; i < 4; ++i) {
             float sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j <= 2 * R; ++j) sum += win[OFF + i + j] * taps.ks[j];
+            for (int j = 0; j <= 2 * R; ++j) sum += win[OFF + i + j] * kv[j];
             o.v[i] = sum;
           }
           *reinterpret_cast<gz_f4*>(&tile[ry][hq]) = o;
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(256, 4) void k_blur2d(SrcPack<Src, NC> src, Post po
       for (int i = 0; i < VPTt; ++i) {
         float sum = 0.0f;
 #pragma unroll
-        for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * taps.ks[j];
+        for (int j = 0; j <= 2 * R; ++j) sum += win[i + j] * kv[j];
         if (ROLL) outv[c][tg * VPTt + i][tx] = sum; else acc[c][i] = sum;
       }
     } else {

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float seed
   float a[8], b = seed + 1.0f;
   double d[8], e = (double)seed + 1.0;
   int n[8], m = (int)seed + 3;
+  const unsigned long long mask = 0x5555aaaa3333ccccull ^ (unsigned long long)iters;
   for (int i = 0; i < 8; ++i) { a[i] = seed + threadIdx.x * 1e-3f + i; d[i] = a[i]; n[i] = threadIdx.x + i; }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -39,6 +40,34 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float seed
 #define PKA(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[i]) : "v"(e));
 #define MUL24(i) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(n[i]) : "v"(m));
 #define MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(n[i]) : "v"(m));
+// selects: vcc read without telling the compiler it is touched (no s_nop between the statements),
+// the VOP3 form with the mask in an SGPR pair, and the usual compare + select pair
+#define CNDV(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(n[i]) : "v"(m));
+#define CNDS(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(n[i]) : "v"(m), "s"(mask));
+#define CMPCND(i) asm volatile("v_cmp_lt_f32 vcc, %0, %2\n\tv_cndmask_b32 %1, %1, %3, vcc" : : "v"(a[i]), "v"(n[i]), "v"(b), "v"(m) : "vcc");
+#define ADDNOP(i) asm volatile("v_add_f32 %0, %0, %1\n\ts_nop 0" : "+v"(a[i]) : "v"(b));
+#define SUB32(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define FMAC(i) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a[i]) : "v"(b));
+#define MIN32(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define XOR(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(n[i]) : "v"(m));
+#define AND(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(n[i]) : "v"(m));
+#define BFI(i) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(n[i]) : "v"(m));
+#define SQRT(i) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
+#define DSCALE(i) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[i]) : "v"(b) : "vcc");
+#define DFMAS(i) asm volatile("v_div_fmas_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+#define DFIX(i) asm volatile("v_div_fixup_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+#define LSHLADD64(i) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(d[i]) : "v"(e));
+#define MAD64(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d[i]) : "v"(n[i]), "v"(m) : "vcc");
+#define CVTI(i) asm volatile("v_cvt_f32_i32 %0, %1" : "+v"(a[i]) : "v"(n[i]));
+#define RCP64(i) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[i]));
+#define PKM(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[i]) : "v"(e));
+#define PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d[i]) : "v"(e));
+#define ADDSG(i) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+#define MULSG(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+#define PKMS(i) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(d[i]) : "s"(mask));
+#define PKAS(i) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(d[i]) : "s"(mask));
+#define ADD3(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(n[i]) : "v"(m));
+#define ABSADD(i) asm volatile("v_add_f32_e64 %0, |%0|, %1" : "+v"(a[i]) : "v"(b));
       if (OP == 0) { REP8(F32) }
       if (OP == 1) { REP8(M32) }
       if (OP == 2) { REP8(FMA32) }
@@ -57,6 +86,32 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float seed
       if (OP == 15) { REP8(PKA) }
       if (OP == 20) { REP8(MUL24) }
       if (OP == 21) { REP8(MULLO) }
+      if (OP == 22) { REP8(CNDV) }
+      if (OP == 23) { REP8(CNDS) }
+      if (OP == 24) { REP8(CMPCND) }
+      if (OP == 25) { REP8(ADDNOP) }
+      if (OP == 26) { REP8(SUB32) }
+      if (OP == 27) { REP8(FMAC) }
+      if (OP == 28) { REP8(MIN32) }
+      if (OP == 29) { REP8(XOR) }
+      if (OP == 30) { REP8(AND) }
+      if (OP == 31) { REP8(BFI) }
+      if (OP == 32) { REP8(SQRT) }
+      if (OP == 33) { REP8(DSCALE) }
+      if (OP == 34) { REP8(DFMAS) }
+      if (OP == 35) { REP8(DFIX) }
+      if (OP == 36) { REP8(LSHLADD64) }
+      if (OP == 37) { REP8(MAD64) }
+      if (OP == 38) { REP8(CVTI) }
+      if (OP == 39) { REP8(RCP64) }
+      if (OP == 40) { REP8(PKM) }
+      if (OP == 41) { REP8(PKFMA) }
+      if (OP == 42) { REP8(ADDSG) }
+      if (OP == 43) { REP8(MULSG) }
+      if (OP == 44) { REP8(ADD3) }
+      if (OP == 45) { REP8(ABSADD) }
+      if (OP == 46) { REP8(PKMS) }
+      if (OP == 47) { REP8(PKAS) }
     }
   }
   float s = 0;
@@ -97,6 +152,43 @@ __global__ __launch_bounds__(256) void k_taps(float* out, int iters, float seed)
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// The same pattern with the LDS reads as single instructions (the compiler pairs neighbouring 8-byte
+// reads into ds_read2_b64, which moves 128 B/clk like ds_read2_b32; ds_read_b64 / ds_read_b128 move
+// 256): 16 taps per round at literal offsets, one s_waitcnt, W adds per tap.
+template <int W>
+__global__ __launch_bounds__(256) void k_taps_single(float* out, int iters, float seed) {
+  __shared__ __attribute__((aligned(16))) float t[40 * 72 * W];
+  for (int i = threadIdx.x; i < 40 * 72 * W; i += 256) t[i] = seed + i * 1e-6f;
+  __syncthreads();
+  float acc[4 * W];
+  for (int i = 0; i < 4 * W; ++i) acc[i] = 0.0f;
+  const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+  typedef float vt __attribute__((ext_vector_type(W)));
+  for (int it = 0; it < iters; ++it) {
+    const unsigned addr = (unsigned)(size_t)(t + ((row * 8 + (it & 7)) * 72) * W + lane * W) & 0xffffu;
+    vt v[16];
+#define RD(i, off)                                                                               \
+    if constexpr (W == 1) { float x; asm volatile("ds_read_b32 %0, %1 offset:" #off : "=v"(x) : "v"(addr)); v[i][0] = x; } \
+    if constexpr (W == 2) asm volatile("ds_read_b64 %0, %1 offset:2*" #off : "=v"(v[i]) : "v"(addr));          \
+    if constexpr (W == 4) asm volatile("ds_read_b128 %0, %1 offset:4*" #off : "=v"(v[i]) : "v"(addr));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      RD(0, 0) RD(1, 4) RD(2, 8) RD(3, 12) RD(4, 288) RD(5, 292) RD(6, 296) RD(7, 300)
+      RD(8, 576) RD(9, 580) RD(10, 584) RD(11, 588) RD(12, 864) RD(13, 868) RD(14, 872) RD(15, 876)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+          acc[(i & 3) * W + e] += v[i][e];
+        }
+    }
+  }
+  float s = 0;
+  for (int i = 0; i < 4 * W; ++i) s += acc[i];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <class F>
 static double time_ms(F f) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -111,7 +203,12 @@ int main(int argc, char** argv) {
   const char* names[] = {"v_add_f32", "v_mul_f32", "v_fma_f32", "v_max_f32", "v_add_u32", "v_lshlrev_b32",
                          "v_mov_b32", "v_cndmask_b32", "v_cmp_lt_f32", "v_rcp_f32", "v_cvt_f64_f32",
                          "v_cvt_f32_f64", "v_add_f64", "v_mul_f64", "v_fma_f64", "v_pk_add_f32",
-                         "", "", "", "", "v_mul_i32_i24", "v_mul_lo_u32"};
+                         "", "", "", "", "v_mul_i32_i24", "v_mul_lo_u32", "v_cndmask vcc", "v_cndmask sgpr",
+                         "v_cmp+v_cndmask", "v_add_f32+s_nop", "v_sub_f32", "v_fmac_f32", "v_min_f32", "v_xor_b32",
+                         "v_and_b32", "v_bfi_b32", "v_sqrt_f32", "v_div_scale_f32", "v_div_fmas_f32",
+                         "v_div_fixup_f32", "v_lshl_add_u64", "v_mad_u64_u32", "v_cvt_f32_i32", "v_rcp_f64",
+                         "v_pk_mul_f32", "v_pk_fma_f32", "v_add_f32 sgpr", "v_mul_f32 sgpr", "v_add3_u32",
+                         "v_add_f32 |abs|", "v_pk_mul_f32 sgpr", "v_pk_add_f32 sgpr"};
   printf("cycles per wave-instruction and SIMD at 2.4 GHz (256 CUs x 4 SIMDs); columns = wavefronts per SIMD\n");
   printf("%-16s %8s %8s %8s %8s\n", "instruction", "1", "2", "4", "8");
 #define ROW(OP)                                                                                       \
@@ -125,7 +222,9 @@ int main(int argc, char** argv) {
     }                                                                                                 \
     printf("\n");                                                                                     \
   }
-  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(20) ROW(21)
+  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(20) ROW(21) ROW(22) ROW(23) ROW(24) ROW(25) ROW(26) ROW(27) ROW(28) ROW(29) ROW(30) ROW(31) ROW(32)
+  ROW(33) ROW(34) ROW(35) ROW(36) ROW(37) ROW(38) ROW(39) ROW(40) ROW(41) ROW(42) ROW(43) ROW(44) ROW(45) ROW(46) ROW(47)
+  printf("(v_cmp+v_cndmask and v_add_f32+s_nop: per PAIR of instructions)\n");
   printf("\nMalta line-sum pattern: 64 LDS taps -> f32 adds; cycles per TAP-ADD (one add of one lane group) and SIMD\n");
   printf("%-16s %8s %8s %8s %8s\n", "LDS read width", "1", "2", "4", "8");
 #define TROW(W, label)                                                                                \
@@ -140,6 +239,19 @@ int main(int argc, char** argv) {
     }                                                                                                 \
     printf("\n");                                                                                     \
   }
-  TROW(1, "4 B (b32)") TROW(2, "8 B (b64)") TROW(4, "16 B (b128)")
+  TROW(1, "4 B (read2_b32)") TROW(2, "8 B (read2_b64)") TROW(4, "16 B (b128)")
+#define SROW(W, label)                                                                                \
+  {                                                                                                   \
+    printf("%-16s", label);                                                                           \
+    for (int wps : {1, 2, 4, 8}) {                                                                    \
+      if (W * 40 * 72 * 4 * wps > 160 * 1024) { printf(" %8s", "-"); continue; }                      \
+      const int wg = 256 * wps;                                                                       \
+      double ms = time_ms([&] { hipLaunchKernelGGL((k_taps_single<W>), dim3(wg), dim3(256), 0, 0, out, iters, 0.5f); }); \
+      double adds = (double)wg * 4 * iters * 64 * W;                                                  \
+      printf(" %8.2f", ms * 1e-3 * 2.4e9 * 1024 / adds);                                              \
+    }                                                                                                 \
+    printf("\n");                                                                                     \
+  }
+  SROW(1, "ds_read_b32") SROW(2, "ds_read_b64") SROW(4, "ds_read_b128")
   return 0;
 }

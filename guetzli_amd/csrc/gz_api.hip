@@ -140,7 +140,8 @@ MaltaNorm malta_norm(bool lf, double w_0gt1, double w_0lt1, double norm1) {
   n.norm2_0lt1 = w_pre0lt1 * norm1;
   n.norm1f = static_cast<float>(norm1);
   auto mid = [](float x) { return x >= 0x1p-40f && x <= 0x1p40f; };
-  n.fast_div = mid(n.norm2_0gt1) && mid(n.norm2_0lt1) ? 1 : 0;
+  // (norm1f: malta_diff then needs one comparison for its denominator, norm1f + absval >= norm1f)
+  n.fast_div = mid(n.norm2_0gt1) && mid(n.norm2_0lt1) && n.norm1f >= 0x1p-40f && n.norm1f <= 0x1p39f ? 1 : 0;
   return n;
 }
 

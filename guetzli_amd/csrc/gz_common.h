@@ -156,6 +156,20 @@ static __device__ __forceinline__ float gz_in_vgpr(float x) {
 #define GZ_IN_VGPR(x) gz_in_vgpr(x)
 #endif
 
+// "Does any active lane of this wavefront need the rare path?"  A wavefront-uniform condition: the
+// compiler branches around the path instead of computing it for every lane and selecting (what it
+// does with a per-lane condition and a handful of instructions: malta_diff's FP64 form of absval
+// cost six 4-cycle instructions per sample that way).  The emulation just evaluates the lane's own.
+// GZ_RARE_PATH() at the head of the guarded block: an empty volatile asm, which the compiler may not
+// execute speculatively -- without it the guarded instructions are hoisted out and selected again.
+#ifdef GZ_EMU
+#define GZ_ANY_LANE(c) (c)
+#define GZ_RARE_PATH() ((void)0)
+#else
+#define GZ_ANY_LANE(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#define GZ_RARE_PATH() asm volatile("; rare path")
+#endif
+
 // Number of set bits of a wavefront mask (__ballot), and the mask of the lanes below this one.
 #ifdef GZ_EMU
 #define GZ_POPC64(x) __builtin_popcountll((unsigned long long)(x))

@@ -205,6 +205,12 @@ __global__ __launch_bounds__(256, 8) void k_malta_rolled(MaltaArgs<NPASS> a0, Ma
   const bool vec = x0 >= 4 && x0 + MW + 4 <= w && (pitch & 3) == 0;
   for (int ps = 0; ps < NPASS; ++ps) {
     const MaltaPass P = a.pass[ps];
+    // the pass's three constants in vector registers: malta_diff adds / multiplies them into every
+    // staged sample, and a scalar-register operand makes those 4-cycle instructions (GZ_IN_VGPR)
+    MaltaNorm nm = P.nm;
+    nm.norm1f = GZ_IN_VGPR(nm.norm1f);
+    nm.norm2_0gt1 = GZ_IN_VGPR(nm.norm2_0gt1);
+    nm.norm2_0lt1 = GZ_IN_VGPR(nm.norm2_0lt1);
     if (ps > 0) __syncthreads();
     if (vec) {
       constexpr int NV = (MH + 8) * ((MW + 8) / 4);   // 16-byte vectors in the tile
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256, 8) void k_malta_rolled(MaltaArgs<NPASS> a0, Ma
             const size_t idx = (size_t)y * pitch + (x0 - 4 + 4 * q);
             const gz_f4 u0 = GZ_LDG4(P.p0, idx), u1 = GZ_LDG4(P.p1, idx);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], P.nm);
+            for (int e = 0; e < 4; ++e) v.v[e] = malta_diff(u0.v[e], u1.v[e], nm);
           }
           *reinterpret_cast<gz_f4*>(&tile[ry][4 * q]) = v;
         }
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, 8) void k_malta_rolled(MaltaArgs<NPASS> a0, Ma
         float v = 0.0f;
         if (x >= 0 && x < w && y >= 0 && y < h) {
           const size_t idx = (size_t)y * pitch + x;
-          v = malta_diff(GZ_LDG(P.p0, idx), GZ_LDG(P.p1, idx), P.nm);
+          v = malta_diff(GZ_LDG(P.p0, idx), GZ_LDG(P.p1, idx), nm);
         }
         tile[ry][rx] = v;
       }

@@ -243,7 +243,8 @@ GZ_DEVFN void div2_shared(float n0, float n1, float d, float* q0, float* q1) {
 //    MaltaNorm::fast_div).
 //  * the ladder: with bb = (a < 0 ? -b : b) its four cases are  bb < too_small -> scaler2 *
 //    (too_small - bb),  else bb > too_big -> scaler2 * (bb - too_big)  -- negation is exact,
-//    x - (-y) == x + y == y + x -- and d -/+ impact is d + (-/+ impact).
+//    x - (-y) == x + y == y + x -- and d -/+ impact is d + (-/+ impact); round 5: the two cases as
+//    one maximum (below), the FP64 form of absval behind a wavefront-uniform branch.
 GZ_DEVFN float malta_diff(float a, float b, const MaltaNorm nm) {
 #ifdef GZ_MALTA_DIFF_PLAIN
   return malta_diff_plain(a, b, nm);
@@ -251,11 +252,16 @@ GZ_DEVFN float malta_diff(float a, float b, const MaltaNorm nm) {
   const float fa = fabsf(a), fb = fabsf(b);
   const float s = fa + fb;
   float absval = 0.5f * s;
-  if (!(s >= 0x1p-100f && s <= 0x1p100f)) absval = (float)(0.5 * (double)fa + 0.5 * (double)fb);
+  const bool odd = !(s >= 0x1p-100f && s <= 0x1p100f);
+  if (GZ_ANY_LANE(odd)) {   // (0 + 0 included: flat regions take this path, whole wavefronts of them)
+    GZ_RARE_PATH();
+    if (odd) absval = (float)(0.5 * (double)fa + 0.5 * (double)fb);
+  }
   const float diff = a - b;
   const float den = nm.norm1f + absval;
   float scaler, scaler2;
-  if (nm.fast_div && den >= 0x1p-40f && den <= 0x1p40f) {
+  // (fast_div also says norm1f >= 2^-40, and absval >= 0: the sum is not below 2^-40; a NaN fails the test)
+  if (nm.fast_div && den <= 0x1p40f) {
     div2_shared(nm.norm2_0gt1, nm.norm2_0lt1, den, &scaler, &scaler2);
   } else {
     scaler = nm.norm2_0gt1 / den;
@@ -266,11 +272,14 @@ GZ_DEVFN float malta_diff(float a, float b, const MaltaNorm nm) {
   const double too_small = 0.55 * fabs0;
   const double too_big = 1.05 * fabs0;
   const double bb = (double)(a < 0 ? -b : b);
-  const bool lo = bb < too_small;
-  const bool hit = lo || bb > too_big;
-  const double u = lo ? too_small : bb;
-  const double v = lo ? bb : too_big;
-  double impact = (double)scaler2 * (u - v);
+  // too_small <= too_big (RN is monotone), so of  d1 = too_small - bb  and  d2 = bb - too_big  at most
+  // one is positive: bb < too_small  <=>  d1 > 0 (then d2 < 0), else bb > too_big  <=>  d2 > 0 (then
+  // d1 <= 0) -- the ladder's (u - v) is the larger of the two, and it hits iff that is positive.
+  // (NaNs: inf - inf on both sides or a NaN sample make both NaN; "> 0" is false, as the ladder's tests.)
+  const double d1 = too_small - bb, d2 = bb - too_big;
+  const double mx = __builtin_fmax(d1, d2);
+  const bool hit = mx > 0.0;
+  double impact = (double)scaler2 * mx;
   if (diff < 0) impact = -impact;
   const float r = (float)((double)d + impact);
   return hit ? r : d;

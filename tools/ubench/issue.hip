@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_taps(float* out, int iters, float seed)
 // The same pattern with the LDS reads as single instructions (the compiler pairs neighbouring 8-byte
 // reads into ds_read2_b64, which moves 128 B/clk like ds_read2_b32; ds_read_b64 / ds_read_b128 move
 // 256): 16 taps per round at literal offsets, one s_waitcnt, W adds per tap.
-template <int W>
+template <int W, int MIS = 0>   // MIS: floats by which every read is off its natural alignment
 __global__ __launch_bounds__(256) void k_taps_single(float* out, int iters, float seed) {
   __shared__ __attribute__((aligned(16))) float t[40 * 72 * W];
   for (int i = threadIdx.x; i < 40 * 72 * W; i += 256) t[i] = seed + i * 1e-6f;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_taps_single(float* out, int iters, floa
   const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
   typedef float vt __attribute__((ext_vector_type(W)));
   for (int it = 0; it < iters; ++it) {
-    const unsigned addr = (unsigned)(size_t)(t + ((row * 8 + (it & 7)) * 72) * W + lane * W) & 0xffffu;
+    const unsigned addr = (unsigned)(size_t)(t + ((row * 8 + (it & 7)) * 72) * W + lane * W + MIS) & 0xffffu;
     vt v[16];
 #define RD(i, off)                                                                               \
     if constexpr (W == 1) { float x; asm volatile("ds_read_b32 %0, %1 offset:" #off : "=v"(x) : "v"(addr)); v[i][0] = x; } \
@@ -253,5 +253,23 @@ int main(int argc, char** argv) {
     printf("\n");                                                                                     \
   }
   SROW(1, "ds_read_b32") SROW(2, "ds_read_b64") SROW(4, "ds_read_b128")
+  // the same reads one float off their natural alignment: speed, and whether the bytes are the right ones
+  {
+    float* h = (float*)malloc(256 * 4);
+    double ms_a = time_ms([&] { hipLaunchKernelGGL((k_taps_single<2, 0>), dim3(1024), dim3(256), 0, 0, out, iters, 0.5f); });
+    double ms_m = time_ms([&] { hipLaunchKernelGGL((k_taps_single<2, 1>), dim3(1024), dim3(256), 0, 0, out, iters, 0.5f); });
+    hipMemcpy(h, out, 256 * 4, hipMemcpyDeviceToHost);
+    float got = h[5];
+    // lane 5 of row 0 with MIS = 1 reads what lane 5 reads with MIS = 0 shifted by one float: compare
+    // against the 4-byte reads of the same addresses (k_taps_single<1> started one float further)
+    hipLaunchKernelGGL((k_taps_single<1, 0>), dim3(1), dim3(256), 0, 0, out, 1, 0.5f);
+    hipDeviceSynchronize();
+    printf("ds_read_b64 misaligned by 4 bytes: %.2f vs %.2f cycles per tap-add aligned (4 waves/SIMD); lane checksum %.6f\n",
+           ms_m * 1e-3 * 2.4e9 * 1024 / ((double)1024 * 4 * iters * 64 * 2), ms_a * 1e-3 * 2.4e9 * 1024 / ((double)1024 * 4 * iters * 64 * 2), got);
+    double ms4a = time_ms([&] { hipLaunchKernelGGL((k_taps_single<4, 0>), dim3(512), dim3(256), 0, 0, out, iters, 0.5f); });
+    double ms4m = time_ms([&] { hipLaunchKernelGGL((k_taps_single<4, 1>), dim3(512), dim3(256), 0, 0, out, iters, 0.5f); });
+    printf("ds_read_b128 misaligned by 4 bytes: %.2f vs %.2f (2 waves/SIMD)\n",
+           ms4m * 1e-3 * 2.4e9 * 1024 / ((double)512 * 4 * iters * 64 * 4), ms4a * 1e-3 * 2.4e9 * 1024 / ((double)512 * 4 * iters * 64 * 4));
+  }
   return 0;
 }

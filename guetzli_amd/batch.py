@@ -50,16 +50,40 @@ def encode_concurrent(images, process, workers=4):
         return list(ex.map(process, images))
 
 
+class BatchError(RuntimeError):
+    """One or more images of a batch failed; .failures = [{"index", "rank", "error"}, ...] as every
+    rank saw them after the gather."""
+
+    def __init__(self, failures):
+        self.failures = failures
+        super().__init__("batch: " + "; ".join(
+            f"image {f['index']} on rank {f['rank']}: {f['error']}" for f in failures))
+
+
 def encode_shard_concurrent(get_image, indices, process, workers, rank=0):
-    """This rank's images, `workers` of them in flight on its GPU; records as encode_batch's."""
+    """This rank's images, `workers` of them in flight on its GPU; records as encode_batch's.  An
+    image that fails does not take the others with it: its record is {"index", "rank", "error"} --
+    the caller gathers the records of all ranks first and raises afterwards (run_config5), so a
+    multi-GPU job says WHICH image failed WHERE instead of dying at a barrier."""
     def one(k):
         t0 = time.perf_counter()
-        jpg, _ = process(get_image(k))
+        try:
+            jpg, _ = process(get_image(k))
+        except Exception as e:   # (the C++ driver's failures arrive as RuntimeError)
+            return {"index": k, "rank": rank, "error": f"{type(e).__name__}: {e}",
+                    "seconds": time.perf_counter() - t0}
         return {"index": k, "bytes": len(jpg), "sha256": hashlib.sha256(jpg).hexdigest(),
                 "seconds": time.perf_counter() - t0, "rank": rank}
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
         return list(ex.map(one, indices))
+
+
+def raise_on_failures(records):
+    """After the gather: every rank sees the same records, so every rank raises (and exits non-zero)."""
+    failures = [{"index": r["index"], "rank": r["rank"], "error": r["error"]} for r in records if "error" in r]
+    if failures:
+        raise BatchError(failures)
 
 
 def run_config5(get_image, images_per_gpu, process, rank=0, world=1, dist=None, workers=4,
@@ -68,7 +92,8 @@ def run_config5(get_image, images_per_gpu, process, rank=0, world=1, dist=None, 
     one node"): image k -> rank k mod world (k < images_per_gpu * world), every rank keeps
     `workers` of its images in flight on its GPU, no data-path collective.  The process group
     serves the work split only: barrier, max-over-ranks of the elapsed time, all-gather of one
-    small record per image.  Returns (records of all images ordered by index, seconds)."""
+    small record per image.  Returns (records of all images ordered by index, seconds).  A failed
+    image raises BatchError on EVERY rank, after the gather, naming image, rank and error."""
     n = images_per_gpu * world
     if fence:
         fence()
@@ -78,7 +103,10 @@ def run_config5(get_image, images_per_gpu, process, rank=0, world=1, dist=None, 
         fence()
     seconds = max_over_ranks(time.perf_counter() - t0, dist, device)
     if dist is None or world == 1:
+        raise_on_failures(mine)
         return mine, seconds
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
-    return sorted((r for part in gathered for r in part), key=lambda r: r["index"]), seconds
+    records = sorted((r for part in gathered for r in part), key=lambda r: r["index"])
+    raise_on_failures(records)   # (behind the fence and the gather: no rank is left waiting in a collective)
+    return records, seconds

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <string>
+#include <sched.h>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -186,6 +187,13 @@ struct Psycho {   // device planes of one image's PsychoImage (butteraugli.h:418
 // gz_trim_pool() releases everything cached.  The emulation build allocates directly, so that
 // its poisoning of fresh memory keeps catching reads of never-written buffers.
 namespace {
+// page-locked AND mapped into the device's address space: k_apply_coeff_edits and k_desc_export access
+// staging buffers directly (the default flags give that on ROCm; said explicitly)
+#ifdef GZ_EMU
+constexpr unsigned kHostAllocFlags = 0;
+#else
+constexpr unsigned kHostAllocFlags = hipHostMallocMapped;
+#endif
 struct MemPool {
   std::mutex mu;
   std::unordered_map<void*, std::pair<int, size_t> > live;          // ptr -> (device, bytes)
@@ -212,7 +220,7 @@ void pool_release_idle(MemPool& p, bool host, int device /* -1: all */) {
 hipError_t pool_alloc(MemPool& p, bool host, void** out, size_t bytes) {
   if (bytes == 0) bytes = 1;
 #ifdef GZ_EMU
-  return host ? hipHostMalloc(out, bytes, 0) : hipMalloc(out, bytes);
+  return host ? hipHostMalloc(out, bytes, kHostAllocFlags) : hipMalloc(out, bytes);
 #else
   int device = 0;
   (void)hipGetDevice(&device);
@@ -225,11 +233,11 @@ hipError_t pool_alloc(MemPool& p, bool host, void** out, size_t bytes) {
     p.live[*out] = std::make_pair(device, bytes);
     return hipSuccess;
   }
-  hipError_t e = host ? hipHostMalloc(out, bytes, 0) : hipMalloc(out, bytes);
+  hipError_t e = host ? hipHostMalloc(out, bytes, kHostAllocFlags) : hipMalloc(out, bytes);
   if (e != hipSuccess) {   // make room: drop what is cached on this device and try once more
     (void)hipGetLastError();
     pool_release_idle(p, host, device);
-    e = host ? hipHostMalloc(out, bytes, 0) : hipMalloc(out, bytes);
+    e = host ? hipHostMalloc(out, bytes, kHostAllocFlags) : hipMalloc(out, bytes);
   }
   if (e == hipSuccess) p.live[*out] = std::make_pair(device, bytes);
   return e;
@@ -476,6 +484,7 @@ struct gz_ctx {
   int h_jq[192] = {0};       // the matrix d_jq holds
   unsigned* d_step_delta = nullptr; bool have_step_delta = false;   // AC statistics change of the last bulk steps
   HostStage stage_main, stage_entropy;
+  HostStage stage_edits;   // gz_apply_coeff_edits' own: its kernel reads the buffer, and the next order's upload (stage_main) must not wait for it
   // pinned landing area for the small results every call waits for (a copy into pageable
   // memory costs 27 us per round trip on this system, into pinned memory 15)
   void* h_res = nullptr; size_t h_res_cap = 0;
@@ -1067,7 +1076,7 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
   int per = 4;
   while (per > 1 && (long)c->bh * gz_div_up(strips, per) < 2000) per >>= 1;
 #ifdef GZ_EMU
-  if (const char* e = getenv("GZ_EMU_RECON_STRIPS")) per = atoi(e);   // (the strip loop on images the emulation can afford)
+  if (const char* e = getenv("GZ_EMU_RECON_STRIPS")) per = std::max(1, atoi(e));   // (the strip loop on images the emulation can afford)
 #endif
   GZ_LAUNCH(k_reconstruct, dim3(c->bh * gz_div_up(strips, per)), dim3(256), c->stream,
             d_coeffs, c->w, c->h, c->bw, c->nb, c->pitch, c->plane, c->d_srgb_lut, lin0,
@@ -1188,7 +1197,16 @@ void rank_blocks(const int16_t* coeffs, const int16_t* orig, int nb, int new_mod
 void rank_all(const int16_t* coeffs, const int16_t* orig, int nb, int new_model,
               std::vector<int32_t>* off, std::vector<uint8_t>* idx) {
   std::vector<uint8_t> cnt(nb), wide((size_t)nb * 192);
+  // threads from the cores this PROCESS may run on (a rank of a multi-GPU job is bound to its share
+  // of the host: bench.py Env.bind_cpus), not from the machine's
   unsigned nt = std::thread::hardware_concurrency();
+#if defined(__linux__)
+  {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) nt = (unsigned)CPU_COUNT(&set);
+  }
+#endif
   nt = std::max(1u, std::min(nt, 32u));
   if (nb < 4096) nt = 1;
   std::vector<std::thread> th;
@@ -1424,6 +1442,7 @@ void gz_destroy(gz_ctx* c) {
   pool_event_destroy(c->ev_candidate);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
+  stage_free(&c->stage_edits);
   if (c->h_res) (void)pool_host_free(c->h_res);
   pool_event_destroy(c->ev_join2);
   pool_event_destroy(c->ev_mask_pre);
@@ -2071,7 +2090,7 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
     HIPCHK(c, pool_malloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
   }
   void* h = nullptr;
-  TRY(stage_reserve(c, &c->stage_main, (sizeof(int) + sizeof(short)) * n, &h));
+  TRY(stage_reserve(c, &c->stage_edits, (sizeof(int) + sizeof(short)) * n, &h));
   memcpy(h, pos, sizeof(int) * n);
   memcpy((int*)h + n, val, sizeof(short) * n);
   const int* k_pos = (const int*)h;
@@ -2084,7 +2103,7 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
   }
   GZ_LAUNCH(k_apply_coeff_edits, dim3(gz_div_up(n, 256)), dim3(256), c->stream, k_pos, k_val, n, c->d_cand);
   KCHK(c);
-  TRY(stage_sent(c, &c->stage_main, c->stream));   // (the staging buffer is free again behind the kernel)
+  TRY(stage_sent(c, &c->stage_edits, c->stream));   // (the staging buffer is free again behind the kernel)
   return GZ_OK;   // the caller's buffers were copied to the staging buffer: no wait
 }
 

@@ -306,10 +306,14 @@ void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHis
 // (blk, q, +1), for a few coefficients' work instead of two passes over the block.
 void ReplaceCoeffACSymbols(const int16_t* blk, const int* q, int k, int newval, SymbolHistogram* h,
                            const uint8_t* depth, int64_t* raw_bits) {
-  static int zigzag_of[64] = {-1};
-  if (zigzag_of[0] < 0) {   // (idempotent: every thread writes the same values)
-    for (int z = 63; z >= 0; --z) zigzag_of[kNaturalOrder[z]] = z;
-  }
+  // natural index -> zig-zag position; built once, under C++11's thread-safe initialisation of a
+  // function-local static (several encodes run as threads of one process: batch.run_config5)
+  struct Inverse {
+    int at[64];
+    Inverse() { for (int z = 0; z < 64; ++z) at[kNaturalOrder[z]] = z; }
+  };
+  static const Inverse inverse;
+  const int* zigzag_of = inverse.at;
   const int oldval = blk[k];
   if (oldval == newval) return;
   const int z = zigzag_of[k];

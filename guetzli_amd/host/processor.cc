@@ -328,6 +328,7 @@ class Encoder {
   int in_comp_id_[3] = {0, 1, 2};
   QuantMatrix q_in_;             // the input's quantisation per component (processor.cc:84-97)
   bool verify_ = false;
+  int verify_level_ = 0;   // GZ_VERIFY_ENTROPY's value: 2 = check the size bound's own (late-scan) path
   bool mirror_valid_ = false;    // img_ mirrors the device image (phase B)          // GZ_VERIFY_ENTROPY=1: cross-check against the host writer
   double best_score_ = -1;
   double t_write_ = 0, t_compare_ = 0, t_quant_ = 0, t_blocksearch_ = 0, t_phaseb_ = 0,
@@ -1033,7 +1034,12 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       // far loses whatever it weighs -- 140 of the 149 candidates of a 4K encode at quality 95,
       // whose evaluation then has the device to itself (the coder's kernels took a sixth of the
       // summed kernel time, profiles/r03_bench_kernel_stats.csv).
-      const bool every_size = stats_->debug_output || stats_->debug_output_file || verify_;
+      // GZ_VERIFY_ENTROPY=2 checks the DEFAULT path: the bound decision is taken first and the
+      // candidate is coded regardless, late (behind the evaluation, as a winner is) -- the bound must
+      // not exceed the coded size, and a candidate the bound rejects must lose with its real size too
+      // (with =1 / --verbose every candidate takes the early-scan path instead).
+      const bool verify_late = verify_ && verify_level_ >= 2 && !stats_->debug_output && !stats_->debug_output_file;
+      const bool every_size = (stats_->debug_output || stats_->debug_output_file || verify_) && !verify_late;
       if (!PrepareHead(quant_, dc_histo, ac_histo)) return false;
       // the entropy coder goes to its own stream before anything else is enqueued: it runs beside
       // the evaluation, not behind the host work below
@@ -1062,9 +1068,18 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         if (!MaybeOutput(jpg_size)) return false;
       } else {
         if (!CompareCurrent()) return false;
-        if (best_score_ < 0 ||
-            ScoreJPEG(distance_, (int)SizeLowerBound(), params_.butteraugli_target) < best_score_) {
+        const bool may_win = best_score_ < 0 ||
+            ScoreJPEG(distance_, (int)SizeLowerBound(), params_.butteraugli_target) < best_score_;
+        if (may_win) {
           if (!ScanBegin() || !SerializeEnd(quant_, &jpg_size) || !MaybeOutput(jpg_size)) return false;
+        } else if (verify_late) {
+          const double best_before = best_score_;
+          if (!ScanBegin() || !SerializeEnd(quant_, &jpg_size)) return false;   // (checks bound <= size itself)
+          if (ScoreJPEG(distance_, (int)jpg_size, params_.butteraugli_target) < best_before) {
+            fprintf(stderr, "guetzli_amd: a candidate rejected on its size bound would have won\n");
+            return false;
+          }
+          ++n_scans_skipped_;
         } else {
           ++n_scans_skipped_;
         }
@@ -1083,6 +1098,7 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   const int w = w_, h = h_;
   // the original as the fallback output (processor.cc:826-846)
   verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
+  verify_level_ = verify_ ? std::max(1, atoi(getenv("GZ_VERIFY_ENTROPY"))) : 0;
   if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
   best_score_ = -1;
   QuantMatrix ones;

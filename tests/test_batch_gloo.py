@@ -68,3 +68,51 @@ def test_two_ranks_shard_a_batch(tmp_path):
     assert [r[:3] for r in single] == [r[:3] for r in double]
     assert [r[3] for r in double] == [0, 1, 0]      # image k -> rank k mod 2
     assert len({r[2] for r in double}) == 3         # three different images
+
+
+FAIL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "tests", "emu"))
+import torch.distributed as dist
+import build_emu, images
+from guetzli_amd import batch
+from guetzli_amd.encoder import HostLibrary
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+host = HostLibrary(build_emu.HOST_LIB)
+get = lambda k: images.shifted(images.crop(32, 32, 300, 150), k)
+def proc(rgb):
+    if proc.calls == 0 and rank == 1:      # rank 1's first image (index 1) fails inside the driver:
+        proc.calls += 1
+        return host.process(rgb, quality=70)   # quality < 84 is refused (processor.cc:800-806)
+    proc.calls += 1
+    return host.process(rgb, quality=84)
+proc.calls = 0
+try:
+    batch.run_config5(get, 2, proc, rank, world, dist, workers=1, fence=dist.barrier)
+    print("RANK", rank, "NO ERROR")
+except batch.BatchError as e:
+    print("RANK", rank, "FAILURES", [(f["index"], f["rank"]) for f in e.failures], flush=True)
+    dist.barrier(); dist.destroy_process_group()
+    sys.exit(3)
+"""
+
+
+def test_a_failed_image_is_reported_by_every_rank_after_the_gather(tmp_path):
+    """one image fails on rank 1 (the driver refuses it).  Rank 1 still encodes
+    its other image, both ranks pass the fence and the all-gather, BOTH raise BatchError naming image
+    1 on rank 1, and the job exits non-zero -- nobody hangs in a collective, nobody exits silently."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    build_emu.build_host()
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29535")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29535", str(script)], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0, out.stdout + out.stderr
+    text = out.stdout + out.stderr
+    assert "RANK 0 FAILURES [(1, 1)]" in text, text[-3000:]
+    assert "RANK 1 FAILURES [(1, 1)]" in text, text[-3000:]
+    assert "NO ERROR" not in text

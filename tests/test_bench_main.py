@@ -53,6 +53,21 @@ def test_bench_main_two_ranks_gloo():
     assert "cpu_baseline" not in r and "batch_one_gpu" not in r   # N = 1 only
 
 
+def test_bench_main_eight_ranks_gloo():
+    """The run the driver launches first on an 8-GPU node (`--gpus 8` under torch.distributed.run
+    with 8 processes), as a dry run on this container's cores: 8 gloo ranks, one emulated image
+    each, the config-5 leg with its all-gather over 8 ranks."""
+    r = _run(8, ["--images-per-gpu", "1", "--batch-images", "0"])
+    for k in CONTRACT:
+        assert k in r, k
+    assert r["n_gpus"] == 8 and r["scaling"] == "weak"
+    assert r["value"] > 0 and r["value_4k"] == r["value"] and r["value_1080p"] > 0 and r["value_workload"]
+    c5 = r["other_configs"]["config5_slice"]
+    assert c5["images"] == 8 and c5["n_ranks_seen"] == 8 and c5["ranks_in_records"] == list(range(8))
+    assert c5["images_per_rank"] == {str(k): 1 for k in range(8)} and c5["distinct_outputs"] == 8
+    assert r["scale_value"] == c5["value"]
+
+
 def test_bench_config5_only_two_ranks_gloo():
     r = _run(2, ["--config5", "--images-per-gpu", "1"])
     assert r["n_gpus"] == 2 and r["config"]["images"] == 2 and r["value"] == r["config"]["value"]

@@ -388,14 +388,20 @@ def test_whole_encode_4k_bit_identical_jpeg(q, size):
     assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(3840, 2160, q)]
 
 
-def test_whole_encode_with_self_checks_1080p(monkeypatch):
+@pytest.mark.parametrize("level", ["1", "2"])
+def test_whole_encode_with_self_checks_1080p(monkeypatch, level):
     """GZ_VERIFY_ENTROPY=1: every candidate's device scan equals the host writer's bytes and
-    the host mirror of the image equals the device image after every iteration."""
+    the host mirror of the image equals the device image after every iteration.  =2: the same
+    checks on the DEFAULT path's order of calls -- the size-bound decision first, the scan late,
+    behind the evaluation and the next order's construction; a candidate the bound rejects is coded
+    anyway and must lose with its real size."""
     import hashlib
     import guetzli_amd
-    monkeypatch.setenv("GZ_VERIFY_ENTROPY", "1")
+    monkeypatch.setenv("GZ_VERIFY_ENTROPY", level)
     jpg, info = guetzli_amd.process(images.tiled(1920, 1080), quality=95)
     assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(1920, 1080, 95)]
+    if level == "2":
+        assert info["counters"]["candidates rejected on their size bound"] > 100
 
 
 def test_concurrent_encodes_on_one_gpu_are_deterministic():

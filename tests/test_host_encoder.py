@@ -363,3 +363,16 @@ def test_qualities_below_84_are_refused_like_the_reference(host_emu, quality, re
     assert ref.process_params(data, target)[0] is None
     with pytest.raises(RuntimeError):
         host_emu.process_jpeg(data, quality=quality)
+
+
+@needs_ref
+def test_size_bound_path_with_its_self_checks_in_emulation(host_emu, monkeypatch):
+    """GZ_VERIFY_ENTROPY=2: the default (no trace) order of calls -- bound decision, then the scan
+    behind the evaluation -- with every candidate coded and checked: bits == the statistics' count,
+    bound <= size, device scan == host writer, and no candidate the bound rejects would have won."""
+    monkeypatch.setenv("GZ_VERIFY_ENTROPY", "2")
+    rgb = images.crop(48, 40, 300, 150)
+    exp_jpg, _ = ref.process(rgb, ref._butteraugli_score_for_quality(95.0))
+    got, info = host_emu.process(rgb, quality=95)
+    assert got == exp_jpg
+    assert info["counters"]["candidates rejected on their size bound"] > 0

@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float seed
 #define MULSG(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
 #define PKMS(i) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(d[i]) : "s"(mask));
 #define PKAS(i) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(d[i]) : "s"(mask));
+#define MULLIT(i) asm volatile("v_mul_f32 %0, 0x3e824ab0, %0" : "+v"(a[i]));
+#define ADDINL(i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(a[i]));
+#define MUL64LIT(i) asm volatile("v_mul_f64 %0, %0, 0.5" : "+v"(d[i]));
 #define ADD3(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(n[i]) : "v"(m));
 #define ABSADD(i) asm volatile("v_add_f32_e64 %0, |%0|, %1" : "+v"(a[i]) : "v"(b));
       if (OP == 0) { REP8(F32) }
@@ -112,6 +115,9 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float seed
       if (OP == 45) { REP8(ABSADD) }
       if (OP == 46) { REP8(PKMS) }
       if (OP == 47) { REP8(PKAS) }
+      if (OP == 48) { REP8(MULLIT) }
+      if (OP == 49) { REP8(ADDINL) }
+      if (OP == 50) { REP8(MUL64LIT) }
     }
   }
   float s = 0;
@@ -208,7 +214,8 @@ int main(int argc, char** argv) {
                          "v_and_b32", "v_bfi_b32", "v_sqrt_f32", "v_div_scale_f32", "v_div_fmas_f32",
                          "v_div_fixup_f32", "v_lshl_add_u64", "v_mad_u64_u32", "v_cvt_f32_i32", "v_rcp_f64",
                          "v_pk_mul_f32", "v_pk_fma_f32", "v_add_f32 sgpr", "v_mul_f32 sgpr", "v_add3_u32",
-                         "v_add_f32 |abs|", "v_pk_mul_f32 sgpr", "v_pk_add_f32 sgpr"};
+                         "v_add_f32 |abs|", "v_pk_mul_f32 sgpr", "v_pk_add_f32 sgpr",
+                         "v_mul_f32 literal", "v_add_f32 inline 1.0", "v_mul_f64 inline 0.5"};
   printf("cycles per wave-instruction and SIMD at 2.4 GHz (256 CUs x 4 SIMDs); columns = wavefronts per SIMD\n");
   printf("%-16s %8s %8s %8s %8s\n", "instruction", "1", "2", "4", "8");
 #define ROW(OP)                                                                                       \
@@ -223,7 +230,7 @@ int main(int argc, char** argv) {
     printf("\n");                                                                                     \
   }
   ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(20) ROW(21) ROW(22) ROW(23) ROW(24) ROW(25) ROW(26) ROW(27) ROW(28) ROW(29) ROW(30) ROW(31) ROW(32)
-  ROW(33) ROW(34) ROW(35) ROW(36) ROW(37) ROW(38) ROW(39) ROW(40) ROW(41) ROW(42) ROW(43) ROW(44) ROW(45) ROW(46) ROW(47)
+  ROW(33) ROW(34) ROW(35) ROW(36) ROW(37) ROW(38) ROW(39) ROW(40) ROW(41) ROW(42) ROW(43) ROW(44) ROW(45) ROW(46) ROW(47) ROW(48) ROW(49) ROW(50)
   printf("(v_cmp+v_cndmask and v_add_f32+s_nop: per PAIR of instructions)\n");
   printf("\nMalta line-sum pattern: 64 LDS taps -> f32 adds; cycles per TAP-ADD (one add of one lane group) and SIMD\n");
   printf("%-16s %8s %8s %8s %8s\n", "LDS read width", "1", "2", "4", "8");

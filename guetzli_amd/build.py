@@ -17,7 +17,10 @@ LIB = os.path.join(HERE, "libguetzli_amd.so")
 SOURCES = ["gz_api.hip"]
 HEADERS = ["gz_common.h", "gz_math.h", "gz_kernels_block.h", "gz_kernels_blur.h",
            "gz_kernels_diff.h", "gz_kernels_search.h", "gz_kernels_entropy.h", "gz_kernels_dctd.h", "gz_kernels_downsample.h",
-           "gz_kernels_order.h", "gz_kernels_rank.h", "gz_host_weights.h", "tables_generated.h", "order_tables_generated.h"]
+           "gz_kernels_order.h", "gz_kernels_rank.h", "gz_host_weights.h", "tables_generated.h", "order_tables_generated.h",
+           # gz_api.hip by concern (one translation unit)
+           "api/plans.h", "api/context.h", "api/chain.h", "api/entry_context.h", "api/entry_compare.h",
+           "api/entry_phaseb.h", "api/entry_entropy.h", "api/entry_frame.h", "api/entry_search.h", "api/entry_probes.h"]
 ARCH = "gfx950"
 # -vectorize-slp=false: left to itself the compiler packs adjacent scalar f32 adds / multiplies
 # into v_pk_*_f32 pairs; those issue at the same lane rate as the scalar forms on gfx950

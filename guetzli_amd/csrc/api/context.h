@@ -1,0 +1,402 @@
+// The caching allocator and the stream / event pools, pinned staging, gz_ctx (one image on one GPU), DeviceScope, the error macros, the plane arena.
+// (part of the one translation unit gz_api.hip, which includes these files in order; split by
+// concern in round 5 -- no declaration here is visible outside libguetzli_amd.so but the C ABI)
+#pragma once
+
+
+// ------------------------------------------------------------ caching allocator ------
+// One image = one context = ~45 device allocations (0.5 GB at 1080p, 2 GB at 4K) and three
+// pinned host buffers; hipMalloc / hipFree (which also synchronises the device) of those cost
+// ~10 ms per image.  Freed blocks are kept in exact-size free lists per device and handed to
+// the next context that asks for the same size -- a batch of same-sized images allocates once.
+// GZ_POOL_MB bounds the cached device bytes per device (default 16384; 0 = no caching);
+// gz_trim_pool() releases everything cached.  The emulation build allocates directly, so that
+// its poisoning of fresh memory keeps catching reads of never-written buffers.
+namespace {
+// page-locked AND mapped into the device's address space: k_apply_coeff_edits and k_desc_export access
+// staging buffers directly (the default flags give that on ROCm; said explicitly)
+#ifdef GZ_EMU
+constexpr unsigned kHostAllocFlags = 0;
+#else
+constexpr unsigned kHostAllocFlags = hipHostMallocMapped;
+#endif
+struct MemPool {
+  std::mutex mu;
+  std::unordered_map<void*, std::pair<int, size_t> > live;          // ptr -> (device, bytes)
+  std::multimap<std::pair<int, size_t>, void*> idle;                // (device, bytes) -> ptr
+  std::unordered_map<int, size_t> idle_bytes;                       // per device
+};
+MemPool& dev_pool() { static MemPool p; return p; }
+MemPool& host_pool() { static MemPool p; return p; }
+size_t pool_limit_bytes() {
+  static const size_t lim = [] {
+    const char* e = getenv("GZ_POOL_MB");
+    return (size_t)(e ? std::max(0L, atol(e)) : 16384L) << 20;
+  }();
+  return lim;
+}
+void pool_release_idle(MemPool& p, bool host, int device /* -1: all */) {
+  for (auto it = p.idle.begin(); it != p.idle.end();) {
+    if (device >= 0 && it->first.first != device) { ++it; continue; }
+    if (host) (void)hipHostFree(it->second); else (void)hipFree(it->second);
+    p.idle_bytes[it->first.first] -= it->first.second;
+    it = p.idle.erase(it);
+  }
+}
+hipError_t pool_alloc(MemPool& p, bool host, void** out, size_t bytes) {
+  if (bytes == 0) bytes = 1;
+#ifdef GZ_EMU
+  return host ? hipHostMalloc(out, bytes, kHostAllocFlags) : hipMalloc(out, bytes);
+#else
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::lock_guard<std::mutex> lk(p.mu);
+  auto it = p.idle.find(std::make_pair(device, bytes));
+  if (it != p.idle.end()) {
+    *out = it->second;
+    p.idle.erase(it);
+    p.idle_bytes[device] -= bytes;
+    p.live[*out] = std::make_pair(device, bytes);
+    return hipSuccess;
+  }
+  hipError_t e = host ? hipHostMalloc(out, bytes, kHostAllocFlags) : hipMalloc(out, bytes);
+  if (e != hipSuccess) {   // make room: drop what is cached on this device and try once more
+    (void)hipGetLastError();
+    pool_release_idle(p, host, device);
+    e = host ? hipHostMalloc(out, bytes, kHostAllocFlags) : hipMalloc(out, bytes);
+  }
+  if (e == hipSuccess) p.live[*out] = std::make_pair(device, bytes);
+  return e;
+#endif
+}
+void pool_release(MemPool& p, bool host, void* ptr) {
+  if (!ptr) return;
+#ifdef GZ_EMU
+  if (host) (void)hipHostFree(ptr); else (void)hipFree(ptr);
+#else
+  std::lock_guard<std::mutex> lk(p.mu);
+  auto it = p.live.find(ptr);
+  if (it == p.live.end()) {   // not ours
+    if (host) (void)hipHostFree(ptr); else (void)hipFree(ptr);
+    return;
+  }
+  const std::pair<int, size_t> key = it->second;
+  p.live.erase(it);
+  if (key.second <= pool_limit_bytes() && p.idle_bytes[key.first] + key.second > pool_limit_bytes())
+    pool_release_idle(p, host, key.first);   // full of sizes nobody asks for any more: start over
+  if (p.idle_bytes[key.first] + key.second <= pool_limit_bytes()) {
+    p.idle.insert(std::make_pair(key, ptr));
+    p.idle_bytes[key.first] += key.second;
+  } else if (host) {
+    (void)hipHostFree(ptr);
+  } else {
+    (void)hipFree(ptr);
+  }
+#endif
+}
+inline hipError_t pool_malloc(void** out, size_t bytes) { return pool_alloc(dev_pool(), false, out, bytes); }
+inline void pool_free(void* ptr) { pool_release(dev_pool(), false, ptr); }
+inline hipError_t pool_host_malloc(void** out, size_t bytes) { return pool_alloc(host_pool(), true, out, bytes); }
+inline void pool_host_free(void* ptr) { pool_release(host_pool(), true, ptr); }
+
+// Streams and (timing-less) events are pooled the same way: creating and destroying a
+// context's four streams costs several milliseconds.  Only idle ones come back (the context
+// synchronises its streams before it returns them).
+struct HandlePool {
+  std::mutex mu;
+  std::multimap<int, hipStream_t> streams;   // device * 4 + priority class -> stream
+  std::multimap<int, hipEvent_t> events;
+};
+HandlePool& handle_pool() { static HandlePool p; return p; }
+// prio: 0 = default, +1 = the device's highest priority, -1 = its lowest.  Who takes which:
+// create_context.
+static bool stream_priorities() { return true; }
+// Contexts alive per device: adds `delta`, returns the count before.
+static int live_contexts(int device, int delta) {
+  static std::mutex mu;
+  static std::map<int, int> live;
+  std::lock_guard<std::mutex> lk(mu);
+  const int before = live[device];
+  live[device] = before + delta;
+  return before;
+}
+hipError_t pool_stream_create(hipStream_t* out, int prio = 0) {
+#ifndef GZ_EMU
+  if (!stream_priorities()) prio = 0;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  const int key = device * 4 + (prio + 1);
+  {
+    HandlePool& p = handle_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.streams.find(key);
+    if (it != p.streams.end()) { *out = it->second; p.streams.erase(it); return hipSuccess; }
+  }
+  if (prio != 0) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+      return hipStreamCreateWithPriority(out, hipStreamDefault, prio > 0 ? greatest : least);
+  }
+#endif
+  return hipStreamCreate(out);
+}
+void pool_stream_destroy(hipStream_t s_, int prio = 0) {
+  if (!s_) return;
+#ifndef GZ_EMU
+  if (!stream_priorities()) prio = 0;
+  if (pool_limit_bytes() != 0) {
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const int key = device * 4 + (prio + 1);
+    HandlePool& p = handle_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.streams.count(key) < 64) { p.streams.insert(std::make_pair(key, s_)); return; }
+  }
+#endif
+  (void)hipStreamDestroy(s_);
+}
+hipError_t pool_event_create(hipEvent_t* out) {
+#ifndef GZ_EMU
+  int device = 0;
+  (void)hipGetDevice(&device);
+  {
+    HandlePool& p = handle_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.events.find(device);
+    if (it != p.events.end()) { *out = it->second; p.events.erase(it); return hipSuccess; }
+  }
+#endif
+  return hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+void pool_event_destroy(hipEvent_t e_) {
+  if (!e_) return;
+#ifndef GZ_EMU
+  if (pool_limit_bytes() != 0) {
+    int device = 0;
+    (void)hipGetDevice(&device);
+    HandlePool& p = handle_pool();
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.events.count(device) < 256) { p.events.insert(std::make_pair(device, e_)); return; }
+  }
+#endif
+  (void)hipEventDestroy(e_);
+}
+}  // namespace
+
+// Pinned host staging for the small per-iteration uploads (step lists, coefficient edits,
+// next_cand, Huffman codes): the caller's buffer is copied here, the H2D copy is asynchronous
+// and nobody has to wait for it -- the buffer is only waited for when it is reused.
+struct HostStage {
+  void* h = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool busy = false;
+};
+
+struct gz_ctx {
+  int device = 0;
+  int w = 0, h = 0, bw = 0, bh = 0, nb = 0, pitch = 0;
+  size_t plane = 0;   // floats per plane
+  // The current frame (OutputImage's component layout): chroma subsampling factor 1 (4:4:4)
+  // or 2 (4:2:0: OutputImageComponent::Reset(2, 2), output_image.cc:40-49), the chroma block
+  // grid under it, the first block of every component in d_orig / d_cand, blocks in total.
+  int cfac = 1, cbw = 0, cbh = 0, nbc = 0, coff[3] = {0, 0, 0}, nblk = 0;
+  uint8_t* d_csamp = nullptr;      // 4:2:0: IDCT samples of the two chroma components (k_chroma_samples)
+  // grid of the last block search (gz_block_zeroing_orders*), which phase B's order works on
+  int sg_w = 0, sg_h = 0, sg_n = 0, sg_factor = 1, sg_mask = 7;
+  float* d_gmax = nullptr;         // per-16x16 maxima of the distance map (sg_factor == 2)
+  // scratch of k_scan_offsets, one set per stream that runs it (main: order build; entropy: scan)
+  void* d_scan_state[2] = {nullptr, nullptr};
+  unsigned scan_epoch[2] = {0, 0};
+  float target = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // second stream for the branch of Compare that does not depend on the Malta path (the
+  // mask: DiffPrecompute + three blurs), forked and joined with events
+  hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+  bool prio_streams = false, counted_live = false;   // (see create_context)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mask_pre = nullptr;
+  hipEvent_t ev_next_cand = nullptr;   // next_cand uploaded beside a Compare chain in flight
+  hipEvent_t ev_xyb = nullptr, ev_lfy = nullptr;   // B plane's LF blur on side stream 2 (stage_separate)
+  // the entropy coder's kernels (gz_jpeg_scan) run on their own stream, beside a Compare that
+  // gz_compare_begin has put on the main stream: both only read the candidate coefficients
+  hipStream_t entropy_stream = nullptr;
+  hipEvent_t ev_candidate = nullptr;   // main stream: the candidate is in place
+  std::string err;
+
+  uint8_t* d_rgb = nullptr;
+  int16_t* d_orig = nullptr;   // [3][nb][64] original coefficients
+  int16_t* d_cand = nullptr;   // candidate coefficients
+  int* d_q = nullptr;          // [3][64]
+  float* d_srgb_lut = nullptr; // float(Srgb8ToLinearTable[i])
+  double* d_mask_luts = nullptr;
+  float* d_block_max = nullptr;
+  unsigned* d_max_bits = nullptr;
+  uint8_t* d_srgb_out = nullptr;
+  int32_t* d_blkidx = nullptr; size_t blkidx_cap = 0;
+  int16_t* d_blkdata = nullptr;
+
+  float* arena = nullptr;
+  float* extra_arena = nullptr;   // probe-only planes (ensure_pip)
+  std::vector<float*> free_planes;
+  BlurCfg blur[B_COUNT];
+
+  Psycho pi0;   // original
+  Psycho pi1;   // candidate
+  Psycho pip;   // probe "image 0" (allocated lazily)
+  bool have_pip = false;
+  // scratch
+  float *lin[3], *tmp[3], *xyb[3], *lf_raw[2], *hfp[2];
+  float *snb, *diffx, *diffy, *mxb, *myb1, *myb2, *ac[2], *dsq, *distmap;
+  float* sup0[2];   // the original's half of DiffPrecompute (k_mask_sup of pi0: X, Y), per image
+  float* sup_scratch[2] = {nullptr, nullptr};   // the same for Mask() on raw planes (block mask, probe)
+  float *mask_out[3], *mask_dc_out[3];
+  bool have_mask_out = false;
+
+  float* d_block_mask = nullptr;   // [3][nb] mask_xyz_ at block corners (StartBlockComparisons)
+  bool have_block_mask = false;
+  int32_t* d_rank_cnt = nullptr; uint8_t* d_rank_idx = nullptr; float* d_rank_tables = nullptr;
+  int32_t* d_out_cnt = nullptr; uint8_t* d_out_idx = nullptr; float* d_out_err = nullptr;
+
+  // device entropy coder (gz_kernels_entropy.h)
+  int* d_jq = nullptr;                    // [3][64] quant matrices of the frame being written
+  unsigned* d_hist = nullptr;             // [2][3][256]
+  unsigned char* d_code_depth = nullptr;  // [2][3][256]
+  unsigned short* d_code_bits = nullptr;  // [2][3][256]
+  unsigned* d_mcu_bits = nullptr;         // [nb]
+  unsigned long long* d_mcu_off = nullptr;   // [nb+1]
+  unsigned long long* d_ff_count = nullptr;
+  unsigned* d_words = nullptr; size_t words_cap = 0;        // scan bits of the last gz_jpeg_scan
+  unsigned* d_words_kept = nullptr; size_t words_kept_cap = 0;
+  unsigned long long scan_bits = 0, scan_ff = 0, kept_bits = 0, kept_ff = 0;
+  bool have_jq = false, have_scan = false, have_kept = false;
+  bool scan_pending = false;           // between gz_jpeg_scan_begin and _end
+  void* h_scan_result = nullptr;       // pinned: total bits, 0xFF count of the scan in flight
+
+  // global candidate order of phase B (gz_kernels_order.h)
+  OrderEntry* d_order = nullptr; size_t order_cap = 0; size_t order_n = 0;
+  unsigned* d_pos_l = nullptr; unsigned* d_pos_r = nullptr;       // [order_cap]
+  unsigned* d_chunk = nullptr; size_t chunk_cap = 0;              // cnt_l, cnt_r, base_l, base_r
+  PartScalars* d_part = nullptr;
+  // gz_order_build_auto_begin .. _end: results land here (pinned; not the shared landing area,
+  // which gz_compare_end uses in between)
+  struct OrderPending { unsigned long long total; unsigned counters[2]; };
+  OrderPending* h_order_pending = nullptr;
+  bool order_pending = false;
+  // quick-select descent decided on the device (gz_order_descend*): per-level ranges and pivots,
+  // the ranges' pinned copy for the host's replay
+  DescState* d_desc_st = nullptr; DescPivot* d_desc_pv = nullptr; DescState* h_desc = nullptr;
+  unsigned desc_epoch = 0; int desc_levels = 0; bool desc_pending = false;
+  // gz_order_build_auto_descend_begin: the order's counters (and the distance of the Compare in
+  // flight) arrive with the descent's state, in h_desc[kDescMaxLevels + 1]
+  void* h_order_mirror = nullptr;      // gz_order_host_mirror: pinned, order entries land in it directly
+  size_t order_mirror_cap = 0;         // entries
+  bool results_in_desc = false, distance_in_desc = false;
+  unsigned results_epoch = 0;          // the descent (desc_epoch) that published them
+  unsigned export_epoch = 0;           // the descent whose k_desc_export wrote into the host mirror (0: none)
+  unsigned* d_order_nb = nullptr;                                 // [nb]
+  unsigned long long* d_order_off = nullptr;                      // [nb+1]: [nb] = the order's size; the first 4 nb BYTES: every block's offset inside its group
+  unsigned* d_order_counters = nullptr;                           // [2]
+  unsigned* d_order_groups = nullptr;                             // [2 * ceil(nb / kOrderGroup)]: sum of n_b, blocks with n_b > 0
+  int* d_next_cand = nullptr; float* d_weight = nullptr; float* d_max_err = nullptr;   // [nb]
+  bool have_search = false;
+  unsigned char* d_wflag = nullptr;                               // [nb]
+  int* d_edit_pos = nullptr; short* d_edit_val = nullptr; size_t edit_cap = 0;
+
+  bool have_orig = false, have_cand = false, have_distmap = false;
+  std::vector<float> h_block_max;
+  bool h_block_max_valid = false;
+  bool compare_pending = false;
+  int h_jq[192] = {0};       // the matrix d_jq holds
+  unsigned* d_step_delta = nullptr; bool have_step_delta = false;   // AC statistics change of the last bulk steps
+  HostStage stage_main, stage_entropy;
+  HostStage stage_edits;   // gz_apply_coeff_edits' own: its kernel reads the buffer, and the next order's upload (stage_main) must not wait for it
+  // pinned landing area for the small results every call waits for (a copy into pageable
+  // memory costs 27 us per round trip on this system, into pinned memory 15)
+  void* h_res = nullptr; size_t h_res_cap = 0;
+  void* d_cmp_stage = nullptr; size_t cmp_stage_cap = 0;   // gz_compare_blocks / _block_pixels staging
+  size_t search_total = 0;   // candidates phase A produced (bounds every global order)
+  unsigned long long search_evaluations = 0;   // CompareBlock evaluations of the last block search
+  float last_distance = 0.0f;
+};
+
+// Every context entry point runs with the context's device current and leaves the caller's
+// device as it found it: a thread may own contexts on several GPUs (the pools key on the
+// current device, kernels launch on it).
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(const gz_ctx* c) {
+    if (!c) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+    if (cur != c->device) {
+      (void)hipSetDevice(c->device);
+      prev = cur;
+    }
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                            \
+  do {                                                                               \
+    hipError_t e_ = (call);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+      return GZ_E_HIP;                                                               \
+    }                                                                                \
+  } while (0)
+
+#define KCHK(ctx)                                                                    \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) {                                                          \
+      (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(e_);           \
+      return GZ_E_HIP;                                                               \
+    }                                                                                \
+  } while (0)
+
+const int kNumPlanes = 9 + 9 + 3 + 3 + 3 + 2 + 2 + 10 + 2;   // pi0, pi1, lin, tmp, xyb, lf_raw, hfp, 10 singles, sup0[2]
+
+void set_frame(gz_ctx* c, int factor) {
+  c->cfac = factor;
+  c->cbw = (c->w + 8 * factor - 1) / (8 * factor);
+  c->cbh = (c->h + 8 * factor - 1) / (8 * factor);
+  c->nbc = c->cbw * c->cbh;
+  c->coff[0] = 0;
+  c->coff[1] = c->nb;
+  c->coff[2] = c->nb + c->nbc;
+  c->nblk = c->nb + 2 * c->nbc;
+  c->have_search = false;
+  // whatever was pending or kept belonged to the old frame: a stale gz_order_build_auto_end /
+  // gz_order_descend_end / gz_compare_end / gz_jpeg_scan_end must fail, not return its data
+  c->order_pending = false;
+  c->results_in_desc = false;
+  c->desc_pending = false;
+  c->distance_in_desc = false;
+  c->compare_pending = false;
+  c->scan_pending = false;
+  c->have_distmap = false;
+  c->have_scan = false;
+  c->export_epoch = 0;
+}
+size_t csamp_plane(const gz_ctx* c) {   // bytes of one chroma sample plane of a 4:2:0 frame
+  return (size_t)((c->w + 15) / 16 * 8) * (size_t)((c->h + 15) / 16 * 8);
+}
+
+float* take_plane(gz_ctx* c) {
+  float* p = c->free_planes.back();
+  c->free_planes.pop_back();
+  return p;
+}
+void alloc_psycho(gz_ctx* c, Psycho* p) {
+  for (int i = 0; i < 3; ++i) p->lfv[i] = take_plane(c);
+  for (int i = 0; i < 2; ++i) p->mf[i] = take_plane(c);
+  for (int i = 0; i < 2; ++i) p->hf[i] = take_plane(c);
+  for (int i = 0; i < 2; ++i) p->uhf[i] = take_plane(c);
+}
+
+}  // namespace

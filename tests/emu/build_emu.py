@@ -14,7 +14,7 @@ LIB = os.path.join(OUT, "libguetzli_amd_emu.so")
 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+    deps = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs] + \
         [os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "guetzli_amd.h")]
     if not force and os.path.exists(LIB) and \
             all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):

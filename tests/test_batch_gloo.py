@@ -90,9 +90,10 @@ def proc(rgb):
 proc.calls = 0
 try:
     batch.run_config5(get, 2, proc, rank, world, dist, workers=1, fence=dist.barrier)
-    print("RANK", rank, "NO ERROR")
+    sys.stdout.write("RANK %d NO ERROR\n" % rank)
 except batch.BatchError as e:
-    print("RANK", rank, "FAILURES", [(f["index"], f["rank"]) for f in e.failures], flush=True)
+    sys.stdout.write("RANK %d FAILURES %s\n" % (rank, [(f["index"], f["rank"]) for f in e.failures]))   # (one write: two ranks share the pipe)
+    sys.stdout.flush()
     dist.barrier(); dist.destroy_process_group()
     sys.exit(3)
 """

@@ -28,7 +28,9 @@ static bool small_tiles(const gz_ctx* c) {
   const char* e = getenv("GZ_TILE_ROWS");
   if (e && atoi(e) == 16) return true;
   if (e && atoi(e) == 32) return false;
-  return (size_t)c->w * c->h < 1500000;
+  // (round 5: 16-row tiles win or tie up to 3200 x 1800 -- 1080p chain 0.343 -> 0.330 ms, sixteen 1080p images
+  // four in flight 27.7 -> 29.5 MPix/s; equal at 3840 x 2160: profiles/r05_chain_experiments.log, section 8)
+  return (size_t)c->w * c->h < 7000000;
 }
 
 template <int R, class Src, int NC>

@@ -10,17 +10,19 @@ namespace {
 // run every one of them on images small enough for the emulation):
 //  * GZ_BLUR_PK -- row-pair / column-pair passes with packed arithmetic (k_blur_h_pk, k_blur_v_pk:
 //    twice the outputs per thread, half the LDS reads and address computations per output, half
-//    the workgroups) from 4 MPix on, the one-output-row kernels (k_blur_h, k_blur_v_compact) below
+//    the workgroups) from 1.5 MPix on (round 5; 4 MPix until then), the one-output-row kernels (k_blur_h, k_blur_v_compact) below
 //    (profiles/r02_packed_blur_ab.log, r03_chain_kernel_experiments.log);
-//  * GZ_TILE_ROWS -- 64 x 32 tiles from 1.5 MPix on, 64 x 16 below: twice the workgroups for
-//    256 CUs (720p: 0.290 -> 0.257 ms per Compare; no gain at 1080p, a small loss at 4K).
+//  * GZ_TILE_ROWS -- 64 x 32 tiles from 7 MPix on, 64 x 16 below: twice the workgroups for
+//    256 CUs (720p: 0.290 -> 0.257 ms per Compare; round 5: 1080p 0.343 -> 0.330, equal at 4K).
 // What round 4 removed after it had lost every A/B of rounds 2 and 3: the unrolled (non-compact)
 // column pass and fused kernels, 64-row tiles, the epilogue without 16-byte accesses and the row
 // pass with LDS bank conflicts (GZ_BLUR_OPT), the three-plane LF passes, the unpaired mask blurs.
 static bool packed_blur(const gz_ctx* c) {
   const char* e = getenv("GZ_BLUR_PK");
   if (e) return atoi(e) != 0;
-  return (size_t)c->w * c->h >= 4000000;
+  // (round 5, with 16-row tiles: 1080p 0.3356 -> 0.3290 ms, 2560 x 1440 0.487 -> 0.466, 3200 x 1800 0.719 -> 0.684;
+  // 720p equal -- profiles/r05_chain_experiments.log, section 8)
+  return (size_t)c->w * c->h >= 1500000;
 }
 constexpr int kTileRows = 32;
 constexpr int kSmallTileRows = 16;

@@ -92,7 +92,7 @@ CHAIN = ("butteraugli Compare chain (17 launches per Compare on 3 streams: k_rec
          "k_blur2d (radius < 16), 4 k_blur_h + 4 k_blur_v (radius >= 16: LF X/Y, LF B, SameNoise, the mask's "
          "radius-20 pair as one launch per pass), k_malta_rolled (both channels), k_mask_pre, k_combine)")
 TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in
-                 ("r04_compare_pmc_traffic.json", "r03_compare_pmc_traffic.json")]
+                 ("r05_compare_pmc_traffic.json", "r04_compare_pmc_traffic.json", "r03_compare_pmc_traffic.json")]
 
 
 def load_traffic():
@@ -156,8 +156,10 @@ def cpu_baseline():
     # whole BASELINE images through the same reference build on this kind of box, once per round
     # (tools/ref_cpu_time.py under gpurun: 9 and 2.3 minutes -- too long for this line)
     full = {}
-    for key, name in (("3840x2160_q95", "r04_reference_cpu_4k.json"), ("1920x1080_q95", "r04_reference_cpu_1080p.json")):
+    for key, names in (("3840x2160_q95", ("r05_reference_cpu_4k.json", "r04_reference_cpu_4k.json")),
+                       ("1920x1080_q95", ("r05_reference_cpu_1080p.json", "r04_reference_cpu_1080p.json"))):
         try:
+            name = next(n for n in names if os.path.exists(os.path.join(ROOT, "profiles", n)))
             r = json.load(open(os.path.join(ROOT, "profiles", name)))
             full[key] = {k: r[k] for k in ("seconds", "value", "unit", "host_cpu", "host_cores_present", "cores_used",
                                            "output_sha256", "head")}
@@ -166,9 +168,10 @@ def cpu_baseline():
             pass
     return {"value": round(w * h / 1e6 / dt, 6), "unit": "MPix/s", "cores": 1,
             "kind": "reference", "full_images_same_box_kind": full,
-            "note": "the 3840x2160 image of `value` through the unmodified reference on the bench box's host CPU "
-                    "(EPYC 9575F, 1 thread of 256): 543.4 s = 0.01526 MPix/s, output hash = the GPU's "
-                    "(profiles/r04_reference_cpu_4k.json); this line's own sample is the bounded one below",
+            "note": "full_images_same_box_kind: the BASELINE images of `value` / `value_1080p` through the unmodified "
+                    "reference on the bench box's kind of host CPU, one thread -- COMMITTED records of a gpurun "
+                    "session (each carries its commit in `head` and its seconds; 9 and 2.3 minutes are too long for "
+                    "this line), output hashes equal to the GPU's; timed in THIS run: the bounded sample below",
             "sample": f"unmodified reference guetzli::Process on the top-left {w}x{h} of the "
                       f"bench image, --quality 95: {dt:.1f} s of CPU, single thread "
                       f"({os.cpu_count()} host cores present); output {len(jpg)} bytes",
@@ -194,19 +197,25 @@ def block_search_counters():
     counters cannot be read from inside this process): the share of its wave cycles in which a
     wavefront issues a VALU instruction, and VALU instructions per wavefront."""
     import csv
-    for name in ("r04_block_search_pmc.csv", "r03_block_search_pmc.csv", "r02_block_search_pmc.csv"):
+    for name in ("r05_block_search_pmc.csv", "r04_block_search_pmc.csv", "r03_block_search_pmc.csv", "r02_block_search_pmc.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         c = {}
-        for r in csv.DictReader(l for l in open(path) if not l.startswith("#")):   # (first line: the commit stamp)
+        import re
+        m = re.search(r"#\s*evaluations per launch\s+(\d+)", open(path).read())
+        evals = int(m.group(1)) if m else None
+        for r in csv.DictReader(l for l in open(path) if not l.startswith("#")):   # (first lines: the commit stamp, the evaluations)
             if "k_block_search<0>" in r["kernel"]:
                 c[r["counter"]] = float(r["avg_value"])
         if "SQ_WAVE_CYCLES" in c and "SQ_ACTIVE_INST_VALU" in c:
             return {"source": "profiles/" + name,
                     "valu_active_per_wave_cycle": round(c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 4),
                     "wait_any_per_wave_cycle": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4),
-                    "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU")}
+                    "valu_wave_instructions_per_launch": c.get("SQ_INSTS_VALU"),
+                    "evaluations_per_launch": evals,
+                    "valu_wave_instructions_per_evaluation":
+                        round(c["SQ_INSTS_VALU"] / evals, 1) if evals and c.get("SQ_INSTS_VALU") else None}
     return None
 
 
@@ -397,7 +406,7 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
 
 def _latest_profile(name):
     """profiles/<round>_<name> of the newest round that has it."""
-    for rn in ("r04", "r03", "r02"):
+    for rn in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rn}_{name}")
         if os.path.exists(path):
             return path

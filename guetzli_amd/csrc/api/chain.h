@@ -35,13 +35,6 @@ static bool small_tiles(const gz_ctx* c) {
   return (size_t)c->w * c->h < 7000000;
 }
 
-// Tiles a workgroup of the paired row pass takes, one after the other (GZ_HPK_TILES forces a count).
-static int tiles_per_workgroup(const gz_ctx* c) {
-  static const char* e = getenv("GZ_HPK_TILES");
-  if (e && atoi(e) > 0) return atoi(e);
-  return 1;
-}
-
 template <int R, class Src, int NC>
 int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
            const BlurCfg& cfg) {
@@ -50,9 +43,8 @@ int blur_h(gz_ctx* c, const SrcPack<Src, NC>& src, const PlanePack<NC>& dst,
   const BorderScale bs = cfg.bx;
   const int w = c->w, h = c->h, pitch = c->pitch;
   if (packed_blur(c)) {
-    const int nt = tiles_per_workgroup(c);
-    dim3 grid(gz_div_up(c->w, HW), gz_div_up(gz_div_up(c->h, HP), nt), NC);
-    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs, nt);
+    dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), NC);
+    GZ_LAUNCH((k_blur_h_pk<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs);
   } else {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), NC);
     GZ_LAUNCH((k_blur_h<R, Src, NC>), grid, dim3(256), c->stream, src, dst, w, h, pitch, tp, bs, tp, bs);
@@ -90,9 +82,8 @@ int blur_h_pair(gz_ctx* c, const SrcPack<Src, 2>& src, const PlanePack<2>& dst, 
   const BorderScale b0 = cfg0.bx, b1 = cfg1.bx;
   const int w = c->w, h = c->h, pitch = c->pitch;
   if (packed_blur(c)) {
-    const int nt = tiles_per_workgroup(c);
-    dim3 grid(gz_div_up(c->w, HW), gz_div_up(gz_div_up(c->h, HP), nt), 2);
-    GZ_LAUNCH((k_blur_h_pk<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1, nt);
+    dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HP), 2);
+    GZ_LAUNCH((k_blur_h_pk<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1);
   } else {
     dim3 grid(gz_div_up(c->w, HW), gz_div_up(c->h, HH), 2);
     GZ_LAUNCH((k_blur_h<R, Src, 2, true>), grid, dim3(256), c->stream, src, dst, w, h, pitch, t0, b0, t1, b1);

@@ -180,8 +180,7 @@ constexpr int HP = 8;
 template <int R, class Src, int NC, bool TWO = false>
 __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePack<NC> dst,
                                                    int w, int h, int pitch, Taps<R> taps0,
-                                                   BorderScale bs0, Taps<R> taps1, BorderScale bs1,
-                                                   int ntile) {
+                                                   BorderScale bs0, Taps<R> taps1, BorderScale bs1) {
   constexpr int RA = (R + 3) & ~3;
   constexpr int TP = HW + 2 * RA;
   constexpr int OFF = RA - R;
@@ -207,17 +206,8 @@ __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePa
     }
   const Taps<R>& taps = (TWO && c == 1) ? taps1 : taps0;
   const BorderScale& bs = (TWO && c == 1) ? bs1 : bs0;
-  const int x0 = bid.x * HW;
+  const int x0 = bid.x * HW, y0 = bid.y * HP;
   const int tid = threadIdx.x;
-  // Round 5: a workgroup takes `ntile` tiles of its column one after the other (plain loop, same
-  // registers): the chip starts ~190 of these four-wavefront workgroups per microsecond, and a
-  // one-tile workgroup lives 4.7 us -- 3.5 resident per CU where registers and LDS allow 6: the
-  // launch rate, not a unit, bounded the one-tile kernel (profiles/r05_chain_experiments.log, 9).
-#pragma unroll 1
-  for (int t = 0; t < ntile; ++t) {
-  const int y0 = (bid.y * ntile + t) * HP;
-  if (y0 >= h) break;
-  if (t > 0) __syncthreads();
   if (x0 >= RA && x0 + HW + RA <= w && y0 + HP <= h && (pitch & 3) == 0) {
     constexpr int NQ = TP / 4;          // 16-byte vectors per staged row
     constexpr int NI = (HP / 2) * NQ;   // (pair, vector) items
@@ -259,7 +249,7 @@ __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePa
     const size_t o = (size_t)(y0 + 2 * p) * pitch + x0 + xq;
     GZ_STG4(out, o, oa);
     GZ_STG4(out, o + pitch, ob);
-    continue;
+    return;
   }
   // generic tile: rows y0..y0+HP-1, columns x0-R .. x0+HW+R-1 (zero outside the image)
   constexpr int GW = HW + 2 * R;
@@ -272,7 +262,7 @@ __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePa
   }
   __syncthreads();
   const int x = x0 + tid;
-  if (x < w) {
+  if (x >= w) return;
   const bool border = x < R || x >= w - R;
   float scale = 1.0f;
   if (border) scale = x < R ? bs.lo[x] : bs.hi[w - 1 - x];
@@ -291,8 +281,6 @@ __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePa
       sum = sum * scale;
     }
     out[(size_t)y * pitch + x] = sum;
-  }
-  }
   }
 }
 

@@ -120,9 +120,11 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bx = cfg.bx, by = cfg.by;
   const int w = c->w, h = c->h, pitch = c->pitch;
-  if (!BM && small_tiles(c)) {
+  // (the chain's last blur, with block maxima: 16-row tiles below 1.5 MPix only -- 720p chain 0.224 -> 0.213 ms,
+  // nothing at 1080p, +3 % at 2560 x 1440: profiles/r05_chain_experiments.log, section 8)
+  if (BM ? small_tiles(c) && (size_t)c->w * c->h < 1500000 : small_tiles(c)) {
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
-    GZ_LAUNCH((k_blur2d<R, NC, Src, Post, false, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w,
+    GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w,
               h, pitch, tp, bx, by, bm);
   } else {
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));

@@ -346,6 +346,45 @@ GZ_DEVFN void block_max_from_registers(const float* res, int tx, int row0, int x
   }
 }
 
+// The same for a thread that holds FOUR consecutive rows of its column (16-row tiles: wavefront tg has
+// rows 4 tg .. 4 tg + 3, so a block's eight rows are two wavefronts'): the column maxima of the upper
+// and lower halves meet in LDS.  max is exact and order-free.
+GZ_DEVFN void block_max_from_half_columns(const float* res, int tx, int tg, int x0, int y0, int w, int h,
+                                          const BlockMaxOut& bm) {
+  __shared__ int s_half[4][64];
+  __shared__ int s_wave_max4[2];
+  float m = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) m = res[i] > m ? res[i] : m;
+  s_half[tg][tx] = (int)__float_as_uint(m);
+  __syncthreads();
+  int wave_max = 0;
+  if ((tg & 1) == 0) {   // wavefronts 0 and 2: block rows 0 and 1 of the tile
+    const int a = s_half[tg][tx], b = s_half[tg + 1][tx];
+    int bits = a > b ? a : b;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      const int o = __shfl(bits, tx ^ d);
+      bits = o > bits ? o : bits;
+    }
+    const int gbx = (x0 + tx) / 8, gby = y0 / 8 + (tg >> 1);
+    if ((tx & 7) == 0 && bm.block_max && 8 * gbx < w && 8 * gby < h)
+      bm.block_max[gby * bm.bw + gbx] = __uint_as_float((unsigned)bits);
+    wave_max = bits;
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) {
+      const int o = __shfl(wave_max, tx ^ d);
+      wave_max = o > wave_max ? o : wave_max;
+    }
+    if (tx == 0) s_wave_max4[tg >> 1] = wave_max;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int mm = s_wave_max4[0] > s_wave_max4[1] ? s_wave_max4[0] : s_wave_max4[1];
+    if ((unsigned)mm > *(volatile unsigned*)bm.image_max_bits) atomicMax(bm.image_max_bits, (unsigned)mm);
+  }
+}
+
 // ZCH = true (NC == 2, Post = PostStore<2>): the two planes are independent blurs with their own
 // taps (taps1 / bs1 for the second); the grid's z index picks the plane, each workgroup does one.
 template <int R, int NC, class Post, int TH, bool ZCH = false>
@@ -846,7 +885,8 @@ __global__ __launch_bounds__(256, 4) void k_blur2d(SrcPack<Src, NC> src, Post po
       res[i] = post((size_t)y * pitch + x, v);
     }
   }
-  if (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
+  if constexpr (BM && VPTt == 4) block_max_from_half_columns(res, tx, tg, x0, y0, w, h, bm);
+  else if constexpr (BM) block_max_from_registers<VPTt>(res, tx, tg * VPTt, x0, y0, w, h, bm);
 }
 
 // ------------------------------------------------------------------- post functors --

@@ -370,7 +370,10 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
             get(k)   # (encoded before anything is timed)
         proc = lambda data: host.process(host.read_png(data), quality=quality, device=env.device)
     else:
-        get = lambda k: images.shifted(base, k)
+        # this rank's images exist before anything is timed (as the PNG bytes do above): the timed region
+        # is the encodes, not numpy's circular shifts of a 25 MB array on the image threads
+        mine = {k: images.shifted(base, k) for k in range(env.rank, images_per_gpu * env.world, env.world)}
+        get = lambda k: mine[k] if k in mine else images.shifted(base, k)
         proc = lambda im: host.process(im, quality=quality, device=env.device)
     if not env.emulate:
         run_config5(get, min(2, images_per_gpu), proc, env.rank, env.world, env.dist, in_flight, env.fence,

@@ -576,9 +576,12 @@ def main():
         img4k = images.tiled(W4, H4)
         host.process(img4k, quality=84, device=local_rank)
         env.sync()
-        t4 = time.perf_counter()
-        j4, i4 = host.process(img4k, quality=84, device=local_rank)
-        t4 = time.perf_counter() - t4
+        runs = []
+        for _ in range(3):   # (median of three timed encodes: a single one varies by 20 %)
+            t4 = time.perf_counter()
+            j4, i4 = host.process(img4k, quality=84, device=local_rank)
+            runs.append(time.perf_counter() - t4)
+        t4 = sorted(runs)[1]
         assert hashlib.sha256(j4).hexdigest() == GOLDEN_SHA_4K[84]
         other["3840x2160_q84"] = {"seconds": round(t4, 3), "value": round(W4 * H4 / 1e6 / t4, 3),
                                   "unit": "MPix/s",
@@ -591,13 +594,16 @@ def main():
             if hashlib.sha256(mos.tobytes()).hexdigest() == gold["rgb_sha256"]:
                 host.process(mos, quality=QUALITY, device=local_rank)
                 env.sync()
-                tm = time.perf_counter()
-                jm, im = host.process(mos, quality=QUALITY, device=local_rank)
-                tm = time.perf_counter() - tm
+                runs = []
+                for _ in range(3):
+                    tm = time.perf_counter()
+                    jm, im = host.process(mos, quality=QUALITY, device=local_rank)
+                    runs.append(time.perf_counter() - tm)
+                tm = sorted(runs)[1]
                 assert hashlib.sha256(jm).hexdigest() == gold["jpeg_sha256"], "mosaic output differs from the reference"
                 other["mosaic_3840x2160_q95"] = {
                     "workload": "3840x2160 mosaic of the nine committed photographs (tests/images.mosaic: no "
-                                "period, no RNG), --quality 95, one untimed and one timed encode",
+                                "period, no RNG), --quality 95, one untimed encode, then the median of three timed ones",
                     "seconds": round(tm, 3), "value": round(W4 * H4 / 1e6 / tm, 3), "unit": "MPix/s",
                     "iterations": im["counters"].get("number of iterations"), "output_bytes": len(jm),
                     "output_sha256_matches_reference": True,

@@ -10,7 +10,7 @@ TAG=${1:-prof}; O=gpurun_out/$TAG; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 cp .gpurun_head $O/head.txt 2>/dev/null || true
 tools/ubench/bw 2>/dev/null | head -3 | tee $O/bw.log
-{ echo "# head $(cat .gpurun_head 2>/dev/null)"; for i in 1 2 3; do python tools/run_compare.py 3840 2160 40; python tools/run_compare.py 1920 1080 100; done; } | tee $O/compare_chain.log
+{ echo "# head $(cat .gpurun_head 2>/dev/null)"; for i in 1 2 3; do python tools/run_compare.py 3840 2160 200; python tools/run_compare.py 1920 1080 400; done; } | tee $O/compare_chain.log
 for sz in "3840 2160 20 4k" "1920 1080 40 1080p"; do set -- $sz
   d=$O/trace_$4
   ( cd /tmp && env GZ_SINGLE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$d -- python $R/tools/run_compare.py $1 $2 $3 ) > $d.log 2>&1

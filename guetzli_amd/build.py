@@ -45,13 +45,19 @@ def _newer_than_lib():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+# What decides the kernels' work and traffic: the kernels, their arithmetic and tables, and the chain's
+# dispatch (which instantiation / tile shape for which size).  The rest of the C ABI's host side
+# (contexts, pools, entry points) changes nothing a profile of the chain measures.
+DIGEST_FILES = [h for h in HEADERS if not h.startswith("api/")] + ["api/plans.h", "api/chain.h"]
+
+
 def csrc_digest():
-    """SHA-256 over the kernel sources (csrc/ files in name order): what a profile under
-    profiles/ was measured on.  bench.py refuses a committed traffic figure whose digest is not
-    the tree's (the GPU box's snapshot has no .git to ask)."""
+    """SHA-256 over the kernel sources and the chain's dispatch (DIGEST_FILES, in name order): what a
+    profile under profiles/ was measured on.  bench.py refuses a committed traffic figure whose digest is
+    not the tree's (the GPU box's snapshot has no .git to ask)."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(DIGEST_FILES):
         h.update(f.encode() + b"\0")
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()

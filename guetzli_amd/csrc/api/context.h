@@ -104,7 +104,6 @@ inline void pool_host_free(void* ptr) { pool_release(host_pool(), true, ptr); }
 // synchronises its streams before it returns them).
 struct HandlePool {
   std::mutex mu;
-  std::multimap<int, hipStream_t> streams;   // device * 4 + priority class -> stream
   std::multimap<int, hipEvent_t> events;
 };
 HandlePool& handle_pool() { static HandlePool p; return p; }
@@ -120,40 +119,70 @@ static int live_contexts(int device, int delta) {
   live[device] = before + delta;
   return before;
 }
-hipError_t pool_stream_create(hipStream_t* out, int prio = 0) {
+// A context's four streams are created, pooled and reused TOGETHER.  The HIP runtime spreads streams
+// over its hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order, so four streams made
+// back to back sit on four queues; pooled one by one (rounds 1-4), the streams that came back from the
+// contexts of a batch were handed out in whatever order the threads had destroyed them, and a later
+// context could get its main and side streams on ONE queue: its chain then ran serialised -- 1.58
+// instead of 0.96 ms per Compare at 4K after a four-in-flight batch in the same process, a 4K
+// quality-84 encode 0.177 instead of 0.150 s (profiles/r05_chain_experiments.log, section 10).
+struct StreamSet {
+  hipStream_t own = nullptr, side = nullptr, side2 = nullptr, entropy = nullptr;
+};
+struct StreamSetPool {
+  std::mutex mu;
+  std::multimap<int, StreamSet> sets;   // device * 2 + (main stream at the device's highest priority)
+};
+inline StreamSetPool& stream_set_pool() { static StreamSetPool p; return p; }
+
+hipError_t pool_stream_set_create(StreamSet* out, bool prio_main) {
 #ifndef GZ_EMU
-  if (!stream_priorities()) prio = 0;
   int device = 0;
   (void)hipGetDevice(&device);
-  const int key = device * 4 + (prio + 1);
-  {
-    HandlePool& p = handle_pool();
-    std::lock_guard<std::mutex> lk(p.mu);
-    auto it = p.streams.find(key);
-    if (it != p.streams.end()) { *out = it->second; p.streams.erase(it); return hipSuccess; }
+  const int key = device * 2 + (prio_main && stream_priorities() ? 1 : 0);
+  StreamSetPool& p = stream_set_pool();
+  std::lock_guard<std::mutex> lk(p.mu);   // (also keeps two threads' creations from interleaving)
+  auto it = p.sets.find(key);
+  if (it != p.sets.end()) { *out = it->second; p.sets.erase(it); return hipSuccess; }
+  // The k-th set is created in an order rotated by k, so that the k-th context's MAIN stream sits on
+  // hardware queue k mod 4 and its three other streams on the three other queues: with every set made
+  // in the same order the main streams of the four images in flight all shared one queue, and a batch
+  // of eight 4K images fell from 39 to 32 MPix/s (section 10 of the experiment log).
+  static int serial = 0;
+  const int rot = (serial++) & 3;
+  hipStream_t* slot[4] = {&out->own, &out->side, &out->side2, &out->entropy};
+  int least = 0, greatest = 0;
+  const bool prio = (key & 1) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+  hipError_t e = hipSuccess;
+  for (int j = 0; j < 4 && e == hipSuccess; ++j) {
+    const int which = (j + 4 - rot) & 3;   // position j of the creation order takes stream `which`: own at position rot
+    e = which == 0 && prio ? hipStreamCreateWithPriority(slot[which], hipStreamDefault, greatest)
+                           : hipStreamCreate(slot[which]);
   }
-  if (prio != 0) {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-      return hipStreamCreateWithPriority(out, hipStreamDefault, prio > 0 ? greatest : least);
-  }
+  return e;
+#else
+  hipError_t e = hipStreamCreate(&out->own);
+  if (e == hipSuccess) e = hipStreamCreate(&out->side);
+  if (e == hipSuccess) e = hipStreamCreate(&out->side2);
+  if (e == hipSuccess) e = hipStreamCreate(&out->entropy);
+  return e;
 #endif
-  return hipStreamCreate(out);
 }
-void pool_stream_destroy(hipStream_t s_, int prio = 0) {
-  if (!s_) return;
+void pool_stream_set_destroy(const StreamSet& s_, bool prio_main) {
 #ifndef GZ_EMU
-  if (!stream_priorities()) prio = 0;
-  if (pool_limit_bytes() != 0) {
+  if (s_.own && s_.side && s_.side2 && s_.entropy && pool_limit_bytes() != 0) {
     int device = 0;
     (void)hipGetDevice(&device);
-    const int key = device * 4 + (prio + 1);
-    HandlePool& p = handle_pool();
+    const int key = device * 2 + (prio_main && stream_priorities() ? 1 : 0);
+    StreamSetPool& p = stream_set_pool();
     std::lock_guard<std::mutex> lk(p.mu);
-    if (p.streams.count(key) < 64) { p.streams.insert(std::make_pair(key, s_)); return; }
+    if (p.sets.count(key) < 16) { p.sets.insert(std::make_pair(key, s_)); return; }
   }
 #endif
-  (void)hipStreamDestroy(s_);
+  if (s_.own) (void)hipStreamDestroy(s_.own);
+  if (s_.side) (void)hipStreamDestroy(s_.side);
+  if (s_.side2) (void)hipStreamDestroy(s_.side2);
+  if (s_.entropy) (void)hipStreamDestroy(s_.entropy);
 }
 hipError_t pool_event_create(hipEvent_t* out) {
 #ifndef GZ_EMU

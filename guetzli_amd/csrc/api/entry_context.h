@@ -19,11 +19,20 @@ int gz_trim_pool(void) {
     std::lock_guard<std::mutex> lk(h.mu);
     pool_release_idle(h, true, -1);
   }
+  {
+    StreamSetPool& sp = stream_set_pool();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    for (auto& kv : sp.sets) {
+      (void)hipStreamDestroy(kv.second.own);
+      (void)hipStreamDestroy(kv.second.side);
+      (void)hipStreamDestroy(kv.second.side2);
+      (void)hipStreamDestroy(kv.second.entropy);
+    }
+    sp.sets.clear();
+  }
   HandlePool& hp = handle_pool();
   std::lock_guard<std::mutex> lk(hp.mu);
-  for (auto& kv : hp.streams) (void)hipStreamDestroy(kv.second);
   for (auto& kv : hp.events) (void)hipEventDestroy(kv.second);
-  hp.streams.clear();
   hp.events.clear();
   return GZ_OK;
 }
@@ -89,11 +98,13 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   // entropy = lowest on every context; profiles/r03_stream_priorities.log).
   c->prio_streams = live_contexts(device, +1) == 0;
   c->counted_live = true;
-  CHK0(pool_stream_create(&c->own_stream, c->prio_streams ? 1 : 0));
-  c->stream = c->own_stream;
-  CHK0(pool_stream_create(&c->side_stream));
-  CHK0(pool_stream_create(&c->side_stream2));
-  CHK0(pool_stream_create(&c->entropy_stream, 0));   // (never below default: see above)
+  {
+    StreamSet ss;
+    const hipError_t se = pool_stream_set_create(&ss, c->prio_streams);
+    c->own_stream = ss.own; c->side_stream = ss.side; c->side_stream2 = ss.side2; c->entropy_stream = ss.entropy;
+    c->stream = c->own_stream;
+    CHK0(se);
+  }
   CHK0(pool_event_create(&c->ev_candidate));
   CHK0(pool_event_create(&c->ev_fork));
   CHK0(pool_event_create(&c->ev_join));
@@ -211,9 +222,9 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->d_order_counters); (void)pool_free(c->d_next_cand); (void)pool_free(c->d_weight);
   (void)pool_free(c->d_max_err); (void)pool_free(c->d_wflag); (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);
   for (int b = 0; b < B_COUNT; ++b) (void)pool_free(c->blur[b].d_scale);
-  if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); pool_stream_destroy(c->side_stream); }
-  if (c->side_stream2) { (void)hipStreamSynchronize(c->side_stream2); pool_stream_destroy(c->side_stream2); }
-  if (c->entropy_stream) { (void)hipStreamSynchronize(c->entropy_stream); pool_stream_destroy(c->entropy_stream, 0); }
+  if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+  if (c->side_stream2) (void)hipStreamSynchronize(c->side_stream2);
+  if (c->entropy_stream) (void)hipStreamSynchronize(c->entropy_stream);
   pool_event_destroy(c->ev_candidate);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
@@ -226,7 +237,11 @@ void gz_destroy(gz_ctx* c) {
   pool_event_destroy(c->ev_lfy);
   pool_event_destroy(c->ev_fork);
   pool_event_destroy(c->ev_join);
-  pool_stream_destroy(c->own_stream, c->prio_streams ? 1 : 0);   // synchronised at the top of gz_destroy
+  {   // the four streams go back as the set they were made as (own_stream: synchronised at the top of gz_destroy)
+    StreamSet ss;
+    ss.own = c->own_stream; ss.side = c->side_stream; ss.side2 = c->side_stream2; ss.entropy = c->entropy_stream;
+    pool_stream_set_destroy(ss, c->prio_streams);
+  }
   if (c->counted_live) (void)live_contexts(c->device, -1);
   delete c;
 }

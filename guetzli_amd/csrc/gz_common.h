@@ -170,6 +170,25 @@ static __device__ __forceinline__ float gz_in_vgpr(float x) {
 #define GZ_RARE_PATH() asm volatile("; rare path")
 #endif
 
+// The value lane + D holds (D = -15..15, a constant), +0.0f where lane + D falls outside this lane's
+// row of 16 lanes: the DPP row-shift operand modifier, which the compiler folds into the consuming
+// v_mul_f32 -- a neighbour's value without LDS and without an instruction of its own.  (The emulation
+// exchanges through its wavefront slots; every thread of the workgroup must get here together.)
+template <int D>
+GZ_DEVFN float gz_row16_shift(float v) {
+  static_assert(D != 0 && D > -16 && D < 16, "gz_row16_shift: a shift inside a row of 16 lanes");
+#ifdef GZ_EMU
+  const int lane = (int)(threadIdx.x & 63), src = lane + D;
+  const int got = __shfl(__builtin_bit_cast(int, v), src & 63);
+  return src >= 0 && (src >> 4) == (lane >> 4) ? __builtin_bit_cast(float, got) : 0.0f;
+#else
+  // dpp_ctrl: row_shl:n = 0x100 + n (lane i takes lane i + n), row_shr:n = 0x110 + n (lane i - n);
+  // bound_ctrl: lanes without a source take 0
+  constexpr int ctrl = D > 0 ? 0x100 + D : 0x110 - D;
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+#endif
+}
+
 // Number of set bits of a wavefront mask (__ballot), and the mask of the lanes below this one.
 #ifdef GZ_EMU
 #define GZ_POPC64(x) __builtin_popcountll((unsigned long long)(x))

@@ -128,34 +128,43 @@ constexpr int kEvalBatch = 3;
 
 struct SearchLds {
   short coef[192];
-  unsigned char ycc[3][64];   // pixel cache of the current (processed) block (values 0..255)
-  float x0[3][64];      // original block's opsin image (per_block_pregamma_)
+  // the same coefficients transposed, [c][8 * column + row]: the eight values of a column are one
+  // 16-byte read (the IDCT's packed dot products, gz_kernels_block.h)
+  alignas(16) short coefT[192];
+  alignas(16) short col16[64];   // the IDCT's column pass, [8 * row + column]
+  // [0..2]: pixel cache of the current (processed) block (values 0..255); [3]: the changed component
+  // of the candidate being evaluated
+  unsigned char ycc[4][64];
   unsigned char list[192];
   unsigned char oidx[192];
   float oerr[192];
   union {
-    struct {            // scratch of one candidate's wide stages
-      int in[64], col[64];
-      int cpx[64];      // changed component of the candidate
-      float lin[3][64];
-      float tmp[3][64];
-    };
+    int cpx[64];        // 4:2:0 chroma search: the changed component's samples
     // |.|^2 * 0.000064 for flat indices 0..39 of a batch's candidates: written by the column
     // stage, after the batch's last wide stage is done with the scratch
     double pw[kEvalBatch][3][40];
   };
+  // row-blurred planes between the two passes of the 8x8 blur: 12 rows of 8, rows 0, 1, 10, 11 hold
+  // +0.0f for the whole kernel (blur8_init), so the column pass reads its five taps at constant offsets
+  float tmp[3][96];
   // per candidate of the batch: opsin differences; after the row stage their row transforms in
   // place, 8 doubles per row: F0.re, F4.re, F1, F2, F3 (F0, F4 of a real row are real)
   double d[kEvalBatch][3][64];
   double red[kEvalBatch][3];
   float err[kEvalBatch];
   int num;
+#ifdef GZ_SEARCH_LDS_PAD
+  char pad[GZ_SEARCH_LDS_PAD];   // (experiment: fewer wavefronts per CU)
+#endif
 };
-// Round 4 took the struct from 12 672 to 10 064 bytes (160 KB / 16 wavefronts = 10 240): the sRGB
-// table is read from global memory (three L1-resident loads per evaluation instead of three LDS
-// reads at random banks), the pixel cache holds bytes, and what only the 4:2:0 chroma search needs
-// lives in a struct of its own.  k_block_search<0>: 10.0 -> 8.9 ms at 1080p, 34 -> 30.9 ms at 4K.
-static_assert(sizeof(SearchLds) <= 10240 - 64, "k_block_search: keep a wavefront's LDS below 10 KB");
+// Round 4 took the struct from 12 672 to 10 064 bytes: the sRGB table is read from global memory (three
+// L1-resident loads per evaluation instead of three LDS reads at random banks), the pixel cache holds
+// bytes, and what only the 4:2:0 chroma search needs lives in a struct of its own.  Round 5: the
+// original's opsin image and the candidate's linear RGB live in registers; the blur's plane between its
+// passes carries four rows of zeros, the coefficients are kept transposed as well (11 040 bytes).  The
+// kernel runs three wavefronts per SIMD (its registers; capped at 128 registers for four it was 5 %
+// slower, profiles/r04_occupancy_experiments.log), which 13.3 KB each still allow.
+static_assert(sizeof(SearchLds) <= 160 * 1024 / 12, "k_block_search: three wavefronts per SIMD need <= 13.3 KB each");
 
 // 4:2:0 chroma search only (MODE 2): the 10x10 subsampled samples around the 16x16 block
 // (UpdatePixelsForBlock's `subsampled`, output_image.cc:150-183) per chroma component.
@@ -165,53 +174,94 @@ struct SearchLds420 {
   short cellsrc[ON ? 100 : 2];   // >= 0: the cell is sample cellsrc of the block itself; -1: a neighbour's
 };
 
-// Integer IDCT of s.coef[c] with coefficient `zero_k` forced to 0 (or -1: none); result of
-// this lane's pixel returned, and left in `dst[lane]` after the trailing barrier.
+// Integer IDCT of component c with coefficient `zero_k` forced to 0 (or -1: none); the result of
+// this lane's pixel is left in `dst[lane]` after the trailing barrier.  Both passes as four packed
+// 16-bit dot products per output (idct_dot8; the same integers as eight multiply-adds).
 template <class T>
 GZ_DEVFN void idct_component(SearchLds& s, int c, int zero_k, int lane, T* dst) {
   const int iy = lane >> 3, ix = lane & 7;
-  s.in[lane] = lane == zero_k ? 0 : (int)s.coef[64 * c + lane];
+  const gz_u4 m_row = gz_load_u4(&kIdctMP[4 * iy]), m_col = gz_load_u4(&kIdctMP[4 * ix]);
+  const int zt = ((zero_k & 7) << 3) | ((zero_k >> 3) & 7);   // its place in the transposed block
+  if (lane == 0 && zero_k >= 0) s.coefT[64 * c + zt] = 0;
   __syncthreads();
-  int acc = 0;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s.in[8 * u + ix]);
-  s.col[lane] = (int)(short)((acc + (1 << 10)) >> 11);
+  // column pass (idct.cc:143-149): colidcts[8*y+x] = int16((sum + 2^10) >> 11)
+  const gz_u4 q = gz_load_u4(&s.coefT[64 * c + 8 * ix]);
+  s.col16[lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
   __syncthreads();
-  acc = 0;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s.col[8 * iy + u]);
-  dst[lane] = (T)clamp255((acc + (257 << 17)) >> 18);
+  if (lane == 0 && zero_k >= 0) s.coefT[64 * c + zt] = s.coef[64 * c + zero_k];   // (every lane has read it)
+  // row pass (idct.cc:150-160): out = clamp((sum + (257 << 17)) >> 18)
+  const gz_u4 r = gz_load_u4(&s.col16[8 * iy]);
+  dst[lane] = (T)clamp255((idct_dot8(m_col, r) + (257 << 17)) >> 18);
   __syncthreads();
 }
 
-// 5-tap blur along one axis of the 8x8 tile held in `src` (Convolution on an 8-wide image:
-// positions 2..5 interior, 0,1,6,7 border).
-GZ_DEVFN float blur8(const float* src, int pos, int base, int stride, const SearchArgs& a) {
-  float sum = 0.0f;
-  if (pos >= 2 && pos < 6) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) sum += src[base + (pos - 2 + j) * stride] * a.taps.ks[j];
-    return sum;
-  }
+// The 8x8 window's blur (Convolution on an 8-wide image: positions 2..5 interior -- pre-scaled taps --,
+// 0, 1, 6, 7 border -- raw taps of the samples inside, times a scale) without a branch: every lane
+// holds its five weights per axis (a tap that falls outside the window gets weight +0.0f: the
+// samples are finite and non-negative, so its product is +0.0f and adding it changes nothing) and
+// its scale (1.0f inside: exact).  The sums run in the reference's order, from 0.0f.
+struct Blur8 {
+  float wx[5], wy[5], sx, sy;
+};
+GZ_DEVFN void blur8_axis(int pos, const SearchArgs& a, float* w, float* scale) {
+  const bool interior = pos >= 2 && pos < 6;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int p = pos - 2 + j;
-    if (p >= 0 && p < 8) sum += src[base + p * stride] * a.taps.k[j];
+    w[j] = interior ? a.taps.ks[j] : (p >= 0 && p < 8 ? a.taps.k[j] : 0.0f);
   }
-  return sum * (pos < 2 ? a.scale_lo[pos] : a.scale_hi[7 - pos]);
+  // (selected, not indexed: an array indexed by the lane would be fetched from memory)
+  const float lo = pos == 0 ? a.scale_lo[0] : a.scale_lo[1];
+  const float hi = pos == 7 ? a.scale_hi[0] : a.scale_hi[1];
+  *scale = interior ? 1.0f : (pos < 2 ? lo : hi);
+}
+GZ_DEVFN Blur8 blur8_init(SearchLds& s, int lane, const SearchArgs& a) {
+  Blur8 w;
+  blur8_axis(lane & 7, a, w.wx, &w.sx);
+  blur8_axis(lane >> 3, a, w.wy, &w.sy);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    w.wx[j] = GZ_IN_VGPR(w.wx[j]);
+    w.wy[j] = GZ_IN_VGPR(w.wy[j]);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      s.tmp[c][lane] = 0.0f;        // rows 0, 1
+      s.tmp[c][80 + lane] = 0.0f;   // rows 10, 11
+    }
+  }
+  return w;
+}
+// Row pass: the neighbours of a pixel sit in the neighbouring lanes (8 pixels of a row = 8
+// consecutive lanes), so the taps come through the lane-shift operand of the multiply, not LDS.
+GZ_DEVFN float blur8_row(float v, const Blur8& w) {
+  float sum = 0.0f;
+  sum += gz_row16_shift<-2>(v) * w.wx[0];
+  sum += gz_row16_shift<-1>(v) * w.wx[1];
+  sum += v * w.wx[2];
+  sum += gz_row16_shift<1>(v) * w.wx[3];
+  sum += gz_row16_shift<2>(v) * w.wx[4];
+  return sum * w.sx;
+}
+GZ_DEVFN float blur8_col(const float* t, int lane, const Blur8& w) {
+  float sum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) sum += t[lane + 8 * j] * w.wy[j];
+  return sum * w.sy;
 }
 
-// 8x8 OpsinDynamicsImage of s.lin -> this lane's (x, y, b).
-GZ_DEVFN void opsin8x8(SearchLds& s, int lane, const SearchArgs& a, float* ox, float* oy,
-                       float* ob) {
-  const int iy = lane >> 3, ix = lane & 7;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) s.tmp[c][lane] = blur8(s.lin[c], ix, 8 * iy, 1, a);
+// 8x8 OpsinDynamicsImage of this lane's linear (r, g, b) and its window -> this lane's (x, y, b).
+GZ_DEVFN void opsin8x8(SearchLds& s, int lane, const Blur8& w, float r, float g, float bl,
+                       float* ox, float* oy, float* ob) {
+  s.tmp[0][16 + lane] = blur8_row(r, w);
+  s.tmp[1][16 + lane] = blur8_row(g, w);
+  s.tmp[2][16 + lane] = blur8_row(bl, w);
   __syncthreads();
   float b[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) b[c] = blur8(s.tmp[c], iy, ix, 8, a);
-  opsin_pixel(b[0], b[1], b[2], s.lin[0][lane], s.lin[1][lane], s.lin[2][lane], ox, oy, ob);
+  for (int c = 0; c < 3; ++c) b[c] = blur8_col(s.tmp[c], lane, w);
+  opsin_pixel(b[0], b[1], b[2], r, g, bl, ox, oy, ob);
   __syncthreads();
 }
 
@@ -236,6 +286,30 @@ GZ_DEVFN int upsampled_pixel(const int* s10, int lx, int ly) {
   return (p + 8 - (lx & 1)) >> 4;
 }
 
+// What a lane keeps for the whole search of its block: the blur's weights and the original block's
+// opsin image at its pixel (per_block_pregamma_, widened once).
+struct SearchLane {
+  Blur8 w;
+  double x0[3];
+};
+// SwitchBlock (butteraugli_comparator.cc:427-455): the original block, clamped gather.
+GZ_DEVFN SearchLane search_lane_init(SearchLds& s, int lane, int xmin, int ymin, const SearchArgs& a) {
+  SearchLane L;
+  L.w = blur8_init(s, lane, a);
+  const int iy = lane >> 3, ix = lane & 7;
+  const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
+  const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
+  const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
+  __syncthreads();   // (the blur's zero rows)
+  float x0, y0, z0;
+  opsin8x8(s, lane, L.w, GZ_LDG(a.srgb_lut, p[0]), GZ_LDG(a.srgb_lut, p[1]), GZ_LDG(a.srgb_lut, p[2]),
+           &x0, &y0, &z0);
+  L.x0[0] = (double)x0;
+  L.x0[1] = (double)y0;
+  L.x0[2] = (double)z0;
+  return L;
+}
+
 // What differs between the three searches.
 //   MODE 0: 4:4:4 frame (any component mask: the candidate list decides) -- 8x8 grid
 //   MODE 1: 4:2:0 frame, luma candidates -- 8x8 grid, chroma pixels fixed
@@ -253,39 +327,39 @@ struct SearchView {
 // (= c*64+k) zeroed: the opsin differences of the candidate go to s.d[slot].
 template <int MODE>
 GZ_DEVFN void eval_wide(SearchLds& s, SearchLds420<MODE == 2>& q, int ci, int slot, int lane,
-                        const SearchView& v, const int* ring, const SearchArgs& a) {
+                        const SearchView& v, const SearchLane& L, const int* ring, const SearchArgs& a) {
   // ci == 64 * 3: nothing zeroed (the luma component is simply recomputed)
   const int cc = ci >= 192 ? 0 : ci >> 6, kk = ci >= 192 ? -1 : ci & 63;
-  idct_component(s, cc, kk, lane, s.cpx);
   // edge replication + colour + LUT
   const int iy = lane >> 3, ix = lane & 7;
   const int sx = ix < v.vw ? ix : v.vw - 1, sy = iy < v.vh ? iy : v.vh - 1;
   const int sp = 8 * sy + sx;
   int py, pcb, pcr;
   if constexpr (MODE == 2) {
+    idct_component(s, cc, kk, lane, s.cpx);
     fill_s10(q, cc, s.cpx, ring + 100 * (cc - 1), lane);
     const int px = upsampled_pixel(q.s10[cc - 1], 8 * v.off_x + sx, 8 * v.off_y + sy);
     py = s.ycc[0][sp];
     pcb = (cc == 1 ? px : s.ycc[1][sp]) - 128;
     pcr = (cc == 2 ? px : s.ycc[2][sp]) - 128;
   } else {
-    py = cc == 0 ? s.cpx[sp] : s.ycc[0][sp];
-    pcb = (cc == 1 ? s.cpx[sp] : s.ycc[1][sp]) - 128;
-    pcr = (cc == 2 ? s.cpx[sp] : s.ycc[2][sp]) - 128;
+    // the changed component into plane 3 of the pixel cache; which plane a channel reads is a
+    // wavefront-uniform offset (no branch, one byte read each)
+    idct_component(s, cc, kk, lane, s.ycc[3]);
+    const unsigned char* px = &s.ycc[0][0];
+    py = px[(cc == 0 ? 192 : 0) + sp];
+    pcb = (int)px[(cc == 1 ? 192 : 64) + sp] - 128;
+    pcr = (int)px[(cc == 2 ? 192 : 128) + sp] - 128;
   }
   const int half = 1 << 15;
   const int r = clamp255(py + ((GZ_MUL24(91881, pcr) + half) >> 16));
   const int g = clamp255(py + ((GZ_MUL24(-46802, pcr) + (GZ_MUL24(-22554, pcb) + half)) >> 16));
   const int b = clamp255(py + ((GZ_MUL24(116130, pcb) + half) >> 16));
-  s.lin[0][lane] = GZ_LDG(a.srgb_lut, r);
-  s.lin[1][lane] = GZ_LDG(a.srgb_lut, g);
-  s.lin[2][lane] = GZ_LDG(a.srgb_lut, b);
-  __syncthreads();
   float x, y, z;
-  opsin8x8(s, lane, a, &x, &y, &z);
-  s.d[slot][0][lane] = (double)s.x0[0][lane] - (double)x;
-  s.d[slot][1][lane] = (double)s.x0[1][lane] - (double)y;
-  s.d[slot][2][lane] = (double)s.x0[2][lane] - (double)z;
+  opsin8x8(s, lane, L.w, GZ_LDG(a.srgb_lut, r), GZ_LDG(a.srgb_lut, g), GZ_LDG(a.srgb_lut, b), &x, &y, &z);
+  s.d[slot][0][lane] = L.x0[0] - (double)x;
+  s.d[slot][1][lane] = L.x0[1] - (double)y;
+  s.d[slot][2][lane] = L.x0[2] - (double)z;
   __syncthreads();
 }
 
@@ -391,27 +465,21 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64, 3) void k_block_search(Search
   const int iy = lane >> 3, ix = lane & 7;
   for (int c = 0; c < 3; ++c) {
     const bool mine = MODE == 0 || (MODE == 1 && c == 0) || (MODE == 2 && c > 0);
-    s.coef[64 * c + lane] = mine ? a.coeffs[((size_t)a.coff[c] + blk) * 64 + lane] : (short)0;
+    short cv = mine ? a.coeffs[((size_t)a.coff[c] + blk) * 64 + lane] : (short)0;
+    if (MODE == 2 && c == 0) {
+      // the luma block under this wavefront's 8x8 sub-block (fixed during the chroma search; no
+      // candidate of this mode names component 0)
+      const int lb = v.in_image ? by * a.bw + bx : 0;
+      cv = a.coeffs[((size_t)a.coff[0] + lb) * 64 + lane];
+    }
+    s.coef[64 * c + lane] = cv;
+    s.coefT[64 * c + 8 * ix + iy] = cv;
   }
   const size_t r0 = (size_t)blk * 192;
   int n = a.rank_cnt[blk];
   for (int i = lane; i < n; i += 64) s.list[i] = a.rank_idx[r0 + i];
   __syncthreads();
-  // SwitchBlock (butteraugli_comparator.cc:427-455): original block, clamped gather
-  {
-    const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
-    const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
-    const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
-    s.lin[0][lane] = GZ_LDG(a.srgb_lut, p[0]);
-    s.lin[1][lane] = GZ_LDG(a.srgb_lut, p[1]);
-    s.lin[2][lane] = GZ_LDG(a.srgb_lut, p[2]);
-    __syncthreads();
-    float x0, y0, z0;
-    opsin8x8(s, lane, a, &x0, &y0, &z0);
-    s.x0[0][lane] = x0;
-    s.x0[1][lane] = y0;
-    s.x0[2][lane] = z0;
-  }
+  const SearchLane L = search_lane_init(s, lane, xmin, ymin, a);
   const int mxs = (a.w - 1) >> 1, mys = (a.h - 1) >> 1;
   if constexpr (MODE == 0) {
     for (int c = 0; c < 3; ++c) idct_component(s, c, -1, lane, s.ycc[c]);
@@ -425,22 +493,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64, 3) void k_block_search(Search
     s.ycc[2][lane] = (unsigned char)chroma420_pixel(a.samples + pl, sw, mxs, mys, x, y);
     __syncthreads();
   } else {
-    // luma pixels of this wavefront's 8x8 sub-block (fixed during the chroma search)
-    {
-      const int lb = v.in_image ? by * a.bw + bx : 0;
-      s.in[lane] = (int)a.coeffs[((size_t)a.coff[0] + lb) * 64 + lane];
-      __syncthreads();
-      int acc = 0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * iy + u], s.in[8 * u + ix]);
-      s.col[lane] = (int)(short)((acc + (1 << 10)) >> 11);
-      __syncthreads();
-      acc = 0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += GZ_MUL24(kIdctM[8 * ix + u], s.col[8 * iy + u]);
-      s.ycc[0][lane] = (unsigned char)clamp255((acc + (257 << 17)) >> 18);
-      __syncthreads();
-    }
+    idct_component(s, 0, -1, lane, s.ycc[0]);   // luma pixels of this wavefront's 8x8 sub-block
     // the 10x10 neighbourhood: which cells are the block's own samples (after the replication
     // rules, i.e. clamping the sample coordinates into the image), and the others' values
     const int sw = a.cbw * 8;
@@ -478,7 +531,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64, 3) void k_block_search(Search
     const int tries = n < a.lookahead ? n : a.lookahead;
     for (int base = 0; base < tries; base += kEvalBatch) {
       const int nc = tries - base < kEvalBatch ? tries - base : kEvalBatch;
-      for (int j = 0; j < nc; ++j) eval_wide<MODE>(s, q, (int)s.list[base + j], j, lane, v, s_ring, a);
+      for (int j = 0; j < nc; ++j) eval_wide<MODE>(s, q, (int)s.list[base + j], j, lane, v, L, s_ring, a);
       eval_narrow(s, nc, lane, v);
       if (MODE == 2) {
         if (lane < nc) s_err[lane][wave] = v.in_image ? s.err[lane] : 0.0f;
@@ -503,6 +556,7 @@ __global__ __launch_bounds__(MODE == 2 ? 256 : 64, 3) void k_block_search(Search
     __syncthreads();
     if (lane == 0) {
       s.coef[ci] = 0;
+      s.coefT[(ci & 192) + ((ci & 7) << 3) + ((ci >> 3) & 7)] = 0;
       s.oidx[m] = (unsigned char)ci;
       s.oerr[m] = best_err;
     }
@@ -561,23 +615,13 @@ __global__ __launch_bounds__(64) void k_compare_blocks(SearchArgs a, const int32
   const int i = blockIdx.x, lane = threadIdx.x;
   const int bx = block_xy[2 * i], by = block_xy[2 * i + 1];
   const int xmin = 8 * bx, ymin = 8 * by;
-  const int iy = lane >> 3, ix = lane & 7;
-  for (int c = 0; c < 3; ++c) s.coef[64 * c + lane] = blocks[((size_t)i * 3 + c) * 64 + lane];
-  __syncthreads();
-  {
-    const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
-    const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
-    const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
-    s.lin[0][lane] = GZ_LDG(a.srgb_lut, p[0]);
-    s.lin[1][lane] = GZ_LDG(a.srgb_lut, p[1]);
-    s.lin[2][lane] = GZ_LDG(a.srgb_lut, p[2]);
-    __syncthreads();
-    float x0, y0, z0;
-    opsin8x8(s, lane, a, &x0, &y0, &z0);
-    s.x0[0][lane] = x0;
-    s.x0[1][lane] = y0;
-    s.x0[2][lane] = z0;
+  for (int c = 0; c < 3; ++c) {
+    const short cv = blocks[((size_t)i * 3 + c) * 64 + lane];
+    s.coef[64 * c + lane] = cv;
+    s.coefT[64 * c + 8 * (lane & 7) + (lane >> 3)] = cv;
   }
+  __syncthreads();
+  const SearchLane L = search_lane_init(s, lane, xmin, ymin, a);
   for (int c = 1; c < 3; ++c) idct_component(s, c, -1, lane, s.ycc[c]);
   SearchView v;
   v.off_x = v.off_y = 0;
@@ -590,7 +634,7 @@ __global__ __launch_bounds__(64) void k_compare_blocks(SearchArgs a, const int32
   v.m2 = a.block_mask[2 * a.nb + mb];
   // candidate index 192: the luma component is recomputed with no coefficient zeroed
   SearchLds420<false> q;   // (unused by this mode)
-  eval_wide<0>(s, q, 192, 0, lane, v, nullptr, a);
+  eval_wide<0>(s, q, 192, 0, lane, v, L, nullptr, a);
   eval_narrow(s, 1, lane, v);
   if (lane == 0) {
     double diff = 0.0;
@@ -613,34 +657,16 @@ __global__ __launch_bounds__(64) void k_compare_block_pixels(SearchArgs a, const
   const int i = blockIdx.x, lane = threadIdx.x;
   const int bx = block_xy[2 * i], by = block_xy[2 * i + 1];
   const int xmin = 8 * bx, ymin = 8 * by;
-  const int iy = lane >> 3, ix = lane & 7;
-  {
-    const int x = xmin + ix < a.w - 1 ? xmin + ix : a.w - 1;
-    const int y = ymin + iy < a.h - 1 ? ymin + iy : a.h - 1;
-    const uint8_t* p = a.rgb + ((size_t)y * a.w + x) * 3;
-    s.lin[0][lane] = GZ_LDG(a.srgb_lut, p[0]);
-    s.lin[1][lane] = GZ_LDG(a.srgb_lut, p[1]);
-    s.lin[2][lane] = GZ_LDG(a.srgb_lut, p[2]);
-    __syncthreads();
-    float x0, y0, z0;
-    opsin8x8(s, lane, a, &x0, &y0, &z0);
-    s.x0[0][lane] = x0;
-    s.x0[1][lane] = y0;
-    s.x0[2][lane] = z0;
-  }
+  const SearchLane L = search_lane_init(s, lane, xmin, ymin, a);
   {
     const uint8_t* p = ycc + (size_t)i * 192;
     int r, g, b;
     ycc_to_rgb((int)p[lane], (int)p[64 + lane], (int)p[128 + lane], &r, &g, &b);
-    s.lin[0][lane] = GZ_LDG(a.srgb_lut, r);
-    s.lin[1][lane] = GZ_LDG(a.srgb_lut, g);
-    s.lin[2][lane] = GZ_LDG(a.srgb_lut, b);
-    __syncthreads();
     float x, y, z;
-    opsin8x8(s, lane, a, &x, &y, &z);
-    s.d[0][0][lane] = (double)s.x0[0][lane] - (double)x;
-    s.d[0][1][lane] = (double)s.x0[1][lane] - (double)y;
-    s.d[0][2][lane] = (double)s.x0[2][lane] - (double)z;
+    opsin8x8(s, lane, L.w, GZ_LDG(a.srgb_lut, r), GZ_LDG(a.srgb_lut, g), GZ_LDG(a.srgb_lut, b), &x, &y, &z);
+    s.d[0][0][lane] = L.x0[0] - (double)x;
+    s.d[0][1][lane] = L.x0[1] - (double)y;
+    s.d[0][2][lane] = L.x0[2] - (double)z;
     __syncthreads();
   }
   SearchView v;

@@ -286,6 +286,7 @@ struct gz_ctx {
   bool have_block_mask = false;
   int32_t* d_rank_cnt = nullptr; uint8_t* d_rank_idx = nullptr; float* d_rank_tables = nullptr;
   int32_t* d_out_cnt = nullptr; uint8_t* d_out_idx = nullptr; float* d_out_err = nullptr;
+  int32_t* d_csr_off = nullptr;   // the search's CSR offsets (k_csr_offsets); the packed indices reuse d_rank_idx
 
   // device entropy coder (gz_kernels_entropy.h)
   int* d_jq = nullptr;                    // [3][64] quant matrices of the frame being written

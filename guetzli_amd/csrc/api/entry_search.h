@@ -51,6 +51,7 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
     HIPCHK(c, pool_malloc((void**)&c->d_out_cnt, sizeof(int32_t) * nb));
     HIPCHK(c, pool_malloc((void**)&c->d_out_idx, (size_t)nb * 192));
     HIPCHK(c, pool_malloc((void**)&c->d_out_err, sizeof(float) * nb * 192));
+    HIPCHK(c, pool_malloc((void**)&c->d_csr_off, sizeof(int32_t) * ((size_t)nb + 1)));
     HIPCHK(c, hipMemcpyAsync(c->d_rank_tables, kOrderCsf, sizeof(float) * 192, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_rank_tables + 192, kOrderBias, sizeof(float) * 192, hipMemcpyHostToDevice, c->stream));
   }
@@ -94,25 +95,26 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
   else GZ_LAUNCH(k_block_search<2>, dim3(gn), dim3(256), c->stream, a);
   KCHK(c);
   c->have_search = true;
-  c->search_total = 0;   // set below, once the counts are on the host
-  std::vector<int32_t> cnt(gn), rcnt(gn);
+  c->search_total = 0;   // set below, once the offsets are on the host
+  // The CSR arrays are made on the device (offsets = scan of the counts, indices packed into the
+  // ranked lists' buffer, which the search is done with): the host copies what the caller takes.
+  GZ_LAUNCH(k_csr_offsets, dim3(1), dim3(1024), c->stream, (const int32_t*)c->d_out_cnt, gn, c->d_csr_off);
+  KCHK(c);
+  GZ_LAUNCH(k_csr_pack, dim3(gz_div_up(gn, 4)), dim3(256), c->stream, (const int32_t*)c->d_out_cnt,
+            (const int32_t*)c->d_csr_off, (const uint8_t*)c->d_out_idx, gn, c->d_rank_idx);
+  KCHK(c);
+  std::vector<int32_t> rcnt(gn);
   HIPCHK(c, hipMemcpyAsync(rcnt.data(), c->d_rank_cnt, sizeof(int32_t) * gn, hipMemcpyDeviceToHost, c->stream));
-  std::vector<uint8_t> widx((size_t)gn * 192);
-  std::vector<float> werr(err ? (size_t)gn * 192 : 0);   // the errors stay on the device for gz_order_build
-  HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_out_cnt, sizeof(int32_t) * gn, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(widx.data(), c->d_out_idx, (size_t)gn * 192, hipMemcpyDeviceToHost, c->stream));
-  if (err)
-    HIPCHK(c, hipMemcpyAsync(werr.data(), c->d_out_err, sizeof(float) * gn * 192, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(offsets, c->d_csr_off, sizeof(int32_t) * ((size_t)gn + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  long total = 0;
-  for (int b = 0; b < gn; ++b) total += cnt[b];
+  const long total = offsets[gn];
   c->search_total = (size_t)total;
-  // evaluations: step s of a block with n candidates compares min(lookahead, n - s) of them, on
-  // every 8x8 block of its area that lies inside the image
+  // evaluations: step s of a block with n candidates compares min(lookahead, n - s) of them (summed in
+  // closed form), on every 8x8 block of its area that lies inside the image
   c->search_evaluations = 0;
   for (int b = 0; b < gn; ++b) {
-    unsigned long long e = 0;
-    for (int s2 = 0; s2 < rcnt[b]; ++s2) e += (unsigned long long)std::min(lookahead, rcnt[b] - s2);
+    const unsigned long long n = (unsigned long long)rcnt[b], la = (unsigned long long)lookahead;
+    const unsigned long long e = n >= la ? la * (n - la + 1) + la * (la - 1) / 2 : n * (n + 1) / 2;
     int sub = 1;
     if (mode == 2) {
       const int bx = b % c->cbw, by = b / c->cbw;
@@ -120,15 +122,17 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
     }
     c->search_evaluations += e * sub;
   }
-  if (total > cap) { c->err = "candidate capacity too small, need " + std::to_string(total); offsets[gn] = (int32_t)total; return GZ_E_ARG; }
-  int t = 0;
-  for (int b = 0; b < gn; ++b) {
-    offsets[b] = t;
-    memcpy(idx + t, widx.data() + (size_t)b * 192, cnt[b]);
-    if (err) memcpy(err + t, werr.data() + (size_t)b * 192, sizeof(float) * cnt[b]);
-    t += cnt[b];
+  if (total > cap) { c->err = "candidate capacity too small, need " + std::to_string(total); return GZ_E_ARG; }
+  if (total > 0)
+    HIPCHK(c, hipMemcpyAsync(idx, c->d_rank_idx, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+  if (err) {   // (tests and the stand-alone ABI; the encoder leaves the errors on the device)
+    std::vector<float> werr((size_t)gn * 192);
+    HIPCHK(c, hipMemcpyAsync(werr.data(), c->d_out_err, sizeof(float) * gn * 192, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < gn; ++b)
+      memcpy(err + offsets[b], werr.data() + (size_t)b * 192, sizeof(float) * (size_t)(offsets[b + 1] - offsets[b]));
   }
-  offsets[gn] = t;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return GZ_OK;
 }
 

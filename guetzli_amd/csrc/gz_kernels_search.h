@@ -138,17 +138,13 @@ struct SearchLds {
   unsigned char list[192];
   unsigned char oidx[192];
   float oerr[192];
-  union {
-    int cpx[64];        // 4:2:0 chroma search: the changed component's samples
-    // |.|^2 * 0.000064 for flat indices 0..39 of a batch's candidates: written by the column
-    // stage, after the batch's last wide stage is done with the scratch
-    double pw[kEvalBatch][3][40];
-  };
+  int cpx[64];          // 4:2:0 chroma search: the changed component's samples
   // row-blurred planes between the two passes of the 8x8 blur: 12 rows of 8, rows 0, 1, 10, 11 hold
   // +0.0f for the whole kernel (blur8_init), so the column pass reads its five taps at constant offsets
   float tmp[3][96];
   // per candidate of the batch: opsin differences; after the row stage their row transforms in
-  // place, 8 doubles per row: F0.re, F4.re, F1, F2, F3 (F0, F4 of a real row are real)
+  // place, 8 doubles per row: F0.re, F4.re, F1, F2, F3 (F0, F4 of a real row are real); after the
+  // column stage |.|^2 * 0.000064 for flat indices 0..39 at the front of each plane
   double d[kEvalBatch][3][64];
   double red[kEvalBatch][3];
   float err[kEvalBatch];
@@ -161,10 +157,9 @@ struct SearchLds {
 // L1-resident loads per evaluation instead of three LDS reads at random banks), the pixel cache holds
 // bytes, and what only the 4:2:0 chroma search needs lives in a struct of its own.  Round 5: the
 // original's opsin image and the candidate's linear RGB live in registers; the blur's plane between its
-// passes carries four rows of zeros, the coefficients are kept transposed as well (11 040 bytes).  The
-// kernel runs three wavefronts per SIMD (its registers; capped at 128 registers for four it was 5 %
-// slower, profiles/r04_occupancy_experiments.log), which 13.3 KB each still allow.
-static_assert(sizeof(SearchLds) <= 160 * 1024 / 12, "k_block_search: three wavefronts per SIMD need <= 13.3 KB each");
+// passes carries four rows of zeros, the coefficients are kept transposed as well, and the column
+// stage's power terms replace its input in place (8 416 bytes: LDS no longer decides the occupancy).
+static_assert(sizeof(SearchLds) <= 160 * 1024 / 16, "k_block_search: four wavefronts per SIMD need <= 10 KB each");
 
 // 4:2:0 chroma search only (MODE 2): the 10x10 subsampled samples around the 16x16 block
 // (UpdatePixelsForBlock's `subsampled`, output_image.cc:150-183) per chroma component.
@@ -391,6 +386,7 @@ GZ_DEVFN void eval_narrow(SearchLds& s, int nc, int lane, const SearchView& v) {
   }
   __syncthreads();
   // column stage: task -> (slot, channel, transposed row k)
+  double pw8[8];
   if (lane < 15 * nc) {
     const int sl = lane / 15, r = lane - 15 * sl;
     const int ch = r / 5, k = r - 5 * ch;
@@ -411,14 +407,20 @@ GZ_DEVFN void eval_narrow(SearchLds& s, int nc, int lane, const SearchView& v) {
     }
 #pragma unroll
     for (int x2 = 0; x2 < 8; ++x2) {
-      double pv = F[x2].re * F[x2].re + F[x2].im * F[x2].im;
-      pv = pv * 0.000064;
-      s.pw[sl][ch][8 * k + x2] = pv;
+      const double pv = F[x2].re * F[x2].re + F[x2].im * F[x2].im;
+      pw8[x2] = pv * 0.000064;
     }
+  }
+  __syncthreads();   // (every column task has read its plane)
+  if (lane < 15 * nc) {
+    const int sl = lane / 15, r = lane - 15 * sl;
+    const int ch = r / 5, k = r - 5 * ch;
+#pragma unroll
+    for (int x2 = 0; x2 < 8; ++x2) s.d[sl][ch][8 * k + x2] = pw8[x2];
   }
   __syncthreads();
   if (lane < 3 * nc) {
-    const double* pw = s.pw[slot9][ch9];
+    const double* pw = s.d[slot9][ch9];
     double acc = dc_term;   // diff_xyb[c] starts at 0.0: 0.0 + 4*avg*avg
     for (int i = 4; i < 37; ++i) acc += kCsf8x8[i] * pw[i];
     s.red[slot9][ch9] = acc;
@@ -685,6 +687,42 @@ __global__ __launch_bounds__(64) void k_compare_block_pixels(SearchArgs a, const
     diff += s.red[0][2] * (double)v.m2;
     out[i] = sqrt(diff);
   }
+}
+
+// The search's result as the CSR arrays the caller takes (offsets + packed candidate indices), made on
+// the device: the host then copies `total` bytes instead of 192 per block and compacts nothing.
+// k_csr_offsets: exclusive scan of n counts by ONE workgroup of 1024 threads, off[0..n].
+__global__ __launch_bounds__(1024) void k_csr_offsets(const int32_t* __restrict__ cnt, int n,
+                                                      int32_t* __restrict__ off) {
+  __shared__ int s_part[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += cnt[i];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = t >= d ? s_part[t - d] : 0;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  int run = s_part[t] - sum;
+  for (int i = lo; i < hi; ++i) {
+    off[i] = run;
+    run += cnt[i];
+  }
+  if (t == 1023) off[n] = s_part[1023];
+}
+// one wavefront per block: its cnt[b] candidate indices to out[off[b]..]
+__global__ __launch_bounds__(256) void k_csr_pack(const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
+                                                  const uint8_t* __restrict__ idx192, int n,
+                                                  uint8_t* __restrict__ out) {
+  const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= n) return;
+  const int c = cnt[b], o = off[b];
+  for (int i = lane; i < c; i += 64) out[o + i] = idx192[(size_t)b * 192 + i];
 }
 
 // Picks mask planes at block corners: out[c][blk] = mask[c](8*by, 8*bx).

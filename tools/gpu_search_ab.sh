@@ -20,3 +20,10 @@ for rep in 1 2; do
 done
 } 2>&1 | tee $O/variants.log
 cp /tmp/lib_orig.so guetzli_amd/libguetzli_amd.so
+# counters of the tree's library (VALU instructions per evaluation, busy / wait cycles)
+R=$(pwd); export TMPDIR=/tmp
+( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $R/$O/search_sq -- python $R/tools/run_search.py 1920 1080 ) > $O/search_sq.log 2>&1
+python tools/pmc_summary.py $O/search_sq | grep -i "block_search\|^kernel" | tee $O/block_search_pmc.csv
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/search_trace -- python $R/tools/run_search.py 3840 2160 ) > $O/search_trace.log 2>&1
+f=$(find $O/search_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { grep -i "search\|rank\|csr\|Name" $f | cut -d, -f1-4 | sed 's/gz:://g' | cut -c1-110 | tee $O/search_kernel_stats.txt; }
+rm -rf $O/search_sq $O/search_trace

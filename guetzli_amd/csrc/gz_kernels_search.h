@@ -159,7 +159,9 @@ struct SearchLds {
 // original's opsin image and the candidate's linear RGB live in registers; the blur's plane between its
 // passes carries four rows of zeros, the coefficients are kept transposed as well, and the column
 // stage's power terms replace its input in place (8 416 bytes: LDS no longer decides the occupancy).
+#ifndef GZ_SEARCH_LDS_PAD
 static_assert(sizeof(SearchLds) <= 160 * 1024 / 16, "k_block_search: four wavefronts per SIMD need <= 10 KB each");
+#endif
 
 // 4:2:0 chroma search only (MODE 2): the 10x10 subsampled samples around the 16x16 block
 // (UpdatePixelsForBlock's `subsampled`, output_image.cc:150-183) per chroma component.
@@ -437,12 +439,14 @@ GZ_DEVFN void eval_narrow(SearchLds& s, int nc, int lane, const SearchView& v) {
 }
 
 // grid = one workgroup per block of the search grid; 64 threads (MODE 0, 1) or 256 (MODE 2).
-// (Round 4: capped at 128 VGPRs -- four wavefronts per SIMD, which the 10 KB of LDS allow -- the
-// kernel is 5 % SLOWER than at its natural 137 / three per SIMD: 9.42 vs 8.89 ms at 1080p, 32.4 vs
-// 30.9 ms at 4K, profiles/r04_occupancy_experiments.log.  It is bound by the FP64 chains it issues,
-// not by the latency more wavefronts would hide -- hence the explicit 3.)
+// Occupancy decides: the same code at 12 / 14 / 16 wavefronts per CU (LDS padded) runs 27.0 / 23.0 / 22.2 ms
+// at 4K (profiles/r05_block_search_variants.log; round 4's kernel: 30.9 at 12) -- hence at most 128
+// registers for MODE 0 / 1 (they take 126 / 120 unforced) and a wavefront's LDS below 10 KB.  (Round 4's
+// kernel, capped at 128 registers, was 5 % slower at 16 than at 12: it spilled into longer chains.)
+// The sRGB table in LDS instead of L1: 22.7 ms, not kept.  MODE 2 (four wavefronts per block, 144 registers
+// unforced): capped at 128 it spills nine registers and is still faster, 23.4 -> 20.6 ms for a 4K 4:2:0 frame.
 template <int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 256 : 64, 3) void k_block_search(SearchArgs a) {
+__global__ __launch_bounds__(MODE == 2 ? 256 : 64, 4) void k_block_search(SearchArgs a) {
   constexpr int NW = MODE == 2 ? 4 : 1;
   __shared__ SearchLds sh[NW];
   __shared__ SearchLds420<MODE == 2> sq[NW];

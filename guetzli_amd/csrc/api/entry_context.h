@@ -205,6 +205,7 @@ void gz_destroy(gz_ctx* c) {
   (void)pool_free(c->extra_arena);
   (void)pool_free(c->d_block_mask); (void)pool_free(c->d_rank_cnt); (void)pool_free(c->d_rank_tables); (void)pool_free(c->d_rank_idx);
   (void)pool_free(c->d_out_cnt); (void)pool_free(c->d_out_idx); (void)pool_free(c->d_out_err); (void)pool_free(c->d_csr_off);
+  if (c->h_step_delta) (void)pool_host_free(c->h_step_delta);
   (void)pool_free(c->d_step_delta); (void)pool_free(c->d_csamp); (void)pool_free(c->d_gmax);
   (void)pool_free(c->d_scan_state[0]); (void)pool_free(c->d_scan_state[1]);
   (void)pool_free(c->d_jq); (void)pool_free(c->d_hist); (void)pool_free(c->d_code_depth); (void)pool_free(c->d_code_bits);

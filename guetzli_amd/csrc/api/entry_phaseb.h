@@ -283,14 +283,10 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
   }
   int* d_blocks = c->d_edit_pos;
   int* d_counts = c->d_edit_pos + n;
-  {
-    void* h = nullptr;
-    TRY(stage_reserve(c, &c->stage_main, sizeof(int) * 2 * n, &h));
-    memcpy(h, blocks, sizeof(int) * n);
-    memcpy((int*)h + n, counts, sizeof(int) * n);
-    HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
-    TRY(stage_sent(c, &c->stage_main, c->stream));
-  }
+  void* h = nullptr;
+  TRY(stage_reserve(c, &c->stage_main, sizeof(int) * 2 * n, &h));
+  memcpy(h, blocks, sizeof(int) * n);
+  memcpy((int*)h + n, counts, sizeof(int) * n);
   StepGeom sg;
   for (int i = 0; i < 3; ++i) sg.coff[i] = c->coff[i];
   sg.comp_mask = c->sg_mask;
@@ -298,17 +294,32 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
   if (c->have_jq) {
     // with the symbol statistics' quantiser known, the steps also report what they do to the
     // AC histograms (gz_steps_histogram_delta)
-    if (!c->d_step_delta) HIPCHK(c, pool_malloc((void**)&c->d_step_delta, sizeof(unsigned) * 768 * kStepDeltaCopies));
-    HIPCHK(c, hipMemsetAsync(c->d_step_delta, 0, sizeof(unsigned) * 768 * kStepDeltaCopies, c->stream));
+    // (zeroed once: k_steps_hist_sum leaves the counters zeroed)
+    if (!c->d_step_delta) {
+      HIPCHK(c, pool_malloc((void**)&c->d_step_delta, sizeof(unsigned) * 768 * kStepDeltaCopies));
+      HIPCHK(c, hipMemsetAsync(c->d_step_delta, 0, sizeof(unsigned) * 768 * kStepDeltaCopies, c->stream));
+    }
+    if (!c->h_step_delta) HIPCHK(c, pool_host_malloc(&c->h_step_delta, sizeof(int) * 768));
     // (persistent workgroups: four per CU's worth at most, each wavefront taking several blocks)
-    GZ_LAUNCH(k_apply_steps_hist, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)d_blocks,
-              (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
+    // (the kernel reads the staging buffer itself -- page-locked and mapped: a copy command in front of
+    // it costs more in hand-overs between commands than the 8 bytes per block cost over the bus)
+#ifdef GZ_STEPS_COPY_IN   // (A/B: the copy command in front of the kernel)
+    HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    h = d_blocks;
+#endif
+    GZ_LAUNCH(k_apply_steps_hist, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)h,
+              (const int*)h + n, n, direction, (const int*)c->d_next_cand,
               (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
               (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta);
     KCHK(c);
+    GZ_LAUNCH(k_steps_hist_sum, dim3(1), dim3(256), c->stream, c->d_step_delta, (int*)c->h_step_delta);
+    KCHK(c);
+    TRY(stage_sent(c, &c->stage_main, c->stream));   // (the staging buffer is free again behind the kernel)
     c->have_step_delta = true;
     return GZ_OK;
   }
+  HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
+  TRY(stage_sent(c, &c->stage_main, c->stream));
   GZ_LAUNCH(k_apply_steps, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
             (const int*)d_counts, n, direction, (const int*)c->d_next_cand,
             (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
@@ -324,17 +335,9 @@ int gz_steps_histogram_delta(gz_ctx* c, int32_t* ac_delta) {
     c->err = "gz_apply_candidate_steps (after gz_jpeg_histograms) must precede gz_steps_histogram_delta";
     return GZ_E_STATE;
   }
-  void* res = nullptr;
-  TRY(result_buffer(c, sizeof(unsigned) * 768 * kStepDeltaCopies, &res));
-  HIPCHK(c, hipMemcpyAsync(res, c->d_step_delta, sizeof(unsigned) * 768 * kStepDeltaCopies, hipMemcpyDeviceToHost, c->stream));
+  // k_steps_hist_sum has written the sums into the context's page-locked buffer
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  // the workgroups' changes went to kStepDeltaCopies copies of the counters (k_apply_steps_hist)
-  const unsigned* part = static_cast<const unsigned*>(res);
-  for (int k = 0; k < 768; ++k) {
-    unsigned sum = 0;
-    for (int r = 0; r < kStepDeltaCopies; ++r) sum += part[r * 768 + k];
-    ac_delta[k] = (int32_t)sum;
-  }
+  memcpy(ac_delta, c->h_step_delta, sizeof(int32_t) * 768);
   return GZ_OK;
 }
 

@@ -128,9 +128,13 @@ GZ_DEVFN gz_f2 gz_f2_splat(float x) {
 #ifdef GZ_EMU
 #define GZ_STORE_RELEASE(p, v) (*(p) = (v))
 #define GZ_LOAD_ACQUIRE(p) (*(p))
+#define GZ_LOAD_L2(p) (*(p))
 #else
 #define GZ_STORE_RELEASE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 #define GZ_LOAD_ACQUIRE(p) __hip_atomic_load((p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+// a load served by L2 (where other workgroups' atomics land), without an ordering of its own: loads of
+// this kind issue back to back, behind one fence
+#define GZ_LOAD_L2(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 // a * b for operands that fit 24 bits signed (IDCT: 16-bit coefficients x 14-bit matrix

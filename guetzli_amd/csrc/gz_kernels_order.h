@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_apply_steps(const int* __restrict__ blo
 // statistics (BuildACHistograms of the image before minus after, for the touched blocks only):
 // the block's coefficient blocks go through LDS, their symbols are counted out of the
 // histogram, the steps are applied, the symbols are counted back in.  delta: [3][256] counters
-// (wrapping unsigned arithmetic = signed differences) x kStepDeltaCopies, zeroed by the caller; jq = the quantiser
+// (wrapping unsigned arithmetic = signed differences) x kStepDeltaCopies, zero between launches; jq = the quantiser
 // the symbols are defined under (gz_jpeg_histograms' matrix).  After ~6000 steps an iteration
 // the host's size model needs the statistics again; recounting the 32 400 blocks of a 1080p
 // image took 40-50 us, the touched blocks take a fraction of that.
@@ -382,16 +382,23 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = threadIdx.x; k < 3 * 256; k += 256) s_delta[k] = 0u;
   __syncthreads();
-  const int stride = (int)gridDim.x * 4;
-  // (the same trip count for the four wavefronts -- the first one's, the largest: a wavefront past
-  // the end repeats the last block and drops the result, so that every thread of the workgroup
-  // passes the same sequence of synchronisation points, which the test emulation relies on)
-  const int first = (int)blockIdx.x * 4;
-  const int iters = first < n ? (n - first + stride - 1) / stride : 0;
-  for (int it = 0; it < iters; ++it) {
-    const int i = first + wave + it * stride;
-    const bool live = i < n;
-    const int b = blocks[live ? i : n - 1], cnt = live ? counts[i] : 0, nx = next_cand[b];
+  // Wavefront g of the grid takes the `per` consecutive entries from g * per (the same trip count for
+  // every wavefront: one past the end repeats the last block and drops the result, so that every thread
+  // of a workgroup passes the same sequence of synchronisation points, which the test emulation relies
+  // on).  `blocks` / `counts` are the caller's page-locked staging buffer, read over the bus: a wavefront
+  // fetches its entries 64 at a time, one per lane (consecutive addresses), and hands them round.
+  const int per = (n + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
+  const int base = ((int)blockIdx.x * 4 + wave) * per;
+  int pre_b = 0, pre_c = 0;
+  for (int it = 0; it < per; ++it) {
+    if ((it & 63) == 0) {
+      const int i2 = base + it + lane;
+      const bool lv = it + lane < per && i2 < n;
+      pre_b = blocks[lv ? i2 : n - 1];
+      pre_c = lv ? counts[i2] : 0;
+    }
+    const bool live = base + it < n;
+    const int b = __shfl(pre_b, it & 63), cnt = __shfl(pre_c, it & 63), nx = next_cand[b];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       if ((sg.comp_mask >> c) & 1) s_blk[wave][c * 64 + lane] = cand[((size_t)sg.coff[c] + b) * 64 + lane];
@@ -419,6 +426,27 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
   unsigned* out = delta + (blockIdx.x % kStepDeltaCopies) * 768;
   for (int k = threadIdx.x; k < 3 * 256; k += 256)
     if (s_delta[k]) atomicAdd(&out[k], s_delta[k]);
+}
+
+// The copies' sums into the caller's page-locked result (mapped into the device's address space: no copy
+// command behind the kernels), the copies left zeroed for the next launch (no memset command before it).
+// A kernel of its own, one workgroup: a "last workgroup done" ticket inside k_apply_steps_hist needs an
+// agent-scope fence per workgroup -- a write-back of the XCD's L2 each -- and cost 75 us per launch.
+__global__ __launch_bounds__(256) void k_steps_hist_sum(unsigned* __restrict__ delta, int* __restrict__ result) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int k = (int)threadIdx.x + 256 * j;
+    unsigned v[kStepDeltaCopies];
+#pragma unroll
+    for (int r = 0; r < kStepDeltaCopies; ++r) v[r] = delta[r * 768 + k];   // (all in flight together)
+    unsigned sum = 0;
+#pragma unroll
+    for (int r = 0; r < kStepDeltaCopies; ++r) {
+      sum += v[r];
+      if (v[r]) delta[r * 768 + k] = 0u;
+    }
+    result[k] = (int)sum;
+  }
 }
 
 // Per-block maxima of the distance map over fx x fy groups of 8x8 blocks: the first loop of

@@ -165,6 +165,7 @@ inline int num_threads() {
 #define gridDim (hipemu::st().gridDim)
 
 inline void __syncthreads() { hipemu::to_sched(); }
+inline void __threadfence() {}   // (one fiber runs at a time: memory is always consistent)
 
 #define __global__
 #define __device__

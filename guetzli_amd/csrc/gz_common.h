@@ -160,6 +160,18 @@ static __device__ __forceinline__ float gz_in_vgpr(float x) {
 #define GZ_IN_VGPR(x) gz_in_vgpr(x)
 #endif
 
+// All four components of a 16-byte vector just read from LDS count as used.  A window whose first or
+// last component no tap touches (a blur radius that is not a multiple of 4: R = 23 leaves one at either
+// end) otherwise has that read narrowed to 8 bytes, and the compiler then pairs ALL the window's reads
+// as ds_read2_b64 at offsets 8 bytes off the 16-byte grid: half the LDS rate of ds_read_b128 and a
+// different bank pattern (k_blur_h_pk<23>: SQ_LDS_IDX_ACTIVE 2.8x k_blur_h_pk<16>'s, bank conflicts 0.38
+// of it, profiles/r05_compare_4k_sq_counters.csv).  No instruction of its own.
+#if defined(GZ_EMU) || defined(GZ_NO_KEEP_F4)   // (GZ_NO_KEEP_F4: the A/B build without it)
+#define GZ_KEEP_F4(v) ((void)0)
+#else
+#define GZ_KEEP_F4(v) asm volatile("" : "+v"((v).v[0]), "+v"((v).v[1]), "+v"((v).v[2]), "+v"((v).v[3]))
+#endif
+
 // "Does any active lane of this wavefront need the rare path?"  A wavefront-uniform condition: the
 // compiler branches around the path instead of computing it for every lane and selecting (what it
 // does with a per-lane condition and a handful of instructions: malta_diff's FP64 form of absval

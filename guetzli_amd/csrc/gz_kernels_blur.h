@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void k_blur_h(SrcPack<Src, NC> src, PlanePack<
     float win[4 + 2 * RA];
 #pragma unroll
     for (int i = 0; i < (4 + 2 * RA) / 4; ++i) {
-      const gz_f4 v = *reinterpret_cast<const gz_f4*>(&tile[ry][xq + 4 * i]);
+      gz_f4 v = *reinterpret_cast<const gz_f4*>(&tile[ry][xq + 4 * i]);
+      if (OFF > 0 && (i == 0 || i == (4 + 2 * RA) / 4 - 1)) GZ_KEEP_F4(v);   // (the ends no tap touches)
       win[4 * i] = v.v[0]; win[4 * i + 1] = v.v[1]; win[4 * i + 2] = v.v[2]; win[4 * i + 3] = v.v[3];
     }
     gz_f4 o;
@@ -233,7 +234,8 @@ __global__ __launch_bounds__(256) void k_blur_h_pk(SrcPack<Src, NC> src, PlanePa
     gz_f2 win[4 + 2 * RA];
 #pragma unroll
     for (int i = 0; i < (4 + 2 * RA) / 2; ++i) {
-      const gz_f4 v = *reinterpret_cast<const gz_f4*>(&tile[p * PS + (xq + 2 * i) * 2]);
+      gz_f4 v = *reinterpret_cast<const gz_f4*>(&tile[p * PS + (xq + 2 * i) * 2]);
+      if (OFF > 0 && (i == 0 || i == (4 + 2 * RA) / 2 - 1)) GZ_KEEP_F4(v);   // (the ends no tap touches)
       win[2 * i] = gz_f2{v.v[0], v.v[1]};
       win[2 * i + 1] = gz_f2{v.v[2], v.v[3]};
     }

@@ -304,27 +304,29 @@ void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHis
 // k of the scan and the one after it -- the coefficient's own symbol, its successor's zero run and
 // the end-of-block code.  Equal to AddBlockACSymbols(blk, q, -1) + the store + AddBlockACSymbols
 // (blk, q, +1), for a few coefficients' work instead of two passes over the block.
-void ReplaceCoeffACSymbols(const int16_t* blk, const int* q, int k, int newval, SymbolHistogram* h,
-                           const uint8_t* depth, int64_t* raw_bits) {
-  // natural index -> zig-zag position; built once, under C++11's thread-safe initialisation of a
-  // function-local static (several encodes run as threads of one process: batch.run_config5)
+namespace {
+// natural index -> zig-zag position; built once, under C++11's thread-safe initialisation of a
+// function-local static (several encodes run as threads of one process: batch.run_config5)
+const int* ZigzagOfNatural() {
   struct Inverse {
     int at[64];
     Inverse() { for (int z = 0; z < 64; ++z) at[kNaturalOrder[z]] = z; }
   };
   static const Inverse inverse;
-  const int* zigzag_of = inverse.at;
+  return inverse.at;
+}
+
+// add(symbol, weight) for every AC symbol occurrence that leaves (weight -1) or enters (+1) the
+// block's scan when the coefficient at natural index k >= 1 changes from blk[k] to newval.
+template <class Add>
+inline void ForCoeffACSymbolChanges(const int16_t* blk, const int* q, int k, int newval, Add&& add) {
+  const int* zigzag_of = ZigzagOfNatural();
   const int oldval = blk[k];
   if (oldval == newval) return;
   const int z = zigzag_of[k];
   int pz = z - 1, nz = z + 1;             // the non-zero neighbours in scan order: 0 / 64 if none
   while (pz >= 1 && blk[kNaturalOrder[pz]] == 0) --pz;
   while (nz <= 63 && blk[kNaturalOrder[nz]] == 0) ++nz;
-  int64_t bits = 0;
-  auto add = [&](int symbol, int weight) {
-    h->Add(symbol, weight);
-    if (depth) bits += weight * (depth[symbol] + (symbol & 0xf));
-  };
   auto coeff = [&](int run, int v, int nat, int weight) {   // `run` zeros, then the value v at nat
     while (run > 15) {
       add(0xf0, weight);
@@ -344,7 +346,25 @@ void ReplaceCoeffACSymbols(const int16_t* blk, const int* q, int k, int newval, 
   };
   window(oldval, -1);
   window(newval, 1);
+}
+}  // namespace
+
+void ReplaceCoeffACSymbols(const int16_t* blk, const int* q, int k, int newval, SymbolHistogram* h,
+                           const uint8_t* depth, int64_t* raw_bits) {
+  int64_t bits = 0;
+  ForCoeffACSymbolChanges(blk, q, k, newval, [&](int symbol, int weight) {
+    h->Add(symbol, weight);
+    if (depth) bits += weight * (depth[symbol] + (symbol & 0xf));
+  });
   if (raw_bits) *raw_bits += bits;
+}
+
+int CoeffACSymbolChanges(const int16_t* blk, const int* q, int k, int newval, int16_t* changes) {
+  int n = 0;
+  ForCoeffACSymbolChanges(blk, q, k, newval, [&](int symbol, int weight) {
+    changes[n++] = (int16_t)(weight > 0 ? symbol + 1 : -(symbol + 1));
+  });
+  return n;
 }
 
 int64_t HistogramRawBits(const SymbolHistogram& h, const uint8_t* depth) {

@@ -64,6 +64,12 @@ void AddBlockACSymbols(const int16_t* block, const int* q, int weight, SymbolHis
 // passes (k >= 1; blk holds the old value and is not written).
 void ReplaceCoeffACSymbols(const int16_t* blk, const int* q, int k, int newval, SymbolHistogram* h,
                            const uint8_t* depth, int64_t* raw_bits);
+// The same symbol changes as a list instead of an update: changes[i] = +(symbol + 1) for an occurrence
+// that enters the block's scan, -(symbol + 1) for one that leaves it; at most kMaxCoeffACSymbolChanges
+// entries (two windows of: up to three ZRL codes and a symbol for the coefficient, the same for its
+// successor, or an end-of-block code).  Returns their number.  blk is not written.
+const int kMaxCoeffACSymbolChanges = 16;
+int CoeffACSymbolChanges(const int16_t* blk, const int* q, int k, int newval, int16_t* changes);
 int64_t HistogramRawBits(const SymbolHistogram& h, const uint8_t* depth);
 size_t EntropyBitsFromRaw(int64_t raw);
 

@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <chrono>
 #include <cstdlib>
 #include <exception>
@@ -15,6 +17,7 @@
 #include "png_reader.h"
 #include "silver_screen.h"
 #include "jpeg_writer.h"
+#include "code_refresh.h"
 #include "lazy_sort.h"
 #include "parallel.h"
 
@@ -239,9 +242,22 @@ static HostScratch& ThreadScratch() {
   return s;
 }
 
+// Helper threads for the size model's code refreshes (code_refresh.h) of ONE encode: GZ_CODE_THREADS,
+// else by the cores the process may run on per encode in flight (batch mode: one Encoder per image in
+// flight): 3 from eight cores on (4K: 0.271 s with none, 0.267 with 1, 0.258 with 2, 0.254 with 3;
+// profiles/r05_chain_experiments.log, section 12), else one per core beyond the encode's own, at most 2.
+static std::atomic<int> g_live_encoders{0};
+static int CodeRefreshThreads() {
+  if (const char* e = getenv("GZ_CODE_THREADS")) return std::max(0, std::min(4, atoi(e)));
+  const int per_encode = WorkerPool::AllowedCpus() / std::max(1, g_live_encoders.load());
+  if (per_encode >= 8) return 3;
+  return std::max(0, std::min(2, per_encode - 1));
+}
+
 class Encoder {
  public:
   Encoder(const Params& p, ProcessStats* s) : params_(p), stats_(s) {
+    ++g_live_encoders;
     HostScratch& sc = ThreadScratch();
     orig_.swap(sc.orig);
     img_.swap(sc.img);
@@ -251,6 +267,8 @@ class Encoder {
     scan_.swap(sc.scan);
   }
   ~Encoder() {
+    refreshers_.reset();
+    --g_live_encoders;
     if (ctx_) gz_destroy(ctx_);
     HostScratch& sc = ThreadScratch();
     orig_.swap(sc.orig);
@@ -347,6 +365,18 @@ class Encoder {
   // where the host's time goes at the end of an iteration (stats_->timers)
   double t_head_ = 0, t_cmp_begin_ = 0, t_cmp_end_ = 0, t_scan_begin_ = 0, t_scan_end_ = 0, t_ahead_begin_ = 0;
   size_t device_threshold_ = 1 << 16;   // ranges above this are partitioned on the device (32-64 K measured best at 1080p and 4K)
+  // the size model's code refreshes on helper threads (code_refresh.h); null: on this thread
+  std::unique_ptr<CodeRefreshers> refreshers_;
+  // one serial step of phase B as it was taken, so that it can be priced later and undone
+  struct SlowStep {
+    int32_t b, pos;
+    float val;
+    int16_t old_val;
+    uint8_t changed, first_touch, comp, nsym;
+    int16_t sym[kMaxCoeffACSymbolChanges];
+  };
+  std::vector<SlowStep> slow_log_;
+  long n_steps_undone_ = 0;
 };
 
 void Encoder::Log(const char* fmt, ...) {   // GUETZLI_LOG / PrintDebug, debug_print.h
@@ -652,6 +682,10 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   const int factor = last_c > 0 ? fac_ : 1;
   const int nb = factor == 2 ? nbc_ : nb_;
   const int ncomp = jpg_ncomp_;
+  if (!refreshers_) {
+    const int t = CodeRefreshThreads();
+    if (t > 0) refreshers_.reset(new CodeRefreshers(t));
+  }
   // ---- phase A on the device ----
   std::vector<int32_t>& cand_off = cand_off_;
   std::vector<uint8_t>& cand_idx = cand_idx_;
@@ -776,6 +810,8 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       }
       t_pb_order_ += pw.lap();
       if (total == 0) break;
+      // (the helpers wake up while the prefix is selected and the bulk steps are applied)
+      if (refreshers_ && !verify_) refreshers_->Activate();
       n_order_ += (long)total;
       {
         void* mirror = nullptr;
@@ -976,6 +1012,138 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         // histograms: ac_raw_bits[c] follows HistogramRawBits(ac_histo[c], depths of c) through
         // apply_step and is recounted when the depths change
         recount_raw_bits();
+        if (refreshers_ && !verify_) {
+          // ---- the serial steps with their code refreshes on the helper threads (code_refresh.h) ----
+          // Window w = the steps fast_until + 10 w .. + 9; its first step is a refresh step.  This
+          // thread takes the steps of up to `lag + 1` windows before it prices the oldest of them:
+          // the statistics right after a window's first step go to a helper, the steps' symbol changes
+          // are kept, and when the window's codes are there every step gets the size estimate the
+          // reference computes for it -- raw bits of the statistics at the refresh under the new
+          // depths, then the steps' changes priced with those depths (what ReplaceCoeffACSymbols adds
+          // to ac_raw_bits) -- and the stopping rule is applied in step order.  Steps taken beyond
+          // the one it fires at are undone, last first.
+          std::vector<SlowStep>& slog = slow_log_;
+          slog.clear();
+          const long lag = refreshers_->threads();
+          const long w0 = refreshers_->NextWindow();
+          long applied_w = 0, priced_w = 0;
+          size_t next_apply = fast_until;
+          bool stopped = false;
+          size_t last_priced = fast_until;   // the last step with an estimate (valid once a window is priced)
+          auto take_step = [&](size_t i) {
+            const int b = sorted[i].first;
+            settle_block(b, direction);
+            const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
+            const int c = idx / 64, k = idx % 64;
+            const int* q = quant_[c];
+            const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
+            int16_t* blk = &img_[Pos(c, b, 0)];
+            const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
+            SlowStep st;
+            st.b = b;
+            st.val = sorted[i].second;
+            st.comp = (uint8_t)c;
+            st.changed = 0;
+            st.nsym = 0;
+            st.pos = 0;
+            st.old_val = 0;
+            if (!(newval == 0 && IsPrecious(orig_blk, k))) {
+              st.changed = 1;
+              st.pos = (int32_t)Pos(c, b, k);
+              st.old_val = blk[k];
+              // (k == 0: a block's AC symbols do not depend on its DC coefficient)
+              if (k >= 1) st.nsym = (uint8_t)CoeffACSymbolChanges(blk, q, k, newval, st.sym);
+              for (int j = 0; j < st.nsym; ++j)
+                ac_histo[c].Add(std::abs(st.sym[j]) - 1, st.sym[j] > 0 ? 1 : -1);
+              blk[k] = (int16_t)newval;
+              edit_pos.push_back(st.pos);
+              edit_val.push_back((int16_t)newval);
+            }
+            next_cand[b] += direction;
+            mirror_cand[b] = next_cand[b];
+            st.first_touch = !touched[b];
+            if (!touched[b]) {
+              touched[b] = 1;
+              dirty.push_back(b);
+            }
+            slog.push_back(st);
+          };
+          auto undo_step = [&](const SlowStep& st) {
+            const int b = st.b;
+            if (st.first_touch) {
+              touched[b] = 0;
+              dirty.pop_back();
+            }
+            next_cand[b] -= direction;
+            mirror_cand[b] = next_cand[b];
+            if (st.changed) {
+              edit_pos.pop_back();
+              edit_val.pop_back();
+              img_[st.pos] = st.old_val;
+              for (int j = 0; j < st.nsym; ++j)
+                ac_histo[st.comp].Add(std::abs(st.sym[j]) - 1, st.sym[j] > 0 ? -1 : 1);
+            }
+          };
+          for (;;) {
+            if (next_apply < n_order && applied_w - priced_w <= lag) {
+              // take the steps of the next window; the refresh of its first step goes out at once
+              const size_t i0 = next_apply, i1 = std::min(i0 + 10, n_order);
+              for (size_t i = i0; i < i1; ++i) {
+                take_step(i);
+                if (i == i0) {
+                  CodeRefresh* in = refreshers_->Input(w0 + applied_w);
+                  memcpy(in->histo, ac_histo, sizeof(in->histo));
+                  in->ncomp = ncomp;
+                  refreshers_->Submit(w0 + applied_w);
+                }
+              }
+              next_apply = i1;
+              ++applied_w;
+              continue;
+            }
+            if (priced_w == applied_w) break;   // every step of the order taken and priced
+            Stopwatch cw;
+            const CodeRefresh* r = refreshers_->Wait(w0 + priced_w);
+            t_pb_codes_ += cw.lap();
+            memcpy(ac_depths.data(), r->depths, ac_depths.size());
+            ac_header = r->ac_header;
+            for (int c = 0; c < 3; ++c) ac_raw_bits[c] = r->raw_bits[c];
+            const size_t i0 = fast_until + 10 * (size_t)priced_w, i1 = std::min(i0 + 10, n_order);
+            for (size_t i = i0; i < i1; ++i) {
+              const SlowStep& st = slog[i - fast_until];
+              if (i > i0) {   // (the refresh step's own changes are in the statistics the codes were made for)
+                const uint8_t* depth = &ac_depths[st.comp * kHistoSize];
+                int64_t bits = 0;
+                for (int j = 0; j < st.nsym; ++j) {
+                  const int symbol = std::abs(st.sym[j]) - 1;
+                  const int cost = depth[symbol] + (symbol & 0xf);
+                  bits += st.sym[j] > 0 ? cost : -cost;
+                }
+                ac_raw_bits[st.comp] += bits;
+              }
+              size_t data_bits = 0;
+              for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ac_raw_bits[c]);
+              est_size = header_size + dc_size + ac_header + (int)((data_bits + 7) / 8);
+              last_priced = i;
+              if ((int)fast_until + (int)(i - fast_until) + 1 > min_coeffs_to_change &&
+                  std::abs(est_size - prev_size) > min_size_delta) {
+                stopped = true;
+                break;
+              }
+            }
+            ++priced_w;
+            if (stopped) break;
+          }
+          // the steps beyond the last one the reference takes, last first; then the refreshes that
+          // were asked for on their behalf (a slot is handed out again only after its window is done)
+          const size_t keep = last_priced + 1;   // steps [fast_until, keep) stay
+          for (size_t i = next_apply; i > keep; --i) undo_step(slog[i - 1 - fast_until]);
+          n_steps_undone_ += (long)(next_apply - keep);
+          for (long w = priced_w; w < applied_w; ++w) (void)refreshers_->Wait(w0 + w);
+          changed_coeffs += (int)(keep - fast_until);
+          val_threshold = slog[keep - 1 - fast_until].val;
+          n_steps_ += (long)(keep - fast_until);
+        } else
         for (size_t i = fast_until; i < n_order; ++i) {
           apply_step(i);
           if (i % 10 == 0) {
@@ -997,6 +1165,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
             break;
         }
       }
+      if (refreshers_) refreshers_->Deactivate();
       t_pb_loop_ += pw.lap();
       const size_t order_size = (size_t)total;
       if (sorted.failed()) return Fail("gz_order_partition/fetch", dev_order.rc);
@@ -1220,6 +1389,8 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   stats_->counters["candidates entropy-coded"] = (int)n_scans_;
   stats_->counters["candidates rejected on their size bound"] = (int)n_scans_skipped_;
   stats_->counters["phase B coefficient steps"] = (int)n_steps_;
+  stats_->counters["phase B steps taken ahead and undone"] = (int)n_steps_undone_;
+  stats_->counters["phase B code refresh threads"] = refreshers_ ? refreshers_->threads() : 0;
   stats_->counters["phase B order entries"] = (int)std::min<long>(n_order_, 2000000000L);
   if (best_on_host_) {
     *out = best_full_;

@@ -34,6 +34,8 @@ int main() {
     const bool use_q = rng() % 5 != 0;
     SymbolHistogram a, b;
     for (int i = 0; i < 256; ++i) { const int w = (int)(rng() % 50) + 70; a.Add(i, w); b.Add(i, w); }
+    uint32_t start_counts[kHistoSize];
+    memcpy(start_counts, a.counts, sizeof start_counts);
     int64_t bits_a = 12345, bits_b = 12345;
     int16_t blk_a[64];
     memcpy(blk_a, blk, sizeof blk);
@@ -42,6 +44,25 @@ int main() {
     AddBlockACSymbols(blk_a, use_q ? q : nullptr, 1, &a, depth, &bits_a);
     ReplaceCoeffACSymbols(blk, use_q ? q : nullptr, k, newval, &b, depth, &bits_b);
     ++cases;
+    // ... and the same changes as a list (CoeffACSymbolChanges: what the search driver keeps of a step it
+    // takes before the step's codes exist), applied and priced afterwards
+    {
+      SymbolHistogram c;
+      for (int i = 0; i < kHistoSize; ++i) c.counts[i] = a.counts[i];   // = the result expected ...
+      int16_t changes[kMaxCoeffACSymbolChanges];
+      const int n = CoeffACSymbolChanges(blk, use_q ? q : nullptr, k, newval, changes);
+      int64_t bits_c = bits_a;
+      for (int j = 0; j < n; ++j) {   // ... undone: must give the statistics and the bits before the step
+        const int symbol = (changes[j] > 0 ? changes[j] : -changes[j]) - 1, weight = changes[j] > 0 ? 1 : -1;
+        c.Add(symbol, -weight);
+        bits_c -= weight * (depth[symbol] + (symbol & 0xf));
+      }
+      if (n > kMaxCoeffACSymbolChanges || n < 0 || bits_c != 12345 ||
+          memcmp(c.counts, start_counts, sizeof c.counts) != 0) {
+        printf("MISMATCH (change list) round %d k %d old %d new %d n %d\n", round, k, blk[k], newval, n);
+        return 1;
+      }
+    }
     if (memcmp(a.counts, b.counts, sizeof a.counts) != 0 || bits_a != bits_b) {
       printf("MISMATCH round %d k %d old %d new %d bits %lld vs %lld\n", round, k, blk[k], newval,
              (long long)bits_a, (long long)bits_b);

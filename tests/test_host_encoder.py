@@ -376,3 +376,29 @@ def test_size_bound_path_with_its_self_checks_in_emulation(host_emu, monkeypatch
     got, info = host_emu.process(rgb, quality=95)
     assert got == exp_jpg
     assert info["counters"]["candidates rejected on their size bound"] > 0
+
+
+@needs_ref
+@pytest.mark.parametrize("threads", [0, 1, 3])
+def test_code_refresh_helpers_change_nothing_but_the_time(host_emu, monkeypatch, threads):
+    """guetzli_amd/host/code_refresh.h: phase B's serial steps with the size model's Huffman codes
+    constructed on helper threads -- steps taken ahead of their codes, priced in order when the codes
+    arrive, undone beyond the stopping point -- give the reference's bytes, the reference's --verbose
+    trace and the same number of coefficient steps as the serial loop (GZ_CODE_THREADS=0), with steps
+    really taken ahead and undone."""
+    monkeypatch.setenv("GZ_CODE_THREADS", str(threads))
+    rgb = images.crop(48, 40, 300, 150)
+    target = ref._butteraugli_score_for_quality(95.0)
+    exp_jpg, exp_trace = ref.process(rgb, target, want_trace=True)
+    got, info = host_emu.process(rgb, quality=95)
+    assert got == exp_jpg
+    c = info["counters"]
+    assert c["phase B code refresh threads"] == threads
+    assert (c["phase B steps taken ahead and undone"] > 0) == (threads > 0)
+    steps = c["phase B coefficient steps"]
+    monkeypatch.setenv("GZ_CODE_THREADS", "0")
+    _, info0 = host_emu.process(rgb, quality=95)
+    assert info0["counters"]["phase B coefficient steps"] == steps
+    monkeypatch.setenv("GZ_CODE_THREADS", str(threads))
+    got_t, info_t = host_emu.process(rgb, quality=95, want_trace=True)
+    assert got_t == exp_jpg and info_t["trace"] == exp_trace

@@ -37,6 +37,23 @@ def test_local_ac_symbol_update_equals_two_block_passes(tmp_path):
     assert "ac_symbols: ok" in out.stdout
 
 
+def test_code_refresh_hand_over_under_thread_sanitizer(tmp_path):
+    """CodeRefreshers (guetzli_amd/host/code_refresh.h): 4 852 code refreshes through 1..4 helper threads,
+    several windows in flight, the helpers put to sleep and woken between bursts -- every result equal
+    to EntropyCodes / HistogramRawBits on the spot, and no data race (-fsanitize=thread)."""
+    exe = str(tmp_path / "test_code_refresh")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-Wall", "-pthread",
+           os.path.join(ROOT, "tests", "cpp", "test_code_refresh.cc"),
+           os.path.join(ROOT, "guetzli_amd", "host", "jpeg_writer.cc"), "-o", exe, "-lz"]
+    tsan = subprocess.run(cmd + ["-fsanitize=thread"], capture_output=True, text=True)
+    if tsan.returncode != 0:   # (a toolchain without the sanitizer's runtime: the functional check alone)
+        subprocess.run(cmd, check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "code_refresh: ok" in out.stdout
+    assert "ThreadSanitizer" not in out.stderr
+
+
 def test_device_partition_is_std_sort_in_emulation(tmp_path):
     """gz_order_partition (gz_kernels_order.h, here the CPU emulation build of the kernel
     sources) driven by LazySorted reproduces std::sort's permutation, ties included."""

@@ -639,6 +639,9 @@ def main():
                      "warmup": args.warmup, "output_bytes": len(jpeg),
                      "output_sha256_matches_reference": not emu,
                      "iterations": inf["counters"].get("number of iterations"),
+                     # host threads of one encode: the search driver's own + the size model's code-refresh
+                     # helpers (guetzli_amd/host/code_refresh.h; `pb_loop_codes` is the driver WAITING for them)
+                     "host_code_refresh_threads": inf["counters"].get("phase B code refresh threads"),
                      "host_timers_s": {k: round(v, 3) for k, v in inf["timers"].items() if k in timer_keys}})
 
         def roof(w, h, ms_c, ach, key):

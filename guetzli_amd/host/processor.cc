@@ -960,15 +960,44 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           int32_t* dl = first_touch.data();
           int* sc = step_count.data();
           char* tc = touched.data();
-          size_t nd = 0;
-          for (size_t i = 0; i < fast_until; ++i) {
-            const int b = order[i].first;
-            dl[nd] = b;
-            nd += sc[b] == 0;
-            ++sc[b];
-            tc[b] = 1;
+          WorkerPool& pool = WorkerPool::Get();
+          const char* pc_env = getenv("GZ_PARALLEL_COUNT_MIN");   // (the tests: this path on small images)
+          const size_t parallel_from = pc_env ? (size_t)atol(pc_env) : (size_t)1 << 20;
+          if (fast_until >= parallel_from && pool.size() > 1) {
+            // The first "up" iteration of an encode takes every candidate below the error limit at
+            // once -- 7.5 M entries at 4K, 7.5 of this loop's 9 ms per encode: the entries in `parts`
+            // ranges, a private count array per range (0.5 MB: it stays in the core's cache), summed
+            // afterwards.  Which order the touched blocks are listed in matters to nobody (independent
+            // blocks on the device, a set to be cleared here).
+            const int parts = std::min(pool.size(), 8);
+            std::vector<std::vector<int32_t> > part_count((size_t)parts);
+            pool.Run(parts, [&](int p) {
+              std::vector<int32_t>& cnt = part_count[(size_t)p];
+              cnt.assign((size_t)nb, 0);
+              const size_t i0 = fast_until * (size_t)p / parts, i1 = fast_until * (size_t)(p + 1) / parts;
+              for (size_t i = i0; i < i1; ++i) ++cnt[(size_t)order[i].first];
+            });
+            size_t nd = 0;
+            for (int b = 0; b < nb; ++b) {
+              int n = 0;
+              for (int p = 0; p < parts; ++p) n += part_count[(size_t)p][(size_t)b];
+              if (n == 0) continue;
+              if (sc[b] == 0) dl[nd++] = b;
+              sc[b] += n;
+              tc[b] = 1;
+            }
+            dirty.assign(dl, dl + nd);
+          } else {
+            size_t nd = 0;
+            for (size_t i = 0; i < fast_until; ++i) {
+              const int b = order[i].first;
+              dl[nd] = b;
+              nd += sc[b] == 0;
+              ++sc[b];
+              tc[b] = 1;
+            }
+            dirty.assign(dl, dl + nd);
           }
-          dirty.assign(dl, dl + nd);
         }
         t_fs_count_ += fw.lap();
         if (fast_until > 0) {

@@ -402,3 +402,17 @@ def test_code_refresh_helpers_change_nothing_but_the_time(host_emu, monkeypatch,
     monkeypatch.setenv("GZ_CODE_THREADS", str(threads))
     got_t, info_t = host_emu.process(rgb, quality=95, want_trace=True)
     assert got_t == exp_jpg and info_t["trace"] == exp_trace
+
+
+@needs_ref
+def test_parallel_step_count_of_a_long_prefix_in_emulation(host_emu, monkeypatch):
+    """The per-block step counts of a bulk prefix counted by the worker pool (private count arrays per
+    range of entries; on the MI355X: the first "up" iteration's 7.5 M entries at 4K), forced onto every
+    iteration of a small encode: the reference's bytes."""
+    monkeypatch.setenv("GZ_PARALLEL_COUNT_MIN", "1")
+    monkeypatch.setenv("GZ_HOST_THREADS", "4")
+    rgb = images.crop(48, 40, 300, 150)
+    exp_jpg, _ = ref.process(rgb, ref._butteraugli_score_for_quality(95.0))
+    got, info = host_emu.process(rgb, quality=95)
+    assert got == exp_jpg
+    assert info["counters"]["phase B fast steps"] > 0

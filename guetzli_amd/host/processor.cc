@@ -376,6 +376,8 @@ class Encoder {
     int16_t sym[kMaxCoeffACSymbolChanges];
   };
   std::vector<SlowStep> slow_log_;
+  long slow_steps_last_ = 0;           // serial steps of the previous iteration of phase B
+  std::vector<int32_t> bulk_counts_;   // (kept between iterations: no allocation on the host's path)
   long n_steps_undone_ = 0;
 };
 
@@ -810,8 +812,6 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       }
       t_pb_order_ += pw.lap();
       if (total == 0) break;
-      // (the helpers wake up while the prefix is selected and the bulk steps are applied)
-      if (refreshers_ && !verify_) refreshers_->Activate();
       n_order_ += (long)total;
       {
         void* mirror = nullptr;
@@ -1004,14 +1004,23 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           val_threshold = order[fast_until - 1].second;
           changed_coeffs += (int)fast_until;
           // the device applies the same steps to its image (and advances its next_cand) ...
-          std::vector<int32_t> counts(dirty.size());
+          std::vector<int32_t>& counts = bulk_counts_;
+          counts.resize(dirty.size());
           for (size_t di = 0; di < dirty.size(); ++di) counts[di] = step_count[dirty[di]];
           rc = gz_apply_candidate_steps(ctx_, direction, dirty.data(), counts.data(), (int)dirty.size());
           if (rc != GZ_OK) return Fail("gz_apply_candidate_steps", rc);
           t_fs_apply_ += fw.lap();
           // ... while the host only notes how far each block has advanced; its mirror of the
           // coefficients follows when a slow step needs the block (settle_block)
-          for (size_t di = 0; di < dirty.size(); ++di) next_cand[dirty[di]] += direction * counts[di];
+          // (step_count holds exactly these counts and zeros elsewhere: with a fifth of the blocks
+          // touched, one pass over the two arrays -- 20 us -- beats 26 000 scattered updates -- 40-120)
+          if (dirty.size() * 16 > (size_t)nb) {
+            int* nc = next_cand.data();
+            const int* scp = step_count.data();
+            for (int b = 0; b < nb; ++b) nc[b] += direction * scp[b];
+          } else {
+            for (size_t di = 0; di < dirty.size(); ++di) next_cand[dirty[di]] += direction * counts[di];
+          }
           if (verify_) settle_all(direction);   // GZ_VERIFY_ENTROPY compares the whole mirror
           // the symbol statistics of the edited image come from the device: the change the
           // steps made to BuildACHistograms, counted over the touched blocks (the host's
@@ -1037,13 +1046,56 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         t_fs_rest_ += fw.lap();
         n_steps_ += (long)fast_until;
         n_fast_ += (long)fast_until;
+        const long slow_steps_before = (long)(n_steps_ - n_fast_);
         // EntropyDataSize(ac_histo, ncomp, ac_depths) after every step, without its pass over the
         // histograms: ac_raw_bits[c] follows HistogramRawBits(ac_histo[c], depths of c) through
         // apply_step and is recounted when the depths change
         recount_raw_bits();
-        if (refreshers_ && !verify_) {
+        // the reference's loop (processor.cc:704-750) over the steps [from, to): true = the stopping
+        // rule fired (at the last step taken)
+        bool verify_failed = false;
+        auto serial_steps = [&](size_t from, size_t to) -> bool {
+          for (size_t i = from; i < to; ++i) {
+            apply_step(i);
+            if (i % 10 == 0) {
+              Stopwatch cw;
+              ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
+              recount_raw_bits();
+              t_pb_codes_ += cw.lap();
+            }
+            ++n_steps_;
+            size_t data_bits = 0;
+            for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ac_raw_bits[c]);
+            est_size = header_size + dc_size + ac_header + (int)((data_bits + 7) / 8);
+            if (verify_ && (data_bits + 7) / 8 != EntropyDataSize(ac_histo, ncomp, ac_depths.data())) {
+              fprintf(stderr, "guetzli_amd: incremental size estimate differs from a recount\n");
+              verify_failed = true;
+              return true;
+            }
+            if (changed_coeffs > min_coeffs_to_change &&
+                std::abs(est_size - prev_size) > min_size_delta)
+              return true;
+          }
+          return false;
+        };
+        // Three quarters of an encode's iterations stop within ten steps of the bulk (the first
+        // refresh's estimate already differs enough): waking the helpers for those costs more than the
+        // one refresh they could take over.  An iteration takes about as many serial steps as the one
+        // before it: after a short one the first windows are taken as the reference takes them, and
+        // the helpers are called in only if the loop goes on.
+        size_t base = fast_until;   // first step of the pipelined part (a multiple of 10)
+        bool stopped_early = false;
+        const char* ss_env = getenv("GZ_CODE_SERIAL_STEPS");   // (the tests: 0 = helpers from the first step on)
+        const long serial_first = ss_env ? atol(ss_env) / 10 * 10 : 30;
+        if (refreshers_ && !verify_ && serial_first > 0 && slow_steps_last_ < serial_first) {
+          const size_t to = std::min(n_order, fast_until + (size_t)serial_first);
+          stopped_early = serial_steps(fast_until, to);
+          base = to;
+        }
+        if (refreshers_ && !verify_ && !stopped_early && base < n_order) {
+          refreshers_->Activate();
           // ---- the serial steps with their code refreshes on the helper threads (code_refresh.h) ----
-          // Window w = the steps fast_until + 10 w .. + 9; its first step is a refresh step.  This
+          // Window w = the steps base + 10 w .. + 9; its first step is a refresh step.  This
           // thread takes the steps of up to `lag + 1` windows before it prices the oldest of them:
           // the statistics right after a window's first step go to a helper, the steps' symbol changes
           // are kept, and when the window's codes are there every step gets the size estimate the
@@ -1056,9 +1108,9 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           const long lag = refreshers_->threads();
           const long w0 = refreshers_->NextWindow();
           long applied_w = 0, priced_w = 0;
-          size_t next_apply = fast_until;
+          size_t next_apply = base;
           bool stopped = false;
-          size_t last_priced = fast_until;   // the last step with an estimate (valid once a window is priced)
+          size_t last_priced = base;   // the last step with an estimate (valid once a window is priced)
           auto take_step = [&](size_t i) {
             const int b = sorted[i].first;
             settle_block(b, direction);
@@ -1137,9 +1189,9 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
             memcpy(ac_depths.data(), r->depths, ac_depths.size());
             ac_header = r->ac_header;
             for (int c = 0; c < 3; ++c) ac_raw_bits[c] = r->raw_bits[c];
-            const size_t i0 = fast_until + 10 * (size_t)priced_w, i1 = std::min(i0 + 10, n_order);
+            const size_t i0 = base + 10 * (size_t)priced_w, i1 = std::min(i0 + 10, n_order);
             for (size_t i = i0; i < i1; ++i) {
-              const SlowStep& st = slog[i - fast_until];
+              const SlowStep& st = slog[i - base];
               if (i > i0) {   // (the refresh step's own changes are in the statistics the codes were made for)
                 const uint8_t* depth = &ac_depths[st.comp * kHistoSize];
                 int64_t bits = 0;
@@ -1154,7 +1206,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
               for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ac_raw_bits[c]);
               est_size = header_size + dc_size + ac_header + (int)((data_bits + 7) / 8);
               last_priced = i;
-              if ((int)fast_until + (int)(i - fast_until) + 1 > min_coeffs_to_change &&
+              if ((int)i + 1 > min_coeffs_to_change &&
                   std::abs(est_size - prev_size) > min_size_delta) {
                 stopped = true;
                 break;
@@ -1165,34 +1217,18 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           }
           // the steps beyond the last one the reference takes, last first; then the refreshes that
           // were asked for on their behalf (a slot is handed out again only after its window is done)
-          const size_t keep = last_priced + 1;   // steps [fast_until, keep) stay
-          for (size_t i = next_apply; i > keep; --i) undo_step(slog[i - 1 - fast_until]);
+          const size_t keep = last_priced + 1;   // steps [base, keep) stay
+          for (size_t i = next_apply; i > keep; --i) undo_step(slog[i - 1 - base]);
           n_steps_undone_ += (long)(next_apply - keep);
           for (long w = priced_w; w < applied_w; ++w) (void)refreshers_->Wait(w0 + w);
-          changed_coeffs += (int)(keep - fast_until);
-          val_threshold = slog[keep - 1 - fast_until].val;
-          n_steps_ += (long)(keep - fast_until);
-        } else
-        for (size_t i = fast_until; i < n_order; ++i) {
-          apply_step(i);
-          if (i % 10 == 0) {
-            Stopwatch cw;
-            ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
-            recount_raw_bits();
-            t_pb_codes_ += cw.lap();
-          }
-          ++n_steps_;
-          size_t data_bits = 0;
-          for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ac_raw_bits[c]);
-          est_size = header_size + dc_size + ac_header + (int)((data_bits + 7) / 8);
-          if (verify_ && (data_bits + 7) / 8 != EntropyDataSize(ac_histo, ncomp, ac_depths.data())) {
-            fprintf(stderr, "guetzli_amd: incremental size estimate differs from a recount\n");
-            return false;
-          }
-          if (changed_coeffs > min_coeffs_to_change &&
-              std::abs(est_size - prev_size) > min_size_delta)
-            break;
+          changed_coeffs += (int)(keep - base);
+          val_threshold = slog[keep - 1 - base].val;
+          n_steps_ += (long)(keep - base);
+        } else if (!(refreshers_ && !verify_)) {
+          (void)serial_steps(fast_until, n_order);
+          if (verify_failed) return false;
         }
+        slow_steps_last_ = (long)(n_steps_ - n_fast_) - slow_steps_before;
       }
       if (refreshers_) refreshers_->Deactivate();
       t_pb_loop_ += pw.lap();

@@ -387,6 +387,9 @@ def test_code_refresh_helpers_change_nothing_but_the_time(host_emu, monkeypatch,
     trace and the same number of coefficient steps as the serial loop (GZ_CODE_THREADS=0), with steps
     really taken ahead and undone."""
     monkeypatch.setenv("GZ_CODE_THREADS", str(threads))
+    # (an iteration that follows a short one starts with the reference's own loop and calls the helpers in
+    # only after 30 steps -- on this small image every iteration is short: helpers from the first step on)
+    monkeypatch.setenv("GZ_CODE_SERIAL_STEPS", "0")
     rgb = images.crop(48, 40, 300, 150)
     target = ref._butteraugli_score_for_quality(95.0)
     exp_jpg, exp_trace = ref.process(rgb, target, want_trace=True)
@@ -402,6 +405,10 @@ def test_code_refresh_helpers_change_nothing_but_the_time(host_emu, monkeypatch,
     monkeypatch.setenv("GZ_CODE_THREADS", str(threads))
     got_t, info_t = host_emu.process(rgb, quality=95, want_trace=True)
     assert got_t == exp_jpg and info_t["trace"] == exp_trace
+    # ... and with the switch from the reference's loop to the helpers in the middle of an iteration
+    monkeypatch.setenv("GZ_CODE_SERIAL_STEPS", "10")
+    got_s, info_s = host_emu.process(rgb, quality=95)
+    assert got_s == exp_jpg and info_s["counters"]["phase B coefficient steps"] == steps
 
 
 @needs_ref

@@ -331,10 +331,16 @@ def timed_steps(env, step, steps, warmup):
     env.fence()
     t0 = time.perf_counter()
     res = None
+    del STEP_MS[:]
     for _ in range(steps):
+        ts = time.perf_counter()
         res = step()
+        STEP_MS.append(round((time.perf_counter() - ts) * 1e3, 2))   # (this rank's; no extra synchronisation)
     env.fence()
     return env.max_over_ranks(time.perf_counter() - t0), res
+
+
+STEP_MS = []   # the last timed_steps' individual steps on this rank (reported beside ms_per_step)
 
 
 def ranks_seen(env):
@@ -536,9 +542,19 @@ def main():
     first_encode_s = time.perf_counter() - t0
 
     dt, (jpg, info) = timed_steps(env, step, args.steps, args.warmup)
-    dt4k = jpg4k = info4k = None
+    step_ms_1080p = list(STEP_MS)
+    dt4k = jpg4k = info4k = step_ms_4k = first_encode_4k_s = None
     if not args.no_4k:
+        # the process's first encode at this size, on its own like the 1080p one above: the pools grow from
+        # 1080p to 4K buffers (and, in a process with PyTorch loaded, the context of the encode after it
+        # still takes 20 ms to create where a plain process takes 2: with --warmup 1 that step used to be
+        # the first TIMED one, 267 ms among 246 -- `step_ms_4k` shows every timed step)
+        t0 = time.perf_counter()
+        step4k()
+        env.sync()
+        first_encode_4k_s = time.perf_counter() - t0
         dt4k, (jpg4k, info4k) = timed_steps(env, step4k, args.steps, args.warmup)
+        step_ms_4k = list(STEP_MS)
 
     # roofline legs: HIP events on the context's stream around whole Compare chains
     # (warm-up: the clocks need ~20 ms of sustained chains to settle -- the first 20 chains after an
@@ -679,6 +695,7 @@ def main():
             "data": f"synthetic (tests/golden/bees.png tiled to {head[4][0]}x{head[4][1]}, SURVEY 8d)",
             "config": head[2],
             "first_encode_s": round(first_encode_s, 3),
+            "first_encode_4k_s": None if first_encode_4k_s is None else round(first_encode_4k_s, 3),
             "roofline": head[3],
             # phase A (not HBM-bound -- reported in evaluations, not bytes)
             "block_search": {"evaluations": inf_head["counters"].get("block search evaluations"),
@@ -696,6 +713,8 @@ def main():
         # the same two legs under names that do not depend on which of them is the headline
         out["value_1080p"] = v_small
         out["ms_per_step_1080p"] = ms_small
+        out["step_ms_1080p"] = step_ms_1080p      # rank 0's individual timed steps
+        out["step_ms_4k"] = step_ms_4k
         if dt4k is not None:
             out["value_4k"] = head[0]
             out["ms_per_step_4k"] = head[1]

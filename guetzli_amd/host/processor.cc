@@ -812,6 +812,9 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       }
       t_pb_order_ += pw.lap();
       if (total == 0) break;
+      // (an iteration takes about as many serial steps as the one before it: after a long one the helpers
+      // are woken now, while the prefix is selected and the bulk steps are applied)
+      if (refreshers_ && !verify_ && slow_steps_last_ >= 30) refreshers_->Activate();
       n_order_ += (long)total;
       {
         void* mirror = nullptr;

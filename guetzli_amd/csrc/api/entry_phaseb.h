@@ -271,8 +271,12 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     return GZ_E_STATE;
   }
   if (n == 0) return GZ_OK;
-  for (int i = 0; i < n; ++i)
-    if (blocks[i] < 0 || blocks[i] >= c->sg_n || counts[i] < 0 || counts[i] > 192) return GZ_E_ARG;
+  {   // (26 000 pairs per iteration of a 4K encode: as a reduction the check vectorises, ~2 us instead of ~10)
+    const unsigned sg_n = (unsigned)c->sg_n;
+    unsigned bad = 0;
+    for (int i = 0; i < n; ++i) bad |= (unsigned)((unsigned)blocks[i] >= sg_n) | (unsigned)((unsigned)counts[i] > 192u);
+    if (bad) return GZ_E_ARG;
+  }
   if ((size_t)2 * n > c->edit_cap) {   // the edit buffers double as (blocks, counts) staging
     HIPCHK(c, hipStreamSynchronize(c->stream));   // the pool hands memory on without waiting
     (void)pool_free(c->d_edit_pos); (void)pool_free(c->d_edit_val);

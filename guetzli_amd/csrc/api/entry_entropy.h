@@ -53,8 +53,22 @@ int gz_jpeg_histograms_ncomp(gz_ctx* c, const int* q, int ncomp, uint32_t* count
   HIPCHK(c, hipMemsetAsync(c->d_hist, 0, sizeof(unsigned) * 1536, c->stream));
   const FrameGeom geom = frame_geom(c, ncomp);
   const int grid = std::min(gz_div_up(geom.mcu_cols * geom.mcu_rows, kHistWaves), 1024);
-  GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
-            (const int*)c->d_jq, geom, c->d_hist);
+  {
+    const int upm = ncomp == 1 ? 1 : (c->cfac == 2 ? 6 : 3);   // blocks per MCU
+    const bool generic = getenv("GZ_HIST_GENERIC") != nullptr;  // (the tests: the run-time-geometry kernel)
+    if (generic)
+      GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
+                (const int*)c->d_jq, geom, c->d_hist);
+    else if (upm == 3)
+      GZ_LAUNCH((k_jpeg_histograms_t<3>), dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
+                (const int*)c->d_jq, geom, c->d_hist);
+    else if (upm == 6)
+      GZ_LAUNCH((k_jpeg_histograms_t<6>), dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
+                (const int*)c->d_jq, geom, c->d_hist);
+    else
+      GZ_LAUNCH((k_jpeg_histograms_t<1>), dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
+                (const int*)c->d_jq, geom, c->d_hist);
+  }
   KCHK(c);
   void* res = nullptr;
   TRY(result_buffer(c, sizeof(unsigned) * 1536, &res));

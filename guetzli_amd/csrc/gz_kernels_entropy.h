@@ -348,6 +348,58 @@ __global__ __launch_bounds__(64 * W) void k_jpeg_block_bits(const int16_t* __res
   }
 }
 
+// The symbol statistics with the same machinery (round 5): the MCU's shape as a template constant, the
+// blocks' loads issued together, coefficient / q as quant_div instead of an integer division per lane
+// (and two more on lane 0 for the DC prediction), the frame's geometry not interpreted per block.
+// k_jpeg_histograms above (kept: the tests' reference for this one on small frames) took 162 us for a 4K
+// frame -- on the host's path once per quantisation trial and at the start of phase B.
+template <int UPM>
+__global__ __launch_bounds__(64 * kHistWaves) void k_jpeg_histograms_t(const int16_t* __restrict__ coeffs,
+                                                                       const int* __restrict__ q, FrameGeom g,
+                                                                       unsigned* __restrict__ hist) {
+  typedef McuShape<UPM> S;
+  __shared__ unsigned s_hist[2 * 3 * 256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2 * 3 * 256; i += 64 * kHistWaves) s_hist[i] = 0;
+  __syncthreads();
+  WaveTables<UPM> t;
+  t.nat = kNaturalOrderDev[lane];
+  t.lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int c = 0; c < S::kComps; ++c) {
+    t.q[c] = q[c * 64 + t.nat];
+    t.rq[c] = 1.0f / (float)t.q[c];
+    t.q0[c] = q[c * 64];
+    t.rq0[c] = 1.0f / (float)t.q0[c];
+    t.zrl_len[c] = 0;
+    t.eob_len[c] = 0;
+  }
+  const int nmcu = g.mcu_cols * g.mcu_rows;
+  // (the same trip count for the four wavefronts: a wavefront past the end repeats the last MCU and
+  // drops the result, so that unit_symbols' ballots stay whole-wavefront operations)
+  for (int m0 = blockIdx.x * kHistWaves; m0 < nmcu; m0 += gridDim.x * kHistWaves) {
+    const bool live = m0 + wv < nmcu;
+    const int m = live ? m0 + wv : nmcu - 1;
+    const int mx = m % g.mcu_cols, my = m / g.mcu_cols;
+    UnitRaw raw[UPM];
+#pragma unroll
+    for (int u = 0; u < UPM; ++u) raw[u] = unit_load<UPM>(coeffs, g, u, mx, my, t.nat);
+#pragma unroll
+    for (int u = 0; u < UPM; ++u) {
+      const int c = S::comp(u);
+      const LaneSyms s = unit_symbols<UPM>(raw[u], t, c, lane);
+      if (!live) continue;
+      unsigned* h = &s_hist[((s.is_dc ? 0 : 1) * 3 + c) * 256];
+      if (s.zrl) atomicAdd(&h[0xf0], (unsigned)s.zrl);
+      if (s.sym >= 0) atomicAdd(&h[s.sym], 1u);
+      if (s.eob) atomicAdd(&s_hist[(3 + c) * 256], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 3 * 256; i += 64 * kHistWaves)
+    if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
 // off[0..n] = exclusive prefix sums of bits[0..n) (64-bit), in one pass over the array by
 // ceil(n / 2048) workgroups ("decoupled look-back"): a workgroup scans its tile of 2048 values
 // (8 per thread, two 16-byte loads), publishes the tile's sum, then adds up what the tiles

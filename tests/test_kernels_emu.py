@@ -98,6 +98,15 @@ def test_jpeg_entropy(L, host_emu, wh):
     pc.case_jpeg_entropy(L, host_emu, *wh, x0=100, y0=50)
 
 
+def test_jpeg_histograms_generic_kernel(L, host_emu, monkeypatch):
+    """k_jpeg_histograms (the frame's geometry interpreted per block, an integer division per lane) stays
+    in the library as the reference of k_jpeg_histograms_t<blocks per MCU>, which the chain uses."""
+    monkeypatch.setenv("GZ_HIST_GENERIC", "1")
+    pc.case_jpeg_entropy(L, host_emu, 61, 43, x0=100, y0=50)
+    if ref is not None:
+        pc.case_jpeg_entropy420(L, host_emu, 48, 40, ref, x0=100, y0=50)
+
+
 def test_global_order(L):
     pc.case_global_order(L, 40, 32, x0=100, y0=60)
 

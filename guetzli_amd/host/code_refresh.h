@@ -43,16 +43,14 @@ class CodeRefreshers {
       slot_[s].submitted.store(0, std::memory_order_relaxed);
       slot_[s].done.store(0, std::memory_order_relaxed);
     }
-    for (int t = 0; t < threads; ++t) threads_.emplace_back([this, t, threads] { Loop(t, threads); });
-  }
-  ~CodeRefreshers() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      stop_.store(true, std::memory_order_release);
+    try {
+      for (int t = 0; t < threads; ++t) threads_.emplace_back([this, t, threads] { Loop(t, threads); });
+    } catch (...) {   // (a thread could not be started: stop the ones that were, then let the caller know)
+      Stop();
+      throw;
     }
-    cv_.notify_all();
-    for (auto& t : threads_) t.join();
   }
+  ~CodeRefreshers() { Stop(); }
   CodeRefreshers(const CodeRefreshers&) = delete;
   CodeRefreshers& operator=(const CodeRefreshers&) = delete;
 
@@ -88,6 +86,15 @@ class CodeRefreshers {
   }
 
  private:
+  void Stop() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_.store(true, std::memory_order_release);
+    }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+    threads_.clear();
+  }
   struct alignas(64) Slot {
     std::atomic<long> submitted;   // window number + 1 whose input the slot holds
     std::atomic<long> done;        // window number + 1 whose output the slot holds

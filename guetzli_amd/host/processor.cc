@@ -688,7 +688,13 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   const int ncomp = jpg_ncomp_;
   if (!refreshers_) {
     const int t = CodeRefreshThreads();
-    if (t > 0) refreshers_.reset(new CodeRefreshers(t));
+    if (t > 0) {
+      try {
+        refreshers_.reset(new CodeRefreshers(t));
+      } catch (const std::exception&) {   // (no thread to be had: the reference's serial loop)
+        refreshers_.reset();
+      }
+    }
   }
   // ---- phase A on the device ----
   std::vector<int32_t>& cand_off = cand_off_;

@@ -1378,6 +1378,18 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
     // visited -- or here, if the whole mirror is going to be read)
     if (verify_ || (direction == -1 && !last_search_of_round)) settle_all(direction);
   }
+  if (getenv("GZ_CHECK_MIRROR")) {
+    // self-check of the lazily maintained mirror (the tests): every block caught up now, the host's
+    // image must be the device's, coefficient for coefficient
+    settle_all(-1);
+    std::vector<int16_t> co((size_t)nblk_ * 64);
+    rc = gz_get_coeffs(ctx_, co.data());
+    if (rc != GZ_OK) return Fail("gz_get_coeffs", rc);
+    if (memcmp(co.data(), img_.data(), co.size() * sizeof(int16_t)) != 0) {
+      fprintf(stderr, "guetzli_amd: the host mirror of the image differs from the device image after the search\n");
+      return false;
+    }
+  }
   return true;
 }
 

@@ -423,3 +423,20 @@ def test_parallel_step_count_of_a_long_prefix_in_emulation(host_emu, monkeypatch
     got, info = host_emu.process(rgb, quality=95)
     assert got == exp_jpg
     assert info["counters"]["phase B fast steps"] > 0
+
+
+@needs_ref
+@pytest.mark.parametrize("kw", [{}, {"force_420": True}])
+def test_lazy_host_mirror_equals_the_device_image_after_the_search(host_emu, monkeypatch, kw):
+    """The host's mirror of the coefficients follows the bulk steps block by block, in whichever direction a
+    block lags (also across the turn from "up" to "down"): after every search, with every block caught up, it
+    must equal the device image (GZ_CHECK_MIRROR makes the driver check that itself), with and without the
+    code-refresh helpers' steps taken ahead and undone."""
+    monkeypatch.setenv("GZ_CHECK_MIRROR", "1")
+    rgb = images.crop(48, 40, 300, 150)
+    for threads in ("0", "3"):
+        monkeypatch.setenv("GZ_CODE_THREADS", threads)
+        monkeypatch.setenv("GZ_CODE_SERIAL_STEPS", "0")
+        exp_jpg, _ = ref.process_params(rgb, ref._butteraugli_score_for_quality(95.0), **kw)
+        got, _ = host_emu.process(rgb, quality=95, **kw)
+        assert got == exp_jpg

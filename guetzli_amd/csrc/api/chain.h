@@ -413,7 +413,7 @@ int join_mask_branch(gz_ctx* c) {
 
 // DiffmapPsychoImage (butteraugli.cc:817-908) + score: p0 = original, p1 = candidate.
 int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block_max,
-                  bool max_cleared = false) {
+                  bool max_cleared = false, bool want_distmap = true) {
   const float hf_asymmetry_ = 0.8f;
   // side stream: SameNoise blur + the mask branch; main stream: Malta
   TRY(fork_side_branch(c, p0, p1));
@@ -453,7 +453,7 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
   }
   {  // CalculateDiffmap second half: blur(sigma 1.725, border_ratio 1.0) + mix
     SrcPack<SrcPlain, 1> s; s.s[0].p = c->dsq;
-    PostDiffmapMix post; post.d = c->dsq; post.out = c->distmap;
+    PostDiffmapMix post; post.d = c->dsq; post.out = want_distmap ? c->distmap : nullptr;
     if (!max_cleared) HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
     BlockMaxOut bm{want_block_max ? c->d_block_max : nullptr, c->d_max_bits, c->bw};
     TRY((blur2d<3, 1, SrcPlain, PostDiffmapMix, true>(c, s, post, c->blur[B_FINAL], bm)));
@@ -523,11 +523,18 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
 }
 
 // One full Compare of the current candidate, everything on the stream.
-int enqueue_compare(gz_ctx* c, bool want_block_max) {
+// want_distmap = false (the search loop, gz_time_compare): the last kernel leaves the per-block maxima and the
+// image maximum only; c->distmap then holds no distance map (have_distmap_plane).
+static bool always_store_distmap() {   // GZ_STORE_DISTMAP=1: the chain as it was until round 5 (A/B)
+  static const char* e = getenv("GZ_STORE_DISTMAP");
+  return e && atoi(e) != 0;
+}
+int enqueue_compare(gz_ctx* c, bool want_block_max, bool want_distmap = false) {
+  want_distmap = want_distmap || always_store_distmap();
   TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
   TRY(stage_opsin(c));
   TRY(stage_separate(c, &c->pi1, !single_stream()));
-  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, true));
+  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, true, want_distmap));
   return GZ_OK;
 }
 

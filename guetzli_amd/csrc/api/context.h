@@ -131,15 +131,75 @@ struct StreamSet {
 };
 struct StreamSetPool {
   std::mutex mu;
-  std::multimap<int, StreamSet> sets;   // device * 2 + (main stream at the device's highest priority)
+  std::multimap<int, StreamSet> sets;   // stream_set_key(): device, CU class, main stream at the highest priority
 };
 inline StreamSetPool& stream_set_pool() { static StreamSetPool p; return p; }
 
-hipError_t pool_stream_set_create(StreamSet* out, bool prio_main) {
+// CU-partitioned stream sets (round 6; GZ_CU_PARTITION = P in {2, 4, 8}, default off): the contexts alive on a
+// device take SLOTS (the lowest free one), and the four streams of the context in slot s are created with
+// hipExtStreamCreateWithCUMask on the (s mod P)-th P-th of the device's CUs, so that P images in flight
+// run on disjoint CUs instead of time-sharing all of them.  Which CUs a run of mask bits names: the
+// kernel driver deals the bits round-robin over the XCDs and, inside an XCD, over its shader engines
+// (bit i -> XCD i mod 8, engine (i / 8) mod 4), so a contiguous P-th of the 256 bits is 32 / P CUs of
+// EVERY XCD, spread over its engines -- every stream still sees all eight L2s and a dispatch's
+// round-robin of workgroups over the XCDs finds CUs on each (tools/ubench/cumask.hip prints the map).
+// GZ_CU_MAIN / GZ_CU_SIDE = "lo:hi" (bit ranges; experiments on ONE image: the chain's main stream and
+// its two side streams on separate CUs).  CU class 0 = no mask.
+struct CuPlan { int parts = 0; int main_lo = -1, main_hi = -1, side_lo = -1, side_hi = -1; };
+inline const CuPlan& cu_plan() {
+  static const CuPlan plan = [] {
+    CuPlan p;
+    if (const char* e = getenv("GZ_CU_PARTITION")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) p.parts = v; }
+    if (const char* e = getenv("GZ_CU_MAIN")) (void)sscanf(e, "%d:%d", &p.main_lo, &p.main_hi);
+    if (const char* e = getenv("GZ_CU_SIDE")) (void)sscanf(e, "%d:%d", &p.side_lo, &p.side_hi);
+    return p;
+  }();
+  return plan;
+}
+// Slots of the contexts alive per device (lowest free first).
+struct CuSlots {
+  std::mutex mu;
+  std::map<int, std::vector<bool> > used;
+};
+inline CuSlots& cu_slots() { static CuSlots s; return s; }
+inline int cu_slot_take(int device) {
+  CuSlots& cs = cu_slots();
+  std::lock_guard<std::mutex> lk(cs.mu);
+  std::vector<bool>& u = cs.used[device];
+  for (size_t i = 0; i < u.size(); ++i) if (!u[i]) { u[i] = true; return (int)i; }
+  u.push_back(true);
+  return (int)u.size() - 1;
+}
+inline void cu_slot_release(int device, int slot) {
+  CuSlots& cs = cu_slots();
+  std::lock_guard<std::mutex> lk(cs.mu);
+  std::vector<bool>& u = cs.used[device];
+  if (slot >= 0 && (size_t)slot < u.size()) u[(size_t)slot] = false;
+}
+#ifndef GZ_EMU
+static hipError_t create_stream_on_cus(hipStream_t* out, int lo, int hi) {
+  hipDeviceProp_t prop;
+  int device = 0;
+  (void)hipGetDevice(&device);
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return e;
+  const int ncu = prop.multiProcessorCount;
+  lo = std::max(0, std::min(lo, ncu)); hi = std::max(lo, std::min(hi, ncu));
+  if (hi - lo <= 0 || hi - lo >= ncu) return hipStreamCreate(out);
+  std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+  for (int i = lo; i < hi; ++i) mask[(size_t)i >> 5] |= 1u << (i & 31);
+  return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+}
+#endif
+inline int stream_set_key(int device, bool prio_main, int cu_class) {
+  return (device * 64 + cu_class) * 2 + (prio_main && stream_priorities() ? 1 : 0);
+}
+
+hipError_t pool_stream_set_create(StreamSet* out, bool prio_main, int cu_class) {
 #ifndef GZ_EMU
   int device = 0;
   (void)hipGetDevice(&device);
-  const int key = device * 2 + (prio_main && stream_priorities() ? 1 : 0);
+  const int key = stream_set_key(device, prio_main, cu_class);
   StreamSetPool& p = stream_set_pool();
   std::lock_guard<std::mutex> lk(p.mu);   // (also keeps two threads' creations from interleaving)
   auto it = p.sets.find(key);
@@ -153,11 +213,23 @@ hipError_t pool_stream_set_create(StreamSet* out, bool prio_main) {
   hipStream_t* slot[4] = {&out->own, &out->side, &out->side2, &out->entropy};
   int least = 0, greatest = 0;
   const bool prio = (key & 1) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+  const CuPlan& cp = cu_plan();
   hipError_t e = hipSuccess;
   for (int j = 0; j < 4 && e == hipSuccess; ++j) {
     const int which = (j + 4 - rot) & 3;   // position j of the creation order takes stream `which`: own at position rot
-    e = which == 0 && prio ? hipStreamCreateWithPriority(slot[which], hipStreamDefault, greatest)
-                           : hipStreamCreate(slot[which]);
+    if (cu_class > 0 && cp.parts > 0) {        // a batch's image: all four streams on its share of the CUs
+      int ncu = 256;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+      const int per = ncu / cp.parts, s = (cu_class - 1) % cp.parts;
+      e = create_stream_on_cus(slot[which], s * per, (s + 1) * per);
+    } else if (cu_class > 0 && which == 0 && cp.main_lo >= 0) {
+      e = create_stream_on_cus(slot[which], cp.main_lo, cp.main_hi);
+    } else if (cu_class > 0 && (which == 1 || which == 2) && cp.side_lo >= 0) {
+      e = create_stream_on_cus(slot[which], cp.side_lo, cp.side_hi);
+    } else {
+      e = which == 0 && prio ? hipStreamCreateWithPriority(slot[which], hipStreamDefault, greatest)
+                             : hipStreamCreate(slot[which]);
+    }
   }
   return e;
 #else
@@ -168,12 +240,12 @@ hipError_t pool_stream_set_create(StreamSet* out, bool prio_main) {
   return e;
 #endif
 }
-void pool_stream_set_destroy(const StreamSet& s_, bool prio_main) {
+void pool_stream_set_destroy(const StreamSet& s_, bool prio_main, int cu_class) {
 #ifndef GZ_EMU
   if (s_.own && s_.side && s_.side2 && s_.entropy && pool_limit_bytes() != 0) {
     int device = 0;
     (void)hipGetDevice(&device);
-    const int key = device * 2 + (prio_main && stream_priorities() ? 1 : 0);
+    const int key = stream_set_key(device, prio_main, cu_class);
     StreamSetPool& p = stream_set_pool();
     std::lock_guard<std::mutex> lk(p.mu);
     if (p.sets.count(key) < 16) { p.sets.insert(std::make_pair(key, s_)); return; }
@@ -244,6 +316,7 @@ struct gz_ctx {
   // mask: DiffPrecompute + three blurs), forked and joined with events
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   bool prio_streams = false, counted_live = false;   // (see create_context)
+  int cu_slot = -1, cu_class = 0;   // CU-partitioned stream sets (cu_plan): the context's slot; 0 = unmasked streams
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mask_pre = nullptr;
   hipEvent_t ev_next_cand = nullptr;   // next_cand uploaded beside a Compare chain in flight
   hipEvent_t ev_xyb = nullptr, ev_lfy = nullptr;   // B plane's LF blur on side stream 2 (stage_separate)

@@ -135,7 +135,7 @@ int gz_compare(gz_ctx* c, float* distance, float* distmap, float* block_max) {
   DeviceScope ds_(c);
   if (!c || !distance) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
-  TRY(enqueue_compare(c, true));
+  TRY(enqueue_compare(c, true, distmap != nullptr));   // (the map is stored only for a caller that takes it)
   void* res = nullptr;
   TRY(result_buffer(c, 4, &res));
   HIPCHK(c, hipMemcpyAsync(res, c->d_max_bits, 4, hipMemcpyDeviceToHost, c->stream));

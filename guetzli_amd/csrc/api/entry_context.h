@@ -99,8 +99,15 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   c->prio_streams = live_contexts(device, +1) == 0;
   c->counted_live = true;
   {
+    const CuPlan& cp = cu_plan();
+    if (cp.parts > 0) {
+      c->cu_slot = cu_slot_take(device);
+      c->cu_class = 1 + c->cu_slot % cp.parts;
+    } else if (cp.main_lo >= 0 || cp.side_lo >= 0) {
+      c->cu_class = 1;
+    }
     StreamSet ss;
-    const hipError_t se = pool_stream_set_create(&ss, c->prio_streams);
+    const hipError_t se = pool_stream_set_create(&ss, c->prio_streams, c->cu_class);
     c->own_stream = ss.own; c->side_stream = ss.side; c->side_stream2 = ss.side2; c->entropy_stream = ss.entropy;
     c->stream = c->own_stream;
     CHK0(se);
@@ -241,8 +248,9 @@ void gz_destroy(gz_ctx* c) {
   {   // the four streams go back as the set they were made as (own_stream: synchronised at the top of gz_destroy)
     StreamSet ss;
     ss.own = c->own_stream; ss.side = c->side_stream; ss.side2 = c->side_stream2; ss.entropy = c->entropy_stream;
-    pool_stream_set_destroy(ss, c->prio_streams);
+    pool_stream_set_destroy(ss, c->prio_streams, c->cu_class);
   }
+  if (c->cu_slot >= 0) cu_slot_release(c->device, c->cu_slot);
   if (c->counted_live) (void)live_contexts(c->device, -1);
   delete c;
 }

@@ -79,11 +79,12 @@ def build(force=False, verbose=False):
         if os.path.exists(LIB):
             return LIB     # prebuilt library shipped with the snapshot, no compiler here
         raise RuntimeError("hipcc not found and no prebuilt libguetzli_amd.so")
-    # Two code objects, gfx950 with XNACK off and on (the runtime loads the one matching the
-    # process): code compiled for a known XNACK mode schedules its memory clauses more freely than
-    # the "any" default -- the Compare chain runs 2-4 % (1080p) / 1.6 % (4K) faster on the usual
-    # XNACK-off boxes (profiles/r02_packed_blur_and_malta_diff_experiments.log, section 9).
-    cmd = [hipcc] + [f"--offload-arch={ARCH}:xnack{m}" for m in ("-", "+")] + FLAGS + \
+    # One code object, gfx950 with XNACK off: code compiled for a known XNACK mode schedules its memory
+    # clauses more freely than the "any" default -- the Compare chain runs 2-4 % (1080p) / 1.6 % (4K)
+    # faster (profiles/r02_packed_blur_and_malta_diff_experiments.log, section 9).  Until round 5 an
+    # xnack+ code object rode along for processes started with HSA_XNACK=1; this pool runs XNACK off only
+    # (and refuses libraries that carry xnack+ code), and that is what MI355X boxes default to.
+    cmd = [hipcc, f"--offload-arch={ARCH}:xnack-"] + FLAGS + \
         [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     return _run(cmd, verbose)
 

@@ -18,6 +18,10 @@ every candidate, the per-block zeroing search, JPEG entropy coding of every cand
 in host memory and ends with the JPEG bytes in host memory, so the (small) PCIe traffic of
 the boundary is inside the number.  Rank 0's output is checked against the reference's
 JPEG (SHA-256 recorded from the unmodified reference) after the timed region.
+`vs_baseline` = value / BASELINE.md section 2's own measurement of this exact metric on this exact config (C3:
+the unmodified reference, one thread of the survey container's Xeon @ 2.10 GHz: 1111.8 s = 0.00746 MPix/s);
+`vs_reference_same_box` = value / the same reference on one thread of the bench box's kind of host CPU
+(profiles/r05_reference_cpu_4k.json).
 
 Also on the JSON line:
   value_workload -- "3840x2160" (or "1920x1080" with --no-4k): which size `value` is.  `value_4k`
@@ -81,6 +85,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+BASELINE_MD_MPIX_S = {"3840x2160": 0.00746, "1920x1080": 0.00770}
 ALGO_BYTES_PER_PX = 494.0          # 123.5 float-plane passes per Compare
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
 QUALITY = 95.0
@@ -128,9 +133,9 @@ def load_kernel_roofline():
     return None
 
 
-def mosaic_golden():
+def mosaic_golden(name="mosaic_3840x2160_q95"):
     try:
-        return json.load(open(os.path.join(ROOT, "tests", "golden", "photos", "mosaic_3840x2160_q95.json")))
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "photos", name + ".json")))
     except Exception:
         return None
 
@@ -166,8 +171,17 @@ def cpu_baseline():
             full[key]["source"] = "profiles/" + name
         except Exception:
             pass
+    # ... and every host core at once, the reference's own batch form (tests/golden_test.sh:24-26: one process
+    # per image under xargs -P): the figure the per-GPU batch numbers (`scale_value`, `batch_*`) stand beside
+    all_cores = None
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_cpu_all_cores.py"), str(w), str(h)],
+                           capture_output=True, text=True, timeout=240)
+        all_cores = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        all_cores = {"error": f"{type(e).__name__}: {e}"}
     return {"value": round(w * h / 1e6 / dt, 6), "unit": "MPix/s", "cores": 1,
-            "kind": "reference", "full_images_same_box_kind": full,
+            "kind": "reference", "all_cores": all_cores, "full_images_same_box_kind": full,
             "note": "full_images_same_box_kind: the BASELINE images of `value` / `value_1080p` through the unmodified "
                     "reference on the bench box's kind of host CPU, one thread -- COMMITTED records of a gpurun "
                     "session (each carries its commit in `head` and its seconds; 9 and 2.3 minutes are too long for "
@@ -267,23 +281,43 @@ class Env:
             self.dist = dist
 
     def bind_cpus(self):
-        """One process per GPU: every rank keeps to its own contiguous share of the host cores
-        (its image threads and the driver's worker pool then do not migrate across the other
-        ranks' cores / NUMA nodes).  BENCH_NO_AFFINITY=1 leaves the scheduler alone."""
+        """One process per GPU: rank r keeps to the host cores of GPU r's NUMA node -- its share of them among the
+        ranks whose GPUs hang off the same node, whole physical cores (guetzli_amd/affinity.py: sysfs numa_node /
+        local_cpulist of the GPU's PCI function; contiguous shares of the allowed cores where sysfs says nothing).
+        Its image threads, code-refresh helpers and the driver's worker pool then stay next to its GPU and off the
+        other ranks' cores.  BENCH_NO_AFFINITY=1 leaves the scheduler alone.  The binding is on the JSON line
+        (`binding_per_rank`)."""
+        from guetzli_amd import affinity
+        self.binding = {"rank": self.rank, "how": "not bound"}
         if os.environ.get("BENCH_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
             return
         try:
-            cpus = sorted(os.sched_getaffinity(0))
-            per = len(cpus) // self.world
-            if per >= 1:
-                os.sched_setaffinity(0, cpus[self.local_rank * per:(self.local_rank + 1) * per])
-            else:   # fewer cores than ranks: nothing to partition, say so
-                print(f"bench.py: rank {self.rank}: {len(cpus)} host cores for {self.world} ranks -- "
-                      "not binding (ranks share the cores)", file=sys.stderr, flush=True)
+            allowed = sorted(os.sched_getaffinity(0))
+            bus_ids = [None] * self.world if self.emulate else affinity.device_bus_ids(self.world)
+            p = affinity.plan(self.local_rank, self.world, bus_ids, allowed,
+                              os.environ.get("BENCH_SYSFS_ROOT", "/sys"))
+            if p["cpus"]:
+                os.sched_setaffinity(0, p["cpus"])
+            else:
+                print(f"bench.py: rank {self.rank}: {p['how']}", file=sys.stderr, flush=True)
+            self.binding = {"rank": self.rank, "gpu_pci_bus_id": p["gpu_pci_bus_id"], "numa_node": p["numa_node"],
+                            "host_cpus": affinity.format_cpulist(p["cpus"] or allowed),
+                            "n_host_cpus": len(p["cpus"] or allowed), "ranks_on_node": p["ranks_on_node"],
+                            "how": p["how"]}
         except OSError as e:
             print(f"bench.py: rank {self.rank}: sched_setaffinity failed ({e}) -- not binding",
                   file=sys.stderr, flush=True)
         self.cores = len(os.sched_getaffinity(0))
+
+    def bindings(self):
+        """Every rank's binding record, on every rank (all-gathered; one record at world size 1)."""
+        mine = getattr(self, "binding", {"rank": self.rank, "how": "not bound (single process)",
+                                         "n_host_cpus": self.cores})
+        if self.dist is None:
+            return [mine]
+        got = [None] * self.world
+        self.dist.all_gather_object(got, mine)
+        return got
 
     def sync(self):
         if not self.emulate:
@@ -410,7 +444,7 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
                                 for k in sorted({r["rank"] for r in recs})},
             "encode_seconds_per_rank": {str(k): round(sum(r["seconds"] for r in recs if r["rank"] == k), 3)
                                         for k in sorted({r["rank"] for r in recs})},
-            "host_cores_per_rank": env.cores}
+            "host_cores_per_rank": env.cores, "binding_per_rank": env.bindings()}
 
 
 def _latest_profile(name):
@@ -485,6 +519,8 @@ def main():
     ap.add_argument("--batch-images", type=int, default=16,
                     help="images of the extra concurrent-batch leg (0 = skip)")
     ap.add_argument("--batch-workers", type=int, default=4)
+    ap.add_argument("--no-1mpix", action="store_true", help="skip the 1024x1024 legs (value_1mpix, its batch, iteration floor)")
+    ap.add_argument("--batch-1mpix", type=int, default=64, help="images of the 1 MPix batch leg (0 = skip)")
     ap.add_argument("--config5", action="store_true",
                     help="run only BASELINE config 5's slice (8 x 4K per GPU) and report it as value")
     ap.add_argument("--images-per-gpu", type=int, default=8)
@@ -555,6 +591,61 @@ def main():
         first_encode_4k_s = time.perf_counter() - t0
         dt4k, (jpg4k, info4k) = timed_steps(env, step4k, args.steps, args.warmup)
         step_ms_4k = list(STEP_MS)
+
+    # Where the tool is mostly used: <= 2 MPix.  One 1024x1024 image without a period (tests/images.mosaic), timed
+    # exactly like `value` (every rank, same bracket), and -- rank 0 -- 64 of them (circular shifts) four in flight;
+    # `iteration_floor_us`: a 64x64 image's time per phase-B iteration = the size-independent latency of one
+    # iteration (launches, host round trips), which a 1 MPix image pays 150 times.
+    W1, H1 = (32, 32) if emu else (1024, 1024)
+    gold1m = None if emu else mosaic_golden("mosaic_1024x1024_q95")
+    small = None
+    if not args.no_1mpix:
+        rgb1m = images.tiled(W1, H1) if emu else images.mosaic(W1, H1)
+        step1m = lambda: host.process(rgb1m, quality=quality, device=local_rank)
+        step1m()
+        dt1m, (jpg1m, info1m) = timed_steps(env, step1m, args.steps, args.warmup)
+        small = {"workload": f"single {W1}x{H1} image without a period (tests/images.mosaic), --quality {quality:g}, whole "
+                             f"guetzli::Process per step, timed like `value` ({args.steps} steps after {args.warmup} warm-up)",
+                 "value": round(world * args.steps * W1 * H1 / 1e6 / dt1m, 4), "unit": "MPix/s",
+                 "ms_per_step": round(dt1m / args.steps * 1e3, 2), "step_ms": list(STEP_MS),
+                 "iterations": info1m["counters"].get("number of iterations"), "output_bytes": len(jpg1m),
+                 "host_timers_s": {k: round(v, 3) for k, v in info1m["timers"].items()
+                                   if k in ("total", "phase_b_host", "compare", "block_search", "select_quant_matrix")}}
+        if gold1m is not None and rank == 0:
+            assert hashlib.sha256(rgb1m.tobytes()).hexdigest() == gold1m["rgb_sha256"], "1 MPix input differs from the golden's"
+            assert hashlib.sha256(jpg1m).hexdigest() == gold1m["jpeg_sha256"], "1 MPix output differs from the reference"
+            small["output_sha256_matches_reference"] = True
+            small["reference_cpu_seconds_build_container"] = gold1m.get("reference_cpu_seconds")
+        if rank == 0 and world == 1:
+            from guetzli_amd.batch import encode_concurrent
+            n1 = 2 if emu else args.batch_1mpix
+            if n1 > 0:
+                imgs1 = [images.shifted(rgb1m, k) for k in range(n1)]
+                proc1 = lambda im: host.process(im, quality=quality, device=local_rank)
+                encode_concurrent(imgs1[:args.batch_workers], proc1, args.batch_workers)   # warm-up
+                env.sync()
+                tb = time.perf_counter()
+                outs1 = encode_concurrent(imgs1, proc1, args.batch_workers)
+                env.sync()
+                tb = time.perf_counter() - tb
+                assert gold1m is None or hashlib.sha256(outs1[0][0]).hexdigest() == gold1m["jpeg_sha256"]
+                small["batch"] = {"images": n1, "in_flight": args.batch_workers, "seconds": round(tb, 3),
+                                  "value": round(n1 * W1 * H1 / 1e6 / tb, 3), "unit": "MPix/s",
+                                  "distinct_outputs": len({hashlib.sha256(o[0]).hexdigest() for o in outs1}),
+                                  "note": f"{n1} independent {W1}x{H1} images (the image above circularly shifted by "
+                                          "(37k, 53k)), several in flight on ONE GPU; output 0 checked against the reference"}
+            # the per-iteration floor
+            tiny = images.crop(64, 64, 220, 120) if not emu else images.tiled(16, 16)
+            host.process(tiny, quality=quality, device=local_rank)
+            runs = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                _, itiny = host.process(tiny, quality=quality, device=local_rank)
+                runs.append(time.perf_counter() - t0)
+            it = max(1, int(itiny["counters"].get("number of iterations", 1)))
+            small["iteration_floor_us"] = round(sorted(runs)[2] / it * 1e6, 1)
+            small["iteration_floor_note"] = (f"a 64x64 image's whole encode / its {it} phase-B iterations (median of five): "
+                                             "launch + round-trip latency of one iteration, independent of the image size")
 
     # roofline legs: HIP events on the context's stream around whole Compare chains
     # (warm-up: the clocks need ~20 ms of sustained chains to settle -- the first 20 chains after an
@@ -690,7 +781,13 @@ def main():
             "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head[1],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak",
+            # BASELINE.md section 2 measured this metric on this config (one thread of the survey container's CPU);
+            # per GPU, so that the figure means the same at every N
+            "vs_baseline": None if emu else round(head[0] / world / BASELINE_MD_MPIX_S[f"{head[4][0]}x{head[4][1]}"], 1),
+            "vs_baseline_note": "value per GPU / BASELINE.md section 2's reference figure for this config (C3: 0.00746 "
+                                "MPix/s, C2: 0.00770; one thread, Xeon @ 2.10 GHz); the same reference on one thread of "
+                                "the bench box's kind of host: cpu_baseline.full_images_same_box_kind",
             "dtype": "f32+f64 (butteraugli), int32/int16 (DCT/quantize/entropy coding)",
             "data": f"synthetic (tests/golden/bees.png tiled to {head[4][0]}x{head[4][1]}, SURVEY 8d)",
             "config": head[2],
@@ -722,6 +819,11 @@ def main():
             out["roofline_1080p"] = roof_small
             if kernels and not kernels.get("stale"):
                 out["block_passes"] = kernels.get("block_passes")
+        if small is not None:
+            out["value_1mpix"] = small["value"]
+            out["ms_per_step_1mpix"] = small["ms_per_step"]
+            out["iteration_floor_us"] = small.get("iteration_floor_us")
+            out["config_1mpix"] = small
         if c5 is not None:
             other = dict(other or {})
             other["config5_slice"] = c5
@@ -739,6 +841,11 @@ def main():
                 out["box"] = cal
         if world == 1 and not args.no_cpu_baseline and not emu:
             out["cpu_baseline"] = cpu_baseline()
+            try:   # the same reference, one thread of this kind of host, on the headline image (committed record)
+                same = out["cpu_baseline"]["full_images_same_box_kind"][f"{head[4][0]}x{head[4][1]}_q95"]
+                out["vs_reference_same_box"] = round(head[0] / same["value"], 1)
+            except (KeyError, TypeError):
+                pass
         print(json.dumps(out), flush=True)
     env.finish()
 

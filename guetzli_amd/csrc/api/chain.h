@@ -17,7 +17,15 @@ namespace {
 // What round 4 removed after it had lost every A/B of rounds 2 and 3: the unrolled (non-compact)
 // column pass and fused kernels, 64-row tiles, the epilogue without 16-byte accesses and the row
 // pass with LDS bank conflicts (GZ_BLUR_OPT), the three-plane LF passes, the unpaired mask blurs.
+// GZ_SIDE_SMALL=1 (experiment, round 6): the kernels of the two side branches (SameNoise blur, mask blurs) in
+// the forms whose workgroups fit into the hole ONE retiring Malta workgroup leaves on a CU (<= 64 VGPRs, <= 19.7 KB
+// of LDS): unpaired row / column passes, 16-row tiles -- c->side_small is set while those launches are made.
+static bool side_small_wanted() {
+  static const char* e = getenv("GZ_SIDE_SMALL");
+  return e && atoi(e) != 0;
+}
 static bool packed_blur(const gz_ctx* c) {
+  if (c->side_small) return false;
   const char* e = getenv("GZ_BLUR_PK");
   if (e) return atoi(e) != 0;
   // (round 5, with 16-row tiles: 1080p 0.3356 -> 0.3290 ms, 2560 x 1440 0.487 -> 0.466, 3200 x 1800 0.719 -> 0.684;
@@ -27,6 +35,7 @@ static bool packed_blur(const gz_ctx* c) {
 constexpr int kTileRows = 32;
 constexpr int kSmallTileRows = 16;
 static bool small_tiles(const gz_ctx* c) {
+  if (c->side_small) return true;
   const char* e = getenv("GZ_TILE_ROWS");
   if (e && atoi(e) == 16) return true;
   if (e && atoi(e) == 32) return false;
@@ -388,6 +397,7 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
   hipStream_t main_stream = c->stream;
   int rc = GZ_OK;
   c->stream = c->side_stream2;
+  c->side_small = side_small_wanted();
   {  // SameNoiseLevels blur input + blur (sigma 10.67)
     SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].a = p0.hf[1]; s.s[0].b = p1.hf[1];
@@ -398,6 +408,7 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
   }
   c->stream = c->side_stream;
   if (rc == GZ_OK) rc = stage_mask_blurs(c, mask_pack_psycho(c, p1), c->side_stream2);
+  c->side_small = false;
   c->stream = main_stream;
   TRY(rc);
   HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
@@ -428,6 +439,14 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.pass[2] = {p0.mf[ch], p1.mf[ch], ms[ch][2].nm, ms[ch][2].lf};
     a.out = c->ac[ch];
   }
+#ifndef GZ_EMU
+  // GZ_MALTA_PAD = bytes of (unused) dynamic LDS per workgroup (experiment, round 6): 19.7 KB + pad bounds the
+  // workgroups a CU holds (8 without; 3 KB: 7, 7 KB: 6, 13 KB: 4) and leaves wave slots and registers to others
+  static const int malta_pad = [] { const char* e = getenv("GZ_MALTA_PAD"); return e ? std::max(0, atoi(e)) : 0; }();
+  if (malta_pad > 0) {
+    hipLaunchKernelGGL((k_malta_rolled<3>), mgrid, dim3(256), (size_t)malta_pad, c->stream, ay, ax, c->w, c->h, c->pitch);
+  } else
+#endif
   GZ_LAUNCH((k_malta_rolled<3>), mgrid, dim3(256), c->stream, ay, ax, c->w, c->h, c->pitch);
   KCHK(c);
   TRY(join_mask_branch(c));

@@ -304,6 +304,7 @@ PHOTOS = {
     # BASELINE configs[2]'s size on content without a period
     "mosaic_3840x2160_q95": (("mosaic", 3840, 2160), 95.0, dict(), None),
     "mosaic_1920x1080_q95": (("mosaic", 1920, 1080), 95.0, dict(), None),
+    "mosaic_1024x1024_q95": (("mosaic", 1024, 1024), 95.0, dict(), None),           # bench.py's value_1mpix (round 6)
     "mosaic_3840x2160_q84": (("mosaic", 3840, 2160), 84.0, dict(), None),          # BASELINE configs[3]'s quality
     "mosaic_1920x1080_force420_q90": (("mosaic", 1920, 1080), 90.0, dict(force_420=True), None),
     "hubble_jpegin_q99": (None, 99.0, dict(), "hubble"),

@@ -120,7 +120,8 @@ def build_host(force=False, verbose=False, device_lib=None, out=None):
     device_lib = device_lib or LIB
     out = out or HOST_LIB
     srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
-    deps = srcs + [os.path.join(HOST_DIR, h) for h in ("jpeg_reader.h", "jpeg_writer.h", "png_reader.h", "processor.h", "lazy_sort.h", "parallel.h", "silver_screen.h")] + \
+    # every header of the directory (round 5's code_refresh.h was missing from a hand-kept list: VERDICT r5)
+    deps = srcs + sorted(os.path.join(HOST_DIR, h) for h in os.listdir(HOST_DIR) if h.endswith(".h")) + \
         [os.path.join(os.path.dirname(HERE), "include", "guetzli_amd.h"), device_lib]
     if not force and os.path.exists(out) and \
             all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps if os.path.exists(d)):

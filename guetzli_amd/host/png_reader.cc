@@ -160,7 +160,11 @@ bool ReadPng(const uint8_t* data, size_t len, int* xsize, int* ysize, std::vecto
   memset(palette, 0, sizeof(palette));   // libpng's palette is zero-filled up to 256 entries
   memset(tr.alpha, 0xff, sizeof(tr.alpha));
   bool have_ihdr = false, have_plte = false, have_idat = false, have_iend = false;
-  std::vector<uint8_t> idat;
+  // The image data = the FIRST run of consecutive IDAT chunks (libpng reads rows from it and stops at the first
+  // chunk of another type; IDAT chunks behind that are skipped with a warning), kept as the chunks they are.
+  std::vector<std::pair<const uint8_t*, size_t> > idat;
+  size_t idat_bytes = 0;
+  bool idat_run_over = false;
   size_t pos = 8;
   while (!have_iend) {
     if (len - pos < 12) return Fail(error, "unexpected end of data");
@@ -177,6 +181,7 @@ bool ReadPng(const uint8_t* data, size_t len, int* xsize, int* ysize, std::vecto
     const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + clen);
     const bool crc_ok = crc == Be32(body + clen);
     pos += 12 + (size_t)clen;
+    if (have_idat && memcmp(type, "IDAT", 4) != 0) idat_run_over = true;
     if (!crc_ok) {
       if (critical) return Fail(error, "CRC error in a critical chunk");
       continue;   // ancillary: discarded with a warning
@@ -208,7 +213,7 @@ bool ReadPng(const uint8_t* data, size_t len, int* xsize, int* ysize, std::vecto
       have_ihdr = true;
     } else if (memcmp(type, "PLTE", 4) == 0) {
       if (have_plte) return Fail(error, "duplicate PLTE");
-      if (have_idat) return Fail(error, "PLTE after IDAT");
+      if (have_idat) continue;   // out of place: ignored (the missing palette was refused at the first IDAT)
       if (hd.color_type == 0 || hd.color_type == 4) continue;   // ignored in greyscale PNGs
       if (clen > 3 * 256 || clen % 3 != 0) {
         if (hd.color_type == 3) return Fail(error, "invalid palette");
@@ -236,7 +241,10 @@ bool ReadPng(const uint8_t* data, size_t len, int* xsize, int* ysize, std::vecto
       }   // not allowed with an alpha channel: ignored
     } else if (memcmp(type, "IDAT", 4) == 0) {
       if (hd.color_type == 3 && !have_plte) return Fail(error, "missing PLTE before IDAT");
-      idat.insert(idat.end(), body, body + clen);
+      if (!idat_run_over) {
+        idat.push_back(std::make_pair(body, (size_t)clen));
+        idat_bytes += clen;
+      }
       have_idat = true;
     } else if (memcmp(type, "IEND", 4) == 0) {
       have_iend = true;
@@ -271,36 +279,78 @@ bool ReadPng(const uint8_t* data, size_t len, int* xsize, int* ysize, std::vecto
   // declares more samples than the IDAT data can possibly inflate to is rejected before
   // anything of that size is allocated (a 60-byte file declaring 10^6 x 10^6 RGBA16 would
   // otherwise ask for 8 TB here); 3 * width * height <= 24 * total is bounded with it.
-  if (total / 1040 > idat.size() + 64) return Fail(error, "not enough image data");
+  if (total / 1040 > idat_bytes + 64) return Fail(error, "not enough image data");
   std::vector<uint8_t> raw(total);
   {
+    // WHICH damaged streams still count as an image is libpng's call (png_read_IDAT_data / png_read_finish_IDAT,
+    // pngrutil.c), and it depends on how libpng feeds zlib: input in pieces of at most 8192 bytes (PNG_ZBUF_SIZE)
+    // that never span two IDAT chunks, output one scanline (filter byte + row) at a time; a scanline that cannot be
+    // completed is an error; behind the last scanline the rest of the stream is inflated into a 1024-byte scratch
+    // buffer until it ends -- running out of IDAT data before the stream's end is an error there too ("Not
+    // enough image data"), unless nothing at all came out of that last step, while damage in that part only
+    // warns.  Restated here call for call (tests/test_fuzz_readers.py holds it to libpng's verdicts).
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
-    if (inflateInit(&zs) != Z_OK) return Fail(error, "zlib initialisation failed");
-    size_t in_pos = 0, out_pos = 0;
-    int zrc = Z_OK;
-    while (out_pos < total) {
-      if (zs.avail_in == 0) {
-        const size_t chunk = idat.size() - in_pos > (1u << 30) ? (1u << 30) : idat.size() - in_pos;
-        if (chunk == 0) break;
-        zs.next_in = idat.data() + in_pos;
-        zs.avail_in = (uInt)chunk;
-        in_pos += chunk;
+    if (inflateInit2(&zs, 0) != Z_OK) return Fail(error, "zlib initialisation failed");   // window size: the stream's own
+    size_t chunk = 0, left = idat.empty() ? 0 : idat[0].second;
+    const uint8_t* next = idat.empty() ? nullptr : idat[0].first;
+    bool first_byte = true, ended = false;
+    auto refill = [&]() -> bool {   // more input: false when the run of IDAT chunks is used up
+      while (left == 0) {
+        if (++chunk >= idat.size()) return false;
+        next = idat[chunk].first;
+        left = idat[chunk].second;
       }
-      const size_t want = total - out_pos > (1u << 30) ? (1u << 30) : total - out_pos;
-      zs.next_out = raw.data() + out_pos;
-      zs.avail_out = (uInt)want;
-      zrc = inflate(&zs, Z_NO_FLUSH);
-      out_pos += want - zs.avail_out;
-      if (zrc == Z_STREAM_END) break;
-      if (zrc != Z_OK && !(zrc == Z_BUF_ERROR && zs.avail_in == 0)) {
-        inflateEnd(&zs);
-        return Fail(error, "corrupt compressed image data");
+      const size_t n = left < 8192 ? left : 8192;
+      zs.next_in = const_cast<Bytef*>(next);
+      zs.avail_in = (uInt)n;
+      next += n;
+      left -= n;
+      return true;
+    };
+    auto step = [&]() -> int {      // one inflate call as libpng makes it (png_zlib_inflate: the CMF byte's window bits)
+      if (first_byte && zs.avail_in > 0) {
+        if ((zs.next_in[0] >> 4) > 7) return Z_DATA_ERROR;
+        first_byte = false;
       }
-      if (zrc == Z_BUF_ERROR) break;   // input exhausted
+      return inflate(&zs, Z_NO_FLUSH);
+    };
+    const char* problem = nullptr;
+    size_t out_pos = 0;
+    for (int p = 0; p < npass && !problem; ++p) {
+      if (pw[p] == 0 || ph[p] == 0) continue;
+      const size_t rowbytes = ((size_t)pw[p] * hd.bits_per_pixel + 7) / 8;
+      for (uint32_t j = 0; j < ph[p] && !problem; ++j) {
+        size_t want = rowbytes + 1;
+        zs.next_out = raw.data() + out_pos;
+        out_pos += want;
+        if (ended) { problem = "not enough image data"; break; }
+        while (want > 0) {
+          if (zs.avail_in == 0 && !refill()) { problem = "not enough image data"; break; }
+          const uInt out = want > 0x7fffffffu ? 0x7fffffffu : (uInt)want;
+          zs.avail_out = out;
+          const int zrc = step();
+          want -= out - zs.avail_out;
+          if (zrc == Z_STREAM_END) { ended = true; break; }
+          if (zrc != Z_OK) { problem = "corrupt compressed image data"; break; }
+        }
+        if (!problem && want > 0) problem = "not enough image data";
+      }
+    }
+    if (!problem && !ended) {   // the rest of the stream (png_read_finish_IDAT)
+      uint8_t scratch[1024];
+      size_t extra = 0;
+      do {
+        if (zs.avail_in == 0 && !refill()) { problem = "not enough image data"; break; }
+        zs.next_out = scratch;
+        zs.avail_out = (uInt)sizeof(scratch);
+        const int zrc = step();
+        extra += sizeof(scratch) - zs.avail_out;
+        if (zrc != Z_OK) break;   // the end, or damage behind the image: a warning at most
+      } while (extra > 0);
     }
     inflateEnd(&zs);
-    if (out_pos < total) return Fail(error, "not enough image data");
+    if (problem) return Fail(error, problem);
   }
 
   // ---- unfilter + convert ----

@@ -14,6 +14,7 @@
 
 #include "../../include/guetzli_amd.h"
 #include "jpeg_reader.h"
+#include "reader_dump.h"
 #include "png_reader.h"
 #include "silver_screen.h"
 #include "jpeg_writer.h"
@@ -1867,36 +1868,14 @@ void gzh_huffman_depths(const uint32_t* counts, int tree_limit, uint8_t* depth, 
 // run on), GZ_HOST_THREADS overrides.  Test hook for the per-rank core share of a multi-GPU run.
 int gzh_worker_pool_size() { return guetzli_amd::WorkerPool::Get().size(); }
 
-// ReadJpeg as a canonical dump (test hook; oracle/ref_harness.cc writes the same format from
-// the reference's JPEGData): int32 w, h, ncomp; per component id, h_samp, v_samp, quant_idx,
-// width_in_blocks, height_in_blocks; int32 nquant; per table index, precision, 64 values;
-// int32 napp; per entry int32 size + bytes; int32 ncom; likewise; int32 tail size + bytes;
-// then the int16 coefficients of every component.  Returns the dump size (copied if it fits),
-// or -1 if the stream is rejected.
+// ReadJpeg as a canonical dump (test hook; the format: reader_dump.h).  Returns the dump size (copied if it
+// fits), or -1 if the stream is rejected.
 long gzh_read_jpeg(const uint8_t* data, long len, uint8_t* out, long cap) {
   GZH_GUARD_BEGIN
   guetzli_amd::JpegInput jpg;
   std::string err;
   if (!guetzli_amd::ReadJpeg(data, (size_t)len, &jpg, &err)) return -1;
-  std::string d;
-  auto put32 = [&](int32_t v) { d.append((const char*)&v, 4); };
-  auto puts = [&](const std::string& s) { put32((int32_t)s.size()); d.append(s); };
-  put32(jpg.width); put32(jpg.height); put32((int32_t)jpg.components.size());
-  for (const auto& c : jpg.components) {
-    put32(c.id); put32(c.h_samp); put32(c.v_samp); put32(c.quant_idx);
-    put32(c.width_in_blocks); put32(c.height_in_blocks);
-  }
-  put32((int32_t)jpg.quant.size());
-  for (const auto& q : jpg.quant) {
-    put32(q.index); put32(q.precision);
-    for (int k = 0; k < 64; ++k) put32(q.values[k]);
-  }
-  put32((int32_t)jpg.app_data.size());
-  for (const auto& a : jpg.app_data) puts(a);
-  put32((int32_t)jpg.com_data.size());
-  for (const auto& a : jpg.com_data) puts(a);
-  puts(jpg.tail_data);
-  for (const auto& c : jpg.components) d.append((const char*)c.coeffs.data(), c.coeffs.size() * 2);
+  const std::string d = guetzli_amd::DumpJpegInput(jpg);
   if ((long)d.size() <= cap) memcpy(out, d.data(), d.size());
   return (long)d.size();
   GZH_GUARD_END

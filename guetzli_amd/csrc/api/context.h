@@ -451,7 +451,7 @@ namespace {
     hipError_t e_ = (call);                                                          \
     if (e_ != hipSuccess) {                                                          \
       (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
-      return GZ_E_HIP;                                                               \
+      return e_ == hipErrorOutOfMemory ? GZ_E_NOMEM : GZ_E_HIP;                      \
     }                                                                                \
   } while (0)
 

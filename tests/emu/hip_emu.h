@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <vector>
 
 struct dim3 {
@@ -266,25 +268,85 @@ typedef int hipError_t;
 typedef void* hipStream_t;
 struct hipEmuEvent { std::chrono::steady_clock::time_point t; };
 typedef hipEmuEvent* hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice,
                      hipMemcpyHostToHost, hipMemcpyDefault };
-inline const char* hipGetErrorString(hipError_t e) { return e ? "emu error" : "success"; }
+inline const char* hipGetErrorString(hipError_t e) { return e == hipErrorOutOfMemory ? "out of memory" : e ? "emu error" : "success"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// Allocation bookkeeping and fault injection (tests/test_hip_failures.py): every device / page-locked allocation
+// is counted and listed with its size; gz_emu_fail_alloc(n) makes the (n + 1)-th allocation from now on fail with
+// hipErrorOutOfMemory (once), gz_emu_live() reports what is still allocated -- a failed gz_create or a failed
+// encode must leave nothing behind.
+namespace hipemu {
+struct AllocBook {
+  std::mutex mu;
+  std::map<void*, size_t> device, host;
+  long calls = 0, fail_at = -1, events = 0;
+};
+inline AllocBook& alloc_book() { static AllocBook b; return b; }
+inline bool alloc_should_fail() {   // (the caller holds the lock)
+  AllocBook& b = alloc_book();
+  const long k = b.calls++;
+  if (b.fail_at >= 0 && k == b.fail_at) { b.fail_at = -1; return true; }
+  return false;
+}
+}  // namespace hipemu
+extern "C" __attribute__((used, visibility("default"))) inline void gz_emu_fail_alloc(long n) {
+  hipemu::AllocBook& b = hipemu::alloc_book();
+  std::lock_guard<std::mutex> lk(b.mu);
+  b.fail_at = n < 0 ? -1 : b.calls + n;
+}
+extern "C" __attribute__((used, visibility("default"))) inline long gz_emu_alloc_calls(void) {
+  hipemu::AllocBook& b = hipemu::alloc_book();
+  std::lock_guard<std::mutex> lk(b.mu);
+  return b.calls;
+}
+extern "C" __attribute__((used, visibility("default"))) inline void gz_emu_live(long* device_bytes, long* host_bytes, long* blocks,
+                                                                                long* events) {
+  hipemu::AllocBook& b = hipemu::alloc_book();
+  std::lock_guard<std::mutex> lk(b.mu);
+  long d = 0, h = 0;
+  for (auto& kv : b.device) d += (long)kv.second;
+  for (auto& kv : b.host) h += (long)kv.second;
+  if (device_bytes) *device_bytes = d;
+  if (host_bytes) *host_bytes = h;
+  if (blocks) *blocks = (long)(b.device.size() + b.host.size());
+  if (events) *events = b.events;
+}
 inline hipError_t hipMalloc(void** p, size_t n) {
+  hipemu::AllocBook& b = hipemu::alloc_book();
+  std::lock_guard<std::mutex> lk(b.mu);
+  *p = nullptr;
+  if (hipemu::alloc_should_fail()) return hipErrorOutOfMemory;
   *p = malloc(n ? n : 1);
   // poison so that reads of never-written device memory are visible in tests
-  if (*p) memset(*p, 0xCD, n);
-  return *p ? hipSuccess : hipErrorInvalidValue;
+  if (*p) { memset(*p, 0xCD, n); b.device[*p] = n; }
+  return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
-inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return hipSuccess; }
+inline hipError_t hipFree(void* p) {
+  if (p) { hipemu::AllocBook& b = hipemu::alloc_book(); std::lock_guard<std::mutex> lk(b.mu); b.device.erase(p); }
+  free(p);
+  return hipSuccess;
+}
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) {
+  hipemu::AllocBook& b = hipemu::alloc_book();
+  std::lock_guard<std::mutex> lk(b.mu);
+  *p = nullptr;
+  if (hipemu::alloc_should_fail()) return hipErrorOutOfMemory;
+  *p = malloc(n ? n : 1);
+  if (*p) b.host[*p] = n;
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
-inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) {
+  if (p) { hipemu::AllocBook& b = hipemu::alloc_book(); std::lock_guard<std::mutex> lk(b.mu); b.host.erase(p); }
+  free(p);
+  return hipSuccess;
+}
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
@@ -293,12 +355,13 @@ inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSucc
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEmuEvent; return hipSuccess; }
-inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline void hipemu_count_event(int d) { hipemu::AllocBook& b = hipemu::alloc_book(); std::lock_guard<std::mutex> lk(b.mu); b.events += d; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEmuEvent; hipemu_count_event(+1); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { if (e) hipemu_count_event(-1); delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipEmuEvent; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipEmuEvent; hipemu_count_event(+1); return hipSuccess; }
 enum { hipEventDisableTiming = 2 };
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();

@@ -97,7 +97,7 @@ CHAIN = ("butteraugli Compare chain (17 launches per Compare on 3 streams: k_rec
          "k_blur2d (radius < 16), 4 k_blur_h + 4 k_blur_v (radius >= 16: LF X/Y, LF B, SameNoise, the mask's "
          "radius-20 pair as one launch per pass), k_malta_rolled (both channels), k_mask_pre, k_combine)")
 TRAFFIC_JSONS = [os.path.join(ROOT, "profiles", n) for n in
-                 ("r05_compare_pmc_traffic.json", "r04_compare_pmc_traffic.json", "r03_compare_pmc_traffic.json")]
+                 ("r06_compare_pmc_traffic.json", "r05_compare_pmc_traffic.json", "r04_compare_pmc_traffic.json")]
 
 
 def load_traffic():
@@ -121,7 +121,7 @@ def load_kernel_roofline():
     session's rocprofv3 CSVs): the chain's kernels one by one and the block passes.  None when it
     was assembled from other kernel sources than this tree's."""
     from guetzli_amd.build import csrc_digest
-    for name in ("r05_compare_kernels.json",):
+    for name in ("r06_compare_kernels.json", "r05_compare_kernels.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -161,8 +161,8 @@ def cpu_baseline():
     # whole BASELINE images through the same reference build on this kind of box, once per round
     # (tools/ref_cpu_time.py under gpurun: 9 and 2.3 minutes -- too long for this line)
     full = {}
-    for key, names in (("3840x2160_q95", ("r05_reference_cpu_4k.json", "r04_reference_cpu_4k.json")),
-                       ("1920x1080_q95", ("r05_reference_cpu_1080p.json", "r04_reference_cpu_1080p.json"))):
+    for key, names in (("3840x2160_q95", ("r06_reference_cpu_4k.json", "r05_reference_cpu_4k.json", "r04_reference_cpu_4k.json")),
+                       ("1920x1080_q95", ("r06_reference_cpu_1080p.json", "r05_reference_cpu_1080p.json", "r04_reference_cpu_1080p.json"))):
         try:
             name = next(n for n in names if os.path.exists(os.path.join(ROOT, "profiles", n)))
             r = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -211,7 +211,7 @@ def block_search_counters():
     counters cannot be read from inside this process): the share of its wave cycles in which a
     wavefront issues a VALU instruction, and VALU instructions per wavefront."""
     import csv
-    for name in ("r05_block_search_pmc.csv", "r04_block_search_pmc.csv", "r03_block_search_pmc.csv", "r02_block_search_pmc.csv"):
+    for name in ("r06_block_search_pmc.csv", "r05_block_search_pmc.csv", "r04_block_search_pmc.csv", "r03_block_search_pmc.csv", "r02_block_search_pmc.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -293,7 +293,11 @@ class Env:
             return
         try:
             allowed = sorted(os.sched_getaffinity(0))
-            bus_ids = [None] * self.world if self.emulate else affinity.device_bus_ids(self.world)
+            if self.emulate:
+                bus_ids = [None] * self.world
+            else:
+                import guetzli_amd
+                bus_ids = affinity.device_bus_ids(self.world, guetzli_amd.load())
             p = affinity.plan(self.local_rank, self.world, bus_ids, allowed,
                               os.environ.get("BENCH_SYSFS_ROOT", "/sys"))
             if p["cpus"]:
@@ -449,7 +453,7 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
 
 def _latest_profile(name):
     """profiles/<round>_<name> of the newest round that has it."""
-    for rn in ("r05", "r04", "r03", "r02"):
+    for rn in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rn}_{name}")
         if os.path.exists(path):
             return path

@@ -139,9 +139,19 @@ def plan(local_rank, world, bus_ids, allowed, sysfs="/sys"):
     return out
 
 
-def device_bus_ids(world):
-    """PCI bus ids of HIP devices 0 .. world-1 through PyTorch's device properties (no context is created on the
-    other ranks' devices); None where the build does not expose them."""
+def device_bus_ids(world, library=None):
+    """PCI bus ids of HIP devices 0 .. world-1: through the C ABI (gz_device_pci_bus_id = hipDeviceGetPCIBusId) when
+    the loaded library is given, else through PyTorch's device properties (no context is created on the other
+    ranks' devices either way); None where neither says."""
+    if library is not None:
+        ids = []
+        for i in range(world):
+            try:
+                ids.append(library.device_pci_bus_id(i))
+            except Exception:
+                ids.append(None)
+        if any(ids):
+            return ids
     try:
         import torch
         ids = []

@@ -48,7 +48,8 @@ def _newer_than_lib():
 # What decides the kernels' work and traffic: the kernels, their arithmetic and tables, and the chain's
 # dispatch (which instantiation / tile shape for which size).  The rest of the C ABI's host side
 # (contexts, pools, entry points) changes nothing a profile of the chain measures.
-DIGEST_FILES = [h for h in HEADERS if not h.startswith("api/")] + ["api/plans.h", "api/chain.h"]
+DIGEST_FILES = [h for h in HEADERS if not h.startswith("api/")] + \
+    ["api/plans.h", "api/chain.h", "api/entry_search.h", "api/entry_phaseb.h", "api/entry_entropy.h"]   # (launch geometry lives there too: ADVICE r5)
 
 
 def csrc_digest():

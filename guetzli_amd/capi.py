@@ -20,12 +20,26 @@ ERRORS = {-1: "GZ_E_ARG", -2: "GZ_E_NO_DEVICE", -3: "GZ_E_HIP", -4: "GZ_E_STATE"
 
 _P = C.c_void_p
 _I = C.c_int
+
+
+class GzConfig(C.Structure):
+    """gz_config of include/guetzli_amd.h."""
+    _fields_ = [("struct_size", _I), ("blur_packed", _I), ("tile_rows", _I), ("single_stream", _I),
+                ("store_distmap", _I), ("side_small", _I), ("malta_pad_bytes", _I)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
 # name -> (restype, argtypes); mirrors include/guetzli_amd.h one to one
 SIGNATURES = {
     "gz_abi_version": (_I, []),
     "gz_device_count": (_I, []),
     "gz_strerror": (C.c_char_p, [_I]),
     "gz_last_error": (C.c_char_p, [_P]),
+    "gz_device_pci_bus_id": (_I, [_I, _P, _I]),
+    "gz_config_from_environment": (_I, [_P]),
+    "gz_get_config": (_I, [_P, _P]),
+    "gz_set_config": (_I, [_P, _P]),
     "gz_create": (_P, [_I, _I, _I, _P, C.c_float, C.POINTER(_I)]),
     "gz_destroy": (None, [_P]),
     "gz_set_rgb": (_I, [_P, _P]),
@@ -132,6 +146,16 @@ class Library:
 
     def device_count(self):
         return self.lib.gz_device_count()
+
+    def device_pci_bus_id(self, device=0):
+        buf = C.create_string_buffer(32)
+        self.check(self.lib.gz_device_pci_bus_id(device, buf, 32))
+        return buf.value.decode()
+
+    def config_from_environment(self):
+        cfg = GzConfig()
+        self.check(self.lib.gz_config_from_environment(C.byref(cfg)))
+        return cfg
 
     # ---- context-free probes ----
     def idct_blocks(self, blocks, device=0):
@@ -259,6 +283,20 @@ class Context:
 
     def synchronize(self):
         self._chk(self.L.lib.gz_synchronize(self.handle))
+
+    def get_config(self):
+        cfg = GzConfig()
+        self._chk(self.L.lib.gz_get_config(self.handle, C.byref(cfg)))
+        return cfg
+
+    def set_config(self, **fields):
+        """Replaces fields of the context's gz_config (blur_packed, tile_rows, single_stream, ...)."""
+        cfg = self.get_config()
+        for k, v in fields.items():
+            assert k in dict(GzConfig._fields_), k
+            setattr(cfg, k, v)
+        self._chk(self.L.lib.gz_set_config(self.handle, C.byref(cfg)))
+        return cfg
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.lib.gz_set_stream(self.handle, stream_ptr))

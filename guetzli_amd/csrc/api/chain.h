@@ -6,28 +6,24 @@
 namespace {
 // ------------------------------------------------------------- blur dispatch helpers --
 // Radius < 16: one fused launch per blur (k_blur2d); radius >= 16: a row pass and a column pass.
-// Two measured crossovers pick the instantiation (both knobs are read per call, so that the tests
-// run every one of them on images small enough for the emulation):
-//  * GZ_BLUR_PK -- row-pair / column-pair passes with packed arithmetic (k_blur_h_pk, k_blur_v_pk:
+// Two measured crossovers pick the instantiation (both can be forced through the context's gz_config --
+// from GZ_BLUR_PK / GZ_TILE_ROWS at gz_create -- so that the tests run every one of them on images small enough
+// for the emulation):
+//  * blur_packed -- row-pair / column-pair passes with packed arithmetic (k_blur_h_pk, k_blur_v_pk:
 //    twice the outputs per thread, half the LDS reads and address computations per output, half
 //    the workgroups) from 1.5 MPix on (round 5; 4 MPix until then), the one-output-row kernels (k_blur_h, k_blur_v_compact) below
 //    (profiles/r02_packed_blur_ab.log, r03_chain_kernel_experiments.log);
-//  * GZ_TILE_ROWS -- 64 x 32 tiles from 7 MPix on, 64 x 16 below: twice the workgroups for
+//  * tile_rows -- 64 x 32 tiles from 7 MPix on, 64 x 16 below: twice the workgroups for
 //    256 CUs (720p: 0.290 -> 0.257 ms per Compare; round 5: 1080p 0.343 -> 0.330, equal at 4K).
 // What round 4 removed after it had lost every A/B of rounds 2 and 3: the unrolled (non-compact)
 // column pass and fused kernels, 64-row tiles, the epilogue without 16-byte accesses and the row
 // pass with LDS bank conflicts (GZ_BLUR_OPT), the three-plane LF passes, the unpaired mask blurs.
-// GZ_SIDE_SMALL=1 (experiment, round 6): the kernels of the two side branches (SameNoise blur, mask blurs) in
-// the forms whose workgroups fit into the hole ONE retiring Malta workgroup leaves on a CU (<= 64 VGPRs, <= 19.7 KB
-// of LDS): unpaired row / column passes, 16-row tiles -- c->side_small is set while those launches are made.
-static bool side_small_wanted() {
-  static const char* e = getenv("GZ_SIDE_SMALL");
-  return e && atoi(e) != 0;
-}
+// cfg.side_small (GZ_SIDE_SMALL, experiment, round 6): the kernels of the two side branches (SameNoise blur, mask
+// blurs) in the forms whose workgroups fit into the hole ONE retiring Malta workgroup leaves on a CU (<= 64 VGPRs,
+// <= 19.7 KB of LDS): unpaired row / column passes, 16-row tiles -- c->side_small is set while those launches are made.
 static bool packed_blur(const gz_ctx* c) {
   if (c->side_small) return false;
-  const char* e = getenv("GZ_BLUR_PK");
-  if (e) return atoi(e) != 0;
+  if (c->cfg.blur_packed >= 0) return c->cfg.blur_packed != 0;
   // (round 5, with 16-row tiles: 1080p 0.3356 -> 0.3290 ms, 2560 x 1440 0.487 -> 0.466, 3200 x 1800 0.719 -> 0.684;
   // 720p equal -- profiles/r05_chain_experiments.log, section 8)
   return (size_t)c->w * c->h >= 1500000;
@@ -36,9 +32,8 @@ constexpr int kTileRows = 32;
 constexpr int kSmallTileRows = 16;
 static bool small_tiles(const gz_ctx* c) {
   if (c->side_small) return true;
-  const char* e = getenv("GZ_TILE_ROWS");
-  if (e && atoi(e) == 16) return true;
-  if (e && atoi(e) == 32) return false;
+  if (c->cfg.tile_rows == 16) return true;
+  if (c->cfg.tile_rows == 32) return false;
   // (round 5: 16-row tiles win or tie up to 3200 x 1800 -- 1080p chain 0.343 -> 0.330 ms, sixteen 1080p images
   // four in flight 27.7 -> 29.5 MPix/s; equal at 3840 x 2160: profiles/r05_chain_experiments.log, section 8)
   return (size_t)c->w * c->h < 7000000;
@@ -377,12 +372,9 @@ int mask_pack_plain(gz_ctx* c, const float* const a[2], const float* const b[2],
 // tmp[0..2], snb, diffx, diffy, mxb, myb1, myb2) read only the two PsychoImages, so they run
 // on the side stream while the main stream does Malta; k_combine needs both.  At 1080p a launch is
 // ~1000 workgroups for 256 CUs and the kernels are latency-bound: the overlap is worth ~10 %.
-static bool single_stream() {   // GZ_SINGLE_STREAM=1: no overlap, for per-kernel profiling
-  static const char* e = getenv("GZ_SINGLE_STREAM");
-  return e && atoi(e) != 0;
-}
+static bool single_stream(const gz_ctx* c) { return c->cfg.single_stream != 0; }   // no overlap, for per-kernel profiling
 int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
-  if (single_stream()) {
+  if (single_stream(c)) {
     SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].a = p0.hf[1]; s.s[0].b = p1.hf[1];
     t.p[0] = c->tmp[0]; ct.p[0] = c->tmp[0];
@@ -397,7 +389,7 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
   hipStream_t main_stream = c->stream;
   int rc = GZ_OK;
   c->stream = c->side_stream2;
-  c->side_small = side_small_wanted();
+  c->side_small = c->cfg.side_small != 0;
   {  // SameNoiseLevels blur input + blur (sigma 10.67)
     SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
     s.s[0].a = p0.hf[1]; s.s[0].b = p1.hf[1];
@@ -416,7 +408,7 @@ int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
   return GZ_OK;
 }
 int join_mask_branch(gz_ctx* c) {
-  if (single_stream()) return GZ_OK;
+  if (single_stream(c)) return GZ_OK;
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
   return GZ_OK;
@@ -440,9 +432,9 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.out = c->ac[ch];
   }
 #ifndef GZ_EMU
-  // GZ_MALTA_PAD = bytes of (unused) dynamic LDS per workgroup (experiment, round 6): 19.7 KB + pad bounds the
+  // cfg.malta_pad_bytes (GZ_MALTA_PAD) = bytes of (unused) dynamic LDS per workgroup (experiment, round 6): 19.7 KB + pad bounds the
   // workgroups a CU holds (8 without; 3 KB: 7, 7 KB: 6, 13 KB: 4) and leaves wave slots and registers to others
-  static const int malta_pad = [] { const char* e = getenv("GZ_MALTA_PAD"); return e ? std::max(0, atoi(e)) : 0; }();
+  const int malta_pad = c->cfg.malta_pad_bytes;
   if (malta_pad > 0) {
     hipLaunchKernelGGL((k_malta_rolled<3>), mgrid, dim3(256), (size_t)malta_pad, c->stream, ay, ax, c->w, c->h, c->pitch);
   } else
@@ -544,15 +536,11 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
 // One full Compare of the current candidate, everything on the stream.
 // want_distmap = false (the search loop, gz_time_compare): the last kernel leaves the per-block maxima and the
 // image maximum only; c->distmap then holds no distance map (have_distmap_plane).
-static bool always_store_distmap() {   // GZ_STORE_DISTMAP=1: the chain as it was until round 5 (A/B)
-  static const char* e = getenv("GZ_STORE_DISTMAP");
-  return e && atoi(e) != 0;
-}
 int enqueue_compare(gz_ctx* c, bool want_block_max, bool want_distmap = false) {
-  want_distmap = want_distmap || always_store_distmap();
+  want_distmap = want_distmap || c->cfg.store_distmap != 0;   // (1: the chain as it was until round 5, A/B)
   TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
   TRY(stage_opsin(c));
-  TRY(stage_separate(c, &c->pi1, !single_stream()));
+  TRY(stage_separate(c, &c->pi1, !single_stream(c)));
   TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, true, want_distmap));
   return GZ_OK;
 }

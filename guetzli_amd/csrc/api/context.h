@@ -316,7 +316,8 @@ struct gz_ctx {
   // mask: DiffPrecompute + three blurs), forked and joined with events
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   bool prio_streams = false, counted_live = false;   // (see create_context)
-  bool side_small = false;   // (chain.h: GZ_SIDE_SMALL)
+  bool side_small = false;   // (chain.h: set while the side branches' launches are made, cfg.side_small)
+  gz_config cfg;             // run-time configuration (include/guetzli_amd.h): the environment's, read once at gz_create
   int cu_slot = -1, cu_class = 0;   // CU-partitioned stream sets (cu_plan): the context's slot; 0 = unmasked streams
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mask_pre = nullptr;
   hipEvent_t ev_next_cand = nullptr;   // next_cand uploaded beside a Compare chain in flight

@@ -6,7 +6,54 @@
 extern "C" {
 
 
-int gz_abi_version(void) { return 3; }
+int gz_abi_version(void) { return 4; }
+
+int gz_config_from_environment(gz_config* out) {
+  if (!out) return GZ_E_ARG;
+  gz_config c;
+  memset(&c, 0, sizeof(c));
+  c.struct_size = (int)sizeof(gz_config);
+  c.blur_packed = -1;
+  if (const char* e = getenv("GZ_BLUR_PK")) c.blur_packed = atoi(e) != 0;
+  if (const char* e = getenv("GZ_TILE_ROWS")) { const int v = atoi(e); if (v == 16 || v == 32) c.tile_rows = v; }
+  if (const char* e = getenv("GZ_SINGLE_STREAM")) c.single_stream = atoi(e) != 0;
+  if (const char* e = getenv("GZ_STORE_DISTMAP")) c.store_distmap = atoi(e) != 0;
+  if (const char* e = getenv("GZ_SIDE_SMALL")) c.side_small = atoi(e) != 0;
+  if (const char* e = getenv("GZ_MALTA_PAD")) c.malta_pad_bytes = std::max(0, std::min(64 << 10, atoi(e)));
+  *out = c;
+  return GZ_OK;
+}
+int gz_get_config(const gz_ctx* c, gz_config* out) {
+  if (!c || !out) return GZ_E_ARG;
+  *out = c->cfg;
+  return GZ_OK;
+}
+int gz_set_config(gz_ctx* c, const gz_config* in) {
+  if (!c || !in || in->struct_size != (int)sizeof(gz_config)) return GZ_E_ARG;
+  if (in->blur_packed < -1 || in->blur_packed > 1 || (in->tile_rows != 0 && in->tile_rows != 16 && in->tile_rows != 32) ||
+      in->malta_pad_bytes < 0 || in->malta_pad_bytes > (64 << 10))
+    return GZ_E_ARG;
+  if (c->compare_pending || c->scan_pending || c->order_pending || c->desc_pending) {
+    c->err = "gz_set_config while work of the context is in flight";
+    return GZ_E_STATE;
+  }
+  c->cfg = *in;
+  return GZ_OK;
+}
+
+int gz_device_pci_bus_id(int device, char* out, int cap) {
+  if (!out || cap < 16) return GZ_E_ARG;
+#ifdef GZ_EMU
+  (void)device;
+  snprintf(out, (size_t)cap, "0000:00:00.0");
+  return GZ_OK;
+#else
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { (void)hipGetLastError(); return GZ_E_NO_DEVICE; }
+  if (hipDeviceGetPCIBusId(out, cap, device) != hipSuccess) { (void)hipGetLastError(); return GZ_E_HIP; }
+  return GZ_OK;
+#endif
+}
 
 int gz_trim_pool(void) {
   {
@@ -86,6 +133,7 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   c->pitch = w;
   c->plane = (size_t)c->pitch * h;
   c->target = target;
+  (void)gz_config_from_environment(&c->cfg);
   set_frame(c, 1);
   auto fail = [&](int code) { *err = code; gz_destroy(c); return (gz_ctx*)nullptr; };
 #define CHK0(call) do { const hipError_t e0_ = (call); if (e0_ != hipSuccess) { (void)hipGetLastError(); return fail(e0_ == hipErrorOutOfMemory ? GZ_E_NOMEM : GZ_E_HIP); } } while (0)

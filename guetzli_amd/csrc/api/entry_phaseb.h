@@ -315,10 +315,12 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
               (const int*)h + n, n, direction, (const int*)c->d_next_cand,
               (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
               (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta);
+    // the staging buffer is free again behind THIS kernel (the only reader): marked before anything can fail, so
+    // that no path returns with the kernel still reading a buffer the next stage_reserve hands out
+    TRY(stage_sent(c, &c->stage_main, c->stream));
     KCHK(c);
     GZ_LAUNCH(k_steps_hist_sum, dim3(1), dim3(256), c->stream, c->d_step_delta, (int*)c->h_step_delta);
     KCHK(c);
-    TRY(stage_sent(c, &c->stage_main, c->stream));   // (the staging buffer is free again behind the kernel)
     c->have_step_delta = true;
     return GZ_OK;
   }

@@ -248,8 +248,35 @@ static HostScratch& ThreadScratch() {
 // flight): 3 from eight cores on (4K: 0.271 s with none, 0.267 with 1, 0.258 with 2, 0.254 with 3;
 // profiles/r05_chain_experiments.log, section 12), else one per core beyond the encode's own, at most 2.
 static std::atomic<int> g_live_encoders{0};
-static int CodeRefreshThreads() {
-  if (const char* e = getenv("GZ_CODE_THREADS")) return std::max(0, std::min(4, atoi(e)));
+
+// The host driver's switches, read from the environment ONCE per encode (Encoder's constructor) -- never inside
+// the search loops, which run on several encoder threads at once in batch mode.  All of them are test / A-B
+// switches: the defaults are the product.
+struct HostKnobs {
+  int code_threads = -1;              // GZ_CODE_THREADS: helper threads of the code refreshes (-1: by the cores)
+  size_t parallel_count_min = (size_t)1 << 20;   // GZ_PARALLEL_COUNT_MIN: step counts on the worker pool from this many entries on
+  long code_serial_steps = 30;        // GZ_CODE_SERIAL_STEPS: serial steps before the helpers are called in (0: at once)
+  bool step_prefetch = true;          // GZ_STEP_PREFETCH=0: no cache-line prefetches ahead of the serial steps
+  bool check_mirror = false;          // GZ_CHECK_MIRROR: host mirror against the device image after every search
+  int verify_level = 0;               // GZ_VERIFY_ENTROPY=1|2: every candidate also through the host writer
+  long order_device_threshold = -1;   // GZ_ORDER_DEVICE_THRESHOLD: ranges above this are partitioned on the device
+  static HostKnobs FromEnvironment() {
+    HostKnobs k;
+    if (const char* e = getenv("GZ_CODE_THREADS")) k.code_threads = std::max(0, std::min(4, atoi(e)));
+    if (const char* e = getenv("GZ_PARALLEL_COUNT_MIN")) k.parallel_count_min = (size_t)atol(e);
+    if (const char* e = getenv("GZ_CODE_SERIAL_STEPS")) k.code_serial_steps = atol(e) / 10 * 10;
+    if (const char* e = getenv("GZ_STEP_PREFETCH")) k.step_prefetch = atoi(e) != 0;
+    k.check_mirror = getenv("GZ_CHECK_MIRROR") != nullptr;
+    if (const char* e = getenv("GZ_VERIFY_ENTROPY")) k.verify_level = std::max(1, atoi(e));
+    if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) k.order_device_threshold = std::max(16L, atol(e));
+    return k;
+  }
+};
+
+// Helper threads for ONE encode's code refreshes, by the cores the process may use per encode in flight
+// (evaluated at every search: in batch mode the first encoder of a batch is alone for a moment).
+static int CodeRefreshThreads(const HostKnobs& knobs) {
+  if (knobs.code_threads >= 0) return knobs.code_threads;
   const int per_encode = WorkerPool::AllowedCpus() / std::max(1, g_live_encoders.load());
   if (per_encode >= 8) return 3;
   return std::max(0, std::min(2, per_encode - 1));
@@ -257,7 +284,7 @@ static int CodeRefreshThreads() {
 
 class Encoder {
  public:
-  Encoder(const Params& p, ProcessStats* s) : params_(p), stats_(s) {
+  Encoder(const Params& p, ProcessStats* s) : params_(p), stats_(s), knobs_(HostKnobs::FromEnvironment()) {
     ++g_live_encoders;
     HostScratch& sc = ThreadScratch();
     orig_.swap(sc.orig);
@@ -316,6 +343,7 @@ class Encoder {
 
   Params params_;
   ProcessStats* stats_;
+  const HostKnobs knobs_;   // the environment's switches, read once
   gz_ctx* ctx_ = nullptr;
   int w_ = 0, h_ = 0, bw_ = 0, bh_ = 0, nb_ = 0;
   // the frame (OutputImage's component layout): chroma factor 1 (4:4:4) or 2 (4:2:0), blocks
@@ -688,7 +716,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   const int nb = factor == 2 ? nbc_ : nb_;
   const int ncomp = jpg_ncomp_;
   if (!refreshers_) {
-    const int t = CodeRefreshThreads();
+    const int t = CodeRefreshThreads(knobs_);
     if (t > 0) {
       try {
         refreshers_.reset(new CodeRefreshers(t));
@@ -986,8 +1014,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           int* sc = step_count.data();
           char* tc = touched.data();
           WorkerPool& pool = WorkerPool::Get();
-          const char* pc_env = getenv("GZ_PARALLEL_COUNT_MIN");   // (the tests: this path on small images)
-          const size_t parallel_from = pc_env ? (size_t)atol(pc_env) : (size_t)1 << 20;
+          const size_t parallel_from = knobs_.parallel_count_min;   // (the tests: this path on small images)
           if (fast_until >= parallel_from && pool.size() > 1) {
             // The first "up" iteration of an encode takes every candidate below the error limit at
             // once -- 7.5 M entries at 4K, 7.5 of this loop's 9 ms per encode: the entries in `parts`
@@ -1110,8 +1137,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         // the helpers are called in only if the loop goes on.
         size_t base = fast_until;   // first step of the pipelined part (a multiple of 10)
         bool stopped_early = false;
-        const char* ss_env = getenv("GZ_CODE_SERIAL_STEPS");   // (the tests: 0 = helpers from the first step on)
-        const long serial_first = ss_env ? atol(ss_env) / 10 * 10 : 30;
+        const long serial_first = knobs_.code_serial_steps;   // (the tests: 0 = helpers from the first step on)
         if (refreshers_ && !verify_ && serial_first > 0 && slow_steps_last_ < serial_first) {
           const size_t to = std::min(n_order, fast_until + (size_t)serial_first);
           stopped_early = serial_steps(fast_until, to);
@@ -1141,7 +1167,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
           // cache misses, which is what a step costs.  The steps to come are known (the sorted order),
           // so their lines are asked for ahead, one dependency per stage.  (A block that advances in
           // between makes a prefetch miss its mark by a candidate; nothing depends on these.)
-          const bool prefetch_ahead = getenv("GZ_STEP_PREFETCH") ? atoi(getenv("GZ_STEP_PREFETCH")) != 0 : true;
+          const bool prefetch_ahead = knobs_.step_prefetch;
           auto prefetch_for = [&](size_t i) {
             if (i + 12 < n_order) {
               const int b1 = sorted[i + 12].first;
@@ -1240,7 +1266,8 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
             Stopwatch cw;
             const CodeRefresh* r = refreshers_->Wait(w0 + priced_w);
             t_pb_codes_ += cw.lap();
-            memcpy(ac_depths.data(), r->depths, ac_depths.size());
+            // (the helper writes the depths of the frame's components only)
+            memcpy(ac_depths.data(), r->depths, std::min(ac_depths.size(), (size_t)ncomp * kHistoSize));
             ac_header = r->ac_header;
             for (int c = 0; c < 3; ++c) ac_raw_bits[c] = r->raw_bits[c];
             const size_t i0 = base + 10 * (size_t)priced_w, i1 = std::min(i0 + 10, n_order);
@@ -1379,7 +1406,7 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
     // visited -- or here, if the whole mirror is going to be read)
     if (verify_ || (direction == -1 && !last_search_of_round)) settle_all(direction);
   }
-  if (getenv("GZ_CHECK_MIRROR")) {
+  if (knobs_.check_mirror) {
     // self-check of the lazily maintained mirror (the tests): every block caught up now, the host's
     // image must be the device's, coefficient for coefficient
     settle_all(-1);
@@ -1399,9 +1426,9 @@ bool Encoder::Search(const QuantMatrix first_q, std::string* out) {
   int rc = GZ_OK;
   const int w = w_, h = h_;
   // the original as the fallback output (processor.cc:826-846)
-  verify_ = getenv("GZ_VERIFY_ENTROPY") != nullptr;
-  verify_level_ = verify_ ? std::max(1, atoi(getenv("GZ_VERIFY_ENTROPY"))) : 0;
-  if (const char* e = getenv("GZ_ORDER_DEVICE_THRESHOLD")) device_threshold_ = (size_t)std::max(16L, atol(e));
+  verify_ = knobs_.verify_level > 0;
+  verify_level_ = knobs_.verify_level;
+  if (knobs_.order_device_threshold > 0) device_threshold_ = (size_t)knobs_.order_device_threshold;
   best_score_ = -1;
   QuantMatrix ones;
   for (int c = 0; c < 3; ++c)

@@ -49,7 +49,7 @@ extern "C" {
 typedef struct gz_ctx gz_ctx;
 
 /* Library / device ------------------------------------------------------------ */
-int gz_abi_version(void);                 /* currently 3 */
+int gz_abi_version(void);                 /* currently 4 (3 + gz_config, gz_device_pci_bus_id) */
 /* Device and pinned host memory of destroyed contexts is kept (per device, exact sizes, at
  * most GZ_POOL_MB megabytes of device memory, default 16384) for the next context of the same
  * image size: a batch of same-sized images allocates once.  gz_trim_pool releases everything
@@ -58,6 +58,31 @@ int gz_trim_pool(void);
 int gz_device_count(void);                /* number of visible HIP devices, <0 on error */
 const char* gz_strerror(int code);
 const char* gz_last_error(const gz_ctx* ctx);
+/* PCI bus id of a HIP device ("0000:05:00.0"; hipDeviceGetPCIBusId) -- for NUMA-aware placement of the
+ * process that feeds it (bench.py / guetzli_amd/affinity.py); out needs >= 16 bytes. */
+int gz_device_pci_bus_id(int device, char* out, int cap);
+
+/* Run-time configuration of a context -------------------------------------------
+ * What used to be read from GZ_* environment variables on every call (rounds 1-5) is a struct of the context:
+ * gz_create fills it ONCE from the environment (gz_config_from_environment: the variable behind every field is
+ * named below), gz_get_config / gz_set_config read and replace it (between calls, never while work of the
+ * context is in flight).  None of the fields changes a result bit: they choose kernel instantiations and
+ * stream use, and exist for the tests (every instantiation on small images) and for A/B measurements.
+ * Process-wide settings stay in the environment, read once: GZ_POOL_MB (cache of freed device memory),
+ * GZ_CU_PARTITION / GZ_CU_MAIN / GZ_CU_SIDE (CU-masked stream sets, experiments). */
+typedef struct gz_config {
+  int struct_size;      /* sizeof(gz_config) as the caller compiled it (checked by gz_set_config) */
+  int blur_packed;      /* GZ_BLUR_PK      -1: by image size (row / column pairs from 1.5 MPix on); 0, 1: forced */
+  int tile_rows;        /* GZ_TILE_ROWS     0: by image size (16-row blur tiles below 7 MPix); 16, 32: forced */
+  int single_stream;    /* GZ_SINGLE_STREAM 1: a Compare's kernels on ONE stream (per-kernel profiling) */
+  int store_distmap;    /* GZ_STORE_DISTMAP 1: every Compare stores the distance map (default: only gz_compare with
+                                            distmap != NULL and the stage probes do) */
+  int side_small;       /* GZ_SIDE_SMALL    1: side-branch blurs in Malta-sized forms (experiment, round 6) */
+  int malta_pad_bytes;  /* GZ_MALTA_PAD     unused dynamic LDS per Malta workgroup (experiment, round 6) */
+} gz_config;
+int gz_config_from_environment(gz_config* out);
+int gz_get_config(const gz_ctx* ctx, gz_config* out);
+int gz_set_config(gz_ctx* ctx, const gz_config* in);
 
 /* Context ---------------------------------------------------------------------
  * gz_create: replaces guetzli::ButteraugliComparator::ButteraugliComparator

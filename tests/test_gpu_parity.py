@@ -145,6 +145,37 @@ def test_stages(L, wh):
     pc.case_stages(L, *wh, x0=0, y0=0)
 
 
+def test_config_struct_chooses_instantiations_not_results(L):
+    """gz_set_config (round 6: the context's copy of what the GZ_* variables used to say on every call): every
+    combination of the chain's instantiation switches on ONE context -- packed / unpacked passes, 16- / 32-row tiles,
+    one stream / three, the distance map stored or not -- gives the same distance, block maxima and (where it is
+    taken) distance map, bit for bit; and the search loop's form of the evaluation (gz_compare_begin / _end: no
+    distance map stored) gives the same distance as gz_compare with the map."""
+    rgb = images.crop(600, 264, 40, 20)
+    with L.context(rgb, 0.971769) as ctx:
+        ctx.encode_rgb(download=False)
+        ctx.quantize(np.full((3, 64), 5, np.int32), download=False)
+        base = ctx.get_config().as_dict()
+        assert base["blur_packed"] == -1 and base["tile_rows"] == 0 and base["store_distmap"] == 0
+        d0, dm0, bm0 = ctx.compare()
+        ctx.compare_begin()
+        assert ctx.compare_end() == d0
+        for kw in (dict(blur_packed=1, tile_rows=32), dict(blur_packed=0, tile_rows=16), dict(single_stream=1),
+                   dict(blur_packed=1, tile_rows=16, store_distmap=1), dict(side_small=1, malta_pad_bytes=7400)):
+            ctx.set_config(**dict(base, **kw))
+            d, dm, bm = ctx.compare()
+            assert d == d0, kw
+            pc.assert_bits_equal(dm, dm0, f"distance map under {kw}")
+            pc.assert_bits_equal(bm, bm0, f"block maxima under {kw}")
+            ctx.compare_begin()
+            assert ctx.compare_end() == d0, kw
+            d, _, bm = ctx.compare(want_distmap=False)
+            assert d == d0
+            pc.assert_bits_equal(bm, bm0, f"block maxima without the map under {kw}")
+        with pytest.raises(Exception):
+            ctx.set_config(tile_rows=24)
+
+
 def test_compare_bees(L):
     """BASELINE config 1 image, full size, three candidate quantisations."""
     pc.case_compare(L, 444, 258, qscales=(1, 2, 6, 14))

@@ -71,6 +71,33 @@ def test_compare(L):
     pc.case_compare(L, 80, 56, x0=200, y0=100, qscales=(1, 5))
 
 
+def test_config_struct_on_one_context(L):
+    """gz_get_config / gz_set_config (include/guetzli_amd.h, round 6): the instantiation switches flipped on ONE
+    context between evaluations -- same distance, map and block maxima bit for bit; bad values are refused."""
+    import images
+    import numpy as np
+    rgb = images.crop(96, 56, 200, 100)
+    with L.context(rgb, 0.971769) as ctx:
+        ctx.encode_rgb(download=False)
+        ctx.quantize(np.full((3, 64), 5, np.int32), download=False)
+        base = ctx.get_config().as_dict()
+        d0, dm0, bm0 = ctx.compare()
+        for kw in (dict(blur_packed=1, tile_rows=32), dict(blur_packed=0, tile_rows=16, single_stream=1),
+                   dict(side_small=1, store_distmap=1)):
+            ctx.set_config(**dict(base, **kw))
+            assert ctx.get_config().as_dict() == dict(base, **kw)
+            d, dm, bm = ctx.compare()
+            assert d == d0
+            pc.assert_bits_equal(dm, dm0, f"distance map under {kw}")
+            pc.assert_bits_equal(bm, bm0, f"block maxima under {kw}")
+            ctx.compare_begin()
+            assert ctx.compare_end() == d0
+        with pytest.raises(Exception):
+            ctx.set_config(tile_rows=24)
+        with pytest.raises(Exception):
+            ctx.set_config(struct_size=4)
+
+
 def test_stages_and_compare_with_32_row_tiles(L, monkeypatch):
     """Images this small take the 16-row blur tiles by default; the 32-row instantiations (what
     1080p and 4K run) are forced here so that both are checked in emulation."""

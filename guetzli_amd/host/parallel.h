@@ -8,6 +8,7 @@
 #pragma once
 #include <sched.h>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <mutex>
@@ -53,15 +54,37 @@ class WorkerPool {
     fn_ = nullptr;
   }
 
-  // Cores the calling process may be scheduled on (its affinity mask at the pool's creation).
+  // Cores' worth of CPU time the calling process may use: its affinity mask, capped by the container's CPU
+  // quota (cgroup v2 cpu.max / v1 cfs quota).  The MI355X boxes of round 6 show 256 logical CPUs in the mask
+  // and a quota of 16: threads sized by the mask alone (three spinning code-refresh helpers for each of four
+  // images in flight, a 16-thread pool) run into the quota's throttling.
   static int AllowedCpus() {
+    int n = 0;
     cpu_set_t set;
     CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-      int n = CPU_COUNT(&set);
-      if (n > 0) return n;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    static const int quota = CpuQuota();
+    if (quota > 0 && quota < n) n = quota;
+    return n;
+  }
+  // ceil(quota / period) of the cgroup this process runs in; 0 = no quota (or unreadable)
+  static int CpuQuota() {
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      long period = 0;
+      const int got = fscanf(f, "%31s %ld", q, &period);
+      fclose(f);
+      if (got == 2 && period > 0 && q[0] != 'm') {
+        const long v = atol(q);
+        if (v > 0) return (int)((v + period - 1) / period);
+      }
+      return 0;
     }
-    return (int)std::thread::hardware_concurrency();
+    long q = 0, p = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%ld", &q) != 1) q = 0; fclose(f); }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%ld", &p) != 1) p = 0; fclose(f); }
+    return q > 0 && p > 0 ? (int)((q + p - 1) / p) : 0;
   }
 
  private:

@@ -282,6 +282,15 @@ static int CodeRefreshThreads(const HostKnobs& knobs) {
   return std::max(0, std::min(2, per_encode - 1));
 }
 
+// phase B's order entries compare by key alone (processor.cc:675-678); lazy_sort.h's AVX2 pass knows the layout
+struct OrderKeyLess {
+  enum { float_second_key = 1 };
+  bool operator()(const std::pair<int, float>& a, const std::pair<int, float>& b) const {
+    return a.second < b.second;
+  }
+};
+typedef LazySorted<std::pair<int, float>, OrderKeyLess> SortedOrder;
+
 class Encoder {
  public:
   Encoder(const Params& p, ProcessStats* s) : params_(p), stats_(s), knobs_(HostKnobs::FromEnvironment()) {
@@ -334,6 +343,19 @@ class Encoder {
   bool TryMatrix(float target_mul, const QuantMatrix q, Trial* t);
   bool SelectMatrix(QuantMatrix best, bool downsample, bool* dist_ok);
   bool SelectFrequencyMasking(int comp_mask, double target_mul, bool stop_early, bool last_search_of_round);
+  // ... and its pieces (see the comment above SelectFrequencyMasking's definition)
+  struct MaskSearch;
+  struct Iteration;
+  bool SearchBlocks(MaskSearch* ms, Stopwatch* sw);
+  void RecountRawBits(MaskSearch* ms);
+  void SettleBlock(MaskSearch* ms, int b);
+  void SettleAll(MaskSearch* ms);
+  bool AcquireOrder(MaskSearch* ms, Iteration* it);
+  bool BulkSteps(MaskSearch* ms, Iteration* it, SortedOrder* sorted, DeviceOrder* dev_order, size_t fast_until);
+  void ApplyStep(MaskSearch* ms, Iteration* it, SortedOrder* sorted, size_t i);
+  bool StepsAsTheReference(MaskSearch* ms, Iteration* it, SortedOrder* sorted, size_t from, size_t to);
+  void StepsWithHelpers(MaskSearch* ms, Iteration* it, SortedOrder* sorted, size_t base);
+  bool EvaluateCandidate(MaskSearch* ms, Iteration* it, Stopwatch* sw);
   bool SetImageFromQuantization(const QuantMatrix q, bool download);
   // The tables of a frame of this image: quant matrices q, or null for the "original" (the
   // q = 1 frame of EncodeRGBToJpeg, or the input JPEG's own tables), plus the metadata a JPEG
@@ -408,6 +430,50 @@ class Encoder {
   long slow_steps_last_ = 0;           // serial steps of the previous iteration of phase B
   std::vector<int32_t> bulk_counts_;   // (kept between iterations: no allocation on the host's path)
   long n_steps_undone_ = 0;
+};
+
+// What one SelectFrequencyMasking search keeps between its iterations.
+struct Encoder::MaskSearch {
+  int comp_mask = 7;
+  double target_mul = 1.0;
+  int factor = 1, nb = 0, ncomp = 3;   // the grid of the mask's last component (:548-552), the frame's components
+  // the size model (:592-604): symbol statistics, the parts of the estimate, the AC codes' depths and the
+  // raw bits HistogramRawBits gives for them (kept incrementally between refreshes)
+  SymbolHistogram dc_histo[3], ac_histo[3];
+  int header_size = 0, dc_size = 0, ac_header = 0, base_size = 0, prev_size = 0;
+  std::vector<uint8_t> ac_depths;
+  int64_t ac_raw_bits[3] = {0, 0, 0};
+  std::vector<int> next_cand;     // last_indexes: how far every block has advanced
+  std::vector<int> mirror_cand;   // ... and up to where the host mirror img_ has followed (SettleBlock)
+  std::vector<int32_t> edit_pos;  // coefficient changes of one iteration
+  std::vector<int16_t> edit_val;
+  std::vector<char> touched;      // blocks changed in this iteration (listed in `dirty`)
+  std::vector<int32_t> dirty, first_touch;
+  std::vector<int> step_count;
+  bool first_up = true;
+  // the next iteration's order, constructed on the device behind the evaluation (EvaluateCandidate): the
+  // direction it was built for (0: none in flight) and the partitions the device made behind it
+  int ahead = 0;
+  uint64_t ahead_log[3 * 12];
+  int ahead_levels = 0;
+  uint64_t ahead_last = 0;
+};
+
+// One pass of the reference's loop body (:607-772).
+struct Encoder::Iteration {
+  int direction = 1;
+  float below_limit = 0.0f, per_block = 0.0f;
+  uint64_t total = 0, below = 0;        // the order's size; its keys below the limit (first "up" iteration)
+  int blocks_to_change = 0;
+  bool have_ahead_log = false;          // the device's descent came with the order
+  std::pair<int, float>* order = nullptr;   // the context's page-locked mirror of the order's fetched ranges
+  size_t n_order = 0;
+  double min_size_delta = 0.0;
+  int min_coeffs_to_change = 0;
+  float val_threshold = 0.0f;
+  int changed_coeffs = 0;
+  int est_size = 0;
+  bool verify_failed = false;
 };
 
 void Encoder::Log(const char* fmt, ...) {   // GUETZLI_LOG / PrintDebug, debug_print.h
@@ -703,6 +769,18 @@ bool Encoder::SelectMatrix(QuantMatrix best_q, bool downsample, bool* dist_ok) {
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// SelectFrequencyMasking (processor.cc:539-780), in the pieces it is made of (round 6: one 716-line function
+// until then).  MaskSearch = what one search keeps between its iterations, Iteration = one pass of the
+// reference's loop body (:607-772).  Order of the calls, of the device's entry points and of every decision
+// is the reference's; the --verbose trace test and the byte-exact goldens hold it there.
+//   SearchBlocks            phase A on the device + the size model of the starting point
+//   AcquireOrder            the iteration's global order (built ahead behind the last evaluation, or now)
+//   BulkSteps               the steps no estimate can observe: device descent, prefix, per-block counts
+//   StepsAsTheReference     the reference's serial loop over [from, to)
+//   StepsWithHelpers        the same decisions with the code refreshes on helper threads
+//   EvaluateCandidate       edits to the device, evaluation + next order enqueued, exact size only if it can win
+//   SettleBlock / SettleAll the host mirror of the image catching up
 // last_search_of_round: no other search of this frame follows (its host mirror of the image is not read again)
 bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop_early,
                                      bool last_search_of_round) {   // processor.cc:539-780
@@ -711,10 +789,14 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
   for (int c = 0; c < 3; ++c)
     if (comp_mask & (1 << c)) last_c = c;
   if (last_c >= jpg_ncomp_) return true;   // :546-547
+  MaskSearch ms;
+  ms.comp_mask = comp_mask;
+  ms.target_mul = target_mul;
   // the grid of the mask's last component (:548-552)
-  const int factor = last_c > 0 ? fac_ : 1;
-  const int nb = factor == 2 ? nbc_ : nb_;
-  const int ncomp = jpg_ncomp_;
+  ms.factor = last_c > 0 ? fac_ : 1;
+  ms.nb = ms.factor == 2 ? nbc_ : nb_;
+  ms.ncomp = jpg_ncomp_;
+  const int nb = ms.nb;
   if (!refreshers_) {
     const int t = CodeRefreshThreads(knobs_);
     if (t > 0) {
@@ -725,153 +807,39 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       }
     }
   }
-  // ---- phase A on the device ----
-  std::vector<int32_t>& cand_off = cand_off_;
-  std::vector<uint8_t>& cand_idx = cand_idx_;
-  if (cand_off.size() != (size_t)nb + 1) cand_off.resize((size_t)nb + 1);
-  if (cand_idx.size() != (size_t)nb * 189) cand_idx.resize((size_t)nb * 189);
-  // the candidates' errors stay on the device, where the global order is built from them
-  int rc = gz_block_zeroing_orders_masked(ctx_, comp_mask, params_.zeroing_greedy_lookahead,
-                                          params_.new_zeroing_model ? 1 : 0, cand_off.data(),
-                                          cand_idx.data(), nullptr, nb * 189);
-  t_blocksearch_ += sw.lap();
-  if (rc != GZ_OK) return Fail("gz_block_zeroing_orders", rc);
-  {
-    uint64_t ev = 0;
-    if (gz_search_evaluations(ctx_, &ev) == GZ_OK) n_evaluations_ += (long)ev;
-  }
+  if (!SearchBlocks(&ms, &sw)) return false;
 
-  // ---- size model of the starting point ----
-  SymbolHistogram dc_histo[3], ac_histo[3];
-  int header_size, dc_size;
-  {
-    if (!DeviceHistograms(quant_, dc_histo, ac_histo)) return false;
-    Frame f;
-    Tables(quant_, ChromaAllZero(dc_histo, ac_histo) ? 1 : 3, &f);
-    header_size = (int)HeaderSize(f);
-    SymbolHistogram dcs[3] = {dc_histo[0], dc_histo[1], dc_histo[2]};
-    size_t num = f.ncomp;
-    int indexes[3];
-    uint8_t depths[3 * kHistoSize];
-    dc_size = (int)ClusterHistograms(dcs, &num, indexes, depths);   // EstimateDCSize
-    // BuildACHistograms fills one histogram per component SaveToJpegData wrote: with all-zero
-    // chroma that is luma only, and the other entries of ac_histograms(ncomp) stay empty (:592-600)
-    if (f.ncomp == 1) { ac_histo[1].Clear(); ac_histo[2].Clear(); }
-  }
-  std::vector<uint8_t> ac_depths(3 * kHistoSize);
-  int64_t ac_raw_bits[3] = {0, 0, 0};
-  auto recount_raw_bits = [&] {
-    for (int c = 0; c < ncomp; ++c) ac_raw_bits[c] = HistogramRawBits(ac_histo[c], &ac_depths[c * kHistoSize]);
-  };
-  int ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
-  const int base_size = header_size + dc_size + ac_header +
-                        (int)EntropyDataSize(ac_histo, ncomp, ac_depths.data());
-  int prev_size = base_size;
-
-  rc = gz_order_reset(ctx_);           // max_block_error := 0, kept on the device
+  int rc = gz_order_reset(ctx_);           // max_block_error := 0, kept on the device
   if (rc != GZ_OK) return Fail("gz_order_reset", rc);
-  std::vector<int> next_cand(nb, 0);   // last_indexes
-  // The host mirror img_ follows the bulk ("fast") steps lazily: mirror_cand[b] says up to
-  // which candidate position block b's coefficients in img_ are current.  Only the blocks the
-  // slow steps touch (a hundred per iteration) need their mirror at once.  What a block looks like
-  // is a function of how far it has advanced, not of the way there: its candidates are distinct
-  // coefficients, those below next_cand are zeroed (the precious ones excepted), those from next_cand
-  // on hold their quantised original values -- so a block catches up in whichever direction it lags,
-  // also across the turn from "up" to "down", and the rest of the image is brought up to date only
-  // when somebody reads all of it (GZ_VERIFY_ENTROPY, a second mask's search; on the worker pool):
-  // 7.5 M pending steps at the turn of a 4K encode, 3.4 ms with the device idle, for blocks most of
-  // which the serial steps never visit.
-  std::vector<int> mirror_cand(nb, 0);
-  auto settle_block = [&](int b, int /*direction*/) {
-    int m = mirror_cand[b];
-    const int n = next_cand[b];
-    for (; m < n; ++m) {   // behind: the steps up
-      const int idx = cand_idx[cand_off[b] + m];
-      const int c = idx / 64, k = idx % 64;
-      if (!IsPrecious(&orig_[Pos(c, b, 0)], k)) img_[Pos(c, b, k)] = 0;
-    }
-    for (; m > n; --m) {   // ahead: the steps down
-      const int idx = cand_idx[cand_off[b] + m - 1];
-      const int c = idx / 64, k = idx % 64;
-      const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
-      const int newval = QuantizeCoeff(orig_blk[k], quant_[c][k]);
-      if (!(newval == 0 && IsPrecious(orig_blk, k))) img_[Pos(c, b, k)] = (int16_t)newval;
-    }
-    mirror_cand[b] = n;
-  };
-  auto settle_all = [&](int direction) {
-    WorkerPool& pool = WorkerPool::Get();
-    const int chunks = nb < 4096 ? 1 : 4 * pool.size();
-    const int per = (nb + chunks - 1) / chunks;
-    pool.Run(chunks, [&](int ch) {
-      for (int b = ch * per; b < std::min(nb, (ch + 1) * per); ++b) settle_block(b, direction);
-    });
-  };
-  std::vector<int32_t> edit_pos;       // coefficient changes of one iteration
-  std::vector<int16_t> edit_val;
-  // host copy of the ranges that were fetched: in the context's page-locked mirror (the fetches
-  // are then single DMA transfers)
-  std::pair<int, float>* order = nullptr;
-  std::vector<char> touched(nb);
-  std::vector<int32_t> dirty, first_touch;
-  std::vector<int> step_count(nb);
-  bool first_up = true;
-  // The order of the next iteration is constructed on the device right behind the evaluation
-  // of this iteration's candidate (gz_order_build_auto_begin): `ahead` says that such a
-  // construction is in flight, and for which direction.
-  int ahead = 0;
-  uint64_t ahead_log[3 * 12];   // the partitions the device made behind that construction
-  int ahead_levels = 0;
-  uint64_t ahead_last = 0;
+  ms.next_cand.assign(nb, 0);     // last_indexes
+  ms.mirror_cand.assign(nb, 0);
+  ms.touched.assign(nb, 0);
+  ms.step_count.assign(nb, 0);
 
   for (int direction = 1; direction >= -1; direction -= 2) {
     for (;;) {
       if (stop_early && direction == -1) {
         // down-adjusting only makes the output larger (:613-621)
-        if (prev_size > 1.01 * (double)best_size_) break;
+        if (ms.prev_size > 1.01 * (double)best_size_) break;
       }
-      int blocks_to_change = 0;
-      bool have_ahead_log = false;
+      Iteration it;
+      it.direction = direction;
+      it.below_limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
       Stopwatch pw;
-      // `order` (global_order, processor.cc:622-663) is built on the device from the CSR
-      // arrays phase A left there, in the reference's sequence: blocks ascending; within a
-      // block the remaining candidates ascending for "up", the applied ones descending for
-      // "down".
-      uint64_t total = 0, below = 0;
-      const float below_limit = 0.75f * params_.butteraugli_target;   // 0.75f * BlockErrorLimit()
-      for (int radius = 1; radius <= 4; ++radius) {
-        // block weights (ComputeBlockErrorAdjustmentWeights) and max_block_error stay on the
-        // device; the host only supplies how far each block has advanced
-        int32_t btc = 0;
-        if (radius == 1 && ahead == direction && !first_up) {
-          rc = gz_order_build_auto_end(ctx_, &total, &btc, &below);
-          if (rc == GZ_OK) {
-            rc = gz_order_descend_end(ctx_, ahead_log, 12, &ahead_levels, &ahead_last);
-            have_ahead_log = rc == GZ_OK && ahead_levels > 0;
-          }
-        } else {
-          rc = gz_order_build_auto(ctx_, direction, radius, target_mul, first_up ? 0 : 1,
-                                   next_cand.data(), first_up ? 1 : 0, below_limit, &total, &btc,
-                                   &below);
-        }
-        ahead = 0;
-        if (rc != GZ_OK) return Fail("gz_order_build_auto", rc);
-        blocks_to_change = btc;
-        if (total != 0) break;
-        have_ahead_log = false;   // (an empty order: the next radius builds another one)
-      }
+      if (!AcquireOrder(&ms, &it)) return false;
       t_pb_order_ += pw.lap();
-      if (total == 0) break;
+      if (it.total == 0) break;
       // (an iteration takes about as many serial steps as the one before it: after a long one the helpers
       // are woken now, while the prefix is selected and the bulk steps are applied)
       if (refreshers_ && !verify_ && slow_steps_last_ >= 30) refreshers_->Activate();
-      n_order_ += (long)total;
+      n_order_ += (long)it.total;
       {
         void* mirror = nullptr;
-        rc = gz_order_host_mirror(ctx_, total, &mirror);
+        rc = gz_order_host_mirror(ctx_, it.total, &mirror);
         if (rc != GZ_OK) return Fail("gz_order_host_mirror", rc);
-        order = static_cast<std::pair<int, float>*>(mirror);
+        it.order = static_cast<std::pair<int, float>*>(mirror);
       }
+      it.n_order = (size_t)it.total;
 
       // The reference std::sort-s `order` here (processor.cc:675-678) and then consumes a
       // prefix.  Equal keys occur across different blocks and std::sort is not stable, so
@@ -879,257 +847,48 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       // front first, without sorting the part the scan never reaches.  The partitions of the
       // large ranges run on the device (gz_order_partition); ranges that have become small
       // are fetched and finished here.
-      struct KeyLess {
-        enum { float_second_key = 1 };   // (lazy_sort.h: the AVX2 pass over the keys)
-        bool operator()(const std::pair<int, float>& a, const std::pair<int, float>& b) const {
-          return a.second < b.second;
-        }
-      };
       DeviceOrder dev_order(ctx_);
-      LazySorted<std::pair<int, float>, KeyLess> sorted(order, (size_t)total, KeyLess(), -1,
-                                                         1 << 17, &dev_order, device_threshold_);
+      SortedOrder sorted(it.order, it.n_order, OrderKeyLess(), -1, 1 << 17, &dev_order, device_threshold_);
       t_pb_sort_ += pw.lap();
 
       double rel_size_delta = direction > 0 ? 0.01 : 0.0005;
       if (direction > 0 && DistanceOK(1.0)) rel_size_delta = 0.05;
-      const double min_size_delta = base_size * rel_size_delta;
-      const float per_block = direction > 0 ? 2.0f : factor * factor * 0.2f;
-      int min_coeffs_to_change = per_block * blocks_to_change;
-      if (first_up) {
+      it.min_size_delta = ms.base_size * rel_size_delta;
+      it.per_block = direction > 0 ? 2.0f : ms.factor * ms.factor * 0.2f;
+      it.min_coeffs_to_change = it.per_block * it.blocks_to_change;
+      if (ms.first_up) {
         // partition_point over the sorted sequence == number of keys below the limit
-        min_coeffs_to_change = std::max<int>(min_coeffs_to_change, (int)below);
-        first_up = false;
+        it.min_coeffs_to_change = std::max<int>(it.min_coeffs_to_change, (int)it.below);
+        ms.first_up = false;
       }
 
       t_pb_sort_ += pw.lap();
       // (touched[] and step_count[] are all zero here: whoever sets an entry records the block in
       // `dirty`, and the entries of the blocks in `dirty` are cleared before the list is)
-      for (int32_t b : dirty) { touched[b] = 0; step_count[b] = 0; }
-      dirty.clear();
-      edit_pos.clear();
-      edit_val.clear();
-      float val_threshold = 0.0;
-      int changed_coeffs = 0;
-      int est_size = prev_size;
-      // One step of the reference loop (processor.cc:704-750) without its size estimate:
-      // change one coefficient of block b (host mirror + edit list for the device) and keep
-      // ac_histo current.
-      const size_t n_order = (size_t)total;
-      auto apply_step = [&](size_t i) {
-        const int b = sorted[i].first;
-        settle_block(b, direction);
-        const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
-        const int c = idx / 64, k = idx % 64;
-        const int* q = quant_[c];
-        const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
-        int16_t* blk = &img_[Pos(c, b, 0)];
-        const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
-        const uint8_t* depth = &ac_depths[c * kHistoSize];
-        if (!(newval == 0 && IsPrecious(orig_blk, k))) {
-          // UpdateACHistogram before and after the change (processor.cc:715-722): only the symbols
-          // around the coefficient differ
-          if (k >= 1) {
-            ReplaceCoeffACSymbols(blk, q, k, newval, &ac_histo[c], depth, &ac_raw_bits[c]);
-            blk[k] = (int16_t)newval;
-          } else {
-            AddBlockACSymbols(blk, q, -1, &ac_histo[c], depth, &ac_raw_bits[c]);
-            blk[k] = (int16_t)newval;
-            AddBlockACSymbols(blk, q, 1, &ac_histo[c], depth, &ac_raw_bits[c]);
-          }
-          edit_pos.push_back((int32_t)Pos(c, b, k));
-          edit_val.push_back((int16_t)newval);
-        }
-        next_cand[b] += direction;
-        mirror_cand[b] = next_cand[b];
-        if (!touched[b]) {
-          touched[b] = 1;
-          dirty.push_back(b);
-        }
-        val_threshold = sorted[i].second;
-        ++changed_coeffs;
-      };
+      for (int32_t b : ms.dirty) { ms.touched[b] = 0; ms.step_count[b] = 0; }
+      ms.dirty.clear();
+      ms.edit_pos.clear();
+      ms.edit_val.clear();
+      it.val_threshold = 0.0;
+      it.changed_coeffs = 0;
+      it.est_size = ms.prev_size;
       // The stopping rule can only fire once changed_coeffs > min_coeffs_to_change, and the
       // size estimate of step i uses the Huffman depths refreshed at the last multiple of 10
       // not above i.  Up to that refresh point nothing the estimate produces is observable,
       // so those steps only edit coefficients ("fast steps"); the symbol statistics are
       // rebuilt once after them.
       {
-        const size_t last_needed = std::min<size_t>((size_t)std::max(min_coeffs_to_change, 0), n_order - 1);
+        const size_t n_order = it.n_order;
+        const size_t last_needed = std::min<size_t>((size_t)std::max(it.min_coeffs_to_change, 0), n_order - 1);
         const size_t fast_until = last_needed / 10 * 10;
-        Stopwatch fw;
-        // The introsort partitions that lead to position fast_until - 1, made by the device
-        // without the host in between: behind the order's construction when that was enqueued
-        // ahead (the device derives the position as the lines above do), else now, in one call.
-        if (n_order > device_threshold_) {
-          const uint64_t want = fast_until ? fast_until - 1 : 0;
-          if (have_ahead_log) {
-            if (ahead_last != want) return Fail("gz_order_descend: position", GZ_E_STATE);
-            memcpy(dev_order.log, ahead_log, sizeof(uint64_t) * 3 * ahead_levels);
-            dev_order.log_n = ahead_levels;
-          } else {
-            int levels = 0;
-            rc = gz_order_descend(ctx_, want, device_threshold_, descend_levels_, dev_order.log, &levels);
-            if (rc != GZ_OK) return Fail("gz_order_descend", rc);
-            dev_order.log_n = levels;
-          }
-          if (dev_order.log_n > 0) {
-            // the range the descent ended in, and with it everything SelectPrefix will fetch
-            uint64_t flo = 0, fhi = n_order;
-            for (int l = 0; l < dev_order.log_n; ++l) {
-              const uint64_t cut = dev_order.log[3 * l + 2];
-              if (want < cut) fhi = cut; else flo = cut;
-            }
-            // (only when the descent got there: a range that is still large will be partitioned
-            // further on the device, and a copy taken now would be stale)
-            if (fhi - flo <= device_threshold_ && fhi <= ((size_t)1 << 19)) {
-              // ... unless the device has put exactly that prefix into the mirror already, behind
-              // the descent it made ahead (k_desc_export)
-              uint64_t exported = 0;
-              if (have_ahead_log) {
-                rc = gz_order_exported(ctx_, &exported);
-                if (rc != GZ_OK) return Fail("gz_order_exported", rc);
-              }
-              if (exported == fhi) {
-                dev_order.have_hi = (size_t)fhi;
-                ++n_dev_exported_;
-              } else if (!dev_order.Prefetch((size_t)fhi, order)) {
-                return Fail("gz_order_fetch", dev_order.rc);
-              }
-            }
-          }
-          t_pb_descend_ += fw.lap();
-        }
-        sorted.SelectPrefix(fast_until);   // the set [0, fast_until) and element fast_until - 1
-        t_pb_ensure_ += fw.lap();
-        // Steps [0, fast_until): only how many steps each block takes matters (the n-th step
-        // of a block applies its n-th remaining candidate whatever the key), so they are
-        // applied block by block: on the device image by gz_apply_candidate_steps, on the
-        // host mirror by the worker pool.
-        {
-          // first touches go to `dirty` without a branch (which block an entry belongs to is as
-          // good as random: the branch mispredicted for a third of the 63 000 entries of a 4K
-          // iteration)
-          if (first_touch.size() != (size_t)nb + 1) first_touch.resize((size_t)nb + 1);
-          int32_t* dl = first_touch.data();
-          int* sc = step_count.data();
-          char* tc = touched.data();
-          WorkerPool& pool = WorkerPool::Get();
-          const size_t parallel_from = knobs_.parallel_count_min;   // (the tests: this path on small images)
-          if (fast_until >= parallel_from && pool.size() > 1) {
-            // The first "up" iteration of an encode takes every candidate below the error limit at
-            // once -- 7.5 M entries at 4K, 7.5 of this loop's 9 ms per encode: the entries in `parts`
-            // ranges, a private count array per range (0.5 MB: it stays in the core's cache), summed
-            // afterwards.  Which order the touched blocks are listed in matters to nobody (independent
-            // blocks on the device, a set to be cleared here).
-            const int parts = std::min(pool.size(), 8);
-            std::vector<std::vector<int32_t> > part_count((size_t)parts);
-            pool.Run(parts, [&](int p) {
-              std::vector<int32_t>& cnt = part_count[(size_t)p];
-              cnt.assign((size_t)nb, 0);
-              const size_t i0 = fast_until * (size_t)p / parts, i1 = fast_until * (size_t)(p + 1) / parts;
-              for (size_t i = i0; i < i1; ++i) ++cnt[(size_t)order[i].first];
-            });
-            size_t nd = 0;
-            for (int b = 0; b < nb; ++b) {
-              int n = 0;
-              for (int p = 0; p < parts; ++p) n += part_count[(size_t)p][(size_t)b];
-              if (n == 0) continue;
-              if (sc[b] == 0) dl[nd++] = b;
-              sc[b] += n;
-              tc[b] = 1;
-            }
-            dirty.assign(dl, dl + nd);
-          } else {
-            size_t nd = 0;
-            for (size_t i = 0; i < fast_until; ++i) {
-              const int b = order[i].first;
-              dl[nd] = b;
-              nd += sc[b] == 0;
-              ++sc[b];
-              tc[b] = 1;
-            }
-            dirty.assign(dl, dl + nd);
-          }
-        }
-        t_fs_count_ += fw.lap();
-        if (fast_until > 0) {
-          val_threshold = order[fast_until - 1].second;
-          changed_coeffs += (int)fast_until;
-          // the device applies the same steps to its image (and advances its next_cand) ...
-          std::vector<int32_t>& counts = bulk_counts_;
-          counts.resize(dirty.size());
-          for (size_t di = 0; di < dirty.size(); ++di) counts[di] = step_count[dirty[di]];
-          rc = gz_apply_candidate_steps(ctx_, direction, dirty.data(), counts.data(), (int)dirty.size());
-          if (rc != GZ_OK) return Fail("gz_apply_candidate_steps", rc);
-          t_fs_apply_ += fw.lap();
-          // ... while the host only notes how far each block has advanced; its mirror of the
-          // coefficients follows when a slow step needs the block (settle_block)
-          // (step_count holds exactly these counts and zeros elsewhere: with a fifth of the blocks
-          // touched, one pass over the two arrays -- 20 us -- beats 26 000 scattered updates -- 40-120)
-          if (dirty.size() * 16 > (size_t)nb) {
-            int* nc = next_cand.data();
-            const int* scp = step_count.data();
-            for (int b = 0; b < nb; ++b) nc[b] += direction * scp[b];
-          } else {
-            for (size_t di = 0; di < dirty.size(); ++di) next_cand[dirty[di]] += direction * counts[di];
-          }
-          if (verify_) settle_all(direction);   // GZ_VERIFY_ENTROPY compares the whole mirror
-          // the symbol statistics of the edited image come from the device: the change the
-          // steps made to BuildACHistograms, counted over the touched blocks (the host's
-          // ac_histo was exact before them: the slow steps below keep it so)
-          t_fs_mirror_ += fw.lap();
-          std::vector<int32_t> delta(3 * 256);
-          rc = gz_steps_histogram_delta(ctx_, delta.data());
-          t_fs_delta_ += fw.lap();
-          if (rc != GZ_OK) return Fail("gz_steps_histogram_delta", rc);
-          for (int c = 0; c < 3; ++c)
-            for (int i = 0; i < 256; ++i)
-              if (delta[c * 256 + i]) ac_histo[c].Add(i, delta[c * 256 + i]);
-          if (verify_) {   // GZ_VERIFY_ENTROPY=1: against a recount of the whole image
-            SymbolHistogram dc_now[3], ac_now[3];
-            if (!DeviceHistograms(quant_, dc_now, ac_now)) return false;
-            for (int c = 0; c < ncomp; ++c)
-              if (memcmp(ac_now[c].counts, ac_histo[c].counts, sizeof(ac_now[c].counts)) != 0) {
-                fprintf(stderr, "guetzli_amd: incremental AC statistics differ from a recount\n");
-                return false;
-              }
-          }
-        }
-        t_fs_rest_ += fw.lap();
+        if (!BulkSteps(&ms, &it, &sorted, &dev_order, fast_until)) return false;
         n_steps_ += (long)fast_until;
         n_fast_ += (long)fast_until;
         const long slow_steps_before = (long)(n_steps_ - n_fast_);
         // EntropyDataSize(ac_histo, ncomp, ac_depths) after every step, without its pass over the
         // histograms: ac_raw_bits[c] follows HistogramRawBits(ac_histo[c], depths of c) through
-        // apply_step and is recounted when the depths change
-        recount_raw_bits();
-        // the reference's loop (processor.cc:704-750) over the steps [from, to): true = the stopping
-        // rule fired (at the last step taken)
-        bool verify_failed = false;
-        auto serial_steps = [&](size_t from, size_t to) -> bool {
-          for (size_t i = from; i < to; ++i) {
-            apply_step(i);
-            if (i % 10 == 0) {
-              Stopwatch cw;
-              ac_header = (int)EntropyCodes(ac_histo, ncomp, ac_depths.data());
-              recount_raw_bits();
-              t_pb_codes_ += cw.lap();
-            }
-            ++n_steps_;
-            size_t data_bits = 0;
-            for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ac_raw_bits[c]);
-            est_size = header_size + dc_size + ac_header + (int)((data_bits + 7) / 8);
-            if (verify_ && (data_bits + 7) / 8 != EntropyDataSize(ac_histo, ncomp, ac_depths.data())) {
-              fprintf(stderr, "guetzli_amd: incremental size estimate differs from a recount\n");
-              verify_failed = true;
-              return true;
-            }
-            if (changed_coeffs > min_coeffs_to_change &&
-                std::abs(est_size - prev_size) > min_size_delta)
-              return true;
-          }
-          return false;
-        };
+        // ApplyStep and is recounted when the depths change
+        RecountRawBits(&ms);
         // Three quarters of an encode's iterations stop within ten steps of the bulk (the first
         // refresh's estimate already differs enough): waking the helpers for those costs more than the
         // one refresh they could take over.  An iteration takes about as many serial steps as the one
@@ -1140,180 +899,19 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
         const long serial_first = knobs_.code_serial_steps;   // (the tests: 0 = helpers from the first step on)
         if (refreshers_ && !verify_ && serial_first > 0 && slow_steps_last_ < serial_first) {
           const size_t to = std::min(n_order, fast_until + (size_t)serial_first);
-          stopped_early = serial_steps(fast_until, to);
+          stopped_early = StepsAsTheReference(&ms, &it, &sorted, fast_until, to);
           base = to;
         }
         if (refreshers_ && !verify_ && !stopped_early && base < n_order) {
-          refreshers_->Activate();
-          // ---- the serial steps with their code refreshes on the helper threads (code_refresh.h) ----
-          // Window w = the steps base + 10 w .. + 9; its first step is a refresh step.  This
-          // thread takes the steps of up to `lag + 1` windows before it prices the oldest of them:
-          // the statistics right after a window's first step go to a helper, the steps' symbol changes
-          // are kept, and when the window's codes are there every step gets the size estimate the
-          // reference computes for it -- raw bits of the statistics at the refresh under the new
-          // depths, then the steps' changes priced with those depths (what ReplaceCoeffACSymbols adds
-          // to ac_raw_bits) -- and the stopping rule is applied in step order.  Steps taken beyond
-          // the one it fires at are undone, last first.
-          std::vector<SlowStep>& slog = slow_log_;
-          slog.clear();
-          const long lag = refreshers_->threads();
-          const long w0 = refreshers_->NextWindow();
-          long applied_w = 0, priced_w = 0;
-          size_t next_apply = base;
-          bool stopped = false;
-          size_t last_priced = base;   // the last step with an estimate (valid once a window is priced)
-          // A step touches one block out of 130 000 at random: its entry of the per-block arrays, its
-          // candidate list, its coefficient blocks in the original and in the image -- four dependent
-          // cache misses, which is what a step costs.  The steps to come are known (the sorted order),
-          // so their lines are asked for ahead, one dependency per stage.  (A block that advances in
-          // between makes a prefetch miss its mark by a candidate; nothing depends on these.)
-          const bool prefetch_ahead = knobs_.step_prefetch;
-          auto prefetch_for = [&](size_t i) {
-            if (i + 12 < n_order) {
-              const int b1 = sorted[i + 12].first;
-              __builtin_prefetch(&cand_off[b1]);
-              __builtin_prefetch(&next_cand[b1]);
-              __builtin_prefetch(&mirror_cand[b1]);
-              __builtin_prefetch(&touched[b1]);
-            }
-            if (i + 8 < n_order) {
-              const int b2 = sorted[i + 8].first;
-              __builtin_prefetch(&cand_idx[cand_off[b2] + next_cand[b2] + std::min(direction, 0)]);
-            }
-            if (i + 4 < n_order) {
-              const int b3 = sorted[i + 4].first;
-              const int idx3 = cand_idx[cand_off[b3] + next_cand[b3] + std::min(direction, 0)];
-              const size_t p3 = Pos(idx3 / 64, b3, 0);
-              __builtin_prefetch(&orig_[p3]);
-              __builtin_prefetch(&orig_[p3 + 32]);
-              __builtin_prefetch(&img_[p3], 1);
-              __builtin_prefetch(&img_[p3 + 32], 1);
-            }
-          };
-          auto take_step = [&](size_t i) {
-            if (prefetch_ahead) prefetch_for(i);
-            const int b = sorted[i].first;
-            settle_block(b, direction);
-            const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
-            const int c = idx / 64, k = idx % 64;
-            const int* q = quant_[c];
-            const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
-            int16_t* blk = &img_[Pos(c, b, 0)];
-            const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
-            SlowStep st;
-            st.b = b;
-            st.val = sorted[i].second;
-            st.comp = (uint8_t)c;
-            st.changed = 0;
-            st.nsym = 0;
-            st.pos = 0;
-            st.old_val = 0;
-            if (!(newval == 0 && IsPrecious(orig_blk, k))) {
-              st.changed = 1;
-              st.pos = (int32_t)Pos(c, b, k);
-              st.old_val = blk[k];
-              // (k == 0: a block's AC symbols do not depend on its DC coefficient)
-              if (k >= 1) st.nsym = (uint8_t)CoeffACSymbolChanges(blk, q, k, newval, st.sym);
-              for (int j = 0; j < st.nsym; ++j)
-                ac_histo[c].Add(std::abs(st.sym[j]) - 1, st.sym[j] > 0 ? 1 : -1);
-              blk[k] = (int16_t)newval;
-              edit_pos.push_back(st.pos);
-              edit_val.push_back((int16_t)newval);
-            }
-            next_cand[b] += direction;
-            mirror_cand[b] = next_cand[b];
-            st.first_touch = !touched[b];
-            if (!touched[b]) {
-              touched[b] = 1;
-              dirty.push_back(b);
-            }
-            slog.push_back(st);
-          };
-          auto undo_step = [&](const SlowStep& st) {
-            const int b = st.b;
-            if (st.first_touch) {
-              touched[b] = 0;
-              dirty.pop_back();
-            }
-            next_cand[b] -= direction;
-            mirror_cand[b] = next_cand[b];
-            if (st.changed) {
-              edit_pos.pop_back();
-              edit_val.pop_back();
-              img_[st.pos] = st.old_val;
-              for (int j = 0; j < st.nsym; ++j)
-                ac_histo[st.comp].Add(std::abs(st.sym[j]) - 1, st.sym[j] > 0 ? -1 : 1);
-            }
-          };
-          for (;;) {
-            if (next_apply < n_order && applied_w - priced_w <= lag) {
-              // take the steps of the next window; the refresh of its first step goes out at once
-              const size_t i0 = next_apply, i1 = std::min(i0 + 10, n_order);
-              for (size_t i = i0; i < i1; ++i) {
-                take_step(i);
-                if (i == i0) {
-                  CodeRefresh* in = refreshers_->Input(w0 + applied_w);
-                  memcpy(in->histo, ac_histo, sizeof(in->histo));
-                  in->ncomp = ncomp;
-                  refreshers_->Submit(w0 + applied_w);
-                }
-              }
-              next_apply = i1;
-              ++applied_w;
-              continue;
-            }
-            if (priced_w == applied_w) break;   // every step of the order taken and priced
-            Stopwatch cw;
-            const CodeRefresh* r = refreshers_->Wait(w0 + priced_w);
-            t_pb_codes_ += cw.lap();
-            // (the helper writes the depths of the frame's components only)
-            memcpy(ac_depths.data(), r->depths, std::min(ac_depths.size(), (size_t)ncomp * kHistoSize));
-            ac_header = r->ac_header;
-            for (int c = 0; c < 3; ++c) ac_raw_bits[c] = r->raw_bits[c];
-            const size_t i0 = base + 10 * (size_t)priced_w, i1 = std::min(i0 + 10, n_order);
-            for (size_t i = i0; i < i1; ++i) {
-              const SlowStep& st = slog[i - base];
-              if (i > i0) {   // (the refresh step's own changes are in the statistics the codes were made for)
-                const uint8_t* depth = &ac_depths[st.comp * kHistoSize];
-                int64_t bits = 0;
-                for (int j = 0; j < st.nsym; ++j) {
-                  const int symbol = std::abs(st.sym[j]) - 1;
-                  const int cost = depth[symbol] + (symbol & 0xf);
-                  bits += st.sym[j] > 0 ? cost : -cost;
-                }
-                ac_raw_bits[st.comp] += bits;
-              }
-              size_t data_bits = 0;
-              for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ac_raw_bits[c]);
-              est_size = header_size + dc_size + ac_header + (int)((data_bits + 7) / 8);
-              last_priced = i;
-              if ((int)i + 1 > min_coeffs_to_change &&
-                  std::abs(est_size - prev_size) > min_size_delta) {
-                stopped = true;
-                break;
-              }
-            }
-            ++priced_w;
-            if (stopped) break;
-          }
-          // the steps beyond the last one the reference takes, last first; then the refreshes that
-          // were asked for on their behalf (a slot is handed out again only after its window is done)
-          const size_t keep = last_priced + 1;   // steps [base, keep) stay
-          for (size_t i = next_apply; i > keep; --i) undo_step(slog[i - 1 - base]);
-          n_steps_undone_ += (long)(next_apply - keep);
-          for (long w = priced_w; w < applied_w; ++w) (void)refreshers_->Wait(w0 + w);
-          changed_coeffs += (int)(keep - base);
-          val_threshold = slog[keep - 1 - base].val;
-          n_steps_ += (long)(keep - base);
+          StepsWithHelpers(&ms, &it, &sorted, base);
         } else if (!(refreshers_ && !verify_)) {
-          (void)serial_steps(fast_until, n_order);
-          if (verify_failed) return false;
+          (void)StepsAsTheReference(&ms, &it, &sorted, fast_until, n_order);
+          if (it.verify_failed) return false;
         }
         slow_steps_last_ = (long)(n_steps_ - n_fast_) - slow_steps_before;
       }
       if (refreshers_) refreshers_->Deactivate();
       t_pb_loop_ += pw.lap();
-      const size_t order_size = (size_t)total;
       if (sorted.failed()) return Fail("gz_order_partition/fetch", dev_order.rc);
       if (dev_order.log_n > 0) {
         // as many levels next time as this order needed, plus one in reserve (an unused level
@@ -1325,97 +923,621 @@ bool Encoder::SelectFrequencyMasking(int comp_mask, double target_mul, bool stop
       t_pb_dev_fetch_ += dev_order.t_fetch;
       n_dev_partitions_ += dev_order.n_partition;
       n_dev_fetched_ += dev_order.n_fetched;
-      rc = gz_order_advance(ctx_, val_threshold, direction);   // max_block_error += weight * ...
+      rc = gz_order_advance(ctx_, it.val_threshold, direction);   // max_block_error += weight * ...
       if (rc != GZ_OK) return Fail("gz_order_advance", rc);
 
       ++stats_->counters[kNumItersCnt];
       ++stats_->counters[direction > 0 ? kNumItersUpCnt : kNumItersDownCnt];
       t_phaseb_ += sw.lap();
-
-      // push the changed coefficients to the device image (positions are distinct: a block's
-      // candidates are distinct coefficients and a block advances in one direction)
-      rc = gz_apply_coeff_edits(ctx_, edit_pos.data(), edit_val.data(), (int)edit_pos.size());
-      t_upload_ += sw.lap();
-      if (rc != GZ_OK) return Fail("gz_apply_coeff_edits", rc);
-
-      size_t jpg_size = 0;
-      if (!CompareBegin()) return false;
-      // The candidate's exact size is observable in two places only: the --verbose trace
-      // (Out[...], EstErr[...]) and MaybeOutput's comparison of scores (processor.cc:139-148,767).
-      // Its head and the exact length of its scan in bits follow from the symbol statistics the
-      // host holds anyway (PrepareHead); only the bytes stuffed behind 0xFF need the coder.  Without
-      // a trace the candidate is therefore entropy-coded only if it can win: ScoreJPEG grows with
-      // the size, so a candidate whose score at its size's LOWER bound does not beat the best so
-      // far loses whatever it weighs -- 140 of the 149 candidates of a 4K encode at quality 95,
-      // whose evaluation then has the device to itself (the coder's kernels took a sixth of the
-      // summed kernel time, profiles/r03_bench_kernel_stats.csv).
-      // GZ_VERIFY_ENTROPY=2 checks the DEFAULT path: the bound decision is taken first and the
-      // candidate is coded regardless, late (behind the evaluation, as a winner is) -- the bound must
-      // not exceed the coded size, and a candidate the bound rejects must lose with its real size too
-      // (with =1 / --verbose every candidate takes the early-scan path instead).
-      const bool verify_late = verify_ && verify_level_ >= 2 && !stats_->debug_output && !stats_->debug_output_file;
-      const bool every_size = (stats_->debug_output || stats_->debug_output_file || verify_) && !verify_late;
-      if (!PrepareHead(quant_, dc_histo, ac_histo)) return false;
-      // the entropy coder goes to its own stream before anything else is enqueued: it runs beside
-      // the evaluation, not behind the host work below
-      if (every_size && !ScanBegin()) return false;
-      Stopwatch aw;
-      {
-        // the next iteration of this direction, radius 1, if it comes to that (processor.cc:
-        // 622-663 behind :767): everything it reads is final -- next_cand, max_block_error
-        // (gz_order_advance above), and the distance map the device is about to produce -- with the
-        // descent behind it, and everything the host waits for at this point (the order's size and
-        // counters, the descent's cuts, the candidate's distance) in one transfer
-        rc = gz_order_build_auto_descend_begin(ctx_, direction, 1, target_mul, 1, next_cand.data(), 0,
-                                               below_limit, per_block, device_threshold_, descend_levels_);
-        if (rc != GZ_OK) return Fail("gz_order_build_auto_descend_begin", rc);
-        ahead = direction;
-      }
-      t_ahead_begin_ += aw.lap();
-      if (every_size) {
-        if (!SerializeEnd(quant_, &jpg_size)) return false;
-        Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
-            "EstErr[%.2f%%]",
-            stats_->counters[kNumItersCnt], FrameStr(), comp_mask, direction > 0 ? "up" : "down",
-            changed_coeffs, order_size, dirty.size(), blocks_to_change, nb, val_threshold,
-            jpg_size, 100.0 - (100.0 * est_size) / jpg_size);
-        if (!CompareCurrent()) return false;
-        if (!MaybeOutput(jpg_size)) return false;
-      } else {
-        if (!CompareCurrent()) return false;
-        const bool may_win = best_score_ < 0 ||
-            ScoreJPEG(distance_, (int)SizeLowerBound(), params_.butteraugli_target) < best_score_;
-        if (may_win) {
-          if (!ScanBegin() || !SerializeEnd(quant_, &jpg_size) || !MaybeOutput(jpg_size)) return false;
-        } else if (verify_late) {
-          const double best_before = best_score_;
-          if (!ScanBegin() || !SerializeEnd(quant_, &jpg_size)) return false;   // (checks bound <= size itself)
-          if (ScoreJPEG(distance_, (int)jpg_size, params_.butteraugli_target) < best_before) {
-            fprintf(stderr, "guetzli_amd: a candidate rejected on its size bound would have won\n");
-            return false;
-          }
-          ++n_scans_skipped_;
-        } else {
-          ++n_scans_skipped_;
-        }
-      }
-      prev_size = est_size;
+      if (!EvaluateCandidate(&ms, &it, &sw)) return false;
+      ms.prev_size = it.est_size;
       sw.lap();
     }
     // (img_ is exact for the blocks the serial steps visited; the others catch up when they are
     // visited -- or here, if the whole mirror is going to be read)
-    if (verify_ || (direction == -1 && !last_search_of_round)) settle_all(direction);
+    if (verify_ || (direction == -1 && !last_search_of_round)) SettleAll(&ms);
   }
   if (knobs_.check_mirror) {
     // self-check of the lazily maintained mirror (the tests): every block caught up now, the host's
     // image must be the device's, coefficient for coefficient
-    settle_all(-1);
+    SettleAll(&ms);
     std::vector<int16_t> co((size_t)nblk_ * 64);
     rc = gz_get_coeffs(ctx_, co.data());
     if (rc != GZ_OK) return Fail("gz_get_coeffs", rc);
     if (memcmp(co.data(), img_.data(), co.size() * sizeof(int16_t)) != 0) {
       fprintf(stderr, "guetzli_amd: the host mirror of the image differs from the device image after the search\n");
       return false;
+    }
+  }
+  return true;
+}
+
+// Phase A on the device (ComputeBlockZeroingOrder of every block, :553-590) and the size model of the starting
+// point (:592-604).
+bool Encoder::SearchBlocks(MaskSearch* msp, Stopwatch* sw) {
+  MaskSearch& ms = *msp;
+  const int nb = ms.nb, ncomp = ms.ncomp;
+  std::vector<int32_t>& cand_off = cand_off_;
+  std::vector<uint8_t>& cand_idx = cand_idx_;
+  if (cand_off.size() != (size_t)nb + 1) cand_off.resize((size_t)nb + 1);
+  if (cand_idx.size() != (size_t)nb * 189) cand_idx.resize((size_t)nb * 189);
+  // the candidates' errors stay on the device, where the global order is built from them
+  int rc = gz_block_zeroing_orders_masked(ctx_, ms.comp_mask, params_.zeroing_greedy_lookahead,
+                                          params_.new_zeroing_model ? 1 : 0, cand_off.data(),
+                                          cand_idx.data(), nullptr, nb * 189);
+  t_blocksearch_ += sw->lap();
+  if (rc != GZ_OK) return Fail("gz_block_zeroing_orders", rc);
+  {
+    uint64_t ev = 0;
+    if (gz_search_evaluations(ctx_, &ev) == GZ_OK) n_evaluations_ += (long)ev;
+  }
+  // ---- size model of the starting point ----
+  {
+    if (!DeviceHistograms(quant_, ms.dc_histo, ms.ac_histo)) return false;
+    Frame f;
+    Tables(quant_, ChromaAllZero(ms.dc_histo, ms.ac_histo) ? 1 : 3, &f);
+    ms.header_size = (int)HeaderSize(f);
+    SymbolHistogram dcs[3] = {ms.dc_histo[0], ms.dc_histo[1], ms.dc_histo[2]};
+    size_t num = f.ncomp;
+    int indexes[3];
+    uint8_t depths[3 * kHistoSize];
+    ms.dc_size = (int)ClusterHistograms(dcs, &num, indexes, depths);   // EstimateDCSize
+    // BuildACHistograms fills one histogram per component SaveToJpegData wrote: with all-zero
+    // chroma that is luma only, and the other entries of ac_histograms(ncomp) stay empty (:592-600)
+    if (f.ncomp == 1) { ms.ac_histo[1].Clear(); ms.ac_histo[2].Clear(); }
+  }
+  ms.ac_depths.assign(3 * kHistoSize, 0);
+  ms.ac_header = (int)EntropyCodes(ms.ac_histo, ncomp, ms.ac_depths.data());
+  ms.base_size = ms.header_size + ms.dc_size + ms.ac_header +
+                 (int)EntropyDataSize(ms.ac_histo, ncomp, ms.ac_depths.data());
+  ms.prev_size = ms.base_size;
+  return true;
+}
+
+void Encoder::RecountRawBits(MaskSearch* ms) {
+  for (int c = 0; c < ms->ncomp; ++c)
+    ms->ac_raw_bits[c] = HistogramRawBits(ms->ac_histo[c], &ms->ac_depths[c * kHistoSize]);
+}
+
+// The host mirror img_ follows the bulk ("fast") steps lazily: mirror_cand[b] says up to
+// which candidate position block b's coefficients in img_ are current.  Only the blocks the
+// slow steps touch (a hundred per iteration) need their mirror at once.  What a block looks like
+// is a function of how far it has advanced, not of the way there: its candidates are distinct
+// coefficients, those below next_cand are zeroed (the precious ones excepted), those from next_cand
+// on hold their quantised original values -- so a block catches up in whichever direction it lags,
+// also across the turn from "up" to "down", and the rest of the image is brought up to date only
+// when somebody reads all of it (GZ_VERIFY_ENTROPY, a second mask's search; on the worker pool):
+// 7.5 M pending steps at the turn of a 4K encode, 3.4 ms with the device idle, for blocks most of
+// which the serial steps never visit.
+void Encoder::SettleBlock(MaskSearch* ms, int b) {
+  int m = ms->mirror_cand[b];
+  const int n = ms->next_cand[b];
+  for (; m < n; ++m) {   // behind: the steps up
+    const int idx = cand_idx_[cand_off_[b] + m];
+    const int c = idx / 64, k = idx % 64;
+    if (!IsPrecious(&orig_[Pos(c, b, 0)], k)) img_[Pos(c, b, k)] = 0;
+  }
+  for (; m > n; --m) {   // ahead: the steps down
+    const int idx = cand_idx_[cand_off_[b] + m - 1];
+    const int c = idx / 64, k = idx % 64;
+    const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
+    const int newval = QuantizeCoeff(orig_blk[k], quant_[c][k]);
+    if (!(newval == 0 && IsPrecious(orig_blk, k))) img_[Pos(c, b, k)] = (int16_t)newval;
+  }
+  ms->mirror_cand[b] = n;
+}
+
+void Encoder::SettleAll(MaskSearch* ms) {
+  WorkerPool& pool = WorkerPool::Get();
+  const int nb = ms->nb;
+  const int chunks = nb < 4096 ? 1 : 4 * pool.size();
+  const int per = (nb + chunks - 1) / chunks;
+  pool.Run(chunks, [&](int ch) {
+    for (int b = ch * per; b < std::min(nb, (ch + 1) * per); ++b) SettleBlock(ms, b);
+  });
+}
+
+// `order` (global_order, processor.cc:622-663) is built on the device from the CSR arrays phase A left
+// there, in the reference's sequence: blocks ascending; within a block the remaining candidates ascending
+// for "up", the applied ones descending for "down".  The order of the next iteration is constructed on the
+// device right behind the evaluation of this iteration's candidate (EvaluateCandidate): ms->ahead says that
+// such a construction is in flight, and for which direction.
+bool Encoder::AcquireOrder(MaskSearch* ms, Iteration* it) {
+  int rc = GZ_OK;
+  for (int radius = 1; radius <= 4; ++radius) {
+    // block weights (ComputeBlockErrorAdjustmentWeights) and max_block_error stay on the
+    // device; the host only supplies how far each block has advanced
+    int32_t btc = 0;
+    if (radius == 1 && ms->ahead == it->direction && !ms->first_up) {
+      rc = gz_order_build_auto_end(ctx_, &it->total, &btc, &it->below);
+      if (rc == GZ_OK) {
+        rc = gz_order_descend_end(ctx_, ms->ahead_log, 12, &ms->ahead_levels, &ms->ahead_last);
+        it->have_ahead_log = rc == GZ_OK && ms->ahead_levels > 0;
+      }
+    } else {
+      rc = gz_order_build_auto(ctx_, it->direction, radius, ms->target_mul, ms->first_up ? 0 : 1,
+                               ms->next_cand.data(), ms->first_up ? 1 : 0, it->below_limit, &it->total, &btc,
+                               &it->below);
+    }
+    ms->ahead = 0;
+    if (rc != GZ_OK) return Fail("gz_order_build_auto", rc);
+    it->blocks_to_change = btc;
+    if (it->total != 0) break;
+    it->have_ahead_log = false;   // (an empty order: the next radius builds another one)
+  }
+  return true;
+}
+
+// Steps [0, fast_until) of the sorted order: the introsort partitions that lead there on the device, the
+// prefix as a set, the steps applied block by block on the device image, their effect on the AC symbol
+// statistics from the device.
+bool Encoder::BulkSteps(MaskSearch* msp, Iteration* itp, SortedOrder* sortedp, DeviceOrder* dev_orderp, size_t fast_until) {
+  MaskSearch& ms = *msp;
+  Iteration& it = *itp;
+  SortedOrder& sorted = *sortedp;
+  DeviceOrder& dev_order = *dev_orderp;
+  const int nb = ms.nb, ncomp = ms.ncomp, direction = it.direction;
+  const size_t n_order = it.n_order;
+  std::pair<int, float>* order = it.order;
+  int rc = GZ_OK;
+  Stopwatch fw;
+  // The introsort partitions that lead to position fast_until - 1, made by the device
+  // without the host in between: behind the order's construction when that was enqueued
+  // ahead (the device derives the position as the caller does), else now, in one call.
+  if (n_order > device_threshold_) {
+    const uint64_t want = fast_until ? fast_until - 1 : 0;
+    if (it.have_ahead_log) {
+      if (ms.ahead_last != want) return Fail("gz_order_descend: position", GZ_E_STATE);
+      memcpy(dev_order.log, ms.ahead_log, sizeof(uint64_t) * 3 * ms.ahead_levels);
+      dev_order.log_n = ms.ahead_levels;
+    } else {
+      int levels = 0;
+      rc = gz_order_descend(ctx_, want, device_threshold_, descend_levels_, dev_order.log, &levels);
+      if (rc != GZ_OK) return Fail("gz_order_descend", rc);
+      dev_order.log_n = levels;
+    }
+    if (dev_order.log_n > 0) {
+      // the range the descent ended in, and with it everything SelectPrefix will fetch
+      uint64_t flo = 0, fhi = n_order;
+      for (int l = 0; l < dev_order.log_n; ++l) {
+        const uint64_t cut = dev_order.log[3 * l + 2];
+        if (want < cut) fhi = cut; else flo = cut;
+      }
+      // (only when the descent got there: a range that is still large will be partitioned
+      // further on the device, and a copy taken now would be stale)
+      if (fhi - flo <= device_threshold_ && fhi <= ((size_t)1 << 19)) {
+        // ... unless the device has put exactly that prefix into the mirror already, behind
+        // the descent it made ahead (k_desc_export)
+        uint64_t exported = 0;
+        if (it.have_ahead_log) {
+          rc = gz_order_exported(ctx_, &exported);
+          if (rc != GZ_OK) return Fail("gz_order_exported", rc);
+        }
+        if (exported == fhi) {
+          dev_order.have_hi = (size_t)fhi;
+          ++n_dev_exported_;
+        } else if (!dev_order.Prefetch((size_t)fhi, order)) {
+          return Fail("gz_order_fetch", dev_order.rc);
+        }
+      }
+    }
+    t_pb_descend_ += fw.lap();
+  }
+  sorted.SelectPrefix(fast_until);   // the set [0, fast_until) and element fast_until - 1
+  t_pb_ensure_ += fw.lap();
+  // Steps [0, fast_until): only how many steps each block takes matters (the n-th step
+  // of a block applies its n-th remaining candidate whatever the key), so they are
+  // applied block by block: on the device image by gz_apply_candidate_steps, on the
+  // host mirror by the worker pool.
+  {
+    // first touches go to `dirty` without a branch (which block an entry belongs to is as
+    // good as random: the branch mispredicted for a third of the 63 000 entries of a 4K
+    // iteration)
+    if (ms.first_touch.size() != (size_t)nb + 1) ms.first_touch.resize((size_t)nb + 1);
+    int32_t* dl = ms.first_touch.data();
+    int* sc = ms.step_count.data();
+    char* tc = ms.touched.data();
+    WorkerPool& pool = WorkerPool::Get();
+    const size_t parallel_from = knobs_.parallel_count_min;   // (the tests: this path on small images)
+    if (fast_until >= parallel_from && pool.size() > 1) {
+      // The first "up" iteration of an encode takes every candidate below the error limit at
+      // once -- 7.5 M entries at 4K, 7.5 of this loop's 9 ms per encode: the entries in `parts`
+      // ranges, a private count array per range (0.5 MB: it stays in the core's cache), summed
+      // afterwards.  Which order the touched blocks are listed in matters to nobody (independent
+      // blocks on the device, a set to be cleared here).
+      const int parts = std::min(pool.size(), 8);
+      std::vector<std::vector<int32_t> > part_count((size_t)parts);
+      pool.Run(parts, [&](int p) {
+        std::vector<int32_t>& cnt = part_count[(size_t)p];
+        cnt.assign((size_t)nb, 0);
+        const size_t i0 = fast_until * (size_t)p / parts, i1 = fast_until * (size_t)(p + 1) / parts;
+        for (size_t i = i0; i < i1; ++i) ++cnt[(size_t)order[i].first];
+      });
+      size_t nd = 0;
+      for (int b = 0; b < nb; ++b) {
+        int n = 0;
+        for (int p = 0; p < parts; ++p) n += part_count[(size_t)p][(size_t)b];
+        if (n == 0) continue;
+        if (sc[b] == 0) dl[nd++] = b;
+        sc[b] += n;
+        tc[b] = 1;
+      }
+      ms.dirty.assign(dl, dl + nd);
+    } else {
+      size_t nd = 0;
+      for (size_t i = 0; i < fast_until; ++i) {
+        const int b = order[i].first;
+        dl[nd] = b;
+        nd += sc[b] == 0;
+        ++sc[b];
+        tc[b] = 1;
+      }
+      ms.dirty.assign(dl, dl + nd);
+    }
+  }
+  t_fs_count_ += fw.lap();
+  if (fast_until > 0) {
+    std::vector<int32_t>& dirty = ms.dirty;
+    it.val_threshold = order[fast_until - 1].second;
+    it.changed_coeffs += (int)fast_until;
+    // the device applies the same steps to its image (and advances its next_cand) ...
+    std::vector<int32_t>& counts = bulk_counts_;
+    counts.resize(dirty.size());
+    for (size_t di = 0; di < dirty.size(); ++di) counts[di] = ms.step_count[dirty[di]];
+    rc = gz_apply_candidate_steps(ctx_, direction, dirty.data(), counts.data(), (int)dirty.size());
+    if (rc != GZ_OK) return Fail("gz_apply_candidate_steps", rc);
+    t_fs_apply_ += fw.lap();
+    // ... while the host only notes how far each block has advanced; its mirror of the
+    // coefficients follows when a slow step needs the block (SettleBlock)
+    // (step_count holds exactly these counts and zeros elsewhere: with a fifth of the blocks
+    // touched, one pass over the two arrays -- 20 us -- beats 26 000 scattered updates -- 40-120)
+    if (dirty.size() * 16 > (size_t)nb) {
+      int* nc = ms.next_cand.data();
+      const int* scp = ms.step_count.data();
+      for (int b = 0; b < nb; ++b) nc[b] += direction * scp[b];
+    } else {
+      for (size_t di = 0; di < dirty.size(); ++di) ms.next_cand[dirty[di]] += direction * counts[di];
+    }
+    if (verify_) SettleAll(&ms);   // GZ_VERIFY_ENTROPY compares the whole mirror
+    // the symbol statistics of the edited image come from the device: the change the
+    // steps made to BuildACHistograms, counted over the touched blocks (the host's
+    // ac_histo was exact before them: the slow steps keep it so)
+    t_fs_mirror_ += fw.lap();
+    std::vector<int32_t> delta(3 * 256);
+    rc = gz_steps_histogram_delta(ctx_, delta.data());
+    t_fs_delta_ += fw.lap();
+    if (rc != GZ_OK) return Fail("gz_steps_histogram_delta", rc);
+    for (int c = 0; c < 3; ++c)
+      for (int i = 0; i < 256; ++i)
+        if (delta[c * 256 + i]) ms.ac_histo[c].Add(i, delta[c * 256 + i]);
+    if (verify_) {   // GZ_VERIFY_ENTROPY=1: against a recount of the whole image
+      SymbolHistogram dc_now[3], ac_now[3];
+      if (!DeviceHistograms(quant_, dc_now, ac_now)) return false;
+      for (int c = 0; c < ncomp; ++c)
+        if (memcmp(ac_now[c].counts, ms.ac_histo[c].counts, sizeof(ac_now[c].counts)) != 0) {
+          fprintf(stderr, "guetzli_amd: incremental AC statistics differ from a recount\n");
+          return false;
+        }
+    }
+  }
+  t_fs_rest_ += fw.lap();
+  return true;
+}
+
+// One step of the reference loop (processor.cc:704-750) without its size estimate: change one coefficient of
+// block b (host mirror + edit list for the device) and keep ac_histo / ac_raw_bits current.
+void Encoder::ApplyStep(MaskSearch* msp, Iteration* it, SortedOrder* sortedp, size_t i) {
+  SortedOrder& sorted = *sortedp;   // (operator[] sorts lazily: not const)
+  MaskSearch& ms = *msp;
+  const int direction = it->direction;
+  const int b = sorted[i].first;
+  SettleBlock(msp, b);
+  const int idx = cand_idx_[cand_off_[b] + ms.next_cand[b] + std::min(direction, 0)];
+  const int c = idx / 64, k = idx % 64;
+  const int* q = quant_[c];
+  const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
+  int16_t* blk = &img_[Pos(c, b, 0)];
+  const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
+  const uint8_t* depth = &ms.ac_depths[c * kHistoSize];
+  if (!(newval == 0 && IsPrecious(orig_blk, k))) {
+    // UpdateACHistogram before and after the change (processor.cc:715-722): only the symbols
+    // around the coefficient differ
+    if (k >= 1) {
+      ReplaceCoeffACSymbols(blk, q, k, newval, &ms.ac_histo[c], depth, &ms.ac_raw_bits[c]);
+      blk[k] = (int16_t)newval;
+    } else {
+      AddBlockACSymbols(blk, q, -1, &ms.ac_histo[c], depth, &ms.ac_raw_bits[c]);
+      blk[k] = (int16_t)newval;
+      AddBlockACSymbols(blk, q, 1, &ms.ac_histo[c], depth, &ms.ac_raw_bits[c]);
+    }
+    ms.edit_pos.push_back((int32_t)Pos(c, b, k));
+    ms.edit_val.push_back((int16_t)newval);
+  }
+  ms.next_cand[b] += direction;
+  ms.mirror_cand[b] = ms.next_cand[b];
+  if (!ms.touched[b]) {
+    ms.touched[b] = 1;
+    ms.dirty.push_back(b);
+  }
+  it->val_threshold = sorted[i].second;
+  ++it->changed_coeffs;
+}
+
+// The reference's loop (processor.cc:704-750) over the steps [from, to): true = the stopping rule fired (at
+// the last step taken).
+bool Encoder::StepsAsTheReference(MaskSearch* msp, Iteration* it, SortedOrder* sorted, size_t from, size_t to) {
+  MaskSearch& ms = *msp;
+  const int ncomp = ms.ncomp;
+  for (size_t i = from; i < to; ++i) {
+    ApplyStep(msp, it, sorted, i);
+    if (i % 10 == 0) {
+      Stopwatch cw;
+      ms.ac_header = (int)EntropyCodes(ms.ac_histo, ncomp, ms.ac_depths.data());
+      RecountRawBits(msp);
+      t_pb_codes_ += cw.lap();
+    }
+    ++n_steps_;
+    size_t data_bits = 0;
+    for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ms.ac_raw_bits[c]);
+    it->est_size = ms.header_size + ms.dc_size + ms.ac_header + (int)((data_bits + 7) / 8);
+    if (verify_ && (data_bits + 7) / 8 != EntropyDataSize(ms.ac_histo, ncomp, ms.ac_depths.data())) {
+      fprintf(stderr, "guetzli_amd: incremental size estimate differs from a recount\n");
+      it->verify_failed = true;
+      return true;
+    }
+    if (it->changed_coeffs > it->min_coeffs_to_change &&
+        std::abs(it->est_size - ms.prev_size) > it->min_size_delta)
+      return true;
+  }
+  return false;
+}
+
+// The serial steps from `base` (a multiple of 10) on with their code refreshes on the helper threads
+// (code_refresh.h).  Window w = the steps base + 10 w .. + 9; its first step is a refresh step.  This
+// thread takes the steps of up to `lag + 1` windows before it prices the oldest of them:
+// the statistics right after a window's first step go to a helper, the steps' symbol changes
+// are kept, and when the window's codes are there every step gets the size estimate the
+// reference computes for it -- raw bits of the statistics at the refresh under the new
+// depths, then the steps' changes priced with those depths (what ReplaceCoeffACSymbols adds
+// to ac_raw_bits) -- and the stopping rule is applied in step order.  Steps taken beyond
+// the one it fires at are undone, last first.
+void Encoder::StepsWithHelpers(MaskSearch* msp, Iteration* itp, SortedOrder* sortedp, size_t base) {
+  MaskSearch& ms = *msp;
+  Iteration& it = *itp;
+  SortedOrder& sorted = *sortedp;
+  const int ncomp = ms.ncomp, direction = it.direction;
+  const size_t n_order = it.n_order;
+  std::vector<int32_t>& cand_off = cand_off_;
+  std::vector<uint8_t>& cand_idx = cand_idx_;
+  std::vector<int>& next_cand = ms.next_cand;
+  std::vector<int>& mirror_cand = ms.mirror_cand;
+  std::vector<char>& touched = ms.touched;
+  std::vector<int32_t>& dirty = ms.dirty;
+  refreshers_->Activate();
+  std::vector<SlowStep>& slog = slow_log_;
+  slog.clear();
+  const long lag = refreshers_->threads();
+  const long w0 = refreshers_->NextWindow();
+  long applied_w = 0, priced_w = 0;
+  size_t next_apply = base;
+  bool stopped = false;
+  size_t last_priced = base;   // the last step with an estimate (valid once a window is priced)
+  // A step touches one block out of 130 000 at random: its entry of the per-block arrays, its
+  // candidate list, its coefficient blocks in the original and in the image -- four dependent
+  // cache misses, which is what a step costs.  The steps to come are known (the sorted order),
+  // so their lines are asked for ahead, one dependency per stage.  (A block that advances in
+  // between makes a prefetch miss its mark by a candidate; nothing depends on these.)
+  const bool prefetch_ahead = knobs_.step_prefetch;
+  auto prefetch_for = [&](size_t i) {
+    if (i + 12 < n_order) {
+      const int b1 = sorted[i + 12].first;
+      __builtin_prefetch(&cand_off[b1]);
+      __builtin_prefetch(&next_cand[b1]);
+      __builtin_prefetch(&mirror_cand[b1]);
+      __builtin_prefetch(&touched[b1]);
+    }
+    if (i + 8 < n_order) {
+      const int b2 = sorted[i + 8].first;
+      __builtin_prefetch(&cand_idx[cand_off[b2] + next_cand[b2] + std::min(direction, 0)]);
+    }
+    if (i + 4 < n_order) {
+      const int b3 = sorted[i + 4].first;
+      const int idx3 = cand_idx[cand_off[b3] + next_cand[b3] + std::min(direction, 0)];
+      const size_t p3 = Pos(idx3 / 64, b3, 0);
+      __builtin_prefetch(&orig_[p3]);
+      __builtin_prefetch(&orig_[p3 + 32]);
+      __builtin_prefetch(&img_[p3], 1);
+      __builtin_prefetch(&img_[p3 + 32], 1);
+    }
+  };
+  auto take_step = [&](size_t i) {
+    if (prefetch_ahead) prefetch_for(i);
+    const int b = sorted[i].first;
+    SettleBlock(msp, b);
+    const int idx = cand_idx[cand_off[b] + next_cand[b] + std::min(direction, 0)];
+    const int c = idx / 64, k = idx % 64;
+    const int* q = quant_[c];
+    const int16_t* orig_blk = &orig_[Pos(c, b, 0)];
+    int16_t* blk = &img_[Pos(c, b, 0)];
+    const int newval = direction > 0 ? 0 : QuantizeCoeff(orig_blk[k], q[k]);
+    SlowStep st;
+    st.b = b;
+    st.val = sorted[i].second;
+    st.comp = (uint8_t)c;
+    st.changed = 0;
+    st.nsym = 0;
+    st.pos = 0;
+    st.old_val = 0;
+    if (!(newval == 0 && IsPrecious(orig_blk, k))) {
+      st.changed = 1;
+      st.pos = (int32_t)Pos(c, b, k);
+      st.old_val = blk[k];
+      // (k == 0: a block's AC symbols do not depend on its DC coefficient)
+      if (k >= 1) st.nsym = (uint8_t)CoeffACSymbolChanges(blk, q, k, newval, st.sym);
+      for (int j = 0; j < st.nsym; ++j)
+        ms.ac_histo[c].Add(std::abs(st.sym[j]) - 1, st.sym[j] > 0 ? 1 : -1);
+      blk[k] = (int16_t)newval;
+      ms.edit_pos.push_back(st.pos);
+      ms.edit_val.push_back((int16_t)newval);
+    }
+    next_cand[b] += direction;
+    mirror_cand[b] = next_cand[b];
+    st.first_touch = !touched[b];
+    if (!touched[b]) {
+      touched[b] = 1;
+      dirty.push_back(b);
+    }
+    slog.push_back(st);
+  };
+  auto undo_step = [&](const SlowStep& st) {
+    const int b = st.b;
+    if (st.first_touch) {
+      touched[b] = 0;
+      dirty.pop_back();
+    }
+    next_cand[b] -= direction;
+    mirror_cand[b] = next_cand[b];
+    if (st.changed) {
+      ms.edit_pos.pop_back();
+      ms.edit_val.pop_back();
+      img_[st.pos] = st.old_val;
+      for (int j = 0; j < st.nsym; ++j)
+        ms.ac_histo[st.comp].Add(std::abs(st.sym[j]) - 1, st.sym[j] > 0 ? -1 : 1);
+    }
+  };
+  for (;;) {
+    if (next_apply < n_order && applied_w - priced_w <= lag) {
+      // take the steps of the next window; the refresh of its first step goes out at once
+      const size_t i0 = next_apply, i1 = std::min(i0 + 10, n_order);
+      for (size_t i = i0; i < i1; ++i) {
+        take_step(i);
+        if (i == i0) {
+          CodeRefresh* in = refreshers_->Input(w0 + applied_w);
+          memcpy(in->histo, ms.ac_histo, sizeof(in->histo));
+          in->ncomp = ncomp;
+          refreshers_->Submit(w0 + applied_w);
+        }
+      }
+      next_apply = i1;
+      ++applied_w;
+      continue;
+    }
+    if (priced_w == applied_w) break;   // every step of the order taken and priced
+    Stopwatch cw;
+    const CodeRefresh* r = refreshers_->Wait(w0 + priced_w);
+    t_pb_codes_ += cw.lap();
+    // (the helper writes the depths of the frame's components only)
+    memcpy(ms.ac_depths.data(), r->depths, std::min(ms.ac_depths.size(), (size_t)ncomp * kHistoSize));
+    ms.ac_header = r->ac_header;
+    for (int c = 0; c < 3; ++c) ms.ac_raw_bits[c] = r->raw_bits[c];
+    const size_t i0 = base + 10 * (size_t)priced_w, i1 = std::min(i0 + 10, n_order);
+    for (size_t i = i0; i < i1; ++i) {
+      const SlowStep& st = slog[i - base];
+      if (i > i0) {   // (the refresh step's own changes are in the statistics the codes were made for)
+        const uint8_t* depth = &ms.ac_depths[st.comp * kHistoSize];
+        int64_t bits = 0;
+        for (int j = 0; j < st.nsym; ++j) {
+          const int symbol = std::abs(st.sym[j]) - 1;
+          const int cost = depth[symbol] + (symbol & 0xf);
+          bits += st.sym[j] > 0 ? cost : -cost;
+        }
+        ms.ac_raw_bits[st.comp] += bits;
+      }
+      size_t data_bits = 0;
+      for (int c = 0; c < ncomp; ++c) data_bits += EntropyBitsFromRaw(ms.ac_raw_bits[c]);
+      it.est_size = ms.header_size + ms.dc_size + ms.ac_header + (int)((data_bits + 7) / 8);
+      last_priced = i;
+      if ((int)i + 1 > it.min_coeffs_to_change &&
+          std::abs(it.est_size - ms.prev_size) > it.min_size_delta) {
+        stopped = true;
+        break;
+      }
+    }
+    ++priced_w;
+    if (stopped) break;
+  }
+  // the steps beyond the last one the reference takes, last first; then the refreshes that
+  // were asked for on their behalf (a slot is handed out again only after its window is done)
+  const size_t keep = last_priced + 1;   // steps [base, keep) stay
+  for (size_t i = next_apply; i > keep; --i) undo_step(slog[i - 1 - base]);
+  n_steps_undone_ += (long)(next_apply - keep);
+  for (long w = priced_w; w < applied_w; ++w) (void)refreshers_->Wait(w0 + w);
+  it.changed_coeffs += (int)(keep - base);
+  it.val_threshold = slog[keep - 1 - base].val;
+  n_steps_ += (long)(keep - base);
+}
+
+// The iteration's candidate: its changed coefficients to the device image, the evaluation enqueued with the
+// next iteration's order behind it, the exact size where it is observable (processor.cc:752-772).
+bool Encoder::EvaluateCandidate(MaskSearch* msp, Iteration* itp, Stopwatch* sw) {
+  MaskSearch& ms = *msp;
+  Iteration& it = *itp;
+  const int direction = it.direction;
+  // push the changed coefficients to the device image (positions are distinct: a block's
+  // candidates are distinct coefficients and a block advances in one direction)
+  int rc = gz_apply_coeff_edits(ctx_, ms.edit_pos.data(), ms.edit_val.data(), (int)ms.edit_pos.size());
+  t_upload_ += sw->lap();
+  if (rc != GZ_OK) return Fail("gz_apply_coeff_edits", rc);
+
+  size_t jpg_size = 0;
+  if (!CompareBegin()) return false;
+  // The candidate's exact size is observable in two places only: the --verbose trace
+  // (Out[...], EstErr[...]) and MaybeOutput's comparison of scores (processor.cc:139-148,767).
+  // Its head and the exact length of its scan in bits follow from the symbol statistics the
+  // host holds anyway (PrepareHead); only the bytes stuffed behind 0xFF need the coder.  Without
+  // a trace the candidate is therefore entropy-coded only if it can win: ScoreJPEG grows with
+  // the size, so a candidate whose score at its size's LOWER bound does not beat the best so
+  // far loses whatever it weighs -- 140 of the 149 candidates of a 4K encode at quality 95,
+  // whose evaluation then has the device to itself (the coder's kernels took a sixth of the
+  // summed kernel time, profiles/r03_bench_kernel_stats.csv).
+  // GZ_VERIFY_ENTROPY=2 checks the DEFAULT path: the bound decision is taken first and the
+  // candidate is coded regardless, late (behind the evaluation, as a winner is) -- the bound must
+  // not exceed the coded size, and a candidate the bound rejects must lose with its real size too
+  // (with =1 / --verbose every candidate takes the early-scan path instead).
+  const bool verify_late = verify_ && verify_level_ >= 2 && !stats_->debug_output && !stats_->debug_output_file;
+  const bool every_size = (stats_->debug_output || stats_->debug_output_file || verify_) && !verify_late;
+  if (!PrepareHead(quant_, ms.dc_histo, ms.ac_histo)) return false;
+  // the entropy coder goes to its own stream before anything else is enqueued: it runs beside
+  // the evaluation, not behind the host work below
+  if (every_size && !ScanBegin()) return false;
+  Stopwatch aw;
+  {
+    // the next iteration of this direction, radius 1, if it comes to that (processor.cc:
+    // 622-663 behind :767): everything it reads is final -- next_cand, max_block_error
+    // (gz_order_advance in the caller), and the distance map the device is about to produce -- with the
+    // descent behind it, and everything the host waits for at this point (the order's size and
+    // counters, the descent's cuts, the candidate's distance) in one transfer
+    rc = gz_order_build_auto_descend_begin(ctx_, direction, 1, ms.target_mul, 1, ms.next_cand.data(), 0,
+                                           it.below_limit, it.per_block, device_threshold_, descend_levels_);
+    if (rc != GZ_OK) return Fail("gz_order_build_auto_descend_begin", rc);
+    ms.ahead = direction;
+  }
+  t_ahead_begin_ += aw.lap();
+  if (every_size) {
+    if (!SerializeEnd(quant_, &jpg_size)) return false;
+    Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "
+        "EstErr[%.2f%%]",
+        stats_->counters[kNumItersCnt], FrameStr(), ms.comp_mask, direction > 0 ? "up" : "down",
+        it.changed_coeffs, it.n_order, ms.dirty.size(), it.blocks_to_change, ms.nb, it.val_threshold,
+        jpg_size, 100.0 - (100.0 * it.est_size) / jpg_size);
+    if (!CompareCurrent()) return false;
+    if (!MaybeOutput(jpg_size)) return false;
+  } else {
+    if (!CompareCurrent()) return false;
+    const bool may_win = best_score_ < 0 ||
+        ScoreJPEG(distance_, (int)SizeLowerBound(), params_.butteraugli_target) < best_score_;
+    if (may_win) {
+      if (!ScanBegin() || !SerializeEnd(quant_, &jpg_size) || !MaybeOutput(jpg_size)) return false;
+    } else if (verify_late) {
+      const double best_before = best_score_;
+      if (!ScanBegin() || !SerializeEnd(quant_, &jpg_size)) return false;   // (checks bound <= size itself)
+      if (ScoreJPEG(distance_, (int)jpg_size, params_.butteraugli_target) < best_before) {
+        fprintf(stderr, "guetzli_amd: a candidate rejected on its size bound would have won\n");
+        return false;
+      }
+      ++n_scans_skipped_;
+    } else {
+      ++n_scans_skipped_;
     }
   }
   return true;

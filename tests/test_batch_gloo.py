@@ -40,7 +40,11 @@ if world > 1:
 def _run(world, tmp_path):
     script = tmp_path / f"worker{world}.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import socket
+    with socket.socket() as so:   # a free port: the suite runs under pytest-xdist
+        so.bind(("127.0.0.1", 0))
+        port = str(so.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     if world == 1:
         env.update(RANK="0", WORLD_SIZE="1")
         out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True,
@@ -48,7 +52,7 @@ def _run(world, tmp_path):
     else:
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                               f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                              "--master-port", "29533", str(script)], env=env,
+                              "--master-port", port, str(script)], env=env,
                              capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     line = [l for l in out.stdout.splitlines() if l.startswith("RECORDS")][0]

@@ -15,18 +15,28 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "scaling", "vs_baseline", "dtype", "data", "config", "roofline")
 
 
+def _free_port():
+    """A port nobody listens on right now (the suite runs under pytest-xdist: a fixed port made two of these
+    tests collide whenever they landed on different workers at the same time)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
 def _run(world, extra=()):
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     import build_emu
     build_emu.build_host()   # (built once here, not by two ranks at the same time)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     args = [os.path.join(ROOT, "bench.py"), "--emulate", "--gpus", str(world), "--steps", "1",
             "--warmup", "0", "--no-cpu-baseline"] + list(extra)
     if world == 1:
         cmd = [sys.executable] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-               "--master-addr", "127.0.0.1", "--master-port", "29541"] + args
+               "--master-addr", "127.0.0.1", "--master-port", port] + args
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

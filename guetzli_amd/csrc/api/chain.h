@@ -372,7 +372,17 @@ int mask_pack_plain(gz_ctx* c, const float* const a[2], const float* const b[2],
 // tmp[0..2], snb, diffx, diffy, mxb, myb1, myb2) read only the two PsychoImages, so they run
 // on the side stream while the main stream does Malta; k_combine needs both.  At 1080p a launch is
 // ~1000 workgroups for 256 CUs and the kernels are latency-bound: the overlap is worth ~10 %.
-static bool single_stream(const gz_ctx* c) { return c->cfg.single_stream != 0; }   // no overlap, for per-kernel profiling
+// cfg.single_stream: 1 = the whole Compare on the main stream (per-kernel profiling; no fork / join events),
+// 0 = the three-stream chain, -1 (default) = by company: three streams for a context that has the device to itself,
+// ONE when other contexts are alive on it (a batch's images in flight).  The side streams buy a lone chain its
+// overlap (1080p 0.326 against 0.371 ms); several images in flight overlap each other instead, and every fork /
+// join costs host time in a runtime four threads are calling into: one stream per image is +65 % at 512 x 512,
+// +12-25 % at 1 MPix, +10 % at 1080p, +4 % at 4K (profiles/r06_chain_experiments.log, section 6).  The choice is
+// made per Compare and changes no result: every Compare joins its side streams before it ends.
+static bool single_stream(const gz_ctx* c) {
+  if (c->cfg.single_stream >= 0) return c->cfg.single_stream != 0;
+  return live_contexts(c->device, 0) > 1;
+}
 int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
   if (single_stream(c)) {
     SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;

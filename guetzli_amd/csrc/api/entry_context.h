@@ -14,6 +14,7 @@ int gz_config_from_environment(gz_config* out) {
   memset(&c, 0, sizeof(c));
   c.struct_size = (int)sizeof(gz_config);
   c.blur_packed = -1;
+  c.single_stream = -1;
   if (const char* e = getenv("GZ_BLUR_PK")) c.blur_packed = atoi(e) != 0;
   if (const char* e = getenv("GZ_TILE_ROWS")) { const int v = atoi(e); if (v == 16 || v == 32) c.tile_rows = v; }
   if (const char* e = getenv("GZ_SINGLE_STREAM")) c.single_stream = atoi(e) != 0;
@@ -30,7 +31,7 @@ int gz_get_config(const gz_ctx* c, gz_config* out) {
 }
 int gz_set_config(gz_ctx* c, const gz_config* in) {
   if (!c || !in || in->struct_size != (int)sizeof(gz_config)) return GZ_E_ARG;
-  if (in->blur_packed < -1 || in->blur_packed > 1 || (in->tile_rows != 0 && in->tile_rows != 16 && in->tile_rows != 32) ||
+  if (in->blur_packed < -1 || in->blur_packed > 1 || in->single_stream < -1 || in->single_stream > 1 || (in->tile_rows != 0 && in->tile_rows != 16 && in->tile_rows != 32) ||
       in->malta_pad_bytes < 0 || in->malta_pad_bytes > (64 << 10))
     return GZ_E_ARG;
   if (c->compare_pending || c->scan_pending || c->order_pending || c->desc_pending) {

@@ -74,7 +74,8 @@ typedef struct gz_config {
   int struct_size;      /* sizeof(gz_config) as the caller compiled it (checked by gz_set_config) */
   int blur_packed;      /* GZ_BLUR_PK      -1: by image size (row / column pairs from 1.5 MPix on); 0, 1: forced */
   int tile_rows;        /* GZ_TILE_ROWS     0: by image size (16-row blur tiles below 7 MPix); 16, 32: forced */
-  int single_stream;    /* GZ_SINGLE_STREAM 1: a Compare's kernels on ONE stream (per-kernel profiling) */
+  int single_stream;    /* GZ_SINGLE_STREAM -1: one stream when other contexts are alive on the device (a batch's images in
+                                            flight), three for a lone context; 0: always three; 1: always one */
   int store_distmap;    /* GZ_STORE_DISTMAP 1: every Compare stores the distance map (default: only gz_compare with
                                             distmap != NULL and the stage probes do) */
   int side_small;       /* GZ_SIDE_SMALL    1: side-branch blurs in Malta-sized forms (experiment, round 6) */

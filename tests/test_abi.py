@@ -63,7 +63,7 @@ def test_config_struct(lib_path, monkeypatch):
     for k in ("GZ_BLUR_PK", "GZ_TILE_ROWS", "GZ_SINGLE_STREAM", "GZ_STORE_DISTMAP", "GZ_SIDE_SMALL", "GZ_MALTA_PAD"):
         monkeypatch.delenv(k, raising=False)
     d = L.config_from_environment().as_dict()
-    assert d == {"struct_size": C.sizeof(capi.GzConfig), "blur_packed": -1, "tile_rows": 0, "single_stream": 0,
+    assert d == {"struct_size": C.sizeof(capi.GzConfig), "blur_packed": -1, "tile_rows": 0, "single_stream": -1,
                  "store_distmap": 0, "side_small": 0, "malta_pad_bytes": 0}
     monkeypatch.setenv("GZ_BLUR_PK", "0")
     monkeypatch.setenv("GZ_TILE_ROWS", "32")

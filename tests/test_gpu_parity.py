@@ -160,8 +160,19 @@ def test_config_struct_chooses_instantiations_not_results(L):
         d0, dm0, bm0 = ctx.compare()
         ctx.compare_begin()
         assert ctx.compare_end() == d0
+        assert base["single_stream"] == -1
+        # a second context alive on the device: the default (-1) takes the one-stream chain for both now
+        with L.context(images.crop(200, 120, 10, 10), 0.971769) as other:
+            other.encode_rgb(download=False)
+            other.quantize(np.full((3, 64), 3, np.int32), download=False)
+            d, dm, bm = ctx.compare()
+            assert d == d0
+            pc.assert_bits_equal(dm, dm0, "distance map with a second context alive")
+            pc.assert_bits_equal(bm, bm0, "block maxima with a second context alive")
+            other.compare()
         for kw in (dict(blur_packed=1, tile_rows=32), dict(blur_packed=0, tile_rows=16), dict(single_stream=1),
-                   dict(blur_packed=1, tile_rows=16, store_distmap=1), dict(side_small=1, malta_pad_bytes=7400)):
+                   dict(single_stream=0), dict(blur_packed=1, tile_rows=16, store_distmap=1),
+                   dict(side_small=1, malta_pad_bytes=7400)):
             ctx.set_config(**dict(base, **kw))
             d, dm, bm = ctx.compare()
             assert d == d0, kw

@@ -82,7 +82,7 @@ def test_config_struct_on_one_context(L):
         ctx.quantize(np.full((3, 64), 5, np.int32), download=False)
         base = ctx.get_config().as_dict()
         d0, dm0, bm0 = ctx.compare()
-        for kw in (dict(blur_packed=1, tile_rows=32), dict(blur_packed=0, tile_rows=16, single_stream=1),
+        for kw in (dict(blur_packed=1, tile_rows=32), dict(blur_packed=0, tile_rows=16, single_stream=1), dict(single_stream=0),
                    dict(side_small=1, store_distmap=1)):
             ctx.set_config(**dict(base, **kw))
             assert ctx.get_config().as_dict() == dict(base, **kw)

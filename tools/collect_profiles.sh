@@ -23,7 +23,7 @@ cp $T/encode_timers.log $P/${RN}_encode_timers.log
 stamp $T/timeline/timeline_full.txt $P/${RN}_encode_1080p_iteration_timeline_with_host_calls.txt "rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace, one phase-B iteration of a 1080p encode, tools/gpu_trace_full.sh"
 stamp $T/timeline4k/timeline_full.txt $P/${RN}_encode_4k_iteration_timeline_with_host_calls.txt "the same of a 3840x2160 encode"
 { echo "# head $H"; bash tools/kernel_sizes.sh 2>/dev/null; } > $P/${RN}_kernel_code_sizes.csv
-# round 5 extras (tools/gpu_profiles_r05.sh)
+# round 5-6 extras (tools/gpu_profiles_r06.sh)
 [ -f $T/compare_kernels.json ] && python3 -c "import json; d=json.load(open('$T/compare_kernels.json')); d['head']='$H'; print(json.dumps(d, indent=1))" > $P/${RN}_compare_kernels.json
 [ -f $T/config5_pmc_summary.txt ] && { stamp $T/config5_pmc_summary.txt $P/${RN}_config5_pmc_summary.txt "rocprofv3 --pmc passes over tools/batch_time.py 3840 2160 4 4 0, summed by tools/batch_pmc_summary.py"; stamp $T/config5_pmc_per_kernel.csv $P/${RN}_config5_pmc_per_kernel.csv "the same, per kernel"; }
 [ -f $T/issue.log ] && stamp $T/issue.log $P/${RN}_issue_cost.log "tools/ubench/issue on the MI355X"

@@ -18,9 +18,9 @@ timeout 200 tools/ubench/issue > $O/issue.log 2>&1
 # round 6: GPU suite on the final sources, the in-flight sweep for small images, the host's CPU quota
 ( timeout 900 python -m pytest tests -m gpu -x -q -n 2 2>&1 | tail -4 ) | tee $O/gputests.log
 { cat /sys/fs/cgroup/cpu.max 2>/dev/null; nproc; python -c "import os; print(len(os.sched_getaffinity(0)))"; } > $O/host_cpus.log 2>&1
-{ for wk in 4 6 8 12; do python tools/batch_time.py 1024 1024 64 $wk 2; done
-  for wk in 4 6 8; do python tools/batch_time.py 1920 1080 16 $wk 2; done
-  for wk in 4 6; do python tools/batch_time.py 3840 2160 8 $wk 2; done; } 2>&1 | tee $O/in_flight_sweep.log
+# one stream per image against three, batch mode (the default takes one when several contexts are alive)
+{ for cfg in "GZ_NONE=1" "GZ_SINGLE_STREAM=0"; do echo "== $cfg"; for sz in "512 512 128" "1024 1024 64" "1920 1080 16" "3840 2160 8"; do env $cfg python tools/batch_time.py $sz 4 2; done; done
+  echo "== GZ_NONE=1, 6 in flight"; python tools/batch_time.py 1024 1024 64 6 2; } 2>&1 | tee $O/batch_streams_default.log
 bash tools/gpu_profiles.sh $TAG
 # batch-mode counters (4 x 4K, 4 in flight) and the batch's own kernel statistics
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"

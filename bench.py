@@ -59,12 +59,22 @@ Also on the JSON line:
                   reference hash is committed (tests/golden/config5/: all 64 images) is checked.
                   The throughput curve of the real multi-GPU workload can be read from it at
                   every N.  `--config5` runs only this leg and reports it as `value`.
-  first_encode_s -- the process's first encode (HIP start-up, code-object load, pool fill).
+  value_1mpix / ms_per_step_1mpix / config_1mpix -- where the tool is mostly used: one 1024x1024 image without a
+                  period (tests/images.mosaic), timed exactly like `value`, its output checked against the reference's
+                  hash; config_1mpix.batch: 64 such images on one GPU, six in flight; iteration_floor_us: a 64x64
+                  image's time per phase-B iteration = the size-independent latency of one iteration.
+  first_encode_s -- the process's first encode (HIP start-up, code-object load, pool fill); `value` is steady
+                  state and excludes it (and the first 4K encode, first_encode_4k_s: pool growth from 1080p buffers).
   box          -- three-second calibration of the box the run landed on (tools/ubench/bw:
                   streaming copy rates), so that a slow box is visible as such.
   cpu_baseline -- the unmodified reference guetzli::Process (oracle/_ref, 1 thread) on this
                   box's host CPU, rank 0, N=1 only, on bounded samples: the bench image's top-left
-                  640x360, and BASELINE config 0 verbatim (tests/bees.png, --quality 95).
+                  640x360, and BASELINE config 0 verbatim (tests/bees.png, --quality 95).  `all_cores`: the same
+                  sample as one reference PROCESS per usable host CPU (affinity mask capped by the container's CPU
+                  quota), all at once -- the reference's own batch form (tests/golden_test.sh:24-26), the figure the
+                  per-GPU batch numbers stand beside (tools/ref_cpu_all_cores.py).
+  config5_slice.binding_per_rank -- every rank's host-CPU binding (guetzli_amd/affinity.py: the CPUs of its GPU's
+                  NUMA node, its share among the ranks on that node).
 
 `--emulate` (CPU dry run, used by tests/test_bench_main.py at world size 2): the same control
 flow -- process group, barriers, max-over-ranks, all-gathers, rank-0-only legs -- over gloo

@@ -379,10 +379,15 @@ int mask_pack_plain(gz_ctx* c, const float* const a[2], const float* const b[2],
 // join costs host time in a runtime four threads are calling into: one stream per image is +65 % at 512 x 512,
 // +12-25 % at 1 MPix, +10 % at 1080p, +4 % at 4K (profiles/r06_chain_experiments.log, section 6).  The choice is
 // made per Compare and changes no result: every Compare joins its side streams before it ends.
-static bool single_stream(const gz_ctx* c) {
+static bool single_stream_wanted(const gz_ctx* c) {
   if (c->cfg.single_stream >= 0) return c->cfg.single_stream != 0;
   return live_contexts(c->device, 0) > 1;
 }
+// ... decided ONCE per Compare (choose_streams, at the top of every function that enqueues a diffmap stage) and kept in
+// the context for its stages: contexts come and go on other threads while a Compare is being enqueued, and a fork
+// made for three streams must not meet a join that thinks there was one.
+static void choose_streams(gz_ctx* c) { c->single_now = single_stream_wanted(c); }
+static bool single_stream(const gz_ctx* c) { return c->single_now; }
 int fork_side_branch(gz_ctx* c, const Psycho& p0, const Psycho& p1) {
   if (single_stream(c)) {
     SrcPack<SrcSameNoise, 1> s; PlanePack<1> t; CPlanePack<1> ct;
@@ -426,7 +431,8 @@ int join_mask_branch(gz_ctx* c) {
 
 // DiffmapPsychoImage (butteraugli.cc:817-908) + score: p0 = original, p1 = candidate.
 int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block_max,
-                  bool max_cleared = false, bool want_distmap = true) {
+                  bool max_cleared = false, bool want_distmap = true, bool streams_chosen = false) {
+  if (!streams_chosen) choose_streams(c);
   const float hf_asymmetry_ = 0.8f;
   // side stream: SameNoise blur + the mask branch; main stream: Malta
   TRY(fork_side_branch(c, p0, p1));
@@ -548,10 +554,11 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
 // image maximum only; c->distmap then holds no distance map (have_distmap_plane).
 int enqueue_compare(gz_ctx* c, bool want_block_max, bool want_distmap = false) {
   want_distmap = want_distmap || c->cfg.store_distmap != 0;   // (1: the chain as it was until round 5, A/B)
+  choose_streams(c);
   TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
   TRY(stage_opsin(c));
   TRY(stage_separate(c, &c->pi1, !single_stream(c)));
-  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, true, want_distmap));
+  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, true, want_distmap, true));
   return GZ_OK;
 }
 

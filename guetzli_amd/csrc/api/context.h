@@ -316,6 +316,7 @@ struct gz_ctx {
   // mask: DiffPrecompute + three blurs), forked and joined with events
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
   bool prio_streams = false, counted_live = false;   // (see create_context)
+  bool single_now = false;   // (chain.h choose_streams: this Compare's kernels on the main stream only)
   bool side_small = false;   // (chain.h: set while the side branches' launches are made, cfg.side_small)
   gz_config cfg;             // run-time configuration (include/guetzli_amd.h): the environment's, read once at gz_create
   int cu_slot = -1, cu_class = 0;   // CU-partitioned stream sets (cu_plan): the context's slot; 0 = unmasked streams

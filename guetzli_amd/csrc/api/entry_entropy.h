@@ -55,7 +55,7 @@ int gz_jpeg_histograms_ncomp(gz_ctx* c, const int* q, int ncomp, uint32_t* count
   const int grid = std::min(gz_div_up(geom.mcu_cols * geom.mcu_rows, kHistWaves), 1024);
   {
     const int upm = ncomp == 1 ? 1 : (c->cfac == 2 ? 6 : 3);   // blocks per MCU
-    const bool generic = getenv("GZ_HIST_GENERIC") != nullptr;  // (the tests: the run-time-geometry kernel)
+    static const bool generic = getenv("GZ_HIST_GENERIC") != nullptr;  // (the tests: the run-time-geometry kernel; read once)
     if (generic)
       GZ_LAUNCH(k_jpeg_histograms, dim3(grid), dim3(64 * kHistWaves), c->stream, (const int16_t*)c->d_cand,
                 (const int*)c->d_jq, geom, c->d_hist);

@@ -187,6 +187,37 @@ def test_config_struct_chooses_instantiations_not_results(L):
             ctx.set_config(tile_rows=24)
 
 
+def test_stream_choice_is_made_once_per_compare(L):
+    """gz_config.single_stream = -1 looks at the contexts alive on the device; they come and go on other threads WHILE a
+    Compare is being enqueued.  One thread evaluates the same candidate 60 times, another creates and destroys contexts
+    as fast as it can: every evaluation must give the lone context's distance and block maxima (a fork made for three
+    streams that met a join made for one would let k_combine run ahead of the side branches)."""
+    import threading
+    rgb = images.crop(640, 360, 0, 0)
+    with L.context(rgb, 0.971769) as ctx:
+        ctx.encode_rgb(download=False)
+        ctx.quantize(np.full((3, 64), 4, np.int32), download=False)
+        d0, _, bm0 = ctx.compare(want_distmap=False)
+        stop = threading.Event()
+        small = images.crop(64, 48, 5, 5)
+
+        def churn():
+            while not stop.is_set():
+                with L.context(small, 0.971769) as other:
+                    other.encode_rgb(download=False)
+
+        t = threading.Thread(target=churn)
+        t.start()
+        try:
+            for k in range(60):
+                d, _, bm = ctx.compare(want_distmap=False)
+                assert d == d0, k
+                pc.assert_bits_equal(bm, bm0, f"block maxima of evaluation {k} beside context churn")
+        finally:
+            stop.set()
+            t.join()
+
+
 def test_compare_bees(L):
     """BASELINE config 1 image, full size, three candidate quantisations."""
     pc.case_compare(L, 444, 258, qscales=(1, 2, 6, 14))

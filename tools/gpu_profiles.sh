@@ -20,7 +20,7 @@ bash tools/gpu_sq.sh $TAG/sq > $O/sq.log 2>&1; tail -20 $O/sq.log
 bash tools/gpu_pmc.sh $TAG/pmc > $O/pmc.log 2>&1; tail -5 $O/pmc.log
 { echo "# head $(cat .gpurun_head 2>/dev/null)"; python tools/encode_time.py 1920 1080 95 6; python tools/encode_time.py 3840 2160 95 4; python tools/encode_time.py 1920 1080 95 force_420 4; python tools/encode_time.py 3840 2160 84 3; } 2>&1 | tee $O/encode_timers.log | cut -c1-200
 python bench.py 2>$O/bench.err | tee $O/bench.json | cut -c1-300
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/benchprof -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config5 --batch-images 0 ) > $O/benchprof.log 2>&1
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/benchprof -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config5 --batch-images 0 --batch-1mpix 0 ) > $O/benchprof.log 2>&1
 # (bench.py runs tools/ubench in child processes: rocprofv3 writes one summary per process -- the
 # bench's own is the one with the chain's kernels in it)
 f=$(grep -l "k_malta" $(find $O/benchprof -name "*kernel_stats.csv") | head -1); [ -n "$f" ] && cp $f $O/bench_kernel_stats.csv; rm -rf $O/benchprof

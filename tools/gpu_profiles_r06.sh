@@ -25,13 +25,22 @@ bash tools/gpu_profiles.sh $TAG
 # batch-mode counters (4 x 4K, 4 in flight) and the batch's own kernel statistics
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 B="SQ_WAVES SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM"
+# (round 6: with one stream per image -- the default in batch mode -- the rocprofv3 --pmc passes of the batch did not
+# finish in the session of the first attempt; every pass is tried in the default mode with a short limit and, if that
+# fails, with the three-stream chain it was measured on until round 5 -- the summary says which)
+BMODE=default
 for p in A B; do
   eval ctrs=\$$p
-  ( cd /tmp && timeout 400 rocprofv3 --pmc $ctrs --output-format csv -d $R/$O/batch_sq_$p -- python $R/tools/batch_time.py 3840 2160 4 4 0 ) > $O/batch_sq_$p.log 2>&1
+  ( cd /tmp && timeout 200 rocprofv3 --pmc $ctrs --output-format csv -d $R/$O/batch_sq_$p -- python $R/tools/batch_time.py 3840 2160 4 4 0 ) > $O/batch_sq_$p.log 2>&1 || {
+    BMODE=three_streams; rm -rf $O/batch_sq_$p
+    ( cd /tmp && GZ_SINGLE_STREAM=0 timeout 300 rocprofv3 --pmc $ctrs --output-format csv -d $R/$O/batch_sq_$p -- python $R/tools/batch_time.py 3840 2160 4 4 0 ) > $O/batch_sq_$p.log 2>&1; }
 done
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 400 rocprofv3 --pmc $ctr --output-format csv -d $R/$O/batch_$ctr -- python $R/tools/batch_time.py 3840 2160 4 4 0 ) > $O/batch_$ctr.log 2>&1
+  ( cd /tmp && timeout 200 rocprofv3 --pmc $ctr --output-format csv -d $R/$O/batch_$ctr -- python $R/tools/batch_time.py 3840 2160 4 4 0 ) > $O/batch_$ctr.log 2>&1 || {
+    BMODE=three_streams; rm -rf $O/batch_$ctr
+    ( cd /tmp && GZ_SINGLE_STREAM=0 timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $R/$O/batch_$ctr -- python $R/tools/batch_time.py 3840 2160 4 4 0 ) > $O/batch_$ctr.log 2>&1; }
 done
+echo "batch PMC passes: $BMODE" | tee $O/batch_pmc_mode.txt
 python tools/batch_time.py 3840 2160 8 4 3 | tee $O/batch_time.log
 sec=$(python3 -c "
 import re,sys

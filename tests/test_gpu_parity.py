@@ -2,6 +2,8 @@
 oracle -- bit-exact on the integer block path AND on the float butteraugli path (the
 output JPEG can only be byte-identical if every distance is).  Full-size cases use
 size-independent properties where the oracle would take too long."""
+import os
+
 import numpy as np
 import pytest
 
@@ -156,11 +158,12 @@ def test_config_struct_chooses_instantiations_not_results(L):
         ctx.encode_rgb(download=False)
         ctx.quantize(np.full((3, 64), 5, np.int32), download=False)
         base = ctx.get_config().as_dict()
-        assert base["blur_packed"] == -1 and base["tile_rows"] == 0 and base["store_distmap"] == 0
+        if not any(k in os.environ for k in ("GZ_BLUR_PK", "GZ_TILE_ROWS", "GZ_STORE_DISTMAP", "GZ_SINGLE_STREAM")):
+            assert base["blur_packed"] == -1 and base["tile_rows"] == 0 and base["store_distmap"] == 0
+            assert base["single_stream"] == -1
         d0, dm0, bm0 = ctx.compare()
         ctx.compare_begin()
         assert ctx.compare_end() == d0
-        assert base["single_stream"] == -1
         # a second context alive on the device: the default (-1) takes the one-stream chain for both now
         with L.context(images.crop(200, 120, 10, 10), 0.971769) as other:
             other.encode_rgb(download=False)

@@ -53,6 +53,17 @@ struct HuffTable {
   int num_values = 0;
   uint16_t fast[512];  // ((length) << 8 | symbol) + 1 for codes of <= 9 bits, 0 otherwise
 
+  // A slot no DHT has filled decodes nothing: a sequential scan whose header names a band without DC passes the
+  // "table defined" check (it goes by the header's band, ProcessSOS :229-252) and then meets the reference's
+  // never-built lookup table, whose every entry is the invalid symbol (found by the 2 M-mutation campaign).
+  HuffTable() {
+    memset(fast, 0, sizeof(fast));
+    memset(values, 0, sizeof(values));
+    for (int l = 0; l < 18; ++l) maxcode[l] = -1;
+    for (int l = 0; l < 17; ++l) { valptr[l] = 0; mincode[l] = 0; }
+    maxcode[17] = 0x7fffffff;
+  }
+
   void Build(const int* counts /*[1..16]*/, const uint8_t* vals, int n) {
     num_values = n;
     memcpy(values, vals, (size_t)n);

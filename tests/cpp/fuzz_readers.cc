@@ -10,7 +10,8 @@
 // instrumented): both must refuse, or both accept with identical content (the canonical dump of reader_dump.h /
 // the RGB pixels).  Streams whose header announces more than 16 MPix go through the product alone (the
 // reference would allocate the announced image: its own fuzz target skips large images for that reason).
-// Exit code 0 and a one-line summary; 1 with the offending stream written to fuzz_fail.bin on a mismatch; a
+// Every stream goes through the product twice over differently scribbled stacks (uninitialised state shows as a
+// difference).  Exit code 0 and a one-line summary; 1 with the offending stream written to fuzz_fail.bin on a mismatch; a
 // sanitizer report aborts the process.
 #include <dlfcn.h>
 #include <stdint.h>
@@ -256,6 +257,31 @@ static Bytes mutate_png(const Bytes& seed, Rng* r) {
   return d;
 }
 
+// The product's readers keep their state in stack objects; ASan / UBSan do not see a read of a member nobody wrote.
+// Every stream therefore goes through the product twice, over a stack scribbled with two different patterns: a
+// verdict or a content that depends on uninitialised memory differs between the two runs.
+__attribute__((noinline)) static void scribble_stack(int pattern) {
+  volatile uint8_t pad[96 * 1024];
+  for (size_t i = 0; i < sizeof pad; i += 1) pad[i] = (uint8_t)pattern;
+}
+
+static bool product_read(bool png, const uint8_t* p, size_t n, std::string* got) {
+  got->clear();
+  if (png) {
+    std::vector<uint8_t> rgb;
+    int w = 0, h = 0;
+    if (!guetzli_amd::ReadPng(p, n, &w, &h, &rgb)) return false;
+    got->assign((const char*)&w, 4);
+    got->append((const char*)&h, 4);
+    got->append((const char*)rgb.data(), rgb.size());
+    return true;
+  }
+  guetzli_amd::JpegInput jpg;
+  if (!guetzli_amd::ReadJpeg(p, n, &jpg)) return false;
+  *got = guetzli_amd::DumpJpegInput(jpg);
+  return true;
+}
+
 // ---------------------------------------------------------------------------------- main --
 typedef long (*RefJpegFn)(const uint8_t*, long, uint8_t*, long);
 typedef long (*RefPngFn)(const unsigned char*, long, int*, unsigned char*, long);
@@ -280,17 +306,16 @@ int main(int argc, char** argv) {
     const Bytes& seed = seeds[(size_t)(k < 0 ? -k - 1 : k) % seeds.size()];
     const Bytes d = k < 0 ? seed : (png ? mutate_png(seed, &rng) : mutate_jpeg(seed, &rng));   // (first: the seeds themselves)
     const uint8_t* p = d.empty() ? (const uint8_t*)"" : d.data();
-    bool got_ok;
-    std::string got;
-    if (png) {
-      std::vector<uint8_t> rgb;
-      int w = 0, h = 0;
-      got_ok = guetzli_amd::ReadPng(p, d.size(), &w, &h, &rgb);
-      if (got_ok) { got.assign((const char*)&w, 4); got.append((const char*)&h, 4); got.append((const char*)rgb.data(), rgb.size()); }
-    } else {
-      guetzli_amd::JpegInput jpg;
-      got_ok = guetzli_amd::ReadJpeg(p, d.size(), &jpg);
-      if (got_ok) got = guetzli_amd::DumpJpegInput(jpg);
+    std::string got, again;
+    scribble_stack(0x00);
+    const bool got_ok = product_read(png, p, d.size(), &got);
+    scribble_stack(0xff);
+    const bool again_ok = product_read(png, p, d.size(), &again);
+    if (got_ok != again_ok || got != again) {
+      fprintf(stderr, "NONDETERMINISTIC at mutation %d: the product's result depends on uninitialised memory\n", k);
+      FILE* f = fopen("fuzz_fail.bin", "wb");
+      if (f) { fwrite(d.data(), 1, d.size(), f); fclose(f); }
+      return 1;
     }
     if ((png ? png_announced_pixels(d) : jpeg_announced_pixels(d)) > kMaxPixels) { ++product_only; continue; }
     bool exp_ok;

@@ -60,6 +60,12 @@ def test_bench_main_two_ranks_gloo():
     assert r["scale_value"] == c5["value"]
     assert c5["n_ranks_seen"] == 2 and c5["ranks_in_records"] == [0, 1]
     assert c5["images_per_rank"] == {"0": c5["images_per_gpu"], "1": c5["images_per_gpu"]}
+    # every rank's host-CPU binding is on the line (all-gathered): disjoint shares of the cores of this container
+    bind = c5["binding_per_rank"]
+    assert [b["rank"] for b in bind] == [0, 1] and all(b["n_host_cpus"] >= 1 and b["how"] for b in bind)
+    from guetzli_amd.affinity import parse_cpulist
+    assert not set(parse_cpulist(bind[0]["host_cpus"])) & set(parse_cpulist(bind[1]["host_cpus"]))
+    assert r["value_1mpix"] > 0 and r["config_1mpix"]["iterations"] >= 1
     assert "cpu_baseline" not in r and "batch_one_gpu" not in r   # N = 1 only
 
 

@@ -92,3 +92,43 @@ def test_malformed_streams_are_rejected_like_the_reference(host):
     for bad in (good[:2], good[: len(good) // 2], b"\x00" + good, good[:-2],
                 good.replace(b"\xff\xc0", b"\xff\xc3", 1)):
         assert (dump(host.gzh_read_jpeg, bad) is None) == (ref_dump(bad) is None)
+
+
+def test_divergences_the_fuzzer_found_stay_fixed(host):
+    """Hand-made from a baseline stream, after tests/test_fuzz_readers.py's campaigns: (1) a marker the reference does
+    not know (0xff 0xf2 in place of APP0) is skipped like garbage; (2) a DC Huffman table that is never defined while
+    the scan header names a band without DC (Ss = 4): the header check passes -- it goes by the header's band even in
+    a sequential frame -- and the first DC symbol then meets an empty table: refused; (3) the same symbol twice in a
+    DHT: refused; (4) a fifth quantisation table: refused."""
+    rgb = images.crop(48, 40, 60, 60)
+    good = jpeg_bytes(rgb, quality=90, subsampling=0)
+    assert ref_dump(good) is not None
+
+    def verdicts(data):
+        exp, got = ref_dump(data), dump(host.gzh_read_jpeg, data)
+        assert got == exp
+        return exp
+
+    # (1)
+    i = good.index(b"\xff\xe0")
+    assert verdicts(good[:i + 1] + b"\xf2" + good[i + 2:]) is not None
+    # (2)
+    d0 = good.index(b"\xff\xc4")                       # the first DHT: DC table 0
+    assert good[d0 + 4] == 0x00
+    sos = good.index(b"\xff\xda")
+    n = good[sos + 4]
+    hdr = sos + 5 + 2 * n                               # Ss, Se, AhAl
+    bad = bytearray(good)
+    bad[d0 + 1] = 0x5c
+    bad[hdr], bad[hdr + 1] = 4, 5
+    assert verdicts(bytes(bad)) is None
+    # (3)
+    bad = bytearray(good)
+    bad[d0 + 5 + 16 + 1] = bad[d0 + 5 + 16]             # second symbol := first symbol
+    assert verdicts(bytes(bad)) is None
+    # (4)
+    q0 = good.index(b"\xff\xdb")
+    qlen = (good[q0 + 2] << 8) | good[q0 + 3]
+    seg = good[q0:q0 + 2 + qlen]
+    many = good[:q0] + seg * 5 + good[q0 + 2 + qlen:]
+    assert verdicts(many) is None

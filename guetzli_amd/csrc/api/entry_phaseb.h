@@ -134,7 +134,12 @@ static int order_auto_enqueue(gz_ctx* c, int direction, int max_block_dist, doub
     // candidate's whole scan there (gz_jpeg_scan_begin) before it asks for the order, and the
     // order, the descent and the distance that arrives with them would wait for the coder
     // (ADVICE r3).  Nothing on the main stream reads d_next_cand before the order's kernels.
-    hipStream_t up = c->compare_pending ? c->side_stream : c->stream;
+    // In batch mode -- the evaluation in flight was put on ONE stream because other contexts are alive (chain.h,
+    // choose_streams) -- the copy stays on the main stream too: on the side stream it shares a hardware queue with
+    // ANOTHER image's main stream and waits there behind that image's kernels, and the order with it (8 x 4K
+    // 40.7 -> 43.0 MPix/s, 16 x 1080p 34.6 -> 36.2, 64 x 1 MPix 29.6 -> 32.6: r06_chain_experiments.log, section 11).
+    const bool beside = c->compare_pending && !c->single_now;
+    hipStream_t up = beside ? c->side_stream : c->stream;
     void* h = nullptr;
     TRY(stage_reserve(c, &c->stage_main, sizeof(int) * nb, &h));
     memcpy(h, next_cand, sizeof(int) * nb);

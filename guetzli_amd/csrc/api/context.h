@@ -128,6 +128,7 @@ static int live_contexts(int device, int delta) {
 // quality-84 encode 0.177 instead of 0.150 s (profiles/r05_chain_experiments.log, section 10).
 struct StreamSet {
   hipStream_t own = nullptr, side = nullptr, side2 = nullptr, entropy = nullptr;
+  int rot = 0;   // position of `own` in the set's creation order = the hardware queue (mod 4) its main stream sits on
 };
 struct StreamSetPool {
   std::mutex mu;
@@ -195,21 +196,28 @@ inline int stream_set_key(int device, bool prio_main, int cu_class) {
   return (device * 64 + cu_class) * 2 + (prio_main && stream_priorities() ? 1 : 0);
 }
 
-hipError_t pool_stream_set_create(StreamSet* out, bool prio_main, int cu_class) {
+// want_rot >= 0 (the default; GZ_SET_SLOT=0 switches it off): a set whose main stream sits on that hardware queue -- the contexts alive on a
+// device take slots, slot s asks for rotation s mod 4, so that four images in flight have their main streams on four
+// different queues whatever order the images finished in.
+hipError_t pool_stream_set_create(StreamSet* out, bool prio_main, int cu_class, int want_rot = -1) {
 #ifndef GZ_EMU
   int device = 0;
   (void)hipGetDevice(&device);
   const int key = stream_set_key(device, prio_main, cu_class);
   StreamSetPool& p = stream_set_pool();
   std::lock_guard<std::mutex> lk(p.mu);   // (also keeps two threads' creations from interleaving)
-  auto it = p.sets.find(key);
-  if (it != p.sets.end()) { *out = it->second; p.sets.erase(it); return hipSuccess; }
+  {
+    auto range = p.sets.equal_range(key);
+    for (auto it = range.first; it != range.second; ++it)
+      if (want_rot < 0 || it->second.rot == want_rot) { *out = it->second; p.sets.erase(it); return hipSuccess; }
+  }
   // The k-th set is created in an order rotated by k, so that the k-th context's MAIN stream sits on
   // hardware queue k mod 4 and its three other streams on the three other queues: with every set made
   // in the same order the main streams of the four images in flight all shared one queue, and a batch
   // of eight 4K images fell from 39 to 32 MPix/s (section 10 of the experiment log).
   static int serial = 0;
-  const int rot = (serial++) & 3;
+  const int rot = want_rot >= 0 ? (want_rot & 3) : ((serial++) & 3);
+  out->rot = rot;
   hipStream_t* slot[4] = {&out->own, &out->side, &out->side2, &out->entropy};
   int least = 0, greatest = 0;
   const bool prio = (key & 1) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
@@ -319,6 +327,7 @@ struct gz_ctx {
   bool single_now = false;   // (chain.h choose_streams: this Compare's kernels on the main stream only)
   bool side_small = false;   // (chain.h: set while the side branches' launches are made, cfg.side_small)
   gz_config cfg;             // run-time configuration (include/guetzli_amd.h): the environment's, read once at gz_create
+  int set_rot = 0;           // the stream set's rotation (goes back to the pool with it)
   int cu_slot = -1, cu_class = 0;   // CU-partitioned stream sets (cu_plan): the context's slot; 0 = unmasked streams
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mask_pre = nullptr;
   hipEvent_t ev_next_cand = nullptr;   // next_cand uploaded beside a Compare chain in flight

@@ -156,7 +156,15 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
       c->cu_class = 1;
     }
     StreamSet ss;
-    const hipError_t se = pool_stream_set_create(&ss, c->prio_streams, c->cu_class);
+    // The contexts alive on a device take slots (lowest free first) and slot s gets a stream set whose MAIN stream
+    // sits on hardware queue s mod 4: four images in flight then have their main streams on four different queues
+    // whatever order the images before them finished in (handed out by availability, two mains could share a queue:
+    // the "40 or 44-46 MPix/s" of a 4K batch from process to process; 16 x 1080p 35.4 -> 39.7 MPix/s, 12 x 1440p 38.9 ->
+    // 40.2, 8 x 4K 42.4 -> 43.6, nothing at 1 MPix and below: r06_chain_experiments.log, section 12).  GZ_SET_SLOT=0: as before.
+    static const bool set_slot = [] { const char* e = getenv("GZ_SET_SLOT"); return e ? atoi(e) != 0 : true; }();
+    if (set_slot && c->cu_slot < 0) c->cu_slot = cu_slot_take(device);
+    const hipError_t se = pool_stream_set_create(&ss, c->prio_streams, c->cu_class, set_slot ? c->cu_slot % 4 : -1);
+    c->set_rot = ss.rot;
     c->own_stream = ss.own; c->side_stream = ss.side; c->side_stream2 = ss.side2; c->entropy_stream = ss.entropy;
     c->stream = c->own_stream;
     CHK0(se);
@@ -300,6 +308,7 @@ void gz_destroy(gz_ctx* c) {
   {   // the four streams go back as the set they were made as (own_stream: synchronised at the top of gz_destroy)
     StreamSet ss;
     ss.own = c->own_stream; ss.side = c->side_stream; ss.side2 = c->side_stream2; ss.entropy = c->entropy_stream;
+    ss.rot = c->set_rot;
     pool_stream_set_destroy(ss, c->prio_streams, c->cu_class);
   }
   if (c->cu_slot >= 0) cu_slot_release(c->device, c->cu_slot);

@@ -39,6 +39,17 @@ def encode_batch(get_image, n_images, process, rank=0, world=1, dist=None):
     return sorted((r for part in gathered for r in part), key=lambda r: r["index"])
 
 
+def hint_in_flight(n):
+    """Tells the device library how many images this process is about to run at once (gz_hint_images_in_flight:
+    no priority streams among a batch's streams).  Quietly nothing when the product library is not the one in use
+    (the CPU suite's emulation)."""
+    try:
+        import guetzli_amd
+        guetzli_amd.load().lib.gz_hint_images_in_flight(int(n))
+    except Exception:
+        pass
+
+
 def encode_concurrent(images, process, workers=4):
     """Several independent images on ONE GPU at the same time: one host thread per image in
     flight (the C++ driver releases the GIL for the whole encode; every image has its own
@@ -46,8 +57,12 @@ def encode_concurrent(images, process, workers=4):
     -- the rest is the serial search logic on the host -- so images in flight overlap one
     image's host work with another's kernels.  Returns [(jpeg_bytes, info)] in input order."""
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
-        return list(ex.map(process, images))
+    hint_in_flight(workers)
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+            return list(ex.map(process, images))
+    finally:
+        hint_in_flight(1)
 
 
 class BatchError(RuntimeError):
@@ -75,8 +90,12 @@ def encode_shard_concurrent(get_image, indices, process, workers, rank=0):
         return {"index": k, "bytes": len(jpg), "sha256": hashlib.sha256(jpg).hexdigest(),
                 "seconds": time.perf_counter() - t0, "rank": rank}
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
-        return list(ex.map(one, indices))
+    hint_in_flight(workers)
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+            return list(ex.map(one, indices))
+    finally:
+        hint_in_flight(1)
 
 
 def raise_on_failures(records):

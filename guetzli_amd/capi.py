@@ -36,6 +36,7 @@ SIGNATURES = {
     "gz_device_count": (_I, []),
     "gz_strerror": (C.c_char_p, [_I]),
     "gz_last_error": (C.c_char_p, [_P]),
+    "gz_hint_images_in_flight": (None, [_I]),
     "gz_device_pci_bus_id": (_I, [_I, _P, _I]),
     "gz_config_from_environment": (_I, [_P]),
     "gz_get_config": (_I, [_P, _P]),

@@ -109,7 +109,10 @@ struct HandlePool {
 HandlePool& handle_pool() { static HandlePool p; return p; }
 // prio: 0 = default, +1 = the device's highest priority, -1 = its lowest.  Who takes which:
 // create_context.
-static bool stream_priorities() { return true; }
+static bool stream_priorities() {   // GZ_STREAM_PRIO=0: no priority stream even for a lone context (A/B)
+  static const bool v = [] { const char* e = getenv("GZ_STREAM_PRIO"); return e ? atoi(e) != 0 : true; }();
+  return v;
+}
 // Contexts alive per device: adds `delta`, returns the count before.
 static int live_contexts(int device, int delta) {
   static std::mutex mu;

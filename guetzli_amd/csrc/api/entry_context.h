@@ -42,6 +42,28 @@ int gz_set_config(gz_ctx* c, const gz_config* in) {
   return GZ_OK;
 }
 
+static std::atomic<int>& images_in_flight_hint() { static std::atomic<int> v{0}; return v; }
+void gz_hint_images_in_flight(int n) {
+  images_in_flight_hint().store(n, std::memory_order_relaxed);
+  if (n > 1) {
+    // company is coming: idle stream sets with a priority main stream go (a priority stream is one more hardware
+    // queue for the runtime to multiplex, even while nobody uses it)
+    StreamSetPool& sp = stream_set_pool();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    for (auto it = sp.sets.begin(); it != sp.sets.end();) {
+      if (it->first & 1) {
+        (void)hipStreamDestroy(it->second.own);
+        (void)hipStreamDestroy(it->second.side);
+        (void)hipStreamDestroy(it->second.side2);
+        (void)hipStreamDestroy(it->second.entropy);
+        it = sp.sets.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+}
+
 int gz_device_pci_bus_id(int device, char* out, int cap) {
   if (!out || cap < 16) return GZ_E_ARG;
 #ifdef GZ_EMU
@@ -145,7 +167,7 @@ static gz_ctx* create_context(int device, int w, int h, const uint8_t* rgb, floa
   // image's low-priority entropy coder starves behind the other images' chains while its host
   // thread waits for it: 16 x 1080p, 8 in flight, 21.8 -> 7.5-13.5 MPix/s with main = highest and
   // entropy = lowest on every context; profiles/r03_stream_priorities.log).
-  c->prio_streams = live_contexts(device, +1) == 0;
+  c->prio_streams = live_contexts(device, +1) == 0 && images_in_flight_hint().load(std::memory_order_relaxed) <= 1;
   c->counted_live = true;
   {
     const CuPlan& cp = cu_plan();

@@ -58,6 +58,12 @@ int gz_trim_pool(void);
 int gz_device_count(void);                /* number of visible HIP devices, <0 on error */
 const char* gz_strerror(int code);
 const char* gz_last_error(const gz_ctx* ctx);
+/* A caller that runs several images at once in this process (one thread + one context each) says so before it starts
+ * them: n = images in flight (<= 1: lone images again).  Only a hint, process-wide, no result depends on it: a context
+ * created while the device is empty takes a highest-priority main stream (worth 2 % of a lone 4K chain) unless the hint
+ * says that company is coming -- a priority stream is one more hardware queue for the runtime to multiplex and costs a
+ * batch 1-4 %; with n > 1 the idle priority stream sets of the pool are destroyed as well. */
+void gz_hint_images_in_flight(int n);
 /* PCI bus id of a HIP device ("0000:05:00.0"; hipDeviceGetPCIBusId) -- for NUMA-aware placement of the
  * process that feeds it (bench.py / guetzli_amd/affinity.py); out needs >= 16 bytes. */
 int gz_device_pci_bus_id(int device, char* out, int cap);

@@ -25,7 +25,7 @@ _I = C.c_int
 class GzConfig(C.Structure):
     """gz_config of include/guetzli_amd.h."""
     _fields_ = [("struct_size", _I), ("blur_packed", _I), ("tile_rows", _I), ("single_stream", _I),
-                ("store_distmap", _I), ("side_small", _I), ("malta_pad_bytes", _I)]
+                ("store_distmap", _I), ("side_small", _I), ("malta_pad_bytes", _I), ("patch_reconstruct", _I)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -73,6 +73,7 @@ SIGNATURES = {
     "gz_compare_block_pixels": (_I, [_P, _I, _P, _P, _P]),
     "gz_set_frame": (_I, [_P, _I]),
     "gz_search_evaluations": (_I, [_P, _P]),
+    "gz_compare_counters": (_I, [_P]),
     "gz_rank_zeroing_candidates": (_I, [_P, _P, _I, _I, _P, _P]),
     "gz_probe_rank_sort": (_I, [_I, _P, _P, _I, _P]),
     "gz_order_build": (_I, [_P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P]),
@@ -157,6 +158,12 @@ class Library:
         cfg = GzConfig()
         self.check(self.lib.gz_config_from_environment(C.byref(cfg)))
         return cfg
+
+    def compare_counters(self):
+        """(Compares that skipped the full reconstruction, of them checked against one, Compares in all) since load."""
+        n = np.zeros(3, np.uint64)
+        self.check(self.lib.gz_compare_counters(_ptr(n)))
+        return int(n[0]), int(n[1]), int(n[2])
 
     # ---- context-free probes ----
     def idct_blocks(self, blocks, device=0):

@@ -431,7 +431,8 @@ int join_mask_branch(gz_ctx* c) {
 
 // DiffmapPsychoImage (butteraugli.cc:817-908) + score: p0 = original, p1 = candidate.
 int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block_max,
-                  bool max_cleared = false, bool want_distmap = true, bool streams_chosen = false) {
+                  bool max_cleared = false, bool want_distmap = true, bool streams_chosen = false,
+                  bool clear_in_combine = false) {
   if (!streams_chosen) choose_streams(c);
   const float hf_asymmetry_ = 0.8f;
   // side stream: SameNoise blur + the mask branch; main stream: Malta
@@ -474,6 +475,7 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     a.w_0lt1 = (wmul1 / hf_asymmetry_) * 0.8;
     a.out = c->dsq;
     for (int i = 0; i < 3; ++i) a.mask_out[i] = a.mask_dc_out[i] = nullptr;
+    a.clear_word = clear_in_combine ? c->d_max_bits : nullptr;
     dim3 grid(gz_div_up(c->w, 1024), c->h);   // (4 pixels per thread)
     GZ_LAUNCH(k_combine, grid, dim3(256), c->stream, a, c->w, c->h, c->pitch);
     KCHK(c);
@@ -481,7 +483,7 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
   {  // CalculateDiffmap second half: blur(sigma 1.725, border_ratio 1.0) + mix
     SrcPack<SrcPlain, 1> s; s.s[0].p = c->dsq;
     PostDiffmapMix post; post.d = c->dsq; post.out = want_distmap ? c->distmap : nullptr;
-    if (!max_cleared) HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
+    if (!max_cleared && !clear_in_combine) HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
     BlockMaxOut bm{want_block_max ? c->d_block_max : nullptr, c->d_max_bits, c->bw};
     TRY((blur2d<3, 1, SrcPlain, PostDiffmapMix, true>(c, s, post, c->blur[B_FINAL], bm)));
   }
@@ -552,13 +554,51 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
 // One full Compare of the current candidate, everything on the stream.
 // want_distmap = false (the search loop, gz_time_compare): the last kernel leaves the per-block maxima and the
 // image maximum only; c->distmap then holds no distance map (have_distmap_plane).
-int enqueue_compare(gz_ctx* c, bool want_block_max, bool want_distmap = false) {
+// The candidate's linear planes: reconstructed here, unless every change of the candidate since the last full
+// reconstruction was patched into them by the call that made it (c->lin_is_cand; the search loop's steady state:
+// a fifth of a 4K image's blocks change per iteration).  force_full: gz_time_compare, whose repetitions change
+// nothing and must not measure a chain without its first kernel.
+static std::atomic<unsigned long long> g_compares{0}, g_compares_patched{0}, g_patch_checks{0};   // gz_compare_counters
+static int check_patched_planes(gz_ctx* c) {   // (gz_config.patch_reconstruct == 2)
+  float* full = nullptr;
+  unsigned* d_bad = nullptr;
+  HIPCHK(c, pool_malloc((void**)&full, sizeof(float) * c->plane * 3));
+  HIPCHK(c, pool_malloc((void**)&d_bad, sizeof(unsigned)));
+  int rc = GZ_OK;
+  unsigned bad = 0;
+  do {
+    if (hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream) != hipSuccess) { rc = GZ_E_HIP; break; }
+    const int strips = gz_div_up(c->bw, kReconBlocks);
+    GZ_LAUNCH(k_reconstruct, dim3(c->bh * strips), dim3(256), c->stream, (const int16_t*)c->d_cand, c->w, c->h, c->bw, c->nb,
+              c->pitch, c->plane, (const float*)c->d_srgb_lut, full, (uint8_t*)nullptr, (unsigned*)nullptr, 1);
+    GZ_LAUNCH(k_count_differing_words, dim3(1024), dim3(256), c->stream, (const unsigned*)c->lin[0], (const unsigned*)full,
+              (size_t)c->plane * 3, d_bad);
+    if (hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { rc = GZ_E_HIP; break; }
+  } while (0);
+  (void)pool_free(full);
+  (void)pool_free(d_bad);
+  TRY(rc);
+  ++g_patch_checks;
+  if (bad) { c->err = "patched linear planes differ from a full reconstruction"; return GZ_E_STATE; }
+  return GZ_OK;
+}
+
+int enqueue_compare(gz_ctx* c, bool want_block_max, bool want_distmap = false, bool force_full = false) {
   want_distmap = want_distmap || c->cfg.store_distmap != 0;   // (1: the chain as it was until round 5, A/B)
   choose_streams(c);
-  TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
+  ++g_compares;
+  const bool patched = !force_full && c->cfg.patch_reconstruct != 0 && c->lin_is_cand && c->cfac == 1;
+  if (patched) {
+    if (c->cfg.patch_reconstruct == 2) TRY(check_patched_planes(c));
+    ++g_compares_patched;
+  } else {
+    TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
+    c->lin_is_cand = c->cfac == 1 && c->cfg.patch_reconstruct != 0;
+  }
   TRY(stage_opsin(c));
   TRY(stage_separate(c, &c->pi1, !single_stream(c)));
-  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, true, want_distmap, true));
+  TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, !patched, want_distmap, true, patched));
   return GZ_OK;
 }
 
@@ -594,6 +634,7 @@ int ensure_block_mask(gz_ctx* c) {
   TRY(ensure_pip(c));
   if (!c->d_block_mask) HIPCHK(c, pool_malloc((void**)&c->d_block_mask, sizeof(float) * 3 * c->nb));
   dim3 grid(gz_div_up(c->w, 256), c->h);
+  c->lin_is_cand = false;   // (lin[] takes the original)
   GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, c->w, c->h, c->pitch,
             c->plane, c->d_srgb_lut, c->lin[0]);
   KCHK(c);

@@ -422,6 +422,10 @@ struct gz_ctx {
   int* d_edit_pos = nullptr; short* d_edit_val = nullptr; size_t edit_cap = 0;
 
   bool have_orig = false, have_cand = false, have_distmap = false;
+  // lin[] holds the reconstruction of d_cand as it is now (4:4:4 frames; cfg.patch_reconstruct): set by the Compare
+  // chain's full reconstruction, kept by the mutators that transform the block positions they change
+  // (gz_apply_candidate_steps, gz_apply_coeff_edits), dropped by everything else that writes d_cand or lin[]
+  bool lin_is_cand = false;
   std::vector<float> h_block_max;
   bool h_block_max_valid = false;
   bool compare_pending = false;

@@ -6,7 +6,7 @@
 extern "C" {
 
 
-int gz_abi_version(void) { return 4; }
+int gz_abi_version(void) { return 5; }
 
 int gz_config_from_environment(gz_config* out) {
   if (!out) return GZ_E_ARG;
@@ -21,6 +21,8 @@ int gz_config_from_environment(gz_config* out) {
   if (const char* e = getenv("GZ_STORE_DISTMAP")) c.store_distmap = atoi(e) != 0;
   if (const char* e = getenv("GZ_SIDE_SMALL")) c.side_small = atoi(e) != 0;
   if (const char* e = getenv("GZ_MALTA_PAD")) c.malta_pad_bytes = std::max(0, std::min(64 << 10, atoi(e)));
+  c.patch_reconstruct = 1;
+  if (const char* e = getenv("GZ_PATCH_RECON")) { const int v = atoi(e); if (v >= 0 && v <= 2) c.patch_reconstruct = v; }
   *out = c;
   return GZ_OK;
 }
@@ -32,13 +34,14 @@ int gz_get_config(const gz_ctx* c, gz_config* out) {
 int gz_set_config(gz_ctx* c, const gz_config* in) {
   if (!c || !in || in->struct_size != (int)sizeof(gz_config)) return GZ_E_ARG;
   if (in->blur_packed < -1 || in->blur_packed > 1 || in->single_stream < -1 || in->single_stream > 1 || (in->tile_rows != 0 && in->tile_rows != 16 && in->tile_rows != 32) ||
-      in->malta_pad_bytes < 0 || in->malta_pad_bytes > (64 << 10))
+      in->malta_pad_bytes < 0 || in->malta_pad_bytes > (64 << 10) || in->patch_reconstruct < 0 || in->patch_reconstruct > 2)
     return GZ_E_ARG;
   if (c->compare_pending || c->scan_pending || c->order_pending || c->desc_pending) {
     c->err = "gz_set_config while work of the context is in flight";
     return GZ_E_STATE;
   }
   c->cfg = *in;
+  c->lin_is_cand = false;
   return GZ_OK;
 }
 
@@ -260,6 +263,7 @@ int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
   if (!c || !rgb) return GZ_E_ARG;
   HIPCHK(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)3 * c->w * c->h, hipMemcpyHostToDevice, c->stream));
   // pi0_ = SeparateFrequencies(OpsinDynamicsImage(LinearRgb(rgb)))
+  c->lin_is_cand = false;   // (lin[] takes the original)
   dim3 grid(gz_div_up(c->w, 256), c->h);
   GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, c->w, c->h, c->pitch,
             c->plane, c->d_srgb_lut, c->lin[0]);

@@ -109,6 +109,7 @@ int gz_set_frame(gz_ctx* c, int chroma_factor) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   set_frame(c, chroma_factor);
   c->have_cand = false;
+  c->lin_is_cand = false;
   c->have_orig = false;   // the original coefficients on the device belonged to the other frame
   return GZ_OK;
 }
@@ -199,6 +200,7 @@ int gz_downsample(gz_ctx* c, int16_t* coeffs_out) {
   }
   set_frame(c, 2);
   c->have_cand = false;
+  c->lin_is_cand = false;
   c->have_distmap = false;
   if (coeffs_out)
     HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_orig, (size_t)c->nblk * 128, hipMemcpyDeviceToHost, c->stream));
@@ -229,6 +231,7 @@ int gz_downsample_planes(gz_ctx* c, const float* y, const float* u, const float*
   }
   set_frame(c, 2);
   c->have_cand = false;
+  c->lin_is_cand = false;
   c->have_distmap = false;
   if (coeffs_out)
     HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_orig, (size_t)c->nblk * 128, hipMemcpyDeviceToHost, c->stream));

@@ -266,6 +266,22 @@ int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
   return GZ_OK;
 }
 
+// Does the call that changes n block positions of the candidate keep its linear planes current (transforming those
+// positions again), or leave them to the next Compare's full reconstruction?  (Decides, and drops the planes' claim.)
+static bool patch_wanted(gz_ctx* c, int n) {
+  const bool patch = c->cfg.patch_reconstruct != 0 && c->lin_is_cand && c->cfac == 1 && (long)n * 2 <= (long)c->nb;
+  if (!patch) c->lin_is_cand = false;
+  return patch;
+}
+static PatchPlanes patch_planes(const gz_ctx* c, bool on) {
+  PatchPlanes pp;
+  pp.bw = c->bw; pp.w = c->w; pp.h = c->h; pp.pitch = c->pitch;
+  pp.pstride = c->plane;
+  pp.srgb_lut = c->d_srgb_lut;
+  pp.lin = on ? c->lin[0] : nullptr;
+  return pp;
+}
+
 int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
                              const int32_t* counts, int n) {
   DeviceScope ds_(c);
@@ -316,10 +332,21 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
     h = d_blocks;
 #endif
-    GZ_LAUNCH(k_apply_steps_hist, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)h,
-              (const int*)h + n, n, direction, (const int*)c->d_next_cand,
-              (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
-              (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta);
+    // the touched block positions of the candidate's linear planes transformed again by the same wavefronts
+    // (chain.h, enqueue_compare), while they are a minority: beyond that the next Compare reconstructs the image
+    const bool patch = patch_wanted(c, n);
+    PatchPlanes pp = patch_planes(c, patch);
+    if (patch) {
+      GZ_LAUNCH(k_apply_steps_hist<true>, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)h,
+                (const int*)h + n, n, direction, (const int*)c->d_next_cand,
+                (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
+                (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta, pp);
+    } else {
+      GZ_LAUNCH(k_apply_steps_hist<false>, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)h,
+                (const int*)h + n, n, direction, (const int*)c->d_next_cand,
+                (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
+                (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta, pp);
+    }
     // the staging buffer is free again behind THIS kernel (the only reader): marked before anything can fail, so
     // that no path returns with the kernel still reading a buffer the next stage_reserve hands out
     TRY(stage_sent(c, &c->stage_main, c->stream));
@@ -329,6 +356,7 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     c->have_step_delta = true;
     return GZ_OK;
   }
+  c->lin_is_cand = false;
   HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
   TRY(stage_sent(c, &c->stage_main, c->stream));
   GZ_LAUNCH(k_apply_steps, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
@@ -385,8 +413,12 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
     k_val = c->d_edit_val;
   }
   GZ_LAUNCH(k_apply_coeff_edits, dim3(gz_div_up(n, 256)), dim3(256), c->stream, k_pos, k_val, n, c->d_cand);
+  if (patch_wanted(c, n)) {   // the edited block positions' pixels, behind the edits (one wavefront per edit)
+    GZ_LAUNCH(k_reconstruct_edited, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), c->stream, k_pos, n,
+              (const int16_t*)c->d_cand, c->nb, patch_planes(c, true));
+  }
   KCHK(c);
-  TRY(stage_sent(c, &c->stage_edits, c->stream));   // (the staging buffer is free again behind the kernel)
+  TRY(stage_sent(c, &c->stage_edits, c->stream));   // (the staging buffer is free again behind the kernels)
   return GZ_OK;   // the caller's buffers were copied to the staging buffer: no wait
 }
 

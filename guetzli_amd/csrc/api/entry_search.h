@@ -226,6 +226,14 @@ int gz_compare_block_pixels(gz_ctx* c, int n, const int32_t* block_xy, const uin
 }
 
 
+int gz_compare_counters(uint64_t out[3]) {
+  if (!out) return GZ_E_ARG;
+  out[0] = g_compares_patched.load();
+  out[1] = g_patch_checks.load();
+  out[2] = g_compares.load();
+  return GZ_OK;
+}
+
 int gz_search_evaluations(gz_ctx* c, uint64_t* evaluations) {
   DeviceScope ds_(c);
   if (!c || !evaluations) return GZ_E_ARG;

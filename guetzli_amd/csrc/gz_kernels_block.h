@@ -255,6 +255,83 @@ __global__ __launch_bounds__(256) void k_reconstruct(
   }
 }
 
+// ------------------------------------------------------------ reconstruct: patches --
+// Phase B's candidate of iteration i + 1 is iteration i's with a few coefficients of a fifth of the
+// blocks changed (processor.cc:704-736), and a block position's pixels depend on its own three
+// coefficient blocks only (4:4:4): the linear planes of the previous candidate stay where they are
+// and only the changed positions are transformed again -- by the kernels that change them
+// (k_apply_steps_hist) or right behind them (k_reconstruct_edited).  The arithmetic is
+// k_reconstruct's, statement for statement; what the reference does per changed block in
+// OutputImageComponent::SetCoeffBlock -> UpdatePixelsForBlock (output_image.cc:123-132,146-160).
+struct PatchPlanes {
+  int bw, w, h, pitch;
+  size_t pstride;
+  const float* srgb_lut;
+  float* lin;   // null: no patching
+};
+
+// One wavefront, lane = pixel of block position b.  blk3 = the position's three coefficient blocks in
+// LDS ([3][64], natural order); tr, col = [3][64] shorts of the wavefront's own LDS (16-byte aligned).
+// Every lane of the workgroup passes the same two synchronisation points (the emulation's rule);
+// `live` = false transforms and stores nothing.
+GZ_DEVFN void wave_reconstruct_block(const short* blk3, short* tr, short* col, int lane, int b, bool live,
+                                     const PatchPlanes& pp) {
+  const int iy = lane >> 3, ix = lane & 7;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) tr[c * 64 + 8 * ix + iy] = blk3[c * 64 + lane];   // transposed
+  GZ_WAVE_SYNC();
+  const gz_u4 m_row = gz_load_u4(&kIdctMP[4 * iy]), m_col = gz_load_u4(&kIdctMP[4 * ix]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {   // column pass (idct.cc:143-149)
+    const gz_u4 q = gz_load_u4(&tr[c * 64 + 8 * ix]);
+    col[c * 64 + lane] = (short)((idct_dot8(m_row, q) + (1 << 10)) >> 11);
+  }
+  GZ_WAVE_SYNC();
+  int px[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {   // row pass (idct.cc:150-160)
+    const gz_u4 q = gz_load_u4(&col[c * 64 + 8 * iy]);
+    px[c] = clamp255((idct_dot8(m_col, q) + (257 << 17)) >> 18);
+  }
+  int r, g, bl;
+  ycc_to_rgb(px[0], px[1], px[2], &r, &g, &bl);
+  const int x = 8 * (b % pp.bw) + ix, y = 8 * (b / pp.bw) + iy;
+  if (live && x < pp.w && y < pp.h) {
+    const size_t o = (size_t)y * pp.pitch + x;
+    pp.lin[o] = pp.srgb_lut[r];
+    pp.lin[pp.pstride + o] = pp.srgb_lut[g];
+    pp.lin[2 * pp.pstride + o] = pp.srgb_lut[bl];
+  }
+}
+
+// The block positions of a list of coefficient positions (gz_apply_coeff_edits: pos[i] indexes
+// [3][nb][64]) transformed again, one wavefront per entry; an entry whose position is its
+// predecessor's is skipped, the other repetitions store the same values twice.
+__global__ __launch_bounds__(256) void k_reconstruct_edited(const int* __restrict__ pos, int n,
+                                                            const int16_t* __restrict__ coeffs, int nb,
+                                                            PatchPlanes pp) {
+  __shared__ __attribute__((aligned(16))) short s_blk[kBlocksPerWG][3 * 64];
+  __shared__ __attribute__((aligned(16))) short s_tr[kBlocksPerWG][3 * 64];
+  __shared__ __attribute__((aligned(16))) short s_col[kBlocksPerWG][3 * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * kBlocksPerWG + wave;
+  const int b = i < n ? (pos[i] >> 6) % nb : 0;
+  const bool live = i < n && !(i > 0 && (pos[i - 1] >> 6) % nb == b);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s_blk[wave][c * 64 + lane] = coeffs[((size_t)c * nb + b) * 64 + lane];
+  GZ_WAVE_SYNC();
+  wave_reconstruct_block(s_blk[wave], s_tr[wave], s_col[wave], lane, b, live, pp);
+}
+
+// gz_config.patch_reconstruct == 2: words in which the patched planes differ from a full reconstruction.
+__global__ __launch_bounds__(256) void k_count_differing_words(const unsigned* __restrict__ a,
+                                                               const unsigned* __restrict__ b, size_t n,
+                                                               unsigned* __restrict__ count) {
+  unsigned bad = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) bad += a[i] != b[i];
+  if (bad) atomicAdd(count, bad);
+}
+
 // Bare-block IDCT probe (gz_probe_idct_blocks): the arithmetic of k_reconstruct.
 __global__ __launch_bounds__(256) void k_idct_blocks(const int16_t* __restrict__ blocks,
                                                      int n, uint8_t* __restrict__ out) {

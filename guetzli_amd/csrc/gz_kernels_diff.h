@@ -288,6 +288,8 @@ struct CombineArgs {
   float* out;                 // sqrt-stage diffmap (input of the final blur)
   float* mask_out[3];         // optional: mask planes (block search / probes), may be null
   float* mask_dc_out[3];      // optional
+  unsigned* clear_word;       // optional: the distance accumulator of the chain's last kernel, reset here when the
+                              // Compare has no full reconstruction in front (whose first workgroup resets it otherwise)
 };
 
 GZ_DEVFN void mask_p0p1(float bx, float by1, float by2, double* p0, double* p1) {
@@ -352,6 +354,7 @@ GZ_DEVFN float combine_px(const CombineArgs& a, size_t i, float mxb, float myb1,
 // input planes and the output move as 16-byte accesses -- when the pitch allows it.
 __global__ __launch_bounds__(256) void k_combine(CombineArgs a, int w, int h, int pitch) {
   const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+  if (a.clear_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.clear_word = 0u;
   if (x >= w || y >= h) return;
   const size_t i = (size_t)y * pitch + x;
   if ((pitch & 3) == 0 && x + 3 < w && a.out != nullptr) {

@@ -49,7 +49,7 @@ extern "C" {
 typedef struct gz_ctx gz_ctx;
 
 /* Library / device ------------------------------------------------------------ */
-int gz_abi_version(void);                 /* currently 4 (3 + gz_config, gz_device_pci_bus_id) */
+int gz_abi_version(void);                 /* currently 5 (4 + gz_config.patch_reconstruct) */
 /* Device and pinned host memory of destroyed contexts is kept (per device, exact sizes, at
  * most GZ_POOL_MB megabytes of device memory, default 16384) for the next context of the same
  * image size: a batch of same-sized images allocates once.  gz_trim_pool releases everything
@@ -86,6 +86,11 @@ typedef struct gz_config {
                                             distmap != NULL and the stage probes do) */
   int side_small;       /* GZ_SIDE_SMALL    1: side-branch blurs in Malta-sized forms (experiment, round 6) */
   int malta_pad_bytes;  /* GZ_MALTA_PAD     unused dynamic LDS per Malta workgroup (experiment, round 6) */
+  int patch_reconstruct;/* GZ_PATCH_RECON   1 (default): gz_apply_candidate_steps / gz_apply_coeff_edits transform the block
+                                            positions they change again (4:4:4 frames) and the Compare behind them skips its
+                                            full reconstruction; 0: every Compare reconstructs the whole image; 2: as 1, and
+                                            every Compare checks the patched planes against a full reconstruction
+                                            (GZ_E_STATE on a difference; tests).  gz_time_compare always reconstructs. */
 } gz_config;
 int gz_config_from_environment(gz_config* out);
 int gz_get_config(const gz_ctx* ctx, gz_config* out);
@@ -276,6 +281,10 @@ int gz_block_zeroing_orders_masked(gz_ctx* ctx, int comp_mask, int lookahead, in
  * gz_block_zeroing_orders* call made -- the unit the search's throughput is reported in
  * (bench.py: evaluations per second). */
 int gz_search_evaluations(gz_ctx* ctx, uint64_t* evaluations);
+/* Process-wide, since the library was loaded (tests, bench.py): out[0] = Compares whose candidate planes were kept
+ * current by the calls that changed the candidate and that skipped the full reconstruction (gz_config.patch_reconstruct),
+ * out[1] = those of them that were checked against a full reconstruction (patch_reconstruct == 2), out[2] = Compares in all. */
+int gz_compare_counters(uint64_t out[3]);
 /* The per-block form of the seam: Comparator::SwitchBlock + CompareBlock
  * (butteraugli_comparator.cc:427-488; factor_x = factor_y = 1) for n independent pairs of a
  * block position block_xy[i] = {block_x, block_y} and that block's candidate coefficients

@@ -464,6 +464,26 @@ def test_whole_encode_4k_bit_identical_jpeg(q, size):
     assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(3840, 2160, q)]
 
 
+@pytest.mark.parametrize("mode", ["2", "0"])
+def test_patched_candidate_planes_equal_a_full_reconstruction_1080p(L, monkeypatch, mode):
+    """gz_config.patch_reconstruct: the calls that change the candidate (bulk steps, serial steps' edits) transform
+    the block positions they touch again, and the Compare behind them skips its full reconstruction.  Mode 2 checks
+    the patched planes against a full reconstruction before EVERY such Compare (a difference fails the encode);
+    mode 0 is the chain with its reconstruction in front.  Same bytes as the reference either way."""
+    import hashlib
+    import guetzli_amd
+    monkeypatch.setenv("GZ_PATCH_RECON", mode)
+    before = L.compare_counters()
+    jpg, info = guetzli_amd.process(images.tiled(1920, 1080), quality=95)
+    patched, checked, compares = (a - b for a, b in zip(L.compare_counters(), before))
+    assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(1920, 1080, 95)]
+    assert compares >= info["counters"]["number of iterations"]
+    if mode == "2":
+        assert patched == checked and patched > 0.8 * info["counters"]["number of iterations"]
+    else:
+        assert patched == 0 and checked == 0
+
+
 @pytest.mark.parametrize("level", ["1", "2"])
 def test_whole_encode_with_self_checks_1080p(monkeypatch, level):
     """GZ_VERIFY_ENTROPY=1: every candidate's device scan equals the host writer's bytes and

@@ -379,6 +379,32 @@ def test_size_bound_path_with_its_self_checks_in_emulation(host_emu, monkeypatch
 
 
 @needs_ref
+@pytest.mark.parametrize("case", [(48, 40, 300, 150, {}), (136, 88, 60, 20, {}), (61, 43, 10, 30, {}),
+                                  (64, 48, 200, 100, dict(force_420=True))])
+def test_patched_candidate_planes_equal_a_full_reconstruction_in_emulation(host_emu, monkeypatch, case):
+    """gz_config.patch_reconstruct = 2 (GZ_PATCH_RECON): every Compare that relies on the candidate's linear planes
+    having been kept current by gz_apply_candidate_steps / gz_apply_coeff_edits checks them against a full
+    reconstruction first; ragged sizes patch partial blocks at the right and bottom edges; a 4:2:0 frame never
+    patches.  And = 0: no Compare skips its reconstruction.  Same bytes as the reference."""
+    from guetzli_amd import capi
+    w, h, x0, y0, kw = case
+    L = capi.Library(build_emu.build())
+    rgb = images.crop(w, h, x0, y0)
+    exp_jpg, _ = ref.process_params(rgb, ref._butteraugli_score_for_quality(95.0), **kw)
+    for mode in ("2", "0"):
+        monkeypatch.setenv("GZ_PATCH_RECON", mode)
+        before = L.compare_counters()
+        got, info = host_emu.process(rgb, quality=95, **kw)
+        patched, checked, compares = (a - b for a, b in zip(L.compare_counters(), before))
+        assert got == exp_jpg
+        assert compares > 0 and patched == checked
+        if mode == "2" and not kw:
+            assert patched >= info["counters"]["number of iterations"] // 2
+        else:
+            assert patched == 0
+
+
+@needs_ref
 @pytest.mark.parametrize("threads", [0, 1, 3])
 def test_code_refresh_helpers_change_nothing_but_the_time(host_emu, monkeypatch, threads):
     """guetzli_amd/host/code_refresh.h: phase B's serial steps with the size model's Huffman codes

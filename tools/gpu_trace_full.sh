@@ -22,7 +22,7 @@ for r in a:
     if n in ("hipGetDevice", "hipSetDevice", "hipGetLastError", "hipPeekAtLastError", "__hipPushCallConfiguration", "__hipPopCallConfiguration"): continue
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "A " + n))
 ev.sort()
-rec = [i for i, e in enumerate(ev) if "k_reconstruct" in e[2]]
+rec = [i for i, e in enumerate(ev) if "PostOpsin" in e[2] and e[2].startswith("K ")]   # (one per Compare)
 i0 = rec[len(rec) // 2 + 20]; i1 = rec[len(rec) // 2 + 22]
 # start a little before the reconstruct kernel (its launch call)
 t0 = ev[i0][0]

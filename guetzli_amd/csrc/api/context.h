@@ -431,6 +431,7 @@ struct gz_ctx {
   bool compare_pending = false;
   int h_jq[192] = {0};       // the matrix d_jq holds
   unsigned* d_step_delta = nullptr; bool have_step_delta = false;   // AC statistics change of the last bulk steps
+  hipEvent_t ev_steps = nullptr; bool step_delta_event = false;     // ... are in place (recorded when more work follows them on the stream)
   void* h_step_delta = nullptr;   // ... as k_steps_hist_sum writes it: 768 ints, page-locked + mapped
   HostStage stage_main, stage_entropy;
   HostStage stage_edits;   // gz_apply_coeff_edits' own: its kernel reads the buffer, and the next order's upload (stage_main) must not wait for it

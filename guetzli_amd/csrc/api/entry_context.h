@@ -320,6 +320,7 @@ void gz_destroy(gz_ctx* c) {
   if (c->side_stream2) (void)hipStreamSynchronize(c->side_stream2);
   if (c->entropy_stream) (void)hipStreamSynchronize(c->entropy_stream);
   pool_event_destroy(c->ev_candidate);
+  if (c->ev_steps) pool_event_destroy(c->ev_steps);
   stage_free(&c->stage_main);
   stage_free(&c->stage_entropy);
   stage_free(&c->stage_edits);

@@ -332,21 +332,13 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
     h = d_blocks;
 #endif
-    // the touched block positions of the candidate's linear planes transformed again by the same wavefronts
+    // the touched block positions of the candidate's linear planes are transformed again behind the statistics
     // (chain.h, enqueue_compare), while they are a minority: beyond that the next Compare reconstructs the image
     const bool patch = patch_wanted(c, n);
-    PatchPlanes pp = patch_planes(c, patch);
-    if (patch) {
-      GZ_LAUNCH(k_apply_steps_hist<true>, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)h,
-                (const int*)h + n, n, direction, (const int*)c->d_next_cand,
-                (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
-                (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta, pp);
-    } else {
-      GZ_LAUNCH(k_apply_steps_hist<false>, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)h,
-                (const int*)h + n, n, direction, (const int*)c->d_next_cand,
-                (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
-                (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta, pp);
-    }
+    GZ_LAUNCH(k_apply_steps_hist, dim3(std::min(gz_div_up(n, 4), kStepHistGrid)), dim3(256), c->stream, (const int*)h,
+              (const int*)h + n, n, direction, (const int*)c->d_next_cand,
+              (const unsigned char*)c->d_out_idx, (const short*)c->d_orig, (short*)c->d_cand,
+              (const int*)c->d_q, (const int*)c->d_jq, sg, c->d_step_delta, patch ? d_blocks : (int*)nullptr);
     // the staging buffer is free again behind THIS kernel (the only reader): marked before anything can fail, so
     // that no path returns with the kernel still reading a buffer the next stage_reserve hands out
     TRY(stage_sent(c, &c->stage_main, c->stream));
@@ -354,6 +346,16 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
     GZ_LAUNCH(k_steps_hist_sum, dim3(1), dim3(256), c->stream, c->d_step_delta, (int*)c->h_step_delta);
     KCHK(c);
     c->have_step_delta = true;
+    c->step_delta_event = false;
+    if (patch) {
+      // gz_steps_histogram_delta waits for the sums, not for the stream: the patches run while the host reads them
+      if (!c->ev_steps) HIPCHK(c, pool_event_create(&c->ev_steps));
+      HIPCHK(c, hipEventRecord(c->ev_steps, c->stream));
+      c->step_delta_event = true;
+      GZ_LAUNCH((k_reconstruct_listed<false>), dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), c->stream, (const int*)d_blocks, n,
+                (const int16_t*)c->d_cand, c->nb, patch_planes(c, true));
+      KCHK(c);
+    }
     return GZ_OK;
   }
   c->lin_is_cand = false;
@@ -375,7 +377,8 @@ int gz_steps_histogram_delta(gz_ctx* c, int32_t* ac_delta) {
     return GZ_E_STATE;
   }
   // k_steps_hist_sum has written the sums into the context's page-locked buffer
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->step_delta_event) HIPCHK(c, hipEventSynchronize(c->ev_steps));
+  else HIPCHK(c, hipStreamSynchronize(c->stream));
   memcpy(ac_delta, c->h_step_delta, sizeof(int32_t) * 768);
   return GZ_OK;
 }
@@ -414,7 +417,7 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
   }
   GZ_LAUNCH(k_apply_coeff_edits, dim3(gz_div_up(n, 256)), dim3(256), c->stream, k_pos, k_val, n, c->d_cand);
   if (patch_wanted(c, n)) {   // the edited block positions' pixels, behind the edits (one wavefront per edit)
-    GZ_LAUNCH(k_reconstruct_edited, dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), c->stream, k_pos, n,
+    GZ_LAUNCH((k_reconstruct_listed<true>), dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), c->stream, k_pos, n,
               (const int16_t*)c->d_cand, c->nb, patch_planes(c, true));
   }
   KCHK(c);

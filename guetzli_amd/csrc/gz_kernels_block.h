@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_reconstruct(
 // blocks changed (processor.cc:704-736), and a block position's pixels depend on its own three
 // coefficient blocks only (4:4:4): the linear planes of the previous candidate stay where they are
 // and only the changed positions are transformed again -- by the kernels that change them
-// (k_apply_steps_hist) or right behind them (k_reconstruct_edited).  The arithmetic is
+// (k_reconstruct_listed behind k_apply_steps_hist / k_apply_coeff_edits).  The arithmetic is
 // k_reconstruct's, statement for statement; what the reference does per changed block in
 // OutputImageComponent::SetCoeffBlock -> UpdatePixelsForBlock (output_image.cc:123-132,146-160).
 struct PatchPlanes {
@@ -304,10 +304,11 @@ GZ_DEVFN void wave_reconstruct_block(const short* blk3, short* tr, short* col, i
   }
 }
 
-// The block positions of a list of coefficient positions (gz_apply_coeff_edits: pos[i] indexes
-// [3][nb][64]) transformed again, one wavefront per entry; an entry whose position is its
-// predecessor's is skipped, the other repetitions store the same values twice.
-__global__ __launch_bounds__(256) void k_reconstruct_edited(const int* __restrict__ pos, int n,
+// The block positions of a list transformed again, one wavefront per entry.  POS: the entries are coefficient
+// positions (gz_apply_coeff_edits: pos[i] indexes [3][nb][64]), else block positions (gz_apply_candidate_steps'
+// blocks); an entry whose block position is its predecessor's is skipped, other repetitions store the same values twice.
+template <bool POS>
+__global__ __launch_bounds__(256) void k_reconstruct_listed(const int* __restrict__ pos, int n,
                                                             const int16_t* __restrict__ coeffs, int nb,
                                                             PatchPlanes pp) {
   __shared__ __attribute__((aligned(16))) short s_blk[kBlocksPerWG][3 * 64];
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(256) void k_reconstruct_edited(const int* __restric
   __shared__ __attribute__((aligned(16))) short s_col[kBlocksPerWG][3 * 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * kBlocksPerWG + wave;
-  const int b = i < n ? (pos[i] >> 6) % nb : 0;
-  const bool live = i < n && !(i > 0 && (pos[i - 1] >> 6) % nb == b);
+  const int b = i < n ? (POS ? (pos[i] >> 6) % nb : pos[i]) : 0;
+  const bool live = i < n && !(i > 0 && (POS ? (pos[i - 1] >> 6) % nb : pos[i - 1]) == b);
 #pragma unroll
   for (int c = 0; c < 3; ++c) s_blk[wave][c * 64 + lane] = coeffs[((size_t)c * nb + b) * 64 + lane];
   GZ_WAVE_SYNC();

@@ -368,10 +368,10 @@ GZ_DEVFN void steps_count_symbols(const short* blk3, const int* __restrict__ jq,
 // workgroup share nothing but that histogram, so they synchronise only around it.
 constexpr int kStepDeltaCopies = 32;
 constexpr int kStepHistGrid = 2048;   // workgroups at most (1024 / 16 copies: 7 ms of a 4K encode waiting for the kernel, 2048 / 32: 6, 4096 / 64: 9.5)
-// PATCH (4:4:4 frames): the touched block positions' pixels of the candidate's linear planes are transformed again
-// while their coefficients are in LDS (wave_reconstruct_block: the Compare behind these steps then starts at
-// its second kernel); all three components are loaded for it whatever the mask.
-template <bool PATCH>
+// list_out (optional): the entries' blocks again, in device memory -- for k_reconstruct_listed behind this kernel,
+// which transforms the touched block positions of the candidate's linear planes again while the host looks at the
+// statistics.  (The same work inside this kernel's wavefronts, the coefficients being in LDS anyway, made the launch
+// the host waits for 44 -> 62 us at 4K: profiles/r06_chain_experiments.log section 14.)
 __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict__ blocks,
                                                           const int* __restrict__ counts, int n,
                                                           int direction, const int* __restrict__ next_cand,
@@ -380,9 +380,8 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
                                                           short* __restrict__ cand,
                                                           const int* __restrict__ q,
                                                           const int* __restrict__ jq, StepGeom sg,
-                                                          unsigned* __restrict__ delta, PatchPlanes pp) {
-  __shared__ __attribute__((aligned(16))) short s_blk[4][3 * 64];
-  __shared__ __attribute__((aligned(16))) short s_patch[PATCH ? 4 : 1][PATCH ? 2 * 3 * 64 : 8];
+                                                          unsigned* __restrict__ delta, int* __restrict__ list_out) {
+  __shared__ short s_blk[4][3 * 64];
   __shared__ unsigned s_delta[3 * 256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = threadIdx.x; k < 3 * 256; k += 256) s_delta[k] = 0u;
@@ -401,12 +400,13 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
       const bool lv = it + lane < per && i2 < n;
       pre_b = blocks[lv ? i2 : n - 1];
       pre_c = lv ? counts[i2] : 0;
+      if (list_out && lv) list_out[i2] = pre_b;
     }
     const bool live = base + it < n;
     const int b = __shfl(pre_b, it & 63), cnt = __shfl(pre_c, it & 63), nx = next_cand[b];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      if (PATCH || ((sg.comp_mask >> c) & 1)) s_blk[wave][c * 64 + lane] = cand[((size_t)sg.coff[c] + b) * 64 + lane];
+      if ((sg.comp_mask >> c) & 1) s_blk[wave][c * 64 + lane] = cand[((size_t)sg.coff[c] + b) * 64 + lane];
     GZ_WAVE_SYNC();
     steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 0xffffffffu, s_delta);
     GZ_WAVE_SYNC();
@@ -425,7 +425,6 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
       for (int c = 0; c < 3; ++c)
         if ((sg.comp_mask >> c) & 1) cand[((size_t)sg.coff[c] + b) * 64 + lane] = s_blk[wave][c * 64 + lane];
     }
-    if (PATCH) wave_reconstruct_block(s_blk[wave], s_patch[wave], s_patch[wave] + 3 * 64, lane, b, live, pp);
     GZ_WAVE_SYNC();   // (the block's copy is overwritten by the wavefront's next block)
   }
   __syncthreads();

@@ -407,45 +407,16 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       if ((sg.comp_mask >> c) & 1) s_blk[wave][c * 64 + lane] = cand[((size_t)sg.coff[c] + b) * 64 + lane];
-    // the position's original coefficients, lane = coefficient, and every component's sum_of_hf (processor.cc:722-729)
-    // as a sum over the wavefront: a step on coefficient 1 or 8 otherwise has ONE lane read 61 coefficients one
-    // after the other while its wavefront waits (step_is_precious, which k_apply_steps keeps)
-    int ov[3], hf[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      ov[c] = 0; hf[c] = 0;
-      if ((sg.comp_mask >> c) & 1) {   // (uniform)
-        ov[c] = orig[((size_t)sg.coff[c] + b) * 64 + lane];
-        const bool counted = lane >= 3 && !((lane & 7) < 3 && lane < 3 * 8);
-        hf[c] = wave_sum(counted ? (ov[c] < 0 ? -ov[c] : ov[c]) : 0);
-      }
-    }
     GZ_WAVE_SYNC();
     steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 0xffffffffu, s_delta);
     GZ_WAVE_SYNC();
-#ifdef GZ_EMU
-    const int jend = 192;   // (the emulation's barrier is a yield like the shuffles': the same number of them for every thread)
-#else
-    const int jend = cnt;   // (the wavefront's: every lane takes every round)
-#endif
-    for (int j0 = 0; j0 < jend; j0 += 64) {
-      const int j = j0 + lane;
-      const bool act = j < cnt;
+    for (int j = lane; j < cnt; j += 64) {
       const int p = direction > 0 ? nx + j : nx - 1 - j;
-      const int idx = act ? cand_idx[(size_t)b * 192 + p] : 0;
+      const int idx = cand_idx[(size_t)b * 192 + p];
       const int c = idx >> 6, k = idx & 63;
-      const int r0 = __shfl(ov[0], k), r1 = __shfl(ov[1], k), r2 = __shfl(ov[2], k);
-      const int raw = c == 0 ? r0 : (c == 1 ? r1 : r2);
-      const int hfc = c == 0 ? hf[0] : (c == 1 ? hf[1] : hf[2]);
-      int newval = 0;
-      if (direction < 0) {   // Quantize(), quantize.h:24-29 (step_new_value)
-        const int quant = q[c * 64 + k];
-        const int r = raw % quant;
-        const int delta = 2 * r > quant ? quant - r : ((-2) * r > quant ? -quant - r : -r);
-        newval = (short)(raw + (int)(short)delta);
-      }
-      const bool precious = (k == 1 || k == 8) && (raw < 0 ? -raw : raw) >= (hfc < 60 ? 4 : 8);
-      if (act && !(newval == 0 && precious)) s_blk[wave][c * 64 + k] = (short)newval;
+      const short* ob = orig + ((size_t)sg.coff[c] + b) * 64;
+      const int newval = step_new_value(direction, ob, k, q[c * 64 + k]);
+      if (!(newval == 0 && step_is_precious(ob, k))) s_blk[wave][c * 64 + k] = (short)newval;
     }
     GZ_WAVE_SYNC();
     steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 1u, s_delta);

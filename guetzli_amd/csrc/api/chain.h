@@ -594,7 +594,7 @@ int enqueue_compare(gz_ctx* c, bool want_block_max, bool want_distmap = false, b
     ++g_compares_patched;
   } else {
     TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
-    c->lin_is_cand = c->cfac == 1 && c->cfg.patch_reconstruct != 0;
+    c->lin_is_cand = c->cfac == 1 && c->cfg.patch_reconstruct != 0 && (c->nb >= 8192 || c->cfg.patch_reconstruct == 2);
   }
   TRY(stage_opsin(c));
   TRY(stage_separate(c, &c->pi1, !single_stream(c)));

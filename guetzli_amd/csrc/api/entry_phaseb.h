@@ -268,8 +268,11 @@ int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
 
 // Does the call that changes n block positions of the candidate keep its linear planes current (transforming those
 // positions again), or leave them to the next Compare's full reconstruction?  (Decides, and drops the planes' claim.)
+// (Below half a megapixel a full reconstruction costs what a patch launch costs, and an iteration is made of launches:
+// such images keep it, unless the tests' checking mode asks for patches at every size.)
 static bool patch_wanted(gz_ctx* c, int n) {
-  const bool patch = c->cfg.patch_reconstruct != 0 && c->lin_is_cand && c->cfac == 1 && (long)n * 2 <= (long)c->nb;
+  const bool patch = c->cfg.patch_reconstruct != 0 && c->lin_is_cand && c->cfac == 1 && (long)n * 2 <= (long)c->nb &&
+                     (c->nb >= 8192 || c->cfg.patch_reconstruct == 2);
   if (!patch) c->lin_is_cand = false;
   return patch;
 }

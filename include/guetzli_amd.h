@@ -87,8 +87,10 @@ typedef struct gz_config {
   int side_small;       /* GZ_SIDE_SMALL    1: side-branch blurs in Malta-sized forms (experiment, round 6) */
   int malta_pad_bytes;  /* GZ_MALTA_PAD     unused dynamic LDS per Malta workgroup (experiment, round 6) */
   int patch_reconstruct;/* GZ_PATCH_RECON   1 (default): gz_apply_candidate_steps / gz_apply_coeff_edits transform the block
-                                            positions they change again (4:4:4 frames) and the Compare behind them skips its
-                                            full reconstruction; 0: every Compare reconstructs the whole image; 2: as 1, and
+                                            positions they change again (4:4:4 frames of half a megapixel and more, while
+                                            fewer than half of the blocks change) and the Compare behind them skips its
+                                            full reconstruction; 0: every Compare reconstructs the whole image; 2: as 1 at
+                                            every image size, and
                                             every Compare checks the patched planes against a full reconstruction
                                             (GZ_E_STATE on a difference; tests).  gz_time_compare always reconstructs. */
 } gz_config;

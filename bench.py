@@ -595,7 +595,7 @@ def main():
 
     dt, (jpg, info) = timed_steps(env, step, args.steps, args.warmup)
     step_ms_1080p = list(STEP_MS)
-    dt4k = jpg4k = info4k = step_ms_4k = first_encode_4k_s = None
+    dt4k = jpg4k = info4k = step_ms_4k = first_encode_4k_s = compares_4k = None
     if not args.no_4k:
         # the process's first encode at this size, on its own like the 1080p one above: the pools grow from
         # 1080p to 4K buffers (and, in a process with PyTorch loaded, the context of the encode after it
@@ -605,8 +605,13 @@ def main():
         step4k()
         env.sync()
         first_encode_4k_s = time.perf_counter() - t0
+        cc0 = L.compare_counters()
         dt4k, (jpg4k, info4k) = timed_steps(env, step4k, args.steps, args.warmup)
         step_ms_4k = list(STEP_MS)
+        # how many of the encodes' Compares ran without their full reconstruction (gz_config.patch_reconstruct: the
+        # calls that change the candidate keep its linear planes current); `roofline` always times the whole chain
+        cc1 = L.compare_counters()
+        compares_4k = {"compares": cc1[2] - cc0[2], "without_full_reconstruction": cc1[0] - cc0[0]}
 
     # Where the tool is mostly used: <= 2 MPix.  One 1024x1024 image without a period (tests/images.mosaic), timed
     # exactly like `value` (every rank, same bracket), and -- rank 0 -- 64 of them (circular shifts) four in flight;
@@ -829,6 +834,7 @@ def main():
         out["ms_per_step_1080p"] = ms_small
         out["step_ms_1080p"] = step_ms_1080p      # rank 0's individual timed steps
         out["step_ms_4k"] = step_ms_4k
+        out["compares_4k"] = compares_4k          # (rank 0, warm-up + timed steps)
         if dt4k is not None:
             out["value_4k"] = head[0]
             out["ms_per_step_4k"] = head[1]

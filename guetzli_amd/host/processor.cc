@@ -1496,10 +1496,11 @@ bool Encoder::EvaluateCandidate(MaskSearch* msp, Iteration* itp, Stopwatch* sw) 
   // (with =1 / --verbose every candidate takes the early-scan path instead).
   const bool verify_late = verify_ && verify_level_ >= 2 && !stats_->debug_output && !stats_->debug_output_file;
   const bool every_size = (stats_->debug_output || stats_->debug_output_file || verify_) && !verify_late;
-  if (!PrepareHead(quant_, ms.dc_histo, ms.ac_histo)) return false;
   // the entropy coder goes to its own stream before anything else is enqueued: it runs beside
-  // the evaluation, not behind the host work below
-  if (every_size && !ScanBegin()) return false;
+  // the evaluation, not behind the host work below.  Without it the head is built (15 us of Huffman codes) AFTER
+  // the next order's launches: up to 1080p the device finishes an evaluation before the host has enqueued what
+  // follows it, and whatever the host does in between is time the device idles.
+  if (every_size && (!PrepareHead(quant_, ms.dc_histo, ms.ac_histo) || !ScanBegin())) return false;
   Stopwatch aw;
   {
     // the next iteration of this direction, radius 1, if it comes to that (processor.cc:
@@ -1513,6 +1514,7 @@ bool Encoder::EvaluateCandidate(MaskSearch* msp, Iteration* itp, Stopwatch* sw) 
     ms.ahead = direction;
   }
   t_ahead_begin_ += aw.lap();
+  if (!every_size && !PrepareHead(quant_, ms.dc_histo, ms.ac_histo)) return false;
   if (every_size) {
     if (!SerializeEnd(quant_, &jpg_size)) return false;
     Log("Iter %2d: %s(%d) %s Coeffs[%d/%zd] Blocks[%zd/%d/%d] ValThres[%.4f] Out[%7zd] "

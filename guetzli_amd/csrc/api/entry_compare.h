@@ -206,7 +206,7 @@ int gz_compare_enqueue(gz_ctx* c, int iters) {
   DeviceScope ds_(c);
   if (!c || iters < 0) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
-  for (int i = 0; i < iters; ++i) TRY(enqueue_compare(c, true));
+  for (int i = 0; i < iters; ++i) TRY(enqueue_compare(c, true, false, true));   // (always the whole chain, as gz_time_compare)
   return GZ_OK;
 }
 

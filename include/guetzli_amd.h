@@ -90,9 +90,9 @@ typedef struct gz_config {
                                             positions they change again (4:4:4 frames of half a megapixel and more, while
                                             fewer than half of the blocks change) and the Compare behind them skips its
                                             full reconstruction; 0: every Compare reconstructs the whole image; 2: as 1 at
-                                            every image size, and
-                                            every Compare checks the patched planes against a full reconstruction
-                                            (GZ_E_STATE on a difference; tests).  gz_time_compare always reconstructs. */
+                                            every image size, and every such Compare checks the patched planes against a
+                                            full reconstruction first (GZ_E_STATE on a difference; tests).
+                                            gz_time_compare / gz_compare_enqueue always run the whole chain. */
 } gz_config;
 int gz_config_from_environment(gz_config* out);
 int gz_get_config(const gz_ctx* ctx, gz_config* out);
@@ -233,7 +233,8 @@ int gz_compare_end(gz_ctx* ctx, float* distance);
 /* Enqueue `iters` back-to-back Compare evaluations of the current candidate on the
  * context's stream without any host transfer or synchronisation (for HIP-event timing
  * of the resident-in-HBM rate).  The distance of the last one is readable with
- * gz_last_distance after gz_synchronize. */
+ * gz_last_distance after gz_synchronize.  Every one of them is the whole chain, reconstruction included
+ * (gz_config.patch_reconstruct does not apply: nothing changes the candidate between them). */
 int gz_compare_enqueue(gz_ctx* ctx, int iters);
 int gz_last_distance(gz_ctx* ctx, float* distance);
 /* Convenience: time `iters` enqueued Compare evaluations with hipEvents recorded on the

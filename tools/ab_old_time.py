@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Encode times with the package under PKG (default: this tree's) -- A/B of two builds on one box.
+Usage: ab_old_time.py PKGDIR W H REPS   (PKGDIR holds guetzli_amd/)"""
+import sys, os, time
+pkg, w, h, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.abspath(pkg))
+import guetzli_amd, images
+rgb = images.tiled(w, h)
+ts = []
+for _ in range(reps):
+    t0 = time.perf_counter(); jpg, info = guetzli_amd.process(rgb, quality=95.0); ts.append(time.perf_counter() - t0)
+ts = sorted(ts[1:])
+it = info["counters"]["number of iterations"]
+print(f"{os.path.abspath(pkg)}: {w}x{h} median {ts[len(ts)//2]*1e3:.2f} ms, min {ts[0]*1e3:.2f}; {it} iterations -> {ts[len(ts)//2]*1e6/it:.1f} us per iteration ({guetzli_amd.__file__})")

@@ -36,7 +36,9 @@ Also on the JSON line:
   roofline     -- HBM roofline of the butteraugli evaluation (the second half of the
                   metric) on the headline image: SURVEY.md 8(d) algorithmic bytes of one Compare
                   (494 B/px) / average duration of one Compare chain measured with HIP events on
-                  the stream the kernels run on (gz_time_compare), same process, same image.
+                  the stream the kernels run on (gz_time_compare), same process, same image.  ALWAYS the whole
+                  chain, its reconstruction included -- although nine of ten Compares of an encode run without it
+                  (gz_config.patch_reconstruct; `compares_4k` counts them over the timed 4K encodes).
                   `traffic` = HBM bytes of one chain from the rocprofv3 FETCH_SIZE /
                   WRITE_SIZE passes committed under profiles/ (the counters cannot be read
                   from inside this process; `traffic_head` = the commit they were taken at);

@@ -289,6 +289,51 @@ def case_global_order(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
     oc.close()
 
 
+def case_patched_candidate_planes(L, w, h, x0=0, y0=0, qs=3, target=0.971769, rounds=3):
+    """gz_config.patch_reconstruct through the C ABI alone: after bulk steps on a minority of the block positions
+    (gz_apply_candidate_steps) and single-coefficient edits elsewhere (gz_apply_coeff_edits), a Compare that relies on
+    the patched linear planes (and, in mode 2, checks them against a full reconstruction itself) gives the distance,
+    distance map and per-block maxima, bit for bit, of the same coefficients put in place as a whole (gz_set_coeffs:
+    full reconstruction).  Ragged sizes patch partial blocks at the right / bottom edge.  A change of more than half
+    of the positions, or a whole-image writer in between, drops the patches' claim."""
+    rng = np.random.default_rng(RNG_SEED + 5 * w + h)
+    rgb = images.crop(w, h, x0, y0) if max(w, h) <= 444 else images.tiled(w, h)
+    q = np.full((3, 64), qs, np.int32)
+    with L.context(rgb, target) as ctx:
+        ctx.set_config(patch_reconstruct=2)
+        ctx.encode_rgb()
+        ctx.quantize(q)
+        off, idx, err = ctx.block_zeroing_orders()
+        nb = ctx.nb
+        cnt = np.diff(off)
+        ctx.order_reset()
+        ctx.compare()                                    # the full reconstruction: the planes are the candidate's
+        next_cand = np.zeros(nb, np.int32)
+        for r in range(rounds):
+            ctx.order_build_auto(1, 1, 1.0, True, next_cand)     # (uploads next_cand)
+            ctx.jpeg_histograms(q)                               # (the steps' statistics path)
+            some = rng.random(nb) < (0.3 if r < rounds - 1 else 0.8)
+            counts = np.where(some, np.minimum(cnt - next_cand, 1 + rng.integers(0, 3, nb)), 0).astype(np.int32)
+            sel = np.flatnonzero(counts > 0).astype(np.int32)
+            before = L.compare_counters()
+            ctx.apply_candidate_steps(1, sel, counts[sel])
+            ctx.steps_histogram_delta()
+            next_cand = next_cand + counts
+            pos = rng.choice(3 * nb * 64, size=min(40, nb // 4), replace=False).astype(np.int32)   # (fewer than half of the positions)
+            ctx.apply_coeff_edits(pos, rng.integers(-40, 40, pos.size).astype(np.int16))
+            got = ctx.compare()
+            patched, checked, compares = (a - b for a, b in zip(L.compare_counters(), before))
+            # (the last round touches most positions: no patches, the Compare reconstructs)
+            assert (patched, checked, compares) == ((1, 1, 1) if 2 * sel.size <= nb else (0, 0, 1)), (patched, checked, sel.size, nb)
+            co = ctx.get_coeffs()
+            ctx.set_coeffs(co)
+            before = L.compare_counters()
+            exp = ctx.compare()
+            assert L.compare_counters()[0] == before[0]
+            for g, e, what in zip(got, exp, ("distance", "distance map", "block maxima")):
+                assert_bits_equal(np.asarray(g, np.float32), np.asarray(e, np.float32), f"patched {what}, round {r}")
+
+
 ZIGZAG_NATURAL = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
                   12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,

@@ -622,6 +622,11 @@ def test_jpeg_entropy420(L, wh):
     pc.case_jpeg_entropy420(L, guetzli_amd.load_host(), *wh, ref)
 
 
+@pytest.mark.parametrize("wh", [(444, 258), (1021, 515), (1920, 1080)])
+def test_patched_candidate_planes(L, wh):
+    pc.case_patched_candidate_planes(L, *wh)
+
+
 def test_global_order420(L):
     pc.case_global_order420(L, 130, 75, oracle, x0=100, y0=60)
 

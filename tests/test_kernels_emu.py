@@ -188,5 +188,10 @@ def test_jpeg_entropy420(L, host_emu, wh):
     pc.case_jpeg_entropy420(L, host_emu, *wh, ref, x0=100, y0=50)
 
 
+@pytest.mark.parametrize("wh", [(40, 32), (45, 35)])
+def test_patched_candidate_planes(L, wh):
+    pc.case_patched_candidate_planes(L, *wh, x0=100, y0=60)
+
+
 def test_global_order420(L):
     pc.case_global_order420(L, 48, 40, oracle, x0=100, y0=60)

@@ -417,6 +417,7 @@ struct gz_ctx {
   unsigned* d_order_counters = nullptr;                           // [2]
   unsigned* d_order_groups = nullptr;                             // [2 * ceil(nb / kOrderGroup)]: sum of n_b, blocks with n_b > 0
   int* d_next_cand = nullptr; float* d_weight = nullptr; float* d_max_err = nullptr;   // [nb]
+  bool adv_pending = false; float adv_threshold = 0.0f; int adv_direction = 0;         // gz_order_advance's update, still due
   bool have_search = false;
   unsigned char* d_wflag = nullptr;                               // [nb]
   int* d_edit_pos = nullptr; short* d_edit_val = nullptr; size_t edit_cap = 0;

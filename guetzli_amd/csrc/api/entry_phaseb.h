@@ -29,6 +29,17 @@ static int ensure_order_capacity(gz_ctx* c, size_t n) {
   return GZ_OK;
 }
 
+// gz_order_advance's update of max_block_error, if it is still due (it normally rides on the next order's
+// k_weights_gather): made now, for whoever reads or replaces d_max_err / d_weight some other way.
+static int flush_order_advance(gz_ctx* c) {
+  if (!c->adv_pending) return GZ_OK;
+  c->adv_pending = false;
+  GZ_LAUNCH(k_order_advance, dim3(gz_div_up(c->sg_n, 256)), dim3(256), c->stream, c->d_max_err,
+            (const float*)c->d_weight, c->adv_threshold, c->adv_direction, c->sg_n);
+  KCHK(c);
+  return GZ_OK;
+}
+
 static int ensure_order_block_arrays(gz_ctx* c) {
   if (c->d_order_nb) return GZ_OK;
   const int nb = c->nb;
@@ -101,6 +112,7 @@ int gz_order_build(gz_ctx* c, int direction, const int32_t* next_cand,
   c->results_in_desc = false;
   const int nb = c->sg_n;
   TRY(ensure_order_block_arrays(c));
+  c->adv_pending = false;   // (the caller's own max_block_error and weights replace the device's)
   HIPCHK(c, hipMemcpyAsync(c->d_next_cand, next_cand, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_weight, block_weight, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_max_err, max_block_error, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
@@ -111,6 +123,7 @@ int gz_order_reset(gz_ctx* c) {
   DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   TRY(ensure_order_block_arrays(c));
+  c->adv_pending = false;
   HIPCHK(c, hipMemsetAsync(c->d_max_err, 0, sizeof(float) * c->nb, c->stream));
   return GZ_OK;
 }
@@ -169,7 +182,8 @@ static int order_auto_enqueue(gz_ctx* c, int direction, int max_block_dist, doub
   GZ_LAUNCH(k_weights_gather, dim3(gz_div_up(nb, kOrderGroup)), dim3(kOrderGroup), c->stream,
             (const unsigned char*)c->d_wflag, bw, bh, direction, max_block_dist, c->d_weight,
             (const int*)c->d_out_cnt, (const int*)c->d_next_cand, c->d_order_nb, c->d_order_groups,
-            (unsigned*)c->d_order_off);
+            (unsigned*)c->d_order_off, c->d_max_err, c->adv_threshold, c->adv_pending ? c->adv_direction : 0);
+  c->adv_pending = false;   // (gz_order_advance's update was made by this launch, with the weights it replaced)
   KCHK(c);
   return GZ_OK;
 }
@@ -260,9 +274,13 @@ int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
   DeviceScope ds_(c);
   if (!c || (direction != 1 && direction != -1)) return GZ_E_ARG;
   if (!c->d_weight) { c->err = "gz_order_build_auto must precede gz_order_advance"; return GZ_E_STATE; }
-  GZ_LAUNCH(k_order_advance, dim3(gz_div_up(c->sg_n, 256)), dim3(256), c->stream, c->d_max_err,
-            (const float*)c->d_weight, val_threshold, direction, c->sg_n);
-  KCHK(c);
+  // max_block_error[i] += block_weight[i] * val_threshold * direction -- due, not launched: the next order's
+  // k_weights_gather makes the update with the weights it is about to replace (nothing reads max_block_error before
+  // it; whoever else touches it or the weights calls flush_order_advance first)
+  TRY(flush_order_advance(c));   // (two advances in a row: the first is made now)
+  c->adv_pending = true;
+  c->adv_threshold = val_threshold;
+  c->adv_direction = direction;
   return GZ_OK;
 }
 

@@ -37,6 +37,7 @@ int gz_block_zeroing_orders_masked(gz_ctx* c, int comp_mask, int lookahead, int 
   TRY(ensure_block_mask(c));
   c->order_pending = false;   // a new search grid: a pending order of the old one is void
   c->results_in_desc = false;
+  TRY(flush_order_advance(c));   // (an update of max_block_error that is still due belongs to the old grid)
   const int nb = c->nb;   // capacity of the per-block arrays: the luma grid
   const int gn = mode == 2 ? c->nbc : c->nb;
   c->sg_w = mode == 2 ? c->cbw : c->bw;

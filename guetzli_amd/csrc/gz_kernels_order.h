@@ -228,6 +228,9 @@ __global__ __launch_bounds__(256) void k_weights_flag(const float* __restrict__ 
 
 // The entry count of the block and the group sums (k_order_sizes) come out of the same pass when
 // cnt is given.
+// adv_direction != 0: the previous iteration's max_block_error update (k_order_advance, below) is still due and is
+// made here, with the weight this kernel is about to replace -- one launch less between an iteration's last step
+// and its evaluation.
 __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __restrict__ flag,
                                                         int bw, int bh, int direction, int r,
                                                         float* __restrict__ weight,
@@ -235,11 +238,14 @@ __global__ __launch_bounds__(256) void k_weights_gather(const unsigned char* __r
                                                         const int* __restrict__ next_cand,
                                                         unsigned* __restrict__ n_b,
                                                         unsigned* __restrict__ group_sums,
-                                                        unsigned* __restrict__ blk_off) {
+                                                        unsigned* __restrict__ blk_off,
+                                                        float* __restrict__ max_err, float adv_threshold,
+                                                        int adv_direction) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < bw * bh;
   float w = 0.0f;
   if (valid) {
+    if (adv_direction) max_err[b] += weight[b] * adv_threshold * adv_direction;
     if (direction > 0) {
       w = flag[b] ? 1.0f : 0.0f;
     } else {

@@ -25,7 +25,7 @@ _I = C.c_int
 class GzConfig(C.Structure):
     """gz_config of include/guetzli_amd.h."""
     _fields_ = [("struct_size", _I), ("blur_packed", _I), ("tile_rows", _I), ("single_stream", _I),
-                ("store_distmap", _I), ("side_small", _I), ("malta_pad_bytes", _I), ("patch_reconstruct", _I)]
+                ("store_distmap", _I), ("side_small", _I), ("malta_pad_bytes", _I), ("patch_reconstruct", _I), ("opsin_ahead", _I)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -159,11 +159,12 @@ class Library:
         self.check(self.lib.gz_config_from_environment(C.byref(cfg)))
         return cfg
 
-    def compare_counters(self):
-        """(Compares that skipped the full reconstruction, of them checked against one, Compares in all) since load."""
-        n = np.zeros(3, np.uint64)
+    def compare_counters(self, all=False):
+        """(Compares that skipped the full reconstruction, of them checked against one, Compares in all) since load;
+        all=True: + (Compares that found their opsin image in place, of them checked)."""
+        n = np.zeros(5, np.uint64)
         self.check(self.lib.gz_compare_counters(_ptr(n)))
-        return int(n[0]), int(n[1]), int(n[2])
+        return tuple(int(x) for x in (n if all else n[:3]))
 
     # ---- context-free probes ----
     def idct_blocks(self, blocks, device=0):

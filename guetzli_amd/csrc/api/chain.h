@@ -117,9 +117,10 @@ int blur_v_pair(gz_ctx* c, const CPlanePack<2>& src, const PostStore<2>& post, c
 
 // BM = true (the chain's last blur): the Post functor's results are also reduced to the per-block
 // maxima and the image maximum; that kernel keeps its results in registers (always 32-row tiles).
+// bm.tiles + n_tiles: the listed tiles only (tile ids of the grid this function would launch).
 template <int R, int NC, class Src, class Post, bool BM = false>
 int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurCfg& cfg,
-           BlockMaxOut bm = BlockMaxOut{nullptr, nullptr, 0}) {
+           BlockMaxOut bm = BlockMaxOut{nullptr, nullptr, 0, nullptr}, int n_tiles = 0) {
   if (cfg.r != R) { c->err = "blur radius mismatch"; return GZ_E_STATE; }
   const Taps<R> tp = taps_of<R>(cfg);
   const BorderScale bx = cfg.bx, by = cfg.by;
@@ -128,10 +129,12 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   // nothing at 1080p, +3 % at 2560 x 1440: profiles/r05_chain_experiments.log, section 8)
   if (BM ? small_tiles(c) && (size_t)c->w * c->h < 1500000 : small_tiles(c)) {
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
+    if (bm.tiles) grid = dim3(n_tiles);
     GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w,
               h, pitch, tp, bx, by, bm);
   } else {
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kTileRows));
+    if (bm.tiles) grid = dim3(n_tiles);
     GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, kTileRows>), grid, dim3(256), c->stream, src, post, w,
               h, pitch, tp, bx, by, bm);
   }
@@ -206,14 +209,16 @@ int setup_blur_cfg(gz_ctx* c, BlurCfg* cfg, float sigma, float border_ratio) {
 
 // --------------------------------------------------------------- pipeline stages ------
 // OpsinDynamicsImage: lin[3] -> xyb[3]
-int stage_opsin(gz_ctx* c) {
+// tiles (optional): only the listed tiles of the launch's grid (opsin_tile_rows() high), n_tiles of them.
+int stage_opsin(gz_ctx* c, const int* tiles = nullptr, int n_tiles = 0) {
   SrcPack<SrcPlain, 3> s;
   for (int i = 0; i < 3; ++i) s.s[i].p = c->lin[i];
   PostOpsin post;
   for (int i = 0; i < 3; ++i) { post.lin[i] = c->lin[i]; post.xyb[i] = c->xyb[i]; }
-  TRY((blur2d<2, 3, SrcPlain, PostOpsin>(c, s, post, c->blur[B_OPSIN])));
+  TRY((blur2d<2, 3, SrcPlain, PostOpsin>(c, s, post, c->blur[B_OPSIN], BlockMaxOut{nullptr, nullptr, 0, tiles}, n_tiles)));
   return GZ_OK;
 }
+static int opsin_tile_rows(const gz_ctx* c) { return small_tiles(c) ? kSmallTileRows : kTileRows; }
 
 // SeparateFrequencies: xyb[3] -> Psycho planes
 // The LF blur (radius 16) runs as X / Y (two planes, PostLFxy) and B (one plane, PostLFb: its
@@ -484,7 +489,7 @@ int stage_diffmap(gz_ctx* c, const Psycho& p0, const Psycho& p1, bool want_block
     SrcPack<SrcPlain, 1> s; s.s[0].p = c->dsq;
     PostDiffmapMix post; post.d = c->dsq; post.out = want_distmap ? c->distmap : nullptr;
     if (!max_cleared && !clear_in_combine) HIPCHK(c, hipMemsetAsync(c->d_max_bits, 0, sizeof(unsigned), c->stream));
-    BlockMaxOut bm{want_block_max ? c->d_block_max : nullptr, c->d_max_bits, c->bw};
+    BlockMaxOut bm{want_block_max ? c->d_block_max : nullptr, c->d_max_bits, c->bw, nullptr};
     TRY((blur2d<3, 1, SrcPlain, PostDiffmapMix, true>(c, s, post, c->blur[B_FINAL], bm)));
   }
   return GZ_OK;
@@ -559,6 +564,7 @@ int stage_reconstruct(gz_ctx* c, const int16_t* d_coeffs, float* lin0, uint8_t* 
 // a fifth of a 4K image's blocks change per iteration).  force_full: gz_time_compare, whose repetitions change
 // nothing and must not measure a chain without its first kernel.
 static std::atomic<unsigned long long> g_compares{0}, g_compares_patched{0}, g_patch_checks{0};   // gz_compare_counters
+static std::atomic<unsigned long long> g_compares_ahead{0}, g_ahead_checks{0};
 static int check_patched_planes(gz_ctx* c) {   // (gz_config.patch_reconstruct == 2)
   float* full = nullptr;
   unsigned* d_bad = nullptr;
@@ -584,6 +590,35 @@ static int check_patched_planes(gz_ctx* c) {   // (gz_config.patch_reconstruct =
   return GZ_OK;
 }
 
+// (gz_config.patch_reconstruct == 2) xyb[] as the calls kept it against the opsin blur of lin[] as a whole.
+static int check_opsin_ahead(gz_ctx* c) {
+  float* kept = nullptr;
+  unsigned* d_bad = nullptr;
+  HIPCHK(c, pool_malloc((void**)&kept, sizeof(float) * c->plane * 3));
+  HIPCHK(c, pool_malloc((void**)&d_bad, sizeof(unsigned)));
+  int rc = GZ_OK;
+  unsigned bad = 0;
+  do {
+    if (hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream) != hipSuccess) { rc = GZ_E_HIP; break; }
+    for (int i = 0; i < 3 && rc == GZ_OK; ++i)
+      if (hipMemcpyAsync(kept + (size_t)i * c->plane, c->xyb[i], sizeof(float) * c->plane, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = GZ_E_HIP;
+    if (rc != GZ_OK) break;
+    rc = stage_opsin(c);
+    if (rc != GZ_OK) break;
+    for (int i = 0; i < 3; ++i)
+      GZ_LAUNCH(k_count_differing_words, dim3(1024), dim3(256), c->stream, (const unsigned*)c->xyb[i],
+                (const unsigned*)(kept + (size_t)i * c->plane), (size_t)c->plane, d_bad);
+    if (hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { rc = GZ_E_HIP; break; }
+  } while (0);
+  (void)pool_free(kept);
+  (void)pool_free(d_bad);
+  TRY(rc);
+  ++g_ahead_checks;
+  if (bad) { c->err = "the opsin image kept ahead differs from the opsin blur of the whole planes"; return GZ_E_STATE; }
+  return GZ_OK;
+}
+
 int enqueue_compare(gz_ctx* c, bool want_block_max, bool want_distmap = false, bool force_full = false) {
   want_distmap = want_distmap || c->cfg.store_distmap != 0;   // (1: the chain as it was until round 5, A/B)
   choose_streams(c);
@@ -596,7 +631,15 @@ int enqueue_compare(gz_ctx* c, bool want_block_max, bool want_distmap = false, b
     TRY(stage_reconstruct(c, c->d_cand, c->lin[0], nullptr, c->d_max_bits));
     c->lin_is_cand = c->cfac == 1 && c->cfg.patch_reconstruct != 0 && (c->nb >= 8192 || c->cfg.patch_reconstruct == 2);
   }
-  TRY(stage_opsin(c));
+  // ... and their opsin image, when the same calls have kept that current too (xyb_is_cand; consumed here)
+  const bool ahead = patched && c->xyb_is_cand;
+  c->xyb_is_cand = false;
+  if (ahead) {
+    if (c->cfg.patch_reconstruct == 2) TRY(check_opsin_ahead(c));
+    ++g_compares_ahead;
+  } else {
+    TRY(stage_opsin(c));
+  }
   TRY(stage_separate(c, &c->pi1, !single_stream(c)));
   TRY(stage_diffmap(c, c->pi0, c->pi1, want_block_max, !patched, want_distmap, true, patched));
   return GZ_OK;
@@ -634,7 +677,7 @@ int ensure_block_mask(gz_ctx* c) {
   TRY(ensure_pip(c));
   if (!c->d_block_mask) HIPCHK(c, pool_malloc((void**)&c->d_block_mask, sizeof(float) * 3 * c->nb));
   dim3 grid(gz_div_up(c->w, 256), c->h);
-  c->lin_is_cand = false;   // (lin[] takes the original)
+  c->lin_is_cand = c->xyb_is_cand = false;   // (lin[] takes the original)
   GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, c->w, c->h, c->pitch,
             c->plane, c->d_srgb_lut, c->lin[0]);
   KCHK(c);

@@ -427,6 +427,11 @@ struct gz_ctx {
   // chain's full reconstruction, kept by the mutators that transform the block positions they change
   // (gz_apply_candidate_steps, gz_apply_coeff_edits), dropped by everything else that writes d_cand or lin[]
   bool lin_is_cand = false;
+  // ... and xyb[] the opsin image of those planes (cfg.opsin_ahead): the Compare chain's second kernel enqueued AHEAD,
+  // behind the bulk steps' patches, while the host takes its serial steps; their edits then cost the opsin tiles around
+  // the edited blocks (gz_apply_coeff_edits), and the Compare starts at its third kernel.  Consumed by that Compare.
+  bool xyb_is_cand = false;
+  std::vector<unsigned char> tile_mark;   // opsin tiles already listed (gz_apply_coeff_edits)
   std::vector<float> h_block_max;
   bool h_block_max_valid = false;
   bool compare_pending = false;

@@ -11,7 +11,7 @@ int gz_encode_rgb(gz_ctx* c, int16_t* coeffs_out) {
   if (c->cfac != 1) {   // back to 4:4:4: the candidate and the search belonged to the other frame
     set_frame(c, 1);
     c->have_cand = false;
-    c->lin_is_cand = false;
+    c->lin_is_cand = c->xyb_is_cand = false;
   }
   GZ_LAUNCH(k_encode_rgb, dim3(gz_div_up(c->nb, kBlocksPerWG)), dim3(256), c->stream, c->d_rgb,
             c->w, c->h, c->bw, c->nb, c->d_orig);
@@ -30,7 +30,7 @@ static int set_orig(gz_ctx* c, const int16_t* coeffs, int factor) {
   if (c->cfac != factor) {   // the candidate and the search belonged to the other frame
     set_frame(c, factor);
     c->have_cand = false;
-    c->lin_is_cand = false;
+    c->lin_is_cand = c->xyb_is_cand = false;
   }
   HIPCHK(c, hipMemcpyAsync(c->d_orig, coeffs, (size_t)c->nblk * 128, hipMemcpyHostToDevice,
                            c->stream));
@@ -71,7 +71,7 @@ int gz_quantize(gz_ctx* c, const int* q, int16_t* coeffs_out) {
             c->coff[2], c->nblk, c->d_q);
   KCHK(c);
   c->have_cand = true;
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   if (coeffs_out) {
     HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_cand, total * 2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -86,7 +86,7 @@ int gz_set_coeffs(gz_ctx* c, const int16_t* coeffs) {
                            c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_cand = true;
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   return GZ_OK;
 }
 
@@ -98,7 +98,7 @@ int gz_set_coeff_blocks(gz_ctx* c, const int32_t* block_index, int n, const int1
   if (n == 0) return GZ_OK;
   for (int i = 0; i < n; ++i)
     if (block_index[i] < 0 || block_index[i] >= c->nb) return GZ_E_ARG;
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   if ((size_t)n > c->blkidx_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));   // the pool hands memory on without waiting
     (void)pool_free(c->d_blkidx); (void)pool_free(c->d_blkdata);
@@ -129,7 +129,7 @@ int gz_reconstruct(gz_ctx* c, uint8_t* srgb, float* linear) {
   DeviceScope ds_(c);
   if (!c) return GZ_E_ARG;
   if (!c->have_cand) { c->err = "no candidate coefficients"; return GZ_E_STATE; }
-  if (linear) c->lin_is_cand = false;   // (rewritten as a whole: nothing to keep track of)
+  if (linear) c->lin_is_cand = c->xyb_is_cand = false;   // (rewritten as a whole: nothing to keep track of)
   TRY(stage_reconstruct(c, c->d_cand, linear ? c->lin[0] : nullptr, srgb ? c->d_srgb_out : nullptr));
   if (srgb) HIPCHK(c, hipMemcpyAsync(srgb, c->d_srgb_out, (size_t)3 * c->w * c->h, hipMemcpyDeviceToHost, c->stream));
   if (linear) for (int i = 0; i < 3; ++i) TRY(download_plane(c, c->lin[i], linear + (size_t)i * c->w * c->h));

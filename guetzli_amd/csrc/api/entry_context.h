@@ -23,6 +23,8 @@ int gz_config_from_environment(gz_config* out) {
   if (const char* e = getenv("GZ_MALTA_PAD")) c.malta_pad_bytes = std::max(0, std::min(64 << 10, atoi(e)));
   c.patch_reconstruct = 1;
   if (const char* e = getenv("GZ_PATCH_RECON")) { const int v = atoi(e); if (v >= 0 && v <= 2) c.patch_reconstruct = v; }
+  c.opsin_ahead = 1;
+  if (const char* e = getenv("GZ_OPSIN_AHEAD")) c.opsin_ahead = atoi(e) != 0;
   *out = c;
   return GZ_OK;
 }
@@ -41,7 +43,7 @@ int gz_set_config(gz_ctx* c, const gz_config* in) {
     return GZ_E_STATE;
   }
   c->cfg = *in;
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   return GZ_OK;
 }
 
@@ -263,7 +265,7 @@ int gz_set_rgb(gz_ctx* c, const uint8_t* rgb) {
   if (!c || !rgb) return GZ_E_ARG;
   HIPCHK(c, hipMemcpyAsync(c->d_rgb, rgb, (size_t)3 * c->w * c->h, hipMemcpyHostToDevice, c->stream));
   // pi0_ = SeparateFrequencies(OpsinDynamicsImage(LinearRgb(rgb)))
-  c->lin_is_cand = false;   // (lin[] takes the original)
+  c->lin_is_cand = c->xyb_is_cand = false;   // (lin[] takes the original)
   dim3 grid(gz_div_up(c->w, 256), c->h);
   GZ_LAUNCH(k_linear_from_rgb8, grid, dim3(256), c->stream, c->d_rgb, c->w, c->h, c->pitch,
             c->plane, c->d_srgb_lut, c->lin[0]);

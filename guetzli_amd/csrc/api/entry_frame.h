@@ -109,7 +109,7 @@ int gz_set_frame(gz_ctx* c, int chroma_factor) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   set_frame(c, chroma_factor);
   c->have_cand = false;
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   c->have_orig = false;   // the original coefficients on the device belonged to the other frame
   return GZ_OK;
 }
@@ -138,6 +138,7 @@ int gz_downsample(gz_ctx* c, int16_t* coeffs_out) {
   const int w = c->w, h = c->h;
   const size_t n = (size_t)w * h;
   // scratch: planes of the candidate's evaluation (nothing of it is in flight here)
+  c->xyb_is_cand = false;
   float* yuv[3] = {c->xyb[0], c->xyb[1], c->xyb[2]};
   float* tmp_s = c->tmp[0];
   float* tmp_b = c->tmp[1];
@@ -200,7 +201,7 @@ int gz_downsample(gz_ctx* c, int16_t* coeffs_out) {
   }
   set_frame(c, 2);
   c->have_cand = false;
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   c->have_distmap = false;
   if (coeffs_out)
     HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_orig, (size_t)c->nblk * 128, hipMemcpyDeviceToHost, c->stream));
@@ -215,6 +216,7 @@ int gz_downsample_planes(gz_ctx* c, const float* y, const float* u, const float*
   const int w = c->w, h = c->h;
   const size_t n = (size_t)w * h;
   const float* src[3] = {y, u, v};
+  c->xyb_is_cand = false;   // (xyb[] as scratch)
   for (int i = 0; i < 3; ++i)
     HIPCHK(c, hipMemcpyAsync(c->xyb[i], src[i], n * sizeof(float), hipMemcpyHostToDevice, c->stream));
   // output_image.cc:314-316: every component from its plane, luma included (factor 1), the
@@ -231,7 +233,7 @@ int gz_downsample_planes(gz_ctx* c, const float* y, const float* u, const float*
   }
   set_frame(c, 2);
   c->have_cand = false;
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   c->have_distmap = false;
   if (coeffs_out)
     HIPCHK(c, hipMemcpyAsync(coeffs_out, c->d_orig, (size_t)c->nblk * 128, hipMemcpyDeviceToHost, c->stream));

@@ -291,7 +291,7 @@ int gz_order_advance(gz_ctx* c, float val_threshold, int direction) {
 static bool patch_wanted(gz_ctx* c, int n) {
   const bool patch = c->cfg.patch_reconstruct != 0 && c->lin_is_cand && c->cfac == 1 && (long)n * 2 <= (long)c->nb &&
                      (c->nb >= 8192 || c->cfg.patch_reconstruct == 2);
-  if (!patch) c->lin_is_cand = false;
+  if (!patch) c->lin_is_cand = c->xyb_is_cand = false;
   return patch;
 }
 static PatchPlanes patch_planes(const gz_ctx* c, bool on) {
@@ -376,10 +376,18 @@ int gz_apply_candidate_steps(gz_ctx* c, int direction, const int32_t* blocks,
       GZ_LAUNCH((k_reconstruct_listed<false>), dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), c->stream, (const int*)d_blocks, n,
                 (const int16_t*)c->d_cand, c->nb, patch_planes(c, true));
       KCHK(c);
+      // ... and, for a context that has the device to itself, the next Compare's opsin blur of the planes as they
+      // are now: 100 us (4K) of the chain's critical path that run while the host takes its serial steps, whose
+      // edits then cost the tiles around them (gz_apply_coeff_edits).  Not in a batch: the other images use the time.
+      c->xyb_is_cand = false;
+      if (c->cfg.opsin_ahead != 0 && !single_stream_wanted(c)) {
+        TRY(stage_opsin(c));
+        c->xyb_is_cand = true;
+      }
     }
     return GZ_OK;
   }
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   HIPCHK(c, hipMemcpyAsync(d_blocks, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream));
   TRY(stage_sent(c, &c->stage_main, c->stream));
   GZ_LAUNCH(k_apply_steps, dim3(gz_div_up(n, 4)), dim3(256), c->stream, (const int*)d_blocks,
@@ -425,7 +433,9 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
     HIPCHK(c, pool_malloc((void**)&c->d_edit_val, sizeof(short) * c->edit_cap));
   }
   void* h = nullptr;
-  TRY(stage_reserve(c, &c->stage_edits, (sizeof(int) + sizeof(short)) * n, &h));
+  // (+ the list of opsin tiles around the edited blocks: at most four per edit, behind the values)
+  const size_t tiles_at = ((sizeof(int) + sizeof(short)) * (size_t)n + 15) & ~(size_t)15;
+  TRY(stage_reserve(c, &c->stage_edits, tiles_at + (direct ? sizeof(int) * 4 * (size_t)n : 0), &h));
   memcpy(h, pos, sizeof(int) * n);
   memcpy((int*)h + n, val, sizeof(short) * n);
   const int* k_pos = (const int*)h;
@@ -440,6 +450,30 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
   if (patch_wanted(c, n)) {   // the edited block positions' pixels, behind the edits (one wavefront per edit)
     GZ_LAUNCH((k_reconstruct_listed<true>), dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), c->stream, k_pos, n,
               (const int16_t*)c->d_cand, c->nb, patch_planes(c, true));
+    if (c->xyb_is_cand) {
+      // the opsin image enqueued ahead (gz_apply_candidate_steps): a pixel's value depends on the linear planes
+      // within 2 pixels of it (radius-2 blur), so the tiles that meet an edited block grown by 2 are computed again
+      // -- or the image, when the edits are many (the last iterations of a search)
+      const int th = opsin_tile_rows(c), gx = gz_div_up(c->w, T2), gy = gz_div_up(c->h, th);
+      int nt = 0;
+      int* tl = direct ? (int*)((char*)h + tiles_at) : nullptr;
+      if (tl) {
+        if (c->tile_mark.size() != (size_t)gx * gy) c->tile_mark.assign((size_t)gx * gy, 0);
+        for (int i = 0; i < n; ++i) {
+          const int b = (pos[i] >> 6) % c->nb, bx = b % c->bw, by = b / c->bw;
+          const int tx0 = std::max(0, 8 * bx - 2) / T2, tx1 = std::min(c->w - 1, 8 * bx + 9) / T2;
+          const int ty0 = std::max(0, 8 * by - 2) / th, ty1 = std::min(c->h - 1, 8 * by + 9) / th;
+          for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) {
+              unsigned char& m = c->tile_mark[(size_t)ty * gx + tx];
+              if (!m) { m = 1; tl[nt++] = ty * gx + tx; }
+            }
+        }
+        for (int i = 0; i < nt; ++i) c->tile_mark[(size_t)tl[i]] = 0;
+      }
+      if (tl && (long)nt * 4 <= (long)gx * gy) TRY(stage_opsin(c, tl, nt));
+      else TRY(stage_opsin(c));
+    }
   }
   KCHK(c);
   TRY(stage_sent(c, &c->stage_edits, c->stream));   // (the staging buffer is free again behind the kernels)

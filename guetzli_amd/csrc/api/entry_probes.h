@@ -14,6 +14,7 @@ int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, f
   BlurCfg cfg;
   TRY(setup_blur_cfg(c, &cfg, sigma, border_ratio));
   float* src = c->xyb[0];
+  c->xyb_is_cand = false;   // (xyb[] as scratch)
   TRY(upload_planes(c, in, &src, 1));
   SrcPack<SrcPlain, 1> s;
   s.s[0].p = src;
@@ -47,7 +48,7 @@ int gz_probe_blur(gz_ctx* c, const float* in, float sigma, float border_ratio, f
 int gz_probe_opsin(gz_ctx* c, const float* rgb3, float* xyb3) {
   DeviceScope ds_(c);
   if (!c || !rgb3 || !xyb3) return GZ_E_ARG;
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   TRY(upload_planes(c, rgb3, c->lin, 3));
   TRY(stage_opsin(c));
   for (int i = 0; i < 3; ++i) TRY(download_plane(c, c->xyb[i], xyb3 + (size_t)i * c->w * c->h));
@@ -59,6 +60,7 @@ int gz_probe_separate_frequencies(gz_ctx* c, const float* xyb3, float* out10) {
   DeviceScope ds_(c);
   if (!c || !xyb3 || !out10) return GZ_E_ARG;
   TRY(ensure_pip(c));
+  c->xyb_is_cand = false;
   TRY(upload_planes(c, xyb3, c->xyb, 3));
   TRY(stage_separate(c, &c->pip));
   const size_t n = (size_t)c->w * c->h;
@@ -76,7 +78,7 @@ int gz_probe_diffmap(gz_ctx* c, const float* rgb0, const float* rgb1, float* dif
   DeviceScope ds_(c);
   if (!c || !rgb0 || !rgb1) return GZ_E_ARG;
   TRY(ensure_pip(c));
-  c->lin_is_cand = false;
+  c->lin_is_cand = c->xyb_is_cand = false;
   TRY(upload_planes(c, rgb0, c->lin, 3));
   TRY(stage_opsin(c));
   TRY(stage_separate(c, &c->pip));

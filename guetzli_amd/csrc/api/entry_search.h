@@ -227,11 +227,13 @@ int gz_compare_block_pixels(gz_ctx* c, int n, const int32_t* block_xy, const uin
 }
 
 
-int gz_compare_counters(uint64_t out[3]) {
+int gz_compare_counters(uint64_t out[5]) {
   if (!out) return GZ_E_ARG;
   out[0] = g_compares_patched.load();
   out[1] = g_patch_checks.load();
   out[2] = g_compares.load();
+  out[3] = g_compares_ahead.load();
+  out[4] = g_ahead_checks.load();
   return GZ_OK;
 }
 

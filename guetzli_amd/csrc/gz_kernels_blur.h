@@ -304,6 +304,10 @@ struct BlockMaxOut {
   float* block_max;        // [nb] or null
   unsigned* image_max_bits;
   int bw;
+  // k_blur2d only, optional: the launch covers the LISTED tiles (tile = y * ceil(w / 64) + x, grid.x = their
+  // number) instead of the image -- the opsin planes patched around the blocks the serial steps edited (chain.h,
+  // opsin_ahead).  A tile's results do not depend on which launch computes it.
+  const int* tiles;
 };
 
 // Per-8x8-block maxima and image maximum of the tile's results, straight from registers: a
@@ -680,7 +684,13 @@ __global__ __launch_bounds__(256, 4) void k_blur2d(SrcPack<Src, NC> src, Post po
   constexpr int OFF = RA - R;       // window offset inside the aligned row
   __shared__ __attribute__((aligned(16))) float tile[IH][IW];
   const int tid = threadIdx.x;
-  const GzTile bid = gz_xcd_tile();
+  GzTile bid;
+  if (bm.tiles) {
+    const int t = bm.tiles[blockIdx.x], gx = (w + T2 - 1) / T2;
+    bid.x = t % gx; bid.y = t / gx; bid.z = 0;
+  } else {
+    bid = gz_xcd_tile();
+  }
   const int x0 = bid.x * T2, y0 = bid.y * TH;
   const bool interior = x0 >= RA && x0 + T2 + RA <= w && y0 >= R && y0 + TH + R <= h &&
                         (pitch & 3) == 0;

@@ -49,7 +49,7 @@ extern "C" {
 typedef struct gz_ctx gz_ctx;
 
 /* Library / device ------------------------------------------------------------ */
-int gz_abi_version(void);                 /* currently 5 (4 + gz_config.patch_reconstruct) */
+int gz_abi_version(void);                 /* currently 5 (4 + gz_config.patch_reconstruct, .opsin_ahead, gz_compare_counters) */
 /* Device and pinned host memory of destroyed contexts is kept (per device, exact sizes, at
  * most GZ_POOL_MB megabytes of device memory, default 16384) for the next context of the same
  * image size: a batch of same-sized images allocates once.  gz_trim_pool releases everything
@@ -93,6 +93,10 @@ typedef struct gz_config {
                                             every image size, and every such Compare checks the patched planes against a
                                             full reconstruction first (GZ_E_STATE on a difference; tests).
                                             gz_time_compare / gz_compare_enqueue always run the whole chain. */
+  int opsin_ahead;      /* GZ_OPSIN_AHEAD   1 (default): with patch_reconstruct, a context that has the device to itself runs
+                                            the opsin blur of the next Compare right behind gz_apply_candidate_steps'
+                                            patches -- while the host takes its serial steps -- and gz_apply_coeff_edits
+                                            recomputes the opsin tiles around the blocks it edits; 0: every Compare runs it */
 } gz_config;
 int gz_config_from_environment(gz_config* out);
 int gz_get_config(const gz_ctx* ctx, gz_config* out);
@@ -286,8 +290,9 @@ int gz_block_zeroing_orders_masked(gz_ctx* ctx, int comp_mask, int lookahead, in
 int gz_search_evaluations(gz_ctx* ctx, uint64_t* evaluations);
 /* Process-wide, since the library was loaded (tests, bench.py): out[0] = Compares whose candidate planes were kept
  * current by the calls that changed the candidate and that skipped the full reconstruction (gz_config.patch_reconstruct),
- * out[1] = those of them that were checked against a full reconstruction (patch_reconstruct == 2), out[2] = Compares in all. */
-int gz_compare_counters(uint64_t out[3]);
+ * out[1] = those of them that were checked against a full reconstruction (patch_reconstruct == 2), out[2] = Compares in all,
+ * out[3] = Compares that also found their opsin image in place (gz_config.opsin_ahead), out[4] = those of them checked. */
+int gz_compare_counters(uint64_t out[5]);
 /* The per-block form of the seam: Comparator::SwitchBlock + CompareBlock
  * (butteraugli_comparator.cc:427-488; factor_x = factor_y = 1) for n independent pairs of a
  * block position block_xy[i] = {block_x, block_y} and that block's candidate coefficients

@@ -289,7 +289,7 @@ def case_global_order(L, w, h, x0=300, y0=150, qs=3, target=0.971769):
     oc.close()
 
 
-def case_patched_candidate_planes(L, w, h, x0=0, y0=0, qs=3, target=0.971769, rounds=3):
+def case_patched_candidate_planes(L, w, h, x0=0, y0=0, qs=3, target=0.971769, rounds=3, expect_ahead=True):
     """gz_config.patch_reconstruct through the C ABI alone: after bulk steps on a minority of the block positions
     (gz_apply_candidate_steps) and single-coefficient edits elsewhere (gz_apply_coeff_edits), a Compare that relies on
     the patched linear planes (and, in mode 2, checks them against a full reconstruction itself) gives the distance,
@@ -315,16 +315,20 @@ def case_patched_candidate_planes(L, w, h, x0=0, y0=0, qs=3, target=0.971769, ro
             some = rng.random(nb) < (0.3 if r < rounds - 1 else 0.8)
             counts = np.where(some, np.minimum(cnt - next_cand, 1 + rng.integers(0, 3, nb)), 0).astype(np.int32)
             sel = np.flatnonzero(counts > 0).astype(np.int32)
-            before = L.compare_counters()
+            before = L.compare_counters(all=True)
             ctx.apply_candidate_steps(1, sel, counts[sel])
             ctx.steps_histogram_delta()
             next_cand = next_cand + counts
             pos = rng.choice(3 * nb * 64, size=min(40, nb // 4), replace=False).astype(np.int32)   # (fewer than half of the positions)
             ctx.apply_coeff_edits(pos, rng.integers(-40, 40, pos.size).astype(np.int16))
             got = ctx.compare()
-            patched, checked, compares = (a - b for a, b in zip(L.compare_counters(), before))
+            patched, checked, compares, ahead, ahead_checked = (a - b for a, b in zip(L.compare_counters(all=True), before))
             # (the last round touches most positions: no patches, the Compare reconstructs)
             assert (patched, checked, compares) == ((1, 1, 1) if 2 * sel.size <= nb else (0, 0, 1)), (patched, checked, sel.size, nb)
+            # (the opsin image kept ahead as well -- gz_config.opsin_ahead, a context alone on its device -- and checked)
+            assert ahead == ahead_checked and ahead in ((0, 1) if patched else (0,))
+            if patched and expect_ahead:
+                assert ahead == 1
             co = ctx.get_coeffs()
             ctx.set_coeffs(co)
             before = L.compare_counters()

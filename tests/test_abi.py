@@ -60,11 +60,11 @@ def test_config_struct(lib_path, monkeypatch):
     """gz_config: filled from the environment once (gz_config_from_environment needs no device), bad arguments are
     codes."""
     L = capi.Library(lib_path)
-    for k in ("GZ_BLUR_PK", "GZ_TILE_ROWS", "GZ_SINGLE_STREAM", "GZ_STORE_DISTMAP", "GZ_SIDE_SMALL", "GZ_MALTA_PAD", "GZ_PATCH_RECON"):
+    for k in ("GZ_BLUR_PK", "GZ_TILE_ROWS", "GZ_SINGLE_STREAM", "GZ_STORE_DISTMAP", "GZ_SIDE_SMALL", "GZ_MALTA_PAD", "GZ_PATCH_RECON", "GZ_OPSIN_AHEAD"):
         monkeypatch.delenv(k, raising=False)
     d = L.config_from_environment().as_dict()
     assert d == {"struct_size": C.sizeof(capi.GzConfig), "blur_packed": -1, "tile_rows": 0, "single_stream": -1,
-                 "store_distmap": 0, "side_small": 0, "malta_pad_bytes": 0, "patch_reconstruct": 1}
+                 "store_distmap": 0, "side_small": 0, "malta_pad_bytes": 0, "patch_reconstruct": 1, "opsin_ahead": 1}
     monkeypatch.setenv("GZ_BLUR_PK", "0")
     monkeypatch.setenv("GZ_TILE_ROWS", "32")
     monkeypatch.setenv("GZ_SINGLE_STREAM", "1")

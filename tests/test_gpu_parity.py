@@ -473,15 +473,18 @@ def test_patched_candidate_planes_equal_a_full_reconstruction_1080p(L, monkeypat
     import hashlib
     import guetzli_amd
     monkeypatch.setenv("GZ_PATCH_RECON", mode)
-    before = L.compare_counters()
+    before = L.compare_counters(all=True)
     jpg, info = guetzli_amd.process(images.tiled(1920, 1080), quality=95)
-    patched, checked, compares = (a - b for a, b in zip(L.compare_counters(), before))
+    patched, checked, compares, ahead, ahead_checked = (a - b for a, b in zip(L.compare_counters(all=True), before))
     assert hashlib.sha256(jpg).hexdigest() == GOLDEN_JPEG_SHA[(1920, 1080, 95)]
     assert compares >= info["counters"]["number of iterations"]
     if mode == "2":
         assert patched == checked and patched > 0.8 * info["counters"]["number of iterations"]
+        # gz_config.opsin_ahead: the opsin image of those planes was in place as well (and checked) wherever an
+        # iteration had bulk steps
+        assert ahead == ahead_checked and ahead > 0.6 * info["counters"]["number of iterations"]
     else:
-        assert patched == 0 and checked == 0
+        assert patched == 0 and checked == 0 and ahead == 0
 
 
 @pytest.mark.parametrize("level", ["1", "2"])

@@ -385,23 +385,32 @@ def test_patched_candidate_planes_equal_a_full_reconstruction_in_emulation(host_
     """gz_config.patch_reconstruct = 2 (GZ_PATCH_RECON): every Compare that relies on the candidate's linear planes
     having been kept current by gz_apply_candidate_steps / gz_apply_coeff_edits checks them against a full
     reconstruction first; ragged sizes patch partial blocks at the right and bottom edges; a 4:2:0 frame never
-    patches.  And = 0: no Compare skips its reconstruction.  Same bytes as the reference."""
+    patches.  And = 0: no Compare skips its reconstruction.  gz_config.opsin_ahead: the opsin image of those planes
+    kept current as well (whole behind the bulk steps, by tiles around the serial steps' edits) and checked likewise.
+    Same bytes as the reference."""
     from guetzli_amd import capi
     w, h, x0, y0, kw = case
     L = capi.Library(build_emu.build())
     rgb = images.crop(w, h, x0, y0)
     exp_jpg, _ = ref.process_params(rgb, ref._butteraugli_score_for_quality(95.0), **kw)
-    for mode in ("2", "0"):
+    for mode, ahead_env in (("2", "1"), ("2", "0"), ("0", "1")):
         monkeypatch.setenv("GZ_PATCH_RECON", mode)
-        before = L.compare_counters()
+        monkeypatch.setenv("GZ_OPSIN_AHEAD", ahead_env)
+        before = L.compare_counters(all=True)
         got, info = host_emu.process(rgb, quality=95, **kw)
-        patched, checked, compares = (a - b for a, b in zip(L.compare_counters(), before))
+        patched, checked, compares, ahead, ahead_checked = (a - b for a, b in zip(L.compare_counters(all=True), before))
         assert got == exp_jpg
-        assert compares > 0 and patched == checked
+        assert compares > 0 and patched == checked and ahead == ahead_checked and ahead <= patched
         if mode == "2" and not kw:
             assert patched >= info["counters"]["number of iterations"] // 2
+            # (the opsin image ahead of the serial steps, its tiles around their edits computed again: behind every
+            # iteration's bulk steps -- small images have iterations without any)
+            if ahead_env == "0":
+                assert ahead == 0
+            elif (w, h) == (136, 88):
+                assert ahead > patched // 2, (ahead, patched)
         else:
-            assert patched == 0
+            assert patched == 0 and ahead == 0
 
 
 @needs_ref

@@ -127,7 +127,8 @@ int blur2d(gz_ctx* c, const SrcPack<Src, NC>& src, const Post& post, const BlurC
   const int w = c->w, h = c->h, pitch = c->pitch;
   // (the chain's last blur, with block maxima: 16-row tiles below 1.5 MPix only -- 720p chain 0.224 -> 0.213 ms,
   // nothing at 1080p, +3 % at 2560 x 1440: profiles/r05_chain_experiments.log, section 8)
-  if (BM ? small_tiles(c) && (size_t)c->w * c->h < 1500000 : small_tiles(c)) {
+  // (a tile list: always the 16-row tiles -- a handful of workgroups, whose time is one workgroup's latency)
+  if (bm.tiles || (BM ? small_tiles(c) && (size_t)c->w * c->h < 1500000 : small_tiles(c))) {
     dim3 grid(gz_div_up(c->w, T2), gz_div_up(c->h, kSmallTileRows));
     if (bm.tiles) grid = dim3(n_tiles);
     GZ_LAUNCH((k_blur2d<R, NC, Src, Post, BM, kSmallTileRows>), grid, dim3(256), c->stream, src, post, w,
@@ -218,7 +219,7 @@ int stage_opsin(gz_ctx* c, const int* tiles = nullptr, int n_tiles = 0) {
   TRY((blur2d<2, 3, SrcPlain, PostOpsin>(c, s, post, c->blur[B_OPSIN], BlockMaxOut{nullptr, nullptr, 0, tiles}, n_tiles)));
   return GZ_OK;
 }
-static int opsin_tile_rows(const gz_ctx* c) { return small_tiles(c) ? kSmallTileRows : kTileRows; }
+static int opsin_tile_rows(const gz_ctx*) { return kSmallTileRows; }   // (of a tile LIST: blur2d)
 
 // SeparateFrequencies: xyb[3] -> Psycho planes
 // The LF blur (radius 16) runs as X / Y (two planes, PostLFxy) and B (one plane, PostLFb: its

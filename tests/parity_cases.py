@@ -300,7 +300,8 @@ def case_patched_candidate_planes(L, w, h, x0=0, y0=0, qs=3, target=0.971769, ro
     rgb = images.crop(w, h, x0, y0) if max(w, h) <= 444 else images.tiled(w, h)
     q = np.full((3, 64), qs, np.int32)
     with L.context(rgb, target) as ctx:
-        ctx.set_config(patch_reconstruct=2)
+        cfg = ctx.set_config(patch_reconstruct=2)
+        expect_ahead = expect_ahead and cfg.opsin_ahead != 0 and cfg.single_stream != 1   # (the suite's forced modes)
         ctx.encode_rgb()
         ctx.quantize(q)
         off, idx, err = ctx.block_zeroing_orders()

@@ -482,7 +482,11 @@ def test_patched_candidate_planes_equal_a_full_reconstruction_1080p(L, monkeypat
         assert patched == checked and patched > 0.8 * info["counters"]["number of iterations"]
         # gz_config.opsin_ahead: the opsin image of those planes was in place as well (and checked) wherever an
         # iteration had bulk steps
-        assert ahead == ahead_checked and ahead > 0.6 * info["counters"]["number of iterations"]
+        # (not under a forced one-stream chain or with the switch off: the suite also runs in those modes)
+        if os.environ.get("GZ_SINGLE_STREAM") == "1" or os.environ.get("GZ_OPSIN_AHEAD") == "0":
+            assert ahead == 0
+        else:
+            assert ahead == ahead_checked and ahead > 0.6 * info["counters"]["number of iterations"]
     else:
         assert patched == 0 and checked == 0 and ahead == 0
 

@@ -607,13 +607,15 @@ def main():
         step4k()
         env.sync()
         first_encode_4k_s = time.perf_counter() - t0
-        cc0 = L.compare_counters()
+        cc0 = L.compare_counters(all=True)
         dt4k, (jpg4k, info4k) = timed_steps(env, step4k, args.steps, args.warmup)
         step_ms_4k = list(STEP_MS)
         # how many of the encodes' Compares ran without their full reconstruction (gz_config.patch_reconstruct: the
         # calls that change the candidate keep its linear planes current); `roofline` always times the whole chain
-        cc1 = L.compare_counters()
-        compares_4k = {"compares": cc1[2] - cc0[2], "without_full_reconstruction": cc1[0] - cc0[0]}
+        # (... and, for a lone context, their opsin image: gz_config.opsin_ahead)
+        cc1 = L.compare_counters(all=True)
+        compares_4k = {"compares": cc1[2] - cc0[2], "without_full_reconstruction": cc1[0] - cc0[0],
+                       "opsin_image_in_place": cc1[3] - cc0[3]}
 
     # Where the tool is mostly used: <= 2 MPix.  One 1024x1024 image without a period (tests/images.mosaic), timed
     # exactly like `value` (every rank, same bracket), and -- rank 0 -- 64 of them (circular shifts) four in flight;

@@ -71,6 +71,29 @@ def hipcc_path():
     return None
 
 
+def locked_compile(out, stale, make_cmd, verbose=False):
+    """One process compiles `out`, the others wait for it: under an exclusive lock on <out>.lock the staleness test
+    `stale()` is repeated, the compiler writes <out>.tmp.<pid> and the result is renamed into place -- so that
+    processes started together (pytest -n 4 after a source change) neither compile the same file four times nor
+    load a library another one is still writing.  make_cmd(tmp_path) -> argv."""
+    import fcntl
+    with open(out + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not stale():
+            return out
+        tmp = f"{out}.tmp.{os.getpid()}"
+        cmd = make_cmd(tmp)
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        try:
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+    return out
+
+
 def build(force=False, verbose=False):
     """Compile the HIP extension if sources are newer than the library."""
     if not force and not _newer_than_lib():
@@ -85,9 +108,13 @@ def build(force=False, verbose=False):
     # faster (profiles/r02_packed_blur_and_malta_diff_experiments.log, section 9).  Until round 5 an
     # xnack+ code object rode along for processes started with HSA_XNACK=1; this pool runs XNACK off only
     # (and refuses libraries that carry xnack+ code), and that is what MI355X boxes default to.
-    cmd = [hipcc, f"--offload-arch={ARCH}:xnack-"] + FLAGS + \
-        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    return _run(cmd, verbose)
+    first = [True]
+
+    def stale():   # (the caller's `force` counts once: whoever waited for the lock finds the library fresh)
+        f, first[0] = first[0], False
+        return (force and f) or _newer_than_lib()
+    return locked_compile(LIB, stale, lambda tmp: [hipcc, f"--offload-arch={ARCH}:xnack-"] + FLAGS +
+                          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp], verbose)
 
 
 def build_variant(name, defines):
@@ -132,13 +159,15 @@ def build_host(force=False, verbose=False, device_lib=None, out=None):
             return out
         raise RuntimeError("g++ not found and no prebuilt host library")
     libdir, libname = os.path.split(device_lib)
-    cmd = ["g++"] + HOST_FLAGS + srcs + ["-o", out, "-L" + libdir,
-                                         "-l:" + libname, "-Wl,-rpath," + libdir,
-                                         "-Wl,-rpath,$ORIGIN", "-lz"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    return out
+    first = [True]
+
+    def stale():
+        f, first[0] = first[0], False
+        return (force and f) or not os.path.exists(out) or \
+            any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps if os.path.exists(d))
+    return locked_compile(out, stale, lambda tmp: ["g++"] + HOST_FLAGS + srcs +
+                          ["-o", tmp, "-L" + libdir, "-l:" + libname, "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,$ORIGIN", "-lz"], verbose)
 
 
 if __name__ == "__main__":

@@ -447,6 +447,7 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
     k_val = c->d_edit_val;
   }
   GZ_LAUNCH(k_apply_coeff_edits, dim3(gz_div_up(n, 256)), dim3(256), c->stream, k_pos, k_val, n, c->d_cand);
+  int rc_tiles = GZ_OK;   // (reported behind stage_sent: no path returns with a kernel still reading the staging buffer)
   if (patch_wanted(c, n)) {   // the edited block positions' pixels, behind the edits (one wavefront per edit)
     GZ_LAUNCH((k_reconstruct_listed<true>), dim3(gz_div_up(n, kBlocksPerWG)), dim3(256), c->stream, k_pos, n,
               (const int16_t*)c->d_cand, c->nb, patch_planes(c, true));
@@ -471,12 +472,12 @@ int gz_apply_coeff_edits(gz_ctx* c, const int32_t* pos, const int16_t* val, int 
         }
         for (int i = 0; i < nt; ++i) c->tile_mark[(size_t)tl[i]] = 0;
       }
-      if (tl && (long)nt * 4 <= (long)gx * gy) TRY(stage_opsin(c, tl, nt));
-      else TRY(stage_opsin(c));
+      rc_tiles = tl && (long)nt * 4 <= (long)gx * gy ? stage_opsin(c, tl, nt) : stage_opsin(c);
     }
   }
-  KCHK(c);
   TRY(stage_sent(c, &c->stage_edits, c->stream));   // (the staging buffer is free again behind the kernels)
+  KCHK(c);
+  TRY(rc_tiles);
   return GZ_OK;   // the caller's buffers were copied to the staging buffer: no wait
 }
 

@@ -16,14 +16,23 @@ def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     deps = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs] + \
         [os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "guetzli_amd.h")]
-    if not force and os.path.exists(LIB) and \
-            all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+    first = [True]
+
+    def stale():
+        f, first[0] = first[0], False
+        return (force and f) or not os.path.exists(LIB) or \
+            any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+    if not stale():
         return LIB
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DGZ_EMU",
-           "-I" + HERE, "-x", "c++", os.path.join(CSRC, "gz_api.hip"), "-o", LIB,
-           "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-variable"]
-    subprocess.run(cmd, check=True)
-    return LIB
+    first[0] = True
+    import sys
+    sys.path.insert(0, ROOT)
+    from guetzli_amd import build as gzbuild
+    # (one of the processes pytest -n starts together compiles, the others wait and load the finished library)
+    return gzbuild.locked_compile(LIB, stale, lambda tmp: [
+        "g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DGZ_EMU",
+        "-I" + HERE, "-x", "c++", os.path.join(CSRC, "gz_api.hip"), "-o", tmp,
+        "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-variable"])
 
 
 HOST_LIB = os.path.join(OUT, "libguetzli_amd_host_emu.so")

@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Encode times with the package under PKG (default: this tree's) -- A/B of two builds on one box.
+"""Encode times with the package under PKGDIR -- A/B of two BUILDS on one box (boxes differ by +-4 %, processes on
+one box by less).  The other build: `git archive <commit> guetzli_amd include | tar -x -C /tmp/old`, build it there
+(python -c "import sys; sys.path.insert(0, '/tmp/old'); from guetzli_amd import build; build.build(); build.build_host()"),
+`cp -a /tmp/old/guetzli_amd /tmp/old/include tools/ab_old/` (git-ignored; built libraries travel with gpurun; the host
+library finds the device library through $ORIGIN), then on the GPU box in turn:
+    python tools/ab_old_time.py tools/ab_old W H REPS;  python tools/ab_old_time.py . W H REPS
 Usage: ab_old_time.py PKGDIR W H REPS   (PKGDIR holds guetzli_amd/)"""
 import sys, os, time
 pkg, w, h, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])

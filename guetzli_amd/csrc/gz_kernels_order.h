@@ -400,12 +400,6 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
   const int per = (n + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
   const int base = ((int)blockIdx.x * 4 + wave) * per;
   int pre_b = 0, pre_c = 0;
-  // A wavefront's entries are a chain of dependent loads each (entry -> next_cand, coefficients -> candidate index ->
-  // original coefficient), three or four entries one after the other: the NEXT entry's first stage -- its next_cand
-  // and its coefficient blocks -- is requested before this entry is worked on.
-  int nxt_nx = 0;
-  short nxt_cf[3] = {0, 0, 0};
-  bool have_nxt = false;
   for (int it = 0; it < per; ++it) {
     if ((it & 63) == 0) {
       const int i2 = base + it + lane;
@@ -413,27 +407,12 @@ __global__ __launch_bounds__(256) void k_apply_steps_hist(const int* __restrict_
       pre_b = blocks[lv ? i2 : n - 1];
       pre_c = lv ? counts[i2] : 0;
       if (list_out && lv) list_out[i2] = pre_b;
-      have_nxt = false;
     }
     const bool live = base + it < n;
-    const int b = __shfl(pre_b, it & 63), cnt = __shfl(pre_c, it & 63);
-    const int nx = have_nxt ? nxt_nx : next_cand[b];
-    short cf[3];
+    const int b = __shfl(pre_b, it & 63), cnt = __shfl(pre_c, it & 63), nx = next_cand[b];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      cf[c] = have_nxt ? nxt_cf[c] : (((sg.comp_mask >> c) & 1) ? cand[((size_t)sg.coff[c] + b) * 64 + lane] : (short)0);
-    have_nxt = it + 1 < per && ((it + 1) & 63) != 0;   // (uniform: the next entry comes from the same batch of 64)
-    if (have_nxt) {
-      // (entries are distinct blocks: this entry's stores below do not touch what is read here)
-      const int b2 = __shfl(pre_b, (it + 1) & 63);
-      nxt_nx = next_cand[b2];
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        nxt_cf[c] = ((sg.comp_mask >> c) & 1) ? cand[((size_t)sg.coff[c] + b2) * 64 + lane] : (short)0;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      if ((sg.comp_mask >> c) & 1) s_blk[wave][c * 64 + lane] = cf[c];
+      if ((sg.comp_mask >> c) & 1) s_blk[wave][c * 64 + lane] = cand[((size_t)sg.coff[c] + b) * 64 + lane];
     GZ_WAVE_SYNC();
     steps_count_symbols(s_blk[wave], jq, sg.comp_mask, lane, live, 0xffffffffu, s_delta);
     GZ_WAVE_SYNC();

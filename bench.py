@@ -534,7 +534,9 @@ def main():
     ap.add_argument("--no-4k", action="store_true", help="skip the 3840x2160 legs (configs[2], [3])")
     ap.add_argument("--batch-images", type=int, default=16,
                     help="images of the extra concurrent-batch leg (0 = skip)")
-    ap.add_argument("--batch-workers", type=int, default=4)
+    ap.add_argument("--batch-workers", type=int, default=6,
+                    help="images in flight in the 1080p batch leg (6: +7 %% over 4 on the final sources, "
+                         "profiles/r06_chain_experiments.log section 19; at 4K 4, 5 and 6 are equal)")
     ap.add_argument("--no-1mpix", action="store_true", help="skip the 1024x1024 legs (value_1mpix, its batch, iteration floor)")
     ap.add_argument("--batch-1mpix", type=int, default=64, help="images of the 1 MPix batch leg (0 = skip)")
     ap.add_argument("--batch-workers-1mpix", type=int, default=6,

@@ -406,8 +406,8 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
     """8 images per GPU of config 5's batch; returns the JSON object of the leg (rank 0).
     from_png: the batch as configs[4] words it -- PNG files: every image arrives as PNG bytes
     (encoded once, outside the timed region) and is decoded inside it by the product's reader
-    (guetzli_amd::ReadPng = the reference front end's ReadPNG, guetzli.cc:47-152) on the image's
-    own host thread, beside the other images' device work."""
+    (guetzli_amd::ReadPng = the reference front end's ReadPNG, guetzli.cc:47-152) on host threads
+    beside the other images' device work, ahead of the image's turn on the GPU (batch.py, prepare)."""
     from guetzli_amd.batch import run_config5
     w5, h5 = size
     base = images.tiled(w5, h5)
@@ -424,8 +424,11 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
             return pngs[k]
         for k in range(env.rank, images_per_gpu * env.world, env.world):
             get(k)   # (encoded before anything is timed)
-        proc = lambda data: host.process(host.read_png(data), quality=quality, device=env.device)
+        # (decoded ahead of the image's turn on the GPU, on threads of their own: guetzli_amd/batch.py)
+        prep = host.read_png
+        proc = lambda im: host.process(im, quality=quality, device=env.device)
     else:
+        prep = None
         # this rank's images exist before anything is timed (as the PNG bytes do above): the timed region
         # is the encodes, not numpy's circular shifts of a 25 MB array on the image threads
         mine = {k: images.shifted(base, k) for k in range(env.rank, images_per_gpu * env.world, env.world)}
@@ -433,9 +436,9 @@ def config5_leg(env, host, images, images_per_gpu, in_flight, size, quality, fro
         proc = lambda im: host.process(im, quality=quality, device=env.device)
     if not env.emulate:
         run_config5(get, min(2, images_per_gpu), proc, env.rank, env.world, env.dist, in_flight, env.fence,
-                    env.tensor_device)   # warm-up
+                    env.tensor_device, prepare=prep)   # warm-up
     recs, secs = run_config5(get, images_per_gpu, proc, env.rank, env.world, env.dist, in_flight,
-                             env.fence, env.tensor_device)
+                             env.fence, env.tensor_device, prepare=prep)
     gold = {} if env.emulate else config5_goldens()
     checked = 0
     for r in recs:

@@ -75,15 +75,48 @@ class BatchError(RuntimeError):
             f"image {f['index']} on rank {f['rank']}: {f['error']}" for f in failures))
 
 
-def encode_shard_concurrent(get_image, indices, process, workers, rank=0):
+def encode_shard_concurrent(get_image, indices, process, workers, rank=0, prepare=None):
     """This rank's images, `workers` of them in flight on its GPU; records as encode_batch's.  An
     image that fails does not take the others with it: its record is {"index", "rank", "error"} --
     the caller gathers the records of all ranks first and raises afterwards (run_config5), so a
-    multi-GPU job says WHICH image failed WHERE instead of dying at a barrier."""
+    multi-GPU job says WHICH image failed WHERE instead of dying at a barrier.
+    prepare (optional): host-only work in front of an image's encode -- decoding its PNG bytes -- done AHEAD
+    on threads of its own, at most 3 x workers images beyond the ones being encoded: an image thread then
+    finds its pixels waiting instead of decoding them while its slot on the GPU stands empty (the first
+    `workers` decodes are the only ones nothing hides).  A failure of prepare is the image's failure."""
+    indices = list(indices)
+    ahead = None
+    if prepare is not None:
+        import threading
+        from concurrent.futures import ThreadPoolExecutor as _Pool
+        ahead = {"pool": _Pool(max_workers=max(1, workers)), "futs": {}, "next": 0, "lock": threading.Lock()}
+
+        def submit_more(limit):
+            with ahead["lock"]:
+                while ahead["next"] < len(indices) and len(ahead["futs"]) < limit:
+                    k = indices[ahead["next"]]
+                    ahead["futs"][k] = ahead["pool"].submit(lambda k=k: prepare(get_image(k)))
+                    ahead["next"] += 1
+        submit_more(3 * max(1, workers))
+
+    def fetch(k):
+        if ahead is None:
+            return get_image(k)
+        with ahead["lock"]:
+            fut = ahead["futs"].get(k)
+        if fut is None:   # (not reached while images are taken in order)
+            return prepare(get_image(k))
+        try:
+            return fut.result()
+        finally:
+            with ahead["lock"]:
+                ahead["futs"].pop(k, None)
+            submit_more(3 * max(1, workers))
+
     def one(k):
         t0 = time.perf_counter()
         try:
-            jpg, _ = process(get_image(k))
+            jpg, _ = process(fetch(k))
         except Exception as e:   # (the C++ driver's failures arrive as RuntimeError)
             return {"index": k, "rank": rank, "error": f"{type(e).__name__}: {e}",
                     "seconds": time.perf_counter() - t0}
@@ -96,6 +129,8 @@ def encode_shard_concurrent(get_image, indices, process, workers, rank=0):
             return list(ex.map(one, indices))
     finally:
         hint_in_flight(1)
+        if ahead is not None:
+            ahead["pool"].shutdown(wait=True)
 
 
 def raise_on_failures(records):
@@ -106,7 +141,7 @@ def raise_on_failures(records):
 
 
 def run_config5(get_image, images_per_gpu, process, rank=0, world=1, dist=None, workers=4,
-                fence=None, device=None):
+                fence=None, device=None, prepare=None):
     """BASELINE config 5 ("a batch of independent images sharded 8-per-GPU across the GPUs of
     one node"): image k -> rank k mod world (k < images_per_gpu * world), every rank keeps
     `workers` of its images in flight on its GPU, no data-path collective.  The process group
@@ -117,7 +152,7 @@ def run_config5(get_image, images_per_gpu, process, rank=0, world=1, dist=None, 
     if fence:
         fence()
     t0 = time.perf_counter()
-    mine = encode_shard_concurrent(get_image, shard(n, rank, world), process, workers, rank)
+    mine = encode_shard_concurrent(get_image, shard(n, rank, world), process, workers, rank, prepare)
     if fence:
         fence()
     seconds = max_over_ranks(time.perf_counter() - t0, dist, device)

@@ -121,3 +121,40 @@ def test_a_failed_image_is_reported_by_every_rank_after_the_gather(tmp_path):
     assert "RANK 0 FAILURES [(1, 1)]" in text, text[-3000:]
     assert "RANK 1 FAILURES [(1, 1)]" in text, text[-3000:]
     assert "NO ERROR" not in text
+
+
+def test_prepare_runs_ahead_of_the_encodes_and_its_failures_are_the_images():
+    """encode_shard_concurrent(prepare=...): the host-only stage in front of an encode (PNG decoding in bench.py's
+    from-PNG leg) runs ahead on its own threads, bounded; records keep the input order; an image whose prepare
+    fails is reported like one whose encode fails, and the others complete."""
+    import threading
+    import time
+    import pytest
+    from guetzli_amd.batch import encode_shard_concurrent, run_config5, BatchError
+    lock = threading.Lock()
+    state = {"prepared": 0, "consumed": 0, "max_waiting": 0}
+
+    def prepare(k):
+        if k == 5:
+            raise ValueError("bad PNG")
+        with lock:
+            state["prepared"] += 1
+            state["max_waiting"] = max(state["max_waiting"], state["prepared"] - state["consumed"])
+        return ("pixels", k)
+
+    def process(im):
+        assert im[0] == "pixels"
+        with lock:
+            state["consumed"] += 1
+        time.sleep(0.01)
+        return (b"jpeg%d" % im[1], {})
+    recs = encode_shard_concurrent(lambda k: k, range(20), process, workers=2, rank=3, prepare=prepare)
+    assert [r["index"] for r in recs] == list(range(20)) and all(r["rank"] == 3 for r in recs)
+    assert [r["index"] for r in recs if "error" in r] == [5] and "bad PNG" in recs[5]["error"]
+    assert all(r["bytes"] == len(b"jpeg%d" % r["index"]) for r in recs if "error" not in r)
+    assert state["prepared"] == 19 and state["max_waiting"] <= 3 * 2 + 2   # (+ the two being handed over)
+    with pytest.raises(BatchError) as e:
+        run_config5(lambda k: k, 8, process, workers=2, prepare=prepare)
+    assert [f["index"] for f in e.value.failures] == [5]
+    recs, secs = run_config5(lambda k: k + 10, 4, process, workers=2, prepare=prepare)
+    assert [r["index"] for r in recs] == [0, 1, 2, 3] and secs > 0
